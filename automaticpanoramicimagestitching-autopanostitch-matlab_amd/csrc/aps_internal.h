@@ -1,0 +1,187 @@
+// aps_internal.h — shared plumbing of libaps_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/aps.h"
+
+namespace aps {
+
+// ---- error transport ---------------------------------------------------------------------------
+struct Error : std::exception {
+    int code;
+    std::string msg;
+    Error(int c, std::string m) : code(c), msg(std::move(m)) {}
+    const char* what() const noexcept override { return msg.c_str(); }
+};
+
+[[noreturn]] void fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const char* s);
+
+#define APS_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            ::aps::fail(e_ == hipErrorOutOfMemory ? APS_E_OOM : APS_E_DEVICE,               \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+#define APS_REQUIRE(cond, code, ...)                   \
+    do {                                               \
+        if (!(cond)) ::aps::fail((code), __VA_ARGS__); \
+    } while (0)
+
+// Wraps the body of every extern "C" entry point.
+template <class F>
+inline int guarded(F&& f) {
+    try {
+        f();
+        return APS_OK;
+    } catch (const Error& e) {
+        set_last_error(e.msg.c_str());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return APS_E_OOM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return APS_E_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown exception");
+        return APS_E_INTERNAL;
+    }
+}
+
+// ---- per-thread context --------------------------------------------------------------------------
+struct Ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t user_stream = nullptr;
+    bool use_user_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct Block {
+        void* p;
+        size_t bytes;
+        bool used;
+    };
+    std::vector<Block> blocks;
+    hipStream_t stream() const { return use_user_stream ? user_stream : own_stream; }
+};
+
+// Makes sure a gfx950 device is selected for this thread and returns the context.
+Ctx& ctx();
+inline hipStream_t stream() { return ctx().stream(); }
+
+// Cached device workspace (hipMalloc is synchronising; steady state must not call it).
+void* ws_alloc(size_t bytes);
+void ws_free(void* p);
+
+template <class T>
+struct Ws {
+    T* p = nullptr;
+    size_t n = 0;
+    Ws() = default;
+    explicit Ws(size_t count) { alloc(count); }
+    Ws(const Ws&) = delete;
+    Ws& operator=(const Ws&) = delete;
+    Ws(Ws&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+    Ws& operator=(Ws&& o) noexcept {
+        if (this != &o) {
+            reset();
+            p = o.p;
+            n = o.n;
+            o.p = nullptr;
+        }
+        return *this;
+    }
+    ~Ws() { reset(); }
+    void alloc(size_t count) {
+        reset();
+        n = count;
+        p = static_cast<T*>(ws_alloc((count ? count : 1) * sizeof(T)));
+    }
+    void reset() {
+        if (p) ws_free(p);
+        p = nullptr;
+    }
+    T* get() const { return p; }
+    operator T*() const { return p; }
+};
+
+// ---- host/device pointer staging -----------------------------------------------------------------
+bool is_device_ptr(const void* p);
+
+// Input that may live on the host: gives a device pointer valid until destruction.
+template <class T>
+struct In {
+    const T* d = nullptr;
+    Ws<T> tmp;
+    In() = default;
+    In(const T* p, size_t count) { bind(p, count); }
+    void bind(const T* p, size_t count) {
+        if (count == 0 || p == nullptr) {
+            d = p;
+            return;
+        }
+        if (is_device_ptr(p)) {
+            d = p;
+        } else {
+            tmp.alloc(count);
+            APS_HIP(hipMemcpyAsync(tmp.p, p, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+            d = tmp.p;
+        }
+    }
+    const T* get() const { return d; }
+    operator const T*() const { return d; }
+};
+
+// Output that may live on the host: device pointer now, copied back by commit().
+template <class T>
+struct Out {
+    T* d = nullptr;
+    T* host = nullptr;
+    size_t n = 0;
+    Ws<T> tmp;
+    Out() = default;
+    Out(T* p, size_t count) { bind(p, count); }
+    void bind(T* p, size_t count) {
+        n = count;
+        if (p == nullptr) return;
+        if (count == 0 || is_device_ptr(p)) {
+            d = p;
+        } else {
+            host = p;
+            tmp.alloc(count);
+            d = tmp.p;
+        }
+    }
+    // Copies back `count` elements (default: all).  Synchronises when the target is host memory.
+    void commit(size_t count = SIZE_MAX) {
+        if (!host) return;
+        if (count > n) count = n;
+        if (count) {
+            APS_HIP(hipMemcpyAsync(host, d, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+        }
+    }
+    T* get() const { return d; }
+    operator T*() const { return d; }
+    bool present() const { return d != nullptr; }
+};
+
+inline void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail(APS_E_DEVICE, "launch of %s failed: %s", what, hipGetErrorString(e));
+}
+
+inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
+
+}  // namespace aps

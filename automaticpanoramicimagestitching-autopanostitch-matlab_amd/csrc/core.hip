@@ -1,0 +1,191 @@
+// core.hip — device selection, per-thread stream/workspace, error transport, library entry points.
+#include <cstdlib>
+
+#include "aps_internal.h"
+
+namespace aps {
+
+static thread_local std::string g_err;
+static thread_local Ctx g_ctx;
+
+void set_last_error(const char* s) { g_err = s ? s : ""; }
+
+void fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+static bool device_is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+static int count_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; ++i)
+        if (device_is_gfx950(i)) ++ok;
+    return ok == n ? n : 0;  // mixed boxes are not supported: this library is gfx950-only
+}
+
+static void bind_device(Ctx& c, int dev) {
+    int n = count_devices();
+    if (n <= 0)
+        fail(APS_E_DEVICE,
+             "no gfx950 (MI355X) device is visible; libaps_hip has no CPU fallback by design");
+    if (dev < 0 || dev >= n) fail(APS_E_ARG, "device %d out of range [0,%d)", dev, n);
+    APS_HIP(hipSetDevice(dev));
+    if (c.device != dev) {
+        // drop everything tied to the previous device
+        for (auto& b : c.blocks) (void)hipFree(b.p);
+        c.blocks.clear();
+        if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+        if (c.ev0) (void)hipEventDestroy(c.ev0);
+        if (c.ev1) (void)hipEventDestroy(c.ev1);
+        c.own_stream = nullptr;
+        c.ev0 = c.ev1 = nullptr;
+        c.device = dev;
+    }
+    if (!c.own_stream) APS_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    if (!c.ev0) APS_HIP(hipEventCreate(&c.ev0));
+    if (!c.ev1) APS_HIP(hipEventCreate(&c.ev1));
+}
+
+Ctx& ctx() {
+    Ctx& c = g_ctx;
+    if (c.device < 0) {
+        int dev = 0;
+        if (const char* e = std::getenv("APS_DEVICE")) dev = std::atoi(e);
+        bind_device(c, dev);
+    } else {
+        APS_HIP(hipSetDevice(c.device));
+    }
+    return c;
+}
+
+void* ws_alloc(size_t bytes) {
+    Ctx& c = ctx();
+    bytes = (bytes + 255) & ~size_t(255);
+    int best = -1;
+    for (int i = 0; i < (int)c.blocks.size(); ++i) {
+        auto& b = c.blocks[i];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < c.blocks[best].bytes)) best = i;
+    }
+    if (best >= 0 && c.blocks[best].bytes <= 2 * bytes + (1u << 20)) {
+        c.blocks[best].used = true;
+        return c.blocks[best].p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // free cached blocks and retry once
+        (void)hipGetLastError();
+        for (auto it = c.blocks.begin(); it != c.blocks.end();) {
+            if (!it->used) {
+                (void)hipFree(it->p);
+                it = c.blocks.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail(APS_E_OOM, "device allocation of %zu bytes failed: %s", bytes,
+                 hipGetErrorString(e));
+        }
+    }
+    c.blocks.push_back({p, bytes, true});
+    return p;
+}
+
+void ws_free(void* p) {
+    for (auto& b : g_ctx.blocks)
+        if (b.p == p) {
+            b.used = false;
+            return;
+        }
+}
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // plain pageable host memory
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_version(void) { return APS_VERSION; }
+
+const char* aps_last_error(void) { return g_err.c_str(); }
+
+int aps_device_count(void) { return count_devices(); }
+
+int aps_set_device(int device) {
+    return guarded([&] { bind_device(g_ctx, device); });
+}
+
+int aps_set_stream(void* hip_stream) {
+    return guarded([&] {
+        Ctx& c = ctx();
+        c.user_stream = static_cast<hipStream_t>(hip_stream);
+        c.use_user_stream = true;
+        if (hip_stream == nullptr) c.use_user_stream = false;
+    });
+}
+
+int aps_synchronize(void) {
+    return guarded([&] { APS_HIP(hipStreamSynchronize(stream())); });
+}
+
+int aps_release_workspace(void) {
+    return guarded([&] {
+        Ctx& c = ctx();
+        APS_HIP(hipStreamSynchronize(c.stream()));
+        for (auto it = c.blocks.begin(); it != c.blocks.end();) {
+            if (!it->used) {
+                (void)hipFree(it->p);
+                it = c.blocks.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    });
+}
+
+int aps_timer_begin(void) {
+    return guarded([&] {
+        Ctx& c = ctx();
+        APS_HIP(hipEventRecord(c.ev0, c.stream()));
+    });
+}
+
+int aps_timer_end(float* ms) {
+    return guarded([&] {
+        APS_REQUIRE(ms != nullptr, APS_E_ARG, "ms is NULL");
+        Ctx& c = ctx();
+        APS_HIP(hipEventRecord(c.ev1, c.stream()));
+        APS_HIP(hipEventSynchronize(c.ev1));
+        APS_HIP(hipEventElapsedTime(ms, c.ev0, c.ev1));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,668 @@
+// match.hip — float-descriptor matching on gfx950.
+//
+// Restates PP/featureMatching/matchFeaturesScratch.m (normalizeRowsL2 :217-234, nearest2SSDExhaustive
+// :322-366, ratio/threshold :170-178, greedy uniqueness :186-207) and the pair scheduling of
+// PP/featureMatching/featureMatchingPairwise.m:48-63.
+//
+// Kernels
+//   prep_desc_kernel     : optional row L2-normalisation, canonical ||x||^2, and a k-permuted copy
+//                          P[i][h*64+s] = X[i][2s+h] so that one lane's MFMA operands are contiguous.
+//   match2nn_kernel      : the N1 x 128 . 128 x N2 distance GEMM on v_mfma_f32_32x32x2_f32 (exact f32,
+//                          k-ascending fma chain) with the top-2 reduction fused into the epilogue.
+//                          A (32 rows x 128 k per wave) lives in 64 VGPRs for the whole workgroup
+//                          lifetime; B streams through a padded, double-buffered LDS tile.
+//   filter/unique kernels: ratio + threshold test in f64 (as MATLAB evaluates it), one-to-one
+//                          resolution as a per-column atomicMin on an order-preserving 64-bit key,
+//                          segmented radix sort (rocPRIM) to the reference's stable ascending order.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "aps_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace aps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDim = 128;   // SIFT descriptor length; the MFMA path is specialised for it
+constexpr int kTM = 128;    // A rows per workgroup (4 waves x 32)
+constexpr int kTN = 64;     // B rows (= distance-matrix columns) per LDS tile
+constexpr int kLdsRow = 132;  // floats per LDS row: 128 + one 16-B pad => ds_read_b128 conflict-free
+
+// ------------------------------------------------------------------------------------------------
+// |x| maximum per descriptor set (the reference's "looks unnormalised" probe, :105)
+// ------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int dim,
+                              int layout, float* __restrict__ out) {
+    float m = 0.f;
+    const int64_t total = n * dim;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i, k;
+        if (layout == APS_ROWMAJOR) {
+            i = e / dim;
+            k = e % dim;
+        } else {
+            k = e / n;
+            i = e % n;
+        }
+        const float v = fabsf(layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + k * ld]);
+        m = fmaxf(m, v);  // NaN is ignored like MATLAB's max
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: one thread per descriptor row (the canonical sums are serial k-ascending chains)
+// ------------------------------------------------------------------------------------------------
+__global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
+                                 int normalize, float* __restrict__ P, float* __restrict__ sq) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[kDim];
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + k * ld];
+    if (normalize) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
+        // n = sqrt(sum(X.^2,2)) + eps('single'); Xn = X ./ n   (matchFeaturesScratch.m:232-233)
+        const float nrm = __fadd_rn(__fsqrt_rn(s), 1.1920928955078125e-07f);
+#pragma unroll
+        for (int k = 0; k < kDim; ++k) x[k] = __fdiv_rn(x[k], nrm);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
+    sq[i] = s;
+    float* p = P + i * kDim;
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+        f32x4 e, o;
+        e.x = x[8 * s4 + 0];
+        o.x = x[8 * s4 + 1];
+        e.y = x[8 * s4 + 2];
+        o.y = x[8 * s4 + 3];
+        e.z = x[8 * s4 + 4];
+        o.z = x[8 * s4 + 5];
+        e.w = x[8 * s4 + 6];
+        o.w = x[8 * s4 + 7];
+        *reinterpret_cast<f32x4*>(p + 4 * s4) = e;
+        *reinterpret_cast<f32x4*>(p + 64 + 4 * s4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the distance GEMM + fused top-2
+// ------------------------------------------------------------------------------------------------
+struct MatchJob {
+    const float* PA;
+    const float* sqA;
+    const float* PB;
+    const float* sqB;
+    int nA;
+    int nB;
+    int64_t out_off;  // first output slot of this job's rows
+};
+
+struct WgJob {
+    int job;
+    int row0;
+};
+
+__device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob, int oi, float os) {
+    const bool take = (ob < b) || (ob == b && oi < i);
+    const float nb = take ? ob : b;
+    const int ni = take ? oi : i;
+    const float ns = take ? fminf(b, os) : fminf(s, ob);
+    b = nb;
+    i = ni;
+    s = ns;
+}
+
+__global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __restrict__ jobs,
+                                                           const WgJob* __restrict__ wgs,
+                                                           uint32_t* __restrict__ out_idx,
+                                                           float* __restrict__ out_d1,
+                                                           float* __restrict__ out_d2) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
+
+    const WgJob w = wgs[blockIdx.x];
+    const MatchJob jb = jobs[w.job];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 31;
+    const int h = lane >> 5;
+    const int rowbase = w.row0 + wave * 32;
+    const int nA = jb.nA, nB = jb.nB;
+
+    // A fragments: lane (c,h) holds A[rowbase+c][2s+h], s = 0..63  == 64 contiguous floats of P
+    f32x4 av[16];
+    {
+        const int arow = min(rowbase + c, nA - 1);
+        const f32x4* ap = reinterpret_cast<const f32x4*>(jb.PA + (size_t)arow * kDim + h * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[q] = ap[q];
+    }
+    // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float a2[16], best[16], second[16];
+    int bidx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+        a2[r] = jb.sqA[min(row, nA - 1)];
+        best[r] = INFINITY;
+        second[r] = INFINITY;
+        bidx[r] = c;
+    }
+
+    // B tile staging: 64 rows x 512 B = 2048 float4; 256 threads x 8
+    const int ntiles = (nB + kTN - 1) / kTN;
+    f32x4 stage[8];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;  // float4 index in tile
+            const int brow = min(t * kTN + (f >> 5), nB - 1);
+            stage[u] = *reinterpret_cast<const f32x4*>(jb.PB + (size_t)brow * kDim + (f & 31) * 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* base = lds + buf * (kTN * kLdsRow);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;
+            *reinterpret_cast<f32x4*>(base + (f >> 5) * kLdsRow + (f & 31) * 4) = stage[u];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1);
+        const float* tile = lds + (t & 1) * (kTN * kLdsRow);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int j = t * kTN + cb * 32 + c;
+            const float b2 = (j < nB) ? jb.sqB[j] : INFINITY;
+            const f32x4* bp =
+                reinterpret_cast<const f32x4*>(tile + (cb * 32 + c) * kLdsRow + h * 64);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 b = bp[q];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, b.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // D2 = a2 + b2.' - 2*G   (matchFeaturesScratch.m:353), left to right, no contraction
+                const float d = __fsub_rn(__fadd_rn(a2[r], b2), __fmul_rn(2.0f, acc[r]));
+                const bool lt = d < best[r];
+                const float s2 = (d < second[r]) ? d : second[r];
+                second[r] = lt ? best[r] : s2;
+                bidx[r] = lt ? j : bidx[r];
+                best[r] = lt ? d : best[r];
+            }
+        }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // merge the 32 column-lanes of each half-wave (first index wins ties, :356)
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ob = __shfl_xor(best[r], off);
+            const int oi = __shfl_xor(bidx[r], off);
+            const float os = __shfl_xor(second[r], off);
+            top2_merge(best[r], bidx[r], second[r], ob, oi, os);
+        }
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < nA) {
+                const int64_t o = jb.out_off + row;
+                out_idx[o] = nB > 0 ? (uint32_t)bidx[r] + 1u : 0u;
+                out_d1[o] = best[r];
+                out_d2[o] = second[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ratio / threshold / uniqueness  (matchFeaturesScratch.m:170-211)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_f32(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorder_f32(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+struct FilterJob {
+    int64_t row_off;  // first row slot (same as MatchJob::out_off)
+    int64_t col_off;  // first slot of this job's B columns in the winner table
+    int nA;
+    int nB;
+};
+
+// row -> job lookup by binary search over row_off
+__device__ __forceinline__ int find_job(const FilterJob* __restrict__ fj, int njobs, int64_t slot) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (fj[mid].row_off <= slot)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void filter_mark_kernel(const FilterJob* __restrict__ fj, int njobs, int64_t total_rows,
+                                   const uint32_t* __restrict__ idx, const float* __restrict__ d1,
+                                   const float* __restrict__ d2, double r2, double thr, int unique,
+                                   unsigned long long* __restrict__ keys,  // per row, ~0 if dropped
+                                   unsigned long long* __restrict__ winner) {
+    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (slot >= total_rows) return;
+    const int j = find_job(fj, njobs, slot);
+    const FilterJob f = fj[j];
+    const uint32_t row = (uint32_t)(slot - f.row_off);
+    const double b = (double)d1[slot], s = (double)d2[slot];
+    // ratioOK = dBest <= r2*dSecond; threshOK = dBest <= MatchThreshold; both finite (:173-178)
+    const bool keep = idx[slot] != 0 && (b <= r2 * s) && (b <= thr) && isfinite(b) && isfinite(s);
+    unsigned long long key = ~0ull;
+    if (keep) {
+        key = ((unsigned long long)order_f32(d1[slot]) << 32) | row;
+        if (unique) atomicMin(&winner[f.col_off + (idx[slot] - 1)], key);
+    }
+    keys[slot] = key;
+}
+
+__global__ void filter_select_kernel(const FilterJob* __restrict__ fj, int njobs,
+                                     int64_t total_rows, const uint32_t* __restrict__ idx,
+                                     int unique, unsigned long long* __restrict__ keys,
+                                     const unsigned long long* __restrict__ winner,
+                                     unsigned long long* __restrict__ job_count) {
+    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (slot >= total_rows) return;
+    unsigned long long key = keys[slot];
+    if (key == ~0ull) return;
+    const int j = find_job(fj, njobs, slot);
+    if (unique && winner[fj[j].col_off + (idx[slot] - 1)] != key) {
+        keys[slot] = ~0ull;
+        return;
+    }
+    atomicAdd(&job_count[j], 1ull);
+}
+
+// After sorting each job's key segment ascending, the kept entries are the first job_count[j] keys.
+__global__ void filter_emit_kernel(const FilterJob* __restrict__ fj, int njobs,
+                                   const unsigned long long* __restrict__ sorted_keys,
+                                   const unsigned long long* __restrict__ job_ptr,  // exclusive scan
+                                   const uint32_t* __restrict__ idx, int unique,
+                                   uint32_t* __restrict__ o1, uint32_t* __restrict__ o2,
+                                   float* __restrict__ metric, int64_t cap) {
+    const int j = blockIdx.y;
+    const FilterJob f = fj[j];
+    const unsigned long long base = job_ptr[j];
+    const unsigned long long cnt = job_ptr[j + 1] - base;
+    for (unsigned long long e = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; e < cnt;
+         e += (unsigned long long)gridDim.x * blockDim.x) {
+        if ((int64_t)(base + e) >= cap) continue;
+        const unsigned long long key = sorted_keys[f.row_off + e];
+        const uint32_t row = (uint32_t)(key & 0xffffffffu);
+        o1[base + e] = row + 1;
+        o2[base + e] = idx[f.row_off + row];
+        metric[base + e] = unorder_f32((uint32_t)(key >> 32));
+    }
+}
+
+// keys for the non-unique case must sort by row only: rewrite (d,row) -> (0,row) keeping d aside is
+// unnecessary because the emit kernel re-reads d1; handled by a variant below.
+__global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
+                                        const unsigned long long* __restrict__ sorted_keys,
+                                        const unsigned long long* __restrict__ job_ptr,
+                                        const uint32_t* __restrict__ idx,
+                                        const float* __restrict__ d1, uint32_t* __restrict__ o1,
+                                        uint32_t* __restrict__ o2, float* __restrict__ metric,
+                                        int64_t cap) {
+    const int j = blockIdx.y;
+    const FilterJob f = fj[j];
+    const unsigned long long base = job_ptr[j];
+    const unsigned long long cnt = job_ptr[j + 1] - base;
+    for (unsigned long long e = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; e < cnt;
+         e += (unsigned long long)gridDim.x * blockDim.x) {
+        if ((int64_t)(base + e) >= cap) continue;
+        const uint32_t row = (uint32_t)(sorted_keys[f.row_off + e] & 0xffffffffu);
+        o1[base + e] = row + 1;
+        o2[base + e] = idx[f.row_off + row];
+        metric[base + e] = d1[f.row_off + row];
+    }
+}
+
+__global__ void keys_rows_only_kernel(unsigned long long* __restrict__ keys, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n && keys[i] != ~0ull) keys[i] &= 0xffffffffull;
+}
+
+__global__ void scan_counts_kernel(const unsigned long long* __restrict__ cnt, int n,
+                                   unsigned long long* __restrict__ ptr) {
+    // single thread: n is the number of image pairs (<= a few 10^5), run once per call
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int i = 0; i < n; ++i) {
+            ptr[i] = s;
+            s += cnt[i];
+        }
+        ptr[n] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+struct Prepared {
+    Ws<float> P, sq;
+    int64_t n = 0;
+};
+
+static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
+                    Prepared& out) {
+    out.n = n;
+    out.P.alloc((size_t)std::max<int64_t>(n, 1) * kDim);
+    out.sq.alloc((size_t)std::max<int64_t>(n, 1));
+    if (n == 0) return;
+    prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
+                                                        out.P, out.sq);
+    check_launch("prep_desc_kernel");
+}
+
+static float absmax(const float* X_dev, int64_t n, int64_t ld, int layout, float* d_slot) {
+    APS_HIP(hipMemsetAsync(d_slot, 0, sizeof(float), stream()));
+    if (n > 0) {
+        const unsigned grid = std::min<unsigned>(cdiv((size_t)n * kDim, 256), 2048);
+        absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
+        check_launch("absmax_kernel");
+    }
+    float h = 0.f;
+    APS_HIP(hipMemcpyAsync(&h, d_slot, sizeof(float), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    return h;
+}
+
+static void check_desc_args(const void* p, int64_t n, int64_t ld, int dim, int layout,
+                            const char* name) {
+    APS_REQUIRE(dim == kDim, APS_E_DIM, "%s: descriptor length %d not supported (this path is built for %d-D SIFT)",
+                name, dim, kDim);
+    APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "%s: unknown layout %d",
+                name, layout);
+    APS_REQUIRE(n >= 0, APS_E_ARG, "%s: negative row count", name);
+    APS_REQUIRE(n == 0 || p != nullptr, APS_E_ARG, "%s: NULL data with %lld rows", name, (long long)n);
+    if (layout == APS_ROWMAJOR)
+        APS_REQUIRE(ld >= dim, APS_E_DIM, "%s: leading dimension %lld < dim %d", name, (long long)ld, dim);
+    else
+        APS_REQUIRE(ld >= n, APS_E_DIM, "%s: leading dimension %lld < rows %lld", name, (long long)ld,
+                    (long long)n);
+    APS_REQUIRE(n < (int64_t)1 << 31, APS_E_DIM, "%s: more than 2^31-1 rows", name);
+}
+
+// Runs the GEMM+top2 for a list of jobs whose operands are already prepared on the device.
+static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2) {
+    std::vector<WgJob> wgs;
+    for (int j = 0; j < (int)jobs.size(); ++j)
+        for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r});
+    if (wgs.empty()) return;
+    Ws<MatchJob> djobs(jobs.size());
+    Ws<WgJob> dwgs(wgs.size());
+    APS_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(MatchJob), hipMemcpyHostToDevice,
+                           stream()));
+    APS_HIP(hipMemcpyAsync(dwgs, wgs.data(), wgs.size() * sizeof(WgJob), hipMemcpyHostToDevice,
+                           stream()));
+    match2nn_kernel<<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, idx, d1, d2);
+    check_launch("match2nn_kernel");
+    // the pageable host vectors must stay alive until the copies have been consumed
+    APS_HIP(hipStreamSynchronize(stream()));
+}
+
+// ratio/threshold/unique for a list of jobs; returns total kept.  Outputs are device pointers.
+static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_rows, int64_t total_cols,
+                          const uint32_t* idx, const float* d1, const float* d2,
+                          const aps_match_opts& o, unsigned long long* d_job_ptr /* njobs+1 */,
+                          uint32_t* o1, uint32_t* o2, float* metric, int64_t cap) {
+    const int njobs = (int)fjobs.size();
+    APS_HIP(hipMemsetAsync(d_job_ptr, 0, (njobs + 1) * sizeof(unsigned long long), stream()));
+    if (total_rows == 0 || njobs == 0) return 0;
+    Ws<FilterJob> dfj(njobs);
+    APS_HIP(hipMemcpyAsync(dfj, fjobs.data(), njobs * sizeof(FilterJob), hipMemcpyHostToDevice,
+                           stream()));
+    Ws<unsigned long long> keys(total_rows), sorted(total_rows), winner(std::max<int64_t>(total_cols, 1)),
+        cnt(njobs);
+    APS_HIP(hipMemsetAsync(winner, 0xff, std::max<int64_t>(total_cols, 1) * sizeof(unsigned long long),
+                           stream()));
+    APS_HIP(hipMemsetAsync(cnt, 0, njobs * sizeof(unsigned long long), stream()));
+    const double r2 = (double)o.max_ratio * (double)o.max_ratio;
+    const unsigned grid = cdiv(total_rows, 256);
+    filter_mark_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, d1, d2, r2,
+                                                    (double)o.match_threshold, o.unique, keys, winner);
+    check_launch("filter_mark_kernel");
+    filter_select_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, o.unique, keys,
+                                                      winner, cnt);
+    check_launch("filter_select_kernel");
+    if (!o.unique) {
+        keys_rows_only_kernel<<<grid, 256, 0, stream()>>>(keys, total_rows);
+        check_launch("keys_rows_only_kernel");
+    }
+    scan_counts_kernel<<<1, 64, 0, stream()>>>(cnt, njobs, d_job_ptr);
+    check_launch("scan_counts_kernel");
+
+    // segmented ascending sort of each job's keys; dropped rows (~0) sink to the segment's end
+    std::vector<int64_t> seg(njobs + 1);
+    for (int j = 0; j < njobs; ++j) seg[j] = fjobs[j].row_off;
+    seg[njobs] = total_rows;
+    Ws<int64_t> dseg(njobs + 1);
+    APS_HIP(hipMemcpyAsync(dseg, seg.data(), (njobs + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                           stream()));
+    size_t tmp_bytes = 0;
+    APS_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, keys.get(), sorted.get(),
+                                               (unsigned)total_rows, (unsigned)njobs, dseg.get(),
+                                               dseg.get() + 1, 0, 64, stream()));
+    Ws<char> tmp(tmp_bytes);
+    APS_HIP(rocprim::segmented_radix_sort_keys(tmp.get(), tmp_bytes, keys.get(), sorted.get(),
+                                               (unsigned)total_rows, (unsigned)njobs, dseg.get(),
+                                               dseg.get() + 1, 0, 64, stream()));
+    unsigned long long total = 0;
+    APS_HIP(hipMemcpyAsync(&total, d_job_ptr + njobs, sizeof total, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));  // also keeps fjobs/seg alive long enough
+    if ((int64_t)total > cap) return (int64_t)total;
+    if (total > 0) {
+        dim3 g(64, njobs);
+        if (o.unique)
+            filter_emit_kernel<<<g, 256, 0, stream()>>>(dfj, njobs, sorted, d_job_ptr, idx, 1, o1, o2,
+                                                         metric, cap);
+        else
+            filter_emit_rows_kernel<<<g, 256, 0, stream()>>>(dfj, sorted, d_job_ptr, idx, d1, o1, o2,
+                                                              metric, cap);
+        check_launch("filter_emit_kernel");
+    }
+    APS_HIP(hipStreamSynchronize(stream()));
+    return (int64_t)total;
+}
+
+static aps_match_opts default_opts() {
+    aps_match_opts o;
+    o.max_ratio = 0.6f;
+    o.match_threshold = 3.5f;
+    o.unique = 1;
+    o.normalize = 2;
+    return o;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, int64_t n2,
+                      int64_t ldb, int dim, int layout, uint32_t* idx2, float* d1, float* d2) {
+    return guarded([&] {
+        check_desc_args(A, n1, lda, dim, layout, "A");
+        check_desc_args(B, n2, ldb, dim, layout, "B");
+        APS_REQUIRE(n1 == 0 || (idx2 && d1 && d2), APS_E_ARG, "NULL output");
+        ctx();
+        if (n1 == 0) return;
+        const size_t a_elems = layout == APS_ROWMAJOR ? (size_t)(n1 - 1) * lda + dim : (size_t)(dim - 1) * lda + n1;
+        const size_t b_elems = n2 == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(n2 - 1) * ldb + dim : (size_t)(dim - 1) * ldb + n2);
+        In<float> dA(A, a_elems), dB(B, b_elems);
+        Out<uint32_t> oi(idx2, n1);
+        Out<float> o1(d1, n1), o2(d2, n1);
+        Prepared pa, pb;
+        prepare(dA, n1, lda, layout, false, pa);
+        prepare(dB, n2, ldb, layout, false, pb);
+        if (n2 == 0) {
+            // no candidates: idx 0, distances inf
+            APS_HIP(hipMemsetAsync(oi.get(), 0, n1 * sizeof(uint32_t), stream()));
+            std::vector<float> inf(n1, std::numeric_limits<float>::infinity());
+            APS_HIP(hipMemcpyAsync(o1.get(), inf.data(), n1 * sizeof(float), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemcpyAsync(o2.get(), inf.data(), n1 * sizeof(float), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+        } else {
+            std::vector<MatchJob> jobs(1);
+            jobs[0] = {pa.P, pa.sq, pb.P, pb.sq, (int)n1, (int)n2, 0};
+            run_match_jobs(jobs, oi, o1, o2);
+        }
+        oi.commit();
+        o1.commit();
+        o2.commit();
+    });
+}
+
+int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2, int64_t n2,
+                       int64_t ld2, int dim, int layout, const aps_match_opts* opts,
+                       uint32_t* idx1, uint32_t* idx2, float* metric, int64_t cap, int64_t* count) {
+    return guarded([&] {
+        const float* descs[2] = {F1, F2};
+        const int64_t counts[2] = {n1, n2};
+        const int64_t lds[2] = {ld1, ld2};
+        int64_t pair_ptr[2] = {0, 0};
+        APS_REQUIRE(count != nullptr, APS_E_ARG, "count is NULL");
+        const int rc = aps_match_pairwise(descs, counts, lds, 2, dim, layout, opts, pair_ptr, idx1,
+                                          idx2, metric, cap, count);
+        if (rc != APS_OK) throw Error(rc, aps_last_error());
+    });
+}
+
+int aps_match_pairwise(const float* const* desc, const int64_t* counts, const int64_t* ld,
+                       int n_img, int dim, int layout, const aps_match_opts* opts,
+                       int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j, float* metric,
+                       int64_t cap, int64_t* count) {
+    return guarded([&] {
+        APS_REQUIRE(n_img >= 0, APS_E_ARG, "negative image count");
+        APS_REQUIRE(count != nullptr && pair_ptr != nullptr, APS_E_ARG, "count/pair_ptr is NULL");
+        APS_REQUIRE(n_img == 0 || (desc && counts && ld), APS_E_ARG, "NULL descriptor table");
+        APS_REQUIRE(cap >= 0, APS_E_ARG, "negative capacity");
+        const aps_match_opts o = opts ? *opts : default_opts();
+        APS_REQUIRE(o.max_ratio > 0.f && o.max_ratio <= 1.f, APS_E_ARG, "MaxRatio must be in (0,1]");
+        APS_REQUIRE(o.match_threshold >= 0.f, APS_E_ARG, "MatchThreshold must be >= 0");
+        APS_REQUIRE(o.normalize >= 0 && o.normalize <= 2, APS_E_ARG, "normalize must be 0, 1 or 2");
+        for (int i = 0; i < n_img; ++i) check_desc_args(desc[i], counts[i], ld[i], dim, layout, "desc");
+        ctx();
+        const int64_t n_pairs = (int64_t)n_img * (n_img - 1) / 2;
+        *count = 0;
+        if (n_pairs <= 0) {
+            pair_ptr[0] = 0;
+            return;
+        }
+
+        // upload + probe
+        std::vector<In<float>> din(n_img);
+        std::vector<float> amax(n_img, 0.f);
+        Ws<float> slot(1);
+        for (int i = 0; i < n_img; ++i) {
+            const int64_t n = counts[i];
+            const size_t elems = n == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld[i] + dim : (size_t)(dim - 1) * ld[i] + n);
+            din[i].bind(desc[i], elems);
+            if (o.normalize == 2) amax[i] = absmax(din[i], n, ld[i], layout, slot);
+        }
+        // which variants (raw / normalised) of each image are needed: the reference decides per pair
+        // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
+        auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
+        std::vector<Prepared> raw(n_img), nrm(n_img);
+        std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
+        for (int j = 1; j < n_img; ++j)
+            for (int i = 0; i < j; ++i) {
+                const bool norm = big(i) || big(j);
+                (norm ? need_nrm : need_raw)[i] = 1;
+                (norm ? need_nrm : need_raw)[j] = 1;
+            }
+        for (int i = 0; i < n_img; ++i) {
+            if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i]);
+            if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i]);
+        }
+
+        // jobs in the reference's pair order (featureMatchingPairwise.m:48: column-major triu)
+        std::vector<MatchJob> jobs;
+        std::vector<FilterJob> fjobs;
+        int64_t rows = 0, cols = 0;
+        for (int j = 1; j < n_img; ++j)
+            for (int i = 0; i < j; ++i) {
+                const bool norm = big(i) || big(j);
+                const Prepared& a = norm ? nrm[i] : raw[i];
+                const Prepared& b = norm ? nrm[j] : raw[j];
+                // an empty side makes the pair empty (the reference's validateattributes would reject
+                // empty float inputs; callers skip such images)
+                const int nA = counts[j] == 0 ? 0 : (int)counts[i];
+                jobs.push_back({a.P, a.sq, b.P, b.sq, nA, (int)counts[j], rows});
+                fjobs.push_back({rows, cols, nA, (int)counts[j]});
+                rows += nA;
+                cols += counts[j];
+            }
+        APS_REQUIRE(rows < ((int64_t)1 << 32), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
+        Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
+        Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
+        run_match_jobs(jobs, idx, d1, d2);
+
+        Out<uint32_t> oi(idx_i, cap), oj(idx_j, cap);
+        Out<float> om(metric, cap);
+        Ws<unsigned long long> job_ptr(n_pairs + 1);
+        const int64_t total = run_filter(fjobs, rows, cols, idx, d1, d2, o, job_ptr, oi, oj, om, cap);
+        *count = total;
+        std::vector<unsigned long long> hp(n_pairs + 1);
+        APS_HIP(hipMemcpyAsync(hp.data(), job_ptr, (n_pairs + 1) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (is_device_ptr(pair_ptr)) {
+            std::vector<int64_t> tmp(hp.begin(), hp.end());
+            APS_HIP(hipMemcpy(pair_ptr, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        } else {
+            for (int64_t p = 0; p <= n_pairs; ++p) pair_ptr[p] = (int64_t)hp[p];
+        }
+        if (total > cap) fail(APS_E_CAP, "output capacity %lld < %lld matches", (long long)cap, (long long)total);
+        APS_REQUIRE(total == 0 || (idx_i && idx_j && metric), APS_E_ARG, "NULL output with matches present");
+        oi.commit(total);
+        oj.commit(total);
+        om.commit(total);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""Host-side mirror of PP/featureMatching/ — same operator names, argument meaning and outputs as the
+reference's MATLAB functions, with the arithmetic done by libaps_hip.so on the MI355X.
+
+MATLAB cell arrays become Python lists (n x n cells -> list of lists), structs become dicts, and
+index outputs stay 1-based ``float64`` exactly like ``double(matches)`` in
+featureMatchingPairwise.m:120.  Inputs may be numpy arrays (host; staged through HBM by the library)
+or torch CUDA tensors (device resident; no copies).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib, ptr
+
+DIM = 128
+
+
+def _as_desc(x):
+    """Row-major float32 N x 128 view of a descriptor matrix (numpy or torch); returns (obj, n, ld, layout)."""
+    if _capi.is_torch(x):
+        import torch
+
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.dim() != 2:
+            raise ValueError("descriptors must be 2-D")
+        if x.stride(1) == 1 and (x.shape[0] <= 1 or x.stride(0) >= x.shape[1]):
+            return x, x.shape[0], max(x.stride(0), x.shape[1]), _capi.APS_ROWMAJOR
+        if x.stride(0) == 1:  # column-major (MATLAB) storage
+            return x, x.shape[0], max(x.stride(1), x.shape[0]), _capi.APS_COLMAJOR
+        x = x.contiguous()
+        return x, x.shape[0], x.shape[1], _capi.APS_ROWMAJOR
+    x = np.asarray(x)
+    if x.dtype != np.float32:
+        x = x.astype(np.float32)  # normalizeInputs casts non-float input to single (matchFeaturesScratch.m:277-278)
+    if x.ndim != 2:
+        raise ValueError("descriptors must be 2-D")
+    if x.flags.f_contiguous and not x.flags.c_contiguous:
+        return x, x.shape[0], x.shape[0], _capi.APS_COLMAJOR
+    x = np.ascontiguousarray(x)
+    return x, x.shape[0], x.shape[1], _capi.APS_ROWMAJOR
+
+
+def _opts(MaxRatio, MatchThreshold, Unique, normalize=2):
+    o = _capi.aps_match_opts()
+    o.max_ratio = float(MaxRatio)
+    o.match_threshold = float(MatchThreshold)
+    o.unique = 1 if Unique else 0
+    o.normalize = int(normalize)
+    return o
+
+
+def nearest2SSDExhaustive(A, B):
+    """[idx1, idx2, d1, d2] = nearest2SSDExhaustive(A, B) (matchFeaturesScratch.m:322-366)."""
+    A, n1, lda, la = _as_desc(A)
+    B, n2, ldb, lb = _as_desc(B)
+    if la != lb:
+        raise ValueError("A and B must share a storage order")
+    if n1 and A.shape[1] != DIM or n2 and B.shape[1] != DIM:
+        raise ValueError("Descriptor dimensions must match for non-binary.")
+    idx2 = np.zeros(n1, np.uint32)
+    d1 = np.zeros(n1, np.float32)
+    d2 = np.zeros(n1, np.float32)
+    check(lib.aps_match_2nn_ssd(ptr(A), n1, lda, ptr(B), n2, ldb, DIM, la, ptr(idx2), ptr(d1), ptr(d2)))
+    return np.arange(1, n1 + 1, dtype=np.float64), idx2, d1, d2
+
+
+def matchFeaturesScratch(F1, F2, Method="Exhaustive", MatchThreshold=3.5, MaxRatio=0.6, Unique=True,
+                         **_ignored_approx_args):
+    """[matches, matchMetric] = matchFeaturesScratch(F1, F2, 'Method', ..., 'MatchThreshold', ...,
+    'MaxRatio', ..., 'Unique', ...) for float descriptors (matchFeaturesScratch.m:1-215).
+
+    Only the exhaustive float back end runs on the device (the north-star path); 'Approximate' float
+    methods of the reference are approximations OF this exhaustive search (random subset / PCA /
+    kd-tree, :142-160) and are served by the same exact kernel.
+    Returns (matches K x 2 uint32 1-based, matchMetric K float32)."""
+    if str(Method).lower() not in ("exhaustive", "approximate"):
+        raise ValueError(f"Unknown Method: {Method}")
+    if not (0 < MaxRatio <= 1) or MatchThreshold < 0:
+        raise ValueError("invalid MaxRatio/MatchThreshold")
+    A, n1, ld1, la = _as_desc(F1)
+    B, n2, ld2, lb = _as_desc(F2)
+    if n1 == 0 or n2 == 0:
+        raise ValueError("Expected input to be nonempty.")  # validateattributes(... 'nonempty') :279-280
+    if A.shape[1] != B.shape[1]:
+        raise ValueError("Descriptor dimensions must match for non-binary.")
+    if la != lb:
+        B = np.ascontiguousarray(B) if la == _capi.APS_ROWMAJOR else np.asfortranarray(B)
+        B, n2, ld2, lb = _as_desc(B)
+    cap = n1
+    i1 = np.zeros(cap, np.uint32)
+    i2 = np.zeros(cap, np.uint32)
+    met = np.zeros(cap, np.float32)
+    cnt = C.c_int64(0)
+    o = _opts(MaxRatio, MatchThreshold, Unique)
+    check(lib.aps_match_features(ptr(A), n1, ld1, ptr(B), n2, ld2, A.shape[1], la, C.byref(o), ptr(i1),
+                                 ptr(i2), ptr(met), cap, C.byref(cnt)))
+    k = cnt.value
+    return np.stack([i1[:k], i2[:k]], axis=1), met[:k].copy()
+
+
+def match_pairwise_csr(allDescriptors, MaxRatio, MatchThreshold, Unique=True, normalize=2,
+                       device_out=False):
+    """Batched all-pairs matcher: the CSR form of featureMatchingPairwise used by the resident pipeline.
+    Returns (pair_ptr int64[P+1], idx_i, idx_j, metric) with pairs in the reference's triu order."""
+    n = len(allDescriptors)
+    prepared = [_as_desc(d) for d in allDescriptors]
+    layouts = {p[3] for p in prepared if p[1] > 0}
+    if len(layouts) > 1:
+        raise ValueError("all descriptor matrices must share a storage order")
+    layout = layouts.pop() if layouts else _capi.APS_ROWMAJOR
+    ptrs = (C.c_void_p * n)(*[ptr(p[0]) if p[1] > 0 else None for p in prepared])
+    counts = (C.c_int64 * n)(*[p[1] for p in prepared])
+    lds = (C.c_int64 * n)(*[max(p[2], DIM if layout == _capi.APS_ROWMAJOR else p[1]) for p in prepared])
+    npairs = n * (n - 1) // 2
+    pair_ptr = np.zeros(npairs + 1, np.int64)
+    o = _opts(MaxRatio, MatchThreshold, Unique, normalize)
+    cnt = C.c_int64(0)
+    # first call with a modest capacity; APS_E_CAP reports the exact need
+    cap = max(1, sum(p[1] for p in prepared) // 4)
+    while True:
+        if device_out:
+            import torch
+
+            i_i = torch.empty(cap, dtype=torch.int32, device="cuda")
+            i_j = torch.empty(cap, dtype=torch.int32, device="cuda")
+            met = torch.empty(cap, dtype=torch.float32, device="cuda")
+        else:
+            i_i = np.zeros(cap, np.uint32)
+            i_j = np.zeros(cap, np.uint32)
+            met = np.zeros(cap, np.float32)
+        rc = lib.aps_match_pairwise(ptrs, counts, lds, n, DIM, layout, C.byref(o), ptr(pair_ptr),
+                                    ptr(i_i), ptr(i_j), ptr(met), cap, C.byref(cnt))
+        if rc == _capi.APS_E_CAP:
+            cap = cnt.value
+            continue
+        check(rc)
+        break
+    k = cnt.value
+    return pair_ptr, i_i[:k], i_j[:k], met[:k]
+
+
+def pair_order(numImg):
+    """The reference's pair order: nonzeros(triu(reshape(1:n^2,n,n),1)) (featureMatchingPairwise.m:48)."""
+    return [(i, j) for j in range(1, numImg) for i in range(j)]
+
+
+def featureMatchingPairwise(input, allDescriptors, numImg):
+    """matches = featureMatchingPairwise(input, allDescriptors, numImg) (featureMatchingPairwise.m:1-63).
+
+    Returns an n x n list of lists; cell (i, j), i < j, holds an M x 2 float64 array of 1-based
+    [idx_i idx_j]; every other cell is None (MATLAB: empty)."""
+    numImg = int(numImg)
+    if numImg <= 0 or len(allDescriptors) != numImg:
+        raise ValueError("numImg must be positive and match numel(allDescriptors)")
+    thr = input.get("Matchingthreshold", 1.5)
+    ratio = input.get("Ratiothreshold", 0.6)
+    pair_ptr, ii, jj, _ = match_pairwise_csr(allDescriptors, ratio, thr, True)
+    matches = [[None] * numImg for _ in range(numImg)]
+    for p, (i, j) in enumerate(pair_order(numImg)):
+        s, e = pair_ptr[p], pair_ptr[p + 1]
+        matches[i][j] = np.stack([ii[s:e], jj[s:e]], axis=1).astype(np.float64)
+    return matches

@@ -1,0 +1,299 @@
+/*
+ * aps.h — C ABI of libaps_hip.so, the MI355X (gfx950) stitching hot path.
+ *
+ * This is the drop-in boundary for AutoPanoStitch's hot path.  The reference's only FFI is the
+ * MATLAB mex gateway (PP/mex/flann_knn.cpp:118-119, PP/mex/nearest2HammingExhaustiveMEX.cpp:16);
+ * every entry point below is what a mex shim for the cited reference function binds (the shims and
+ * the shadowing .m wrappers are in matlab/, described in INTEGRATION.md).  "PP/" abbreviates
+ * "/root/reference/Procedural Program/".
+ *
+ * Conventions (all functions):
+ *   - extern "C", return int status: APS_OK (0) or a negative APS_E_* code; a human-readable
+ *     message for the calling thread is available from aps_last_error().  Nothing throws or
+ *     long-jumps across the boundary (the mex shim turns a non-zero status into
+ *     mexErrMsgIdAndTxt("aps:<kind>", aps_last_error()), as flann_knn.cpp:130-166 does).
+ *   - Pointers are plain pointers; each may point to HOST memory (what a mex shim holds) or to
+ *     DEVICE memory (what a resident pipeline holds).  The library asks the HIP runtime which it
+ *     is (hipPointerGetAttributes) and stages host buffers through HBM itself.  No torch types.
+ *   - The caller owns every buffer; outputs are caller-allocated; the library keeps no pointer
+ *     after return.  Data-dependent output sizes use (capacity in, count out); if the capacity
+ *     is too small the call fails with APS_E_CAP and *count holds the needed size.
+ *   - Matrices carry an explicit layout + leading dimension.  APS_COLMAJOR is MATLAB's layout
+ *     (element (i,k) at p[i + k*ld], flann_knn.cpp:111-112); APS_ROWMAJOR is C/numpy/torch
+ *     (element (i,k) at p[i*ld + k]).
+ *   - Indices crossing the boundary are 1-based uint32 like the reference's mex outputs
+ *     (flann_knn.cpp:214,248; nearest2HammingExhaustiveMEX.cpp:76); 0 means "none".
+ *   - Thread-safe and re-entrant: per-thread HIP stream and workspace; no global mutable state
+ *     besides the device selection of the calling thread.
+ *   - There is NO CPU fallback in this library.  Without a usable gfx950 device every compute
+ *     entry point returns APS_E_DEVICE.
+ */
+#ifndef APS_H_
+#define APS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APS_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes -------------------------------------------------------------------------- */
+enum {
+    APS_OK = 0,
+    APS_E_ARG = -1,      /* bad argument value (null pointer, negative size, unknown enum)       */
+    APS_E_DIM = -2,      /* dimension mismatch (flann_knn:dim, hamm2nn:cols)                      */
+    APS_E_TYPE = -3,     /* unsupported element type / layout                                     */
+    APS_E_OOM = -4,      /* device or host allocation failed (renderPanorama.m:245-266 semantics) */
+    APS_E_DEVICE = -5,   /* no gfx950 device / HIP runtime error                                  */
+    APS_E_INTERNAL = -6, /* invariant violated inside the library                                 */
+    APS_E_CAP = -7       /* output capacity too small; needed size reported through *count        */
+};
+
+enum { APS_COLMAJOR = 0, APS_ROWMAJOR = 1 };
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int aps_version(void);
+const char* aps_last_error(void);
+/* Number of usable gfx950 devices (0 if none; never fails). */
+int aps_device_count(void);
+/* Select the device for the calling thread (default: env APS_DEVICE, else 0). */
+int aps_set_device(int device);
+/* Run the calling thread's work on an existing HIP stream (e.g. torch's current stream);
+ * NULL restores the library's own per-thread stream. */
+int aps_set_stream(void* hip_stream);
+/* Block until the calling thread's stream has drained. */
+int aps_synchronize(void);
+/* Release the calling thread's cached device workspace. */
+int aps_release_workspace(void);
+/* Per-thread event timer on the library's stream (used by bench.py for in-stream kernel timing):
+ * aps_timer_begin() records an event, aps_timer_end() records another, synchronises and returns
+ * the elapsed milliseconds between them. */
+int aps_timer_begin(void);
+int aps_timer_end(float* ms);
+
+/* ============================================================================================
+ * (1) Descriptor matching — PP/featureMatching/matchFeaturesScratch.m
+ * ============================================================================================ */
+
+/* a5: nearest2SSDExhaustive (matchFeaturesScratch.m:322-366).
+ *   D2(i,j) = (a2(i) + b2(j)) - 2*G(i,j),  G = A*B'  in f32;
+ *   idx2(i) = argmin_j D2(i,j) (first index on ties, :356), d1 = that minimum,
+ *   d2 = min over j != idx2(i) (inf if n2 == 1).
+ * Arithmetic contract (the canonical order the oracle restates): G(i,j) is the k-ascending f32 fma
+ * chain acc = fmaf(A(i,k), B(j,k), acc) from acc = 0 — exactly what v_mfma_f32_32x32x2_f32 computes;
+ * a2/b2 are k-ascending sums s = s + x*x (separate multiply and add).
+ * idx2: 1-based uint32[n1]; d1, d2: f32[n1]. */
+int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, int64_t n2,
+                      int64_t ldb, int dim, int layout, uint32_t* idx2, float* d1, float* d2);
+
+/* Options of the a4 driver (matchFeaturesScratch.m:59-78 name/value pairs). */
+typedef struct aps_match_opts {
+    float max_ratio;       /* 'MaxRatio'       (inputs.m:59  Ratiothreshold = 0.6)                 */
+    float match_threshold; /* 'MatchThreshold' (inputs.m:55  Matchingthreshold = 1.5; raw SSD)     */
+    int unique;            /* 'Unique'         (featureMatchingPairwise.m:113: true)               */
+    int normalize;         /* 0 never, 1 always, 2 = the reference's rule: L2-normalise both sets
+                              iff max|A| > 2 or max|B| > 2 (matchFeaturesScratch.m:105-110)        */
+} aps_match_opts;
+
+/* a4 + a5: matchFeaturesScratch(F1, F2, 'Method','Exhaustive', ...) for float descriptors
+ * (matchFeaturesScratch.m:81-215): conditional row normalisation x./(sqrt(sum(x.^2))+eps('single'))
+ * (:232-233), exhaustive 2-NN, keep iff d1 <= r^2*d2 (:173-174) and d1 <= MatchThreshold (:177) and
+ * both finite (:178), then greedy one-to-one by ascending d with stable order (:186-207).
+ * Outputs: idx1/idx2 1-based uint32[cap], metric f32[cap], *count = K.  cap >= n1 always suffices. */
+int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2, int64_t n2,
+                       int64_t ld2, int dim, int layout, const aps_match_opts* opts,
+                       uint32_t* idx1, uint32_t* idx2, float* metric, int64_t cap, int64_t* count);
+
+/* a3: featureMatchingPairwise (featureMatchingPairwise.m:48-63): all upper-triangular image pairs
+ * in the reference's order (column-major linear index of triu(.,1): (1,2),(1,3),(2,3),(1,4),...),
+ * each through aps_match_features' rule, in ONE batched launch sequence.
+ *   desc[i]  : descriptors of image i, counts[i] x dim, row stride ld[i] (layout as above)
+ *   pair_ptr : int64[n_pairs+1] CSR offsets into idx_i/idx_j/metric, n_pairs = n_img*(n_img-1)/2
+ *   idx_i/idx_j : 1-based feature indices in image i / j (i < j), metric: SSD
+ * cap >= sum over pairs of counts[i] always suffices. */
+int aps_match_pairwise(const float* const* desc, const int64_t* counts, const int64_t* ld,
+                       int n_img, int dim, int layout, const aps_match_opts* opts,
+                       int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j, float* metric,
+                       int64_t cap, int64_t* count);
+
+/* a8 kNN: [idx, dist] = flann_knn_win(train, query, k, 'flann', trees, checks) for float
+ * descriptors (flann_knn.cpp:118-253; caller featureMatchingGlobal.m:108-117), with an EXACT
+ * search in place of OpenCV's randomized kd-forest: squared-L2, ascending, ties -> lower index.
+ * idx: 1-based uint32 Fq x k, dist: f32 Fq x k, both in `layout` with leading dimension ldo. */
+int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* query, int64_t fq,
+                   int64_t ldq, int dim, int layout, int k, uint32_t* idx, float* dist,
+                   int64_t ldo);
+
+/* a8 filter: the per-query loop of featureMatchingGlobal.m:123-161 (drop self, drop same-image,
+ * need >= 2 left, reject iff d1/max(d2,eps('single')) > ratio, append [li lj] to pair (min,max) in
+ * query order).  img_idx (1-based image id per row) and local_idx (1-based) are uint32[f].
+ * Output CSR over pairs in the same pair order as aps_match_pairwise. */
+int aps_global_filter(const uint32_t* nn_idx, const float* nn_dist, int64_t f, int k,
+                      int64_t ldn, int layout, const uint32_t* img_idx, const uint32_t* local_idx,
+                      int n_img, float ratio, int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j,
+                      int64_t cap, int64_t* count);
+
+/* a9: [idx2,d1,d2] = nearest2HammingExhaustiveMEX(Abytes,Bbytes)
+ * (nearest2HammingExhaustiveMEX.cpp:16-80, ...OMPMEX.cpp:18-83): brute-force Hamming 2-NN on packed
+ * bytes with the reference's tie rule (strict < for best, <= for second, :63-68), N2==0 -> idx 0 and
+ * NaN (:42-45), single candidate -> second = nb*8 (:71-74). */
+int aps_hamming_2nn(const uint8_t* A, int64_t n1, int64_t lda, const uint8_t* B, int64_t n2,
+                    int64_t ldb, int nbytes, int layout, uint32_t* idx2, float* d1, float* d2);
+
+/* ============================================================================================
+ * (2) Geometric verification — PP/imageMatching/estimateTransformationRANSAC.m
+ * ============================================================================================ */
+
+enum { APS_TFORM_PROJECTIVE = 0 };
+
+/* a12 findInliers (estimateTransformationRANSAC.m:444-516) for T hypotheses at once.
+ *   Hs    : f64 3x3xT, each 3x3 column-major (MATLAB page layout)
+ *   p1,p2 : f64 Mx2 column-major with leading dimension ldp (x column then y column)
+ *   n_inl : int32[T]; mean_err: f64[T] (mean error over inliers, NaN if none);
+ *   mask  : uint8 MxT column-major (may be NULL).
+ * Projective: e = sqrt(|x2-Hx1|^2 + |x1-H^-1 x2|^2) < thr (:474-481); non-finite or |w|<eps -> inf
+ * (:499-503); >=4 inliers whose centred x1 have s2/s1 < 1e-3 -> all false (:506-513,:567). */
+int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double* p2, int64_t m,
+                     int64_t ldp, double thr, int tform_type, int32_t* n_inl, double* mean_err,
+                     uint8_t* mask);
+
+typedef struct aps_ransac_opts {
+    double max_distance; /* input.maxDistance        (inputs.m:69: 5.5)  */
+    double confidence;   /* input.inliersConfidence  (inputs.m:72: 99.9) */
+    int max_iter;        /* input.maxIter            (inputs.m:68: 500)  */
+    int tform_type;      /* APS_TFORM_PROJECTIVE                          */
+} aps_ransac_opts;
+
+/* a12 whole loop: [model, inliers, isFound] = estimateTransformationRANSAC(p1, p2, 'projective', input)
+ * (estimateTransformationRANSAC.m:54-183).  The random 4-subsets are an INPUT: sample_idx is
+ * uint32 4 x n_samples column-major, 1-based, one column per loop iteration (each iteration of
+ * :94-143 consumes one randperm draw, skipped ones included).  All hypotheses are fitted and scored
+ * on the device in one batch; the data-dependent best/early-exit logic (:115-130) is replayed on the
+ * host in order, so the result equals the sequential loop on the same draws.
+ * model: f64 3x3 column-major; inlier_mask: uint8[m]; is_found: 0/1; trials_used: loop iterations
+ * the sequential algorithm would have executed (may be NULL). */
+int aps_ransac_homography(const double* p1, const double* p2, int64_t m, int64_t ldp,
+                          const uint32_t* sample_idx, int n_samples, const aps_ransac_opts* opts,
+                          double* model, uint8_t* inlier_mask, int* is_found, int* trials_used);
+
+/* Batched a10/a11/a12: every candidate pair of imageMatching.m:121-156 in one device batch.
+ *   pts1/pts2 : f64, pair p's matched points are rows pair_ptr[p]..pair_ptr[p+1]-1 of two
+ *               (total x 2) column-major arrays with leading dimension ldp
+ *   sample_idx: uint32 4 x n_samples x n_pairs (1-based, local to the pair)
+ * Outputs per pair: models f64 3x3xP, mask uint8[total], found int32[P], n_inl int32[P]. */
+int aps_ransac_homography_batch(const double* pts1, const double* pts2, int64_t ldp,
+                                const int64_t* pair_ptr, int n_pairs, const uint32_t* sample_idx,
+                                int n_samples, const aps_ransac_opts* opts, double* models,
+                                uint8_t* mask, int32_t* found, int32_t* n_inl);
+
+/* ============================================================================================
+ * (3) Rendering — PP/renderPanorama/renderPanorama.m, PP/blending/ (both .m files), PP/imageProcessing/imageWarp.m
+ * ============================================================================================ */
+
+enum {
+    APS_PROJ_CYLINDRICAL = 0,
+    APS_PROJ_SPHERICAL = 1, /* 'equirectangular' is an alias (renderPanorama.m:180-189,357) */
+    APS_PROJ_PLANAR = 2,
+    APS_PROJ_STEREOGRAPHIC = 3
+};
+enum { APS_BLEND_NONE = 0, APS_BLEND_LINEAR = 1, APS_BLEND_MULTIBAND = 2 };
+enum { APS_NONE_LAST = 0, APS_NONE_FIRST = 1, APS_NONE_MAXANGLE = 2 };
+enum {
+    APS_IMG_U8_HWC = 0,   /* row-major interleaved H x W x C (numpy / torch)            */
+    APS_IMG_U8_MATLAB = 1 /* column-major planar H x W x C (MATLAB uint8 array)        */
+};
+
+/* One source image + its camera (cameras struct: initializeCameraMatrices.m:114-122). */
+typedef struct aps_image {
+    const uint8_t* data; /* uint8 pixels, host or device                                        */
+    int height, width, channels; /* channels: 1 or 3 (gray is replicated, loadImages.m:62)    */
+    int layout;          /* APS_IMG_U8_*                                                        */
+    double K[9];         /* 3x3 intrinsics, column-major                                        */
+    double R[9];         /* 3x3 world->camera rotation, column-major                            */
+    float gain[3];       /* per-channel gain (gainCompensationRKf output row; ones if off)      */
+} aps_image;
+
+/* Geometry of the panorama canvas: the values renderPanorama.m:125-232 derives on the host. */
+typedef struct aps_canvas {
+    int mode;            /* APS_PROJ_*                                                          */
+    int height, width;   /* H, W (:137-146,180-189)                                             */
+    double f_pan;        /* opts.fPan * opts.resScale enters only through these three:          */
+    double origin0;      /* th0 (cyl/sph) or u0 (planar/stereo)                                 */
+    double origin1;      /* h0 (cyl), ph0 (sph) or v0 (planar/stereo)                           */
+    double R_ref[9];     /* cameras(refIdx).R, column-major (planar/stereographic only)         */
+} aps_canvas;
+
+typedef struct aps_render_opts {
+    int tile_h, tile_w;    /* opts.tile — explicit, never derived from free memory */
+    float angle_power;     /* opts.anglePower (displayPanorama.m:101: 2)                        */
+    int blending;          /* APS_BLEND_*                                                       */
+    int pyr_levels;        /* opts.pyrLevels = input.bands                                      */
+    float pyr_sigma;       /* opts.pyrSigma  = input.MBBsigma                                   */
+    int none_policy;       /* opts.composeNonePolicy                                            */
+    int canvas_white;      /* opts.canvasColor == 'white'                                       */
+} aps_render_opts;
+
+/* a14-a17: the tile loop of renderPanorama.m:342-425 (ray generation, fuseTile, sampleOneTile,
+ * sampleBlock, warpWeights, void paint, uint8 conversion), all tiles, on the device.
+ *   pano    : uint8 H x W x 3 in `out_layout` (APS_IMG_U8_HWC or APS_IMG_U8_MATLAB)
+ *   covered : uint8 H x W (same 2-D layout), may be NULL. */
+int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
+               const aps_render_opts* opts, int out_layout, uint8_t* pano, uint8_t* covered);
+
+/* a15/a16 for ONE tile, layers out (for tests): rows r0..r0+ht-1, cols c0..c0+wt-1 (0-based) of
+ * the canvas sampled from ONE image.  S: f32 ht x wt x 3 row-major interleaved, Wang/Wf: f32 ht x wt,
+ * M: uint8 ht x wt (sampleOneTile, renderPanorama.m:1063-1146). */
+int aps_warp_tile(const aps_image* image, const aps_canvas* canvas, int r0, int c0, int ht, int wt,
+                  float angle_power, float* S, uint8_t* M, float* Wang, float* Wf);
+
+/* a21: F = multiBandBlending(Ci, Wi, levels, onGPU, sigma) (multiBandBlending.m:45-171).
+ *   C: f32 K x h x w x 3 (row-major interleaved per layer), Wt: f32 K x h x w, F: f32 h x w x 3. */
+int aps_multiband_blend(const float* C, const float* Wt, int k, int h, int w, int levels,
+                        float sigma, float* F);
+
+/* a22: linearBlending (linearBlending.m:46-115) on f32 layers: sum(I.*W)/max(sum(W),eps('single')). */
+int aps_linear_blend(const float* C, const float* Wt, int k, int h, int w, float* F);
+
+/* a19: warped = imageWarp(image, tform, outputView, 'bilinear') (imageWarp.m:39-168) for uint8 or
+ * f32 images: inverse homography warp onto an imref2d-like grid, valid only when all four taps are
+ * inside (:133), fill value elsewhere.
+ *   H: f64 3x3 column-major; x0,y0,sx,sy: outputView.XWorldLimits(1), YWorldLimits(1),
+ *   PixelExtentInWorldX/Y (:36-41).  in/out: row-major interleaved h x w x c. */
+int aps_image_warp_h_u8(const uint8_t* in, int in_h, int in_w, int c, const double* H, int out_h,
+                        int out_w, double x0, double y0, double sx, double sy, uint8_t fill,
+                        uint8_t* out);
+int aps_image_warp_h_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h,
+                         int out_w, double x0, double y0, double sx, double sy, float fill,
+                         float* out);
+
+/* ============================================================================================
+ * (4) SIFT — PP/featureMatching/getFeaturePoints.m:36-40,71-74
+ * ============================================================================================ */
+
+typedef struct aps_sift_params {
+    double sigma;              /* input.Sigma              (inputs.m:34: 1.6)     */
+    int n_layers;              /* input.NumLayersInOctave  (inputs.m:35: 4)       */
+    double contrast_threshold; /* input.ContrastThreshold  (inputs.m:36: 0.00133) */
+    double edge_threshold;     /* input.EdgeThreshold      (inputs.m:40: 6)       */
+    int max_features;          /* capacity guard; 0 = library default (262144)    */
+} aps_sift_params;
+
+/* a1: [features, validPts] = getFeaturePoints(input, img) for detector 'SIFT': rgb2gray, Lowe/OpenCV
+ * SIFT (detectSIFTFeatures + extractFeatures are closed toolbox code; the algorithm restated is
+ * OpenCV's cv::SIFT, which the toolbox is documented to wrap — see DESIGN.md "SIFT contract").
+ *   desc : f32 count x 128, `desc_layout` with leading dimension ldd, unit L2 norm
+ *   loc  : f64 count x 2 [x y], 1-based sub-pixel, column-major with leading dimension ldl
+ *   aux  : f32 count x 4 row-major [scale(size), angle_deg, response, octave_layer] or NULL
+ * cap = rows available in desc/loc/aux; *count = features found (APS_E_CAP if cap is too small).
+ * Feature order is canonical: ascending (octave, layer, row, col, orientation bin). */
+int aps_sift_extract(const uint8_t* img, int height, int width, int channels, int img_layout,
+                     const aps_sift_params* params, float* desc, int desc_layout, int64_t ldd,
+                     double* loc, int64_t ldl, float* aux, int64_t cap, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APS_H_ */

@@ -1,0 +1,129 @@
+"""GPU parity: the HIP matcher (through the C ABI) against the CPU oracle, bit for bit."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle
+from util import bits, planted_pair, sift_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(gpu):
+    return import_module(gpu.__name__ + ".featureMatching")
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 2), (2, 1), (3, 3), (33, 65), (257, 129), (128, 64), (1000, 4096),
+                                   (4096, 1000)])
+def test_2nn_bit_exact(fm, n1, n2):
+    rng = np.random.default_rng(100 + n1 + n2)
+    a, b, _, _ = planted_pair(rng, n1, n2, min(n1, n2) // 2)
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(bits(d1), bits(o1))
+    assert np.array_equal(bits(d2), bits(o2))
+
+
+def test_2nn_ties_first_index_and_duplicates(fm):
+    rng = np.random.default_rng(7)
+    b = sift_like(rng, 300)
+    b[250] = b[17]
+    b[40] = b[17]
+    a = np.concatenate([b[[17, 40, 250]], sift_like(rng, 61)])
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert idx[:3].tolist() == [18, 18, 18]
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+
+
+def test_2nn_column_major_input_is_identical(fm):
+    rng = np.random.default_rng(8)
+    a, b, _, _ = planted_pair(rng, 200, 333, 100)
+    r = fm.nearest2SSDExhaustive(a, b)
+    c = fm.nearest2SSDExhaustive(np.asfortranarray(a), np.asfortranarray(b))
+    for x, y in zip(r[1:], c[1:]):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+@pytest.mark.parametrize("unit", [True, False])
+@pytest.mark.parametrize("unique", [True, False])
+def test_match_features_equals_oracle(fm, unit, unique):
+    rng = np.random.default_rng(11)
+    a, b, ia, ib = planted_pair(rng, 1500, 1700, 600, noise=0.03, unit=unit)
+    m, met = fm.matchFeaturesScratch(a, b, Method="Exhaustive", MatchThreshold=1.5, MaxRatio=0.6,
+                                     Unique=unique)
+    om, omet = oracle.match_features(a, b, 0.6, 1.5, unique, 2)
+    assert len(om) > 300
+    assert np.array_equal(m, om)
+    assert np.array_equal(bits(met), bits(omet))
+
+
+def test_unique_resolves_collisions_like_the_greedy_loop(fm):
+    """Many A rows competing for few B rows: the atomicMin formulation must equal the sequential greedy."""
+    rng = np.random.default_rng(12)
+    b = sift_like(rng, 40)
+    src = rng.integers(0, 8, size=500)
+    a = b[src] + 0.01 * rng.standard_normal((500, 128)).astype(np.float32)
+    a = np.maximum(a, 0).astype(np.float32)
+    m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=10.0, MaxRatio=0.9, Unique=True)
+    om, omet = oracle.match_features(a, b, 0.9, 10.0, True, 2)
+    assert 1 <= len(om) <= 8
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
+def test_pairwise_cells_equal_per_pair_oracle(fm):
+    rng = np.random.default_rng(13)
+    base = sift_like(rng, 900)
+    descs = []
+    for i in range(5):
+        keep = rng.permutation(900)[: 500 + 37 * i]
+        d = base[keep] + 0.02 * rng.standard_normal((len(keep), 128)).astype(np.float32)
+        d = np.maximum(d, 0)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        descs.append(d.astype(np.float32))
+    inp = {"Matchingthreshold": 1.5, "Ratiothreshold": 0.6}
+    cells = fm.featureMatchingPairwise(inp, descs, 5)
+    total = 0
+    for i in range(5):
+        for j in range(5):
+            if i < j:
+                om, _ = oracle.match_features(descs[i], descs[j], 0.6, 1.5, True, 2)
+                assert np.array_equal(cells[i][j], om.astype(np.float64)), (i, j)
+                assert cells[i][j].dtype == np.float64
+                total += len(om)
+            else:
+                assert cells[i][j] is None
+    assert total > 500
+
+
+def test_pairwise_with_empty_image(fm):
+    rng = np.random.default_rng(14)
+    descs = [sift_like(rng, 100), np.zeros((0, 128), np.float32), sift_like(rng, 80)]
+    cells = fm.featureMatchingPairwise({"Matchingthreshold": 10.0, "Ratiothreshold": 0.9}, descs, 3)
+    assert cells[0][1].shape == (0, 2) and cells[1][2].shape == (0, 2)
+    om, _ = oracle.match_features(descs[0], descs[2], 0.9, 10.0, True, 2)
+    assert np.array_equal(cells[0][2], om.astype(np.float64))
+
+
+def test_torch_device_tensors_are_accepted(fm):
+    import torch
+
+    rng = np.random.default_rng(15)
+    a, b, _, _ = planted_pair(rng, 700, 900, 300)
+    m, met = fm.matchFeaturesScratch(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(),
+                                     MatchThreshold=1.5, MaxRatio=0.6)
+    om, omet = oracle.match_features(a, b, 0.6, 1.5, True, 2)
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
+def test_argument_errors(fm, gpu):
+    a = np.zeros((4, 64), np.float32)
+    with pytest.raises((gpu.ApsError, ValueError)):
+        fm.matchFeaturesScratch(a, a)
+    with pytest.raises(ValueError):
+        fm.matchFeaturesScratch(np.zeros((0, 128), np.float32), np.zeros((3, 128), np.float32))
+    with pytest.raises(ValueError):
+        fm.matchFeaturesScratch(np.zeros((3, 128), np.float32), np.zeros((3, 128), np.float32), MaxRatio=1.5)
