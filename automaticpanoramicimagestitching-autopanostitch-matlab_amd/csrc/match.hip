@@ -72,7 +72,8 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
 #pragma unroll
         for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
         // n = sqrt(sum(X.^2,2)) + eps('single'); Xn = X ./ n   (matchFeaturesScratch.m:232-233)
-        const float nrm = __fadd_rn(__fsqrt_rn(s), 1.1920928955078125e-07f);
+        // NB: sqrtf is correctly rounded on gfx950/ROCm 7.2; __fsqrt_rn is NOT (scripts/probe/fpcheck.hip)
+        const float nrm = __fadd_rn(sqrtf(s), 1.1920928955078125e-07f);
 #pragma unroll
         for (int k = 0; k < kDim; ++k) x[k] = __fdiv_rn(x[k], nrm);
     }

@@ -1,0 +1,693 @@
+// ransac.hip — batched projective RANSAC on gfx950 (f64).
+//
+// Restates PP/imageMatching/estimateTransformationRANSAC.m:54-183 (loop), :188-225 (normalised DLT),
+// :444-516 (findInliers), :518-535 (checkModel), :537-574 (isDegenerate), :579-610 (normalizePoints)
+// for transformType 'projective', batched over the candidate image pairs of
+// PP/imageMatching/imageMatching.m:121-156.
+//
+// Shape of the computation (why it is batched this way):
+//   fit kernel    : one lane per (pair, draw): 4-point normalised DLT.  The right null vector of the
+//                   8x9 system is the smallest eigenvector of the 9x9 Gram matrix (cyclic Jacobi); the
+//                   two 9x9 work matrices of every lane live in LDS as [element][lane].
+//   score kernel  : one 64-lane wave per (pair, draw): lanes stride over the pair's matches, symmetric
+//                   transfer error in f64, inlier count / error sum / centroid by wavefront butterfly
+//                   reductions, then the collinearity (degeneracy) test on the inliers.
+//   replay (host) : the data-dependent part of the loop — best-so-far update and the adaptive shrink of
+//                   maxTrials (:115-130) — is replayed sequentially over the pre-scored draws, which is
+//                   exactly the sequential algorithm on the same draws.
+//   finalize      : one wave per pair: inlier mask of the winning draw, refit on all inliers (:146-150),
+//                   re-score, fallback rules (:153-176).
+// All reductions use one fixed order (lane-strided partial sums + xor butterfly) that the oracle
+// restates, so inlier masks compare bit-exactly.  f64 only; no contraction (-ffp-contract=off).
+#include <cmath>
+#include <vector>
+
+#include "aps_internal.h"
+
+namespace aps {
+
+constexpr double kDblEps = 2.220446049250313e-16;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+
+struct Mat3 {
+    double m[9];  // column-major: m[r + 3c]
+};
+#define M3(H, r, c) (H).m[(r) + 3 * (c)]
+
+__device__ __forceinline__ Mat3 adjugate3(const Mat3& H) {
+    Mat3 A;
+    M3(A, 0, 0) = M3(H, 1, 1) * M3(H, 2, 2) - M3(H, 1, 2) * M3(H, 2, 1);
+    M3(A, 0, 1) = M3(H, 0, 2) * M3(H, 2, 1) - M3(H, 0, 1) * M3(H, 2, 2);
+    M3(A, 0, 2) = M3(H, 0, 1) * M3(H, 1, 2) - M3(H, 0, 2) * M3(H, 1, 1);
+    M3(A, 1, 0) = M3(H, 1, 2) * M3(H, 2, 0) - M3(H, 1, 0) * M3(H, 2, 2);
+    M3(A, 1, 1) = M3(H, 0, 0) * M3(H, 2, 2) - M3(H, 0, 2) * M3(H, 2, 0);
+    M3(A, 1, 2) = M3(H, 0, 2) * M3(H, 1, 0) - M3(H, 0, 0) * M3(H, 1, 2);
+    M3(A, 2, 0) = M3(H, 1, 0) * M3(H, 2, 1) - M3(H, 1, 1) * M3(H, 2, 0);
+    M3(A, 2, 1) = M3(H, 0, 1) * M3(H, 2, 0) - M3(H, 0, 0) * M3(H, 2, 1);
+    M3(A, 2, 2) = M3(H, 0, 0) * M3(H, 1, 1) - M3(H, 0, 1) * M3(H, 1, 0);
+    return A;
+}
+
+__device__ __forceinline__ double det3(const Mat3& H) {
+    const double c0 = M3(H, 1, 1) * M3(H, 2, 2) - M3(H, 1, 2) * M3(H, 2, 1);
+    const double c1 = M3(H, 1, 0) * M3(H, 2, 2) - M3(H, 1, 2) * M3(H, 2, 0);
+    const double c2 = M3(H, 1, 0) * M3(H, 2, 1) - M3(H, 1, 1) * M3(H, 2, 0);
+    return (M3(H, 0, 0) * c0 - M3(H, 0, 1) * c1) + M3(H, 0, 2) * c2;
+}
+
+__device__ __forceinline__ double norm1_3(const Mat3& H) {
+    double m = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double s = (fabs(M3(H, 0, c)) + fabs(M3(H, 1, c))) + fabs(M3(H, 2, c));
+        if (s > m) m = s;
+    }
+    return m;
+}
+
+// checkModel (estimateTransformationRANSAC.m:518-535)
+__device__ __forceinline__ bool check_model(const Mat3& H) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    const double d = det3(H);
+    if (!(fabs(d) > kDblEps)) return false;
+    const Mat3 A = adjugate3(H);
+    Mat3 I;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) I.m[e] = A.m[e] / d;
+    const double rc = 1.0 / (norm1_3(H) * norm1_3(I));
+    return rc > kDblEps;
+}
+
+// LDS work matrices: element e of lane l at [e*64 + l]
+#define GE(p, q) sG[((p) * 9 + (q)) * 64 + lane]
+#define VE(p, q) sV[((p) * 9 + (q)) * 64 + lane]
+
+// Cyclic Jacobi on the symmetric 9x9 in GE; eigenvectors in the columns of VE.
+__device__ void jacobi9(double* sG, double* sV, int lane) {
+    for (int p = 0; p < 9; ++p)
+        for (int q = 0; q < 9; ++q) VE(p, q) = (p == q) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double gpq = GE(p, q);
+                const double gpp = GE(p, p), gqq = GE(q, q);
+                if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;
+                rotated = true;
+                const double theta = (gqq - gpp) / (2.0 * gpq);
+                const double t =
+                    (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    if (k == p || k == q) continue;
+                    const double gkp = GE(k, p), gkq = GE(k, q);
+                    const double np_ = c * gkp - s * gkq;
+                    const double nq_ = s * gkp + c * gkq;
+                    GE(k, p) = np_;
+                    GE(p, k) = np_;
+                    GE(k, q) = nq_;
+                    GE(q, k) = nq_;
+                }
+                GE(p, p) = gpp - t * gpq;
+                GE(q, q) = gqq + t * gpq;
+                GE(p, q) = 0.0;
+                GE(q, p) = 0.0;
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = VE(k, p), vkq = VE(k, q);
+                    VE(k, p) = c * vkp - s * vkq;
+                    VE(k, q) = s * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+struct Norm {
+    double s, tx, ty;
+};
+
+// Row `half` (0: x-row, 1: y-row) of the DLT matrix for one normalised correspondence (:209-212)
+__device__ __forceinline__ double dlt_entry(int k, int half, double x, double y, double u, double v) {
+    const double w = half ? v : u;
+    if (k >= 6) return k == 6 ? x * w : (k == 7 ? y * w : w);
+    const int kk = half ? k - 3 : k;
+    if (kk < 0 || kk > 2) return 0.0;
+    return kk == 0 ? -x : (kk == 1 ? -y : -1.0);
+}
+
+// From the filled Gram matrix to the denormalised H (:214-224).  Returns false if not finite.
+__device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, const Norm& n2, Mat3& H) {
+    for (int p = 0; p < 9; ++p)
+        for (int q = 0; q < p; ++q) GE(p, q) = GE(q, p);
+    jacobi9(sG, sV, lane);
+    int kmin = 0;
+    for (int k = 1; k < 9; ++k)
+        if (GE(k, k) < GE(kmin, kmin)) kmin = k;
+    double h[9];
+    for (int k = 0; k < 9; ++k) h[k] = VE(k, kmin);
+    Mat3 Hn, M;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M3(Hn, r, c) = h[3 * r + c] / h[8];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = M3(Hn, 2, c);
+        M3(M, 2, c) = m2;
+        M3(M, 1, c) = (M3(Hn, 1, c) - n2.ty * m2) / n2.s;
+        M3(M, 0, c) = (M3(Hn, 0, c) - n2.tx * m2) / n2.s;
+    }
+    for (int r = 0; r < 3; ++r) {
+        M3(H, r, 0) = M3(M, r, 0) * n1.s;
+        M3(H, r, 1) = M3(M, r, 1) * n1.s;
+        M3(H, r, 2) = (M3(M, r, 0) * n1.tx + M3(M, r, 1) * n1.ty) + M3(M, r, 2);
+    }
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fit kernel: one lane per (pair, draw)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict__ pts1,
+                                                         const double* __restrict__ pts2,
+                                                         int64_t ldp,
+                                                         const int64_t* __restrict__ pair_ptr,
+                                                         int n_pairs,
+                                                         const uint32_t* __restrict__ sample_idx,
+                                                         int n_samples, double* __restrict__ Hs,
+                                                         uint8_t* __restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) double lds_fit[];
+    double* sG = lds_fit;
+    double* sV = lds_fit + 81 * 64;
+    const int lane = threadIdx.x;
+    const int64_t gid = blockIdx.x * (int64_t)64 + lane;
+    const int64_t total = (int64_t)n_pairs * n_samples;
+    if (gid >= total) return;  // no barriers below: every lane works on its own LDS column
+    const int p = (int)(gid / n_samples);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    double x1[4], y1[4], x2[4], y2[4];
+    bool ok = m >= 4;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t id = sample_idx[gid * 4 + k];
+        if (id < 1 || (int64_t)id > m) ok = false;
+        const int64_t row = r0 + (ok ? (int64_t)id - 1 : 0);
+        x1[k] = ok ? pts1[row] : 0.0;
+        y1[k] = ok ? pts1[ldp + row] : 0.0;
+        x2[k] = ok ? pts2[row] : 0.0;
+        y2[k] = ok ? pts2[ldp + row] : 0.0;
+    }
+    Mat3 H;
+    for (int e = 0; e < 9; ++e) H.m[e] = 0.0;
+    if (ok) {
+        // normalizePoints (:579-610), sums in index order
+        Norm n1, n2;
+        {
+            double sx = 0, sy = 0;
+            for (int k = 0; k < 4; ++k) {
+                sx = sx + x1[k];
+                sy = sy + y1[k];
+            }
+            const double cx = sx / 4.0, cy = sy / 4.0;
+            double sd = 0;
+            for (int k = 0; k < 4; ++k) {
+                const double dx = x1[k] - cx, dy = y1[k] - cy;
+                sd = sd + sqrt(dx * dx + dy * dy);
+            }
+            n1.s = 1.0 / (sd / 4.0);
+            n1.tx = -n1.s * cx;
+            n1.ty = -n1.s * cy;
+        }
+        {
+            double sx = 0, sy = 0;
+            for (int k = 0; k < 4; ++k) {
+                sx = sx + x2[k];
+                sy = sy + y2[k];
+            }
+            const double cx = sx / 4.0, cy = sy / 4.0;
+            double sd = 0;
+            for (int k = 0; k < 4; ++k) {
+                const double dx = x2[k] - cx, dy = y2[k] - cy;
+                sd = sd + sqrt(dx * dx + dy * dy);
+            }
+            n2.s = 1.0 / (sd / 4.0);
+            n2.tx = -n2.s * cx;
+            n2.ty = -n2.s * cy;
+        }
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b) GE(a, b) = 0.0;
+        for (int half = 0; half < 2; ++half)
+            for (int k = 0; k < 4; ++k) {
+                const double x = n1.s * x1[k] + n1.tx, y = n1.s * y1[k] + n1.ty;
+                const double u = n2.s * x2[k] + n2.tx, v = n2.s * y2[k] + n2.ty;
+                double a[9];
+                for (int e = 0; e < 9; ++e) a[e] = dlt_entry(e, half, x, y, u, v);
+                for (int pp = 0; pp < 9; ++pp)
+                    for (int qq = pp; qq < 9; ++qq) GE(pp, qq) = GE(pp, qq) + a[pp] * a[qq];
+            }
+        ok = gram_to_h(sG, sV, lane, n1, n2, H) && check_model(H);
+    }
+    for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
+    valid[gid] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-collective findInliers (:444-516)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double transfer_error(const Mat3& H, const Mat3& A, double x1, double y1,
+                                                 double x2, double y2) {
+    const double X = (M3(H, 0, 0) * x1 + M3(H, 0, 1) * y1) + M3(H, 0, 2);
+    const double Y = (M3(H, 1, 0) * x1 + M3(H, 1, 1) * y1) + M3(H, 1, 2);
+    const double W = (M3(H, 2, 0) * x1 + M3(H, 2, 1) * y1) + M3(H, 2, 2);
+    const double tx = X / W, ty = Y / W;
+    const double IX = (A.m[0] * x2 + A.m[3] * y2) + A.m[6];
+    const double IY = (A.m[1] * x2 + A.m[4] * y2) + A.m[7];
+    const double IW = (A.m[2] * x2 + A.m[5] * y2) + A.m[8];
+    const double ix = IX / IW, iy = IY / IW;
+    const double ex = x2 - tx, ey = y2 - ty, fx = x1 - ix, fy = y1 - iy;
+    const double d1 = ex * ex + ey * ey;
+    const double d2 = fx * fx + fy * fy;
+    double e = sqrt(d1 + d2);
+    if (!isfinite(e)) e = INFINITY;
+    if (fabs(W) < kDblEps) e = INFINITY;
+    return e;
+}
+
+// All 64 lanes of a wave call this with the same arguments.  mask (may be NULL) receives 0/1 per match.
+__device__ int wave_find_inliers(const Mat3& H, const double* __restrict__ x1,
+                                 const double* __restrict__ y1, const double* __restrict__ x2,
+                                 const double* __restrict__ y2, int64_t m, double thr,
+                                 uint8_t* __restrict__ mask, double* mean_err) {
+    const int lane = threadIdx.x & 63;
+    const Mat3 A = adjugate3(H);
+    double pc = 0, pe = 0, px = 0, py = 0;
+    for (int64_t i = lane; i < m; i += 64) {
+        const double e = transfer_error(H, A, x1[i], y1[i], x2[i], y2[i]);
+        const bool in = e < thr;
+        if (mask) mask[i] = in ? 1 : 0;
+        if (in) {
+            pc += 1.0;
+            pe = pe + e;
+            px = px + x1[i];
+            py = py + y1[i];
+        }
+    }
+    const double cnt = wave_sum(pc);
+    const double se = wave_sum(pe), sx = wave_sum(px), sy = wave_sum(py);
+    const int n = (int)cnt;
+    if (n >= 4) {  // isDegenerate on pts1(inliers) (:506-513, :537-574)
+        const double mx = sx / cnt, my = sy / cnt;
+        double pxx = 0, pxy = 0, pyy = 0;
+        for (int64_t i = lane; i < m; i += 64) {
+            const double e = transfer_error(H, A, x1[i], y1[i], x2[i], y2[i]);
+            if (e < thr) {
+                const double dx = x1[i] - mx, dy = y1[i] - my;
+                pxx = pxx + dx * dx;
+                pxy = pxy + dx * dy;
+                pyy = pyy + dy * dy;
+            }
+        }
+        const double sxx = wave_sum(pxx), sxy = wave_sum(pxy), syy = wave_sum(pyy);
+        const double hs = 0.5 * (sxx + syy), hd = 0.5 * (sxx - syy);
+        const double r = sqrt(hd * hd + sxy * sxy);
+        const double l1 = hs + r;
+        double l2 = hs - r;
+        if (l2 < 0) l2 = 0;
+        const double s1 = sqrt(l1), s2 = sqrt(l2);
+        if (s2 / s1 < 1e-3) {
+            if (mask)
+                for (int64_t i = lane; i < m; i += 64) mask[i] = 0;
+            *mean_err = NAN;
+            return 0;
+        }
+    }
+    *mean_err = n > 0 ? se / cnt : NAN;
+    return n;
+}
+
+// one wave per (pair, draw); 4 waves per block
+__global__ __launch_bounds__(256) void ransac_score_kernel(
+    const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
+    const int64_t* __restrict__ pair_ptr, int n_pairs, int n_samples, const double* __restrict__ Hs,
+    const uint8_t* __restrict__ valid, double thr, int32_t* __restrict__ n_inl,
+    double* __restrict__ mean_err) {
+    const int64_t gid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (gid >= (int64_t)n_pairs * n_samples) return;
+    const int lane = threadIdx.x & 63;
+    if (!valid[gid]) {
+        if (lane == 0) {
+            n_inl[gid] = 0;
+            mean_err[gid] = NAN;
+        }
+        return;
+    }
+    const int p = (int)(gid / n_samples);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = Hs[gid * 9 + e];
+    double me;
+    const int n = wave_find_inliers(H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr,
+                                    nullptr, &me);
+    if (lane == 0) {
+        n_inl[gid] = n;
+        mean_err[gid] = me;
+    }
+}
+
+// explicit-hypothesis scoring for aps_ransac_score: one wave per hypothesis, optional masks
+__global__ __launch_bounds__(256) void ransac_score_explicit_kernel(
+    const double* __restrict__ p1, const double* __restrict__ p2, int64_t ldp, int64_t m,
+    const double* __restrict__ Hs, int n_hyp, double thr, int32_t* __restrict__ n_inl,
+    double* __restrict__ mean_err, uint8_t* __restrict__ mask) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_hyp) return;
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = Hs[(int64_t)t * 9 + e];
+    double me;
+    const int n = wave_find_inliers(H, p1, p1 + ldp, p2, p2 + ldp, m, thr,
+                                    mask ? mask + (int64_t)t * m : nullptr, &me);
+    if ((threadIdx.x & 63) == 0) {
+        n_inl[t] = n;
+        mean_err[t] = me;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: one wave per pair (:146-181)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ransac_finalize_kernel(
+    const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
+    const int64_t* __restrict__ pair_ptr, int n_samples, const double* __restrict__ Hs,
+    const int32_t* __restrict__ best_it, double thr, double* __restrict__ models,
+    uint8_t* __restrict__ mask, uint8_t* __restrict__ scratch_mask, int32_t* __restrict__ found,
+    int32_t* __restrict__ n_final) {
+    extern __shared__ __attribute__((aligned(16))) double lds_fin[];
+    double* sG = lds_fin;
+    double* sV = lds_fin + 81 * 64;
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    const double *x1 = pts1 + r0, *y1 = pts1 + ldp + r0, *x2 = pts2 + r0, *y2 = pts2 + ldp + r0;
+    uint8_t* out_mask = mask + r0;
+    uint8_t* tmp_mask = scratch_mask + r0;
+    const int bi = best_it[p];
+    if (bi < 0) {
+        for (int64_t i = lane; i < m; i += 64) out_mask[i] = 0;
+        if (lane < 9) models[(int64_t)p * 9 + lane] = NAN;
+        if (lane == 0) {
+            found[p] = 0;
+            n_final[p] = 0;
+        }
+        return;
+    }
+    Mat3 Hb;
+    for (int e = 0; e < 9; ++e) Hb.m[e] = Hs[((int64_t)p * n_samples + bi) * 9 + e];
+    double me;
+    const int nb = wave_find_inliers(Hb, x1, y1, x2, y2, m, thr, out_mask, &me);
+    __threadfence_block();
+    // refit on the inliers: sums in ascending index order, identical in every lane (uniform branches)
+    Norm n1, n2;
+    {
+        double sx = 0, sy = 0, ux = 0, uy = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (out_mask[i]) {
+                sx = sx + x1[i];
+                sy = sy + y1[i];
+                ux = ux + x2[i];
+                uy = uy + y2[i];
+            }
+        const double dn = (double)nb;
+        const double cx = sx / dn, cy = sy / dn, dx2 = ux / dn, dy2 = uy / dn;
+        double sd = 0, ud = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (out_mask[i]) {
+                const double ax = x1[i] - cx, ay = y1[i] - cy;
+                sd = sd + sqrt(ax * ax + ay * ay);
+                const double bx = x2[i] - dx2, by = y2[i] - dy2;
+                ud = ud + sqrt(bx * bx + by * by);
+            }
+        n1.s = 1.0 / (sd / dn);
+        n1.tx = -n1.s * cx;
+        n1.ty = -n1.s * cy;
+        n2.s = 1.0 / (ud / dn);
+        n2.tx = -n2.s * dx2;
+        n2.ty = -n2.s * dy2;
+    }
+    // Gram matrix: lane e < 45 owns the upper-triangular entry (pp,qq); rows in the reference's order
+    int pp = 0, qq = 0;
+    {
+        int e = lane < 45 ? lane : 0, row = 0;
+        while (e >= 9 - row) {
+            e -= 9 - row;
+            ++row;
+        }
+        pp = row;
+        qq = row + e;
+    }
+    double g = 0;
+    for (int half = 0; half < 2; ++half)
+        for (int64_t i = 0; i < m; ++i)
+            if (out_mask[i]) {
+                const double x = n1.s * x1[i] + n1.tx, y = n1.s * y1[i] + n1.ty;
+                const double u = n2.s * x2[i] + n2.tx, v = n2.s * y2[i] + n2.ty;
+                g = g + dlt_entry(pp, half, x, y, u, v) * dlt_entry(qq, half, x, y, u, v);
+            }
+    if (lane < 45) sG[(pp * 9 + qq) * 64 + 0] = g;  // lane 0's column of the work matrix
+    __syncthreads();
+    Mat3 Hr;
+    int ok = 0;
+    if (lane == 0) {
+        ok = gram_to_h(sG, sV, 0, n1, n2, Hr) && check_model(Hr) ? 1 : 0;
+        for (int e = 0; e < 9; ++e) sV[e * 64 + 1] = Hr.m[e];  // broadcast through a free LDS column
+        sV[9 * 64 + 1] = (double)ok;
+    }
+    __syncthreads();
+    for (int e = 0; e < 9; ++e) Hr.m[e] = sV[e * 64 + 1];
+    ok = sV[9 * 64 + 1] != 0.0;
+    bool use_refit = false;
+    int nr = 0;
+    if (ok) {
+        nr = wave_find_inliers(Hr, x1, y1, x2, y2, m, thr, tmp_mask, &me);
+        use_refit = nr >= 4;
+    }
+    if (use_refit) {
+        __threadfence_block();
+        for (int64_t i = lane; i < m; i += 64) out_mask[i] = tmp_mask[i];
+    }
+    if (lane < 9) models[(int64_t)p * 9 + lane] = use_refit ? Hr.m[lane] : Hb.m[lane];
+    if (lane == 0) {
+        found[p] = 1;
+        n_final[p] = use_refit ? nr : nb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void check_opts(const aps_ransac_opts& o) {
+    APS_REQUIRE(o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
+                "only transformationType 'projective' is built (inputs.m:74)");
+    APS_REQUIRE(o.max_iter > 0, APS_E_ARG, "maxIter must be positive");
+    APS_REQUIRE(o.max_distance > 0, APS_E_ARG, "maxDistance must be positive");
+    APS_REQUIRE(o.confidence > 0 && o.confidence < 100, APS_E_ARG, "inliersConfidence must be in (0,100)");
+}
+
+// The sequential part of the loop (:94-143) over pre-scored draws.  Returns the winning draw or -1.
+static int replay_loop(const uint8_t* valid, const int32_t* n_inl, const double* mean_err,
+                       int n_samples, int64_t m, const aps_ransac_opts& o, int* trials_used) {
+    const int min_pts = 4;
+    int max_trials = o.max_iter;
+    const int max_skip = o.max_iter * 10;
+    int trial = 1, skip = 0, it = 0, best_n = 0, best_it = -1;
+    double best_err = INFINITY;
+    if (m < min_pts) {
+        if (trials_used) *trials_used = 0;
+        return -1;
+    }
+    while (trial <= max_trials && skip < max_skip && it < n_samples) {
+        const int cur = it++;
+        if (!valid[cur]) {
+            ++skip;
+            continue;
+        }
+        const int n = n_inl[cur];
+        if (n >= min_pts) {
+            const double me = mean_err[cur];
+            if (n > best_n || (n == best_n && me < best_err)) {
+                best_n = n;
+                best_err = me;
+                best_it = cur;
+                const double ratio = (double)n / (double)m;
+                if (ratio > 0) {
+                    const double need = std::ceil(std::log(1 - o.confidence / 100) /
+                                                  std::log(1 - std::pow(ratio, min_pts)));
+                    if (need < (double)max_trials) max_trials = (int)need;
+                }
+            }
+        }
+        ++trial;
+    }
+    if (trials_used) *trials_used = it;
+    return best_it;
+}
+
+static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
+                         const std::vector<int64_t>& h_ptr, const uint32_t* d_samples, int n_samples,
+                         const aps_ransac_opts& o, double* d_models, uint8_t* d_mask, int32_t* d_found,
+                         int32_t* d_ninl, std::vector<int>* trials_out) {
+    const int n_pairs = (int)h_ptr.size() - 1;
+    if (n_pairs <= 0) return;
+    const int64_t total_rows = h_ptr.back();
+    const int64_t nh = (int64_t)n_pairs * n_samples;
+    Ws<int64_t> d_ptr(n_pairs + 1);
+    APS_HIP(hipMemcpyAsync(d_ptr, h_ptr.data(), (n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                           stream()));
+    Ws<double> Hs(nh * 9), merr(nh);
+    Ws<uint8_t> valid(nh), scratch(std::max<int64_t>(total_rows, 1));
+    Ws<int32_t> ninl(nh), best(n_pairs);
+    const size_t lds_bytes = 2 * 81 * 64 * sizeof(double);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        APS_HIP(hipFuncSetAttribute((const void*)ransac_fit_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        APS_HIP(hipFuncSetAttribute((const void*)ransac_finalize_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    ransac_fit_kernel<<<cdiv(nh, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs,
+                                                                  d_samples, n_samples, Hs, valid);
+    check_launch("ransac_fit_kernel");
+    ransac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples,
+                                                            Hs, valid, o.max_distance, ninl, merr);
+    check_launch("ransac_score_kernel");
+    std::vector<uint8_t> h_valid(nh);
+    std::vector<int32_t> h_ninl(nh), h_best(n_pairs);
+    std::vector<double> h_merr(nh);
+    APS_HIP(hipMemcpyAsync(h_valid.data(), valid, nh, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipMemcpyAsync(h_ninl.data(), ninl, nh * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipMemcpyAsync(h_merr.data(), merr, nh * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    if (trials_out) trials_out->assign(n_pairs, 0);
+    for (int p = 0; p < n_pairs; ++p) {
+        int used = 0;
+        h_best[p] = replay_loop(h_valid.data() + (int64_t)p * n_samples,
+                                h_ninl.data() + (int64_t)p * n_samples,
+                                h_merr.data() + (int64_t)p * n_samples, n_samples,
+                                h_ptr[p + 1] - h_ptr[p], o, &used);
+        if (trials_out) (*trials_out)[p] = used;
+    }
+    APS_HIP(hipMemcpyAsync(best, h_best.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice,
+                           stream()));
+    ransac_finalize_kernel<<<n_pairs, 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
+                                                                  best, o.max_distance, d_models,
+                                                                  d_mask, scratch, d_found, d_ninl);
+    check_launch("ransac_finalize_kernel");
+    APS_HIP(hipStreamSynchronize(stream()));
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double* p2, int64_t m,
+                     int64_t ldp, double thr, int tform_type, int32_t* n_inl, double* mean_err,
+                     uint8_t* mask) {
+    return guarded([&] {
+        APS_REQUIRE(tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE, "only 'projective' is built");
+        APS_REQUIRE(n_hyp >= 0 && m >= 0, APS_E_ARG, "negative size");
+        APS_REQUIRE(ldp >= m, APS_E_DIM, "ldp < m");
+        APS_REQUIRE(n_hyp == 0 || (Hs && n_inl && mean_err), APS_E_ARG, "NULL argument");
+        APS_REQUIRE(m == 0 || (p1 && p2), APS_E_ARG, "NULL points");
+        ctx();
+        if (n_hyp == 0) return;
+        In<double> dH(Hs, (size_t)n_hyp * 9), d1(p1, (size_t)ldp + m), d2(p2, (size_t)ldp + m);
+        Out<int32_t> on(n_inl, n_hyp);
+        Out<double> oe(mean_err, n_hyp);
+        Out<uint8_t> om(mask, (size_t)n_hyp * m);
+        ransac_score_explicit_kernel<<<cdiv(n_hyp, 4), 256, 0, stream()>>>(
+            d1, d2, ldp, m, dH, n_hyp, thr, on, oe, om.present() ? om.get() : nullptr);
+        check_launch("ransac_score_explicit_kernel");
+        on.commit();
+        oe.commit();
+        om.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_ransac_homography_batch(const double* pts1, const double* pts2, int64_t ldp,
+                                const int64_t* pair_ptr, int n_pairs, const uint32_t* sample_idx,
+                                int n_samples, const aps_ransac_opts* opts, double* models,
+                                uint8_t* mask, int32_t* found, int32_t* n_inl) {
+    return guarded([&] {
+        APS_REQUIRE(opts != nullptr, APS_E_ARG, "opts is NULL");
+        check_opts(*opts);
+        APS_REQUIRE(n_pairs >= 0 && n_samples > 0, APS_E_ARG, "bad n_pairs/n_samples");
+        if (n_pairs == 0) return;
+        APS_REQUIRE(pair_ptr && sample_idx && models && found && n_inl, APS_E_ARG, "NULL argument");
+        ctx();
+        std::vector<int64_t> h_ptr(n_pairs + 1);
+        if (is_device_ptr(pair_ptr))
+            APS_HIP(hipMemcpy(h_ptr.data(), pair_ptr, (n_pairs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        else
+            std::copy(pair_ptr, pair_ptr + n_pairs + 1, h_ptr.begin());
+        APS_REQUIRE(h_ptr[0] == 0, APS_E_ARG, "pair_ptr[0] must be 0");
+        for (int p = 0; p < n_pairs; ++p)
+            APS_REQUIRE(h_ptr[p + 1] >= h_ptr[p], APS_E_ARG, "pair_ptr must be non-decreasing");
+        const int64_t total = h_ptr.back();
+        APS_REQUIRE(ldp >= total, APS_E_DIM, "ldp < total rows");
+        APS_REQUIRE(total == 0 || (pts1 && pts2 && mask), APS_E_ARG, "NULL points/mask");
+        In<double> d1(pts1, (size_t)ldp + total), d2(pts2, (size_t)ldp + total);
+        In<uint32_t> ds(sample_idx, (size_t)4 * n_samples * n_pairs);
+        Out<double> om(models, (size_t)n_pairs * 9);
+        Out<uint8_t> omask(mask, (size_t)std::max<int64_t>(total, 1));
+        Out<int32_t> of(found, n_pairs), on(n_inl, n_pairs);
+        ransac_batch(d1, d2, ldp, h_ptr, ds, n_samples, *opts, om, omask, of, on, nullptr);
+        om.commit();
+        omask.commit(total);
+        of.commit();
+        on.commit();
+    });
+}
+
+int aps_ransac_homography(const double* p1, const double* p2, int64_t m, int64_t ldp,
+                          const uint32_t* sample_idx, int n_samples, const aps_ransac_opts* opts,
+                          double* model, uint8_t* inlier_mask, int* is_found, int* trials_used) {
+    return guarded([&] {
+        APS_REQUIRE(opts != nullptr, APS_E_ARG, "opts is NULL");
+        check_opts(*opts);
+        APS_REQUIRE(m >= 0 && n_samples > 0, APS_E_ARG, "bad m/n_samples");
+        APS_REQUIRE(ldp >= m, APS_E_DIM, "ldp < m");
+        APS_REQUIRE(model && is_found && sample_idx, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(m == 0 || (p1 && p2 && inlier_mask), APS_E_ARG, "NULL points/mask");
+        ctx();
+        std::vector<int64_t> h_ptr = {0, m};
+        In<double> d1(p1, (size_t)ldp + m), d2(p2, (size_t)ldp + m);
+        In<uint32_t> ds(sample_idx, (size_t)4 * n_samples);
+        Out<double> om(model, 9);
+        Out<uint8_t> omask(inlier_mask, (size_t)std::max<int64_t>(m, 1));
+        Ws<int32_t> df(1), dn(1);
+        std::vector<int> trials;
+        ransac_batch(d1, d2, ldp, h_ptr, ds, n_samples, *opts, om, omask, df, dn, &trials);
+        int32_t f = 0;
+        APS_HIP(hipMemcpy(&f, df, sizeof f, hipMemcpyDeviceToHost));
+        *is_found = f;
+        if (trials_used) *trials_used = trials.empty() ? 0 : trials[0];
+        om.commit();
+        omask.commit(m);
+    });
+}
+
+}  // extern "C"

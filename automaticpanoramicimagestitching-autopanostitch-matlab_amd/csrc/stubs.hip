@@ -8,9 +8,6 @@ extern "C" {
 APS_STUB(aps_knn_global, const float*, int64_t, int64_t, const float*, int64_t, int64_t, int, int, int, uint32_t*, float*, int64_t)
 APS_STUB(aps_global_filter, const uint32_t*, const float*, int64_t, int, int64_t, int, const uint32_t*, const uint32_t*, int, float, int64_t*, uint32_t*, uint32_t*, int64_t, int64_t*)
 APS_STUB(aps_hamming_2nn, const uint8_t*, int64_t, int64_t, const uint8_t*, int64_t, int64_t, int, int, uint32_t*, float*, float*)
-APS_STUB(aps_ransac_score, const double*, int, const double*, const double*, int64_t, int64_t, double, int, int32_t*, double*, uint8_t*)
-APS_STUB(aps_ransac_homography, const double*, const double*, int64_t, int64_t, const uint32_t*, int, const aps_ransac_opts*, double*, uint8_t*, int*, int*)
-APS_STUB(aps_ransac_homography_batch, const double*, const double*, int64_t, const int64_t*, int, const uint32_t*, int, const aps_ransac_opts*, double*, uint8_t*, int32_t*, int32_t*)
 APS_STUB(aps_render, const aps_image*, int, const aps_canvas*, const aps_render_opts*, int, uint8_t*, uint8_t*)
 APS_STUB(aps_warp_tile, const aps_image*, const aps_canvas*, int, int, int, int, float, float*, uint8_t*, float*, float*)
 APS_STUB(aps_multiband_blend, const float*, const float*, int, int, int, int, float, float*)

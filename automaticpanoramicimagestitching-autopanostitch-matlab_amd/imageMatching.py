@@ -1,0 +1,197 @@
+"""Host-side mirror of PP/imageMatching/ (imageMatching.m, estimateTransformationRANSAC.m) on top of the
+batched device RANSAC of libaps_hip.so.
+
+The reference draws its 4-point samples from MATLAB's unseeded global RNG inside parfor workers
+(estimateTransformationRANSAC.m:96); here the draws are an explicit, seeded input so runs are
+reproducible and the device result can be compared bit-exactly with the oracle on the same draws.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib, ptr
+
+
+def draw_samples(counts, n_samples, seed=0):
+    """randperm(numPoints, 4) for every loop iteration of every pair (estimateTransformationRANSAC.m:96).
+
+    counts: matches per pair.  Returns uint32 [n_pairs, n_samples, 4], 1-based, distinct within a draw
+    (pairs with fewer than 4 matches get ones; they are never fitted).  Counter-based Philox stream keyed
+    by `seed`, so draws do not depend on how pairs are sharded over GPUs."""
+    counts = np.asarray(counts, np.int64).reshape(-1)
+    P = counts.size
+    out = np.ones((P, n_samples, 4), np.uint32)
+    for p in range(P):
+        n = int(counts[p])
+        if n < 4:
+            continue
+        rng = np.random.Generator(np.random.Philox(key=[seed, p]))
+        u = rng.random((n_samples, 4))
+        c = np.empty((n_samples, 4), np.int64)
+        c[:, 0] = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
+        for k in range(1, 4):
+            v = np.minimum((u[:, k] * (n - k)).astype(np.int64), n - k - 1)
+            prev = np.sort(c[:, :k], axis=1)
+            for t in range(k):  # skip over already chosen values in ascending order
+                v = v + (v >= prev[:, t])
+            c[:, k] = v
+        out[p] = (c + 1).astype(np.uint32)
+    return out
+
+
+def _ransac_opts(input):
+    o = _capi.aps_ransac_opts()
+    o.max_distance = float(input.get("maxDistance", 2.0))
+    o.confidence = float(input.get("inliersConfidence", 99.9))
+    o.max_iter = int(input.get("maxIter", 500))
+    o.tform_type = _capi.APS_TFORM_PROJECTIVE
+    return o
+
+
+def _check_type(transformType):
+    if str(transformType).lower() != "projective":
+        raise ValueError("Unknown transform type" if str(transformType).lower() not in
+                         ("translation", "rigid", "similarity", "affine") else
+                         "only transformationType 'projective' runs on the device path (inputs.m:74)")
+
+
+def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, input=None,
+                                 sample_idx=None, seed=0):
+    """[model, inliers, isFound] = estimateTransformationRANSAC(matchedPoints1, matchedPoints2,
+    transformType, input) (estimateTransformationRANSAC.m:1-183).
+
+    model maps matchedPoints1 -> matchedPoints2.  Returns (3x3 float64 or None, bool[M], bool)."""
+    _check_type(transformType)
+    input = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 500} if input is None else input
+    p1 = np.asfortranarray(np.asarray(matchedPoints1, np.float64))
+    p2 = np.asfortranarray(np.asarray(matchedPoints2, np.float64))
+    if p1.ndim != 2 or p1.shape[1] != 2 or p2.ndim != 2 or p2.shape[1] != 2:
+        raise ValueError("matchedPoints must be M-by-2")
+    if p1.shape[0] != p2.shape[0]:
+        raise ValueError("matchedPoints1 and matchedPoints2 must have the same number of rows.")
+    m = p1.shape[0]
+    if m < 4:  # :71-76
+        return None, np.zeros(m, bool), False
+    o = _ransac_opts(input)
+    if sample_idx is None:
+        sample_idx = draw_samples([m], o.max_iter + 64, seed)[0]
+    s = np.ascontiguousarray(sample_idx, np.uint32)
+    model = np.zeros(9, np.float64)
+    mask = np.zeros(m, np.uint8)
+    found = C.c_int(0)
+    trials = C.c_int(0)
+    check(lib.aps_ransac_homography(ptr(p1), ptr(p2), m, m, ptr(s), s.shape[0], C.byref(o), ptr(model),
+                                    ptr(mask), C.byref(found), C.byref(trials)))
+    if not found.value:
+        return None, mask.astype(bool), False
+    return model.reshape(3, 3).T.copy(), mask.astype(bool), True
+
+
+def ransac_score(Hs, p1, p2, thr):
+    """findInliers for T hypotheses (estimateTransformationRANSAC.m:444-516): (n_inl, mean_err, mask[T,M])."""
+    Hs = np.asarray(Hs, np.float64)
+    T = Hs.shape[0]
+    Hc = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))
+    a = np.asfortranarray(np.asarray(p1, np.float64))
+    b = np.asfortranarray(np.asarray(p2, np.float64))
+    m = a.shape[0]
+    n = np.zeros(T, np.int32)
+    e = np.zeros(T, np.float64)
+    mask = np.zeros((T, max(m, 1)), np.uint8)
+    check(lib.aps_ransac_score(ptr(Hc), T, ptr(a), ptr(b), m, m, float(thr), _capi.APS_TFORM_PROJECTIVE,
+                               ptr(n), ptr(e), ptr(mask)))
+    return n, e, mask[:, :m]
+
+
+def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
+    """Batched form used by imageMatching and the resident pipeline.
+    pts_src/pts_dst: total x 2 float64; pair_ptr: int64[P+1]; samples: uint32[P, S, 4].
+    Returns (models [P,3,3], mask uint8[total], found int32[P], n_inl int32[P])."""
+    a = np.asfortranarray(np.asarray(pts_src, np.float64))
+    b = np.asfortranarray(np.asarray(pts_dst, np.float64))
+    pair_ptr = np.ascontiguousarray(pair_ptr, np.int64)
+    P = pair_ptr.size - 1
+    total = int(pair_ptr[-1])
+    samples = np.ascontiguousarray(samples, np.uint32)
+    assert samples.shape[0] == P and samples.shape[2] == 4
+    models = np.zeros((P, 9), np.float64)
+    mask = np.zeros(max(total, 1), np.uint8)
+    found = np.zeros(P, np.int32)
+    ninl = np.zeros(P, np.int32)
+    o = _ransac_opts(input)
+    check(lib.aps_ransac_homography_batch(ptr(a), ptr(b), max(total, 1) if a.shape[0] == 0 else a.shape[0],
+                                          ptr(pair_ptr), P, ptr(samples), samples.shape[1], C.byref(o),
+                                          ptr(models), ptr(mask), ptr(found), ptr(ninl)))
+    return models.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mask[:total], found, ninl
+
+
+def candidate_pairs(matchesAll, n, m):
+    """Top-m candidate selection of imageMatching.m:76-100 (Brown-Lowe m = 6): union over images of the m
+    partners with the most putative matches (stable descending sort), upper triangle, column-major order."""
+    put = np.zeros((n, n), np.int64)
+    for i in range(n):
+        for j in range(n):
+            c = matchesAll[i][j]
+            put[i, j] = 0 if c is None else len(c)
+    sym = put + put.T
+    np.fill_diagonal(sym, 0)
+    order = np.argsort(-sym, axis=1, kind="stable")  # MATLAB sort(...,'descend') is stable
+    top = order[:, : min(m, n - 1)]
+    cand = np.zeros((n, n), bool)
+    cand[np.repeat(np.arange(n), top.shape[1]), top.reshape(-1)] = True
+    cand = np.triu(cand | cand.T, 1)
+    jj, ii = np.nonzero(cand.T)  # find() walks column-major
+    return list(zip(ii.tolist(), jj.tolist()))
+
+
+def imageMatching(input, n, keypoints, matchesAll, imagesProcessed=None, seed=0):
+    """[allMatches, numMatches, tforms] = imageMatching(input, n, keypoints, matchesAll, imagesProcessed)
+    (imageMatching.m:1-167).  tforms[i][j] maps image-j points to image-i points (:242), tforms[j][i] is
+    its inverse (:154); a pair is accepted iff ni > 8 + 0.3*nf (:150)."""
+    n = int(n)
+    if len(matchesAll) != n or any(len(r) != n for r in matchesAll):
+        raise ValueError("matchesAll must be an n-by-n cell array.")
+    if len(keypoints) != n:
+        raise ValueError("keypoints must contain n elements (one per image).")
+    if imagesProcessed is not None and len(imagesProcessed) != n:
+        raise ValueError("images must contain n elements (one per image).")
+    _check_type(input.get("transformationType", "projective"))
+    allMatches = [[None] * n for _ in range(n)]
+    numMatches = np.zeros((n, n))
+    tforms = [[None] * n for _ in range(n)]
+    pairs = candidate_pairs(matchesAll, n, int(input.get("mBrownLowe", 6)))
+    work = []
+    for (i, j) in pairs:
+        mt = matchesAll[i][j]
+        if mt is None or len(mt) < 4:  # :133
+            continue
+        mt = np.asarray(mt)
+        k1 = np.asarray(keypoints[i], np.float64)
+        k2 = np.asarray(keypoints[j], np.float64)
+        a = mt[:, 0].astype(np.int64)
+        b = mt[:, 1].astype(np.int64)
+        if a.max() > len(k1) or b.max() > len(k2) or a.min() < 1 or b.min() < 1:
+            raise ValueError("Match indices exceed keypoint array sizes.")  # refineMatch :222-226
+        work.append((i, j, mt, k2[b - 1], k1[a - 1]))  # (pts_j, pts_i): model maps j -> i (:242)
+    if not work:
+        return allMatches, numMatches, tforms
+    counts = [len(w[2]) for w in work]
+    pair_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    src = np.concatenate([w[3] for w in work])
+    dst = np.concatenate([w[4] for w in work])
+    n_samples = int(input.get("maxIter", 500)) + 64
+    samples = draw_samples(counts, n_samples, seed)
+    models, mask, found, ninl = ransac_batch(src, dst, pair_ptr, samples, input)
+    for p, (i, j, mt, _, _) in enumerate(work):
+        nf = len(mt)
+        inl = np.nonzero(mask[pair_ptr[p]:pair_ptr[p + 1]])[0]
+        ni = len(inl) if found[p] else 0
+        if ni > 8 + 0.3 * nf:  # :150
+            allMatches[i][j] = np.asarray(mt, np.float64)[inl]
+            numMatches[i, j] = ni
+            tforms[i][j] = models[p]
+            tforms[j][i] = np.linalg.inv(models[p])
+    return allMatches, numMatches, tforms

@@ -117,3 +117,61 @@ def hamming_2nn(A, B):
     _orc_hamming_2nn(A.ctypes.data, n1, B.ctypes.data, B.shape[0], A.shape[1], idx.ctypes.data,
                      d1.ctypes.data, d2.ctypes.data)
     return idx, d1, d2
+
+
+# ---- RANSAC (ransac_oracle.c) -------------------------------------------------------------------
+_orc_ransac_score = _sig("orc_ransac_score", [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp])
+_orc_fit_homography = _sig("orc_fit_homography", [_vp, _vp, _i64, _vp, _i64, _vp], _i)
+_orc_check_model = _sig("orc_check_model", [_vp], _i)
+_orc_ransac_homography = _sig("orc_ransac_homography",
+                              [_vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
+
+
+def _pts(p):
+    """M x 2 [x y] -> column-major buffer (x column then y column), returns (array, ldp)."""
+    p = np.asarray(p, np.float64)
+    return np.asfortranarray(p), p.shape[0]
+
+
+def ransac_score(Hs, p1, p2, thr, want_mask=True):
+    """Hs: T x 3 x 3 (usual row/col indexing); returns (n_inl[T], mean_err[T], mask[T, M])."""
+    Hs = np.asarray(Hs, np.float64)
+    T = Hs.shape[0]
+    Hc = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))  # each page column-major
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    n = np.zeros(T, np.int32)
+    e = np.zeros(T, np.float64)
+    mask = np.zeros((T, m), np.uint8) if want_mask else None
+    _orc_ransac_score(Hc.ctypes.data, T, a.ctypes.data, b.ctypes.data, m, m, float(thr), n.ctypes.data,
+                      e.ctypes.data, mask.ctypes.data if want_mask else None)
+    return n, e, mask
+
+
+def fit_homography(p1, p2, sel):
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    sel = np.ascontiguousarray(sel, np.int64)
+    H = np.zeros(9, np.float64)
+    ok = _orc_fit_homography(a.ctypes.data, b.ctypes.data, m, sel.ctypes.data, len(sel), H.ctypes.data)
+    return H.reshape(3, 3).T.copy(), bool(ok)
+
+
+def check_model(H):
+    Hc = np.ascontiguousarray(np.asarray(H, np.float64).T)
+    return bool(_orc_check_model(Hc.ctypes.data))
+
+
+def ransac_homography(p1, p2, sample_idx, max_distance=5.5, confidence=99.9, max_iter=500):
+    """sample_idx: n_samples x 4, 1-based.  Returns (model 3x3, mask bool[M], found, trials)."""
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    s = np.ascontiguousarray(sample_idx, np.uint32)
+    model = np.zeros(9, np.float64)
+    mask = np.zeros(max(m, 1), np.uint8)
+    found = C.c_int(0)
+    trials = C.c_int(0)
+    _orc_ransac_homography(a.ctypes.data, b.ctypes.data, m, m, s.ctypes.data, s.shape[0],
+                           float(max_distance), float(confidence), int(max_iter), model.ctypes.data,
+                           mask.ctypes.data, C.byref(found), C.byref(trials))
+    return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value

@@ -1,0 +1,355 @@
+/*
+ * ransac_oracle.c — CPU restatement of PP/imageMatching/estimateTransformationRANSAC.m (projective).
+ *
+ * TEST INFRASTRUCTURE ONLY (see match_oracle.c).  PARITY UNPINNED: the reference has no tests and
+ * relies on MATLAB's svd / mldivide / rcond / det (LAPACK, closed build) and on the unseeded global
+ * RNG inside parfor workers (:96).  What is fixed here, and mirrored by the HIP path:
+ *   - the random 4-subsets are an INPUT (one column per loop iteration of :94-143);
+ *   - svd(A) -> V(:,end) (:214-216) is computed as the eigenvector of the smallest eigenvalue of the
+ *     9x9 Gram matrix A'A by cyclic Jacobi (same subspace; Gram sums in row order);
+ *   - H \ x (:472) is evaluated as adj(H)*x: only the ratio of homogeneous coordinates is used;
+ *   - rcond(H) (:532) is the exact 1-norm value 1/(|H|_1 |H^-1|_1); det by first-row cofactors;
+ *   - sums over inliers (mean error :117, centroid and second moments of isDegenerate :559-567) use
+ *     the "wave order": 64 lane-strided partial sums (element i -> lane i%64, ascending i), combined
+ *     by the xor butterfly 32,16,8,4,2,1;
+ *   - svd of the centred n x 2 inlier matrix (:562) is the closed form from its 2x2 scatter matrix.
+ * Everything is IEEE double with no contraction (-ffp-contract=off), so the device reproduces it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+#define DBL_EPS 2.220446049250313e-16
+
+/* ---- wave-order reduction ------------------------------------------------------------------- */
+static double wave_reduce(double p[64]) {
+    double q[64];
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof q);
+    }
+    return p[0];
+}
+
+/* ---- 3x3 helpers (column-major: H[r + 3c]) ---------------------------------------------------- */
+#define H_(r, c) H[(r) + 3 * (c)]
+static void adjugate3(const double* H, double* A) {
+    A[0 + 3 * 0] = H_(1, 1) * H_(2, 2) - H_(1, 2) * H_(2, 1);
+    A[0 + 3 * 1] = H_(0, 2) * H_(2, 1) - H_(0, 1) * H_(2, 2);
+    A[0 + 3 * 2] = H_(0, 1) * H_(1, 2) - H_(0, 2) * H_(1, 1);
+    A[1 + 3 * 0] = H_(1, 2) * H_(2, 0) - H_(1, 0) * H_(2, 2);
+    A[1 + 3 * 1] = H_(0, 0) * H_(2, 2) - H_(0, 2) * H_(2, 0);
+    A[1 + 3 * 2] = H_(0, 2) * H_(1, 0) - H_(0, 0) * H_(1, 2);
+    A[2 + 3 * 0] = H_(1, 0) * H_(2, 1) - H_(1, 1) * H_(2, 0);
+    A[2 + 3 * 1] = H_(0, 1) * H_(2, 0) - H_(0, 0) * H_(2, 1);
+    A[2 + 3 * 2] = H_(0, 0) * H_(1, 1) - H_(0, 1) * H_(1, 0);
+}
+static double det3(const double* H) {
+    const double c0 = H_(1, 1) * H_(2, 2) - H_(1, 2) * H_(2, 1);
+    const double c1 = H_(1, 0) * H_(2, 2) - H_(1, 2) * H_(2, 0);
+    const double c2 = H_(1, 0) * H_(2, 1) - H_(1, 1) * H_(2, 0);
+    return (H_(0, 0) * c0 - H_(0, 1) * c1) + H_(0, 2) * c2;
+}
+static double norm1_3(const double* H) {
+    double m = 0;
+    for (int c = 0; c < 3; ++c) {
+        const double s = (fabs(H_(0, c)) + fabs(H_(1, c))) + fabs(H_(2, c));
+        if (s > m) m = s;
+    }
+    return m;
+}
+
+/* checkModel (:518-535) */
+static int check_model(const double* H) {
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0;
+    const double d = det3(H);
+    if (!(fabs(d) > DBL_EPS)) return 0;
+    double A[9], Inv[9];
+    adjugate3(H, A);
+    for (int e = 0; e < 9; ++e) Inv[e] = A[e] / d;
+    const double rc = 1.0 / (norm1_3(H) * norm1_3(Inv));
+    return rc > DBL_EPS;
+}
+
+/* ---- cyclic Jacobi on a symmetric 9x9 (row-major G[9*p+q]); returns V (columns = eigenvectors) */
+static void jacobi9(double* G, double* V) {
+    for (int p = 0; p < 9; ++p)
+        for (int q = 0; q < 9; ++q) V[9 * p + q] = (p == q) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double gpq = G[9 * p + q];
+                const double gpp = G[9 * p + p], gqq = G[9 * q + q];
+                if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;
+                rotated = 1;
+                const double theta = (gqq - gpp) / (2.0 * gpq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    if (k == p || k == q) continue;
+                    const double gkp = G[9 * k + p], gkq = G[9 * k + q];
+                    const double np_ = c * gkp - s * gkq;
+                    const double nq_ = s * gkp + c * gkq;
+                    G[9 * k + p] = np_; G[9 * p + k] = np_;
+                    G[9 * k + q] = nq_; G[9 * q + k] = nq_;
+                }
+                G[9 * p + p] = gpp - t * gpq;
+                G[9 * q + q] = gqq + t * gpq;
+                G[9 * p + q] = 0.0;
+                G[9 * q + p] = 0.0;
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = V[9 * k + p], vkq = V[9 * k + q];
+                    V[9 * k + p] = c * vkp - s * vkq;
+                    V[9 * k + q] = s * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+/* normalizePoints (:579-610): sequential sums in index order over the SELECTED points */
+static void normalize_sel(const double* x, const double* y, const int64_t* sel, int64_t n,
+                          double* scale, double* tx, double* ty) {
+    double sx = 0, sy = 0;
+    for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    const double cx = sx / (double)n, cy = sy / (double)n;
+    double sd = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+        sd = sd + sqrt(dx * dx + dy * dy);
+    }
+    const double s = 1.0 / (sd / (double)n);
+    *scale = s;
+    *tx = -s * cx; /* T(1,3) = -scale*centroid(1) */
+    *ty = -s * cy;
+}
+
+/* estimateHomography (:188-225) on the points listed in sel (n >= 4).  H column-major.
+ * Returns 0 if the result is not finite. */
+static int fit_homography(const double* x1, const double* y1, const double* x2, const double* y2,
+                          const int64_t* sel, int64_t n, double* H) {
+    double s1, t1x, t1y, s2, t2x, t2y;
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    double G[81];
+    for (int e = 0; e < 81; ++e) G[e] = 0;
+    /* rows of A in the reference's order: first all "x" rows, then all "y" rows (:209-212) */
+    for (int half = 0; half < 2; ++half)
+        for (int64_t e = 0; e < n; ++e) {
+            const double x = s1 * x1[sel[e]] + t1x, y = s1 * y1[sel[e]] + t1y;
+            const double u = s2 * x2[sel[e]] + t2x, v = s2 * y2[sel[e]] + t2y;
+            double a[9];
+            if (half == 0) {
+                a[0] = -x; a[1] = -y; a[2] = -1; a[3] = 0; a[4] = 0; a[5] = 0;
+                a[6] = x * u; a[7] = y * u; a[8] = u;
+            } else {
+                a[0] = 0; a[1] = 0; a[2] = 0; a[3] = -x; a[4] = -y; a[5] = -1;
+                a[6] = x * v; a[7] = y * v; a[8] = v;
+            }
+            for (int p = 0; p < 9; ++p)
+                for (int q = p; q < 9; ++q) G[9 * p + q] = G[9 * p + q] + a[p] * a[q];
+        }
+    for (int p = 0; p < 9; ++p)
+        for (int q = 0; q < p; ++q) G[9 * p + q] = G[9 * q + p];
+    double V[81];
+    jacobi9(G, V);
+    int kmin = 0;
+    for (int k = 1; k < 9; ++k)
+        if (G[9 * k + k] < G[9 * kmin + kmin]) kmin = k;
+    double h[9];
+    for (int k = 0; k < 9; ++k) h[k] = V[9 * k + kmin];
+    /* H_norm = reshape(h,3,3)' -> H_norm(r,c) = h[3r+c];  Hn = H_norm / H_norm(3,3) */
+    double Hn[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Hn[r + 3 * c] = h[3 * r + c] / h[8];
+    /* M = T2 \ Hn by back substitution (T2 = [s2 0 t2x; 0 s2 t2y; 0 0 1]) */
+    double M[9];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Hn[2 + 3 * c];
+        M[2 + 3 * c] = m2;
+        M[1 + 3 * c] = (Hn[1 + 3 * c] - t2y * m2) / s2;
+        M[0 + 3 * c] = (Hn[0 + 3 * c] - t2x * m2) / s2;
+    }
+    /* H = M * T1, T1 = [s1 0 t1x; 0 s1 t1y; 0 0 1] */
+    for (int r = 0; r < 3; ++r) {
+        H[r + 3 * 0] = M[r + 3 * 0] * s1;
+        H[r + 3 * 1] = M[r + 3 * 1] * s1;
+        H[r + 3 * 2] = (M[r + 3 * 0] * t1x + M[r + 3 * 1] * t1y) + M[r + 3 * 2];
+    }
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0;
+    return 1;
+}
+
+/* symmetric transfer error of one correspondence (:469-481,:499-503) */
+static double transfer_error(const double* H, const double* A, double x1, double y1, double x2,
+                             double y2) {
+    const double X = (H_(0, 0) * x1 + H_(0, 1) * y1) + H_(0, 2);
+    const double Y = (H_(1, 0) * x1 + H_(1, 1) * y1) + H_(1, 2);
+    const double W = (H_(2, 0) * x1 + H_(2, 1) * y1) + H_(2, 2);
+    const double tx = X / W, ty = Y / W;
+    const double IX = (A[0] * x2 + A[3] * y2) + A[6];
+    const double IY = (A[1] * x2 + A[4] * y2) + A[7];
+    const double IW = (A[2] * x2 + A[5] * y2) + A[8];
+    const double ix = IX / IW, iy = IY / IW;
+    const double ex = x2 - tx, ey = y2 - ty, fx = x1 - ix, fy = y1 - iy;
+    const double d1 = ex * ex + ey * ey;
+    const double d2 = fx * fx + fy * fy;
+    double e = sqrt(d1 + d2);
+    if (!isfinite(e)) e = INFINITY;
+    if (fabs(W) < DBL_EPS) e = INFINITY;
+    return e;
+}
+
+/* findInliers (:444-516).  mask may be NULL.  Returns the inlier count; *mean_err = mean error over
+ * inliers in wave order (NaN if none). */
+static int find_inliers(const double* H, const double* x1, const double* y1, const double* x2,
+                        const double* y2, int64_t m, double thr, uint8_t* mask, double* mean_err) {
+    double A[9];
+    adjugate3(H, A);
+    double pc[64], pe[64], px[64], py[64];
+    for (int l = 0; l < 64; ++l) pc[l] = pe[l] = px[l] = py[l] = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const double e = transfer_error(H, A, x1[i], y1[i], x2[i], y2[i]);
+        const int in = e < thr;
+        if (mask) mask[i] = (uint8_t)in;
+        if (in) {
+            const int l = (int)(i & 63);
+            pc[l] += 1.0;
+            pe[l] = pe[l] + e;
+            px[l] = px[l] + x1[i];
+            py[l] = py[l] + y1[i];
+        }
+    }
+    const double cnt = wave_reduce(pc);
+    const double se = wave_reduce(pe), sx = wave_reduce(px), sy = wave_reduce(py);
+    int n = (int)cnt;
+    if (n >= 4) { /* isDegenerate on pts1(inliers) (:506-513, :537-574) */
+        const double mx = sx / cnt, my = sy / cnt;
+        double pxx[64], pxy[64], pyy[64];
+        for (int l = 0; l < 64; ++l) pxx[l] = pxy[l] = pyy[l] = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            const double e = transfer_error(H, A, x1[i], y1[i], x2[i], y2[i]);
+            if (e < thr) {
+                const int l = (int)(i & 63);
+                const double dx = x1[i] - mx, dy = y1[i] - my;
+                pxx[l] = pxx[l] + dx * dx;
+                pxy[l] = pxy[l] + dx * dy;
+                pyy[l] = pyy[l] + dy * dy;
+            }
+        }
+        const double sxx = wave_reduce(pxx), sxy = wave_reduce(pxy), syy = wave_reduce(pyy);
+        const double hs = 0.5 * (sxx + syy), hd = 0.5 * (sxx - syy);
+        const double r = sqrt(hd * hd + sxy * sxy);
+        const double l1 = hs + r;
+        double l2 = hs - r;
+        if (l2 < 0) l2 = 0;
+        const double s1 = sqrt(l1), s2 = sqrt(l2);
+        if (s2 / s1 < 1e-3) { /* :567 — NaN (0/0) compares false like MATLAB */
+            if (mask) memset(mask, 0, (size_t)m);
+            *mean_err = NAN;
+            return 0;
+        }
+    }
+    *mean_err = n > 0 ? se / cnt : NAN;
+    return n;
+}
+
+/* ---- exported: batched scoring ------------------------------------------------------------------
+ * Hs: 3x3xT column-major pages; p1, p2: m x 2 column-major with leading dimension ldp. */
+ORC_API void orc_ransac_score(const double* Hs, int n_hyp, const double* p1, const double* p2,
+                              int64_t m, int64_t ldp, double thr, int32_t* n_inl, double* mean_err,
+                              uint8_t* mask) {
+    for (int t = 0; t < n_hyp; ++t)
+        n_inl[t] = find_inliers(Hs + 9 * t, p1, p1 + ldp, p2, p2 + ldp, m, thr,
+                                mask ? mask + (size_t)t * m : NULL, mean_err + t);
+}
+
+ORC_API int orc_fit_homography(const double* p1, const double* p2, int64_t ldp, const int64_t* sel,
+                               int64_t n, double* H) {
+    return fit_homography(p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+}
+
+ORC_API int orc_check_model(const double* H) { return check_model(H); }
+
+/* ---- exported: the whole loop (:54-183) ---------------------------------------------------------
+ * sample_idx: 4 x n_samples, 1-based, column-major; one column per loop iteration. */
+ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m, int64_t ldp,
+                                   const uint32_t* sample_idx, int n_samples, double max_distance,
+                                   double confidence, int max_iter, double* model,
+                                   uint8_t* inlier_mask, int* is_found, int* trials_used) {
+    const double *x1 = p1, *y1 = p1 + ldp, *x2 = p2, *y2 = p2 + ldp;
+    const int min_pts = 4;
+    memset(inlier_mask, 0, (size_t)m);
+    for (int e = 0; e < 9; ++e) model[e] = NAN;
+    *is_found = 0;
+    if (trials_used) *trials_used = 0;
+    if (m < min_pts) return; /* :71-76 */
+
+    int max_trials = max_iter;
+    const int max_skip = max_iter * 10;
+    int trial = 1, skip = 0, it = 0, best_n = 0, have_best = 0;
+    double best_err = INFINITY, bestH[9];
+    uint8_t* cur = (uint8_t*)malloc((size_t)m);
+    uint8_t* best_mask = (uint8_t*)calloc((size_t)m, 1);
+    while (trial <= max_trials && skip < max_skip && it < n_samples) { /* :94 */
+        int64_t sel[4];
+        for (int k = 0; k < 4; ++k) sel[k] = (int64_t)sample_idx[4 * it + k] - 1;
+        ++it;
+        double H[9];
+        if (!fit_homography(x1, y1, x2, y2, sel, 4, H) || !check_model(H)) { /* :101-108,:138-141 */
+            ++skip;
+            continue;
+        }
+        double me;
+        const int n = find_inliers(H, x1, y1, x2, y2, m, max_distance, cur, &me);
+        if (n >= min_pts) { /* :114-134 */
+            if (n > best_n || (n == best_n && me < best_err)) {
+                best_n = n;
+                best_err = me;
+                have_best = 1;
+                memcpy(bestH, H, sizeof bestH);
+                memcpy(best_mask, cur, (size_t)m);
+                const double ratio = (double)n / (double)m;
+                if (ratio > 0) {
+                    const double need = ceil(log(1 - confidence / 100) / log(1 - pow(ratio, min_pts)));
+                    if (need < (double)max_trials) max_trials = (int)need; /* min(maxTrials, ...) */
+                }
+            }
+        }
+        ++trial;
+    }
+    if (trials_used) *trials_used = it;
+
+    if (have_best && best_n >= min_pts) { /* :146-176 */
+        int64_t* sel = (int64_t*)malloc(sizeof(int64_t) * (size_t)best_n);
+        int64_t c = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (best_mask[i]) sel[c++] = i;
+        double R[9];
+        const int ok = fit_homography(x1, y1, x2, y2, sel, c, R) && check_model(R);
+        free(sel);
+        if (ok) {
+            double me;
+            const int n = find_inliers(R, x1, y1, x2, y2, m, max_distance, cur, &me);
+            if (n >= min_pts) {
+                memcpy(model, R, sizeof R);
+                memcpy(inlier_mask, cur, (size_t)m);
+            } else {
+                memcpy(model, bestH, sizeof bestH);
+                memcpy(inlier_mask, best_mask, (size_t)m);
+            }
+        } else {
+            memcpy(model, bestH, sizeof bestH);
+            memcpy(inlier_mask, best_mask, (size_t)m);
+        }
+        *is_found = 1;
+    }
+    free(cur);
+    free(best_mask);
+}

@@ -1,0 +1,119 @@
+"""GPU parity: batched device RANSAC against the oracle — inlier masks and counts bit-exact."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle
+from test_ransac_oracle import H_TRUE, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def im(gpu):
+    return import_module(gpu.__name__ + ".imageMatching")
+
+
+def test_score_bit_exact(im):
+    rng = np.random.default_rng(10)
+    p1, p2, truth = make_scene(rng, 1000, 400, H_TRUE, noise=0.5)
+    Hs = []
+    for t in range(64):
+        sel = rng.permutation(1000)[:4]
+        H, ok = oracle.fit_homography(p1, p2, sel)
+        Hs.append(H if ok else np.eye(3))
+    Hs.append(H_TRUE)
+    Hs.append(np.array([[1., 2, 3], [2, 4, 6], [0, 0, 1]]))  # singular: errors inf/NaN -> 0 inliers
+    Hs = np.stack(Hs)
+    n, e, mask = im.ransac_score(Hs, p1, p2, 5.5)
+    on, oe, omask = oracle.ransac_score(Hs, p1, p2, 5.5)
+    assert np.array_equal(n, on)
+    assert np.array_equal(mask, omask)
+    assert np.array_equal(e.view(np.uint64), oe.view(np.uint64))
+    assert n[-2] >= 590
+
+
+@pytest.mark.parametrize("m,n_out,noise", [(4, 0, 0.0), (30, 10, 0.2), (400, 150, 0.3), (3000, 2000, 0.5),
+                                           (257, 0, 0.0)])
+def test_whole_loop_bit_exact(im, m, n_out, noise):
+    rng = np.random.default_rng(20 + m)
+    p1, p2, truth = make_scene(rng, m, n_out, H_TRUE, noise=noise)
+    s = im.draw_samples([m], 564, seed=m)[0]
+    inp = {"maxDistance": 5.5, "inliersConfidence": 99.9, "maxIter": 500}
+    H, mask, found = im.estimateTransformationRANSAC(p1, p2, "projective", inp, sample_idx=s)
+    oH, omask, ofound, _ = oracle.ransac_homography(p1, p2, s, 5.5, 99.9, 500)
+    assert found == ofound
+    assert np.array_equal(mask, omask)
+    if found:
+        assert np.array_equal(H.view(np.uint64), oH.view(np.uint64))
+        assert mask[truth].mean() > 0.95
+
+
+def test_degenerate_and_tiny_inputs(im):
+    t = np.linspace(0, 1000, 40)
+    line = np.stack([t, 2 * t + 5], 1)
+    inp = {"maxDistance": 5.5, "inliersConfidence": 99.9, "maxIter": 100}
+    s = im.draw_samples([40], 164, seed=1)[0]
+    H, mask, found = im.estimateTransformationRANSAC(line, line.copy(), "projective", inp, sample_idx=s)
+    oH, omask, ofound, _ = oracle.ransac_homography(line, line.copy(), s, 5.5, 99.9, 100)
+    assert found == ofound and np.array_equal(mask, omask)
+    H, mask, found = im.estimateTransformationRANSAC(line[:3], line[:3], "projective", inp)
+    assert H is None and not found and mask.shape == (3,)
+    with pytest.raises(ValueError):
+        im.estimateTransformationRANSAC(line, line[:5], "projective", inp)
+    with pytest.raises(ValueError):
+        im.estimateTransformationRANSAC(line, line, "affine", inp)
+
+
+def test_image_matching_batch_equals_per_pair_oracle(im):
+    rng = np.random.default_rng(30)
+    n = 5
+    kp = [np.stack([rng.uniform(0, 4000, 900), rng.uniform(0, 2000, 900)], 1) for _ in range(n)]
+    matchesAll = [[None] * n for _ in range(n)]
+    truth_H = {}
+    for i in range(n):
+        for j in range(i + 1, n):
+            if (i + j) % 4 == 3:
+                matchesAll[i][j] = np.zeros((0, 2))
+                continue
+            m = 150 + 40 * (i + j)
+            a = rng.permutation(900)[:m] + 1
+            b = rng.permutation(900)[:m] + 1
+            H = H_TRUE.copy()
+            H[0, 2] += 50 * i
+            H[1, 2] -= 30 * j
+            good = rng.random(m) < (0.7 if (i * j) % 3 else 0.15)
+            # make image-i points the image of image-j points under H for the good ones
+            q = np.c_[kp[j][b - 1], np.ones(m)] @ H.T
+            proj = q[:, :2] / q[:, 2:3]
+            kp[i][a[good] - 1] = proj[good] + 0.3 * rng.standard_normal((good.sum(), 2))
+            matchesAll[i][j] = np.stack([a, b], 1).astype(np.float64)
+            truth_H[(i, j)] = H
+    inp = {"maxDistance": 5.5, "inliersConfidence": 99.9, "maxIter": 500, "mBrownLowe": 6,
+           "transformationType": "projective"}
+    allM, numM, tf = im.imageMatching(inp, n, kp, matchesAll, None, seed=3)
+    pairs = im.candidate_pairs(matchesAll, n, 6)
+    counts = [len(matchesAll[i][j]) for (i, j) in pairs if len(matchesAll[i][j]) >= 4]
+    samples = im.draw_samples(counts, 564, 3)
+    p = 0
+    accepted = 0
+    for (i, j) in pairs:
+        mt = matchesAll[i][j]
+        if len(mt) < 4:
+            assert allM[i][j] is None
+            continue
+        a = mt[:, 0].astype(int) - 1
+        b = mt[:, 1].astype(int) - 1
+        oH, omask, ofound, _ = oracle.ransac_homography(kp[j][b], kp[i][a], samples[p], 5.5, 99.9, 500)
+        p += 1
+        ni = int(omask.sum()) if ofound else 0
+        if ni > 8 + 0.3 * len(mt):
+            accepted += 1
+            assert np.array_equal(allM[i][j], mt[omask])
+            assert numM[i, j] == ni
+            assert np.array_equal(tf[i][j].view(np.uint64), oH.view(np.uint64))
+            np.testing.assert_allclose(tf[j][i] @ tf[i][j], np.eye(3), atol=1e-8)
+        else:
+            assert allM[i][j] is None and numM[i, j] == 0 and tf[i][j] is None
+    assert accepted >= 3
