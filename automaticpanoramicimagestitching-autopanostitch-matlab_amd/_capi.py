@@ -119,6 +119,15 @@ def _load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). This package has no CPU or PyTorch fallback.")
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64/libhsa-runtime64 with the
+    # same SONAMEs as /opt/rocm's.  If ours were loaded first, torch would later bring up a second HSA
+    # runtime and see no GPUs ("No HIP GPUs are available").  Importing torch first makes the dynamic
+    # loader resolve libaps_hip.so's dependency to the copy torch already mapped.  (A MATLAB/mex host
+    # has no torch and simply uses the system ROCm runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is plumbing, not a requirement of the C ABI
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == the .so does not export what aps.h declares

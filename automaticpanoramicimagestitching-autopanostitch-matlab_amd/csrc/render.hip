@@ -1,0 +1,990 @@
+// render.hip — inverse-warp resampling, tile fusion and Laplacian-pyramid multiband blending on gfx950.
+//
+// Restates PP/renderPanorama/renderPanorama.m:342-425 (tile loop, rays, paint), :825-1060 (fuseTile),
+// :1063-1146 (sampleOneTile), :1282-1312 (warpWeights), :1393-1456 (sampleBlock),
+// PP/blending/multiBandBlending.m:45-171, PP/blending/linearBlending.m:64-101 and
+// PP/imageProcessing/imageWarp.m:39-168.
+//
+// HBM layout
+//   source images : RGBA8, row-major, one 32-bit word per pixel (a bilinear tap is one dword gather);
+//                   converted once from the caller's layout (HWC or MATLAB planar column-major).
+//   tile layers   : float4 per pixel (r, g, b, w): colour and blend weight travel together because the
+//                   reference blurs/downsamples both identically at every pyramid level.
+//   numerator pyr : float4 per pixel per level (w unused).
+// All tap sums are k-ascending f32 fma chains (the oracle's order); toolbox semantics (interp2,
+// imgaussfilt, imresize) are the ones written down in oracle/render_oracle.c.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "aps_internal.h"
+
+namespace aps {
+
+// ------------------------------------------------------------------------------------------------
+// device-side descriptors
+// ------------------------------------------------------------------------------------------------
+struct DevImage {
+    const uint32_t* rgba;  // h*w words
+    const float* wx;       // tent LUT, w entries
+    const float* wy;       // tent LUT, h entries
+    int h, w;
+    float R[9];  // column-major, single(cam.R)
+    float fx, fy, cx, cy;
+    float gain[3];
+};
+
+struct DevCanvas {
+    int mode, H, W;
+    float f, o0, o1;
+    float Rref[9];
+};
+
+__device__ __forceinline__ void canvas_ray(const DevCanvas& cv, float xp, float yp, float d[3]) {
+    float x, y, z;
+    if (cv.mode == APS_PROJ_CYLINDRICAL) {
+        const float th = cv.o0 + xp / cv.f, hl = cv.o1 + yp / cv.f;
+        x = sinf(th);
+        y = hl;
+        z = cosf(th);
+    } else if (cv.mode == APS_PROJ_SPHERICAL) {
+        const float th = cv.o0 + xp / cv.f, ph = cv.o1 + yp / cv.f;
+        const float cp = cosf(ph), sp = sinf(ph);
+        x = cp * sinf(th);
+        y = sp;
+        z = cp * cosf(th);
+    } else {
+        float rx, ry, rz;
+        if (cv.mode == APS_PROJ_PLANAR) {
+            rx = cv.o0 + xp / cv.f;
+            ry = cv.o1 + yp / cv.f;
+            rz = 1.0f;
+        } else {
+            const float a = cv.o0 + xp / cv.f, b = cv.o1 + yp / cv.f;
+            const float r2 = a * a + b * b, den = 1.0f + r2;
+            rx = 2.0f * a / den;
+            ry = 2.0f * b / den;
+            rz = (1.0f - r2) / den;
+        }
+        x = (cv.Rref[0] * rx + cv.Rref[1] * ry) + cv.Rref[2] * rz;
+        y = (cv.Rref[3] * rx + cv.Rref[4] * ry) + cv.Rref[5] * rz;
+        z = (cv.Rref[6] * rx + cv.Rref[7] * ry) + cv.Rref[8] * rz;
+    }
+    float n = sqrtf((x * x + y * y) + z * z);
+    if (!(n > 1e-8f)) n = 1e-8f;
+    d[0] = x / n;
+    d[1] = y / n;
+    d[2] = z / n;
+}
+
+struct Sample {
+    float s[3];
+    float wang, wf;
+    bool m;
+};
+
+// Geometry only: (u, v, Wang, inside&front).  Used by the coverage prepass and by the sampler.
+__device__ __forceinline__ bool project(const DevImage& im, const float d[3], float angle_pow,
+                                        float& u, float& v, float& wa) {
+    float cam[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cam[c] = fmaf(d[2], im.R[c + 6], fmaf(d[1], im.R[c + 3], d[0] * im.R[c]));
+    const float epsz = 1e-6f;
+    const bool front = cam[2] > epsz;
+    const float cz = cam[2] > epsz ? cam[2] : epsz;
+    u = im.fx * (cam[0] / cz) + im.cx;
+    v = im.fy * (cam[1] / cz) + im.cy;
+    wa = cam[2] > 0.0f ? cam[2] : 0.0f;
+    if (angle_pow == 2.0f)
+        wa = wa * wa;
+    else if (angle_pow != 1.0f)
+        wa = powf(wa, angle_pow);
+    wa = front ? wa : 0.0f;
+    if (!isfinite(u) || !isfinite(v)) {
+        u = 1.0f;
+        v = 1.0f;
+    }
+    const bool inside = (u >= 1.0f) && (u <= (float)im.w) && (v >= 1.0f) && (v <= (float)im.h);
+    return inside && wa > 0.0f;
+}
+
+__device__ __forceinline__ Sample sample_one(const DevImage& im, const float d[3], float angle_pow) {
+    Sample r;
+    float u, v, wa;
+    r.m = project(im, d, angle_pow, u, v, wa);
+    if (r.m) {
+        const int w = im.w, h = im.h;
+        int x0 = (int)floorf(u), y0 = (int)floorf(v);
+        x0 = max(1, min(x0, w - 1));
+        y0 = max(1, min(y0, h - 1));
+        const int x1 = min(x0 + 1, w), y1 = min(y0 + 1, h);
+        const float s = u - (float)x0, t = v - (float)y0;
+        const uint32_t p00 = im.rgba[(size_t)(y0 - 1) * w + (x0 - 1)];
+        const uint32_t p10 = im.rgba[(size_t)(y0 - 1) * w + (x1 - 1)];
+        const uint32_t p01 = im.rgba[(size_t)(y1 - 1) * w + (x0 - 1)];
+        const uint32_t p11 = im.rgba[(size_t)(y1 - 1) * w + (x1 - 1)];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = im.gain[c];
+            const float v00 = ((float)((p00 >> (8 * c)) & 255u) / 255.0f) * g;
+            const float v10 = ((float)((p10 >> (8 * c)) & 255u) / 255.0f) * g;
+            const float v01 = ((float)((p01 >> (8 * c)) & 255u) / 255.0f) * g;
+            const float v11 = ((float)((p11 >> (8 * c)) & 255u) / 255.0f) * g;
+            const float top = (1.0f - s) * v00 + s * v10;
+            const float bot = (1.0f - s) * v01 + s * v11;
+            r.s[c] = top * (1.0f - t) + bot * t;
+        }
+        const float wy0 = im.wy[y0 - 1], wy1 = im.wy[y1 - 1], wx0 = im.wx[x0 - 1], wx1 = im.wx[x1 - 1];
+        const float f00 = wy0 * wx0, f10 = wy0 * wx1, f01 = wy1 * wx0, f11 = wy1 * wx1;
+        const float top = (1.0f - s) * f00 + s * f10;
+        const float bot = (1.0f - s) * f01 + s * f11;
+        r.wf = top * (1.0f - t) + bot * t;
+        r.wang = wa;
+    } else {
+        r.s[0] = r.s[1] = r.s[2] = 0.0f;
+        r.wf = 0.0f;
+        r.wang = 0.0f;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image conversion
+// ------------------------------------------------------------------------------------------------
+__global__ void to_rgba_kernel(const uint8_t* __restrict__ src, int h, int w, int c, int layout,
+                               uint32_t* __restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    uint32_t ch[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int kk = c == 1 ? 0 : k;
+        ch[k] = layout == APS_IMG_U8_HWC ? src[((size_t)y * w + x) * c + kk]
+                                         : src[(size_t)kk * h * w + (size_t)x * h + y];
+    }
+    dst[(size_t)y * w + x] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// coverage prepass: which images touch which tile (exact: the same predicate as the sampler)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cover_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
+                                                     int n_img, int r0, int c0, int ht, int wt,
+                                                     float angle_pow, uint32_t* __restrict__ flags) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const bool in_tile = x < wt && y < ht;
+    float d[3] = {0.f, 0.f, 1.f};
+    if (in_tile) canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
+    for (int i = 0; i < n_img; ++i) {
+        float u, v, wa;
+        const bool m = in_tile && project(imgs[i], d, angle_pow, u, v, wa);
+        if (__any(m)) {
+            if ((threadIdx.x & 63) == 0) flags[i] = 1u;  // benign race: every writer stores 1
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// warp: one layer (tile x image) as float4 (r,g,b,w = Wang*Wf)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_layer_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
+                                                          int img, int r0, int c0, int ht, int wt,
+                                                          float angle_pow, float wf_floor,
+                                                          float4* __restrict__ layer) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= wt || y >= ht) return;
+    float d[3];
+    canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
+    const Sample s = sample_one(imgs[img], d, angle_pow);
+    float wf = s.wf;
+    if (wf_floor > 0.f) {  // 'linear': Wf = max(Wf, 1e-4) (:933)
+        if (!isfinite(wf)) wf = 0.f;
+        wf = wf > wf_floor ? wf : wf_floor;
+    }
+    const float wv = s.m ? s.wang * wf : 0.0f;
+    layer[(size_t)y * wt + x] = make_float4(s.s[0], s.s[1], s.s[2], wv);
+}
+
+// test/diagnostic form: the four outputs of sampleOneTile separately
+__global__ __launch_bounds__(256) void warp_tile_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
+                                                         int r0, int c0, int ht, int wt,
+                                                         float angle_pow, float* __restrict__ S,
+                                                         uint8_t* __restrict__ M,
+                                                         float* __restrict__ Wang,
+                                                         float* __restrict__ Wf) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= wt || y >= ht) return;
+    float d[3];
+    canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
+    const Sample s = sample_one(imgs[0], d, angle_pow);
+    const size_t o = (size_t)y * wt + x;
+    S[3 * o + 0] = s.s[0];
+    S[3 * o + 1] = s.s[1];
+    S[3 * o + 2] = s.s[2];
+    M[o] = s.m ? 1 : 0;
+    Wang[o] = s.wang;
+    Wf[o] = s.wf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight normalisation over the K layers of a tile
+// ------------------------------------------------------------------------------------------------
+// fuse_norm: renderPanorama.m:1009-1017 (w *= 1/sum where sum > 1e-8), coverage = any(w > 0)
+// mbb_norm : multiBandBlending.m:72-85   (w = max(0,w)/sum where sum > 1e-8)
+__global__ void norm_weights_kernel(float4* const* __restrict__ layers, int K, size_t n, int fuse_norm,
+                                    int mbb_norm, uint8_t* __restrict__ cov) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    bool any = false;
+    if (fuse_norm) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float w = layers[k][p].w;
+            s = s + w;
+            any |= w > 0.f;
+        }
+        const float inv = s > 1e-8f ? 1.0f / s : 0.f;
+        for (int k = 0; k < K; ++k) layers[k][p].w = layers[k][p].w * inv;
+    }
+    if (mbb_norm) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float w = layers[k][p].w;
+            s = s + (w > 0.f ? w : 0.f);
+        }
+        for (int k = 0; k < K; ++k) {
+            const float w = layers[k][p].w > 0.f ? layers[k][p].w : 0.f;
+            layers[k][p].w = s > 1e-8f ? w / s : 0.f;
+        }
+    }
+    if (cov) cov[p] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyramid building blocks on float4 images
+// ------------------------------------------------------------------------------------------------
+struct Taps {
+    float k[17];
+    int r;
+};
+
+__device__ __forceinline__ float4 fma4(float w, const float4 v, float4 a) {
+    a.x = fmaf(w, v.x, a.x);
+    a.y = fmaf(w, v.y, a.y);
+    a.z = fmaf(w, v.z, a.z);
+    a.w = fmaf(w, v.w, a.w);
+    return a;
+}
+
+__global__ void blur_v_kernel(const float4* __restrict__ in, int h, int w, Taps tp,
+                              float4* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t <= 2 * tp.r; ++t) {
+        const int yy = min(max(y + t - tp.r, 0), h - 1);
+        a = fma4(tp.k[t], in[(size_t)yy * w + x], a);
+    }
+    out[(size_t)y * w + x] = a;
+}
+
+__global__ void blur_h_kernel(const float4* __restrict__ in, int h, int w, Taps tp,
+                              float4* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t <= 2 * tp.r; ++t) {
+        const int xx = min(max(x + t - tp.r, 0), w - 1);
+        a = fma4(tp.k[t], in[(size_t)y * w + xx], a);
+    }
+    out[(size_t)y * w + x] = a;
+}
+
+// imresize contributions (triangle kernel) for output index x (0-based); all in f64 like MATLAB
+__device__ __forceinline__ int resize_taps(int in_len, int out_len, int x, int& left, float wts[12]) {
+    const double scale = (double)out_len / (double)in_len;
+    const double kw = scale < 1.0 ? 2.0 / scale : 2.0;
+    const double u = (double)(x + 1) / scale + 0.5 * (1.0 - 1.0 / scale);
+    left = (int)floor(u - kw / 2.0);
+    int P = (int)ceil(kw) + 2;
+    if (P > 12) P = 12;  // scale >= 0.2 always holds for floor(/2) pyramids (scale in [1/3, 1/2] or >= 2)
+    double wd[12], s = 0;
+    for (int t = 0; t < P; ++t) {
+        const double dx = u - (double)(left + t);
+        double a = scale < 1.0 ? scale * dx : dx;
+        a = fabs(a);
+        double v = a < 1.0 ? 1.0 - a : 0.0;
+        if (scale < 1.0) v = scale * v;
+        wd[t] = v;
+        s += v;
+    }
+    for (int t = 0; t < P; ++t) wts[t] = (float)(wd[t] / s);
+    return P;
+}
+
+// dim 0 (rows): in h x w -> out oh x w
+__global__ void resize_rows_kernel(const float4* __restrict__ in, int h, int w, int oh,
+                                   float4* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    int left;
+    float wts[12];
+    const int P = resize_taps(h, oh, y, left, wts);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < P; ++t) {
+        const int yy = min(max(left + t, 1), h) - 1;
+        a = fma4(wts[t], in[(size_t)yy * w + x], a);
+    }
+    out[(size_t)y * w + x] = a;
+}
+
+// dim 1 (cols): in h x w -> out h x ow
+__global__ void resize_cols_kernel(const float4* __restrict__ in, int h, int w, int ow,
+                                   float4* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= ow) return;
+    int left;
+    float wts[12];
+    const int P = resize_taps(w, ow, x, left, wts);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < P; ++t) {
+        const int xx = min(max(left + t, 1), w) - 1;
+        a = fma4(wts[t], in[(size_t)y * w + xx], a);
+    }
+    out[(size_t)y * ow + x] = a;
+}
+
+// Num_l += (G - U) .* G.w   (multiBandBlending.m:139-144)
+__global__ void lap_accum_kernel(const float4* __restrict__ G, const float4* __restrict__ U, size_t n,
+                                 float4* __restrict__ Num) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 g = G[p], u = U[p];
+    float4 a = Num[p];
+    a.x = a.x + (g.x - u.x) * g.w;
+    a.y = a.y + (g.y - u.y) * g.w;
+    a.z = a.z + (g.z - u.z) * g.w;
+    Num[p] = a;
+}
+
+// Num_L += G .* G.w   (:159)
+__global__ void coarse_accum_kernel(const float4* __restrict__ G, size_t n, float4* __restrict__ Num) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 g = G[p];
+    float4 a = Num[p];
+    a.x = a.x + g.x * g.w;
+    a.y = a.y + g.y * g.w;
+    a.z = a.z + g.z * g.w;
+    Num[p] = a;
+}
+
+// F = up + Num_l   (:166)
+__global__ void add_kernel(const float4* __restrict__ A, const float4* __restrict__ B, size_t n,
+                           float4* __restrict__ out) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 a = A[p], b = B[p];
+    out[p] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, 0.f);
+}
+
+__global__ void pack_layer_kernel(const float* __restrict__ C3, const float* __restrict__ W, size_t n,
+                                  float4* __restrict__ out) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    out[p] = make_float4(C3[3 * p], C3[3 * p + 1], C3[3 * p + 2], W[p]);
+}
+
+__global__ void unpack_clamp_kernel(const float4* __restrict__ in, size_t n, int clamp01,
+                                    float* __restrict__ out) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float v[3] = {in[p].x, in[p].y, in[p].z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = v[c];
+        if (clamp01) {
+            t = t > 0.f ? t : 0.f;  // max(0,F): NaN -> 0
+            t = t < 1.f ? t : 1.f;
+        }
+        out[3 * p + c] = t;
+    }
+}
+
+// 'linear' (:916-978) over K layers that already hold w = Wang*max(Wf,1e-4) (0 outside the mask)
+__global__ void linear_fuse_kernel(float4* const* __restrict__ layers, int K, size_t n,
+                                   float4* __restrict__ F, uint8_t* __restrict__ cov) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float acc[3] = {0.f, 0.f, 0.f}, ws = 0.f, bestw = 0.f, best[3] = {0.f, 0.f, 0.f};
+    bool anyv = false;
+    for (int k = 0; k < K; ++k) {
+        const float4 g = layers[k][p];
+        acc[0] = acc[0] + g.x * g.w;
+        acc[1] = acc[1] + g.y * g.w;
+        acc[2] = acc[2] + g.z * g.w;
+        ws = ws + g.w;
+        // inside the mask Wang > 0 and Wf >= 1e-4, so w > 0 <=> M (the reference tests M)
+        const bool m = g.w > 0.f;
+        anyv |= m;
+        if (m && g.w > bestw) {
+            bestw = g.w;
+            best[0] = g.x;
+            best[1] = g.y;
+            best[2] = g.z;
+        }
+    }
+    const bool z = ws > 1e-12f;
+    float4 o;
+    o.x = z ? acc[0] / ws : (anyv ? best[0] : 0.f);
+    o.y = z ? acc[1] / ws : (anyv ? best[1] : 0.f);
+    o.z = z ? acc[2] / ws : (anyv ? best[2] : 0.f);
+    o.w = 0.f;
+    F[p] = o;
+    cov[p] = ws > 0.f ? 1 : 0;
+}
+
+// linearBlending.m:64-101 (sum(I.*W) / max(sum(W), eps('single')))
+__global__ void linear_blend_kernel(float4* const* __restrict__ layers, int K, size_t n,
+                                    float4* __restrict__ F) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float acc[3] = {0.f, 0.f, 0.f}, den = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float4 g = layers[k][p];
+        acc[0] = acc[0] + g.x * g.w;
+        acc[1] = acc[1] + g.y * g.w;
+        acc[2] = acc[2] + g.z * g.w;
+        den = den + g.w;
+    }
+    const float tiny = 1.1920928955078125e-07f;
+    const float d = den > tiny ? den : tiny;
+    F[p] = make_float4(acc[0] / d, acc[1] / d, acc[2] / d, 0.f);
+}
+
+// 'none' policies (:864-914): images visited in order, one launch per image
+__global__ __launch_bounds__(256) void none_fuse_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
+                                                         int img, int r0, int c0, int ht, int wt,
+                                                         float angle_pow, int policy,
+                                                         float4* __restrict__ F,
+                                                         uint8_t* __restrict__ cov) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= wt || y >= ht) return;
+    float d[3];
+    canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
+    const Sample s = sample_one(imgs[img], d, angle_pow);
+    const size_t p = (size_t)y * wt + x;
+    float4 f = F[p];  // f.w carries bestW for 'maxangle'
+    bool upd;
+    if (policy == APS_NONE_LAST)
+        upd = s.m;
+    else if (policy == APS_NONE_FIRST)
+        upd = s.m && !cov[p];
+    else
+        upd = s.m && (s.wang > f.w);
+    if (upd) {
+        f.x = s.s[0];
+        f.y = s.s[1];
+        f.z = s.s[2];
+        if (policy == APS_NONE_MAXANGLE) f.w = s.wang;
+        F[p] = f;
+        cov[p] = 1;
+    }
+}
+
+// paint + uint8 (:408-425): pano = covered ? uint8(round(255*clamp(F))) : canvas colour
+__global__ void paint_kernel(const float4* __restrict__ F, const uint8_t* __restrict__ cov, int r0,
+                             int c0, int ht, int wt, int H, int W, int white, int out_layout,
+                             uint8_t* __restrict__ pano, uint8_t* __restrict__ covered) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= wt) return;
+    const size_t p = (size_t)y * wt + x;
+    const float4 f = F[p];
+    const bool c = cov[p] != 0;
+    const float v[3] = {f.x, f.y, f.z};
+    const int gy = r0 + y, gx = c0 + x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = roundf(255.0f * v[k]);  // MATLAB round: half away from zero
+        if (!(t > 0.f)) t = 0.f;
+        if (t > 255.f) t = 255.f;
+        const uint8_t b = c ? (uint8_t)t : (white ? 255 : 0);
+        if (out_layout == APS_IMG_U8_HWC)
+            pano[((size_t)gy * W + gx) * 3 + k] = b;
+        else
+            pano[(size_t)k * H * W + (size_t)gx * H + gy] = b;
+    }
+    if (covered) {
+        if (out_layout == APS_IMG_U8_HWC)
+            covered[(size_t)gy * W + gx] = c ? 1 : 0;
+        else
+            covered[(size_t)gx * H + gy] = c ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// imageWarp 'bilinear' (imageWarp.m:125-168)
+// ------------------------------------------------------------------------------------------------
+struct HWarp {
+    double A[9];  // adjugate of H/H(3,3)
+    double det;
+};
+
+template <class T>
+__global__ void image_warp_h_kernel(const T* __restrict__ in, int in_h, int in_w, int C, HWarp hw,
+                                    int out_h, int out_w, double x0, double y0, double sx, double sy,
+                                    T fill, T* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= out_w) return;
+    const double X = x0 + (double)x * sx, Y = y0 + (double)y * sy;
+    const double s0 = ((hw.A[0] * X + hw.A[3] * Y) + hw.A[6]) / hw.det;
+    const double s1 = ((hw.A[1] * X + hw.A[4] * Y) + hw.A[7]) / hw.det;
+    const double s2 = ((hw.A[2] * X + hw.A[5] * Y) + hw.A[8]) / hw.det;
+    double wv = fabs(s2) > 1e-12 ? fabs(s2) : 1e-12;
+    wv = s2 < 0 ? -wv : (s2 > 0 ? wv : 0.0);
+    const double srcx = s0 / wv, srcy = s1 / wv;
+    const double fx1 = floor(srcx), fy1 = floor(srcy);
+    const bool valid = fx1 >= 1 && fx1 + 1 <= in_w && fy1 >= 1 && fy1 + 1 <= in_h;
+    for (int c = 0; c < C; ++c) {
+        T o = fill;
+        if (valid) {
+            const int x1 = (int)fx1, y1 = (int)fy1;
+            const double wx = srcx - fx1, wy = srcy - fy1;
+            const double w11 = (1 - wx) * (1 - wy), w12 = (1 - wx) * wy, w21 = wx * (1 - wy),
+                         w22 = wx * wy;
+            const double p11 = (double)in[((size_t)(y1 - 1) * in_w + (x1 - 1)) * C + c];
+            const double p12 = (double)in[((size_t)(y1)*in_w + (x1 - 1)) * C + c];
+            const double p21 = (double)in[((size_t)(y1 - 1) * in_w + (x1)) * C + c];
+            const double p22 = (double)in[((size_t)(y1)*in_w + (x1)) * C + c];
+            const double v = ((w11 * p11 + w12 * p12) + w21 * p21) + w22 * p22;
+            if (sizeof(T) == 1) {
+                double rr = round(v);
+                rr = rr < 0 ? 0 : (rr > 255 ? 255 : rr);
+                o = (T)rr;
+            } else {
+                o = (T)v;
+            }
+        }
+        out[((size_t)y * out_w + x) * C + c] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+static void host_tent(int n, std::vector<float>& w) {  // warpWeights (:1282-1312)
+    w.assign(n, 1.0f);
+    const int a = (n + 1) / 2;
+    for (int k = 0; k < a; ++k) {
+        double v = a > 1 ? 0.0 + ((double)k * 1.0) / (double)(a - 1) : 1.0;
+        if (k == a - 1) v = 1.0;
+        w[k] = (float)v;
+    }
+    const int b0 = n / 2, nb = n - n / 2;
+    for (int k = 0; k < nb; ++k) {
+        double v = nb > 1 ? 1.0 + ((double)k * -1.0) / (double)(nb - 1) : 0.0;
+        if (k == 0 && nb > 1) v = 1.0;
+        if (k == nb - 1) v = 0.0;
+        w[b0 + k] = (float)v;
+    }
+}
+
+static Taps make_taps(float sigma) {
+    Taps tp;
+    const int r = (int)std::ceil(2.0 * (double)sigma);
+    APS_REQUIRE(r >= 0 && r <= 8, APS_E_ARG, "MBBsigma %g needs a %d-tap filter (max 17 supported)",
+                (double)sigma, 2 * r + 1);
+    double t[17], s = 0;
+    for (int i = 0; i <= 2 * r; ++i) {
+        const double x = (double)(i - r);
+        t[i] = std::exp(-(x * x) / (2.0 * (double)sigma * (double)sigma));
+        s += t[i];
+    }
+    for (int i = 0; i <= 2 * r; ++i) tp.k[i] = (float)(t[i] / s);
+    tp.r = r;
+    return tp;
+}
+
+// imresize(in,[oh ow],'bilinear') on float4 images; dimension with the smaller scale first
+static void imresize4(const float4* in, int h, int w, int oh, int ow, float4* out, Ws<float4>& tmp) {
+    const double sr = (double)oh / h, sc = (double)ow / w;
+    if (sr <= sc) {
+        tmp.alloc((size_t)oh * w);
+        resize_rows_kernel<<<dim3(cdiv(w, 256), oh), 256, 0, stream()>>>(in, h, w, oh, tmp);
+        resize_cols_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(tmp, oh, w, ow, out);
+    } else {
+        tmp.alloc((size_t)h * ow);
+        resize_cols_kernel<<<dim3(cdiv(ow, 256), h), 256, 0, stream()>>>(in, h, w, ow, tmp);
+        resize_rows_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(tmp, h, ow, oh, out);
+    }
+    check_launch("imresize4");
+}
+
+// multiBandBlending on K float4 layers (weights already in .w); result float4 in F (unclamped)
+static void multiband_device(std::vector<float4*>& layers, int h, int w, int levels, float sigma,
+                             float4* F) {
+    const int K = (int)layers.size();
+    const size_t hw = (size_t)h * w;
+    // :72-85
+    Ws<float4*> dl(K);
+    APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
+    norm_weights_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dl, K, hw, 0, 1, nullptr);
+    check_launch("norm_weights_kernel");
+    // :98-109
+    int maxl = (int)std::floor(std::log2((double)std::min(h, w)));
+    levels = std::max(1, std::min(levels, maxl));
+    std::vector<int> lh(levels), lw(levels);
+    lh[0] = h;
+    lw[0] = w;
+    for (int l = 1; l < levels; ++l) {
+        lh[l] = std::max(1, lh[l - 1] / 2);
+        lw[l] = std::max(1, lw[l - 1] / 2);
+    }
+    std::vector<Ws<float4>> num(levels);
+    for (int l = 0; l < levels; ++l) {
+        num[l].alloc((size_t)lh[l] * lw[l]);
+        APS_HIP(hipMemsetAsync(num[l], 0, (size_t)lh[l] * lw[l] * sizeof(float4), stream()));
+    }
+    const Taps tp = make_taps(sigma);
+    Ws<float4> t1(hw), t2(hw), U(hw), rt, gA, gB;
+    for (int k = 0; k < K; ++k) {
+        const float4* G = layers[k];
+        Ws<float4>* next = &gA;
+        for (int l = 0; l < levels - 1; ++l) {
+            const int hl = lh[l], wl = lw[l], nh = lh[l + 1], nw = lw[l + 1];
+            const size_t n = (size_t)hl * wl;
+            blur_v_kernel<<<dim3(cdiv(wl, 256), hl), 256, 0, stream()>>>(G, hl, wl, tp, t1);
+            blur_h_kernel<<<dim3(cdiv(wl, 256), hl), 256, 0, stream()>>>(t1, hl, wl, tp, t2);
+            check_launch("blur");
+            next->alloc((size_t)nh * nw);
+            imresize4(t2, hl, wl, nh, nw, *next, rt);
+            imresize4(*next, nh, nw, hl, wl, U, rt);
+            lap_accum_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(G, U, n, num[l]);
+            check_launch("lap_accum_kernel");
+            G = next->get();
+            next = (next == &gA) ? &gB : &gA;
+        }
+        const size_t n = (size_t)lh[levels - 1] * lw[levels - 1];
+        coarse_accum_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(G, n, num[levels - 1]);
+        check_launch("coarse_accum_kernel");
+    }
+    // :163-167
+    if (levels == 1) {
+        APS_HIP(hipMemcpyAsync(F, num[0], hw * sizeof(float4), hipMemcpyDeviceToDevice, stream()));
+    } else {
+        const float4* cur = num[levels - 1];
+        for (int l = levels - 2; l >= 0; --l) {
+            const size_t n = (size_t)lh[l] * lw[l];
+            imresize4(cur, lh[l + 1], lw[l + 1], lh[l], lw[l], U, rt);
+            float4* dst = l == 0 ? F : (l % 2 ? t1.get() : t2.get());
+            add_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(U, num[l], n, dst);
+            check_launch("add_kernel");
+            cur = dst;
+        }
+    }
+    APS_HIP(hipStreamSynchronize(stream()));  // `layers` (host vector) was copied asynchronously
+}
+
+struct PreparedImages {
+    std::vector<Ws<uint32_t>> rgba;
+    std::vector<Ws<float>> wx, wy;
+    std::vector<In<uint8_t>> src;
+    std::vector<DevImage> host;
+    Ws<DevImage> dev;
+};
+
+static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
+    P.rgba.resize(n);
+    P.wx.resize(n);
+    P.wy.resize(n);
+    P.src.resize(n);
+    P.host.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const aps_image& im = images[i];
+        APS_REQUIRE(im.data != nullptr, APS_E_ARG, "image %d: NULL data", i);
+        APS_REQUIRE(im.height > 0 && im.width > 0, APS_E_DIM, "image %d: empty", i);
+        APS_REQUIRE(im.channels == 1 || im.channels == 3, APS_E_DIM, "image %d: channels must be 1 or 3", i);
+        APS_REQUIRE(im.layout == APS_IMG_U8_HWC || im.layout == APS_IMG_U8_MATLAB, APS_E_TYPE,
+                    "image %d: unknown layout", i);
+        const size_t px = (size_t)im.height * im.width;
+        P.src[i].bind(im.data, px * im.channels);
+        P.rgba[i].alloc(px);
+        to_rgba_kernel<<<dim3(cdiv(im.width, 256), im.height), 256, 0, stream()>>>(
+            P.src[i], im.height, im.width, im.channels, im.layout, P.rgba[i]);
+        check_launch("to_rgba_kernel");
+        std::vector<float> tx, ty;
+        host_tent(im.width, tx);
+        host_tent(im.height, ty);
+        P.wx[i].alloc(im.width);
+        P.wy[i].alloc(im.height);
+        APS_HIP(hipMemcpyAsync(P.wx[i], tx.data(), tx.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemcpyAsync(P.wy[i], ty.data(), ty.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));  // tx/ty are stack-lifetime host buffers
+        DevImage& d = P.host[i];
+        d.rgba = P.rgba[i];
+        d.wx = P.wx[i];
+        d.wy = P.wy[i];
+        d.h = im.height;
+        d.w = im.width;
+        for (int e = 0; e < 9; ++e) d.R[e] = (float)im.R[e];
+        d.fx = (float)im.K[0];
+        d.fy = (float)im.K[4];
+        d.cx = (float)im.K[6];
+        d.cy = (float)im.K[7];
+        for (int c = 0; c < 3; ++c) d.gain[c] = im.gain[c];
+    }
+    P.dev.alloc(n);
+    APS_HIP(hipMemcpyAsync(P.dev, P.host.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+}
+
+static DevCanvas make_canvas(const aps_canvas& c) {
+    APS_REQUIRE(c.mode >= APS_PROJ_CYLINDRICAL && c.mode <= APS_PROJ_STEREOGRAPHIC, APS_E_ARG, "unknown projection mode %d", c.mode);
+    APS_REQUIRE(c.height > 0 && c.width > 0, APS_E_DIM, "empty canvas");
+    APS_REQUIRE(c.f_pan > 0, APS_E_ARG, "fPan must be positive");
+    DevCanvas d;
+    d.mode = c.mode;
+    d.H = c.height;
+    d.W = c.width;
+    d.f = (float)c.f_pan;
+    d.o0 = (float)c.origin0;
+    d.o1 = (float)c.origin1;
+    // Rref entries in the order the ray formula uses them: row c of R_ref' = column c of R_ref
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) d.Rref[3 * col + row] = (float)c.R_ref[row + 3 * col];
+    return d;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_warp_tile(const aps_image* image, const aps_canvas* canvas, int r0, int c0, int ht, int wt,
+                  float angle_power, float* S, uint8_t* M, float* Wang, float* Wf) {
+    return guarded([&] {
+        APS_REQUIRE(image && canvas && S && M && Wang && Wf, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(ht > 0 && wt > 0 && r0 >= 0 && c0 >= 0, APS_E_ARG, "bad tile");
+        ctx();
+        PreparedImages P;
+        prepare_images(image, 1, P);
+        const DevCanvas cv = make_canvas(*canvas);
+        const size_t n = (size_t)ht * wt;
+        Out<float> oS(S, n * 3), oA(Wang, n), oF(Wf, n);
+        Out<uint8_t> oM(M, n);
+        warp_tile_kernel<<<dim3(cdiv(wt, 32), cdiv(ht, 8)), 256, 0, stream()>>>(cv, P.dev, r0, c0, ht, wt,
+                                                                                angle_power, oS, oM, oA, oF);
+        check_launch("warp_tile_kernel");
+        oS.commit();
+        oM.commit();
+        oA.commit();
+        oF.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_multiband_blend(const float* C, const float* Wt, int k, int h, int w, int levels, float sigma,
+                        float* F) {
+    return guarded([&] {
+        APS_REQUIRE(C && Wt && F, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(k >= 1 && h > 0 && w > 0, APS_E_DIM, "need K >= 1 non-empty layers");
+        APS_REQUIRE(levels >= 1, APS_E_ARG, "levels must be a positive integer");
+        APS_REQUIRE(sigma > 0, APS_E_ARG, "sigma must be positive");
+        ctx();
+        const size_t hw = (size_t)h * w;
+        In<float> dC(C, hw * 3 * k), dW(Wt, hw * k);
+        Out<float> oF(F, hw * 3);
+        std::vector<Ws<float4>> store(k);
+        std::vector<float4*> layers(k);
+        for (int i = 0; i < k; ++i) {
+            store[i].alloc(hw);
+            pack_layer_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dC.get() + (size_t)i * hw * 3,
+                                                                   dW.get() + (size_t)i * hw, hw, store[i]);
+            layers[i] = store[i];
+        }
+        check_launch("pack_layer_kernel");
+        Ws<float4> F4(hw);
+        multiband_device(layers, h, w, levels, sigma, F4);
+        unpack_clamp_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(F4, hw, 1, oF);
+        check_launch("unpack_clamp_kernel");
+        oF.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_linear_blend(const float* C, const float* Wt, int k, int h, int w, float* F) {
+    return guarded([&] {
+        APS_REQUIRE(C && Wt && F, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(k >= 1 && h > 0 && w > 0, APS_E_DIM, "need K >= 1 non-empty layers");
+        ctx();
+        const size_t hw = (size_t)h * w;
+        In<float> dC(C, hw * 3 * k), dW(Wt, hw * k);
+        Out<float> oF(F, hw * 3);
+        std::vector<Ws<float4>> store(k);
+        std::vector<float4*> layers(k);
+        for (int i = 0; i < k; ++i) {
+            store[i].alloc(hw);
+            pack_layer_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dC.get() + (size_t)i * hw * 3,
+                                                                   dW.get() + (size_t)i * hw, hw, store[i]);
+            layers[i] = store[i];
+        }
+        Ws<float4*> dl(k);
+        APS_HIP(hipMemcpyAsync(dl, layers.data(), k * sizeof(float4*), hipMemcpyHostToDevice, stream()));
+        Ws<float4> F4(hw);
+        linear_blend_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dl, k, hw, F4);
+        unpack_clamp_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(F4, hw, 0, oF);
+        check_launch("linear_blend_kernel");
+        oF.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
+               const aps_render_opts* opts, int out_layout, uint8_t* pano, uint8_t* covered) {
+    return guarded([&] {
+        APS_REQUIRE(images && canvas && opts && pano, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(n_img >= 1, APS_E_ARG, "need at least one image");
+        APS_REQUIRE(opts->tile_h > 0 && opts->tile_w > 0, APS_E_ARG,
+                    "opts.tile must be given explicitly (never derived from free memory)");
+        APS_REQUIRE(opts->blending >= APS_BLEND_NONE && opts->blending <= APS_BLEND_MULTIBAND, APS_E_ARG, "unknown blending");
+        APS_REQUIRE(out_layout == APS_IMG_U8_HWC || out_layout == APS_IMG_U8_MATLAB, APS_E_TYPE, "unknown output layout");
+        if (opts->blending == APS_BLEND_MULTIBAND) {
+            APS_REQUIRE(opts->pyr_levels >= 1, APS_E_ARG, "pyrLevels must be >= 1");
+            APS_REQUIRE(opts->pyr_sigma > 0, APS_E_ARG, "pyrSigma must be positive");
+        }
+        ctx();
+        PreparedImages P;
+        prepare_images(images, n_img, P);
+        const DevCanvas cv = make_canvas(*canvas);
+        const int H = cv.H, W = cv.W;
+        const size_t HW = (size_t)H * W;
+        Out<uint8_t> oP(pano, HW * 3), oC(covered, HW);
+        const int TH = opts->tile_h, TW = opts->tile_w;
+        const size_t tmax = (size_t)std::min(TH, H) * std::min(TW, W);
+        Ws<float4> F(tmax);
+        Ws<uint8_t> cov(tmax);
+        Ws<uint32_t> flags(n_img);
+        std::vector<uint32_t> hflags(n_img);
+        std::vector<Ws<float4>> store;
+        for (int r0 = 0; r0 < H; r0 += TH)
+            for (int c0 = 0; c0 < W; c0 += TW) {
+                const int ht = std::min(TH, H - r0), wt = std::min(TW, W - c0);
+                const size_t T = (size_t)ht * wt;
+                const dim3 g2(cdiv(wt, 32), cdiv(ht, 8));
+                APS_HIP(hipMemsetAsync(F, 0, T * sizeof(float4), stream()));
+                APS_HIP(hipMemsetAsync(cov, 0, T, stream()));
+                if (opts->blending == APS_BLEND_NONE) {
+                    for (int i = 0; i < n_img; ++i)
+                        none_fuse_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, i, r0, c0, ht, wt, opts->angle_power,
+                                                                   opts->none_policy, F, cov);
+                    check_launch("none_fuse_kernel");
+                } else {
+                    // contributors of this tile (the reference skips images with ~any(Mi), :989)
+                    APS_HIP(hipMemsetAsync(flags, 0, n_img * sizeof(uint32_t), stream()));
+                    cover_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, n_img, r0, c0, ht, wt, opts->angle_power, flags);
+                    check_launch("cover_kernel");
+                    APS_HIP(hipMemcpyAsync(hflags.data(), flags, n_img * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+                    APS_HIP(hipStreamSynchronize(stream()));
+                    std::vector<int> contrib;
+                    for (int i = 0; i < n_img; ++i)
+                        if (hflags[i]) contrib.push_back(i);
+                    const int K = (int)contrib.size();
+                    if (K > 0) {
+                        if ((int)store.size() < K) store.resize(K);
+                        std::vector<float4*> layers(K);
+                        const float wf_floor = opts->blending == APS_BLEND_LINEAR ? 1e-4f : 0.f;
+                        for (int k = 0; k < K; ++k) {
+                            if (store[k].n < T) store[k].alloc(tmax);
+                            layers[k] = store[k];
+                            warp_layer_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, contrib[k], r0, c0, ht, wt,
+                                                                        opts->angle_power, wf_floor, layers[k]);
+                        }
+                        check_launch("warp_layer_kernel");
+                        Ws<float4*> dl(K);
+                        APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
+                        if (opts->blending == APS_BLEND_LINEAR) {
+                            linear_fuse_kernel<<<cdiv(T, 256), 256, 0, stream()>>>(dl, K, T, F, cov);
+                            check_launch("linear_fuse_kernel");
+                            APS_HIP(hipStreamSynchronize(stream()));
+                        } else {
+                            norm_weights_kernel<<<cdiv(T, 256), 256, 0, stream()>>>(dl, K, T, 1, 0, cov);
+                            check_launch("norm_weights_kernel");
+                            multiband_device(layers, ht, wt, opts->pyr_levels, opts->pyr_sigma, F);
+                        }
+                    }
+                }
+                paint_kernel<<<dim3(cdiv(wt, 256), ht), 256, 0, stream()>>>(
+                    F, cov, r0, c0, ht, wt, H, W, opts->canvas_white, out_layout, oP,
+                    oC.present() ? oC.get() : nullptr);
+                check_launch("paint_kernel");
+            }
+        oP.commit();
+        oC.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+}  // extern "C"
+
+static void make_hwarp(const double* H, HWarp& hw) {
+    double h[9];
+    for (int e = 0; e < 9; ++e) h[e] = H[8] != 0 ? H[e] / H[8] : H[e];
+#define HH(r, c) h[(r) + 3 * (c)]
+    hw.A[0] = HH(1, 1) * HH(2, 2) - HH(1, 2) * HH(2, 1);
+    hw.A[3] = HH(0, 2) * HH(2, 1) - HH(0, 1) * HH(2, 2);
+    hw.A[6] = HH(0, 1) * HH(1, 2) - HH(0, 2) * HH(1, 1);
+    hw.A[1] = HH(1, 2) * HH(2, 0) - HH(1, 0) * HH(2, 2);
+    hw.A[4] = HH(0, 0) * HH(2, 2) - HH(0, 2) * HH(2, 0);
+    hw.A[7] = HH(0, 2) * HH(1, 0) - HH(0, 0) * HH(1, 2);
+    hw.A[2] = HH(1, 0) * HH(2, 1) - HH(1, 1) * HH(2, 0);
+    hw.A[5] = HH(0, 1) * HH(2, 0) - HH(0, 0) * HH(2, 1);
+    hw.A[8] = HH(0, 0) * HH(1, 1) - HH(0, 1) * HH(1, 0);
+    hw.det = (HH(0, 0) * hw.A[0] + HH(0, 1) * hw.A[1]) + HH(0, 2) * hw.A[2];
+#undef HH
+}
+
+template <class T>
+static int image_warp_impl(const T* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w,
+                           double x0, double y0, double sx, double sy, T fill, T* out) {
+    return guarded([&] {
+        APS_REQUIRE(in && H && out, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0 && c >= 1 && c <= 4, APS_E_DIM, "bad dimensions");
+        ctx();
+        HWarp hw;
+        make_hwarp(H, hw);
+        In<T> di(in, (size_t)in_h * in_w * c);
+        Out<T> oo(out, (size_t)out_h * out_w * c);
+        image_warp_h_kernel<T><<<dim3(cdiv(out_w, 256), out_h), 256, 0, stream()>>>(
+            di, in_h, in_w, c, hw, out_h, out_w, x0, y0, sx, sy, fill, oo);
+        check_launch("image_warp_h_kernel");
+        oo.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+extern "C" {
+
+int aps_image_warp_h_u8(const uint8_t* in, int in_h, int in_w, int c, const double* H, int out_h,
+                        int out_w, double x0, double y0, double sx, double sy, uint8_t fill,
+                        uint8_t* out) {
+    return image_warp_impl<uint8_t>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, out);
+}
+
+int aps_image_warp_h_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h,
+                         int out_w, double x0, double y0, double sx, double sy, float fill, float* out) {
+    return image_warp_impl<float>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, out);
+}
+
+}  // extern "C"

@@ -8,11 +8,5 @@ extern "C" {
 APS_STUB(aps_knn_global, const float*, int64_t, int64_t, const float*, int64_t, int64_t, int, int, int, uint32_t*, float*, int64_t)
 APS_STUB(aps_global_filter, const uint32_t*, const float*, int64_t, int, int64_t, int, const uint32_t*, const uint32_t*, int, float, int64_t*, uint32_t*, uint32_t*, int64_t, int64_t*)
 APS_STUB(aps_hamming_2nn, const uint8_t*, int64_t, int64_t, const uint8_t*, int64_t, int64_t, int, int, uint32_t*, float*, float*)
-APS_STUB(aps_render, const aps_image*, int, const aps_canvas*, const aps_render_opts*, int, uint8_t*, uint8_t*)
-APS_STUB(aps_warp_tile, const aps_image*, const aps_canvas*, int, int, int, int, float, float*, uint8_t*, float*, float*)
-APS_STUB(aps_multiband_blend, const float*, const float*, int, int, int, int, float, float*)
-APS_STUB(aps_linear_blend, const float*, const float*, int, int, int, float*)
-APS_STUB(aps_image_warp_h_u8, const uint8_t*, int, int, int, const double*, int, int, double, double, double, double, uint8_t, uint8_t*)
-APS_STUB(aps_image_warp_h_f32, const float*, int, int, int, const double*, int, int, double, double, double, double, float, float*)
 APS_STUB(aps_sift_extract, const uint8_t*, int, int, int, int, const aps_sift_params*, float*, int, int64_t, double*, int64_t, float*, int64_t, int64_t*)
 }

@@ -1,0 +1,310 @@
+"""Host-side mirror of PP/renderPanorama/renderPanorama.m: option defaults, bounds and canvas sizing stay
+on the host in float64 exactly as the reference computes them; the tile loop (rays, sampling, fusion,
+multiband blending, paint) runs on the device through aps_render.
+
+Cameras are dicts with 'K' and 'R' (3x3, world->camera), optionally 'noRotation' and 'H2refined'
+(cameras struct, initializeCameraMatrices.m:114-122).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib, ptr
+
+_MODES = {"cylindrical": _capi.APS_PROJ_CYLINDRICAL, "spherical": _capi.APS_PROJ_SPHERICAL,
+          "equirectangular": _capi.APS_PROJ_SPHERICAL, "planar": _capi.APS_PROJ_PLANAR,
+          "perspective": _capi.APS_PROJ_PLANAR, "stereographic": _capi.APS_PROJ_STEREOGRAPHIC}
+_BLEND = {"none": _capi.APS_BLEND_NONE, "linear": _capi.APS_BLEND_LINEAR, "multiband": _capi.APS_BLEND_MULTIBAND}
+_POLICY = {"last": _capi.APS_NONE_LAST, "first": _capi.APS_NONE_FIRST, "maxangle": _capi.APS_NONE_MAXANGLE}
+
+
+def default_opts(opts, cameras, refIdx):
+    """renderPanorama.m:41-71."""
+    o = dict(opts or {})
+    o.setdefault("fPan", float(np.asarray(cameras[refIdx]["K"])[0, 0]))
+    for k, v in (("resScale", 1.0), ("anglePower", 1), ("cropBorder", True), ("margin", 0.01),
+                 ("tile", None), ("maxMegapixel", 50), ("robustPct", (1, 99)), ("uvAbsCap", 8.0),
+                 ("pixelPad", 24), ("autoRef", True), ("canvasColor", "black"),
+                 ("gainCompensation", True), ("blending", "multiband"), ("pyrLevels", 3),
+                 ("pyrSigma", 1.0), ("composeNonePolicy", "last")):
+        o.setdefault(k, v)
+    return o
+
+
+def _grid_rays(cam, H, W, nx=48, ny=32, border=0):
+    xs = np.linspace(1, W, nx)
+    ys = np.linspace(1, H, ny)
+    U, V = np.meshgrid(xs, ys)
+    u = U.T.reshape(-1)  # MATLAB U(:) walks column-major
+    v = V.T.reshape(-1)
+    if border:
+        xb = np.linspace(1, W, border)
+        yb = np.linspace(1, H, border)
+        u = np.concatenate([u, xb, xb, np.ones(border), W * np.ones(border)])
+        v = np.concatenate([v, np.ones(border), H * np.ones(border), yb, yb])
+    xy1 = np.stack([u, v, np.ones_like(u)])
+    rayC = np.linalg.solve(np.asarray(cam["K"], np.float64), xy1)
+    return np.asarray(cam["R"], np.float64).T @ rayC
+
+
+def sphericalBounds(cams, imgSize):
+    """renderPanorama.m:1544-1579."""
+    tmin = pmin = math.inf
+    tmax = pmax = -math.inf
+    for i, cam in enumerate(cams):
+        x, y, z = _grid_rays(cam, imgSize[i][0], imgSize[i][1])
+        th = np.arctan2(x, z)
+        ph = np.arctan2(y, np.hypot(x, z))
+        tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
+        pmin, pmax = min(pmin, ph.min()), max(pmax, ph.max())
+    return tmin, tmax, pmin, pmax
+
+
+def cylindricalBounds(cams, imgSize):
+    """renderPanorama.m:1507-1542."""
+    tmin = hmin = math.inf
+    tmax = hmax = -math.inf
+    for i, cam in enumerate(cams):
+        x, y, z = _grid_rays(cam, imgSize[i][0], imgSize[i][1])
+        th = np.arctan2(x, z)
+        hh = y / np.hypot(x, z)
+        tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
+        hmin, hmax = min(hmin, hh.min()), max(hmax, hh.max())
+    return tmin, tmax, hmin, hmax
+
+
+def _prctile(x, p):
+    """MATLAB prctile: linear interpolation with sample i at 100*(i-0.5)/n percent."""
+    x = np.sort(np.asarray(x, np.float64))
+    n = x.size
+    pos = p / 100.0 * n + 0.5  # 1-based fractional rank
+    pos = min(max(pos, 1.0), float(n))
+    lo = int(math.floor(pos))
+    hi = min(lo + 1, n)
+    return x[lo - 1] + (pos - lo) * (x[hi - 1] - x[lo - 1])
+
+
+def planarBounds(cams, imgSize, Rref, robustPct, uvAbsCap):
+    """renderPanorama.m:1581-1665."""
+    umin = vmin = math.inf
+    umax = vmax = -math.inf
+    for i, cam in enumerate(cams):
+        rayR = np.asarray(Rref, np.float64) @ _grid_rays(cam, imgSize[i][0], imgSize[i][1], border=512)
+        zr = rayR[2]
+        m = zr > 1e-4
+        if not m.any():
+            continue
+        ur, vr = rayR[0, m] / zr[m], rayR[1, m] / zr[m]
+        if np.isfinite(uvAbsCap) and uvAbsCap > 0:
+            ur = np.clip(ur, -uvAbsCap, uvAbsCap)
+            vr = np.clip(vr, -uvAbsCap, uvAbsCap)
+        umin, umax = min(umin, _prctile(ur, robustPct[0])), max(umax, _prctile(ur, robustPct[1]))
+        vmin, vmax = min(vmin, _prctile(vr, robustPct[0])), max(vmax, _prctile(vr, robustPct[1]))
+    if not (np.isfinite(umin) and np.isfinite(umax)) or umin >= umax:
+        umin, umax = -1.0, 1.0
+    if not (np.isfinite(vmin) and np.isfinite(vmax)) or vmin >= vmax:
+        vmin, vmax = -1.0, 1.0
+    return umin, umax, vmin, vmax
+
+
+def stereographicBounds(cams, imgSize, Rref, robustPct, absCap):
+    """renderPanorama.m:1667-1754."""
+    amin = bmin = math.inf
+    amax = bmax = -math.inf
+    for i, cam in enumerate(cams):
+        rayR = np.asarray(Rref, np.float64) @ _grid_rays(cam, imgSize[i][0], imgSize[i][1], border=512)
+        nr = np.sqrt((rayR ** 2).sum(0))
+        xr, yr, zr = rayR / nr
+        den = 1 + zr
+        valid = den > 1e-6
+        if not valid.any():
+            continue
+        a, b = xr[valid] / den[valid], yr[valid] / den[valid]
+        if np.isfinite(absCap) and absCap > 0:
+            a = np.clip(a, -absCap, absCap)
+            b = np.clip(b, -absCap, absCap)
+        amin, amax = min(amin, _prctile(a, robustPct[0])), max(amax, _prctile(a, robustPct[1]))
+        bmin, bmax = min(bmin, _prctile(b, robustPct[0])), max(bmax, _prctile(b, robustPct[1]))
+    if not (np.isfinite(amin) and np.isfinite(amax)) or amin >= amax:
+        amin, amax = -1.0, 1.0
+    if not (np.isfinite(bmin) and np.isfinite(bmax)) or bmin >= bmax:
+        bmin, bmax = -1.0, 1.0
+    return amin, amax, bmin, bmax
+
+
+def canvas_geometry(cameras, imgSize, mode, refIdx, opts):
+    """Bounds + canvas size (renderPanorama.m:84-232).  Returns dict(mode, H, W, fPan, o0, o1, Rref, refIdx)."""
+    mode = str(mode).lower()
+    if mode not in _MODES:
+        raise ValueError("mode must be cylindrical, spherical, or planar/perspective")
+    o = opts
+    f = float(o["fPan"])
+    n = len(cameras)
+    if mode in ("planar", "perspective", "stereographic") and o["autoRef"]:  # :84-122
+        best, best_idx = math.inf, refIdx
+        for ii in range(n):
+            Rr = cameras[ii]["R"]
+            if mode == "stereographic":
+                a0, a1, b0, b1 = stereographicBounds(cameras, imgSize, Rr, o["robustPct"], o["uvAbsCap"])
+                ext = max(abs(a0), abs(a1), abs(b0), abs(b1)) * (1 + 2 * o["margin"]) + o["pixelPad"] / f
+                Wi = max(1, math.ceil(2 * f * ext * o["resScale"]))
+                area = float(Wi) * Wi
+            else:
+                u0, u1, v0, v1 = planarBounds(cameras, imgSize, Rr, o["robustPct"], o["uvAbsCap"])
+                du, dv = u1 - u0, v1 - v0
+                u0, u1 = u0 - o["margin"] * du - o["pixelPad"] / f, u1 + o["margin"] * du + o["pixelPad"] / f
+                v0, v1 = v0 - o["margin"] * dv - o["pixelPad"] / f, v1 + o["margin"] * dv + o["pixelPad"] / f
+                area = float(max(1, math.ceil(f * (u1 - u0) * o["resScale"]))) * max(1, math.ceil(f * (v1 - v0) * o["resScale"]))
+            if area < best:
+                best, best_idx = area, ii
+        refIdx = best_idx
+    Rref = np.asarray(cameras[refIdx]["R"], np.float64)
+    rs = o["resScale"]
+    if mode == "cylindrical":
+        a0, a1, b0, b1 = cylindricalBounds(cameras, imgSize)
+    elif mode in ("spherical", "equirectangular"):
+        a0, a1, b0, b1 = sphericalBounds(cameras, imgSize)
+    elif mode in ("planar", "perspective"):
+        a0, a1, b0, b1 = planarBounds(cameras, imgSize, Rref, o["robustPct"], o["uvAbsCap"])
+    else:
+        a0, a1, b0, b1 = stereographicBounds(cameras, imgSize, Rref, o["robustPct"], o["uvAbsCap"])
+        ext = max(abs(a0), abs(a1), abs(b0), abs(b1))
+        a0, a1, b0, b1 = -ext, ext, -ext, ext
+    da, db = a1 - a0, b1 - b0
+    a0, a1 = a0 - o["margin"] * da, a1 + o["margin"] * da
+    b0, b1 = b0 - o["margin"] * db, b1 + o["margin"] * db
+    if mode in ("planar", "perspective", "stereographic"):
+        a0, a1 = a0 - o["pixelPad"] / f, a1 + o["pixelPad"] / f
+        b0, b1 = b0 - o["pixelPad"] / f, b1 + o["pixelPad"] / f
+    W = max(1, math.ceil(f * (a1 - a0) * rs))
+    H = max(1, math.ceil(f * (b1 - b0) * rs))
+    if mode in ("planar", "perspective", "stereographic"):  # global pixel cap (:170-177)
+        maxPixel = round(o["maxMegapixel"] * 1e6)
+        if float(H) * float(W) > maxPixel:
+            s = math.sqrt(maxPixel / (float(H) * float(W)))
+            rs = rs * s
+            W = max(1, math.ceil(f * (a1 - a0) * rs))
+            H = max(1, math.ceil(f * (b1 - b0) * rs))
+    return {"mode": mode, "H": int(H), "W": int(W), "fPan": f, "o0": float(a0), "o1": float(b0),
+            "Rref": Rref, "refIdx": refIdx}
+
+
+def cropNonzeroBbox(panorama, canvasColor="black"):
+    """renderPanorama.m:1459-1504 (rgb2gray > 0 bounding box, 6 px pad)."""
+    p = panorama.astype(np.float64)
+    G = np.floor(0.298936021293775 * p[..., 0] + 0.587043074451121 * p[..., 1] + 0.114020904255103 * p[..., 2] + 0.5)
+    fg = (G < 255) if str(canvasColor).lower() == "white" else (G > 0)
+    rr, cc = np.nonzero(fg)
+    if rr.size == 0:
+        return panorama, (1, panorama.shape[0], 1, panorama.shape[1]), False
+    pad = 6
+    H, W = panorama.shape[:2]
+    r1, r2 = max(1, rr.min() + 1 - pad), min(H, rr.max() + 1 + pad)
+    c1, c2 = max(1, cc.min() + 1 - pad), min(W, cc.max() + 1 + pad)
+    return panorama[r1 - 1:r2, c1 - 1:c2], (r1, r2, c1, c2), True
+
+
+def make_image_structs(images, cameras, gains=None):
+    n = len(images)
+    arr = (_capi.aps_image * n)()
+    keep = []
+    for i, img in enumerate(images):
+        if _capi.is_torch(img):
+            t = img.contiguous()
+            h, w = t.shape[0], t.shape[1]
+            c = 1 if t.dim() == 2 else t.shape[2]
+        else:
+            t = np.ascontiguousarray(img, np.uint8)
+            h, w = t.shape[0], t.shape[1]
+            c = 1 if t.ndim == 2 else t.shape[2]
+        keep.append(t)
+        a = arr[i]
+        a.data = ptr(t)
+        a.height, a.width, a.channels, a.layout = int(h), int(w), int(c), _capi.APS_IMG_U8_HWC
+        K = np.asarray(cameras[i]["K"], np.float64)
+        R = np.asarray(cameras[i]["R"], np.float64)
+        for e in range(9):
+            a.K[e] = K[e % 3, e // 3]
+            a.R[e] = R[e % 3, e // 3]
+        g = (1.0, 1.0, 1.0) if gains is None else gains[i]
+        for ch in range(3):
+            a.gain[ch] = float(g[ch])
+    return arr, keep
+
+
+def make_canvas_struct(geo):
+    cv = _capi.aps_canvas()
+    cv.mode = _MODES[geo["mode"]]
+    cv.height, cv.width = geo["H"], geo["W"]
+    cv.f_pan, cv.origin0, cv.origin1 = geo["fPan"], geo["o0"], geo["o1"]
+    R = np.asarray(geo["Rref"], np.float64)
+    for e in range(9):
+        cv.R_ref[e] = R[e % 3, e // 3]
+    return cv
+
+
+def make_render_opts(opts):
+    ro = _capi.aps_render_opts()
+    tile = opts["tile"]
+    ro.tile_h, ro.tile_w = int(tile[0]), int(tile[1])
+    ro.angle_power = float(opts["anglePower"])
+    ro.blending = _BLEND[str(opts["blending"]).lower()]
+    ro.pyr_levels = int(opts["pyrLevels"])
+    ro.pyr_sigma = float(opts["pyrSigma"])
+    ro.none_policy = _POLICY[str(opts["composeNonePolicy"]).lower()]
+    ro.canvas_white = 1 if str(opts["canvasColor"]).lower() == "white" else 0
+    return ro
+
+
+def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gains=None,
+                   return_covered=False, device_out=False):
+    """[panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts)
+    (renderPanorama.m:1-500).  refIdx is 0-based here.  Differences that are deliberate:
+      * opts['tile'] must be explicit; the reference derives it from free GPU/CPU memory (:269-298),
+        which makes its multiband output machine dependent.  Default here: [2048 2048] clamped to the
+        canvas — the value the reference's auto-tiler reaches whenever memory is plentiful.
+      * gain compensation stays on the host (north star): pass `gains` (N x 3) or ones are used.
+      * annotations (insertShape/insertText) are not produced: rgbAnnotation is always None."""
+    if cameras and (cameras[0].get("noRotation", 0) == 1 or input.get("forcePlanarScan", False)):
+        raise NotImplementedError("planar-scan path (pureNonRotationalPanoramas) is served by imageWarp + blending")
+    o = default_opts(opts, cameras, refIdx)
+    imgSize = [tuple(int(v) for v in s) for s in imgSize]
+    geo = canvas_geometry(cameras, imgSize, mode, refIdx, o)
+    if o["tile"] is None:
+        side = max(512, min(2048, geo["H"], geo["W"])) if min(geo["H"], geo["W"]) >= 512 else min(geo["H"], geo["W"])
+        o["tile"] = (side, side)
+    arr, keep = make_image_structs(images, cameras, gains)
+    cv = make_canvas_struct(geo)
+    ro = make_render_opts(o)
+    H, W = geo["H"], geo["W"]
+    if device_out:
+        import torch
+
+        pano = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        cov = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    else:
+        pano = np.zeros((H, W, 3), np.uint8)
+        cov = np.zeros((H, W), np.uint8)
+    check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
+    del keep
+    if o["cropBorder"] and not device_out:
+        pano, _, _ = cropNonzeroBbox(pano, o["canvasColor"])
+    if return_covered:
+        return pano, None, cov, geo
+    return pano, None
+
+
+def warp_tile(image, camera, geo, r0, c0, ht, wt, anglePower=2.0, gain=(1.0, 1.0, 1.0)):
+    """sampleOneTile for one tile/image (renderPanorama.m:1063-1146): returns S, M, Wang, Wf."""
+    arr, keep = make_image_structs([image], [camera], [gain])
+    cv = make_canvas_struct(geo)
+    S = np.zeros((ht, wt, 3), np.float32)
+    M = np.zeros((ht, wt), np.uint8)
+    Wa = np.zeros((ht, wt), np.float32)
+    Wf = np.zeros((ht, wt), np.float32)
+    check(lib.aps_warp_tile(arr, C.byref(cv), r0, c0, ht, wt, float(anglePower), ptr(S), ptr(M), ptr(Wa), ptr(Wf)))
+    return S, M.astype(bool), Wa, Wf

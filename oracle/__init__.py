@@ -175,3 +175,148 @@ def ransac_homography(p1, p2, sample_idx, max_distance=5.5, confidence=99.9, max
                            float(max_distance), float(confidence), int(max_iter), model.ctypes.data,
                            mask.ctypes.data, C.byref(found), C.byref(trials))
     return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value
+
+
+# ---- render (render_oracle.c) ------------------------------------------------------------------------
+class orc_image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int), ("width", C.c_int), ("channels", C.c_int),
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("gain", C.c_float * 3)]
+
+
+class orc_canvas(C.Structure):
+    _fields_ = [("mode", C.c_int), ("height", C.c_int), ("width", C.c_int), ("f_pan", C.c_double),
+                ("origin0", C.c_double), ("origin1", C.c_double), ("R_ref", C.c_double * 9)]
+
+
+class orc_render_opts(C.Structure):
+    _fields_ = [("tile_h", C.c_int), ("tile_w", C.c_int), ("angle_power", C.c_float), ("blending", C.c_int),
+                ("pyr_levels", C.c_int), ("pyr_sigma", C.c_float), ("none_policy", C.c_int),
+                ("canvas_white", C.c_int)]
+
+
+_orc_tent = _sig("orc_tent", [_i, _vp])
+_orc_warp_tile = _sig("orc_warp_tile", [C.POINTER(orc_image), C.POINTER(orc_canvas), _i, _i, _i, _i, _f,
+                                        _vp, _vp, _vp, _vp])
+_orc_gaussfilt = _sig("orc_gaussfilt", [_vp, _i, _i, _i, _f, _vp])
+_orc_imresize = _sig("orc_imresize", [_vp, _i, _i, _i, _i, _i, _vp])
+_orc_multiband_blend = _sig("orc_multiband_blend", [_vp, _vp, _i, _i, _i, _i, _f, _vp])
+_orc_linear_blend = _sig("orc_linear_blend", [_vp, _vp, _i, _i, _i, _vp])
+_orc_render = _sig("orc_render", [C.POINTER(orc_image), _i, C.POINTER(orc_canvas),
+                                  C.POINTER(orc_render_opts), _vp, _vp])
+_orc_image_warp_h = _sig("orc_image_warp_h", [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _i, _vp])
+
+_MODE_IDS = {"cylindrical": 0, "spherical": 1, "equirectangular": 1, "planar": 2, "perspective": 2,
+             "stereographic": 3}
+_BLEND_IDS = {"none": 0, "linear": 1, "multiband": 2}
+_POLICY_IDS = {"last": 0, "first": 1, "maxangle": 2}
+
+
+def _images(images, cameras, gains=None):
+    n = len(images)
+    arr = (orc_image * n)()
+    keep = []
+    for i, img in enumerate(images):
+        t = np.ascontiguousarray(img, np.uint8)
+        keep.append(t)
+        a = arr[i]
+        a.data = t.ctypes.data
+        a.height, a.width = t.shape[0], t.shape[1]
+        a.channels = 1 if t.ndim == 2 else t.shape[2]
+        K = np.asarray(cameras[i]["K"], np.float64)
+        R = np.asarray(cameras[i]["R"], np.float64)
+        for e in range(9):
+            a.K[e] = K[e % 3, e // 3]
+            a.R[e] = R[e % 3, e // 3]
+        g = (1.0, 1.0, 1.0) if gains is None else gains[i]
+        for ch in range(3):
+            a.gain[ch] = float(g[ch])
+    return arr, keep
+
+
+def _canvas(geo):
+    cv = orc_canvas()
+    cv.mode = _MODE_IDS[geo["mode"]]
+    cv.height, cv.width = geo["H"], geo["W"]
+    cv.f_pan, cv.origin0, cv.origin1 = geo["fPan"], geo["o0"], geo["o1"]
+    R = np.asarray(geo["Rref"], np.float64)
+    for e in range(9):
+        cv.R_ref[e] = R[e % 3, e // 3]
+    return cv
+
+
+def tent(n):
+    w = np.zeros(n, np.float32)
+    _orc_tent(n, w.ctypes.data)
+    return w
+
+
+def warp_tile(image, camera, geo, r0, c0, ht, wt, angle_power=2.0, gain=(1.0, 1.0, 1.0)):
+    arr, keep = _images([image], [camera], [gain])
+    cv = _canvas(geo)
+    S = np.zeros((ht, wt, 3), np.float32)
+    M = np.zeros((ht, wt), np.uint8)
+    Wa = np.zeros((ht, wt), np.float32)
+    Wf = np.zeros((ht, wt), np.float32)
+    _orc_warp_tile(arr, C.byref(cv), r0, c0, ht, wt, float(angle_power), S.ctypes.data, M.ctypes.data,
+                   Wa.ctypes.data, Wf.ctypes.data)
+    return S, M.astype(bool), Wa, Wf
+
+
+def gaussfilt(img, sigma):
+    a = _f32(img)
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    out = np.zeros_like(a)
+    _orc_gaussfilt(a.ctypes.data, h, w, c, float(sigma), out.ctypes.data)
+    return out
+
+
+def imresize(img, oh, ow):
+    a = _f32(img)
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    out = np.zeros((oh, ow) + (() if a.ndim == 2 else (c,)), np.float32)
+    _orc_imresize(a.ctypes.data, h, w, c, oh, ow, out.ctypes.data)
+    return out
+
+
+def multiband_blend(C_, W_, levels, sigma=1.0):
+    C_ = _f32(C_)
+    W_ = _f32(W_)
+    K, h, w = W_.shape
+    F = np.zeros((h, w, 3), np.float32)
+    _orc_multiband_blend(C_.ctypes.data, W_.ctypes.data, K, h, w, int(levels), float(sigma), F.ctypes.data)
+    return F
+
+
+def linear_blend(C_, W_):
+    C_ = _f32(C_)
+    W_ = _f32(W_)
+    K, h, w = W_.shape
+    F = np.zeros((h, w, 3), np.float32)
+    _orc_linear_blend(C_.ctypes.data, W_.ctypes.data, K, h, w, F.ctypes.data)
+    return F
+
+
+def render(images, cameras, geo, tile, angle_power=2.0, blending="multiband", pyr_levels=3, pyr_sigma=1.0,
+           none_policy="last", canvas_white=False, gains=None):
+    arr, keep = _images(images, cameras, gains)
+    cv = _canvas(geo)
+    ro = orc_render_opts(int(tile[0]), int(tile[1]), float(angle_power), _BLEND_IDS[blending], int(pyr_levels),
+                         float(pyr_sigma), _POLICY_IDS[none_policy], int(bool(canvas_white)))
+    pano = np.zeros((geo["H"], geo["W"], 3), np.uint8)
+    cov = np.zeros((geo["H"], geo["W"]), np.uint8)
+    _orc_render(arr, len(images), C.byref(cv), C.byref(ro), pano.ctypes.data, cov.ctypes.data)
+    return pano, cov
+
+
+def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
+    a = np.asarray(img)
+    is_u8 = a.dtype == np.uint8
+    src = _f32(a if a.ndim == 3 else a[..., None])
+    Hc = np.ascontiguousarray(np.asarray(H, np.float64).T)
+    out = np.zeros((out_h, out_w, src.shape[2]), np.float32)
+    _orc_image_warp_h(src.ctypes.data, src.shape[0], src.shape[1], src.shape[2], Hc.ctypes.data, out_h, out_w,
+                      float(x0), float(y0), float(sx), float(sy), float(fill), int(is_u8), out.ctypes.data)
+    out = out.astype(np.uint8) if is_u8 else out
+    return out if a.ndim == 3 else out[..., 0]

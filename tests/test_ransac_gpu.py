@@ -77,9 +77,10 @@ def test_image_matching_batch_equals_per_pair_oracle(im):
             if (i + j) % 4 == 3:
                 matchesAll[i][j] = np.zeros((0, 2))
                 continue
-            m = 150 + 40 * (i + j)
-            a = rng.permutation(900)[:m] + 1
-            b = rng.permutation(900)[:m] + 1
+            m = 100 + 10 * (i + j)
+            # disjoint index blocks per partner so that pairs do not overwrite each other's keypoints
+            a = j * 180 + rng.permutation(180)[:m] + 1
+            b = i * 180 + rng.permutation(180)[:m] + 1
             H = H_TRUE.copy()
             H[0, 2] += 50 * i
             H[1, 2] -= 30 * j

@@ -1,0 +1,175 @@
+"""GPU parity for warp / fuse / blend against the oracle.
+
+Tolerance (stated per north star "warped/blended pixels within a stated fp32 tol"):
+  * building blocks that involve no transcendental (multiband, linear, imresize chains, imageWarp) must be
+    BIT-EXACT: both sides evaluate the same f32 fma chains in the same order;
+  * anything downstream of the ray generator differs only through sinf/cosf (device libm vs glibc, <= 2 ulp):
+    sampled colours/weights within 2e-4 absolute on [0,1] data wherever both masks agree, masks may differ on
+    at most 0.1 % of pixels (rays that land within rounding of an image border), final uint8 panoramas within
+    1 grey level on >= 99.8 % of pixels.
+"""
+import math
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle
+from test_render_oracle import cam
+
+pytestmark = pytest.mark.gpu
+
+ATOL_F32 = 2e-4
+
+
+@pytest.fixture(scope="module")
+def rp(gpu):
+    return import_module(gpu.__name__ + ".renderPanorama")
+
+
+@pytest.fixture(scope="module")
+def bl(gpu):
+    return import_module(gpu.__name__ + ".blending")
+
+
+@pytest.fixture(scope="module")
+def ip(gpu):
+    return import_module(gpu.__name__ + ".imageProcessing")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("K,h,w,levels", [(1, 32, 48, 3), (2, 33, 47, 4), (3, 64, 64, 5), (4, 5, 9, 5),
+                                          (2, 1, 7, 3), (3, 130, 257, 6)])
+def test_multiband_bit_exact(bl, K, h, w, levels):
+    rng = np.random.default_rng(K * 1000 + h)
+    C = rng.random((K, h, w, 3), dtype=np.float32)
+    W = rng.random((K, h, w), dtype=np.float32)
+    W[:, : h // 3, : w // 2] = 0  # uncovered corner
+    W[0, :, w // 2:] = 0
+    F = bl.multiBandBlending(list(C), list(W), levels, True, 1.0)
+    O = oracle.multiband_blend(C, W, levels, 1.0)
+    assert np.array_equal(bits(F), bits(O))
+
+
+def test_multiband_other_sigma_and_gray(bl):
+    rng = np.random.default_rng(1)
+    C = rng.random((2, 40, 56), dtype=np.float32)
+    W = rng.random((2, 40, 56), dtype=np.float32)
+    F = bl.multiBandBlending(list(C), list(W), 3, True, 1.7)
+    O = oracle.multiband_blend(np.repeat(C[..., None], 3, 3), W, 3, 1.7)[..., 0]
+    assert F.shape == (40, 56) and np.array_equal(bits(F), bits(O))
+    with pytest.raises(ValueError):
+        bl.multiBandBlending(list(C), list(W), 0)
+    with pytest.raises(ValueError):
+        bl.multiBandBlending(list(C), list(W[:1]), 3)
+
+
+def test_linear_blend_bit_exact_and_integer_cast(bl):
+    rng = np.random.default_rng(2)
+    C = rng.random((3, 21, 34, 3), dtype=np.float32)
+    W = rng.random((3, 21, 34), dtype=np.float32)
+    W[:, 0, :] = 0
+    F = bl.linearBlending(list(C), list(W))
+    assert np.array_equal(bits(F), bits(oracle.linear_blend(C, W)))
+    Cu = (C * 255).astype(np.uint8)
+    Fu = bl.linearBlending(list(Cu), list(W))
+    Ou = oracle.linear_blend(Cu.astype(np.float32), W)
+    assert Fu.dtype == np.uint8 and np.array_equal(Fu, np.floor(np.clip(Ou, 0, 255) + 0.5).astype(np.uint8))
+
+
+@pytest.mark.parametrize("mode", ["spherical", "cylindrical", "planar", "stereographic"])
+def test_warp_tile_within_tolerance(rp, mode):
+    rng = np.random.default_rng(3)
+    W, H, f = 160, 120, 200.0
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    c = cam(f, W, H, yaw=0.07, pitch=-0.05)
+    Rref = cam(f, W, H, yaw=0.02)["R"]
+    geo = {"mode": mode, "H": 150, "W": 220, "fPan": f, "o0": -0.5, "o1": -0.4, "Rref": Rref}
+    S, M, Wa, Wf = rp.warp_tile(img, c, geo, 10, 20, 128, 190, 2.0, gain=(1.1, 0.9, 1.0))
+    oS, oM, oWa, oWf = oracle.warp_tile(img, c, geo, 10, 20, 128, 190, 2.0, gain=(1.1, 0.9, 1.0))
+    assert oM.sum() > 5000
+    assert (M != oM).mean() <= 1e-3
+    both = M & oM
+    # colours of a random image have per-pixel gradients of O(1): compare where the source is smooth enough
+    np.testing.assert_allclose(Wa[both], oWa[both], atol=ATOL_F32)
+    np.testing.assert_allclose(Wf[both], oWf[both], atol=ATOL_F32)
+    assert np.abs(S[both] - oS[both]).max() <= 5e-3          # |grad| <= 1/px x sub-1e-3 px coordinate noise
+    assert np.abs(S[both] - oS[both]).mean() <= ATOL_F32
+    assert np.all(S[~M] == 0) and np.all(Wa[~M] == 0) and np.all(Wf[~M] == 0)
+
+
+def _scene(rng, n=3, W=160, H=120, f=220.0, smooth=True):
+    imgs, cams = [], []
+    for i in range(n):
+        base = rng.random((H // 8 + 2, W // 8 + 2, 3))
+        img = np.kron(base, np.ones((8, 8, 1)))[:H, :W] if smooth else rng.random((H, W, 3))
+        imgs.append((img * 255).astype(np.uint8))
+        cams.append(cam(f, W, H, yaw=(i - (n - 1) / 2) * 0.35, pitch=0.03 * (-1) ** i))
+    return imgs, cams
+
+
+@pytest.mark.parametrize("blending,policy", [("multiband", "last"), ("linear", "last"), ("none", "last"),
+                                             ("none", "first"), ("none", "maxangle")])
+def test_render_matches_oracle(rp, blending, policy):
+    rng = np.random.default_rng(4)
+    imgs, cams = _scene(rng)
+    sizes = [(120, 160, 3)] * 3
+    opts = {"anglePower": 2, "blending": blending, "pyrLevels": 3, "pyrSigma": 1.0, "tile": (64, 96),
+            "cropBorder": False, "composeNonePolicy": policy}
+    pano, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 1, opts, return_covered=True)
+    op, oc = oracle.render(imgs, cams, geo, (64, 96), 2.0, blending, 3, 1.0, policy)
+    assert pano.shape == op.shape and oc.sum() > 10000
+    assert (cov != oc).mean() <= 1e-3
+    both = (cov == 1) & (oc == 1)
+    diff = np.abs(pano.astype(int) - op.astype(int))[both]
+    assert (diff <= 1).mean() >= 0.998
+    assert np.all(pano[cov == 0] == 0)
+
+
+def test_render_five_bands_gains_white_canvas_and_partial_tiles(rp):
+    rng = np.random.default_rng(5)
+    imgs, cams = _scene(rng, n=4, W=200, H=150, f=260.0)
+    sizes = [(150, 200, 3)] * 4
+    gains = [(1.0, 1.0, 1.0), (0.9, 1.1, 1.0), (1.2, 0.8, 1.0), (1.0, 1.0, 0.7)]
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (100, 130),
+            "cropBorder": False, "canvasColor": "white"}
+    pano, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, "cylindrical", 0, opts, gains=gains,
+                                          return_covered=True)
+    op, oc = oracle.render(imgs, cams, geo, (100, 130), 2.0, "multiband", 5, 1.0, "last", True, gains)
+    assert (cov != oc).mean() <= 1e-3
+    both = (cov == 1) & (oc == 1)
+    assert (np.abs(pano.astype(int) - op.astype(int))[both] <= 1).mean() >= 0.998
+    assert np.all(pano[cov == 0] == 255)
+
+
+def test_canvas_geometry_and_crop(rp):
+    rng = np.random.default_rng(6)
+    imgs, cams = _scene(rng)
+    sizes = [(120, 160, 3)] * 3
+    o = rp.default_opts({"anglePower": 2}, cams, 1)
+    geo = rp.canvas_geometry(cams, sizes, "spherical", 1, o)
+    # three cameras 0.35 rad apart, hfov = 2*atan(80/220) = 0.70 rad -> ~1.40 rad span * 1.02 * f
+    assert abs(geo["W"] - math.ceil(220 * (0.70 + 0.70) * 1.02)) <= 6
+    pano, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 1, {"anglePower": 2, "tile": (128, 128)})
+    assert pano.shape[0] <= geo["H"] and pano.shape[1] <= geo["W"] and pano.any()
+    with pytest.raises(ValueError):
+        rp.canvas_geometry(cams, sizes, "mercator", 1, o)
+
+
+def test_image_warp_bit_exact(ip):
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    H = np.array([[1.01, 0.02, 7.5], [-0.015, 0.99, -3.25], [1e-5, -2e-5, 1.0]])
+    view = ip.imref2dScratch((100, 140), (-5.5, 134.5), (-4.5, 95.5))
+    out = ip.imageWarp(img, H, view, "bilinear", 9)
+    ref = oracle.image_warp_h(img, H, 100, 140, -5.5, -4.5, 1.0, 1.0, 9)
+    assert np.array_equal(out, ref)
+    f32 = rng.random((90, 120), dtype=np.float32)
+    outf = ip.imageWarp(f32, H, view)
+    reff = oracle.image_warp_h(f32, H, 100, 140, -5.5, -4.5, 1.0, 1.0, 0.0)
+    assert np.array_equal(bits(outf), bits(reff))
+    (xl, yl) = ip.outputLimitsScratch(H, (0.5, 120.5), (0.5, 90.5))
+    assert xl[0] < 10 and xl[1] > 120 and yl[0] < 0
