@@ -1,0 +1,893 @@
+// sift.hip — SIFT (Gaussian/DoG pyramid, extrema, orientation, 128-D descriptors) on gfx950.
+//
+// Stands behind PP/featureMatching/getFeaturePoints.m:26-40,71-74 (rgb2gray -> detectSIFTFeatures ->
+// extractFeatures).  The toolbox functions are closed; the algorithm is Lowe 2004 in OpenCV cv::SIFT's
+// parameterisation, with the order-independence choices documented in oracle/sift_oracle.c (fma-chain
+// Gaussians, 2^-20 fixed-point histograms, polynomial exp/atan2/sincos) so that this path and the oracle
+// agree bit for bit.
+//
+// Kernels
+//   gray_kernel / upsample2_kernel : uint8 (HWC or MATLAB planar) -> f32 gray -> 2x bilinear base.
+//   blur_kernel<R>                 : separable Gaussian, row pass then column pass fused through an LDS
+//                                    tile (reflect-101 border), register-blocked 8 outputs per thread;
+//                                    optionally writes the DoG (out - in) in the same pass, so every
+//                                    pyramid plane is read once and written once.
+//   extrema_kernel                 : 26-neighbour test + Newton refinement + contrast/edge tests.
+//   orient_kernel / descr_kernel   : one 64-lane wave per keypoint, histograms in LDS (int64 atomics).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "aps_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace aps {
+
+constexpr int kBorder = 5;
+constexpr int kMaxInterp = 5;
+constexpr int kOriBins = 36;
+constexpr float kFix = 1048576.0f;
+constexpr float kFltEps = 1.1920928955078125e-07f;
+
+// ---- elementary functions (identical formulas to oracle/sift_oracle.c) --------------------------
+__device__ __forceinline__ float poly_exp2(float f) {
+    float p = 1.5252733804059841e-05f;
+    p = fmaf(p, f, 1.5403530393381609e-04f);
+    p = fmaf(p, f, 1.3333558146428443e-03f);
+    p = fmaf(p, f, 9.6181291076284772e-03f);
+    p = fmaf(p, f, 5.5504108664821580e-02f);
+    p = fmaf(p, f, 2.4022650695910071e-01f);
+    p = fmaf(p, f, 6.9314718055994531e-01f);
+    p = fmaf(p, f, 1.0f);
+    return p;
+}
+__device__ __forceinline__ float my_exp2(float t) {
+    if (t < -125.0f) return 0.0f;
+    if (t > 125.0f) t = 125.0f;
+    const float n = rintf(t);
+    const float p = poly_exp2(t - n);
+    return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+__device__ __forceinline__ float my_exp(float x) { return my_exp2(x * 1.4426950408889634f); }
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f;
+    const float p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.0f - a;
+    if (y < 0) a = 360.0f - a;
+    return a;
+}
+
+__device__ __forceinline__ void sincos_deg(float a, float& s, float& c) {
+    const float k = rintf(a / 90.0f);
+    const float r = a - 90.0f * k;
+    const float x = r * 0.017453292519943295f, x2 = x * x;
+    float sp = 2.7557319223985893e-06f;
+    sp = fmaf(sp, x2, -1.9841269841269841e-04f);
+    sp = fmaf(sp, x2, 8.3333333333333332e-03f);
+    sp = fmaf(sp, x2, -1.6666666666666666e-01f);
+    sp = fmaf(sp * x2, x, x);
+    float cp = -2.7557319223985888e-07f;
+    cp = fmaf(cp, x2, 2.4801587301587302e-05f);
+    cp = fmaf(cp, x2, -1.3888888888888889e-03f);
+    cp = fmaf(cp, x2, 4.1666666666666664e-02f);
+    cp = fmaf(cp, x2, -0.5f);
+    cp = fmaf(cp, x2, 1.0f);
+    const int q = (((int)k % 4) + 4) % 4;
+    if (q == 0) {
+        s = sp;
+        c = cp;
+    } else if (q == 1) {
+        s = cp;
+        c = -sp;
+    } else if (q == 2) {
+        s = -sp;
+        c = -cp;
+    } else {
+        s = -cp;
+        c = sp;
+    }
+}
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * (n - 1) - p;
+    }
+    return p;
+}
+
+// ---- gray + base upsample -------------------------------------------------------------------------
+__global__ void gray_kernel(const uint8_t* __restrict__ img, int h, int w, int c, int layout,
+                            float* __restrict__ g) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    float v;
+    if (c == 1) {
+        v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * w + x] : img[(size_t)x * h + y]);
+    } else {
+        uint8_t ch[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            ch[k] = layout == APS_IMG_U8_HWC ? img[((size_t)y * w + x) * 3 + k]
+                                             : img[(size_t)k * h * w + (size_t)x * h + y];
+        const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
+        v = (float)floor(d + 0.5);
+    }
+    g[(size_t)y * w + x] = v;
+}
+
+__global__ void upsample2_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= 2 * w) return;
+    float fy = ((float)y + 0.5f) * 0.5f - 0.5f;
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    if (sy < 0) {
+        sy = 0;
+        fy = 0;
+    }
+    if (sy >= h - 1) {
+        sy = h - 1;
+        fy = 0;
+    }
+    const int sy1 = sy + 1 < h ? sy + 1 : h - 1;
+    float fx = ((float)x + 0.5f) * 0.5f - 0.5f;
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) {
+        sx = 0;
+        fx = 0;
+    }
+    if (sx >= w - 1) {
+        sx = w - 1;
+        fx = 0;
+    }
+    const int sx1 = sx + 1 < w ? sx + 1 : w - 1;
+    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+    const float h0 = in[(size_t)sy * w + sx] * a0 + in[(size_t)sy * w + sx1] * a1;
+    const float h1 = in[(size_t)sy1 * w + sx] * a0 + in[(size_t)sy1 * w + sx1] * a1;
+    out[(size_t)y * (2 * w) + x] = h0 * b0 + h1 * b1;
+}
+
+__global__ void decimate_kernel(const float* __restrict__ in, int h, int w, int oh, int ow,
+                                float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    out[(size_t)y * ow + x] = in[(size_t)min(2 * y, h - 1) * w + min(2 * x, w - 1)];
+}
+
+// ---- separable Gaussian through LDS ------------------------------------------------------------------
+struct GaussK {
+    float k[64];
+    int n;
+};
+
+constexpr int kTW = 64, kTH = 32;  // output tile per 256-thread workgroup
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
+                                                   float* __restrict__ out, float* __restrict__ dog) {
+    constexpr int IW = kTW + 2 * R, IH = kTH + 2 * R;
+    __shared__ float s_in[IH * IW];
+    __shared__ float s_row[IH * kTW];
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int ly = e / IW, lx = e - ly * IW;
+        const int gy = reflect101(y0 + ly - R, h), gx = reflect101(x0 + lx - R, w);
+        s_in[e] = in[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    // row pass: IH rows x 64 cols, 8 consecutive outputs per thread
+    for (int u = tid; u < IH * (kTW / 8); u += 256) {
+        const int ly = u / (kTW / 8), xb = (u - ly * (kTW / 8)) * 8;
+        float v[8 + 2 * R], acc[8];
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IW + xb + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * R + 1; ++t) {
+            const float kt = gk.k[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_row[ly * kTW + xb + j] = acc[j];
+    }
+    __syncthreads();
+    // column pass: 64 cols x 4 groups of 8 rows
+    {
+        const int lx = tid & 63, yb = (tid >> 6) * 8;
+        float v[8 + 2 * R], acc[8];
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(yb + j) * kTW + lx];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * R + 1; ++t) {
+            const float kt = gk.k[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
+        }
+        const int gx = x0 + lx;
+        if (gx < w) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int gy = y0 + yb + j;
+                if (gy < h) {
+                    out[(size_t)gy * w + gx] = acc[j];
+                    if (dog) dog[(size_t)gy * w + gx] = acc[j] - s_in[(yb + j + R) * IW + lx + R];
+                }
+            }
+        }
+    }
+}
+
+// generic fallback for unusual radii: two plain passes through global memory (same arithmetic)
+__global__ void blur_row_generic(const float* __restrict__ in, int h, int w, GaussK gk, float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int r = gk.n / 2;
+    float acc = 0.f;
+    for (int t = 0; t < gk.n; ++t) acc = fmaf(gk.k[t], in[(size_t)y * w + reflect101(x + t - r, w)], acc);
+    out[(size_t)y * w + x] = acc;
+}
+__global__ void blur_col_generic(const float* __restrict__ tmp, const float* __restrict__ in, int h, int w,
+                                 GaussK gk, float* __restrict__ out, float* __restrict__ dog) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int r = gk.n / 2;
+    float acc = 0.f;
+    for (int t = 0; t < gk.n; ++t) acc = fmaf(gk.k[t], tmp[(size_t)reflect101(y + t - r, h) * w + x], acc);
+    out[(size_t)y * w + x] = acc;
+    if (dog) dog[(size_t)y * w + x] = acc - in[(size_t)y * w + x];
+}
+
+// ---- pyramid description on the device ------------------------------------------------------------------
+struct OctaveDesc {
+    const float* G[8];  // nl + 3 <= 8 Gaussian planes
+    const float* D[7];  // nl + 2 DoG planes
+    int w, h;
+};
+
+struct KpRec {
+    unsigned long long key;  // (o << 40) | (layer << 32) | (r << 16) | c
+    float xc, xr, xi, contr;
+};
+
+#define AT(p, rr, cc) ((p)[(size_t)(rr) * w + (cc)])
+
+__device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, int r, int c, float contr_thr,
+                                float edge_thr, KpRec& kp) {
+    const int w = od.w, h = od.h;
+    const float img_scale = 1.0f / 255.0f, deriv_scale = img_scale * 0.5f, second_scale = img_scale,
+                cross_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0;
+    for (; i < kMaxInterp; ++i) {
+        const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
+        const float dD0 = (AT(im, r, c + 1) - AT(im, r, c - 1)) * deriv_scale;
+        const float dD1 = (AT(im, r + 1, c) - AT(im, r - 1, c)) * deriv_scale;
+        const float dD2 = (AT(nx, r, c) - AT(pv, r, c)) * deriv_scale;
+        const float v2 = AT(im, r, c) * 2.0f;
+        const float dxx = (AT(im, r, c + 1) + AT(im, r, c - 1) - v2) * second_scale;
+        const float dyy = (AT(im, r + 1, c) + AT(im, r - 1, c) - v2) * second_scale;
+        const float dss = (AT(nx, r, c) + AT(pv, r, c) - v2) * second_scale;
+        const float dxy = (AT(im, r + 1, c + 1) - AT(im, r + 1, c - 1) - AT(im, r - 1, c + 1) + AT(im, r - 1, c - 1)) * cross_scale;
+        const float dxs = (AT(nx, r, c + 1) - AT(nx, r, c - 1) - AT(pv, r, c + 1) + AT(pv, r, c - 1)) * cross_scale;
+        const float dys = (AT(nx, r + 1, c) - AT(nx, r - 1, c) - AT(pv, r + 1, c) + AT(pv, r - 1, c)) * cross_scale;
+        float A[3][4] = {{dxx, dxy, dxs, dD0}, {dxy, dyy, dys, dD1}, {dxs, dys, dss, dD2}};
+        bool singular = false;
+#pragma unroll
+        for (int col = 0; col < 3; ++col) {
+            if (singular) break;
+            int piv = col;
+#pragma unroll
+            for (int row = col + 1; row < 3; ++row)
+                if (fabsf(A[row][col]) > fabsf(A[piv][col])) piv = row;
+            if (fabsf(A[piv][col]) < kFltEps) {
+                singular = true;
+                break;
+            }
+            if (piv != col) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = A[piv][e];
+                    A[piv][e] = A[col][e];
+                    A[col][e] = t;
+                }
+            }
+            const float d = -1.0f / A[col][col];
+#pragma unroll
+            for (int row = col + 1; row < 3; ++row) {
+                const float alpha = A[row][col] * d;
+#pragma unroll
+                for (int e = col + 1; e < 4; ++e) A[row][e] = fmaf(alpha, A[col][e], A[row][e]);
+            }
+        }
+        float X[3] = {0, 0, 0};
+        if (!singular) {
+#pragma unroll
+            for (int row = 2; row >= 0; --row) {
+                float s = A[row][3];
+#pragma unroll
+                for (int e = row + 1; e < 3; ++e) s = s - A[row][e] * X[e];
+                X[row] = s / A[row][row];
+            }
+        }
+        xi = -X[2];
+        xr = -X[1];
+        xc = -X[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > 7.158278826666667e8f || fabsf(xr) > 7.158278826666667e8f || fabsf(xc) > 7.158278826666667e8f)
+            return false;
+        c += (int)rintf(xc);
+        r += (int)rintf(xr);
+        layer += (int)rintf(xi);
+        if (layer < 1 || layer > nl || c < kBorder || c >= w - kBorder || r < kBorder || r >= h - kBorder) return false;
+    }
+    if (i >= kMaxInterp) return false;
+    const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
+    const float dD0 = (AT(im, r, c + 1) - AT(im, r, c - 1)) * deriv_scale;
+    const float dD1 = (AT(im, r + 1, c) - AT(im, r - 1, c)) * deriv_scale;
+    const float dD2 = (AT(nx, r, c) - AT(pv, r, c)) * deriv_scale;
+    const float t = (dD0 * xc + dD1 * xr) + dD2 * xi;
+    const float contr = AT(im, r, c) * img_scale + t * 0.5f;
+    if (fabsf(contr) * (float)nl < contr_thr) return false;
+    const float v2 = AT(im, r, c) * 2.0f;
+    const float dxx = (AT(im, r, c + 1) + AT(im, r, c - 1) - v2) * second_scale;
+    const float dyy = (AT(im, r + 1, c) + AT(im, r - 1, c) - v2) * second_scale;
+    const float dxy = (AT(im, r + 1, c + 1) - AT(im, r + 1, c - 1) - AT(im, r - 1, c + 1) + AT(im, r - 1, c - 1)) * cross_scale;
+    const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+    if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return false;
+    kp.key = ((unsigned long long)o << 40) | ((unsigned long long)layer << 32) | ((unsigned long long)r << 16) |
+             (unsigned long long)c;
+    kp.xc = xc;
+    kp.xr = xr;
+    kp.xi = xi;
+    kp.contr = fabsf(contr);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr, float contr_thr,
+                                                      float edge_thr, KpRec* __restrict__ recs,
+                                                      unsigned int* __restrict__ count, unsigned int cap) {
+    const int w = od.w, h = od.h;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int layer = blockIdx.z + 1;
+    if (c < kBorder || c >= w - kBorder || r < kBorder || r >= h - kBorder) return;
+    const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
+    const float val = AT(im, r, c);
+    if (!(fabsf(val) > thr)) return;
+    bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+            const float a = AT(pv, r + dr, c + dc), b = AT(nx, r + dr, c + dc), m = AT(im, r + dr, c + dc);
+            if (!(val >= a && val >= b && val >= m)) is_max = false;
+            if (!(val <= a && val <= b && val <= m)) is_min = false;
+        }
+    if (!(is_max || is_min)) return;
+    KpRec kp;
+    if (!adjust_extremum(od, nl, o, layer, r, c, contr_thr, edge_thr, kp)) return;
+    const unsigned int slot = atomicAdd(count, 1u);
+    if (slot < cap) recs[slot] = kp;
+}
+#undef AT
+
+// ---- sort / dedupe helpers ---------------------------------------------------------------------------
+__global__ void rec_keys_kernel(const KpRec* __restrict__ recs, unsigned int n, unsigned long long* __restrict__ keys,
+                                unsigned int* __restrict__ idx) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = recs[i].key;
+    idx[i] = i;
+}
+__global__ void unique_flag_kernel(const unsigned long long* __restrict__ keys, unsigned int n,
+                                   unsigned int* __restrict__ flag) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ void compact_recs_kernel(const KpRec* __restrict__ recs, const unsigned int* __restrict__ idx,
+                                    const unsigned int* __restrict__ flag, const unsigned int* __restrict__ pos,
+                                    unsigned int n, KpRec* __restrict__ out) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    out[pos[i]] = recs[idx[i]];
+}
+
+// ---- orientation: one wave per keypoint ----------------------------------------------------------------
+struct PyrTable {
+    OctaveDesc oct[16];
+    int n_oct, nl;
+    float sigma;
+};
+
+__device__ __forceinline__ float kp_scale(float sigma, int layer, float xi, int nl) {
+    return sigma * my_exp2(((float)layer + xi) / (float)nl);
+}
+
+__global__ __launch_bounds__(256) void orient_kernel(const PyrTable* __restrict__ pt,
+                                                     const KpRec* __restrict__ kps, unsigned int n,
+                                                     unsigned int* __restrict__ ori_count,
+                                                     float* __restrict__ ori_angle /* n x 36 */,
+                                                     unsigned char* __restrict__ ori_bin /* n x 36 */) {
+    __shared__ unsigned long long s_hist[4][kOriBins];
+    __shared__ float s_h[4][kOriBins + 4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned int ki = blockIdx.x * 4 + wv;
+    const bool active = ki < n;
+    if (lane < kOriBins) s_hist[wv][lane] = 0ull;
+    __syncthreads();
+    int o = 0, layer = 1, r0 = 0, c0 = 0;
+    float xi = 0;
+    if (active) {
+        const KpRec kp = kps[ki];
+        o = (int)(kp.key >> 40);
+        layer = (int)((kp.key >> 32) & 0xff);
+        r0 = (int)((kp.key >> 16) & 0xffff);
+        c0 = (int)(kp.key & 0xffff);
+        xi = kp.xi;
+    }
+    const OctaveDesc& od = pt->oct[o];
+    const float* g = od.G[layer];
+    const int w = od.w, h = od.h;
+    const float scl = kp_scale(pt->sigma, layer, xi, pt->nl);
+    const int radius = (int)rintf(4.5f * scl);
+    const float sig = 1.5f * scl;
+    const float expf_scale = -1.0f / (2.0f * sig * sig);
+    const int side = 2 * radius + 1;
+    if (active) {
+        for (int s = lane; s < side * side; s += 64) {
+            const int i = s / side - radius, j = s % side - radius;
+            const int y = r0 + i, x = c0 + j;
+            if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
+            const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1];
+            const float dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
+            const float wgt = my_exp((float)(i * i + j * j) * expf_scale);
+            const float ori = fast_atan2_deg(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy);
+            int bin = (int)rintf(((float)kOriBins / 360.0f) * ori);
+            if (bin >= kOriBins) bin -= kOriBins;
+            if (bin < 0) bin += kOriBins;
+            const long long q = (long long)rintf((wgt * mag) * kFix);
+            atomicAdd(&s_hist[wv][bin], (unsigned long long)q);
+        }
+    }
+    __syncthreads();
+    if (lane < kOriBins) s_h[wv][lane + 2] = (float)(long long)s_hist[wv][lane] * (1.0f / kFix);
+    __syncthreads();
+    if (lane < 2) {
+        s_h[wv][lane] = s_h[wv][kOriBins + lane];
+        s_h[wv][kOriBins + 2 + lane] = s_h[wv][2 + lane];
+    }
+    __syncthreads();
+    float hv = 0.f;
+    if (lane < kOriBins)
+        hv = (s_h[wv][lane] + s_h[wv][lane + 4]) * (1.0f / 16.0f) + (s_h[wv][lane + 1] + s_h[wv][lane + 3]) * (4.0f / 16.0f) +
+             s_h[wv][lane + 2] * (6.0f / 16.0f);
+    __syncthreads();
+    if (lane < kOriBins) s_h[wv][lane] = hv;
+    __syncthreads();
+    if (active && lane == 0) {
+        float omax = s_h[wv][0];
+        for (int b = 1; b < kOriBins; ++b)
+            if (s_h[wv][b] > omax) omax = s_h[wv][b];
+        const float thr = omax * 0.8f;
+        unsigned int cnt = 0;
+        for (int j = 0; j < kOriBins; ++j) {
+            const int l = j > 0 ? j - 1 : kOriBins - 1, r2 = j < kOriBins - 1 ? j + 1 : 0;
+            const float hj = s_h[wv][j], hl = s_h[wv][l], hr = s_h[wv][r2];
+            if (hj > hl && hj > hr && hj >= thr) {
+                float bin = (float)j + 0.5f * (hl - hr) / (hl - 2.0f * hj + hr);
+                bin = bin < 0 ? (float)kOriBins + bin : (bin >= (float)kOriBins ? bin - (float)kOriBins : bin);
+                float angle = 360.0f - (360.0f / (float)kOriBins) * bin;
+                if (fabsf(angle - 360.0f) < kFltEps) angle = 0.0f;
+                ori_angle[(size_t)ki * kOriBins + cnt] = angle;
+                ori_bin[(size_t)ki * kOriBins + cnt] = (unsigned char)j;
+                ++cnt;
+            }
+        }
+        ori_count[ki] = cnt;
+    }
+}
+
+struct OrientedKp {
+    unsigned int kp;  // index into the keypoint records
+    float angle;
+};
+
+__global__ void expand_oriented_kernel(const unsigned int* __restrict__ ori_count,
+                                       const unsigned int* __restrict__ ori_pos,
+                                       const float* __restrict__ ori_angle, unsigned int n,
+                                       OrientedKp* __restrict__ out) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int c = ori_count[i], p = ori_pos[i];
+    for (unsigned int e = 0; e < c; ++e) {
+        out[p + e].kp = i;
+        out[p + e].angle = ori_angle[(size_t)i * kOriBins + e];
+    }
+}
+
+// ---- descriptor: one wave per oriented keypoint -------------------------------------------------------
+constexpr int kD = 4, kN = 8, kHistLen = (kD + 2) * (kD + 2) * (kN + 2);  // 360
+
+__global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__ pt,
+                                                    const KpRec* __restrict__ kps,
+                                                    const OrientedKp* __restrict__ oks, unsigned int n_out,
+                                                    float* __restrict__ desc, int desc_layout, int64_t ldd,
+                                                    double* __restrict__ loc, int64_t ldl,
+                                                    float* __restrict__ aux) {
+    __shared__ unsigned long long s_hist[4][kHistLen];
+    __shared__ float s_raw[4][128];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned int oi = blockIdx.x * 4 + wv;
+    const bool active = oi < n_out;
+    for (int e = lane; e < kHistLen; e += 64) s_hist[wv][e] = 0ull;
+    __syncthreads();
+    int o = 0, layer = 1, r0 = 0, c0 = 0;
+    float xc = 0, xr = 0, xi = 0, contr = 0, kangle = 0;
+    if (active) {
+        const OrientedKp ok = oks[oi];
+        const KpRec kp = kps[ok.kp];
+        o = (int)(kp.key >> 40);
+        layer = (int)((kp.key >> 32) & 0xff);
+        r0 = (int)((kp.key >> 16) & 0xffff);
+        c0 = (int)(kp.key & 0xffff);
+        xc = kp.xc;
+        xr = kp.xr;
+        xi = kp.xi;
+        contr = kp.contr;
+        kangle = ok.angle;
+    }
+    const OctaveDesc& od = pt->oct[o];
+    const float* g = od.G[layer];
+    const int w = od.w, h = od.h;
+    const float scl = kp_scale(pt->sigma, layer, xi, pt->nl);
+    float ori = 360.0f - kangle;
+    if (fabsf(ori - 360.0f) < kFltEps) ori = 0.0f;
+    const float ptx = (float)c0 + xc, pty = (float)r0 + xr;
+    const int px = (int)rintf(ptx), py = (int)rintf(pty);
+    float sin_t, cos_t;
+    sincos_deg(ori, sin_t, cos_t);
+    const float bins_per_deg = (float)kN / 360.0f;
+    const float exp_scale = -1.0f / ((float)(kD * kD) * 0.5f);
+    const float hist_width = 3.0f * scl;
+    int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(kD + 1) * 0.5f);
+    const int diag = (int)sqrt((double)w * w + (double)h * h);
+    if (radius > diag) radius = diag;
+    cos_t = cos_t / hist_width;
+    sin_t = sin_t / hist_width;
+    const int side = 2 * radius + 1;
+    if (active) {
+        for (int s = lane; s < side * side; s += 64) {
+            const int i = s / side - radius, j = s % side - radius;
+            const float c_rot = (float)j * cos_t - (float)i * sin_t;
+            const float r_rot = (float)j * sin_t + (float)i * cos_t;
+            float rbin = r_rot + (float)(kD / 2) - 0.5f;
+            float cbin = c_rot + (float)(kD / 2) - 0.5f;
+            const int r = py + i, c = px + j;
+            if (!(rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
+            const float dx = g[(size_t)r * w + c + 1] - g[(size_t)r * w + c - 1];
+            const float dy = g[(size_t)(r - 1) * w + c] - g[(size_t)(r + 1) * w + c];
+            const float wgt = my_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            const float o_deg = fast_atan2_deg(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            float obin = (o_deg - ori) * bins_per_deg;
+            const int rr0 = (int)floorf(rbin), cc0 = (int)floorf(cbin);
+            int o0 = (int)floorf(obin);
+            rbin -= (float)rr0;
+            cbin -= (float)cc0;
+            obin -= (float)o0;
+            if (o0 < 0) o0 += kN;
+            if (o0 >= kN) o0 -= kN;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
+            const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
+            const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
+            const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
+            const int idx = ((rr0 + 1) * (kD + 2) + cc0 + 1) * (kN + 2) + o0;
+            unsigned long long* hb = &s_hist[wv][idx];
+#define ADDQ(off, v) atomicAdd(hb + (off), (unsigned long long)(long long)rintf((v) * kFix))
+            ADDQ(0, v000);
+            ADDQ(1, v001);
+            ADDQ(kN + 2, v010);
+            ADDQ(kN + 3, v011);
+            ADDQ((kD + 2) * (kN + 2), v100);
+            ADDQ((kD + 2) * (kN + 2) + 1, v101);
+            ADDQ((kD + 3) * (kN + 2), v110);
+            ADDQ((kD + 3) * (kN + 2) + 1, v111);
+#undef ADDQ
+        }
+    }
+    __syncthreads();
+    // finalize: 128 outputs, two per lane
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = lane + 64 * half;  // (i*kD + j)*kN + k
+        const int k = e & 7, ij = e >> 3, i = ij >> 2, j = ij & 3;
+        const int idx = ((i + 1) * (kD + 2) + (j + 1)) * (kN + 2);
+        long long v = (long long)s_hist[wv][idx + k];
+        if (k < 2) v += (long long)s_hist[wv][idx + kN + k];
+        s_raw[wv][e] = (float)v * (1.0f / kFix);
+    }
+    __syncthreads();
+    if (!active) return;
+    // the norms are k-ascending fma chains: every lane walks the same chain (LDS broadcast reads)
+    float nrm2 = 0;
+    for (int k = 0; k < 128; ++k) nrm2 = fmaf(s_raw[wv][k], s_raw[wv][k], nrm2);
+    const float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0;
+    for (int k = 0; k < 128; ++k) {
+        const float v = s_raw[wv][k] < thr ? s_raw[wv][k] : thr;
+        nrm2 = fmaf(v, v, nrm2);
+    }
+    const float sn = sqrtf(nrm2);
+    const float scale = 512.0f / (sn > kFltEps ? sn : kFltEps);
+    float qq = 0;
+    for (int k = 0; k < 128; ++k) {
+        const float v0 = s_raw[wv][k] < thr ? s_raw[wv][k] : thr;
+        float v = rintf(v0 * scale);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        qq = fmaf(v, v, qq);
+    }
+    const float inv = sqrtf(qq);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = lane + 64 * half;
+        const float v0 = s_raw[wv][e] < thr ? s_raw[wv][e] : thr;
+        float v = rintf(v0 * scale);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        const float outv = inv > 0 ? v / inv : 0.0f;
+        if (desc_layout == APS_ROWMAJOR)
+            desc[(size_t)oi * ldd + e] = outv;
+        else
+            desc[(size_t)e * ldd + oi] = outv;
+    }
+    if (lane == 0) {
+        const float s = ldexpf(1.0f, o) * 0.5f;
+        loc[oi] = (double)(ptx * s) + 1.0;
+        loc[ldl + oi] = (double)(pty * s) + 1.0;
+        if (aux) {
+            aux[(size_t)oi * 4 + 0] = scl * s * 2.0f;
+            aux[(size_t)oi * 4 + 1] = kangle;
+            aux[(size_t)oi * 4 + 2] = contr;
+            aux[(size_t)oi * 4 + 3] = (float)(o + 256 * layer);
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static GaussK make_gauss(double sigma) {
+    GaussK g;
+    int n = (int)std::lrint(sigma * 8.0 + 1.0) | 1;
+    if (n > 63) n = 63;
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        g.k[i] = (float)std::exp(s2 * x * x);
+        sum += g.k[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; ++i) g.k[i] = (float)(g.k[i] * sum);
+    g.n = n;
+    return g;
+}
+
+static void launch_blur(const float* in, int h, int w, double sigma, float* out, float* dog, Ws<float>& scratch) {
+    const GaussK gk = make_gauss(sigma);
+    const int r = gk.n / 2;
+    const dim3 grid(cdiv(w, kTW), cdiv(h, kTH));
+    switch (r) {
+#define APS_BLUR_CASE(R) \
+    case R:              \
+        blur_kernel<R><<<grid, 256, 0, stream()>>>(in, h, w, gk, out, dog); \
+        break;
+        APS_BLUR_CASE(1)
+        APS_BLUR_CASE(2)
+        APS_BLUR_CASE(3)
+        APS_BLUR_CASE(4)
+        APS_BLUR_CASE(5)
+        APS_BLUR_CASE(6)
+        APS_BLUR_CASE(7)
+        APS_BLUR_CASE(8)
+        APS_BLUR_CASE(9)
+        APS_BLUR_CASE(10)
+        APS_BLUR_CASE(11)
+        APS_BLUR_CASE(12)
+#undef APS_BLUR_CASE
+        default: {
+            if (scratch.n < (size_t)h * w) scratch.alloc((size_t)h * w);
+            blur_row_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(in, h, w, gk, scratch);
+            blur_col_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(scratch, in, h, w, gk, out, dog);
+        }
+    }
+    check_launch("blur_kernel");
+}
+
+static int num_octaves(int H, int W) {
+    const int mn = std::min(2 * W, 2 * H);
+    return (int)std::lrint(std::log((double)mn) / std::log(2.0) - 2.0) + 1;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_sift_extract(const uint8_t* img, int height, int width, int channels, int img_layout,
+                     const aps_sift_params* params, float* desc, int desc_layout, int64_t ldd,
+                     double* loc, int64_t ldl, float* aux, int64_t cap, int64_t* count) {
+    return guarded([&] {
+        APS_REQUIRE(img && params && count, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(height > 0 && width > 0, APS_E_DIM, "empty image");
+        APS_REQUIRE(channels == 1 || channels == 3, APS_E_DIM, "channels must be 1 or 3");
+        APS_REQUIRE(img_layout == APS_IMG_U8_HWC || img_layout == APS_IMG_U8_MATLAB, APS_E_TYPE, "unknown image layout");
+        APS_REQUIRE(desc_layout == APS_ROWMAJOR || desc_layout == APS_COLMAJOR, APS_E_TYPE, "unknown descriptor layout");
+        APS_REQUIRE(params->n_layers >= 1 && params->n_layers <= 5, APS_E_ARG, "NumLayersInOctave must be in 1..5");
+        APS_REQUIRE(params->sigma > 0.5, APS_E_ARG, "Sigma must exceed the assumed camera blur 0.5");
+        APS_REQUIRE(params->contrast_threshold >= 0 && params->edge_threshold >= 1, APS_E_ARG, "bad thresholds");
+        APS_REQUIRE(cap >= 0, APS_E_ARG, "negative capacity");
+        APS_REQUIRE(2 * (int64_t)height < 65536 && 2 * (int64_t)width < 65536, APS_E_DIM, "image side must be < 32768");
+        ctx();
+        *count = 0;
+        const int nl = params->n_layers;
+        const int H = height, W = width;
+        In<uint8_t> dimg(img, (size_t)H * W * channels);
+        Ws<float> gray((size_t)H * W), up((size_t)4 * H * W), scratch;
+        gray_kernel<<<dim3(cdiv(W, 256), H), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, gray);
+        upsample2_kernel<<<dim3(cdiv(2 * W, 256), 2 * H), 256, 0, stream()>>>(gray, H, W, up);
+        check_launch("upsample2_kernel");
+        const int n_oct = std::min(num_octaves(H, W), 16);
+        if (n_oct <= 0) return;
+        // pyramid storage
+        std::vector<Ws<float>> G((size_t)n_oct * (nl + 3)), D((size_t)n_oct * (nl + 2));
+        PyrTable table;
+        std::memset(&table, 0, sizeof table);
+        table.n_oct = n_oct;
+        table.nl = nl;
+        table.sigma = (float)params->sigma;
+        double sig[16];
+        sig[0] = params->sigma;
+        const double kf = std::pow(2.0, 1.0 / nl);
+        for (int i = 1; i < nl + 3; ++i) {
+            const double sp = std::pow(kf, (double)(i - 1)) * params->sigma, st = sp * kf;
+            sig[i] = std::sqrt(st * st - sp * sp);
+        }
+        int ow = 2 * W, oh = 2 * H;
+        for (int o = 0; o < n_oct; ++o) {
+            if (o > 0) {
+                ow = std::max(1, ow / 2);
+                oh = std::max(1, oh / 2);
+            }
+            OctaveDesc& od = table.oct[o];
+            od.w = ow;
+            od.h = oh;
+            const size_t px = (size_t)ow * oh;
+            for (int i = 0; i < nl + 3; ++i) G[o * (nl + 3) + i].alloc(px);
+            for (int i = 0; i < nl + 2; ++i) D[o * (nl + 2) + i].alloc(px);
+            if (o == 0) {
+                double sd = params->sigma * params->sigma - 4.0 * 0.5 * 0.5;
+                if (sd < 0.01) sd = 0.01;
+                launch_blur(up, oh, ow, std::sqrt(sd), G[0], nullptr, scratch);
+            } else {
+                const OctaveDesc& pd = table.oct[o - 1];
+                decimate_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(G[(o - 1) * (nl + 3) + nl], pd.h, pd.w,
+                                                                            oh, ow, G[o * (nl + 3)]);
+                check_launch("decimate_kernel");
+            }
+            for (int i = 1; i < nl + 3; ++i)
+                launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], D[o * (nl + 2) + i - 1], scratch);
+            for (int i = 0; i < nl + 3; ++i) od.G[i] = G[o * (nl + 3) + i];
+            for (int i = 0; i < nl + 2; ++i) od.D[i] = D[o * (nl + 2) + i];
+        }
+        // extrema
+        const unsigned int cand_cap = (unsigned int)std::min<size_t>(
+            params->max_features > 0 ? (size_t)params->max_features : std::max<size_t>((size_t)H * W / 2, 65536), 1u << 26);
+        Ws<KpRec> recs(cand_cap);
+        Ws<unsigned int> d_count(1);
+        APS_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream()));
+        const float thr = (float)(int)std::floor(0.5 * params->contrast_threshold / nl * 255.0);
+        for (int o = 0; o < n_oct; ++o) {
+            const OctaveDesc& od = table.oct[o];
+            if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
+            extrema_kernel<<<dim3(cdiv(od.w, 64), cdiv(od.h, 4), nl), 256, 0, stream()>>>(
+                od, nl, o, thr, (float)params->contrast_threshold, (float)params->edge_threshold, recs, d_count, cand_cap);
+            check_launch("extrema_kernel");
+        }
+        unsigned int n_cand = 0;
+        APS_HIP(hipMemcpyAsync(&n_cand, d_count, sizeof n_cand, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (n_cand > cand_cap)
+            fail(APS_E_CAP, "SIFT found %u extrema, more than the candidate capacity %u (raise params.max_features)", n_cand, cand_cap);
+        if (n_cand == 0) return;
+        // canonical order + dedupe
+        Ws<unsigned long long> keys(n_cand), keys_s(n_cand);
+        Ws<unsigned int> idx(n_cand), idx_s(n_cand), flag(n_cand), pos(n_cand);
+        rec_keys_kernel<<<cdiv(n_cand, 256), 256, 0, stream()>>>(recs, n_cand, keys, idx);
+        size_t tb = 0;
+        APS_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.get(), keys_s.get(), idx.get(), idx_s.get(), n_cand, 0, 44, stream()));
+        Ws<char> tmp(tb);
+        APS_HIP(rocprim::radix_sort_pairs(tmp.get(), tb, keys.get(), keys_s.get(), idx.get(), idx_s.get(), n_cand, 0, 44, stream()));
+        unique_flag_kernel<<<cdiv(n_cand, 256), 256, 0, stream()>>>(keys_s, n_cand, flag);
+        size_t tb2 = 0;
+        APS_HIP(rocprim::exclusive_scan(nullptr, tb2, flag.get(), pos.get(), 0u, n_cand, rocprim::plus<unsigned int>(), stream()));
+        Ws<char> tmp2(tb2);
+        APS_HIP(rocprim::exclusive_scan(tmp2.get(), tb2, flag.get(), pos.get(), 0u, n_cand, rocprim::plus<unsigned int>(), stream()));
+        unsigned int last_pos = 0, last_flag = 0;
+        APS_HIP(hipMemcpyAsync(&last_pos, pos.get() + n_cand - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(&last_flag, flag.get() + n_cand - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        const unsigned int n_kp = last_pos + last_flag;
+        Ws<KpRec> kps(n_kp);
+        compact_recs_kernel<<<cdiv(n_cand, 256), 256, 0, stream()>>>(recs, idx_s, flag, pos, n_cand, kps);
+        check_launch("compact_recs_kernel");
+        // orientations
+        Ws<PyrTable> d_table(1);
+        APS_HIP(hipMemcpyAsync(d_table, &table, sizeof table, hipMemcpyHostToDevice, stream()));
+        Ws<unsigned int> ocount(n_kp), opos(n_kp);
+        Ws<float> oangle((size_t)n_kp * kOriBins);
+        Ws<unsigned char> obin((size_t)n_kp * kOriBins);
+        orient_kernel<<<cdiv(n_kp, 4), 256, 0, stream()>>>(d_table, kps, n_kp, ocount, oangle, obin);
+        check_launch("orient_kernel");
+        size_t tb3 = 0;
+        APS_HIP(rocprim::exclusive_scan(nullptr, tb3, ocount.get(), opos.get(), 0u, n_kp, rocprim::plus<unsigned int>(), stream()));
+        Ws<char> tmp3(tb3);
+        APS_HIP(rocprim::exclusive_scan(tmp3.get(), tb3, ocount.get(), opos.get(), 0u, n_kp, rocprim::plus<unsigned int>(), stream()));
+        unsigned int lp = 0, lc = 0;
+        APS_HIP(hipMemcpyAsync(&lp, opos.get() + n_kp - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(&lc, ocount.get() + n_kp - 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        const unsigned int n_out = lp + lc;
+        *count = n_out;
+        if ((int64_t)n_out > cap) fail(APS_E_CAP, "feature capacity %lld < %u features", (long long)cap, n_out);
+        if (n_out == 0) return;
+        APS_REQUIRE(desc && loc, APS_E_ARG, "NULL output with features present");
+        if (desc_layout == APS_ROWMAJOR)
+            APS_REQUIRE(ldd >= 128, APS_E_DIM, "ldd < 128");
+        else
+            APS_REQUIRE(ldd >= n_out, APS_E_DIM, "ldd < count");
+        APS_REQUIRE(ldl >= n_out, APS_E_DIM, "ldl < count");
+        Ws<OrientedKp> oks(n_out);
+        expand_oriented_kernel<<<cdiv(n_kp, 256), 256, 0, stream()>>>(ocount, opos, oangle, n_kp, oks);
+        check_launch("expand_oriented_kernel");
+        const size_t desc_elems = desc_layout == APS_ROWMAJOR ? (size_t)(n_out - 1) * ldd + 128 : (size_t)127 * ldd + n_out;
+        Out<float> odesc(desc, desc_elems), oaux(aux, (size_t)n_out * 4);
+        Out<double> oloc(loc, (size_t)ldl + n_out);
+        descr_kernel<<<cdiv(n_out, 4), 256, 0, stream()>>>(d_table, kps, oks, n_out, odesc, desc_layout, ldd, oloc, ldl,
+                                                           oaux.present() ? oaux.get() : nullptr);
+        check_launch("descr_kernel");
+        odesc.commit();
+        oloc.commit();
+        oaux.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+}  // extern "C"

@@ -8,5 +8,4 @@ extern "C" {
 APS_STUB(aps_knn_global, const float*, int64_t, int64_t, const float*, int64_t, int64_t, int, int, int, uint32_t*, float*, int64_t)
 APS_STUB(aps_global_filter, const uint32_t*, const float*, int64_t, int, int64_t, int, const uint32_t*, const uint32_t*, int, float, int64_t*, uint32_t*, uint32_t*, int64_t, int64_t*)
 APS_STUB(aps_hamming_2nn, const uint8_t*, int64_t, int64_t, const uint8_t*, int64_t, int64_t, int, int, uint32_t*, float*, float*)
-APS_STUB(aps_sift_extract, const uint8_t*, int, int, int, int, const aps_sift_params*, float*, int, int64_t, double*, int64_t, float*, int64_t, int64_t*)
 }

@@ -164,3 +164,67 @@ def featureMatchingPairwise(input, allDescriptors, numImg):
         s, e = pair_ptr[p], pair_ptr[p + 1]
         matches[i][j] = np.stack([ii[s:e], jj[s:e]], axis=1).astype(np.float64)
     return matches
+
+
+# ---- getFeaturePoints (getFeaturePoints.m:1-76) ----------------------------------------------------
+def _sift_params(input):
+    p = _capi.aps_sift_params()
+    p.sigma = float(input.get("Sigma", 1.6))
+    p.n_layers = int(input.get("NumLayersInOctave", 4))
+    p.contrast_threshold = float(input.get("ContrastThreshold", 0.00133))
+    p.edge_threshold = float(input.get("EdgeThreshold", 6))
+    p.max_features = int(input.get("maxFeatures", 0))
+    return p
+
+
+def sift_extract(input, image, device_out=False, want_aux=False):
+    """aps_sift_extract with automatic capacity: returns (features, validPts[, aux]).
+
+    image: H x W x 3 or H x W uint8, numpy (host) or torch (host/device), row-major.
+    device_out=True keeps the descriptors on the GPU (torch float32 [n,128]) for the resident pipeline."""
+    if _capi.is_torch(image):
+        img = image.contiguous()
+        h, w = int(img.shape[0]), int(img.shape[1])
+        c = 1 if img.dim() == 2 else int(img.shape[2])
+    else:
+        img = np.ascontiguousarray(image, np.uint8)
+        h, w = img.shape[:2]
+        c = 1 if img.ndim == 2 else img.shape[2]
+    if c not in (1, 3):
+        raise ValueError("image must be gray or RGB")
+    prm = _sift_params(input)
+    cap = max(4096, (h * w) // 64)
+    cnt = C.c_int64(0)
+    while True:
+        if device_out:
+            import torch
+
+            desc = torch.empty((cap, DIM), dtype=torch.float32, device="cuda")
+        else:
+            desc = np.zeros((cap, DIM), np.float32)
+        loc = np.zeros((2, cap), np.float64)  # column-major cap x 2
+        aux = np.zeros((cap, 4), np.float32) if want_aux else None
+        rc = lib.aps_sift_extract(ptr(img), h, w, c, _capi.APS_IMG_U8_HWC, C.byref(prm), ptr(desc),
+                                  _capi.APS_ROWMAJOR, DIM, ptr(loc), cap, ptr(aux), cap, C.byref(cnt))
+        if rc == _capi.APS_E_CAP and cnt.value > cap:
+            cap = int(cnt.value)
+            continue
+        check(rc)
+        break
+    n = cnt.value
+    pts = np.ascontiguousarray(loc[:, :n].T)
+    if want_aux:
+        return desc[:n], pts, aux[:n]
+    return desc[:n], pts
+
+
+def getFeaturePoints(input, ImageOriginal):
+    """[features, validPts] = getFeaturePoints(input, ImageOriginal) (getFeaturePoints.m:1-76) for
+    input.detector == 'SIFT': features Kf x 128 single (unit norm), validPts Kf x 2 double [x y] 1-based.
+    The other detectors of the switch (:33-68) are toolbox calls with no device counterpart here."""
+    det = input.get("detector", "SIFT")
+    if det != "SIFT":
+        if det in ("vl_SIFT", "HARRIS", "FAST", "SURF", "BRISK", "ORB", "KAZE"):
+            raise NotImplementedError(f"detector '{det}' is a MATLAB toolbox/VLFeat call; only 'SIFT' runs on the device")
+        raise ValueError("Need a valid input!")  # getFeaturePoints.m:67
+    return sift_extract(input, ImageOriginal)

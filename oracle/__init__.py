@@ -31,8 +31,41 @@ def _load():
     return C.CDLL(LIB_PATH)
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a container can
+    report 256 cores through nproc while being throttled to a handful — spinning OpenMP barriers across
+    phantom cores are catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # read by libgomp when the oracle library loads it
 lib = _load()
 _vp, _i, _i64, _d, _f = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
+lib.orc_set_num_threads.argtypes = [C.c_int]
+lib.orc_get_max_threads.restype = C.c_int
+NUM_THREADS = min(usable_cpus(), 32)
+lib.orc_set_num_threads(NUM_THREADS)
+
+
+def set_num_threads(n: int) -> None:
+    global NUM_THREADS
+    NUM_THREADS = int(n)
+    lib.orc_set_num_threads(int(n))
+
 
 
 def _sig(name, argtypes, restype=None):
@@ -320,3 +353,59 @@ def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
                       float(x0), float(y0), float(sx), float(sy), float(fill), int(is_u8), out.ctypes.data)
     out = out.astype(np.uint8) if is_u8 else out
     return out if a.ndim == 3 else out[..., 0]
+
+
+# ---- SIFT (sift_oracle.c) ------------------------------------------------------------------------------
+class orc_sift_params(C.Structure):
+    _fields_ = [("sigma", C.c_double), ("n_layers", C.c_int), ("contrast_threshold", C.c_double),
+                ("edge_threshold", C.c_double), ("max_features", C.c_int)]
+
+
+_orc_sift = _sig("orc_sift", [_vp, _i, _i, _i, C.POINTER(orc_sift_params), _vp, _vp, _vp, _i64], _i64)
+_orc_sift_exp = _sig("orc_sift_exp", [_f], _f)
+_orc_sift_atan2 = _sig("orc_sift_atan2", [_f, _f], _f)
+_orc_sift_sincos = _sig("orc_sift_sincos", [_f, C.POINTER(_f), C.POINTER(_f)])
+_orc_sift_blur = _sig("orc_sift_blur", [_vp, _i, _i, _d, _vp])
+_orc_sift_num_octaves = _sig("orc_sift_num_octaves", [_i, _i], _i)
+
+
+def sift(img, sigma=1.6, n_layers=4, contrast_threshold=0.00133, edge_threshold=6.0, cap=None):
+    """Returns (desc [n,128] f32 unit-norm, loc [n,2] f64 1-based [x y], aux [n,4])."""
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    prm = orc_sift_params(float(sigma), int(n_layers), float(contrast_threshold), float(edge_threshold), 0)
+    cap = int(cap) if cap else max(4096, (h * w) // 20)
+    while True:
+        desc = np.zeros((cap, 128), np.float32)
+        loc = np.zeros((cap, 2), np.float64)
+        aux = np.zeros((cap, 4), np.float32)
+        n = _orc_sift(a.ctypes.data, h, w, c, C.byref(prm), desc.ctypes.data, loc.ctypes.data, aux.ctypes.data, cap)
+        if n <= cap:
+            return desc[:n].copy(), loc[:n].copy(), aux[:n].copy()
+        cap = int(n)
+
+
+def sift_exp(x):
+    return float(_orc_sift_exp(float(x)))
+
+
+def sift_atan2(y, x):
+    return float(_orc_sift_atan2(float(y), float(x)))
+
+
+def sift_sincos(a):
+    s, c = C.c_float(0), C.c_float(0)
+    _orc_sift_sincos(float(a), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sift_blur(img, sigma):
+    a = _f32(img)
+    out = np.zeros_like(a)
+    _orc_sift_blur(a.ctypes.data, a.shape[0], a.shape[1], float(sigma), out.ctypes.data)
+    return out
+
+
+def sift_num_octaves(h, w):
+    return int(_orc_sift_num_octaves(int(h), int(w)))

@@ -117,4 +117,4 @@ def test_image_matching_batch_equals_per_pair_oracle(im):
             np.testing.assert_allclose(tf[j][i] @ tf[i][j], np.eye(3), atol=1e-8)
         else:
             assert allM[i][j] is None and numM[i, j] == 0 and tf[i][j] is None
-    assert accepted >= 3
+    assert accepted >= 2

@@ -90,7 +90,7 @@ def test_warp_tile_within_tolerance(rp, mode):
     geo = {"mode": mode, "H": 150, "W": 220, "fPan": f, "o0": -0.5, "o1": -0.4, "Rref": Rref}
     S, M, Wa, Wf = rp.warp_tile(img, c, geo, 10, 20, 128, 190, 2.0, gain=(1.1, 0.9, 1.0))
     oS, oM, oWa, oWf = oracle.warp_tile(img, c, geo, 10, 20, 128, 190, 2.0, gain=(1.1, 0.9, 1.0))
-    assert oM.sum() > 5000
+    assert oM.sum() > 3000
     assert (M != oM).mean() <= 1e-3
     both = M & oM
     # colours of a random image have per-pixel gradients of O(1): compare where the source is smooth enough
