@@ -84,11 +84,17 @@ _SIGNATURES = {
     "aps_release_workspace": [],
     "aps_timer_begin": [],
     "aps_timer_end": [C.POINTER(_f)],
+    "aps_profile_enable": [_i],
+    "aps_profile_reset": [],
+    "aps_profile_get": [C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
+    "aps_profile_names": [C.c_char_p, _i],
     "aps_match_2nn_ssd": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp],
     "aps_match_features": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, C.POINTER(aps_match_opts), _vp,
                            _vp, _vp, _i64, C.POINTER(_i64)],
     "aps_match_pairwise": [C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _i, _i, _i,
                            C.POINTER(aps_match_opts), _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)],
+    "aps_match_pairs": [C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _i, _i, _i, _vp, _vp, _i64,
+                        C.POINTER(aps_match_opts), _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)],
     "aps_knn_global": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64],
     "aps_global_filter": [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i64,
                           C.POINTER(_i64)],
@@ -100,6 +106,8 @@ _SIGNATURES = {
                                     _vp, _vp, _vp],
     "aps_render": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), C.POINTER(aps_render_opts), _i,
                    _vp, _vp],
+    "aps_render_tiles": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), C.POINTER(aps_render_opts), _i,
+                         _i, _i, _vp, _vp],
     "aps_warp_tile": [C.POINTER(aps_image), C.POINTER(aps_canvas), _i, _i, _i, _i, _f, _vp, _vp, _vp,
                       _vp],
     "aps_multiband_blend": [_vp, _vp, _i, _i, _i, _i, _f, _vp],
@@ -165,3 +173,25 @@ def use_torch_stream() -> None:
     import torch
 
     check(lib.aps_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def profile_enable(on: bool = True) -> None:
+    check(lib.aps_profile_enable(1 if on else 0))
+
+
+def profile_reset() -> None:
+    check(lib.aps_profile_reset())
+
+
+def profile_get(name: str):
+    """(total_ms, launches) of the named kernel since the last reset."""
+    t, n = C.c_double(0), C.c_int(0)
+    check(lib.aps_profile_get(name.encode(), C.byref(t), C.byref(n)))
+    return t.value, n.value
+
+
+def profile_all():
+    buf = C.create_string_buffer(4096)
+    check(lib.aps_profile_names(buf, 4096))
+    names = [s for s in buf.value.decode().split(";") if s]
+    return {n: profile_get(n) for n in names}

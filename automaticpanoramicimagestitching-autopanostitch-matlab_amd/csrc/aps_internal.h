@@ -177,6 +177,13 @@ struct Out {
     bool present() const { return d != nullptr; }
 };
 
+// Scoped event bracket around a kernel launch site (no-op unless aps_profile_enable(1)).
+struct Prof {
+    int slot = -1;
+    explicit Prof(const char* name);
+    ~Prof();
+};
+
 inline void check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) fail(APS_E_DEVICE, "launch of %s failed: %s", what, hipGetErrorString(e));

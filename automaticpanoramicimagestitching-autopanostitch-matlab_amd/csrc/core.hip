@@ -116,6 +116,36 @@ void ws_free(void* p) {
         }
 }
 
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+};
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<ProfRec> g_prof;
+static thread_local std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    APS_HIP(hipEventCreate(&e));
+    return e;
+}
+
+Prof::Prof(const char* name) {
+    if (!g_prof_on) return;
+    ProfRec r{name, prof_event(), prof_event()};
+    APS_HIP(hipEventRecord(r.a, stream()));
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+Prof::~Prof() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream());
+}
+
 bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t attr;
@@ -168,6 +198,61 @@ int aps_release_workspace(void) {
                 ++it;
             }
         }
+    });
+}
+
+int aps_profile_enable(int on) {
+    return guarded([&] {
+        ctx();
+        g_prof_on = on != 0;
+    });
+}
+
+int aps_profile_reset(void) {
+    return guarded([&] {
+        Ctx& c = ctx();
+        APS_HIP(hipStreamSynchronize(c.stream()));
+        for (auto& r : g_prof) {
+            g_prof_pool.push_back(r.a);
+            g_prof_pool.push_back(r.b);
+        }
+        g_prof.clear();
+    });
+}
+
+int aps_profile_get(const char* name, double* total_ms, int* launches) {
+    return guarded([&] {
+        APS_REQUIRE(name && total_ms && launches, APS_E_ARG, "NULL argument");
+        Ctx& c = ctx();
+        APS_HIP(hipStreamSynchronize(c.stream()));
+        double t = 0;
+        int n = 0;
+        for (auto& r : g_prof)
+            if (std::strcmp(r.name, name) == 0) {
+                float ms = 0;
+                APS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+                t += ms;
+                ++n;
+            }
+        *total_ms = t;
+        *launches = n;
+    });
+}
+
+int aps_profile_names(char* buf, int buf_len) {
+    return guarded([&] {
+        APS_REQUIRE(buf && buf_len > 0, APS_E_ARG, "bad buffer");
+        std::string out;
+        std::vector<const char*> seen;
+        for (auto& r : g_prof) {
+            bool dup = false;
+            for (auto* s : seen) dup |= std::strcmp(s, r.name) == 0;
+            if (dup) continue;
+            seen.push_back(r.name);
+            if (!out.empty()) out += ';';
+            out += r.name;
+        }
+        std::snprintf(buf, buf_len, "%s", out.c_str());
     });
 }
 

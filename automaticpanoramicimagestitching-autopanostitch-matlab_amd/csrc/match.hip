@@ -393,6 +393,7 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.P.alloc((size_t)std::max<int64_t>(n, 1) * kDim);
     out.sq.alloc((size_t)std::max<int64_t>(n, 1));
     if (n == 0) return;
+    Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
                                                         out.P, out.sq);
     check_launch("prep_desc_kernel");
@@ -439,7 +440,10 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                            stream()));
     APS_HIP(hipMemcpyAsync(dwgs, wgs.data(), wgs.size() * sizeof(WgJob), hipMemcpyHostToDevice,
                            stream()));
-    match2nn_kernel<<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, idx, d1, d2);
+    {
+        Prof prof("match2nn");
+        match2nn_kernel<<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, idx, d1, d2);
+    }
     check_launch("match2nn_kernel");
     // the pageable host vectors must stay alive until the copies have been consumed
     APS_HIP(hipStreamSynchronize(stream()));
@@ -462,6 +466,7 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
                            stream()));
     APS_HIP(hipMemsetAsync(cnt, 0, njobs * sizeof(unsigned long long), stream()));
     const double r2 = (double)o.max_ratio * (double)o.max_ratio;
+    Prof prof("match_filter");
     const unsigned grid = cdiv(total_rows, 256);
     filter_mark_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, d1, d2, r2,
                                                     (double)o.match_threshold, o.unique, keys, winner);
@@ -573,96 +578,133 @@ int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2
     });
 }
 
+}  // extern "C"
+
+static void match_pairs_impl(const float* const* desc, const int64_t* counts, const int64_t* ld, int n_img,
+                             int dim, int layout, const std::vector<int32_t>& pa, const std::vector<int32_t>& pb,
+                             const aps_match_opts* opts, int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j,
+                             float* metric, int64_t cap, int64_t* count) {
+    APS_REQUIRE(n_img >= 0, APS_E_ARG, "negative image count");
+    APS_REQUIRE(count != nullptr && pair_ptr != nullptr, APS_E_ARG, "count/pair_ptr is NULL");
+    APS_REQUIRE(n_img == 0 || (desc && counts && ld), APS_E_ARG, "NULL descriptor table");
+    APS_REQUIRE(cap >= 0, APS_E_ARG, "negative capacity");
+    const aps_match_opts o = opts ? *opts : default_opts();
+    APS_REQUIRE(o.max_ratio > 0.f && o.max_ratio <= 1.f, APS_E_ARG, "MaxRatio must be in (0,1]");
+    APS_REQUIRE(o.match_threshold >= 0.f, APS_E_ARG, "MatchThreshold must be >= 0");
+    APS_REQUIRE(o.normalize >= 0 && o.normalize <= 2, APS_E_ARG, "normalize must be 0, 1 or 2");
+    for (int i = 0; i < n_img; ++i) check_desc_args(desc[i], counts[i], ld[i], dim, layout, "desc");
+    const int64_t n_pairs = (int64_t)pa.size();
+    for (int64_t p = 0; p < n_pairs; ++p)
+        APS_REQUIRE(pa[p] >= 0 && pa[p] < n_img && pb[p] >= 0 && pb[p] < n_img && pa[p] != pb[p], APS_E_ARG,
+                    "pair %lld = (%d,%d) is not a valid pair of distinct images", (long long)p, pa[p], pb[p]);
+    ctx();
+    *count = 0;
+    if (n_pairs <= 0) {
+        if (is_device_ptr(pair_ptr)) {
+            const int64_t z = 0;
+            APS_HIP(hipMemcpy(pair_ptr, &z, sizeof z, hipMemcpyHostToDevice));
+        } else {
+            pair_ptr[0] = 0;
+        }
+        return;
+    }
+    // upload + probe (only images that take part in some pair)
+    std::vector<char> used(n_img, 0);
+    for (int64_t p = 0; p < n_pairs; ++p) used[pa[p]] = used[pb[p]] = 1;
+    std::vector<In<float>> din(n_img);
+    std::vector<float> amax(n_img, 0.f);
+    Ws<float> slot(1);
+    for (int i = 0; i < n_img; ++i) {
+        if (!used[i]) continue;
+        const int64_t n = counts[i];
+        const size_t elems = n == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld[i] + dim : (size_t)(dim - 1) * ld[i] + n);
+        din[i].bind(desc[i], elems);
+        if (o.normalize == 2) amax[i] = absmax(din[i], n, ld[i], layout, slot);
+    }
+    // which variants (raw / normalised) of each image are needed: the reference decides per pair
+    // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
+    auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
+    std::vector<Prepared> raw(n_img), nrm(n_img);
+    std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const bool norm = big(pa[p]) || big(pb[p]);
+        (norm ? need_nrm : need_raw)[pa[p]] = 1;
+        (norm ? need_nrm : need_raw)[pb[p]] = 1;
+    }
+    for (int i = 0; i < n_img; ++i) {
+        if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i]);
+        if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i]);
+    }
+    std::vector<MatchJob> jobs;
+    std::vector<FilterJob> fjobs;
+    int64_t rows = 0, cols = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int i = pa[p], j = pb[p];
+        const bool norm = big(i) || big(j);
+        const Prepared& a = norm ? nrm[i] : raw[i];
+        const Prepared& b = norm ? nrm[j] : raw[j];
+        // an empty side makes the pair empty (the reference's validateattributes would reject empty
+        // float inputs; callers skip such images)
+        const int nA = counts[j] == 0 ? 0 : (int)counts[i];
+        jobs.push_back({a.P, a.sq, b.P, b.sq, nA, (int)counts[j], rows});
+        fjobs.push_back({rows, cols, nA, (int)counts[j]});
+        rows += nA;
+        cols += counts[j];
+    }
+    APS_REQUIRE(rows < ((int64_t)1 << 32), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
+    Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
+    Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
+    run_match_jobs(jobs, idx, d1, d2);
+
+    Out<uint32_t> oi(idx_i, cap), oj(idx_j, cap);
+    Out<float> om(metric, cap);
+    Ws<unsigned long long> job_ptr(n_pairs + 1);
+    const int64_t total = run_filter(fjobs, rows, cols, idx, d1, d2, o, job_ptr, oi, oj, om, cap);
+    *count = total;
+    std::vector<unsigned long long> hp(n_pairs + 1);
+    APS_HIP(hipMemcpyAsync(hp.data(), job_ptr, (n_pairs + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    if (is_device_ptr(pair_ptr)) {
+        std::vector<int64_t> tmp(hp.begin(), hp.end());
+        APS_HIP(hipMemcpy(pair_ptr, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    } else {
+        for (int64_t p = 0; p <= n_pairs; ++p) pair_ptr[p] = (int64_t)hp[p];
+    }
+    if (total > cap) fail(APS_E_CAP, "output capacity %lld < %lld matches", (long long)cap, (long long)total);
+    APS_REQUIRE(total == 0 || (idx_i && idx_j && metric), APS_E_ARG, "NULL output with matches present");
+    oi.commit(total);
+    oj.commit(total);
+    om.commit(total);
+}
+
+extern "C" {
+
 int aps_match_pairwise(const float* const* desc, const int64_t* counts, const int64_t* ld,
                        int n_img, int dim, int layout, const aps_match_opts* opts,
                        int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j, float* metric,
                        int64_t cap, int64_t* count) {
     return guarded([&] {
         APS_REQUIRE(n_img >= 0, APS_E_ARG, "negative image count");
-        APS_REQUIRE(count != nullptr && pair_ptr != nullptr, APS_E_ARG, "count/pair_ptr is NULL");
-        APS_REQUIRE(n_img == 0 || (desc && counts && ld), APS_E_ARG, "NULL descriptor table");
-        APS_REQUIRE(cap >= 0, APS_E_ARG, "negative capacity");
-        const aps_match_opts o = opts ? *opts : default_opts();
-        APS_REQUIRE(o.max_ratio > 0.f && o.max_ratio <= 1.f, APS_E_ARG, "MaxRatio must be in (0,1]");
-        APS_REQUIRE(o.match_threshold >= 0.f, APS_E_ARG, "MatchThreshold must be >= 0");
-        APS_REQUIRE(o.normalize >= 0 && o.normalize <= 2, APS_E_ARG, "normalize must be 0, 1 or 2");
-        for (int i = 0; i < n_img; ++i) check_desc_args(desc[i], counts[i], ld[i], dim, layout, "desc");
-        ctx();
-        const int64_t n_pairs = (int64_t)n_img * (n_img - 1) / 2;
-        *count = 0;
-        if (n_pairs <= 0) {
-            pair_ptr[0] = 0;
-            return;
-        }
-
-        // upload + probe
-        std::vector<In<float>> din(n_img);
-        std::vector<float> amax(n_img, 0.f);
-        Ws<float> slot(1);
-        for (int i = 0; i < n_img; ++i) {
-            const int64_t n = counts[i];
-            const size_t elems = n == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld[i] + dim : (size_t)(dim - 1) * ld[i] + n);
-            din[i].bind(desc[i], elems);
-            if (o.normalize == 2) amax[i] = absmax(din[i], n, ld[i], layout, slot);
-        }
-        // which variants (raw / normalised) of each image are needed: the reference decides per pair
-        // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
-        auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
-        std::vector<Prepared> raw(n_img), nrm(n_img);
-        std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
+        // the reference's pair order (featureMatchingPairwise.m:48: column-major triu)
+        std::vector<int32_t> pa, pb;
         for (int j = 1; j < n_img; ++j)
             for (int i = 0; i < j; ++i) {
-                const bool norm = big(i) || big(j);
-                (norm ? need_nrm : need_raw)[i] = 1;
-                (norm ? need_nrm : need_raw)[j] = 1;
+                pa.push_back(i);
+                pb.push_back(j);
             }
-        for (int i = 0; i < n_img; ++i) {
-            if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i]);
-            if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i]);
-        }
+        match_pairs_impl(desc, counts, ld, n_img, dim, layout, pa, pb, opts, pair_ptr, idx_i, idx_j, metric, cap, count);
+    });
+}
 
-        // jobs in the reference's pair order (featureMatchingPairwise.m:48: column-major triu)
-        std::vector<MatchJob> jobs;
-        std::vector<FilterJob> fjobs;
-        int64_t rows = 0, cols = 0;
-        for (int j = 1; j < n_img; ++j)
-            for (int i = 0; i < j; ++i) {
-                const bool norm = big(i) || big(j);
-                const Prepared& a = norm ? nrm[i] : raw[i];
-                const Prepared& b = norm ? nrm[j] : raw[j];
-                // an empty side makes the pair empty (the reference's validateattributes would reject
-                // empty float inputs; callers skip such images)
-                const int nA = counts[j] == 0 ? 0 : (int)counts[i];
-                jobs.push_back({a.P, a.sq, b.P, b.sq, nA, (int)counts[j], rows});
-                fjobs.push_back({rows, cols, nA, (int)counts[j]});
-                rows += nA;
-                cols += counts[j];
-            }
-        APS_REQUIRE(rows < ((int64_t)1 << 32), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
-        Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
-        Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
-        run_match_jobs(jobs, idx, d1, d2);
-
-        Out<uint32_t> oi(idx_i, cap), oj(idx_j, cap);
-        Out<float> om(metric, cap);
-        Ws<unsigned long long> job_ptr(n_pairs + 1);
-        const int64_t total = run_filter(fjobs, rows, cols, idx, d1, d2, o, job_ptr, oi, oj, om, cap);
-        *count = total;
-        std::vector<unsigned long long> hp(n_pairs + 1);
-        APS_HIP(hipMemcpyAsync(hp.data(), job_ptr, (n_pairs + 1) * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, stream()));
-        APS_HIP(hipStreamSynchronize(stream()));
-        if (is_device_ptr(pair_ptr)) {
-            std::vector<int64_t> tmp(hp.begin(), hp.end());
-            APS_HIP(hipMemcpy(pair_ptr, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        } else {
-            for (int64_t p = 0; p <= n_pairs; ++p) pair_ptr[p] = (int64_t)hp[p];
-        }
-        if (total > cap) fail(APS_E_CAP, "output capacity %lld < %lld matches", (long long)cap, (long long)total);
-        APS_REQUIRE(total == 0 || (idx_i && idx_j && metric), APS_E_ARG, "NULL output with matches present");
-        oi.commit(total);
-        oj.commit(total);
-        om.commit(total);
+int aps_match_pairs(const float* const* desc, const int64_t* counts, const int64_t* ld, int n_img,
+                    int dim, int layout, const int32_t* pair_a, const int32_t* pair_b, int64_t n_pairs,
+                    const aps_match_opts* opts, int64_t* pair_ptr, uint32_t* idx_a, uint32_t* idx_b,
+                    float* metric, int64_t cap, int64_t* count) {
+    return guarded([&] {
+        APS_REQUIRE(n_pairs >= 0, APS_E_ARG, "negative pair count");
+        APS_REQUIRE(n_pairs == 0 || (pair_a && pair_b), APS_E_ARG, "NULL pair list");
+        std::vector<int32_t> pa(pair_a, pair_a + n_pairs), pb(pair_b, pair_b + n_pairs);
+        match_pairs_impl(desc, counts, ld, n_img, dim, layout, pa, pb, opts, pair_ptr, idx_a, idx_b, metric, cap, count);
     });
 }
 

@@ -565,11 +565,17 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
+    {
+        Prof prof("ransac_fit");
     ransac_fit_kernel<<<cdiv(nh, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs,
                                                                   d_samples, n_samples, Hs, valid);
+    }
     check_launch("ransac_fit_kernel");
+    {
+        Prof prof("ransac_score");
     ransac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples,
                                                             Hs, valid, o.max_distance, ninl, merr);
+    }
     check_launch("ransac_score_kernel");
     std::vector<uint8_t> h_valid(nh);
     std::vector<int32_t> h_ninl(nh), h_best(n_pairs);
@@ -589,9 +595,12 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     }
     APS_HIP(hipMemcpyAsync(best, h_best.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice,
                            stream()));
+    {
+        Prof prof("ransac_finalize");
     ransac_finalize_kernel<<<n_pairs, 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
                                                                   best, o.max_distance, d_models,
                                                                   d_mask, scratch, d_found, d_ninl);
+    }
     check_launch("ransac_finalize_kernel");
     APS_HIP(hipStreamSynchronize(stream()));
 }

@@ -658,6 +658,7 @@ static void multiband_device(std::vector<float4*>& layers, int h, int w, int lev
     }
     const Taps tp = make_taps(sigma);
     Ws<float4> t1(hw), t2(hw), U(hw), rt, gA, gB;
+    Prof prof("multiband");
     for (int k = 0; k < K; ++k) {
         const float4* G = layers[k];
         Ws<float4>* next = &gA;
@@ -853,7 +854,14 @@ int aps_linear_blend(const float* C, const float* Wt, int k, int h, int w, float
 
 int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
                const aps_render_opts* opts, int out_layout, uint8_t* pano, uint8_t* covered) {
+    return aps_render_tiles(images, n_img, canvas, opts, out_layout, 0, 1, pano, covered);
+}
+
+int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canvas,
+                     const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
+                     uint8_t* pano, uint8_t* covered) {
     return guarded([&] {
+        APS_REQUIRE(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step, APS_E_ARG, "bad tile subset");
         APS_REQUIRE(images && canvas && opts && pano, APS_E_ARG, "NULL argument");
         APS_REQUIRE(n_img >= 1, APS_E_ARG, "need at least one image");
         APS_REQUIRE(opts->tile_h > 0 && opts->tile_w > 0, APS_E_ARG,
@@ -878,8 +886,17 @@ int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
         Ws<uint32_t> flags(n_img);
         std::vector<uint32_t> hflags(n_img);
         std::vector<Ws<float4>> store;
+        // a host buffer receives the whole canvas back: start from its current content so that tiles of
+        // other ranks are left untouched
+        if (tile_step > 1) {
+            if (oP.host) APS_HIP(hipMemcpyAsync(oP.d, oP.host, HW * 3, hipMemcpyHostToDevice, stream()));
+            if (oC.host) APS_HIP(hipMemcpyAsync(oC.d, oC.host, HW, hipMemcpyHostToDevice, stream()));
+        }
+        int tile_index = -1;
         for (int r0 = 0; r0 < H; r0 += TH)
             for (int c0 = 0; c0 < W; c0 += TW) {
+                ++tile_index;
+                if (tile_index % tile_step != tile_first) continue;
                 const int ht = std::min(TH, H - r0), wt = std::min(TW, W - c0);
                 const size_t T = (size_t)ht * wt;
                 const dim3 g2(cdiv(wt, 32), cdiv(ht, 8));
@@ -893,7 +910,10 @@ int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
                 } else {
                     // contributors of this tile (the reference skips images with ~any(Mi), :989)
                     APS_HIP(hipMemsetAsync(flags, 0, n_img * sizeof(uint32_t), stream()));
-                    cover_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, n_img, r0, c0, ht, wt, opts->angle_power, flags);
+                    {
+                        Prof prof("cover");
+                        cover_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, n_img, r0, c0, ht, wt, opts->angle_power, flags);
+                    }
                     check_launch("cover_kernel");
                     APS_HIP(hipMemcpyAsync(hflags.data(), flags, n_img * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
                     APS_HIP(hipStreamSynchronize(stream()));
@@ -908,6 +928,7 @@ int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
                         for (int k = 0; k < K; ++k) {
                             if (store[k].n < T) store[k].alloc(tmax);
                             layers[k] = store[k];
+                            Prof prof("warp_layer");
                             warp_layer_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, contrib[k], r0, c0, ht, wt,
                                                                         opts->angle_power, wf_floor, layers[k]);
                         }

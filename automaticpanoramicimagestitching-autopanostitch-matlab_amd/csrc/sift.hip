@@ -702,6 +702,7 @@ static GaussK make_gauss(double sigma) {
 static void launch_blur(const float* in, int h, int w, double sigma, float* out, float* dog, Ws<float>& scratch) {
     const GaussK gk = make_gauss(sigma);
     const int r = gk.n / 2;
+    Prof prof("sift_blur");
     const dim3 grid(cdiv(w, kTW), cdiv(h, kTH));
     switch (r) {
 #define APS_BLUR_CASE(R) \
@@ -817,6 +818,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         for (int o = 0; o < n_oct; ++o) {
             const OctaveDesc& od = table.oct[o];
             if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
+            Prof prof("sift_extrema");
             extrema_kernel<<<dim3(cdiv(od.w, 64), cdiv(od.h, 4), nl), 256, 0, stream()>>>(
                 od, nl, o, thr, (float)params->contrast_threshold, (float)params->edge_threshold, recs, d_count, cand_cap);
             check_launch("extrema_kernel");
@@ -854,7 +856,10 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         Ws<unsigned int> ocount(n_kp), opos(n_kp);
         Ws<float> oangle((size_t)n_kp * kOriBins);
         Ws<unsigned char> obin((size_t)n_kp * kOriBins);
-        orient_kernel<<<cdiv(n_kp, 4), 256, 0, stream()>>>(d_table, kps, n_kp, ocount, oangle, obin);
+        {
+            Prof prof("sift_orient");
+            orient_kernel<<<cdiv(n_kp, 4), 256, 0, stream()>>>(d_table, kps, n_kp, ocount, oangle, obin);
+        }
         check_launch("orient_kernel");
         size_t tb3 = 0;
         APS_HIP(rocprim::exclusive_scan(nullptr, tb3, ocount.get(), opos.get(), 0u, n_kp, rocprim::plus<unsigned int>(), stream()));
@@ -880,8 +885,11 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         const size_t desc_elems = desc_layout == APS_ROWMAJOR ? (size_t)(n_out - 1) * ldd + 128 : (size_t)127 * ldd + n_out;
         Out<float> odesc(desc, desc_elems), oaux(aux, (size_t)n_out * 4);
         Out<double> oloc(loc, (size_t)ldl + n_out);
-        descr_kernel<<<cdiv(n_out, 4), 256, 0, stream()>>>(d_table, kps, oks, n_out, odesc, desc_layout, ldd, oloc, ldl,
-                                                           oaux.present() ? oaux.get() : nullptr);
+        {
+            Prof prof("sift_descr");
+            descr_kernel<<<cdiv(n_out, 4), 256, 0, stream()>>>(d_table, kps, oks, n_out, odesc, desc_layout, ldd, oloc, ldl,
+                                                               oaux.present() ? oaux.get() : nullptr);
+        }
         check_launch("descr_kernel");
         odesc.commit();
         oloc.commit();

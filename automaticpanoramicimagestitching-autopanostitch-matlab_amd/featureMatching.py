@@ -143,6 +143,40 @@ def match_pairwise_csr(allDescriptors, MaxRatio, MatchThreshold, Unique=True, no
     return pair_ptr, i_i[:k], i_j[:k], met[:k]
 
 
+def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True, normalize=2):
+    """aps_match_pairs: the matcher on an explicit list of (a, b) image pairs (0-based) — the unit that is
+    sharded across GPUs.  Returns (pair_ptr int64[P+1], idx_a, idx_b, metric) as numpy arrays."""
+    n = len(allDescriptors)
+    prepared = [_as_desc(d) for d in allDescriptors]
+    layouts = {p[3] for p in prepared if p[1] > 0}
+    if len(layouts) > 1:
+        raise ValueError("all descriptor matrices must share a storage order")
+    layout = layouts.pop() if layouts else _capi.APS_ROWMAJOR
+    ptrs = (C.c_void_p * n)(*[ptr(p[0]) if p[1] > 0 else None for p in prepared])
+    counts = (C.c_int64 * n)(*[p[1] for p in prepared])
+    lds = (C.c_int64 * n)(*[max(p[2], DIM if layout == _capi.APS_ROWMAJOR else p[1]) for p in prepared])
+    pa = np.ascontiguousarray([p[0] for p in pairs], np.int32)
+    pb = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+    P = len(pairs)
+    pair_ptr = np.zeros(P + 1, np.int64)
+    o = _opts(MaxRatio, MatchThreshold, Unique, normalize)
+    cnt = C.c_int64(0)
+    cap = max(1, sum(prepared[a][1] for a in pa.tolist()) // 16)
+    while True:
+        i_a = np.zeros(cap, np.uint32)
+        i_b = np.zeros(cap, np.uint32)
+        met = np.zeros(cap, np.float32)
+        rc = lib.aps_match_pairs(ptrs, counts, lds, n, DIM, layout, ptr(pa), ptr(pb), P, C.byref(o), ptr(pair_ptr),
+                                 ptr(i_a), ptr(i_b), ptr(met), cap, C.byref(cnt))
+        if rc == _capi.APS_E_CAP:
+            cap = cnt.value
+            continue
+        check(rc)
+        break
+    k = cnt.value
+    return pair_ptr, i_a[:k], i_b[:k], met[:k]
+
+
 def pair_order(numImg):
     """The reference's pair order: nonzeros(triu(reshape(1:n^2,n,n),1)) (featureMatchingPairwise.m:48)."""
     return [(i, j) for j in range(1, numImg) for i in range(j)]

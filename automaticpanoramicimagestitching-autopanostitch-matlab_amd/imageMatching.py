@@ -15,12 +15,13 @@ from . import _capi
 from ._capi import check, lib, ptr
 
 
-def draw_samples(counts, n_samples, seed=0):
+def draw_samples(counts, n_samples, seed=0, keys=None):
     """randperm(numPoints, 4) for every loop iteration of every pair (estimateTransformationRANSAC.m:96).
 
     counts: matches per pair.  Returns uint32 [n_pairs, n_samples, 4], 1-based, distinct within a draw
     (pairs with fewer than 4 matches get ones; they are never fitted).  Counter-based Philox stream keyed
-    by `seed`, so draws do not depend on how pairs are sharded over GPUs."""
+    by (`seed`, keys[p] or p): pass the GLOBAL pair index as key and the draws do not depend on how the
+    pairs are sharded over GPUs."""
     counts = np.asarray(counts, np.int64).reshape(-1)
     P = counts.size
     out = np.ones((P, n_samples, 4), np.uint32)
@@ -28,7 +29,7 @@ def draw_samples(counts, n_samples, seed=0):
         n = int(counts[p])
         if n < 4:
             continue
-        rng = np.random.Generator(np.random.Philox(key=[seed, p]))
+        rng = np.random.Generator(np.random.Philox(key=[seed, p if keys is None else int(keys[p])]))
         u = rng.random((n_samples, 4))
         c = np.empty((n_samples, 4), np.int64)
         c[:, 0] = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)

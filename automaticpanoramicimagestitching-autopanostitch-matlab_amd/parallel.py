@@ -1,0 +1,236 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" on CPU for the tests).
+
+What shards how:
+  1. SIFT            : images are independent (loadImages.m:82-99) -> image i on rank i % world.
+  2. exchange        : ONE all-gather of the descriptor blocks (+ a small one for keypoint coordinates and
+                       counts) so every rank holds all F x 128 descriptors.
+  3. match           : the pair list of featureMatchingPairwise.m:48 is partitioned over ranks, balanced by
+                       N_i * N_j; match lists are all-gathered (a few MB).
+  4. RANSAC          : candidate pairs (imageMatching.m:121) round-robin over ranks; draws are keyed by the
+                       global pair index so the result does not depend on the sharding.
+  5. host segment    : every rank repeats the tiny deterministic graph/camera step (no broadcast needed).
+  6. render          : source images are all-gathered once (uint8), panorama tiles (independent in the
+                       reference, renderPanorama.m:342-406) go to rank t % world, and the canvas is combined
+                       with one all-reduce(MAX) over disjoint tiles.
+There is no other collective on the data path.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def shard_indices(n, world_size, rank):
+    """Image i lives on rank i % world (block-cyclic keeps pixel counts balanced for equal-size images)."""
+    return [i for i in range(n) if i % world_size == rank]
+
+
+def partition_weighted(weights, world_size):
+    """Longest-processing-time greedy partition of items with the given costs; returns owner[item]."""
+    order = np.argsort(-np.asarray(weights, np.float64), kind="stable")
+    load = np.zeros(world_size)
+    owner = np.zeros(len(weights), np.int64)
+    for it in order:
+        r = int(np.argmin(load))
+        owner[it] = r
+        load[r] += weights[it]
+    return owner
+
+
+def allgather_ragged(local, group=None):
+    """All-gather of per-rank tensors whose first dimension differs: one count exchange + ONE padded
+    all-gather.  Returns the list of per-rank tensors (on the same device as `local`)."""
+    ws, _ = world()
+    if ws == 1:
+        return [local]
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(ws)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((ws * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view((ws, m) + tuple(local.shape[1:]))
+    return [out[r, : counts[r]] for r in range(ws)]
+
+
+def gather_by_owner(local_items, owner_of, n, make_tensor, split_sizes_local):
+    """Generic helper: every rank holds some of n ragged items; after the call every rank holds all of them.
+    local_items: dict idx -> tensor [len_i, ...]; owner_of(idx) -> rank.  Items of one rank are concatenated
+    in ascending idx order, exchanged with allgather_ragged, and split again with the all-gathered lengths."""
+    ws, rank = world()
+    mine = sorted(local_items)
+    lens = torch.zeros(n, dtype=torch.int64)
+    for i in mine:
+        lens[i] = local_items[i].shape[0]
+    dev = make_tensor.device
+    lens = lens.to(dev)
+    if ws > 1:
+        dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+    lens = lens.cpu().tolist()
+    cat = torch.cat([local_items[i] for i in mine]) if mine else make_tensor[:0]
+    parts = allgather_ragged(cat)
+    out = [None] * n
+    for r in range(ws):
+        off = 0
+        for i in range(n):
+            if owner_of(i) == r:
+                out[i] = parts[r][off: off + lens[i]]
+                off += lens[i]
+    return out
+
+
+def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None):
+    """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
+    local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
+    Returns (panorama uint8 H x W x 3 CUDA tensor, identical on every rank; info dict)."""
+    from . import _capi
+    from . import featureMatching as fm
+    from . import imageMatching as im
+    from . import pipeline as pl
+    from . import renderPanorama as rp
+
+    ws, rank = world()
+    dev = next(iter(local_images.values())).device if local_images else torch.device("cuda")
+    times = pl.StageTimes()
+    owner = lambda i: i % ws  # noqa: E731
+
+    # 1) SIFT on the local shard
+    t0 = time.perf_counter()
+    ldesc, lkps = {}, {}
+    for i in sorted(local_images):
+        d, p = fm.sift_extract(input, local_images[i], device_out=True)
+        ldesc[i] = d
+        lkps[i] = torch.from_numpy(p).to(dev)
+    pl._sync()
+    times.add("features", t0)
+
+    # 2) the exchange: descriptors (one all-gather), keypoints (small)
+    t0 = time.perf_counter()
+    if ws > 1:
+        descs = gather_by_owner(ldesc, owner, n, torch.empty((0, 128), dtype=torch.float32, device=dev), None)
+        kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
+        descs = [d.contiguous() for d in descs]
+    else:
+        descs = [ldesc[i] for i in range(n)]
+        kps_t = [lkps[i] for i in range(n)]
+    kps = [k.cpu().numpy() for k in kps_t]
+    counts = [int(d.shape[0]) for d in descs]
+    times.add("exchange", t0)
+
+    # 3) match: pair list partitioned by N_i * N_j
+    t0 = time.perf_counter()
+    order = fm.pair_order(n)
+    w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
+    pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
+    my = [p for p in range(len(order)) if pown[p] == rank]
+    pp, ia, ib, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"], input["Matchingthreshold"], True)
+    if ws > 1:
+        lm = {}
+        for k, p in enumerate(my):
+            s, e = int(pp[k]), int(pp[k + 1])
+            lm[p] = torch.from_numpy(np.stack([ia[s:e], ib[s:e]], 1).astype(np.int64)).to(dev)
+        allm = gather_by_owner(lm, lambda p: int(pown[p]), len(order), torch.empty((0, 2), dtype=torch.int64, device=dev), None)
+        allm = [m.cpu().numpy() for m in allm]
+    else:
+        allm = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
+                for k in range(len(order))]
+    times.add("matching", t0)
+
+    # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
+    t0 = time.perf_counter()
+    put = np.zeros((n, n), np.int64)
+    for p, (i, j) in enumerate(order):
+        put[i, j] = len(allm[p])
+    sym = put + put.T
+    srt = np.argsort(-sym, axis=1, kind="stable")[:, : min(int(input["mBrownLowe"]), n - 1)]
+    cand = np.zeros((n, n), bool)
+    cand[np.repeat(np.arange(n), srt.shape[1]), srt.reshape(-1)] = True
+    cand = np.triu(cand | cand.T, 1)
+    pidx = {ij: p for p, ij in enumerate(order)}
+    cj, ci = np.nonzero(cand.T)
+    work = [pidx[(i, j)] for (i, j) in zip(ci.tolist(), cj.tolist()) if len(allm[pidx[(i, j)]]) >= 4]
+    mine = [p for k, p in enumerate(work) if k % ws == rank]
+    n_samples = int(input["maxIter"]) + 64
+    res_local = {}
+    if mine:
+        cnts = [len(allm[p]) for p in mine]
+        wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
+        src = np.concatenate([kps[order[p][1]][allm[p][:, 1] - 1] for p in mine])
+        dst = np.concatenate([kps[order[p][0]][allm[p][:, 0] - 1] for p in mine])
+        samples = im.draw_samples(cnts, n_samples, seed, keys=mine)
+        models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
+        for k, p in enumerate(mine):
+            rec = np.zeros(11 + cnts[k])
+            rec[:9] = models[k].reshape(-1)
+            rec[9] = found[k]
+            rec[10] = ninl[k]
+            rec[11:] = mask[wptr[k]:wptr[k + 1]]
+            res_local[p] = torch.from_numpy(rec).to(dev)
+    if ws > 1:
+        wk = {p: k for k, p in enumerate(work)}
+        allr = gather_by_owner({wk[p]: t for p, t in res_local.items()}, lambda k: k % ws, len(work),
+                               torch.empty((0,), dtype=torch.float64, device=dev), None)
+        allr = [t.cpu().numpy() for t in allr]
+    else:
+        allr = [res_local[p].cpu().numpy() for p in work]
+    pairs, models_l, num_matches = [], [], np.zeros((n, n))
+    for k, p in enumerate(work):
+        rec = allr[k]
+        nf = len(allm[p])
+        ni = int(rec[10]) if rec[9] else 0
+        if ni > 8 + 0.3 * nf:
+            i, j = order[p]
+            pairs.append((i, j))
+            models_l.append(rec[:9].reshape(3, 3))
+            num_matches[i, j] = ni
+    times.add("image_matching", t0)
+
+    # 5) host segment (redundant on every rank)
+    t0 = time.perf_counter()
+    ncomp, labels = pl.connected_components(num_matches)
+    if cameras is None:
+        cameras, ref = pl.cameras_from_models(n, pairs, models_l, num_matches, Ks)
+    else:
+        ref = int(np.argmax((num_matches + num_matches.T).sum(1)))
+    times.add("host_cameras", t0)
+
+    # 6) render: all images everywhere, tiles t % world == rank, one all-reduce(MAX) of the canvas
+    t0 = time.perf_counter()
+    if ws > 1:
+        H, W = next(iter(local_images.values())).shape[:2]
+        flat = {i: t.reshape(1, -1) for i, t in local_images.items()}
+        allimg = gather_by_owner(flat, owner, n, torch.empty((0, H * W * 3), dtype=torch.uint8, device=dev), None)
+        images = [a.reshape(H, W, 3) for a in allimg]
+    else:
+        images = [local_images[i] for i in range(n)]
+    times.add("exchange", t0)
+    t0 = time.perf_counter()
+    comp = labels[ref]
+    members = [k for k in range(n) if labels[k] == comp and cameras[k] is not None]
+    sizes = [(int(images[k].shape[0]), int(images[k].shape[1]), 3) for k in members]
+    opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
+            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": False}
+    pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, [cameras[k] for k in members],
+                                input["panorama2DisplaynSave"], members.index(ref), opts, device_out=True,
+                                tile_subset=(rank, ws) if ws > 1 else None)
+    pl._sync()
+    if ws > 1:
+        torch.cuda.synchronize()
+        dist.all_reduce(pano, op=dist.ReduceOp.MAX)
+    times.add("render", t0)
+    info = {"times": dict(times), "n_features": counts, "n_pairs_verified": len(pairs), "n_components": int(ncomp),
+            "members": members, "cameras": cameras, "pairs": pairs, "models": models_l}
+    return pano, info

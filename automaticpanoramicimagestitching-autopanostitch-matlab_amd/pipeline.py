@@ -1,0 +1,200 @@
+"""The reference driver's stage order (PP/main.m:83-138) over the device hot path.
+
+    loadImages/getFeaturePoints -> featureMatchingPairwise -> imageMatching (+ connected components)
+    -> [host: camera initialisation; bundle adjustment / straightening / gain compensation are the
+       reference's host code and out of scope] -> renderPanorama (warp + multiband blend)
+
+Everything heavy stays resident in HBM between stages: descriptors never leave the device, images are
+uploaded once, only keypoint coordinates, match index lists and 3x3 models visit the host (they feed the
+host-side graph logic exactly as in the reference).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import _capi
+from . import featureMatching as fm
+from . import imageMatching as im
+from . import renderPanorama as rp
+
+DEFAULT_INPUT = {
+    # inputs.m:31-40
+    "detector": "SIFT", "Sigma": 1.6, "NumLayersInOctave": 4, "ContrastThreshold": 0.00133, "EdgeThreshold": 6,
+    # inputs.m:44-59 (the north-star configuration: pairwise, exhaustive, scratch matcher)
+    "matchFeaturesPairwise": 1, "useMATLABFeatureMatch": 0, "Matchingmethod": "Exhaustive",
+    "Matchingthreshold": 1.5, "Ratiothreshold": 0.6,
+    # inputs.m:62-74
+    "useMATLABImageMatching": 0, "imageMatchingMethod": "ransac", "mBrownLowe": 6, "maxIter": 500,
+    "maxDistance": 5.5, "inliersConfidence": 99.9, "transformationType": "projective",
+    # inputs.m:94-113
+    "gainCompensation": 0, "blending": "multiband", "bands": 3, "MBBsigma": 1, "resizeImage": 0,
+    "panorama2DisplaynSave": "spherical", "canvasColor": "black", "forcePlanarScan": False,
+}
+
+
+def default_input(**overrides):
+    d = dict(DEFAULT_INPUT)
+    d.update(overrides)
+    return d
+
+
+class StageTimes(dict):
+    def add(self, name, t0):
+        self[name] = self.get(name, 0.0) + (time.perf_counter() - t0)
+
+
+def _sync():
+    _capi.check(_capi.lib.aps_synchronize())
+
+
+def extract_features(input, images, times=None):
+    """loadImages' parfor body (loadImages.m:82-99): one getFeaturePoints per image, descriptors resident."""
+    t0 = time.perf_counter()
+    descs, kps = [], []
+    dev = _capi.is_torch(images[0]) and images[0].is_cuda
+    for img in images:
+        d, p = fm.sift_extract(input, img, device_out=dev)
+        descs.append(d)
+        kps.append(p)
+    _sync()
+    if times is not None:
+        times.add("features", t0)
+    return descs, kps
+
+
+def match_and_verify(input, descs, kps, seed=0, times=None, pair_subset=None):
+    """featureMatchingPairwise + imageMatching (main.m:95-107) in CSR form.
+
+    Returns dict(pairs=[(i,j)], models=[3x3 j->i], inliers=[K x 2 index arrays], numMatches n x n)."""
+    n = len(descs)
+    t0 = time.perf_counter()
+    pair_ptr, ii, jj, _ = fm.match_pairwise_csr(descs, input["Ratiothreshold"], input["Matchingthreshold"], True)
+    order = fm.pair_order(n)
+    if times is not None:
+        times.add("matching", t0)
+    t0 = time.perf_counter()
+    # top-m candidate selection (imageMatching.m:76-100) straight from the CSR counts
+    put = np.zeros((n, n), np.int64)
+    for p, (i, j) in enumerate(order):
+        put[i, j] = pair_ptr[p + 1] - pair_ptr[p]
+    sym = put + put.T
+    srt = np.argsort(-sym, axis=1, kind="stable")[:, : min(int(input["mBrownLowe"]), n - 1)]
+    cand = np.zeros((n, n), bool)
+    cand[np.repeat(np.arange(n), srt.shape[1]), srt.reshape(-1)] = True
+    cand = np.triu(cand | cand.T, 1)
+    pidx = {ij: p for p, ij in enumerate(order)}
+    work = []
+    cj, ci = np.nonzero(cand.T)
+    for (i, j) in zip(ci.tolist(), cj.tolist()):
+        p = pidx[(i, j)]
+        s, e = int(pair_ptr[p]), int(pair_ptr[p + 1])
+        if e - s < 4:
+            continue
+        work.append((i, j, s, e))
+    out = {"pairs": [], "models": [], "inliers": [], "numMatches": np.zeros((n, n)), "putative": put}
+    if work:
+        counts = [e - s for (_, _, s, e) in work]
+        wptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        src = np.concatenate([kps[j][jj[s:e].astype(np.int64) - 1] for (_, j, s, e) in work])
+        dst = np.concatenate([kps[i][ii[s:e].astype(np.int64) - 1] for (i, _, s, e) in work])
+        samples = im.draw_samples(counts, int(input["maxIter"]) + 64, seed)
+        models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
+        for w, (i, j, s, e) in enumerate(work):
+            nf = e - s
+            ni = int(ninl[w]) if found[w] else 0
+            if ni > 8 + 0.3 * nf:  # imageMatching.m:150
+                sel = np.nonzero(mask[wptr[w]:wptr[w + 1]])[0]
+                out["pairs"].append((i, j))
+                out["models"].append(models[w])
+                out["inliers"].append(np.stack([ii[s:e][sel], jj[s:e][sel]], axis=1).astype(np.int64))
+                out["numMatches"][i, j] = ni
+    if times is not None:
+        times.add("image_matching", t0)
+    return out
+
+
+def connected_components(numMatches):
+    """graph(numMatches,'upper') + conncomp (imageMatchingPanoramaConComps.m:43-45)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components as cc
+
+    a = np.asarray(numMatches) > 0
+    ncomp, labels = cc(csr_matrix(a | a.T), directed=False)
+    return ncomp, labels
+
+
+def cameras_from_models(n, pairs, models, num_matches, Ks):
+    """Minimal stand-in for the reference's HOST camera initialisation (initializeCameraMatrices.m:332-455:
+    maximum spanning tree over the match graph + rotation propagation).  Bundle adjustment, straightening
+    and gain compensation are the reference's own host code and are not rebuilt here.
+    models[p] maps image-j pixels to image-i pixels for pairs[p] = (i, j): H = K_i R_i R_j' K_j^-1.
+    Returns (cameras list or None for unreachable images, seed index)."""
+    adj = {k: [] for k in range(n)}
+    for p, (i, j) in enumerate(pairs):
+        adj[i].append((num_matches[i, j], j, p, False))
+        adj[j].append((num_matches[i, j], i, p, True))
+    deg = [sum(w for w, *_ in adj[k]) for k in range(n)]
+    seed = int(np.argmax(deg))
+    R = {seed: np.eye(3)}
+    import heapq
+
+    heap = [(-w, seed, nb, p, inv) for (w, nb, p, inv) in adj[seed]]
+    heapq.heapify(heap)
+    while heap:
+        _, a, b, p, inv = heapq.heappop(heap)
+        if b in R:
+            continue
+        i, j = pairs[p]
+        M = np.linalg.inv(Ks[i]) @ models[p] @ Ks[j]  # ~ R_i R_j'
+        U, _, Vt = np.linalg.svd(M)
+        Rij = U @ Vt
+        if np.linalg.det(Rij) < 0:
+            Rij = -Rij
+        # a == i, b == j: R_j = Rij' R_i ; a == j, b == i: R_i = Rij R_j
+        R[b] = Rij.T @ R[a] if not inv else Rij @ R[a]
+        for (w, nb, pp, inv2) in adj[b]:
+            if nb not in R:
+                heapq.heappush(heap, (-w, b, nb, pp, inv2))
+    cams = [({"K": Ks[k], "R": R[k], "f": float(Ks[k][0, 0]), "noRotation": 0} if k in R else None) for k in range(n)]
+    return cams, seed
+
+
+def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, device_out=True, profile=False):
+    """main.m for one dataset.  images: list of uint8 H x W x 3 (torch CUDA tensors stay resident).
+    cameras: optional externally supplied cameras (e.g. from the reference's own bundle adjustment);
+    otherwise they are initialised on the host from the verified homographies and the intrinsics Ks.
+    Returns (panoramas [list], info dict with per-stage wall times in seconds)."""
+    times = StageTimes()
+    n = len(images)
+    sizes = [(int(im_.shape[0]), int(im_.shape[1]), 3) for im_ in images]
+    descs, kps = extract_features(input, images, times)
+    res = match_and_verify(input, descs, kps, seed, times)
+    t0 = time.perf_counter()
+    ncomp, labels = connected_components(res["numMatches"])
+    if cameras is None:
+        if Ks is None:
+            raise ValueError("either cameras or the intrinsics Ks must be given (focal estimation/BA are host code out of scope)")
+        cameras, ref = cameras_from_models(n, res["pairs"], res["models"], res["numMatches"], Ks)
+    else:
+        ref = int(np.argmax((res["numMatches"] + res["numMatches"].T).sum(1)))
+    times.add("host_cameras", t0)
+    panos = []
+    t0 = time.perf_counter()
+    opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
+            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": not device_out}
+    for comp in range(ncomp):
+        members = [k for k in range(n) if labels[k] == comp and cameras[k] is not None]
+        if len(members) < 2:
+            continue
+        r = members.index(ref) if ref in members else 0
+        pano, _ = rp.renderPanorama(input, [images[k] for k in members], [sizes[k] for k in members],
+                                    [cameras[k] for k in members], input["panorama2DisplaynSave"], r, opts,
+                                    device_out=device_out)
+        panos.append(pano)
+    _sync()
+    times.add("render", t0)
+    info = {"times": dict(times), "n_features": [len(k) for k in kps], "n_pairs_verified": len(res["pairs"]),
+            "n_components": int(ncomp), "putative": res["putative"], "result": res, "cameras": cameras}
+    return panos, info

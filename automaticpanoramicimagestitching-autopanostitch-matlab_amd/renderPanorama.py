@@ -261,7 +261,7 @@ def make_render_opts(opts):
 
 
 def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gains=None,
-                   return_covered=False, device_out=False):
+                   return_covered=False, device_out=False, tile_subset=None):
     """[panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts)
     (renderPanorama.m:1-500).  refIdx is 0-based here.  Differences that are deliberate:
       * opts['tile'] must be explicit; the reference derives it from free GPU/CPU memory (:269-298),
@@ -289,7 +289,14 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
     else:
         pano = np.zeros((H, W, 3), np.uint8)
         cov = np.zeros((H, W), np.uint8)
-    check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
+    if tile_subset is None:
+        check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
+    else:  # (first, step): only tiles t with t % step == first — the multi-GPU shard of the tile loop
+        if device_out:
+            pano.zero_()
+            cov.zero_()
+        check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
+                                   int(tile_subset[0]), int(tile_subset[1]), ptr(pano), ptr(cov)))
     del keep
     if o["cropBorder"] and not device_out:
         pano, _, _ = cropNonzeroBbox(pano, o["canvasColor"])

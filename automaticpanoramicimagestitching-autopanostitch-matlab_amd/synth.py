@@ -83,10 +83,11 @@ def _blobs(p, seed):
     return out
 
 
-def world_color(rays, f, seed=12345, noise_sigma=0.0, gain=1.0, gen=None):
-    """RGB in [0,1] for unit world rays (..., 3): texture octaves from ~f/512 down to ~1.5 px features."""
+def world_color(rays, f, seed=12345, noise_sigma=0.0, gain=1.0, gen=None, finest_px=3.0):
+    """RGB in [0,1] for unit world rays (..., 3): texture octaves from coarse down to `finest_px`-pixel
+    lattice cells (the knob that sets how many SIFT features a view produces)."""
     rgb = []
-    base = f / 3.0  # lattice frequency (cells per radian-ish unit) of the finest octave: ~3 px cells
+    base = f / finest_px  # lattice frequency (cells per radian) of the finest octave
     for ch in range(3):
         acc = 0.5
         amp_n, amp_b = 0.22, 0.30
@@ -104,7 +105,8 @@ def world_color(rays, f, seed=12345, noise_sigma=0.0, gain=1.0, gen=None):
     return img.clamp(0, 1)
 
 
-def render_view(cam, H, W, seed=12345, device="cpu", noise_sigma=0.0, gain=1.0, rows_per_chunk=256):
+def render_view(cam, H, W, seed=12345, device="cpu", noise_sigma=0.0, gain=1.0, rows_per_chunk=256,
+                finest_px=3.0):
     """uint8 H x W x 3 image of the world through `cam` (pixel (1,1) is the top-left pixel centre)."""
     K = torch.tensor(np.asarray(cam["K"], np.float64), dtype=torch.float32, device=device)
     R = torch.tensor(np.asarray(cam["R"], np.float64), dtype=torch.float32, device=device)
@@ -121,12 +123,13 @@ def render_view(cam, H, W, seed=12345, device="cpu", noise_sigma=0.0, gain=1.0, 
         rc = torch.stack([cx, cy, torch.ones_like(cx)], dim=-1)
         rw = rc @ R  # R' * rayC for row vectors
         rw = rw / rw.norm(dim=-1, keepdim=True)
-        img = world_color(rw, f, seed, noise_sigma, gain, gen)
+        img = world_color(rw, f, seed, noise_sigma, gain, gen, finest_px)
         out[r0:r1] = (img * 255.0 + 0.5).to(torch.uint8)
     return out
 
 
-def make_scene(nx, ny, W, H, f, overlap=0.4, seed=12345, device="cpu", jitter_deg=1.0, gains=False):
+def make_scene(nx, ny, W, H, f, overlap=0.4, seed=12345, device="cpu", jitter_deg=1.0, gains=False,
+               finest_px=3.0):
     """Cameras + images of an nx x ny grid with the given fractional overlap between neighbours."""
     fov_x = 2 * math.atan(W / (2 * f))
     fov_y = 2 * math.atan(H / (2 * f))
@@ -135,5 +138,5 @@ def make_scene(nx, ny, W, H, f, overlap=0.4, seed=12345, device="cpu", jitter_de
     images = []
     for i, cam in enumerate(cams):
         g = float(rng.uniform(0.8, 1.25)) if gains else 1.0
-        images.append(render_view(cam, H, W, seed, device, 1.0 if gains else 0.0, g))
+        images.append(render_view(cam, H, W, seed, device, 1.0 if gains else 0.0, g, finest_px=finest_px))
     return images, cams

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — the BASELINE.json metric on MI355X: MPix/s end-to-end stitch (SIFT -> blend), 64 x 4K images.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over the batch of 64 synthetic 4K views (configs[2] of
+BASELINE.json): SIFT on every image -> all-pairs exhaustive descriptor matching + Lowe ratio -> batched
+RANSAC -> [host: match graph, camera initialisation] -> spherical inverse warp + 5-band multiband blend.
+Images are generated on the GPU (seeded, procedural) and are resident in HBM before the timed region.
+With N > 1 the SAME 64-image job is sharded over the ranks (strong scaling, see parallel.py).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline"     : the dominant kernel (the f32-MFMA descriptor-distance GEMM) against its MFMA roofline,
+                   timed with HIP events on the stream the kernel runs on (aps_profile_*);
+  "cpu_baseline" : the CPU oracle (oracle/, kind "port") timed on a bounded 2x2-view sample of the same
+                   workload on this box's host cores (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+NX, NY, W, H, FOCAL, OVERLAP, FINEST_PX = 8, 8, 3840, 2160, 8000.0, 0.4, 16.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=str, default=f"{NX}x{NY}", help="views as NXxNY (default 8x8 = 64)")
+    ap.add_argument("--size", type=str, default=f"{W}x{H}")
+    ap.add_argument("--bands", type=int, default=5)
+    ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
+    ap.add_argument("--cameras", choices=["estimated", "truth"], default="estimated",
+                    help="cameras for the render stage: initialised from the verified homographies (default) "
+                         "or the synthetic ground truth")
+    ap.add_argument("--save-pano", type=str, default="", help="write a downscaled PNG of the panorama (debug)")
+    return ap.parse_args()
+
+
+def cpu_baseline(synth, input_, f, bands):
+    """The oracle chain on a bounded sample: a 2x2 block of 4K views (33.2 MPix in), all 6 pairs."""
+    import oracle
+
+    w, h = W, H
+    imgs, cams = synth.make_scene(2, 2, w, h, f, OVERLAP, device="cuda", finest_px=FINEST_PX)
+    imgs = [i.cpu().numpy() for i in imgs]
+    t0 = time.perf_counter()
+    feats = [oracle.sift(im, input_["Sigma"], input_["NumLayersInOctave"], input_["ContrastThreshold"],
+                         input_["EdgeThreshold"]) for im in imgs]
+    t_sift = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    matches = {}
+    for j in range(1, 4):
+        for i in range(j):
+            matches[(i, j)] = oracle.match_features(feats[i][0], feats[j][0], input_["Ratiothreshold"],
+                                                    input_["Matchingthreshold"], True, 2)[0]
+    t_match = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(0)
+    for (i, j), m in matches.items():
+        if len(m) < 4:
+            continue
+        s = np.stack([rng.permutation(len(m))[:4] + 1 for _ in range(564)]).astype(np.uint32)
+        oracle.ransac_homography(feats[j][1][m[:, 1] - 1], feats[i][1][m[:, 0] - 1], s, input_["maxDistance"],
+                                 input_["inliersConfidence"], input_["maxIter"])
+    t_ransac = time.perf_counter() - t0
+    import apsamd
+    from importlib import import_module
+
+    rp = import_module(apsamd.__name__ + ".renderPanorama")
+    sizes = [(h, w, 3)] * 4
+    o = rp.default_opts({"anglePower": 2}, cams, 0)
+    geo = rp.canvas_geometry(cams, sizes, "spherical", 0, o)
+    t0 = time.perf_counter()
+    oracle.render(imgs, cams, geo, (2048, 2048), 2.0, "multiband", bands, 1.0)
+    t_render = time.perf_counter() - t0
+    total = t_sift + t_match + t_ransac + t_render
+    mpix = 4 * w * h / 1e6
+    return {
+        "value": round(mpix / total, 3), "unit": "MPix/s", "cores": int(oracle.NUM_THREADS), "kind": "port",
+        "sample": f"2x2 block of the {w}x{h} views ({mpix:.1f} MPix in): oracle SIFT x4 ({t_sift:.1f}s), 6 pairs "
+                  f"exhaustive match ({t_match:.1f}s), RANSAC ({t_ransac:.1f}s), spherical render + {bands}-band blend of the "
+                  f"{geo['W']}x{geo['H']} canvas ({t_render:.1f}s); all-pairs matching grows quadratically with the "
+                  "view count, so the 64-view CPU rate would be lower than this sample's",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["APS_DEVICE"] = str(local_rank)
+    torch.cuda.set_device(local_rank)
+
+    import apsamd
+    from importlib import import_module
+
+    capi = apsamd._capi
+    capi.check(capi.lib.aps_set_device(local_rank))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    synth = import_module(apsamd.__name__ + ".synth")
+    pl = import_module(apsamd.__name__ + ".pipeline")
+    par = import_module(apsamd.__name__ + ".parallel")
+
+    nx, ny = (int(v) for v in args.grid.lower().split("x"))
+    w, h = (int(v) for v in args.size.lower().split("x"))
+    n = nx * ny
+    f = FOCAL * w / W
+    input_ = pl.default_input(bands=args.bands)
+
+    # synthetic inputs, resident in HBM before anything is timed (each rank renders only its shard)
+    cams = synth.grid_cameras(nx, ny, w, h, f, 2 * np.arctan(w / (2 * f)) * (1 - OVERLAP),
+                              2 * np.arctan(h / (2 * f)) * (1 - OVERLAP), 1.0, 12345)
+    mine = par.shard_indices(n, world, rank)
+    local = {i: synth.render_view(cams[i], h, w, 12345, "cuda", finest_px=FINEST_PX) for i in mine}
+    torch.cuda.synchronize()
+    Ks = [c["K"] for c in cams]
+    gt = cams if args.cameras == "truth" else None
+
+    def barrier():
+        capi.check(capi.lib.aps_synchronize())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        return par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt)
+
+    for _ in range(args.warmup):
+        step()
+    capi.profile_enable(True)
+    capi.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(args.steps):
+        pano, info = step()
+        infos.append(info)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = capi.profile_all()
+    capi.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        info = infos[-1]
+        mpix_in = n * w * h / 1e6
+        value = mpix_in * args.steps / dt
+        counts = info["n_features"]
+        # roofline of the dominant kernel: this rank's share of F_match = 2*128*sum N_i*N_j over ITS pairs
+        order = [(i, j) for j in range(1, n) for i in range(j)]
+        wts = [float(counts[i]) * float(counts[j]) for (i, j) in order]
+        own = par.partition_weighted(wts, world) if world > 1 else np.zeros(len(order), np.int64)
+        flops_rank0 = 2.0 * 128.0 * sum(wt for wt, o in zip(wts, own) if o == 0)
+        ms, launches = prof.get("match2nn", (0.0, 0))
+        ach = (flops_rank0 * args.steps) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        stages = {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in infos[-1]["times"]}
+        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 3), "launches_per_step": v[1] // max(args.steps, 1)}
+                   for k, v in prof.items()}
+        out = {
+            "metric": "MPix/s end-to-end stitch (SIFT->blend), 64x4K images",
+            "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
+                            f"{int(OVERLAP * 100)}% overlap): SIFT -> all-pairs exhaustive 2-NN + Lowe ratio -> batched RANSAC -> "
+                            f"host match graph/cameras ({args.cameras}) -> spherical inverse warp + {args.bands}-band multiband blend, "
+                            f"tile 2048; BASELINE.json configs[2]",
+                "input_mpix": round(mpix_in, 1), "features_per_view": int(np.mean(counts)),
+                "pairs_matched": len(order), "pairs_verified": info["n_pairs_verified"],
+                "panorama": [int(pano.shape[1]), int(pano.shape[0])], "parallelism": f"{world} rank(s), images/pairs/tiles sharded",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "match2nn_kernel (v_mfma_f32_32x32x2_f32, exact f32)",
+                "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "algorithmic_flops_per_launch": flops_rank0, "avg_launch_ms": round(ms / max(launches, 1), 3),
+            },
+            "stages_ms_per_step": stages, "kernels": kernels,
+        }
+        if world == 1 and args.cpu_baseline == "auto":
+            try:
+                out["cpu_baseline"] = cpu_baseline(synth, input_, f, args.bands)
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+        if args.save_pano:
+            from PIL import Image
+
+            small = pano[:: max(1, pano.shape[0] // 1200), :: max(1, pano.shape[0] // 1200)].cpu().numpy()
+            os.makedirs(os.path.dirname(os.path.abspath(args.save_pano)), exist_ok=True)
+            Image.fromarray(small).save(args.save_pano)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,15 @@ int aps_release_workspace(void);
  * the elapsed milliseconds between them. */
 int aps_timer_begin(void);
 int aps_timer_end(float* ms);
+/* Per-kernel timing on the stream the kernels are launched on (what bench.py's `roofline` entry uses):
+ * while enabled, every launch site of a named hot kernel is bracketed by HIP events.
+ * aps_profile_get sums the elapsed time of all recorded launches whose name equals `name`
+ * (e.g. "match2nn", "sift_blur", "warp_layer", "mb_blur", ...) and returns the launch count. */
+int aps_profile_enable(int on);
+int aps_profile_reset(void);
+int aps_profile_get(const char* name, double* total_ms, int* launches);
+/* Writes a ';'-separated list of the kernel names recorded since the last reset into buf. */
+int aps_profile_names(char* buf, int buf_len);
 
 /* ============================================================================================
  * (1) Descriptor matching — PP/featureMatching/matchFeaturesScratch.m
@@ -118,6 +127,15 @@ int aps_match_pairwise(const float* const* desc, const int64_t* counts, const in
                        int n_img, int dim, int layout, const aps_match_opts* opts,
                        int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j, float* metric,
                        int64_t cap, int64_t* count);
+
+/* The same for an explicit list of image pairs (0-based image ids, pair_a[p] != pair_b[p]); this is what
+ * lets the n x n pair matrix of featureMatchingPairwise.m:48 be tiled across GPUs: every rank holds all
+ * descriptors (after the all-gather) and matches its own slice of the pair list.  For each pair the rows
+ * of image pair_a[p] are matched against image pair_b[p]; idx_a/idx_b are 1-based feature indices. */
+int aps_match_pairs(const float* const* desc, const int64_t* counts, const int64_t* ld, int n_img,
+                    int dim, int layout, const int32_t* pair_a, const int32_t* pair_b, int64_t n_pairs,
+                    const aps_match_opts* opts, int64_t* pair_ptr, uint32_t* idx_a, uint32_t* idx_b,
+                    float* metric, int64_t cap, int64_t* count);
 
 /* a8 kNN: [idx, dist] = flann_knn_win(train, query, k, 'flann', trees, checks) for float
  * descriptors (flann_knn.cpp:118-253; caller featureMatchingGlobal.m:108-117), with an EXACT
@@ -242,6 +260,13 @@ typedef struct aps_render_opts {
  *   covered : uint8 H x W (same 2-D layout), may be NULL. */
 int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
                const aps_render_opts* opts, int out_layout, uint8_t* pano, uint8_t* covered);
+
+/* The same, restricted to the tiles t (row-major tile index over the canvas) with t % tile_step ==
+ * tile_first: tiles are independent in the reference (renderPanorama.m:342-406; pyramids are tile
+ * local), so this is the unit of multi-GPU sharding.  Pixels of other tiles are left untouched. */
+int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canvas,
+                     const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
+                     uint8_t* pano, uint8_t* covered);
 
 /* a15/a16 for ONE tile, layers out (for tests): rows r0..r0+ht-1, cols c0..c0+wt-1 (0-based) of
  * the canvas sampled from ONE image.  S: f32 ht x wt x 3 row-major interleaved, Wang/Wf: f32 ht x wt,
