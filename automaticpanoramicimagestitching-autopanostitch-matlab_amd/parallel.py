@@ -203,6 +203,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     ncomp, labels = pl.connected_components(num_matches)
     if cameras is None:
         cameras, ref = pl.cameras_from_models(n, pairs, models_l, num_matches, Ks)
+        cameras = pl.straightening(cameras)
     else:
         ref = int(np.argmax((num_matches + num_matches.T).sum(1)))
     times.add("host_cameras", t0)

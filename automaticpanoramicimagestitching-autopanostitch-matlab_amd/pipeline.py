@@ -161,6 +161,44 @@ def cameras_from_models(n, pairs, models, num_matches, Ks):
     return cams, seed
 
 
+def straightening(cameras, up_angle_t=(60, 60, 105), theta_t=90):
+    """Host step, PP/straightening/straightening.m:74-176: global rotation S that makes the cameras' X axes
+    horizontal (Brown-Lowe), R <- R*S, with the reference's skip rules.  3x3 algebra per component."""
+    cams = [c for c in cameras if c is not None]
+    if len(cams) < 2:
+        return cameras
+    X = np.stack([c["R"][0, :] for c in cams], axis=1)
+    _, _, Vt = np.linalg.svd(X @ X.T)
+    up = Vt[-1]
+    avgY = np.mean(np.stack([c["R"][1, :] for c in cams], axis=1), axis=1)
+    avgY = avgY / np.linalg.norm(avgY)
+    if up @ avgY < 0:
+        up = -up
+    Zsum = np.sum(np.stack([c["R"][2, :] for c in cams], axis=1), axis=1)
+    xhat = np.cross(up, Zsum)
+    if np.linalg.norm(xhat) < np.finfo(float).eps:
+        e1 = np.array([1.0, 0, 0]) if abs(up[0]) <= 0.99 else np.array([0, 0, 1.0])
+        xhat = np.cross(up, e1)
+    if np.linalg.norm(xhat) < np.finfo(float).eps:
+        return cameras
+    xhat = xhat / np.linalg.norm(xhat)
+    zhat = np.cross(xhat, up)
+    if np.linalg.norm(zhat) < np.finfo(float).eps:
+        return cameras
+    zhat = zhat / np.linalg.norm(zhat)
+    S = np.stack([xhat, up, zhat], axis=1)
+    theta = np.degrees(np.arccos(np.clip((np.trace(S) - 1) / 2, -1, 1)))
+    up_angle = np.degrees(np.arccos(np.clip(abs(up[1]), -1, 1)))
+    if up_angle_t[0] < up_angle < up_angle_t[2]:
+        return cameras
+    if up_angle > up_angle_t[1] and theta > theta_t:
+        return cameras
+    out = []
+    for c in cameras:
+        out.append(None if c is None else dict(c, R=c["R"] @ S))
+    return out
+
+
 def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, device_out=True, profile=False):
     """main.m for one dataset.  images: list of uint8 H x W x 3 (torch CUDA tensors stay resident).
     cameras: optional externally supplied cameras (e.g. from the reference's own bundle adjustment);
@@ -177,6 +215,7 @@ def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, devi
         if Ks is None:
             raise ValueError("either cameras or the intrinsics Ks must be given (focal estimation/BA are host code out of scope)")
         cameras, ref = cameras_from_models(n, res["pairs"], res["models"], res["numMatches"], Ks)
+        cameras = straightening(cameras)
     else:
         ref = int(np.argmax((res["numMatches"] + res["numMatches"].T).sum(1)))
     times.add("host_cameras", t0)
