@@ -114,6 +114,7 @@ _SIGNATURES = {
     "aps_linear_blend": [_vp, _vp, _i, _i, _i, _vp],
     "aps_image_warp_h_u8": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, C.c_uint8, _vp],
     "aps_image_warp_h_f32": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _vp],
+    "aps_synth_view": [_vp, _vp, _i, _i, C.c_uint, _f, _f, _vp],
     "aps_sift_extract": [_vp, _i, _i, _i, _i, C.POINTER(aps_sift_params), _vp, _i, _i64, _vp, _i64,
                          _vp, _i64, C.POINTER(_i64)],
 }

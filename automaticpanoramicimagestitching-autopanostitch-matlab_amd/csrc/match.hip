@@ -16,6 +16,7 @@
 //                          segmented radix sort (rocPRIM) to the reference's stable ascending order.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -60,8 +61,16 @@ __global__ void absmax_kernel(const float* __restrict__ X, int64_t n, int64_t ld
 // ------------------------------------------------------------------------------------------------
 // prep: one thread per descriptor row (the canonical sums are serial k-ascending chains)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {  // round to nearest even (finite inputs)
+    const uint32_t u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
+
 __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
-                                 int normalize, float* __restrict__ P, float* __restrict__ sq) {
+                                 int normalize, float* __restrict__ P, float* __restrict__ sq,
+                                 unsigned short* __restrict__ Hh, unsigned short* __restrict__ Hl,
+                                 float* __restrict__ maxsq) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x[kDim];
@@ -96,6 +105,33 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         *reinterpret_cast<f32x4*>(p + 4 * s4) = e;
         *reinterpret_cast<f32x4*>(p + 64 + 4 * s4) = o;
     }
+    // split-precision copies in natural k order: x ~= hi + lo, each bf16 (|x - hi - lo| <= 2^-16 |x|)
+    if (Hh) {
+        unsigned short* ph = Hh + i * kDim;
+        unsigned short* pl = Hl + i * kDim;
+#pragma unroll
+        for (int k8 = 0; k8 < kDim / 8; ++k8) {
+            unsigned short hv[8], lv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = x[8 * k8 + j];
+                hv[j] = f32_to_bf16_rn(v);
+                lv[j] = f32_to_bf16_rn(v - bf16_to_f32(hv[j]));
+            }
+            uint4 a, b;
+            a.x = hv[0] | ((uint32_t)hv[1] << 16);
+            a.y = hv[2] | ((uint32_t)hv[3] << 16);
+            a.z = hv[4] | ((uint32_t)hv[5] << 16);
+            a.w = hv[6] | ((uint32_t)hv[7] << 16);
+            b.x = lv[0] | ((uint32_t)lv[1] << 16);
+            b.y = lv[2] | ((uint32_t)lv[3] << 16);
+            b.z = lv[4] | ((uint32_t)lv[5] << 16);
+            b.w = lv[6] | ((uint32_t)lv[7] << 16);
+            *reinterpret_cast<uint4*>(ph + 8 * k8) = a;
+            *reinterpret_cast<uint4*>(pl + 8 * k8) = b;
+        }
+        atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -109,11 +145,18 @@ struct MatchJob {
     int nA;
     int nB;
     int64_t out_off;  // first output slot of this job's rows
+    // split-precision operands (natural k order) and max ||b||^2 of the B set, for the bf16x3 path
+    const unsigned short* AH;
+    const unsigned short* AL;
+    const unsigned short* BH;
+    const unsigned short* BL;
+    const float* maxsqB;
 };
 
 struct WgJob {
     int job;
-    int row0;
+    int row0;      // first A row of the tile (dense mode) / first entry of the row list (list mode)
+    int list_cnt;  // list mode: number of listed rows in this tile (<= kTM)
 };
 
 __device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob, int oi, float os) {
@@ -126,12 +169,18 @@ __device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob,
     s = ns;
 }
 
+// LIST = false: the tile is the 128 consecutive A rows from w.row0.
+// LIST = true : the tile is w.list_cnt rows named by row_list[w.row0 ...] (global output slots of ONE job):
+//               the exact-f32 fallback for rows the split-precision path could not certify.
+template <bool LIST>
 __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __restrict__ jobs,
                                                            const WgJob* __restrict__ wgs,
+                                                           const uint32_t* __restrict__ row_list,
                                                            uint32_t* __restrict__ out_idx,
                                                            float* __restrict__ out_d1,
                                                            float* __restrict__ out_d2) {
     __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
+    __shared__ int s_rows[kTM];
 
     const WgJob w = wgs[blockIdx.x];
     const MatchJob jb = jobs[w.job];
@@ -140,13 +189,22 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     const int wave = tid >> 6;
     const int c = lane & 31;
     const int h = lane >> 5;
-    const int rowbase = w.row0 + wave * 32;
     const int nA = jb.nA, nB = jb.nB;
+    if (LIST) {
+        if (tid < kTM) s_rows[tid] = tid < w.list_cnt ? (int)((int64_t)row_list[w.row0 + tid] - jb.out_off) : -1;
+        __syncthreads();
+    }
+    const int rowbase = LIST ? wave * 32 : w.row0 + wave * 32;
+    auto a_row = [&](int local) -> int {  // A row index of tile-local row `local`, or -1
+        if (LIST) return s_rows[local];
+        return local < nA ? local : -1;
+    };
 
     // A fragments: lane (c,h) holds A[rowbase+c][2s+h], s = 0..63  == 64 contiguous floats of P
     f32x4 av[16];
     {
-        const int arow = min(rowbase + c, nA - 1);
+        const int ar = a_row(rowbase + c);
+        const int arow = ar >= 0 ? ar : (LIST ? max(s_rows[0], 0) : nA - 1);
         const f32x4* ap = reinterpret_cast<const f32x4*>(jb.PA + (size_t)arow * kDim + h * 64);
 #pragma unroll
         for (int q = 0; q < 16; ++q) av[q] = ap[q];
@@ -156,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     int bidx[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-        a2[r] = jb.sqA[min(row, nA - 1)];
+        const int ar = a_row(rowbase + (r & 3) + 8 * (r >> 2) + 4 * h);
+        a2[r] = jb.sqA[ar >= 0 ? ar : 0];
         best[r] = INFINITY;
         second[r] = INFINITY;
         bidx[r] = c;
@@ -235,14 +293,283 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     if (c == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < nA) {
+            const int row = a_row(rowbase + (r & 3) + 8 * (r >> 2) + 4 * h);
+            if (row >= 0) {
                 const int64_t o = jb.out_off + row;
                 out_idx[o] = nB > 0 ? (uint32_t)bidx[r] + 1u : 0u;
                 out_d1[o] = best[r];
                 out_d2[o] = second[r];
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-precision candidate search: bf16 hi/lo, three MFMA products, error-bounded
+// ------------------------------------------------------------------------------------------------
+// G~ = Ah.Bh + Ah.Bl + Al.Bh on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate, 3 products => 5.3x).
+// With x = hi + lo + r, |r| <= 2^-16 |x|, the dropped terms are bounded by 3*2^-16 |a||b| per product and
+// the f32 accumulation of 384 exact bf16 products by ~384*2^-24; kSplitEps below covers both with margin:
+//   |d~ - d| <= kSplitEps * sqrt(a2 * max b2) + 2^-20   for every pair (i, j).
+// The kernel keeps, per A row, the three smallest d~ with their indices and the FOURTH smallest value (a
+// lower bound for every column that is not a candidate).  rescore_kernel then evaluates the canonical f32
+// distance of the three candidates exactly; the row is certified iff its exact second-best is below
+// (fourth - eps), otherwise it goes to the exact f32 kernel (row-list mode).  The final (idx, d1, d2) are
+// therefore bit-identical to the all-f32 path.
+//
+// Operands are swapped w.r.t. match2nn_kernel: the streamed B-descriptor tile is the MFMA "A" operand and
+// the resident A rows are the MFMA "B" operand, so that in the 32x32 accumulator a lane owns ONE A row
+// (col = lane&31) and sees 16 B columns per block: the running top-4 of a row is 7 registers, and the
+// common case is two VALU ops per element (fma + compare against the row's current fourth-best).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kLdsRowB = 272;        // bytes per bf16 LDS row: 256 + one 16-B pad (conflict-free b128 reads)
+constexpr float kSplitEps = 2.44140625e-4f;  // 2^-12
+
+__device__ __forceinline__ void top4_insert(float t, int j, float& u0, float& u1, float& u2, float& u3,
+                                            int& i0, int& i1, int& i2) {
+    const bool lt3 = t < u3, lt2 = t < u2, lt1 = t < u1, lt0 = t < u0;
+    u3 = lt2 ? u2 : (lt3 ? t : u3);
+    i2 = lt1 ? i1 : (lt2 ? j : i2);
+    u2 = lt1 ? u1 : (lt2 ? t : u2);
+    i1 = lt0 ? i0 : (lt1 ? j : i1);
+    u1 = lt0 ? u0 : (lt1 ? t : u1);
+    i0 = lt0 ? j : i0;
+    u0 = lt0 ? t : u0;
+}
+
+constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
+constexpr int kTNB = 128;   // B rows per LDS tile of the split-precision kernel (4 column blocks per barrier)
+
+__global__ __launch_bounds__(512, 2) void match_cand_bf16_kernel(const MatchJob* __restrict__ jobs,
+                                                                  const WgJob* __restrict__ wgs,
+                                                                  uint32_t* __restrict__ cand,  // 3 per slot
+                                                                  float* __restrict__ bound, int ablate) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTNB * kLdsRowB];
+    __shared__ float s_b2[4][kTNB];  // 4-deep: the deferred epilogue of waves 4-7 reads the previous tile's values
+
+    const WgJob w = wgs[blockIdx.x];
+    const MatchJob jb = jobs[w.job];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 31;
+    const int h = lane >> 5;
+    const int nA = jb.nA, nB = jb.nB;
+    const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
+
+    // resident operand: the lane's two A rows, k = 16 s + 8 h + (0..7), hi and lo
+    bf16x8 ah[2][8], al[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int arow = min(row0 + 32 * rb, nA - 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ah[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AH + (size_t)arow * kDim + 16 * s + 8 * h);
+            al[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AL + (size_t)arow * kDim + 16 * s + 8 * h);
+        }
+    }
+    float u0[2], u1[2], u2[2], u3[2];  // d~ - a2, ascending, per owned row
+    int i0[2], i1[2], i2[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        u0[rb] = u1[rb] = u2[rb] = u3[rb] = INFINITY;
+        i0[rb] = i1[rb] = i2[rb] = -1;
+    }
+
+    const int ntiles = (nB + kTNB - 1) / kTNB;
+    uint4 stage[8];
+    float stage_b2 = 0.f;
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 512 * u;  // 16-B chunk index: 128 rows x 16 chunks
+            const int brow = min(t * kTNB + (f >> 4), nB - 1);
+            stage[u] = *reinterpret_cast<const uint4*>(jb.BH + (size_t)brow * kDim + (f & 15) * 8);
+            stage[4 + u] = *reinterpret_cast<const uint4*>(jb.BL + (size_t)brow * kDim + (f & 15) * 8);
+        }
+        if (tid < kTNB) {
+            const int j = t * kTNB + tid;
+            stage_b2 = j < nB ? jb.sqB[j] : INFINITY;
+        }
+    };
+    auto store_tile = [&](int buf, int buf_t) {
+        unsigned char* base = lds + buf * (2 * kTNB * kLdsRowB);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 512 * u;
+            *reinterpret_cast<uint4*>(base + (f >> 4) * kLdsRowB + (f & 15) * 16) = stage[u];
+            *reinterpret_cast<uint4*>(base + kTNB * kLdsRowB + (f >> 4) * kLdsRowB + (f & 15) * 16) = stage[4 + u];
+        }
+        if (tid < kTNB) s_b2[(buf_t) & 3][tid] = stage_b2;
+    };
+    // Stagger (MI355X_MICROARCH "Two waves per SIMD", item 9): the two waves that share a SIMD would run
+    // their MFMA blocks and their VALU epilogues in lockstep (one barrier per tile).  Waves 4-7 therefore run
+    // the epilogue of block k-1 BEFORE the MFMAs of block k (the accumulators simply stay in registers across
+    // the barrier), so one wave's VALU work always sits beside its partner's matrix work.
+    const bool late = __builtin_amdgcn_readfirstlane(tid) >= 256;
+    f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc1 = acc0;
+    auto epilogue = [&](int t, int cb) {
+        if (ablate & 1) {  // timing experiment only: keep the accumulators alive, skip the selection
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+            return;
+        }
+        // acc[r] <-> B column jj = (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb)
+        const float* b2p = &s_b2[t & 3][cb * 32 + 4 * h];
+        const int jbase = t * kTNB + cb * 32 + 4 * h;
+        // the 16 b2 values of this lane's columns: four 16-B reads up front (no LDS latency inside the loop)
+        f32x4 b2v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b2v[g] = *reinterpret_cast<const f32x4*>(b2p + 8 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2);
+            const float b2 = b2v[r >> 2][r & 3];
+            const float t0 = fmaf(-2.0f, acc0[r], b2);  // d~ - a2 (inf for padded columns)
+            const float t1 = fmaf(-2.0f, acc1[r], b2);
+            if (__any(t0 < u3[0] || t1 < u3[1])) {
+                top4_insert(t0, jbase + jj, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
+                top4_insert(t1, jbase + jj, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
+            }
+        }
+    };
+
+    load_tile(0);
+    store_tile(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles && !(ablate & 2)) load_tile(t + 1);
+        const unsigned char* tile = lds + (t & 1) * (2 * kTNB * kLdsRowB);
+#pragma unroll
+        for (int cb = 0; cb < kTNB / 32; ++cb) {
+            const unsigned char* ph = tile + (cb * 32 + c) * kLdsRowB + 16 * h;
+            const unsigned char* pl = ph + kTNB * kLdsRowB;
+            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kTNB / 32 - 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc0[e] = 0.f;
+                acc1[e] = 0.f;
+            }
+            // operand reads run one k-step ahead of the MFMAs that consume them
+            bf16x8 bh_n = *reinterpret_cast<const bf16x8*>(ph);
+            bf16x8 bl_n = *reinterpret_cast<const bf16x8*>(pl);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 bh = bh_n, bl = bl_n;
+                if (s < 7) {
+                    bh_n = *reinterpret_cast<const bf16x8*>(ph + 32 * (s + 1));
+                    bl_n = *reinterpret_cast<const bf16x8*>(pl + 32 * (s + 1));
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[1][s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[1][s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[1][s], acc1, 0, 0, 0);
+            }
+            if (!late) epilogue(t, cb);
+        }
+        if (t + 1 < ntiles && !(ablate & 2)) store_tile((t + 1) & 1, t + 1);
+        __syncthreads();
+    }
+    if (late && ntiles > 0) epilogue(ntiles - 1, kTNB / 32 - 1);
+
+    // the two half-waves saw disjoint column sets of the same rows: merge
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
+                    p3 = __shfl_xor(u3[rb], 32);
+        const int q0 = __shfl_xor(i0[rb], 32), q1 = __shfl_xor(i1[rb], 32), q2 = __shfl_xor(i2[rb], 32);
+        top4_insert(p0, q0, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        top4_insert(p1, q1, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        top4_insert(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        u3[rb] = fminf(u3[rb], p3);
+        const int row = row0 + 32 * rb;
+        if (h == 0 && row < nA) {
+            const int64_t o = jb.out_off + row;
+            cand[3 * o + 0] = (uint32_t)i0[rb];
+            cand[3 * o + 1] = (uint32_t)i1[rb];
+            cand[3 * o + 2] = (uint32_t)i2[rb];
+            bound[o] = jb.sqA[row] + u3[rb];  // approximate 4th-smallest distance (inf if < 4 columns)
+        }
+    }
+}
+
+// exact canonical distance of A row `pa` and B row `pb` (both in the permuted f32 layout of prep_desc_kernel):
+// G = k-ascending fma chain, d = (a2 + b2) - 2G — the same arithmetic as match2nn_kernel / the oracle.
+__device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const float* __restrict__ pb, float a2,
+                                            float b2) {
+    float g = 0.f;
+#pragma unroll 4
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
+        const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(pb + 4 * s4);
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(pb + 64 + 4 * s4);
+        g = fmaf(ae.x, be.x, g);
+        g = fmaf(ao.x, bo.x, g);
+        g = fmaf(ae.y, be.y, g);
+        g = fmaf(ao.y, bo.y, g);
+        g = fmaf(ae.z, be.z, g);
+        g = fmaf(ao.z, bo.z, g);
+        g = fmaf(ae.w, be.w, g);
+        g = fmaf(ao.w, bo.w, g);
+    }
+    return __fsub_rn(__fadd_rn(a2, b2), __fmul_rn(2.0f, g));
+}
+
+struct FilterJobLite {
+    int64_t row_off;
+};
+
+__global__ void rescore_kernel(const MatchJob* __restrict__ jobs, const FilterJobLite* __restrict__ fj, int njobs,
+                               int64_t total_rows, const uint32_t* __restrict__ cand,
+                               const float* __restrict__ bound, uint32_t* __restrict__ out_idx,
+                               float* __restrict__ out_d1, float* __restrict__ out_d2,
+                               uint32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (slot >= total_rows) return;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (fj[mid].row_off <= slot)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const MatchJob jb = jobs[lo];
+    const int row = (int)(slot - jb.out_off);
+    const float a2 = jb.sqA[row];
+    const float* pa = jb.PA + (size_t)row * kDim;
+    float d[3];
+    int id[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int j = (int)cand[3 * slot + e];
+        id[e] = j;
+        d[e] = (j >= 0 && j < jb.nB) ? exact_dist(pa, jb.PB + (size_t)j * kDim, a2, jb.sqB[j]) : INFINITY;
+        if (!(j >= 0 && j < jb.nB)) id[e] = 0x7fffffff;
+    }
+    // order the three by (d, idx): exact best and exact second
+#define APS_CSWAP(a, b)                                                    \
+    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
+        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
+        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
+    }
+    APS_CSWAP(0, 1)
+    APS_CSWAP(1, 2)
+    APS_CSWAP(0, 1)
+#undef APS_CSWAP
+    const float eps = kSplitEps * sqrtf(a2 * (*jb.maxsqB)) + 9.5367431640625e-07f;
+    const bool certified = jb.nB <= 3 || (d[1] < bound[slot] - eps);
+    if (certified) {
+        out_idx[slot] = jb.nB > 0 ? (uint32_t)id[0] + 1u : 0u;
+        out_d1[slot] = d[0];
+        out_d2[slot] = d[1];
+    } else {
+        const unsigned int p = atomicAdd(fb_count, 1u);
+        fb_list[p] = (uint32_t)slot;
     }
 }
 
@@ -383,20 +710,43 @@ __global__ void scan_counts_kernel(const unsigned long long* __restrict__ cnt, i
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 struct Prepared {
-    Ws<float> P, sq;
+    Ws<float> P, sq, maxsq;
+    Ws<unsigned short> H, L;
     int64_t n = 0;
 };
 
 static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
                     Prepared& out) {
     out.n = n;
-    out.P.alloc((size_t)std::max<int64_t>(n, 1) * kDim);
-    out.sq.alloc((size_t)std::max<int64_t>(n, 1));
+    const size_t rows = (size_t)std::max<int64_t>(n, 1);
+    out.P.alloc(rows * kDim);
+    out.sq.alloc(rows);
+    out.H.alloc(rows * kDim);
+    out.L.alloc(rows * kDim);
+    out.maxsq.alloc(1);
+    APS_HIP(hipMemsetAsync(out.maxsq, 0, sizeof(float), stream()));
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
-                                                        out.P, out.sq);
+                                                        out.P, out.sq, out.H, out.L, out.maxsq);
     check_launch("prep_desc_kernel");
+}
+
+static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, int64_t out_off) {
+    MatchJob j;
+    j.PA = a.P;
+    j.sqA = a.sq;
+    j.PB = b.P;
+    j.sqB = b.sq;
+    j.nA = nA;
+    j.nB = nB;
+    j.out_off = out_off;
+    j.AH = a.H;
+    j.AL = a.L;
+    j.BH = b.H;
+    j.BL = b.L;
+    j.maxsqB = b.maxsq;
+    return j;
 }
 
 static float absmax(const float* X_dev, int64_t n, int64_t ld, int layout, float* d_slot) {
@@ -428,11 +778,18 @@ static void check_desc_args(const void* p, int64_t n, int64_t ld, int dim, int l
     APS_REQUIRE(n < (int64_t)1 << 31, APS_E_DIM, "%s: more than 2^31-1 rows", name);
 }
 
-// Runs the GEMM+top2 for a list of jobs whose operands are already prepared on the device.
+// Matching mode: "split" (default) = bf16x3 candidate search + exact rescoring + exact-f32 fallback rows;
+// "f32" = the all-f32 MFMA kernel on every row.  Both produce bit-identical (idx, d1, d2).
+static bool use_split_path() {
+    const char* e = std::getenv("APS_MATCH_MODE");
+    return !(e && std::strcmp(e, "f32") == 0);
+}
+
+// Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2) {
     std::vector<WgJob> wgs;
     for (int j = 0; j < (int)jobs.size(); ++j)
-        for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r});
+        for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r, 0});
     if (wgs.empty()) return;
     Ws<MatchJob> djobs(jobs.size());
     Ws<WgJob> dwgs(wgs.size());
@@ -440,12 +797,66 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                            stream()));
     APS_HIP(hipMemcpyAsync(dwgs, wgs.data(), wgs.size() * sizeof(WgJob), hipMemcpyHostToDevice,
                            stream()));
-    {
-        Prof prof("match2nn");
-        match2nn_kernel<<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, idx, d1, d2);
+    if (!use_split_path()) {
+        {
+            Prof prof("match2nn");
+            match2nn_kernel<false><<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, nullptr, idx, d1, d2);
+        }
+        check_launch("match2nn_kernel");
+        APS_HIP(hipStreamSynchronize(stream()));  // the pageable host vectors must outlive the copies
+        return;
     }
-    check_launch("match2nn_kernel");
-    // the pageable host vectors must stay alive until the copies have been consumed
+    const int64_t total_rows = jobs.back().out_off + jobs.back().nA;
+    Ws<uint32_t> cand((size_t)total_rows * 3), fb_list((size_t)total_rows);
+    Ws<float> bound((size_t)total_rows);
+    Ws<unsigned int> fb_count(1);
+    APS_HIP(hipMemsetAsync(fb_count, 0, sizeof(unsigned int), stream()));
+    std::vector<WgJob> bw;
+    for (int j = 0; j < (int)jobs.size(); ++j)
+        for (int r = 0; r < jobs[j].nA; r += kTMB) bw.push_back({j, r, 0});
+    Ws<WgJob> dbw(bw.size());
+    APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+    {
+        Prof prof("match_cand_bf16");
+        const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
+        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, cand, bound, ab ? std::atoi(ab) : 0);
+    }
+    check_launch("match_cand_bf16_kernel");
+    std::vector<FilterJobLite> fl(jobs.size());
+    for (size_t j = 0; j < jobs.size(); ++j) fl[j].row_off = jobs[j].out_off;
+    Ws<FilterJobLite> dfl(jobs.size());
+    APS_HIP(hipMemcpyAsync(dfl, fl.data(), fl.size() * sizeof(FilterJobLite), hipMemcpyHostToDevice, stream()));
+    {
+        Prof prof("match_rescore");
+        rescore_kernel<<<cdiv(total_rows, 256), 256, 0, stream()>>>(djobs, dfl, (int)jobs.size(), total_rows, cand,
+                                                                    bound, idx, d1, d2, fb_list, fb_count);
+    }
+    check_launch("rescore_kernel");
+    unsigned int n_fb = 0;
+    APS_HIP(hipMemcpyAsync(&n_fb, fb_count, sizeof n_fb, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    if (n_fb == 0) return;
+    // rows that could not be certified: exact f32 kernel in row-list mode, tiles grouped per job
+    std::vector<uint32_t> h_fb(n_fb);
+    APS_HIP(hipMemcpy(h_fb.data(), fb_list, n_fb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::sort(h_fb.begin(), h_fb.end());
+    std::vector<WgJob> fwgs;
+    size_t p = 0;
+    for (int j = 0; j < (int)jobs.size() && p < h_fb.size(); ++j) {
+        const int64_t lo = jobs[j].out_off, hi = lo + jobs[j].nA;
+        size_t q = p;
+        while (q < h_fb.size() && (int64_t)h_fb[q] < hi) ++q;
+        for (size_t b = p; b < q; b += kTM) fwgs.push_back({j, (int)b, (int)std::min<size_t>(kTM, q - b)});
+        p = q;
+    }
+    Ws<WgJob> dfw(fwgs.size());
+    APS_HIP(hipMemcpyAsync(fb_list, h_fb.data(), n_fb * sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(dfw, fwgs.data(), fwgs.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+    {
+        Prof prof("match2nn_fallback");
+        match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_list, idx, d1, d2);
+    }
+    check_launch("match2nn_kernel<list>");
     APS_HIP(hipStreamSynchronize(stream()));
 }
 
@@ -554,7 +965,7 @@ int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, i
             APS_HIP(hipStreamSynchronize(stream()));
         } else {
             std::vector<MatchJob> jobs(1);
-            jobs[0] = {pa.P, pa.sq, pb.P, pb.sq, (int)n1, (int)n2, 0};
+            jobs[0] = make_job(pa, pb, (int)n1, (int)n2, 0);
             run_match_jobs(jobs, oi, o1, o2);
         }
         oi.commit();
@@ -646,7 +1057,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
         // an empty side makes the pair empty (the reference's validateattributes would reject empty
         // float inputs; callers skip such images)
         const int nA = counts[j] == 0 ? 0 : (int)counts[i];
-        jobs.push_back({a.P, a.sq, b.P, b.sq, nA, (int)counts[j], rows});
+        jobs.push_back(make_job(a, b, nA, (int)counts[j], rows));
         fjobs.push_back({rows, cols, nA, (int)counts[j]});
         rows += nA;
         cols += counts[j];

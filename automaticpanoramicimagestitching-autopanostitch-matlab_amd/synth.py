@@ -107,7 +107,18 @@ def world_color(rays, f, seed=12345, noise_sigma=0.0, gain=1.0, gen=None, finest
 
 def render_view(cam, H, W, seed=12345, device="cpu", noise_sigma=0.0, gain=1.0, rows_per_chunk=256,
                 finest_px=3.0):
-    """uint8 H x W x 3 image of the world through `cam` (pixel (1,1) is the top-left pixel centre)."""
+    """uint8 H x W x 3 image of the world through `cam` (pixel (1,1) is the top-left pixel centre).
+    On a CUDA device without sensor noise this is ONE launch of the library's synth kernel (same formulas);
+    the torch implementation below serves CPU tests and the noisy variant."""
+    if str(device).startswith("cuda") and noise_sigma == 0:
+        from . import _capi
+
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+        Kc = np.ascontiguousarray(np.asarray(cam["K"], np.float64))
+        Rc = np.ascontiguousarray(np.asarray(cam["R"], np.float64))
+        _capi.check(_capi.lib.aps_synth_view(_capi.ptr(Kc), _capi.ptr(Rc), int(H), int(W), int(seed) & 0xFFFFFFFF,
+                                             float(finest_px), float(gain), _capi.ptr(out)))
+        return out
     K = torch.tensor(np.asarray(cam["K"], np.float64), dtype=torch.float32, device=device)
     R = torch.tensor(np.asarray(cam["R"], np.float64), dtype=torch.float32, device=device)
     f = float(K[0, 0])

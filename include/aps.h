@@ -318,6 +318,14 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                      const aps_sift_params* params, float* desc, int desc_layout, int64_t ldd,
                      double* loc, int64_t ldl, float* aux, int64_t cap, int64_t* count);
 
+/* ============================================================================================
+ * Bench / test support — NOT part of the reference boundary
+ * ============================================================================================ */
+/* One uint8 H x W x 3 (row-major interleaved) view of the seeded procedural world used by bench.py and the
+ * pipeline tests, through the pinhole camera (K, R), both 3x3 ROW-major here.  See synth.py. */
+int aps_synth_view(const double* K_rowmajor, const double* R_rowmajor, int height, int width,
+                   unsigned seed, float finest_px, float gain, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,3 +127,51 @@ def test_argument_errors(fm, gpu):
         fm.matchFeaturesScratch(np.zeros((0, 128), np.float32), np.zeros((3, 128), np.float32))
     with pytest.raises(ValueError):
         fm.matchFeaturesScratch(np.zeros((3, 128), np.float32), np.zeros((3, 128), np.float32), MaxRatio=1.5)
+
+
+def test_split_precision_path_equals_f32_path_and_oracle(fm, monkeypatch):
+    """Default mode = bf16x3 candidate search + exact rescoring + exact fallback rows; APS_MATCH_MODE=f32 = the
+    all-f32 MFMA kernel.  Both must be bit-identical to the oracle."""
+    rng = np.random.default_rng(21)
+    a, b, _, _ = planted_pair(rng, 3000, 5000, 1200, noise=0.02)
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    for mode in ("split", "f32"):
+        monkeypatch.setenv("APS_MATCH_MODE", mode)
+        _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+        assert np.array_equal(idx, oi), mode
+        assert np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2)), mode
+
+
+def test_split_path_fallback_rows_on_near_ties(fm, gpu, monkeypatch):
+    """Clusters of near-duplicate B rows make the 2nd..4th neighbours closer than the split-precision error bound:
+    those rows cannot be certified and must go through the exact fallback — still bit-identical."""
+    rng = np.random.default_rng(22)
+    centres = sift_like(rng, 60)
+    b = np.repeat(centres, 8, axis=0) + 2e-5 * rng.standard_normal((480, 128)).astype(np.float32)
+    b = np.maximum(b, 0).astype(np.float32)
+    b[100] = b[101]  # exact duplicate pair too
+    a = np.concatenate([centres[:40] + 1e-4 * rng.standard_normal((40, 128)).astype(np.float32), sift_like(rng, 300)])
+    a = np.maximum(a, 0).astype(np.float32)
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    gpu._capi.profile_enable(True)
+    gpu._capi.profile_reset()
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    prof = gpu._capi.profile_all()
+    gpu._capi.profile_enable(False)
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+    assert "match2nn_fallback" in prof and "match_cand_bf16" in prof  # the fallback really ran
+
+
+def test_split_path_unnormalised_descriptors(fm, monkeypatch):
+    """0..255-valued descriptors are normalised on the device first; large-norm raw inputs (normalize=0 via 2-NN API)
+    scale the error bound with sqrt(a2 * max b2)."""
+    rng = np.random.default_rng(23)
+    a, b, _, _ = planted_pair(rng, 700, 900, 300, unit=False)
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)  # raw values up to 255: distances ~1e5
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+    m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=1.5, MaxRatio=0.6)
+    om, omet = oracle.match_features(a, b, 0.6, 1.5, True, 2)
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
