@@ -102,6 +102,7 @@ _SIGNATURES = {
     "aps_ransac_score": [_vp, _i, _vp, _vp, _i64, _i64, _d, _i, _vp, _vp, _vp],
     "aps_ransac_homography": [_vp, _vp, _i64, _i64, _vp, _i, C.POINTER(aps_ransac_opts), _vp, _vp,
                               C.POINTER(_i), C.POINTER(_i)],
+    "aps_ransac_draw_samples": [_vp, _vp, _i, _i, C.c_uint64, _vp],
     "aps_ransac_homography_batch": [_vp, _vp, _i64, _vp, _i, _vp, _i, C.POINTER(aps_ransac_opts), _vp,
                                     _vp, _vp, _vp],
     "aps_render": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), C.POINTER(aps_render_opts), _i,

@@ -493,6 +493,55 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// seeded 4-subsets (stand-in for randperm(numPoints, 4), :96)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mix_uniform(unsigned long long seed, unsigned long long key, unsigned long long ctr) {
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + key * 0xD1B54A32D192ED03ull + ctr * 0x8CB92BA72F3D8DD7ull +
+                           0x2545F4914F6CDD1Dull;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void draw_samples_kernel(const int64_t* __restrict__ counts, const unsigned long long* __restrict__ keys,
+                                    int n_pairs, int n_samples, unsigned long long seed,
+                                    uint32_t* __restrict__ out) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)n_pairs * n_samples) return;
+    const int p = (int)(gid / n_samples), it = (int)(gid % n_samples);
+    const long long n = counts[p];
+    uint32_t* o = out + gid * 4;
+    if (n < 4) {
+        o[0] = o[1] = o[2] = o[3] = 1u;
+        return;
+    }
+    const unsigned long long key = keys ? keys[p] : (unsigned long long)p;
+    auto draw = [&](int k) -> long long {
+        const long long v = (long long)(mix_uniform(seed, key, 4ull * it + k) * (double)(n - k));
+        return v < n - k - 1 ? v : n - k - 1;
+    };
+    const long long c0 = draw(0);
+    long long v = draw(1);
+    const long long c1 = v + (v >= c0);
+    const long long lo = c0 < c1 ? c0 : c1, hi = c0 < c1 ? c1 : c0;
+    v = draw(2);
+    v = v + (v >= lo);
+    const long long c2 = v + (v >= hi);
+    const long long l3 = lo < c2 ? lo : c2, h3 = hi > c2 ? hi : c2, m3 = c0 + c1 + c2 - l3 - h3;
+    v = draw(3);
+    v = v + (v >= l3);
+    v = v + (v >= m3);
+    const long long c3 = v + (v >= h3);
+    o[0] = (uint32_t)(c0 + 1);
+    o[1] = (uint32_t)(c1 + 1);
+    o[2] = (uint32_t)(c2 + 1);
+    o[3] = (uint32_t)(c3 + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static void check_opts(const aps_ransac_opts& o) {
@@ -632,6 +681,25 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
         on.commit();
         oe.commit();
         om.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
+                            uint64_t seed, uint32_t* sample_idx) {
+    return guarded([&] {
+        APS_REQUIRE(n_pairs >= 0 && n_samples > 0, APS_E_ARG, "bad n_pairs/n_samples");
+        if (n_pairs == 0) return;
+        APS_REQUIRE(counts && sample_idx, APS_E_ARG, "NULL argument");
+        ctx();
+        In<int64_t> dc(counts, n_pairs);
+        In<unsigned long long> dk(reinterpret_cast<const unsigned long long*>(keys), keys ? n_pairs : 0);
+        Out<uint32_t> o(sample_idx, (size_t)4 * n_samples * n_pairs);
+        const int64_t total = (int64_t)n_pairs * n_samples;
+        draw_samples_kernel<<<cdiv(total, 256), 256, 0, stream()>>>(dc, keys ? dk.get() : nullptr, n_pairs, n_samples,
+                                                                    seed, o);
+        check_launch("draw_samples_kernel");
+        o.commit();
         APS_HIP(hipStreamSynchronize(stream()));
     });
 }

@@ -19,27 +19,63 @@ def draw_samples(counts, n_samples, seed=0, keys=None):
     """randperm(numPoints, 4) for every loop iteration of every pair (estimateTransformationRANSAC.m:96).
 
     counts: matches per pair.  Returns uint32 [n_pairs, n_samples, 4], 1-based, distinct within a draw
-    (pairs with fewer than 4 matches get ones; they are never fitted).  Counter-based Philox stream keyed
+    (pairs with fewer than 4 matches get ones; they are never fitted).  Counter-based hash stream keyed
     by (`seed`, keys[p] or p): pass the GLOBAL pair index as key and the draws do not depend on how the
     pairs are sharded over GPUs."""
     counts = np.asarray(counts, np.int64).reshape(-1)
     P = counts.size
     out = np.ones((P, n_samples, 4), np.uint32)
-    for p in range(P):
-        n = int(counts[p])
-        if n < 4:
-            continue
-        rng = np.random.Generator(np.random.Philox(key=[seed, p if keys is None else int(keys[p])]))
-        u = rng.random((n_samples, 4))
-        c = np.empty((n_samples, 4), np.int64)
-        c[:, 0] = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
-        for k in range(1, 4):
-            v = np.minimum((u[:, k] * (n - k)).astype(np.int64), n - k - 1)
-            prev = np.sort(c[:, :k], axis=1)
-            for t in range(k):  # skip over already chosen values in ascending order
-                v = v + (v >= prev[:, t])
-            c[:, k] = v
-        out[p] = (c + 1).astype(np.uint32)
+    if P == 0:
+        return out
+    # counter-based uniforms: u[p, it, k] = mix64(seed, key_p, 4*it + k) (splitmix64 finaliser), vectorised
+    # over pairs; a draw depends only on (seed, global pair id, iteration), never on the sharding or batch
+    kk = np.arange(P, dtype=np.uint64) if keys is None else np.asarray(keys, np.uint64)
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + kk[:, None, None] * np.uint64(0xD1B54A32D192ED03)
+             + np.arange(n_samples * 4, dtype=np.uint64).reshape(1, n_samples, 4) * np.uint64(0x8CB92BA72F3D8DD7)
+             + np.uint64(0x2545F4914F6CDD1D))
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    n = np.maximum(counts, 4)[:, None]
+    c = np.empty((P, n_samples, 4), np.int64)
+    def draw(k):
+        return np.minimum((u[..., k] * (n - k)).astype(np.int64), n - k - 1)
+
+    # partial Fisher-Yates without a table: the k-th draw picks among the n-k values not chosen yet, so it
+    # skips over the earlier picks in ascending order (sorting networks instead of np.sort: k <= 3)
+    c0 = draw(0)
+    v = draw(1)
+    c1 = v + (v >= c0)
+    lo, hi = np.minimum(c0, c1), np.maximum(c0, c1)
+    v = draw(2)
+    v = v + (v >= lo)
+    c2 = v + (v >= hi)
+    l3, h3 = np.minimum(lo, c2), np.maximum(hi, c2)
+    m3 = c0 + c1 + c2 - l3 - h3
+    v = draw(3)
+    v = v + (v >= l3)
+    v = v + (v >= m3)
+    c3 = v + (v >= h3)
+    c[..., 0], c[..., 1], c[..., 2], c[..., 3] = c0, c1, c2, c3
+    ok = counts >= 4
+    out[ok] = (c[ok] + 1).astype(np.uint32)
+    return out
+
+
+def draw_samples_device(counts, n_samples, seed=0, keys=None):
+    """The same draws produced on the device (aps_ransac_draw_samples); returns a torch CUDA int32 tensor
+    [n_pairs, n_samples, 4] that can be handed to ransac_batch without a host round trip."""
+    import torch
+
+    counts = np.ascontiguousarray(counts, np.int64).reshape(-1)
+    P = counts.size
+    out = torch.empty((P, n_samples, 4), dtype=torch.int32, device="cuda")
+    k = None if keys is None else np.ascontiguousarray(keys, np.uint64)
+    check(lib.aps_ransac_draw_samples(ptr(counts), ptr(k), P, int(n_samples), int(seed), ptr(out)))
     return out
 
 
@@ -116,7 +152,8 @@ def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
     pair_ptr = np.ascontiguousarray(pair_ptr, np.int64)
     P = pair_ptr.size - 1
     total = int(pair_ptr[-1])
-    samples = np.ascontiguousarray(samples, np.uint32)
+    if not _capi.is_torch(samples):
+        samples = np.ascontiguousarray(samples, np.uint32)
     assert samples.shape[0] == P and samples.shape[2] == 4
     models = np.zeros((P, 9), np.float64)
     mask = np.zeros(max(total, 1), np.uint8)

@@ -110,11 +110,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     # 1) SIFT on the local shard
     t0 = time.perf_counter()
     ldesc, lkps = {}, {}
-    for i in sorted(local_images):
-        d, p = fm.sift_extract(input, local_images[i], device_out=True)
+    for i, (d, p) in zip(sorted(local_images), pl.sift_many(input, [local_images[i] for i in sorted(local_images)])):
         ldesc[i] = d
         lkps[i] = torch.from_numpy(p).to(dev)
-    pl._sync()
     times.add("features", t0)
 
     # 2) the exchange: descriptors (one all-gather), keypoints (small)
@@ -170,7 +168,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
         src = np.concatenate([kps[order[p][1]][allm[p][:, 1] - 1] for p in mine])
         dst = np.concatenate([kps[order[p][0]][allm[p][:, 0] - 1] for p in mine])
-        samples = im.draw_samples(cnts, n_samples, seed, keys=mine)
+        samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
         models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
         for k, p in enumerate(mine):
             rec = np.zeros(11 + cnts[k])

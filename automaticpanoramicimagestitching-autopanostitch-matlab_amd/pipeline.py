@@ -49,16 +49,44 @@ def _sync():
     _capi.check(_capi.lib.aps_synchronize())
 
 
+_SIFT_POOL = None
+
+
+def sift_many(input, images, workers=4):
+    """getFeaturePoints for many images — the reference runs this loop as a parfor (loadImages.m:82-99).
+    Here a few host threads each drive their own HIP stream (the C ABI is thread-safe with per-thread streams
+    and workspaces), so the small-octave launches and the count read-backs of one image overlap with the
+    large-octave kernels of another.  Results are returned in input order and are independent of the
+    interleaving (every kernel is deterministic)."""
+    global _SIFT_POOL
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    dev = _capi.is_torch(images[0]) and images[0].is_cuda
+    if len(images) <= 1 or workers <= 1:
+        out = [fm.sift_extract(input, img, device_out=dev) for img in images]
+        _sync()
+        return out
+    if dev:
+        torch.cuda.synchronize()  # the images were produced on torch's stream; worker streams must see them
+    if _SIFT_POOL is None:
+        _SIFT_POOL = ThreadPoolExecutor(max_workers=workers)
+
+    def work(img):
+        r = fm.sift_extract(input, img, device_out=dev)
+        _sync()  # this thread's stream
+        return r
+
+    return list(_SIFT_POOL.map(work, images))
+
+
 def extract_features(input, images, times=None):
     """loadImages' parfor body (loadImages.m:82-99): one getFeaturePoints per image, descriptors resident."""
     t0 = time.perf_counter()
     descs, kps = [], []
-    dev = _capi.is_torch(images[0]) and images[0].is_cuda
-    for img in images:
-        d, p = fm.sift_extract(input, img, device_out=dev)
+    for d, p in sift_many(input, images):
         descs.append(d)
         kps.append(p)
-    _sync()
     if times is not None:
         times.add("features", t0)
     return descs, kps
@@ -99,7 +127,7 @@ def match_and_verify(input, descs, kps, seed=0, times=None, pair_subset=None):
         wptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         src = np.concatenate([kps[j][jj[s:e].astype(np.int64) - 1] for (_, j, s, e) in work])
         dst = np.concatenate([kps[i][ii[s:e].astype(np.int64) - 1] for (i, _, s, e) in work])
-        samples = im.draw_samples(counts, int(input["maxIter"]) + 64, seed)
+        samples = im.draw_samples_device(counts, int(input["maxIter"]) + 64, seed)
         models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
         for w, (i, j, s, e) in enumerate(work):
             nf = e - s

@@ -197,6 +197,13 @@ int aps_ransac_homography(const double* p1, const double* p2, int64_t m, int64_t
                           const uint32_t* sample_idx, int n_samples, const aps_ransac_opts* opts,
                           double* model, uint8_t* inlier_mask, int* is_found, int* trials_used);
 
+/* The seeded stand-in for randperm(numPoints, 4) (estimateTransformationRANSAC.m:96): fills sample_idx
+ * (uint32 4 x n_samples x n_pairs, 1-based) with distinct 4-subsets of 1..counts[p] from the counter-based
+ * stream u = mix64(seed, keys[p] (or p if keys is NULL), 4*iteration + k) — identical to
+ * imageMatching.draw_samples on the host.  Pairs with counts[p] < 4 get ones. */
+int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
+                            uint64_t seed, uint32_t* sample_idx);
+
 /* Batched a10/a11/a12: every candidate pair of imageMatching.m:121-156 in one device batch.
  *   pts1/pts2 : f64, pair p's matched points are rows pair_ptr[p]..pair_ptr[p+1]-1 of two
  *               (total x 2) column-major arrays with leading dimension ldp

@@ -118,3 +118,12 @@ def test_image_matching_batch_equals_per_pair_oracle(im):
         else:
             assert allM[i][j] is None and numM[i, j] == 0 and tf[i][j] is None
     assert accepted >= 2
+
+
+def test_device_draws_equal_host_draws(im):
+    counts = [7, 3, 100, 5, 4, 20000, 123457]
+    keys = [5, 9, 2, 77, 1, 0, 123456789]
+    host = im.draw_samples(counts, 700, seed=11, keys=keys)
+    dev = im.draw_samples_device(counts, 700, seed=11, keys=keys).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(host, dev)
+    assert np.array_equal(im.draw_samples(counts, 64, seed=3), im.draw_samples_device(counts, 64, seed=3).cpu().numpy().astype(np.uint32))
