@@ -180,6 +180,7 @@ struct Out {
 // Scoped event bracket around a kernel launch site (no-op unless aps_profile_enable(1)).
 struct Prof {
     int slot = -1;
+    void* ev_b = nullptr;
     explicit Prof(const char* name);
     ~Prof();
 };

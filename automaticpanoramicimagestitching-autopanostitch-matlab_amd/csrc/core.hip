@@ -1,5 +1,7 @@
 // core.hip — device selection, per-thread stream/workspace, error transport, library entry points.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "aps_internal.h"
 
@@ -120,11 +122,14 @@ struct ProfRec {
     const char* name;
     hipEvent_t a, b;
 };
-static thread_local bool g_prof_on = false;
-static thread_local std::vector<ProfRec> g_prof;
-static thread_local std::vector<hipEvent_t> g_prof_pool;
+// The profile store is process-wide (worker threads with their own streams all record into it); each record
+// carries the two events of one launch site on the stream it ran on.
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
 
-static hipEvent_t prof_event() {
+static hipEvent_t prof_event_locked() {
     if (!g_prof_pool.empty()) {
         hipEvent_t e = g_prof_pool.back();
         g_prof_pool.pop_back();
@@ -136,14 +141,17 @@ static hipEvent_t prof_event() {
 }
 
 Prof::Prof(const char* name) {
-    if (!g_prof_on) return;
-    ProfRec r{name, prof_event(), prof_event()};
-    APS_HIP(hipEventRecord(r.a, stream()));
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    hipStream_t st = stream();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{name, prof_event_locked(), prof_event_locked()};
+    APS_HIP(hipEventRecord(r.a, st));
     g_prof.push_back(r);
-    slot = (int)g_prof.size() - 1;
+    ev_b = r.b;
+    slot = 1;
 }
 Prof::~Prof() {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream());
+    if (slot >= 0) (void)hipEventRecord(static_cast<hipEvent_t>(ev_b), stream());
 }
 
 bool is_device_ptr(const void* p) {
@@ -204,14 +212,15 @@ int aps_release_workspace(void) {
 int aps_profile_enable(int on) {
     return guarded([&] {
         ctx();
-        g_prof_on = on != 0;
+        g_prof_on.store(on != 0);
     });
 }
 
 int aps_profile_reset(void) {
     return guarded([&] {
-        Ctx& c = ctx();
-        APS_HIP(hipStreamSynchronize(c.stream()));
+        ctx();
+        APS_HIP(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         for (auto& r : g_prof) {
             g_prof_pool.push_back(r.a);
             g_prof_pool.push_back(r.b);
@@ -223,8 +232,9 @@ int aps_profile_reset(void) {
 int aps_profile_get(const char* name, double* total_ms, int* launches) {
     return guarded([&] {
         APS_REQUIRE(name && total_ms && launches, APS_E_ARG, "NULL argument");
-        Ctx& c = ctx();
-        APS_HIP(hipStreamSynchronize(c.stream()));
+        ctx();
+        APS_HIP(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         double t = 0;
         int n = 0;
         for (auto& r : g_prof)
@@ -244,6 +254,7 @@ int aps_profile_names(char* buf, int buf_len) {
         APS_REQUIRE(buf && buf_len > 0, APS_E_ARG, "bad buffer");
         std::string out;
         std::vector<const char*> seen;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         for (auto& r : g_prof) {
             bool dup = false;
             for (auto* s : seen) dup |= std::strcmp(s, r.name) == 0;

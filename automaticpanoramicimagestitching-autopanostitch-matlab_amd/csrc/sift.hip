@@ -367,31 +367,54 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
     return true;
 }
 
+// 64 x 16 pixel tile per 256-thread workgroup; all nl+2 DoG planes of the tile (plus a 1-pixel halo) are staged
+// in LDS once, so every plane is read from HBM ~1.16x instead of 27x per layer through the caches.
+constexpr int kEW = 64, kEH = 16;
+
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr, float contr_thr,
                                                       float edge_thr, KpRec* __restrict__ recs,
                                                       unsigned int* __restrict__ count, unsigned int cap) {
+    __shared__ float s_d[7][(kEH + 2) * (kEW + 2)];
     const int w = od.w, h = od.h;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int layer = blockIdx.z + 1;
-    if (c < kBorder || c >= w - kBorder || r < kBorder || r >= h - kBorder) return;
-    const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
-    const float val = AT(im, r, c);
-    if (!(fabsf(val) > thr)) return;
-    bool is_max = val > 0, is_min = val < 0;
-#pragma unroll
-    for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-            const float a = AT(pv, r + dr, c + dc), b = AT(nx, r + dr, c + dc), m = AT(im, r + dr, c + dc);
-            if (!(val >= a && val >= b && val >= m)) is_max = false;
-            if (!(val <= a && val <= b && val <= m)) is_min = false;
+    const int x0 = blockIdx.x * kEW, y0 = blockIdx.y * kEH;
+    const int tid = threadIdx.x;
+    constexpr int TW = kEW + 2, TH = kEH + 2;
+    for (int p = 0; p < nl + 2; ++p) {
+        const float* src = od.D[p];
+        for (int e = tid; e < TW * TH; e += 256) {
+            const int ly = e / TW, lx = e - ly * TW;
+            const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = min(max(x0 + lx - 1, 0), w - 1);
+            s_d[p][e] = src[(size_t)gy * w + gx];
         }
-    if (!(is_max || is_min)) return;
-    KpRec kp;
-    if (!adjust_extremum(od, nl, o, layer, r, c, contr_thr, edge_thr, kp)) return;
-    const unsigned int slot = atomicAdd(count, 1u);
-    if (slot < cap) recs[slot] = kp;
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    const int c = x0 + lx;
+    if (c < kBorder || c >= w - kBorder) return;
+    for (int ry = tid >> 6; ry < kEH; ry += 4) {
+        const int r = y0 + ry;
+        if (r < kBorder || r >= h - kBorder) continue;
+        const int ctr = (ry + 1) * TW + lx + 1;
+        for (int layer = 1; layer <= nl; ++layer) {
+            const float val = s_d[layer][ctr];
+            if (!(fabsf(val) > thr)) continue;
+            bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+            for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int q = ctr + dr * TW + dc;
+                    const float a = s_d[layer - 1][q], b = s_d[layer + 1][q], m = s_d[layer][q];
+                    if (!(val >= a && val >= b && val >= m)) is_max = false;
+                    if (!(val <= a && val <= b && val <= m)) is_min = false;
+                }
+            if (!(is_max || is_min)) continue;
+            KpRec kp;
+            if (!adjust_extremum(od, nl, o, layer, r, c, contr_thr, edge_thr, kp)) continue;
+            const unsigned int slot = atomicAdd(count, 1u);
+            if (slot < cap) recs[slot] = kp;
+        }
+    }
 }
 #undef AT
 
@@ -819,7 +842,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             const OctaveDesc& od = table.oct[o];
             if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
             Prof prof("sift_extrema");
-            extrema_kernel<<<dim3(cdiv(od.w, 64), cdiv(od.h, 4), nl), 256, 0, stream()>>>(
+            extrema_kernel<<<dim3(cdiv(od.w, kEW), cdiv(od.h, kEH)), 256, 0, stream()>>>(
                 od, nl, o, thr, (float)params->contrast_threshold, (float)params->edge_threshold, recs, d_count, cand_cap);
             check_launch("extrema_kernel");
         }

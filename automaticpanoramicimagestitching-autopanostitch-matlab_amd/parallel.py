@@ -92,6 +92,36 @@ def gather_by_owner(local_items, owner_of, n, make_tensor, split_sizes_local):
     return out
 
 
+def exchange_items(local_ids, local_arrays, n_items, owner_of, width, dtype, dev):
+    """Every rank owns some of n_items ragged numpy arrays ([len_i, width]); returns the list of all n_items
+    arrays on every rank.  One all-reduce of the lengths + ONE padded all-gather of the concatenated payload
+    (no per-item tensors)."""
+    ws, rank = world()
+    if ws == 1:
+        out = [None] * n_items
+        for i, a in zip(local_ids, local_arrays):
+            out[i] = a
+        return out
+    lens = torch.zeros(n_items, dtype=torch.int64)
+    for i, a in zip(local_ids, local_arrays):
+        lens[i] = a.shape[0]
+    lens = lens.to(dev)
+    dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+    lens = lens.cpu().numpy()
+    order = np.argsort(np.asarray(local_ids, np.int64), kind="stable") if len(local_ids) else np.zeros(0, np.int64)
+    cat = (np.concatenate([local_arrays[k].reshape(-1, width) for k in order]) if len(order)
+           else np.zeros((0, width), dtype))
+    parts = allgather_ragged(torch.from_numpy(np.ascontiguousarray(cat)).to(dev))
+    parts = [p_.cpu().numpy() for p_ in parts]
+    out = [None] * n_items
+    offs = [0] * ws
+    for i in range(n_items):
+        r = owner_of(i)
+        out[i] = parts[r][offs[r]: offs[r] + lens[i]]
+        offs[r] += int(lens[i])
+    return out
+
+
 def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None):
     """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
     local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
@@ -135,16 +165,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
     my = [p for p in range(len(order)) if pown[p] == rank]
     pp, ia, ib, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"], input["Matchingthreshold"], True)
-    if ws > 1:
-        lm = {}
-        for k, p in enumerate(my):
-            s, e = int(pp[k]), int(pp[k + 1])
-            lm[p] = torch.from_numpy(np.stack([ia[s:e], ib[s:e]], 1).astype(np.int64)).to(dev)
-        allm = gather_by_owner(lm, lambda p: int(pown[p]), len(order), torch.empty((0, 2), dtype=torch.int64, device=dev), None)
-        allm = [m.cpu().numpy() for m in allm]
-    else:
-        allm = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
-                for k in range(len(order))]
+    mine_m = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
+              for k in range(len(my))]
+    allm = exchange_items(my, mine_m, len(order), lambda p: int(pown[p]), 2, np.int64, dev)
     times.add("matching", t0)
 
     # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
@@ -161,29 +184,37 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     cj, ci = np.nonzero(cand.T)
     work = [pidx[(i, j)] for (i, j) in zip(ci.tolist(), cj.tolist()) if len(allm[pidx[(i, j)]]) >= 4]
     mine = [p for k, p in enumerate(work) if k % ws == rank]
+    times.add("im_select", t0)
+    t0 = time.perf_counter()
     n_samples = int(input["maxIter"]) + 64
-    res_local = {}
+    recs = []
     if mine:
         cnts = [len(allm[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
-        src = np.concatenate([kps[order[p][1]][allm[p][:, 1] - 1] for p in mine])
-        dst = np.concatenate([kps[order[p][0]][allm[p][:, 0] - 1] for p in mine])
+        # one gather over the concatenated keypoint table instead of one fancy-index per pair
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        kp_all = np.concatenate(kps)
+        cat = np.concatenate([allm[p] for p in mine])
+        img_i = np.repeat(np.asarray([order[p][0] for p in mine], np.int64), cnts)
+        img_j = np.repeat(np.asarray([order[p][1] for p in mine], np.int64), cnts)
+        dst = kp_all[offs[img_i] + cat[:, 0] - 1]
+        src = kp_all[offs[img_j] + cat[:, 1] - 1]
         samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
+        times.add("im_gather", t0)
+        t0 = time.perf_counter()
         models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
-        for k, p in enumerate(mine):
-            rec = np.zeros(11 + cnts[k])
+        times.add("im_ransac", t0)
+        t0 = time.perf_counter()
+        for k in range(len(mine)):
+            rec = np.empty(11 + cnts[k])
             rec[:9] = models[k].reshape(-1)
             rec[9] = found[k]
             rec[10] = ninl[k]
             rec[11:] = mask[wptr[k]:wptr[k + 1]]
-            res_local[p] = torch.from_numpy(rec).to(dev)
-    if ws > 1:
-        wk = {p: k for k, p in enumerate(work)}
-        allr = gather_by_owner({wk[p]: t for p, t in res_local.items()}, lambda k: k % ws, len(work),
-                               torch.empty((0,), dtype=torch.float64, device=dev), None)
-        allr = [t.cpu().numpy() for t in allr]
-    else:
-        allr = [res_local[p].cpu().numpy() for p in work]
+            recs.append(rec.reshape(-1, 1))
+    wk = {p: k for k, p in enumerate(work)}
+    allr = exchange_items([wk[p] for p in mine], recs, len(work), lambda k: k % ws, 1, np.float64, dev)
+    allr = [r.reshape(-1) for r in allr]
     pairs, models_l, num_matches = [], [], np.zeros((n, n))
     for k, p in enumerate(work):
         rec = allr[k]
@@ -194,7 +225,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
             pairs.append((i, j))
             models_l.append(rec[:9].reshape(3, 3))
             num_matches[i, j] = ni
-    times.add("image_matching", t0)
+    times.add("im_merge", t0)
 
     # 5) host segment (redundant on every rank)
     t0 = time.perf_counter()
