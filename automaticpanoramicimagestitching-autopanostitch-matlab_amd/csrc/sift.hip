@@ -371,8 +371,8 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
 // in LDS once, so every plane is read from HBM ~1.16x instead of 27x per layer through the caches.
 constexpr int kEW = 64, kEH = 16;
 
-__global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr, float contr_thr,
-                                                      float edge_thr, KpRec* __restrict__ recs,
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr,
+                                                      unsigned long long* __restrict__ cells,
                                                       unsigned int* __restrict__ count, unsigned int cap) {
     __shared__ float s_d[7][(kEH + 2) * (kEW + 2)];
     const int w = od.w, h = od.h;
@@ -388,31 +388,49 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         }
     }
     __syncthreads();
-    const int lx = tid & 63;
+    // thread (lx, g) owns column lx and the four consecutive rows 4g .. 4g+3 of the tile.  Per plane: the
+    // horizontal 3-max/3-min of the six rows it touches, then the vertical 3-max/3-min per owned pixel = the
+    // 3x3 window extrema (centre included).  A pixel is a 26-neighbour maximum iff val >= the max of the three
+    // planes' window maxima (val itself is inside its own window, which changes nothing).
+    const int lx = tid & 63, g = tid >> 6;
     const int c = x0 + lx;
+    float wmax[7][4], wmin[7][4];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        if (p >= nl + 2) break;
+        float hmx[6], hmn[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+            const float* row = &s_d[p][(4 * g + rr) * TW + lx];
+            hmx[rr] = fmaxf(fmaxf(row[0], row[1]), row[2]);
+            hmn[rr] = fminf(fminf(row[0], row[1]), row[2]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wmax[p][k] = fmaxf(fmaxf(hmx[k], hmx[k + 1]), hmx[k + 2]);
+            wmin[p][k] = fminf(fminf(hmn[k], hmn[k + 1]), hmn[k + 2]);
+        }
+    }
     if (c < kBorder || c >= w - kBorder) return;
-    for (int ry = tid >> 6; ry < kEH; ry += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ry = 4 * g + k;
         const int r = y0 + ry;
         if (r < kBorder || r >= h - kBorder) continue;
         const int ctr = (ry + 1) * TW + lx + 1;
-        for (int layer = 1; layer <= nl; ++layer) {
+#pragma unroll
+        for (int layer = 1; layer <= 5; ++layer) {
+            if (layer > nl) break;
             const float val = s_d[layer][ctr];
             if (!(fabsf(val) > thr)) continue;
-            bool is_max = val > 0, is_min = val < 0;
-#pragma unroll
-            for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-                for (int dc = -1; dc <= 1; ++dc) {
-                    const int q = ctr + dr * TW + dc;
-                    const float a = s_d[layer - 1][q], b = s_d[layer + 1][q], m = s_d[layer][q];
-                    if (!(val >= a && val >= b && val >= m)) is_max = false;
-                    if (!(val <= a && val <= b && val <= m)) is_min = false;
-                }
+            const float mx = fmaxf(fmaxf(wmax[layer - 1][k], wmax[layer][k]), wmax[layer + 1][k]);
+            const float mn = fminf(fminf(wmin[layer - 1][k], wmin[layer][k]), wmin[layer + 1][k]);
+            const bool is_max = val > 0 && val >= mx, is_min = val < 0 && val <= mn;
             if (!(is_max || is_min)) continue;
-            KpRec kp;
-            if (!adjust_extremum(od, nl, o, layer, r, c, contr_thr, edge_thr, kp)) continue;
             const unsigned int slot = atomicAdd(count, 1u);
-            if (slot < cap) recs[slot] = kp;
+            if (slot < cap)
+                cells[slot] = ((unsigned long long)o << 40) | ((unsigned long long)layer << 32) |
+                              ((unsigned long long)r << 16) | (unsigned long long)c;
         }
     }
 }
@@ -446,6 +464,24 @@ struct PyrTable {
     int n_oct, nl;
     float sigma;
 };
+
+// one lane per detected extremum: Newton refinement + contrast/edge tests (dense, no divergence against
+// the detection sweep)
+__global__ void refine_kernel(const PyrTable* __restrict__ pt, const unsigned long long* __restrict__ cells,
+                              const unsigned int* __restrict__ n_cells, unsigned int cells_cap, float contr_thr,
+                              float edge_thr, KpRec* __restrict__ recs, unsigned int* __restrict__ count,
+                              unsigned int cap) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n = min(*n_cells, cells_cap);
+    if (i >= n) return;
+    const unsigned long long key = cells[i];
+    const int o = (int)(key >> 40), layer = (int)((key >> 32) & 0xff), r = (int)((key >> 16) & 0xffff),
+              c = (int)(key & 0xffff);
+    KpRec kp;
+    if (!adjust_extremum(pt->oct[o], pt->nl, o, layer, r, c, contr_thr, edge_thr, kp)) return;
+    const unsigned int slot = atomicAdd(count, 1u);
+    if (slot < cap) recs[slot] = kp;
+}
 
 __device__ __forceinline__ float kp_scale(float sigma, int layer, float xi, int nl) {
     return sigma * my_exp2(((float)layer + xi) / (float)nl);
@@ -831,23 +867,46 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             for (int i = 0; i < nl + 3; ++i) od.G[i] = G[o * (nl + 3) + i];
             for (int i = 0; i < nl + 2; ++i) od.D[i] = D[o * (nl + 2) + i];
         }
-        // extrema
+        // extrema: detection sweep per octave -> packed cells; then one dense refinement launch
+        Ws<PyrTable> d_table(1);
+        APS_HIP(hipMemcpyAsync(d_table, &table, sizeof table, hipMemcpyHostToDevice, stream()));
         const unsigned int cand_cap = (unsigned int)std::min<size_t>(
             params->max_features > 0 ? (size_t)params->max_features : std::max<size_t>((size_t)H * W / 2, 65536), 1u << 26);
+        unsigned int cells_cap = (unsigned int)std::min<size_t>(std::max<size_t>((size_t)H * W / 2, 1u << 18), 1u << 27);
+        Ws<unsigned long long> cells(cells_cap);
         Ws<KpRec> recs(cand_cap);
-        Ws<unsigned int> d_count(1);
-        APS_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned int), stream()));
+        Ws<unsigned int> d_count(2);  // [0] cells, [1] refined records
         const float thr = (float)(int)std::floor(0.5 * params->contrast_threshold / nl * 255.0);
-        for (int o = 0; o < n_oct; ++o) {
-            const OctaveDesc& od = table.oct[o];
-            if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
-            Prof prof("sift_extrema");
-            extrema_kernel<<<dim3(cdiv(od.w, kEW), cdiv(od.h, kEH)), 256, 0, stream()>>>(
-                od, nl, o, thr, (float)params->contrast_threshold, (float)params->edge_threshold, recs, d_count, cand_cap);
-            check_launch("extrema_kernel");
+        unsigned int h_counts[2] = {0, 0};
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            APS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned int), stream()));
+            for (int o = 0; o < n_oct; ++o) {
+                const OctaveDesc& od = table.oct[o];
+                if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
+                Prof prof("sift_extrema");
+                extrema_kernel<<<dim3(cdiv(od.w, kEW), cdiv(od.h, kEH)), 256, 0, stream()>>>(od, nl, o, thr, cells,
+                                                                                      d_count, cells_cap);
+                check_launch("extrema_kernel");
+            }
+            APS_HIP(hipMemcpyAsync(h_counts, d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+            if (h_counts[0] <= cells_cap) break;
+            // flat or band-limited images can have far more (weak) scale-space extrema than the default room:
+            // grow to the exact need and sweep once more
+            APS_REQUIRE(attempt == 0, APS_E_INTERNAL, "extrema count changed between identical sweeps");
+            cells_cap = h_counts[0];
+            cells.alloc(cells_cap);
+        }
+        if (h_counts[0] > 0) {
+            Prof prof("sift_refine");
+            refine_kernel<<<cdiv(h_counts[0], 256), 256, 0, stream()>>>(d_table, cells, d_count, cells_cap,
+                                                                     (float)params->contrast_threshold,
+                                                                     (float)params->edge_threshold, recs, d_count.get() + 1,
+                                                                     cand_cap);
+            check_launch("refine_kernel");
         }
         unsigned int n_cand = 0;
-        APS_HIP(hipMemcpyAsync(&n_cand, d_count, sizeof n_cand, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(&n_cand, d_count.get() + 1, sizeof n_cand, hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));
         if (n_cand > cand_cap)
             fail(APS_E_CAP, "SIFT found %u extrema, more than the candidate capacity %u (raise params.max_features)", n_cand, cand_cap);
@@ -874,8 +933,6 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         compact_recs_kernel<<<cdiv(n_cand, 256), 256, 0, stream()>>>(recs, idx_s, flag, pos, n_cand, kps);
         check_launch("compact_recs_kernel");
         // orientations
-        Ws<PyrTable> d_table(1);
-        APS_HIP(hipMemcpyAsync(d_table, &table, sizeof table, hipMemcpyHostToDevice, stream()));
         Ws<unsigned int> ocount(n_kp), opos(n_kp);
         Ws<float> oangle((size_t)n_kp * kOriBins);
         Ws<unsigned char> obin((size_t)n_kp * kOriBins);
