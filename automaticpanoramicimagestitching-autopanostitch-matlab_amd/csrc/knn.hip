@@ -1,0 +1,435 @@
+// knn.hip — the global (AutoStitch-style) matcher's device side and the binary-descriptor 2-NN.
+//
+//   aps_knn_global    : [idx, dist] = flann_knn_win(train, query, k, 'flann', trees, checks) for float
+//                       descriptors (PP/mex/flann_knn.cpp:118-253, caller PP/featureMatching/
+//                       featureMatchingGlobal.m:106-120) with an EXACT search in place of OpenCV's randomized
+//                       kd-forest: squared L2 in the canonical f32 arithmetic of match.hip, ascending,
+//                       ties -> lower index.
+//   aps_global_filter : the per-query loop of featureMatchingGlobal.m:123-161.
+//   aps_hamming_2nn   : PP/mex/nearest2HammingExhaustiveMEX.cpp:16-80 (and the OMP twin): brute-force Hamming
+//                       2-NN with the reference's tie rule.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "aps_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace aps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDim = 128;
+constexpr int kTN = 64;
+constexpr int kLdsRow = 132;
+
+// ---- prep: canonical ||x||^2 and the k-permuted copy (same as match.hip's, without normalisation) --------
+__global__ void knn_prep_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
+                                float* __restrict__ P, float* __restrict__ sq) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[kDim];
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + k * ld];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
+    sq[i] = s;
+    float* p = P + i * kDim;
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) p[(k & 1) * 64 + (k >> 1)] = x[k];
+}
+
+// ---- exact kNN on v_mfma_f32_32x32x2_f32 ----------------------------------------------------------------
+// Operands are swapped as in match_cand_bf16_kernel: the streamed train tile is the MFMA "A" operand, the
+// resident query rows are the "B" operand, so a lane owns ONE query row (col = lane & 31) and sees 16 train
+// columns per block; its running top-K is 2K registers.  Distances are exact canonical f32, so no rescoring.
+template <int K>
+__device__ __forceinline__ void topk_insert(float d, int j, float (&v)[K], int (&id)[K]) {
+    // ascending (d, j) list; (d, j) goes in front of every entry it precedes lexicographically
+    bool lt[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) lt[e] = d < v[e] || (d == v[e] && j < id[e]);
+#pragma unroll
+    for (int e = K - 1; e >= 1; --e) {
+        v[e] = lt[e - 1] ? v[e - 1] : (lt[e] ? d : v[e]);
+        id[e] = lt[e - 1] ? id[e - 1] : (lt[e] ? j : id[e]);
+    }
+    v[0] = lt[0] ? d : v[0];
+    id[0] = lt[0] ? j : id[0];
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void knn_f32_kernel(const float* __restrict__ PQ, const float* __restrict__ sqQ,
+                                                         int nq, const float* __restrict__ PT,
+                                                         const float* __restrict__ sqT, int nt, int k_out,
+                                                         uint32_t* __restrict__ idx, float* __restrict__ dist,
+                                                         int64_t ldo, int layout) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
+    __shared__ float s_t2[2][kTN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + c;
+    const int qrow = min(row, nq - 1);
+    // resident operand (MFMA B): this lane's query row, k = 2s + h
+    f32x4 qv[16];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(PQ + (size_t)qrow * kDim + h * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) qv[q] = qp[q];
+    }
+    const float q2 = sqQ[qrow];
+    float v[K];
+    int id[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        v[e] = INFINITY;
+        id[e] = 0x7fffffff;
+    }
+    const int ntiles = (nt + kTN - 1) / kTN;
+    f32x4 stage[8];
+    float stage_t2 = 0.f;
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;
+            const int trow = min(t * kTN + (f >> 5), nt - 1);
+            stage[u] = *reinterpret_cast<const f32x4*>(PT + (size_t)trow * kDim + (f & 31) * 4);
+        }
+        if (tid < kTN) stage_t2 = (t * kTN + tid) < nt ? sqT[t * kTN + tid] : INFINITY;
+    };
+    auto store_tile = [&](int buf) {
+        float* base = lds + buf * (kTN * kLdsRow);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u;
+            *reinterpret_cast<f32x4*>(base + (f >> 5) * kLdsRow + (f & 31) * 4) = stage[u];
+        }
+        if (tid < kTN) s_t2[buf][tid] = stage_t2;
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1);
+        const float* tile = lds + (t & 1) * (kTN * kLdsRow);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f32x4* tp = reinterpret_cast<const f32x4*>(tile + (cb * 32 + c) * kLdsRow + h * 64);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 tv = tp[q];
+                // G(train j, query i) = sum_k q_k * t_k in k-ascending fma order: the MFMA's A operand is the
+                // train value, B the query value; the product is commutative, the chain order is k
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tv.x, qv[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tv.y, qv[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tv.z, qv[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tv.w, qv[q].w, acc, 0, 0, 0);
+            }
+            const float* t2p = &s_t2[t & 1][cb * 32 + 4 * h];
+            const int jbase = t * kTN + cb * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = (r & 3) + 8 * (r >> 2);
+                // same arithmetic as the pairwise matcher: (q2 + t2) - 2*G
+                const float d = __fsub_rn(__fadd_rn(q2, t2p[jj]), __fmul_rn(2.0f, acc[r]));
+                if (__any(d < v[K - 1])) topk_insert<K>(d, jbase + jj, v, id);
+            }
+        }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+    // merge the two half-waves (disjoint column sets of the same row)
+    float pv[K];
+    int pid[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        pv[e] = __shfl_xor(v[e], 32);
+        pid[e] = __shfl_xor(id[e], 32);
+    }
+#pragma unroll
+    for (int e = 0; e < K; ++e) topk_insert<K>(pv[e], pid[e], v, id);
+    if (h == 0 && row < nq) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            if (e >= k_out) break;
+            const bool ok = id[e] != 0x7fffffff && id[e] < nt;
+            const int64_t o = layout == APS_ROWMAJOR ? (int64_t)row * ldo + e : (int64_t)e * ldo + row;
+            idx[o] = ok ? (uint32_t)id[e] + 1u : 0u;
+            dist[o] = ok ? v[e] : INFINITY;
+        }
+    }
+}
+
+// ---- featureMatchingGlobal.m:123-161 ------------------------------------------------------------------------
+__global__ void global_filter_kernel(const uint32_t* __restrict__ nn_idx, const float* __restrict__ nn_dist,
+                                     int64_t f, int k, int64_t ldn, int layout,
+                                     const uint32_t* __restrict__ img_idx, const uint32_t* __restrict__ local_idx,
+                                     float ratio, unsigned long long* __restrict__ keys /* pair<<40 | q */,
+                                     uint32_t* __restrict__ li, uint32_t* __restrict__ lj) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= f) return;
+    const uint32_t qi = img_idx[q];
+    uint32_t n0 = 0;
+    float d0 = 0, d1 = 0;
+    int c = 0;
+    for (int u = 0; u < k && c < 2; ++u) {
+        const int64_t o = layout == APS_ROWMAJOR ? q * ldn + u : (int64_t)u * ldn + q;
+        const uint32_t id = nn_idx[o];
+        if (id == 0 || id > (uint32_t)f) continue;   // missing neighbour
+        if (id == (uint32_t)(q + 1)) continue;       // :130 self
+        if (img_idx[id - 1] == qi) continue;         // :135 same image
+        if (c == 0) {
+            n0 = id;
+            d0 = nn_dist[o];
+        } else {
+            d1 = nn_dist[o];
+        }
+        ++c;
+    }
+    unsigned long long key = ~0ull;
+    if (c >= 2) {                                    // :140
+        const float eps = 1.1920928955078125e-07f;
+        const float r = d0 / (d1 > eps ? d1 : eps);  // :145 in single
+        if (!(r > ratio)) {
+            const uint32_t j = img_idx[n0 - 1];
+            const uint32_t a = qi < j ? qi : j, b = qi < j ? j : qi;  // 1-based image ids, a < b
+            const unsigned long long pair = (unsigned long long)(b - 1) * (b - 2) / 2 + (a - 1);
+            key = (pair << 40) | (unsigned long long)q;
+            li[q] = qi < j ? local_idx[q] : local_idx[n0 - 1];
+            lj[q] = qi < j ? local_idx[n0 - 1] : local_idx[q];
+        }
+    }
+    keys[q] = key;
+}
+
+__global__ void global_emit_kernel(const unsigned long long* __restrict__ sorted, int64_t total,
+                                   const uint32_t* __restrict__ li, const uint32_t* __restrict__ lj,
+                                   uint32_t* __restrict__ oi, uint32_t* __restrict__ oj,
+                                   unsigned long long* __restrict__ pair_count) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const unsigned long long key = sorted[e];
+    const int64_t q = (int64_t)(key & ((1ull << 40) - 1));
+    oi[e] = li[q];
+    oj[e] = lj[q];
+    atomicAdd(&pair_count[key >> 40], 1ull);
+}
+
+// ---- Hamming 2-NN ----------------------------------------------------------------------------------------------
+// one thread per A row (its bytes in registers), B streamed through LDS in tiles; the scan order over j and the
+// strict-< / <= update rule are those of nearest2HammingExhaustiveMEX.cpp:52-69.
+template <int NW>  // words of 4 bytes per descriptor
+__global__ void hamming_kernel(const uint32_t* __restrict__ A, int64_t n1, const uint32_t* __restrict__ B, int64_t n2,
+                               int nbytes, uint32_t* __restrict__ idx2, float* __restrict__ d1, float* __restrict__ d2) {
+    __shared__ uint32_t s_b[256 * NW];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t a[NW];
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) a[wv] = i < n1 ? A[i * NW + wv] : 0u;
+    unsigned best = 0xFFFFu, second = 0xFFFFu;
+    int64_t ibest = -1, isecond = -1;
+    for (int64_t j0 = 0; j0 < n2; j0 += 256) {
+        const int cnt = (int)(n2 - j0 < 256 ? n2 - j0 : 256);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * NW; e += blockDim.x) s_b[e] = B[j0 * NW + e];
+        __syncthreads();
+        for (int jj = 0; jj < cnt; ++jj) {
+            unsigned hsum = 0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) hsum += __popc(a[wv] ^ s_b[jj * NW + wv]);
+            const int64_t j = j0 + jj;
+            if (hsum < best) {
+                second = best;
+                isecond = ibest;
+                best = hsum;
+                ibest = j;
+            } else if (hsum <= second && j != ibest) {
+                second = hsum;
+                isecond = j;
+            }
+        }
+    }
+    if (i >= n1) return;
+    if (n2 == 1 || isecond == -1) second = (unsigned)(nbytes * 8);  // :71-74
+    idx2[i] = (uint32_t)(ibest + 1);
+    d1[i] = (float)best;
+    d2[i] = (float)second;
+}
+
+__global__ void pack_bytes_kernel(const uint8_t* __restrict__ X, int64_t n, int64_t ld, int nbytes, int layout, int nw,
+                                  uint32_t* __restrict__ out) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n * nw) return;
+    const int64_t i = e / nw;
+    const int wv = (int)(e % nw);
+    uint32_t v = 0;
+    for (int b = 0; b < 4; ++b) {
+        const int k = 4 * wv + b;
+        if (k < nbytes) v |= (uint32_t)(layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + (int64_t)k * ld]) << (8 * b);
+    }
+    out[e] = v;
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" {
+
+int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* query, int64_t fq, int64_t ldq,
+                   int dim, int layout, int k, uint32_t* idx, float* dist, int64_t ldo) {
+    return guarded([&] {
+        APS_REQUIRE(dim == kDim, APS_E_DIM, "descriptor length %d not supported (built for %d-D SIFT)", dim, kDim);
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(k > 0, APS_E_ARG, "k must be > 0");                       // flann_knn:k
+        APS_REQUIRE(k <= 8, APS_E_ARG, "k <= 8 supported (featureMatchingGlobal uses k = 4)");
+        APS_REQUIRE(ft >= 0 && fq >= 0 && ft < (1ll << 31) && fq < (1ll << 31), APS_E_ARG, "bad sizes");
+        APS_REQUIRE(fq == 0 || (idx && dist && query), APS_E_ARG, "NULL argument");
+        APS_REQUIRE(ft == 0 || train, APS_E_ARG, "NULL train");
+        if (layout == APS_ROWMAJOR)
+            APS_REQUIRE(ldt >= dim && ldq >= dim && ldo >= k, APS_E_DIM, "leading dimension too small");
+        else
+            APS_REQUIRE(ldt >= ft && ldq >= fq && ldo >= fq, APS_E_DIM, "leading dimension too small");
+        ctx();
+        if (fq == 0) return;
+        const size_t te = ft == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(ft - 1) * ldt + dim : (size_t)(dim - 1) * ldt + ft);
+        const size_t qe = layout == APS_ROWMAJOR ? (size_t)(fq - 1) * ldq + dim : (size_t)(dim - 1) * ldq + fq;
+        const size_t oe = layout == APS_ROWMAJOR ? (size_t)(fq - 1) * ldo + k : (size_t)(k - 1) * ldo + fq;
+        const bool same = train == query && ft == fq && ldt == ldq;
+        In<float> dT(train, te), dQ;
+        if (!same) dQ.bind(query, qe);
+        Out<uint32_t> oi(idx, oe);
+        Out<float> od(dist, oe);
+        Ws<float> PT((size_t)std::max<int64_t>(ft, 1) * kDim), sT(std::max<int64_t>(ft, 1)), PQ, sQ;
+        if (ft > 0) knn_prep_kernel<<<cdiv(ft, 64), 64, 0, stream()>>>(dT, ft, ldt, layout, PT, sT);
+        const float *pq = PT, *sq = sT;
+        if (!same) {
+            PQ.alloc((size_t)fq * kDim);
+            sQ.alloc(fq);
+            knn_prep_kernel<<<cdiv(fq, 64), 64, 0, stream()>>>(dQ, fq, ldq, layout, PQ, sQ);
+            pq = PQ;
+            sq = sQ;
+        }
+        check_launch("knn_prep_kernel");
+        if (ft == 0) {
+            std::vector<uint32_t> z(oe, 0u);
+            std::vector<float> inf(oe, INFINITY);
+            APS_HIP(hipMemcpyAsync(oi.get(), z.data(), oe * sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemcpyAsync(od.get(), inf.data(), oe * sizeof(float), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+        } else {
+            Prof prof("knn_f32");
+            if (k <= 4)
+                knn_f32_kernel<4><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout);
+            else
+                knn_f32_kernel<8><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout);
+        }
+        check_launch("knn_f32_kernel");
+        oi.commit();
+        od.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_global_filter(const uint32_t* nn_idx, const float* nn_dist, int64_t f, int k, int64_t ldn, int layout,
+                      const uint32_t* img_idx, const uint32_t* local_idx, int n_img, float ratio,
+                      int64_t* pair_ptr, uint32_t* idx_i, uint32_t* idx_j, int64_t cap, int64_t* count) {
+    return guarded([&] {
+        APS_REQUIRE(count && pair_ptr, APS_E_ARG, "count/pair_ptr is NULL");
+        APS_REQUIRE(f >= 0 && k > 0 && n_img >= 0 && cap >= 0, APS_E_ARG, "bad sizes");
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(f < (1ll << 40), APS_E_DIM, "too many features");
+        APS_REQUIRE(f == 0 || (nn_idx && nn_dist && img_idx && local_idx), APS_E_ARG, "NULL argument");
+        ctx();
+        const int64_t n_pairs = (int64_t)n_img * (n_img - 1) / 2;
+        *count = 0;
+        std::vector<int64_t> hp(std::max<int64_t>(n_pairs, 0) + 1, 0);
+        if (f > 0 && n_pairs > 0) {
+            const size_t ne = layout == APS_ROWMAJOR ? (size_t)(f - 1) * ldn + k : (size_t)(k - 1) * ldn + f;
+            In<uint32_t> di(nn_idx, ne), dimg(img_idx, f), dloc(local_idx, f);
+            In<float> dd(nn_dist, ne);
+            Ws<unsigned long long> keys(f), sorted(f), pc(n_pairs);
+            Ws<uint32_t> li(f), lj(f);
+            APS_HIP(hipMemsetAsync(pc, 0, n_pairs * sizeof(unsigned long long), stream()));
+            global_filter_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(di, dd, f, k, ldn, layout, dimg, dloc, ratio, keys, li, lj);
+            check_launch("global_filter_kernel");
+            size_t tb = 0;
+            APS_HIP(rocprim::radix_sort_keys(nullptr, tb, keys.get(), sorted.get(), (unsigned)f, 0, 64, stream()));
+            Ws<char> tmp(tb);
+            APS_HIP(rocprim::radix_sort_keys(tmp.get(), tb, keys.get(), sorted.get(), (unsigned)f, 0, 64, stream()));
+            // rejected queries carry key ~0 and sink to the end: count the accepted prefix on the host side
+            std::vector<unsigned long long> hs(f);
+            APS_HIP(hipMemcpyAsync(hs.data(), sorted, f * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+            const int64_t total = std::lower_bound(hs.begin(), hs.end(), ~0ull) - hs.begin();
+            *count = total;
+            for (int64_t e = 0; e < total; ++e) hp[(hs[e] >> 40) + 1]++;
+            for (int64_t p = 0; p < n_pairs; ++p) hp[p + 1] += hp[p];
+            if (total > cap) fail(APS_E_CAP, "output capacity %lld < %lld matches", (long long)cap, (long long)total);
+            if (total > 0) {
+                APS_REQUIRE(idx_i && idx_j, APS_E_ARG, "NULL output with matches present");
+                Out<uint32_t> oi(idx_i, total), oj(idx_j, total);
+                global_emit_kernel<<<cdiv(total, 256), 256, 0, stream()>>>(sorted, total, li, lj, oi, oj, pc);
+                check_launch("global_emit_kernel");
+                oi.commit();
+                oj.commit();
+                APS_HIP(hipStreamSynchronize(stream()));
+            }
+        }
+        if (is_device_ptr(pair_ptr))
+            APS_HIP(hipMemcpy(pair_ptr, hp.data(), hp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        else
+            std::copy(hp.begin(), hp.end(), pair_ptr);
+    });
+}
+
+int aps_hamming_2nn(const uint8_t* A, int64_t n1, int64_t lda, const uint8_t* B, int64_t n2, int64_t ldb,
+                    int nbytes, int layout, uint32_t* idx2, float* d1, float* d2) {
+    return guarded([&] {
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(n1 >= 0 && n2 >= 0, APS_E_ARG, "negative size");
+        APS_REQUIRE(nbytes > 0 && nbytes <= 64, APS_E_DIM, "byte width must be in 1..64 (ORB 32, BRISK 64)");
+        APS_REQUIRE(n1 == 0 || (A && idx2 && d1 && d2), APS_E_ARG, "NULL argument");
+        APS_REQUIRE(n2 == 0 || B, APS_E_ARG, "NULL B");
+        if (layout == APS_ROWMAJOR)
+            APS_REQUIRE(lda >= nbytes && ldb >= nbytes, APS_E_DIM, "Byte width mismatch.");  // hamm2nn:cols
+        else
+            APS_REQUIRE(lda >= n1 && ldb >= n2, APS_E_DIM, "leading dimension too small");
+        ctx();
+        if (n1 == 0) return;
+        Out<uint32_t> oi(idx2, n1);
+        Out<float> o1(d1, n1), o2(d2, n1);
+        if (n2 == 0) {  // :42-45
+            std::vector<uint32_t> z(n1, 0u);
+            std::vector<float> nan(n1, NAN);
+            APS_HIP(hipMemcpyAsync(oi.get(), z.data(), n1 * sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemcpyAsync(o1.get(), nan.data(), n1 * sizeof(float), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemcpyAsync(o2.get(), nan.data(), n1 * sizeof(float), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+        } else {
+            const size_t ae = layout == APS_ROWMAJOR ? (size_t)(n1 - 1) * lda + nbytes : (size_t)(nbytes - 1) * lda + n1;
+            const size_t be = layout == APS_ROWMAJOR ? (size_t)(n2 - 1) * ldb + nbytes : (size_t)(nbytes - 1) * ldb + n2;
+            In<uint8_t> dA(A, ae), dB(B, be);
+            const int nw = nbytes <= 32 ? 8 : 16;
+            Ws<uint32_t> pa((size_t)n1 * nw), pb((size_t)n2 * nw);
+            pack_bytes_kernel<<<cdiv((size_t)n1 * nw, 256), 256, 0, stream()>>>(dA, n1, lda, nbytes, layout, nw, pa);
+            pack_bytes_kernel<<<cdiv((size_t)n2 * nw, 256), 256, 0, stream()>>>(dB, n2, ldb, nbytes, layout, nw, pb);
+            Prof prof("hamming_2nn");
+            if (nw == 8)
+                hamming_kernel<8><<<cdiv(n1, 256), 256, 0, stream()>>>(pa, n1, pb, n2, nbytes, oi, o1, o2);
+            else
+                hamming_kernel<16><<<cdiv(n1, 256), 256, 0, stream()>>>(pa, n1, pb, n2, nbytes, oi, o1, o2);
+            check_launch("hamming_kernel");
+        }
+        oi.commit();
+        o1.commit();
+        o2.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+}  // extern "C"

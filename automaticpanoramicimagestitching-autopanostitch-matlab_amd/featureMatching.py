@@ -262,3 +262,81 @@ def getFeaturePoints(input, ImageOriginal):
             raise NotImplementedError(f"detector '{det}' is a MATLAB toolbox/VLFeat call; only 'SIFT' runs on the device")
         raise ValueError("Need a valid input!")  # getFeaturePoints.m:67
     return sift_extract(input, ImageOriginal)
+
+
+# ---- global matcher (featureMatchingGlobal.m) and the mex contracts it calls ------------------------
+def flann_knn_win(train, query, k, method="flann", trees=4, checks=32):
+    """[idx, dist] = flann_knn_win(train, query, k, 'flann', trees, checks) (PP/mex/flann_knn.cpp:118-253) for
+    float descriptors, computed EXACTLY on the device (the reference's kd-forest is approximate and
+    seed-dependent; `trees`/`checks` are accepted and ignored).  idx: Fq x k uint32 1-based, dist: Fq x k
+    single squared-L2, ascending."""
+    if k != int(k) or k <= 0:
+        raise ValueError("k must be > 0")  # flann_knn:k
+    if str(method) != "flann":
+        raise NotImplementedError("'bf' is the binary-descriptor BFMatcher path (see nearest2HammingExhaustiveMEX)")
+    T, ft, ldt, lt = _as_desc(train)
+    Q, fq, ldq, lq = _as_desc(query)
+    if (ft and T.shape[1] != DIM) or (fq and Q.shape[1] != DIM) or lt != lq:
+        raise ValueError("query must have same descriptor dimension as train")  # flann_knn:dim
+    k = int(k)
+    idx = np.zeros((fq, k), np.uint32)
+    dist = np.zeros((fq, k), np.float32)
+    check(lib.aps_knn_global(ptr(T), ft, ldt, ptr(Q), fq, ldq, DIM, lt, k, ptr(idx), ptr(dist), k))
+    return idx, dist
+
+
+def nearest2HammingExhaustiveMEX(Abytes, Bbytes):
+    """[idx2, d1, d2] = nearest2HammingExhaustiveMEX(Abytes, Bbytes) (PP/mex/nearest2HammingExhaustiveMEX.cpp)."""
+    A = np.ascontiguousarray(Abytes)
+    B = np.ascontiguousarray(Bbytes)
+    if A.dtype != np.uint8 or B.dtype != np.uint8:
+        raise TypeError("Inputs must be uint8.")  # hamm2nn:type
+    if A.ndim != 2 or B.ndim != 2:
+        raise ValueError("2D only.")  # hamm2nn:dim
+    if A.shape[1] != B.shape[1]:
+        raise ValueError("Byte width mismatch.")  # hamm2nn:cols
+    n1 = A.shape[0]
+    idx2 = np.zeros(n1, np.uint32)
+    d1 = np.zeros(n1, np.float32)
+    d2 = np.zeros(n1, np.float32)
+    check(lib.aps_hamming_2nn(ptr(A), n1, A.shape[1], ptr(B), B.shape[0], B.shape[1], A.shape[1],
+                              _capi.APS_ROWMAJOR, ptr(idx2), ptr(d1), ptr(d2)))
+    return idx2, d1, d2
+
+
+nearest2HammingExhaustiveOMPMEX = nearest2HammingExhaustiveMEX  # same arithmetic (OMP twin)
+
+
+def featureMatchingGlobal(input, allDescriptors, numImg):
+    """matches = featureMatchingGlobal(input, allDescriptors, numImg) (featureMatchingGlobal.m:1-161): pool all
+    descriptors, L2-normalise (:80-86), exact kNN (k = input.k) of the pool against itself, per-query filter
+    (drop self / same image, need >= 2, ratio on squared L2), append to the upper-triangular cell in query order."""
+    numImg = int(numImg)
+    counts = [len(d) for d in allDescriptors]
+    matches = [[None] * numImg for _ in range(numImg)]
+    F = sum(counts)
+    if F == 0:
+        return matches
+    k = int(input.get("k", 4))
+    ratio = float(input.get("Ratiothreshold", 0.6))
+    pool = np.concatenate([np.asarray(d.cpu() if _capi.is_torch(d) else d, np.float32) for d in allDescriptors])
+    # allDesc ./ sqrt(sum(allDesc.^2,2) + eps('single'))  (:83-85) — eps INSIDE the root, unlike normalizeRowsL2
+    sq = np.zeros(F, np.float32)
+    for kk in range(DIM):
+        sq = sq + pool[:, kk] * pool[:, kk]
+    pool = (pool / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    img_idx = np.repeat(np.arange(1, numImg + 1, dtype=np.uint32), counts)
+    local_idx = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
+    nn_idx, nn_dist = flann_knn_win(pool, pool, k)
+    npairs = numImg * (numImg - 1) // 2
+    pair_ptr = np.zeros(npairs + 1, np.int64)
+    oi = np.zeros(F, np.uint32)
+    oj = np.zeros(F, np.uint32)
+    cnt = C.c_int64(0)
+    check(lib.aps_global_filter(ptr(nn_idx), ptr(nn_dist), F, k, k, _capi.APS_ROWMAJOR, ptr(img_idx), ptr(local_idx),
+                                numImg, ratio, ptr(pair_ptr), ptr(oi), ptr(oj), F, C.byref(cnt)))
+    for p, (i, j) in enumerate(pair_order(numImg)):
+        s, e = pair_ptr[p], pair_ptr[p + 1]
+        if e > s:
+            matches[i][j] = np.stack([oi[s:e], oj[s:e]], axis=1).astype(np.float64)
+    return matches

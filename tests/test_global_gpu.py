@@ -1,0 +1,96 @@
+"""GPU parity for the global matcher's device side (exact kNN, per-query filter) and the Hamming 2-NN."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle
+from util import bits, sift_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fm(gpu):
+    return import_module(gpu.__name__ + ".featureMatching")
+
+
+@pytest.mark.parametrize("ft,fq,k", [(300, 300, 4), (1000, 257, 4), (64, 500, 8), (5, 40, 4), (3000, 3000, 2)])
+def test_knn_bit_exact(fm, ft, fq, k):
+    rng = np.random.default_rng(ft + fq + k)
+    train = sift_like(rng, ft)
+    query = train if ft == fq else sift_like(rng, fq)
+    train[ft // 2] = train[1]  # an exact duplicate: ties resolve to the lower index
+    idx, dist = fm.flann_knn_win(train, query, k)
+    oi, od = oracle.knn(train, query, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(bits(dist), bits(od))
+    if ft == fq:
+        assert np.array_equal(idx[:, 0][np.arange(ft) != ft // 2], (np.arange(ft) + 1)[np.arange(ft) != ft // 2])
+
+
+def test_knn_fewer_train_rows_than_k_and_errors(fm, gpu):
+    rng = np.random.default_rng(1)
+    t, q = sift_like(rng, 2), sift_like(rng, 7)
+    idx, dist = fm.flann_knn_win(t, q, 4)
+    assert np.all(idx[:, 2:] == 0) and np.all(np.isinf(dist[:, 2:])) and np.all(idx[:, :2] > 0)
+    with pytest.raises(ValueError):
+        fm.flann_knn_win(t, q, 0)
+    with pytest.raises(gpu.ApsError):
+        fm.flann_knn_win(t, q, 9)
+
+
+def test_global_matcher_equals_oracle_chain(fm):
+    rng = np.random.default_rng(2)
+    base = sift_like(rng, 700)
+    descs = []
+    for i in range(4):
+        keep = rng.permutation(700)[: 350 + 40 * i]
+        d = base[keep] + 0.02 * rng.standard_normal((len(keep), 128)).astype(np.float32)
+        descs.append(np.maximum(d, 0).astype(np.float32))
+    inp = {"k": 4, "Ratiothreshold": 0.6}
+    cells = fm.featureMatchingGlobal(inp, descs, 4)
+    # oracle chain: same pooling/normalisation, exact kNN, sequential filter
+    pool = np.concatenate(descs)
+    sq = np.zeros(len(pool), np.float32)
+    for kk in range(128):
+        sq = sq + pool[:, kk] * pool[:, kk]
+    pool = (pool / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    counts = [len(d) for d in descs]
+    img = np.repeat(np.arange(1, 5, dtype=np.uint32), counts)
+    loc = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
+    ni, nd = oracle.knn(pool, pool, 4)
+    rows = oracle.global_filter(ni, nd, img, loc, 0.6)
+    total = 0
+    for i in range(4):
+        for j in range(i + 1, 4):
+            exp = rows[(rows[:, 0] == i + 1) & (rows[:, 1] == j + 1)][:, 2:]
+            got = cells[i][j]
+            if len(exp) == 0:
+                assert got is None
+            else:
+                assert np.array_equal(got, exp.astype(np.float64)), (i, j)
+            total += len(exp)
+    assert total > 300
+
+
+def test_hamming_equals_oracle_including_edges(fm):
+    rng = np.random.default_rng(3)
+    for nb in (32, 64, 17):
+        A = rng.integers(0, 256, (300, nb), dtype=np.uint8)
+        B = rng.integers(0, 256, (777, nb), dtype=np.uint8)
+        B[5] = A[0]
+        B[600] = A[0]          # equal best distances: first wins (strict <), later one becomes second via <=
+        B[10] = B[11]
+        got = fm.nearest2HammingExhaustiveMEX(A, B)
+        exp = oracle.hamming_2nn(A, B)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
+    one = fm.nearest2HammingExhaustiveMEX(A, B[:1])
+    assert np.all(one[2] == 17 * 8) and np.all(one[0] == 1)
+    none = fm.nearest2HammingExhaustiveMEX(A, B[:0])
+    assert np.all(none[0] == 0) and np.all(np.isnan(none[1])) and np.all(np.isnan(none[2]))
+    with pytest.raises(ValueError):
+        fm.nearest2HammingExhaustiveMEX(A, B[:, :8])
+    with pytest.raises(TypeError):
+        fm.nearest2HammingExhaustiveMEX(A.astype(np.float32), B)
