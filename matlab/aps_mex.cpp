@@ -1,0 +1,295 @@
+// aps_mex.cpp — the thin MATLAB mex gateway over libaps_hip.so's C ABI (include/aps.h).
+//
+// Build (on a machine that has MATLAB; NOT compiled in this repository's CI — there is no mex.h here):
+//     mex -O -I../include aps_mex.cpp -L../<package>/lib -laps_hip
+// One gateway, dispatched on a command string, replaces the reference's three mex files
+// (PP/mex/flann_knn.cpp, nearest2HammingExhaustiveMEX.cpp, nearest2HammingExhaustiveOMPMEX.cpp) and adds
+// the entry points the shadowing .m wrappers in this directory call.  Conventions kept from the reference
+// gateways: inputs are borrowed column-major mxArrays (flann_knn.cpp:111-112), outputs are created with
+// mxCreateNumericMatrix and owned by MATLAB (:193-194), indices are 1-based uint32, distances single, errors
+// are raised with mexErrMsgIdAndTxt("aps:<kind>", ...) (cf. "flann_knn:type", "hamm2nn:cols").
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aps.h"
+#include "mex.h"
+
+static void check(int rc) {
+    if (rc == APS_OK) return;
+    const char* kind = rc == APS_E_ARG ? "aps:args" : rc == APS_E_DIM ? "aps:dim" : rc == APS_E_TYPE ? "aps:type"
+                     : rc == APS_E_OOM ? "aps:oom" : rc == APS_E_DEVICE ? "aps:device" : rc == APS_E_CAP ? "aps:cap" : "aps:internal";
+    mexErrMsgIdAndTxt(kind, "%s", aps_last_error());
+}
+static std::string str(const mxArray* a) {
+    char* c = mxArrayToString(a);
+    std::string s(c ? c : "");
+    if (c) mxFree(c);
+    return s;
+}
+static double field(const mxArray* s, const char* name, double dflt) {
+    const mxArray* f = mxIsStruct(s) ? mxGetField(s, 0, name) : nullptr;
+    return f ? mxGetScalar(f) : dflt;
+}
+static void need(bool ok, const char* id, const char* msg) {
+    if (!ok) mexErrMsgIdAndTxt(id, "%s", msg);
+}
+
+// [features, validPts] = aps_mex('sift_extract', img_uint8, input)
+static void cmd_sift(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 3 && mxIsUint8(prhs[1]), "aps:type", "usage: aps_mex('sift_extract', uint8 image, input struct)");
+    const mwSize* d = mxGetDimensions(prhs[1]);
+    const int h = (int)d[0], w = (int)d[1], c = mxGetNumberOfDimensions(prhs[1]) > 2 ? (int)d[2] : 1;
+    aps_sift_params p;
+    p.sigma = field(prhs[2], "Sigma", 1.6);
+    p.n_layers = (int)field(prhs[2], "NumLayersInOctave", 4);
+    p.contrast_threshold = field(prhs[2], "ContrastThreshold", 0.00133);
+    p.edge_threshold = field(prhs[2], "EdgeThreshold", 6);
+    p.max_features = 0;
+    int64_t cap = (int64_t)h * w / 64 + 4096, count = 0;
+    for (;;) {
+        mxArray* desc = mxCreateNumericMatrix(cap, 128, mxSINGLE_CLASS, mxREAL);
+        mxArray* loc = mxCreateNumericMatrix(cap, 2, mxDOUBLE_CLASS, mxREAL);
+        const int rc = aps_sift_extract((const uint8_t*)mxGetData(prhs[1]), h, w, c, APS_IMG_U8_MATLAB, &p,
+                                        (float*)mxGetData(desc), APS_COLMAJOR, cap, mxGetPr(loc), cap, nullptr, cap, &count);
+        if (rc == APS_E_CAP && count > cap) {
+            mxDestroyArray(desc);
+            mxDestroyArray(loc);
+            cap = count;
+            continue;
+        }
+        check(rc);
+        // shrink to count rows (column-major: compact each column)
+        mxArray* f = mxCreateNumericMatrix(count, 128, mxSINGLE_CLASS, mxREAL);
+        mxArray* v = mxCreateNumericMatrix(count, 2, mxDOUBLE_CLASS, mxREAL);
+        for (int k = 0; k < 128; ++k)
+            std::memcpy((float*)mxGetData(f) + (size_t)k * count, (float*)mxGetData(desc) + (size_t)k * cap, sizeof(float) * count);
+        for (int k = 0; k < 2; ++k) std::memcpy(mxGetPr(v) + (size_t)k * count, mxGetPr(loc) + (size_t)k * cap, sizeof(double) * count);
+        mxDestroyArray(desc);
+        mxDestroyArray(loc);
+        plhs[0] = f;
+        if (nlhs > 1) plhs[1] = v; else mxDestroyArray(v);
+        return;
+    }
+}
+
+static aps_match_opts match_opts(const mxArray* s) {
+    aps_match_opts o;
+    o.max_ratio = (float)field(s, "MaxRatio", 0.6);
+    o.match_threshold = (float)field(s, "MatchThreshold", 3.5);
+    o.unique = field(s, "Unique", 1) != 0;
+    o.normalize = 2;
+    return o;
+}
+
+// [matches, metric] = aps_mex('match_features', F1 single N1x128, F2 single N2x128, opts)
+static void cmd_match(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 4 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]), "aps:type", "descriptors must be single");
+    const int64_t n1 = mxGetM(prhs[1]), n2 = mxGetM(prhs[2]);
+    need(mxGetN(prhs[1]) == mxGetN(prhs[2]), "aps:dim", "Descriptor dimensions must match for non-binary.");
+    const aps_match_opts o = match_opts(prhs[3]);
+    std::vector<uint32_t> i1(n1 ? n1 : 1), i2(n1 ? n1 : 1);
+    std::vector<float> met(n1 ? n1 : 1);
+    int64_t k = 0;
+    check(aps_match_features((const float*)mxGetData(prhs[1]), n1, n1, (const float*)mxGetData(prhs[2]), n2, n2,
+                             (int)mxGetN(prhs[1]), APS_COLMAJOR, &o, i1.data(), i2.data(), met.data(), n1, &k));
+    plhs[0] = mxCreateNumericMatrix(k, 2, mxUINT32_CLASS, mxREAL);
+    uint32_t* m = (uint32_t*)mxGetData(plhs[0]);
+    for (int64_t e = 0; e < k; ++e) { m[e] = i1[e]; m[e + k] = i2[e]; }
+    if (nlhs > 1) {
+        plhs[1] = mxCreateNumericMatrix(k, 1, mxSINGLE_CLASS, mxREAL);
+        std::memcpy(mxGetData(plhs[1]), met.data(), sizeof(float) * k);
+    }
+}
+
+// matches = aps_mex('match_pairwise', allDescriptors (1xN cell of single Ki x 128), opts) -> N x N cell, upper triangle
+static void cmd_pairwise(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 3 && mxIsCell(prhs[1]), "aps:type", "allDescriptors must be a cell array");
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    std::vector<const float*> ptr(n);
+    std::vector<int64_t> cnt(n), ld(n);
+    int64_t cap = 0;
+    for (int i = 0; i < n; ++i) {
+        const mxArray* d = mxGetCell(prhs[1], i);
+        need(d && mxIsSingle(d) && (mxGetM(d) == 0 || mxGetN(d) == 128), "aps:type", "descriptors must be single K x 128");
+        ptr[i] = (const float*)mxGetData(d);
+        cnt[i] = ld[i] = (int64_t)mxGetM(d);
+        cap += cnt[i];
+    }
+    const int64_t np = (int64_t)n * (n - 1) / 2;
+    const aps_match_opts o = match_opts(prhs[2]);
+    std::vector<int64_t> pp(np + 1);
+    std::vector<uint32_t> ii, jj;
+    std::vector<float> met;
+    int64_t k = 0;
+    cap = cap / 4 + 1;
+    for (;;) {
+        ii.resize(cap); jj.resize(cap); met.resize(cap);
+        const int rc = aps_match_pairwise(ptr.data(), cnt.data(), ld.data(), n, 128, APS_COLMAJOR, &o, pp.data(), ii.data(), jj.data(), met.data(), cap, &k);
+        if (rc == APS_E_CAP) { cap = k; continue; }
+        check(rc);
+        break;
+    }
+    plhs[0] = mxCreateCellMatrix(n, n);
+    int64_t p = 0;
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i, ++p) {  // featureMatchingPairwise.m:48 order
+            const int64_t s = pp[p], m = pp[p + 1] - pp[p];
+            mxArray* c = mxCreateDoubleMatrix(m, 2, mxREAL);  // double(matches), :120
+            double* out = mxGetPr(c);
+            for (int64_t e = 0; e < m; ++e) { out[e] = ii[s + e]; out[e + m] = jj[s + e]; }
+            mxSetCell(plhs[0], i + (mwSize)j * n, c);
+        }
+}
+
+// [idx, dist] = aps_mex('knn_global', train, query, k)            (flann_knn_win contract)
+static void cmd_knn(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs >= 4 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]), "flann_knn:type", "Descriptors must be single (float)");
+    need(mxIsDouble(prhs[3]) && mxGetNumberOfElements(prhs[3]) == 1, "flann_knn:type", "k must be a scalar double");
+    const int k = (int)mxGetScalar(prhs[3]);
+    need(k > 0, "flann_knn:k", "k must be > 0");
+    need(mxGetN(prhs[1]) == mxGetN(prhs[2]), "flann_knn:dim", "query must have same descriptor dimension as train");
+    const int64_t ft = mxGetM(prhs[1]), fq = mxGetM(prhs[2]);
+    plhs[0] = mxCreateNumericMatrix(fq, k, mxUINT32_CLASS, mxREAL);
+    mxArray* dist = mxCreateNumericMatrix(fq, k, mxSINGLE_CLASS, mxREAL);
+    check(aps_knn_global((const float*)mxGetData(prhs[1]), ft, ft, (const float*)mxGetData(prhs[2]), fq, fq, (int)mxGetN(prhs[1]),
+                         APS_COLMAJOR, k, (uint32_t*)mxGetData(plhs[0]), (float*)mxGetData(dist), fq));
+    if (nlhs > 1) plhs[1] = dist; else mxDestroyArray(dist);
+}
+
+// [idx2, d1, d2] = aps_mex('hamming_2nn', Abytes, Bbytes)
+static void cmd_hamming(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 3, "hamm2nn:nrhs", "Need Abytes,Bbytes");
+    need(mxIsUint8(prhs[1]) && mxIsUint8(prhs[2]), "hamm2nn:type", "Inputs must be uint8.");
+    need(mxGetNumberOfDimensions(prhs[1]) == 2 && mxGetNumberOfDimensions(prhs[2]) == 2, "hamm2nn:dim", "2D only.");
+    need(mxGetN(prhs[1]) == mxGetN(prhs[2]), "hamm2nn:cols", "Byte width mismatch.");
+    const int64_t n1 = mxGetM(prhs[1]), n2 = mxGetM(prhs[2]);
+    plhs[0] = mxCreateNumericMatrix(n1, 1, mxUINT32_CLASS, mxREAL);
+    mxArray* d1 = mxCreateNumericMatrix(n1, 1, mxSINGLE_CLASS, mxREAL);
+    mxArray* d2 = mxCreateNumericMatrix(n1, 1, mxSINGLE_CLASS, mxREAL);
+    check(aps_hamming_2nn((const uint8_t*)mxGetData(prhs[1]), n1, n1, (const uint8_t*)mxGetData(prhs[2]), n2, n2, (int)mxGetN(prhs[1]),
+                          APS_COLMAJOR, (uint32_t*)mxGetData(plhs[0]), (float*)mxGetData(d1), (float*)mxGetData(d2)));
+    if (nlhs > 1) plhs[1] = d1; else mxDestroyArray(d1);
+    if (nlhs > 2) plhs[2] = d2; else mxDestroyArray(d2);
+}
+
+// [model, inliers, isFound] = aps_mex('ransac_homography', p1 Mx2, p2 Mx2, input, sampleIdx uint32 4xS)
+static void cmd_ransac(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 5 && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsUint32(prhs[4]), "aps:type", "usage: p1, p2 double Mx2; sampleIdx uint32 4xS");
+    const int64_t m = mxGetM(prhs[1]);
+    need(mxGetM(prhs[2]) == (mwSize)m, "aps:dim", "matchedPoints1 and matchedPoints2 must have the same number of rows.");
+    aps_ransac_opts o;
+    o.max_distance = field(prhs[3], "maxDistance", 2.0);
+    o.confidence = field(prhs[3], "inliersConfidence", 99.9);
+    o.max_iter = (int)field(prhs[3], "maxIter", 500);
+    o.tform_type = APS_TFORM_PROJECTIVE;
+    plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
+    std::vector<uint8_t> mask(m ? m : 1);
+    int found = 0;
+    if (m >= 4)
+        check(aps_ransac_homography(mxGetPr(prhs[1]), mxGetPr(prhs[2]), m, m, (const uint32_t*)mxGetData(prhs[4]), (int)mxGetN(prhs[4]), &o,
+                                    mxGetPr(plhs[0]), mask.data(), &found, nullptr));
+    if (nlhs > 1) {
+        plhs[1] = mxCreateLogicalMatrix(m, 1);
+        mxLogical* l = mxGetLogicals(plhs[1]);
+        for (int64_t e = 0; e < m; ++e) l[e] = mask[e] != 0;
+    }
+    if (nlhs > 2) plhs[2] = mxCreateLogicalScalar(found != 0);
+}
+
+// F = aps_mex('multiband_blend', Ci (1xK cell of single h x w x 3), Wi (1xK cell of single h x w), levels, sigma)
+// F = aps_mex('linear_blend', Ci, Wi)
+static void cmd_blend(bool multiband, int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs >= 3 && mxIsCell(prhs[1]) && mxIsCell(prhs[2]), "aps:type", "Ci and Wi must be cell arrays");
+    const int K = (int)mxGetNumberOfElements(prhs[1]);
+    need(K >= 1 && K == (int)mxGetNumberOfElements(prhs[2]), "aps:dim", "numel(Ci) must equal numel(Wi) >= 1");
+    const mwSize* d = mxGetDimensions(mxGetCell(prhs[1], 0));
+    const int h = (int)d[0], w = (int)d[1];
+    const size_t hw = (size_t)h * w;
+    std::vector<float> C(hw * 3 * K), W(hw * K), F(hw * 3);
+    for (int k = 0; k < K; ++k) {  // MATLAB planar column-major -> row-major interleaved
+        const mxArray* c = mxGetCell(prhs[1], k);
+        const mxArray* wv = mxGetCell(prhs[2], k);
+        need(mxIsSingle(c) && mxIsSingle(wv), "aps:type", "layers must be single");
+        const float* cp = (const float*)mxGetData(c);
+        const float* wp = (const float*)mxGetData(wv);
+        const int ch = mxGetNumberOfDimensions(c) > 2 ? (int)mxGetDimensions(c)[2] : 1;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                for (int q = 0; q < 3; ++q) C[((size_t)k * hw + (size_t)y * w + x) * 3 + q] = cp[(size_t)(ch == 1 ? 0 : q) * hw + (size_t)x * h + y];
+                W[(size_t)k * hw + (size_t)y * w + x] = wp[(size_t)x * h + y];
+            }
+    }
+    if (multiband)
+        check(aps_multiband_blend(C.data(), W.data(), K, h, w, (int)mxGetScalar(prhs[3]), nrhs > 4 ? (float)mxGetScalar(prhs[4]) : 1.0f, F.data()));
+    else
+        check(aps_linear_blend(C.data(), W.data(), K, h, w, F.data()));
+    const mwSize dims[3] = {(mwSize)h, (mwSize)w, 3};
+    plhs[0] = mxCreateNumericArray(3, dims, mxSINGLE_CLASS, mxREAL);
+    float* o = (float*)mxGetData(plhs[0]);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int q = 0; q < 3; ++q) o[(size_t)q * hw + (size_t)x * h + y] = F[((size_t)y * w + x) * 3 + q];
+}
+
+// [panorama, covered] = aps_mex('render', images (1xN cell uint8), cameras (struct array K,R), canvas struct, opts struct, gains Nx3)
+static void cmd_render(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 6 && mxIsCell(prhs[1]) && mxIsStruct(prhs[2]), "aps:type", "usage: images cell, cameras struct, canvas, opts, gains");
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    std::vector<aps_image> im(n);
+    const double* g = mxGetPr(prhs[5]);
+    for (int i = 0; i < n; ++i) {
+        const mxArray* a = mxGetCell(prhs[1], i);
+        need(mxIsUint8(a), "aps:type", "images must be uint8");
+        const mwSize* d = mxGetDimensions(a);
+        im[i].data = (const uint8_t*)mxGetData(a);
+        im[i].height = (int)d[0];
+        im[i].width = (int)d[1];
+        im[i].channels = mxGetNumberOfDimensions(a) > 2 ? (int)d[2] : 1;
+        im[i].layout = APS_IMG_U8_MATLAB;
+        std::memcpy(im[i].K, mxGetPr(mxGetField(prhs[2], i, "K")), 9 * sizeof(double));
+        std::memcpy(im[i].R, mxGetPr(mxGetField(prhs[2], i, "R")), 9 * sizeof(double));
+        for (int c = 0; c < 3; ++c) im[i].gain[c] = (float)g[i + (size_t)c * n];
+    }
+    aps_canvas cv;
+    cv.mode = (int)field(prhs[3], "mode", APS_PROJ_SPHERICAL);
+    cv.height = (int)field(prhs[3], "H", 0);
+    cv.width = (int)field(prhs[3], "W", 0);
+    cv.f_pan = field(prhs[3], "fPan", 1);
+    cv.origin0 = field(prhs[3], "origin0", 0);
+    cv.origin1 = field(prhs[3], "origin1", 0);
+    const mxArray* rr = mxGetField(prhs[3], 0, "Rref");
+    for (int e = 0; e < 9; ++e) cv.R_ref[e] = rr ? mxGetPr(rr)[e] : (e % 4 == 0);
+    aps_render_opts ro;
+    ro.tile_h = (int)field(prhs[4], "tileH", 2048);
+    ro.tile_w = (int)field(prhs[4], "tileW", 2048);
+    ro.angle_power = (float)field(prhs[4], "anglePower", 1);
+    ro.blending = (int)field(prhs[4], "blendingId", APS_BLEND_MULTIBAND);
+    ro.pyr_levels = (int)field(prhs[4], "pyrLevels", 3);
+    ro.pyr_sigma = (float)field(prhs[4], "pyrSigma", 1);
+    ro.none_policy = (int)field(prhs[4], "nonePolicyId", APS_NONE_LAST);
+    ro.canvas_white = (int)field(prhs[4], "canvasWhite", 0);
+    const mwSize dims[3] = {(mwSize)cv.height, (mwSize)cv.width, 3};
+    plhs[0] = mxCreateNumericArray(3, dims, mxUINT8_CLASS, mxREAL);
+    mxArray* cov = mxCreateNumericMatrix(cv.height, cv.width, mxUINT8_CLASS, mxREAL);
+    check(aps_render(im.data(), n, &cv, &ro, APS_IMG_U8_MATLAB, (uint8_t*)mxGetData(plhs[0]), (uint8_t*)mxGetData(cov)));
+    if (nlhs > 1) plhs[1] = cov; else mxDestroyArray(cov);
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
+    const std::string cmd = str(prhs[0]);
+    if (cmd == "version") plhs[0] = mxCreateDoubleScalar(aps_version());
+    else if (cmd == "set_device") check(aps_set_device((int)mxGetScalar(prhs[1])));
+    else if (cmd == "sift_extract") cmd_sift(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "match_features") cmd_match(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "match_pairwise") cmd_pairwise(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "knn_global") cmd_knn(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "hamming_2nn") cmd_hamming(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "ransac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "multiband_blend") cmd_blend(true, nlhs, plhs, nrhs, prhs);
+    else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
+    else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);
+    else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
+}
