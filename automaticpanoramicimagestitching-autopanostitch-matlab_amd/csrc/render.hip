@@ -233,9 +233,24 @@ __global__ __launch_bounds__(256) void warp_tile_kernel(DevCanvas cv, const DevI
 // ------------------------------------------------------------------------------------------------
 // weight normalisation over the K layers of a tile
 // ------------------------------------------------------------------------------------------------
+// Up to kMaxK layer pointers travel as a kernel argument (no table upload, no host sync); tiles with more
+// contributors take the uploaded-table path.
+constexpr int kMaxK = 16;
+struct PtrTab {
+    float4* p[kMaxK];
+};
+
 // fuse_norm: renderPanorama.m:1009-1017 (w *= 1/sum where sum > 1e-8), coverage = any(w > 0)
 // mbb_norm : multiBandBlending.m:72-85   (w = max(0,w)/sum where sum > 1e-8)
-__global__ void norm_weights_kernel(float4* const* __restrict__ layers, int K, size_t n, int fuse_norm,
+template <class Tab>
+__device__ __forceinline__ float4* tab_get(const Tab& t, int k);
+template <>
+__device__ __forceinline__ float4* tab_get<PtrTab>(const PtrTab& t, int k) { return t.p[k]; }
+template <>
+__device__ __forceinline__ float4* tab_get<float4* const*>(float4* const* const& t, int k) { return t[k]; }
+
+template <class Tab>
+__global__ void norm_weights_kernel(Tab layers_tab, int K, size_t n, int fuse_norm,
                                     int mbb_norm, uint8_t* __restrict__ cov) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -243,22 +258,22 @@ __global__ void norm_weights_kernel(float4* const* __restrict__ layers, int K, s
     if (fuse_norm) {
         float s = 0.f;
         for (int k = 0; k < K; ++k) {
-            const float w = layers[k][p].w;
+            const float w = tab_get<Tab>(layers_tab, k)[p].w;
             s = s + w;
             any |= w > 0.f;
         }
         const float inv = s > 1e-8f ? 1.0f / s : 0.f;
-        for (int k = 0; k < K; ++k) layers[k][p].w = layers[k][p].w * inv;
+        for (int k = 0; k < K; ++k) tab_get<Tab>(layers_tab, k)[p].w = tab_get<Tab>(layers_tab, k)[p].w * inv;
     }
     if (mbb_norm) {
         float s = 0.f;
         for (int k = 0; k < K; ++k) {
-            const float w = layers[k][p].w;
+            const float w = tab_get<Tab>(layers_tab, k)[p].w;
             s = s + (w > 0.f ? w : 0.f);
         }
         for (int k = 0; k < K; ++k) {
-            const float w = layers[k][p].w > 0.f ? layers[k][p].w : 0.f;
-            layers[k][p].w = s > 1e-8f ? w / s : 0.f;
+            const float w = tab_get<Tab>(layers_tab, k)[p].w > 0.f ? tab_get<Tab>(layers_tab, k)[p].w : 0.f;
+            tab_get<Tab>(layers_tab, k)[p].w = s > 1e-8f ? w / s : 0.f;
         }
     }
     if (cov) cov[p] = any ? 1 : 0;
@@ -420,14 +435,15 @@ __global__ void unpack_clamp_kernel(const float4* __restrict__ in, size_t n, int
 }
 
 // 'linear' (:916-978) over K layers that already hold w = Wang*max(Wf,1e-4) (0 outside the mask)
-__global__ void linear_fuse_kernel(float4* const* __restrict__ layers, int K, size_t n,
+template <class Tab>
+__global__ void linear_fuse_kernel(Tab layers_tab, int K, size_t n,
                                    float4* __restrict__ F, uint8_t* __restrict__ cov) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
     float acc[3] = {0.f, 0.f, 0.f}, ws = 0.f, bestw = 0.f, best[3] = {0.f, 0.f, 0.f};
     bool anyv = false;
     for (int k = 0; k < K; ++k) {
-        const float4 g = layers[k][p];
+        const float4 g = tab_get<Tab>(layers_tab, k)[p];
         acc[0] = acc[0] + g.x * g.w;
         acc[1] = acc[1] + g.y * g.w;
         acc[2] = acc[2] + g.z * g.w;
@@ -453,13 +469,14 @@ __global__ void linear_fuse_kernel(float4* const* __restrict__ layers, int K, si
 }
 
 // linearBlending.m:64-101 (sum(I.*W) / max(sum(W), eps('single')))
-__global__ void linear_blend_kernel(float4* const* __restrict__ layers, int K, size_t n,
+template <class Tab>
+__global__ void linear_blend_kernel(Tab layers_tab, int K, size_t n,
                                     float4* __restrict__ F) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
     float acc[3] = {0.f, 0.f, 0.f}, den = 0.f;
     for (int k = 0; k < K; ++k) {
-        const float4 g = layers[k][p];
+        const float4 g = tab_get<Tab>(layers_tab, k)[p];
         acc[0] = acc[0] + g.x * g.w;
         acc[1] = acc[1] + g.y * g.w;
         acc[2] = acc[2] + g.z * g.w;
@@ -631,18 +648,200 @@ static void imresize4(const float4* in, int h, int w, int oh, int ow, float4* ou
     check_launch("imresize4");
 }
 
-// multiBandBlending on K float4 layers (weights already in .w); result float4 in F (unclamped)
-static void multiband_device(std::vector<float4*>& layers, int h, int w, int levels, float sigma,
-                             float4* F) {
+// ------------------------------------------------------------------------------------------------
+// fused pyramid kernels (same per-stage f32 roundings as the unfused building blocks above)
+// ------------------------------------------------------------------------------------------------
+// imgaussfilt: column (vertical) pass then row pass through one LDS tile; replicate padding.
+constexpr int kBW = 32, kBH = 16;  // output tile of mb_blur_kernel
+template <int R>
+__global__ __launch_bounds__(256) void mb_blur_kernel(PtrTab ins, int h, int w, Taps tp, PtrTab outs) {
+    const float4* __restrict__ in = ins.p[blockIdx.z];
+    float4* __restrict__ out = outs.p[blockIdx.z];
+    constexpr int IW = kBW + 2 * R, IH = kBH + 2 * R;
+    __shared__ float4 s_in[IH * IW];
+    __shared__ float4 s_v[kBH * IW];
+    const int x0 = blockIdx.x * kBW, y0 = blockIdx.y * kBH, tid = threadIdx.x;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int ly = e / IW, lx = e - ly * IW;
+        const int gy = min(max(y0 + ly - R, 0), h - 1), gx = min(max(x0 + lx - R, 0), w - 1);
+        s_in[e] = in[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int e = tid; e < kBH * IW; e += 256) {  // vertical pass for every column of the haloed tile
+        const int ly = e / IW, lx = e - ly * IW;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], s_in[(ly + t) * IW + lx], a);
+        s_v[e] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < kBH * kBW; e += 256) {  // horizontal pass
+        const int ly = e / kBW, lx = e - ly * kBW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= w || gy >= h) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], s_v[ly * IW + lx + t], a);
+        out[(size_t)gy * w + gx] = a;
+    }
+}
+
+// imresize: both passes in one kernel.  Each thread produces one output pixel by evaluating, for each of its
+// second-pass taps, the first-pass result at that intermediate position (an fma chain over the first-pass taps).
+// The intermediate value depends only on its own position, so this equals materialising the intermediate image.
+// ROWS_FIRST = the reference's rule (smaller scale factor first, ties -> rows).
+template <bool ROWS_FIRST>
+__global__ void mb_resize_kernel(PtrTab ins, int h, int w, int oh, int ow, PtrTab outs) {
+    const float4* __restrict__ in = ins.p[blockIdx.z];
+    float4* __restrict__ out = outs.p[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    int lr, lc;
+    float wr[12], wc[12];
+    const int Pr = resize_taps(h, oh, y, lr, wr);
+    const int Pc = resize_taps(w, ow, x, lc, wc);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ROWS_FIRST) {  // pass 1 resizes rows (at full width), pass 2 resizes columns
+        for (int tc = 0; tc < Pc; ++tc) {
+            const int xx = min(max(lc + tc, 1), w) - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tr = 0; tr < Pr; ++tr) {
+                const int yy = min(max(lr + tr, 1), h) - 1;
+                v = fma4(wr[tr], in[(size_t)yy * w + xx], v);
+            }
+            a = fma4(wc[tc], v, a);
+        }
+    } else {
+        for (int tr = 0; tr < Pr; ++tr) {
+            const int yy = min(max(lr + tr, 1), h) - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tc = 0; tc < Pc; ++tc) {
+                const int xx = min(max(lc + tc, 1), w) - 1;
+                v = fma4(wc[tc], in[(size_t)yy * w + xx], v);
+            }
+            a = fma4(wr[tr], v, a);
+        }
+    }
+    out[(size_t)y * ow + x] = a;
+}
+
+// Level l of multiBandBlending.m:136-144 for ALL K layers in one pass:
+//   Num_l = sum_k (G_k - imresize(D_k, size_l)) .* w_k      (accumulated in layer order, from zero)
+// or, with D == nullptr, the coarsest level (:159): Num_L = sum_k G_k .* w_k.
+template <bool ROWS_FIRST>
+__global__ void mb_lap_all_kernel(PtrTab Gt, PtrTab Dt, int has_d, int cont, int K, int h, int w,
+                                  int dh, int dw, float4* __restrict__ num) {
+    float4* const* G = Gt.p;
+    float4* const* D = has_d ? Dt.p : nullptr;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (cont) {  // continue the layer-ordered sum of a previous chunk of layers
+        const float4 p = num[(size_t)y * w + x];
+        acc[0] = p.x;
+        acc[1] = p.y;
+        acc[2] = p.z;
+    }
+    if (D == nullptr) {
+        for (int k = 0; k < K; ++k) {
+            const float4 g = G[k][(size_t)y * w + x];
+            acc[0] = acc[0] + g.x * g.w;
+            acc[1] = acc[1] + g.y * g.w;
+            acc[2] = acc[2] + g.z * g.w;
+        }
+    } else {
+        int lr, lc;
+        float wr[12], wc[12];
+        const int Pr = resize_taps(dh, h, y, lr, wr);
+        const int Pc = resize_taps(dw, w, x, lc, wc);
+        for (int k = 0; k < K; ++k) {
+            const float4* d = D[k];
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ROWS_FIRST) {
+                for (int tc = 0; tc < Pc; ++tc) {
+                    const int xx = min(max(lc + tc, 1), dw) - 1;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], d[(size_t)(min(max(lr + tr, 1), dh) - 1) * dw + xx], v);
+                    u = fma4(wc[tc], v, u);
+                }
+            } else {
+                for (int tr = 0; tr < Pr; ++tr) {
+                    const int yy = min(max(lr + tr, 1), dh) - 1;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], d[(size_t)yy * dw + min(max(lc + tc, 1), dw) - 1], v);
+                    u = fma4(wr[tr], v, u);
+                }
+            }
+            const float4 g = G[k][(size_t)y * w + x];
+            acc[0] = acc[0] + (g.x - u.x) * g.w;
+            acc[1] = acc[1] + (g.y - u.y) * g.w;
+            acc[2] = acc[2] + (g.z - u.z) * g.w;
+        }
+    }
+    num[(size_t)y * w + x] = make_float4(acc[0], acc[1], acc[2], 0.f);
+}
+
+// collapse step (:166): F_l = imresize(F_{l+1}, size_l) + Num_l
+template <bool ROWS_FIRST>
+__global__ void mb_collapse_kernel(const float4* __restrict__ Fc, int ch, int cw, const float4* __restrict__ num, int h,
+                                   int w, float4* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    int lr, lc;
+    float wr[12], wc[12];
+    const int Pr = resize_taps(ch, h, y, lr, wr);
+    const int Pc = resize_taps(cw, w, x, lc, wc);
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ROWS_FIRST) {
+        for (int tc = 0; tc < Pc; ++tc) {
+            const int xx = min(max(lc + tc, 1), cw) - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], Fc[(size_t)(min(max(lr + tr, 1), ch) - 1) * cw + xx], v);
+            u = fma4(wc[tc], v, u);
+        }
+    } else {
+        for (int tr = 0; tr < Pr; ++tr) {
+            const int yy = min(max(lr + tr, 1), ch) - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], Fc[(size_t)yy * cw + min(max(lc + tc, 1), cw) - 1], v);
+            u = fma4(wr[tr], v, u);
+        }
+    }
+    const float4 n = num[(size_t)y * w + x];
+    out[(size_t)y * w + x] = make_float4(u.x + n.x, u.y + n.y, u.z + n.z, 0.f);
+}
+
+static bool rows_first(int h, int w, int oh, int ow) { return (double)oh / h <= (double)ow / w; }
+
+static PtrTab make_tab(float4* const* p, int count) {
+    PtrTab t;
+    for (int k = 0; k < kMaxK; ++k) t.p[k] = k < count ? p[k] : nullptr;
+    return t;
+}
+
+// fuseTile's and multiBandBlending's weight normalisations over K layers (either or both), coverage optional
+static void normalize_weights(const std::vector<float4*>& layers, size_t n, int fuse_norm, int mbb_norm, uint8_t* cov) {
+    const int K = (int)layers.size();
+    if (K <= kMaxK) {
+        norm_weights_kernel<PtrTab><<<cdiv(n, 256), 256, 0, stream()>>>(make_tab(layers.data(), K), K, n, fuse_norm, mbb_norm, cov);
+        check_launch("norm_weights_kernel");
+    } else {
+        Ws<float4*> dl(K);
+        APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
+        norm_weights_kernel<float4* const*><<<cdiv(n, 256), 256, 0, stream()>>>(dl.get(), K, n, fuse_norm, mbb_norm, cov);
+        check_launch("norm_weights_kernel");
+        APS_HIP(hipStreamSynchronize(stream()));
+    }
+}
+
+// multiBandBlending on K float4 layers whose weights are ALREADY normalised (normalize_weights(..., mbb=1));
+// result float4 in F (unclamped).  Level-major: per level one launch blurs up to 16 layers, one launch
+// downsamples them, one pass forms their Laplacians and accumulates them in layer order.  No host sync.
+static void multiband_device(const std::vector<float4*>& layers, int h, int w, int levels, float sigma, float4* F) {
     const int K = (int)layers.size();
     const size_t hw = (size_t)h * w;
-    // :72-85
-    Ws<float4*> dl(K);
-    APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
-    norm_weights_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dl, K, hw, 0, 1, nullptr);
-    check_launch("norm_weights_kernel");
-    // :98-109
-    int maxl = (int)std::floor(std::log2((double)std::min(h, w)));
+    Prof prof("multiband");
+    int maxl = (int)std::floor(std::log2((double)std::min(h, w)));  // :98-109
     levels = std::max(1, std::min(levels, maxl));
     std::vector<int> lh(levels), lw(levels);
     lh[0] = h;
@@ -651,50 +850,73 @@ static void multiband_device(std::vector<float4*>& layers, int h, int w, int lev
         lh[l] = std::max(1, lh[l - 1] / 2);
         lw[l] = std::max(1, lw[l - 1] / 2);
     }
-    std::vector<Ws<float4>> num(levels);
-    for (int l = 0; l < levels; ++l) {
-        num[l].alloc((size_t)lh[l] * lw[l]);
-        APS_HIP(hipMemsetAsync(num[l], 0, (size_t)lh[l] * lw[l] * sizeof(float4), stream()));
-    }
+    std::vector<Ws<float4>> store((size_t)std::max(levels - 1, 0) * K), blurred(std::min(K, kMaxK)), num(levels);
+    std::vector<std::vector<float4*>> lev(levels, std::vector<float4*>(K));
+    lev[0] = layers;
+    for (int l = 1; l < levels; ++l)
+        for (int k = 0; k < K; ++k) {
+            store[(size_t)(l - 1) * K + k].alloc((size_t)lh[l] * lw[l]);
+            lev[l][k] = store[(size_t)(l - 1) * K + k];
+        }
+    std::vector<float4*> bl(std::min(K, kMaxK), nullptr);
+    if (levels > 1)
+        for (int k = 0; k < (int)bl.size(); ++k) {
+            blurred[k].alloc(hw);
+            bl[k] = blurred[k];
+        }
+    for (int l = 0; l < levels; ++l) num[l].alloc((size_t)lh[l] * lw[l]);
     const Taps tp = make_taps(sigma);
-    Ws<float4> t1(hw), t2(hw), U(hw), rt, gA, gB;
-    Prof prof("multiband");
-    for (int k = 0; k < K; ++k) {
-        const float4* G = layers[k];
-        Ws<float4>* next = &gA;
-        for (int l = 0; l < levels - 1; ++l) {
-            const int hl = lh[l], wl = lw[l], nh = lh[l + 1], nw = lw[l + 1];
-            const size_t n = (size_t)hl * wl;
-            blur_v_kernel<<<dim3(cdiv(wl, 256), hl), 256, 0, stream()>>>(G, hl, wl, tp, t1);
-            blur_h_kernel<<<dim3(cdiv(wl, 256), hl), 256, 0, stream()>>>(t1, hl, wl, tp, t2);
-            check_launch("blur");
-            next->alloc((size_t)nh * nw);
-            imresize4(t2, hl, wl, nh, nw, *next, rt);
-            imresize4(*next, nh, nw, hl, wl, U, rt);
-            lap_accum_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(G, U, n, num[l]);
-            check_launch("lap_accum_kernel");
-            G = next->get();
-            next = (next == &gA) ? &gB : &gA;
-        }
-        const size_t n = (size_t)lh[levels - 1] * lw[levels - 1];
-        coarse_accum_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(G, n, num[levels - 1]);
-        check_launch("coarse_accum_kernel");
-    }
-    // :163-167
-    if (levels == 1) {
-        APS_HIP(hipMemcpyAsync(F, num[0], hw * sizeof(float4), hipMemcpyDeviceToDevice, stream()));
-    } else {
-        const float4* cur = num[levels - 1];
-        for (int l = levels - 2; l >= 0; --l) {
-            const size_t n = (size_t)lh[l] * lw[l];
-            imresize4(cur, lh[l + 1], lw[l + 1], lh[l], lw[l], U, rt);
-            float4* dst = l == 0 ? F : (l % 2 ? t1.get() : t2.get());
-            add_kernel<<<cdiv(n, 256), 256, 0, stream()>>>(U, num[l], n, dst);
-            check_launch("add_kernel");
-            cur = dst;
+    APS_REQUIRE(tp.r >= 1 && tp.r <= 4, APS_E_ARG, "pyrSigma %g needs a %d-tap filter; 3..9 taps are built", (double)sigma, 2 * tp.r + 1);
+    for (int l = 0; l < levels; ++l) {
+        const int hl = lh[l], wl = lw[l];
+        const bool last = l == levels - 1;
+        const int nh = last ? 0 : lh[l + 1], nw = last ? 0 : lw[l + 1];
+        float4* dst = (last && levels == 1) ? F : num[l].get();
+        for (int k0 = 0; k0 < K; k0 += kMaxK) {
+            const int kc = std::min(kMaxK, K - k0);
+            const PtrTab gt = make_tab(lev[l].data() + k0, kc);
+            PtrTab dt = gt;
+            if (!last) {
+                const PtrTab bt = make_tab(bl.data(), kc);
+                dt = make_tab(lev[l + 1].data() + k0, kc);
+                const dim3 bg(cdiv(wl, kBW), cdiv(hl, kBH), kc);
+                switch (tp.r) {
+                    case 1: mb_blur_kernel<1><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
+                    case 2: mb_blur_kernel<2><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
+                    case 3: mb_blur_kernel<3><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
+                    default: mb_blur_kernel<4><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
+                }
+                const dim3 rg(cdiv(nw, 128), nh, kc);
+                if (rows_first(hl, wl, nh, nw))
+                    mb_resize_kernel<true><<<rg, 128, 0, stream()>>>(bt, hl, wl, nh, nw, dt);
+                else
+                    mb_resize_kernel<false><<<rg, 128, 0, stream()>>>(bt, hl, wl, nh, nw, dt);
+            }
+            const dim3 lg(cdiv(wl, 128), hl);
+            if (last || rows_first(nh, nw, hl, wl))
+                mb_lap_all_kernel<true><<<lg, 128, 0, stream()>>>(gt, dt, last ? 0 : 1, k0 > 0, kc, hl, wl, nh, nw, dst);
+            else
+                mb_lap_all_kernel<false><<<lg, 128, 0, stream()>>>(gt, dt, 1, k0 > 0, kc, hl, wl, nh, nw, dst);
+            check_launch("multiband level");
         }
     }
-    APS_HIP(hipStreamSynchronize(stream()));  // `layers` (host vector) was copied asynchronously
+    // collapse (:163-167)
+    std::vector<Ws<float4>> fl(std::max(levels - 1, 0));
+    const float4* cur = levels > 1 ? num[levels - 1].get() : nullptr;
+    for (int l = levels - 2; l >= 0; --l) {
+        float4* dst = F;
+        if (l > 0) {
+            fl[l].alloc((size_t)lh[l] * lw[l]);
+            dst = fl[l];
+        }
+        if (rows_first(lh[l + 1], lw[l + 1], lh[l], lw[l]))
+            mb_collapse_kernel<true><<<dim3(cdiv(lw[l], 128), lh[l]), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
+        else
+            mb_collapse_kernel<false><<<dim3(cdiv(lw[l], 128), lh[l]), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
+        check_launch("mb_collapse_kernel");
+        cur = dst;
+    }
+    // no synchronisation: all buffers are stream-ordered workspace of this thread's stream
 }
 
 struct PreparedImages {
@@ -817,6 +1039,7 @@ int aps_multiband_blend(const float* C, const float* Wt, int k, int h, int w, in
         }
         check_launch("pack_layer_kernel");
         Ws<float4> F4(hw);
+        normalize_weights(layers, hw, 0, 1, nullptr);  // multiBandBlending.m:72-85
         multiband_device(layers, h, w, levels, sigma, F4);
         unpack_clamp_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(F4, hw, 1, oF);
         check_launch("unpack_clamp_kernel");
@@ -844,7 +1067,7 @@ int aps_linear_blend(const float* C, const float* Wt, int k, int h, int w, float
         Ws<float4*> dl(k);
         APS_HIP(hipMemcpyAsync(dl, layers.data(), k * sizeof(float4*), hipMemcpyHostToDevice, stream()));
         Ws<float4> F4(hw);
-        linear_blend_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(dl, k, hw, F4);
+        linear_blend_kernel<float4* const*><<<cdiv(hw, 256), 256, 0, stream()>>>(dl.get(), k, hw, F4);
         unpack_clamp_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(F4, hw, 0, oF);
         check_launch("linear_blend_kernel");
         oF.commit();
@@ -883,8 +1106,6 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         const size_t tmax = (size_t)std::min(TH, H) * std::min(TW, W);
         Ws<float4> F(tmax);
         Ws<uint8_t> cov(tmax);
-        Ws<uint32_t> flags(n_img);
-        std::vector<uint32_t> hflags(n_img);
         std::vector<Ws<float4>> store;
         // a host buffer receives the whole canvas back: start from its current content so that tiles of
         // other ranks are left untouched
@@ -892,65 +1113,93 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
             if (oP.host) APS_HIP(hipMemcpyAsync(oP.d, oP.host, HW * 3, hipMemcpyHostToDevice, stream()));
             if (oC.host) APS_HIP(hipMemcpyAsync(oC.d, oC.host, HW, hipMemcpyHostToDevice, stream()));
         }
+        struct Tile {
+            int r0, c0, ht, wt;
+        };
+        std::vector<Tile> tiles;
         int tile_index = -1;
         for (int r0 = 0; r0 < H; r0 += TH)
             for (int c0 = 0; c0 < W; c0 += TW) {
                 ++tile_index;
                 if (tile_index % tile_step != tile_first) continue;
-                const int ht = std::min(TH, H - r0), wt = std::min(TW, W - c0);
-                const size_t T = (size_t)ht * wt;
-                const dim3 g2(cdiv(wt, 32), cdiv(ht, 8));
+                tiles.push_back({r0, c0, std::min(TH, H - r0), std::min(TW, W - c0)});
+            }
+        const int nt = (int)tiles.size();
+        // phase 1: contributors of every tile (the reference skips images with ~any(Mi), :989); one read-back
+        std::vector<uint32_t> hflags((size_t)nt * n_img, 0);
+        if (opts->blending != APS_BLEND_NONE && nt > 0) {
+            Ws<uint32_t> flags((size_t)nt * n_img);
+            APS_HIP(hipMemsetAsync(flags, 0, (size_t)nt * n_img * sizeof(uint32_t), stream()));
+            {
+                Prof prof("cover");
+                for (int t = 0; t < nt; ++t) {
+                    const Tile& tl = tiles[t];
+                    cover_kernel<<<dim3(cdiv(tl.wt, 32), cdiv(tl.ht, 8)), 256, 0, stream()>>>(
+                        cv, P.dev, n_img, tl.r0, tl.c0, tl.ht, tl.wt, opts->angle_power, flags.get() + (size_t)t * n_img);
+                }
+            }
+            check_launch("cover_kernel");
+            APS_HIP(hipMemcpyAsync(hflags.data(), flags, hflags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+        }
+        // phase 2: tiles back to back on the stream, no host round trip in between
+        for (int t = 0; t < nt; ++t) {
+            const Tile& tl = tiles[t];
+            const int r0 = tl.r0, c0 = tl.c0, ht = tl.ht, wt = tl.wt;
+            const size_t T = (size_t)ht * wt;
+            const dim3 g2(cdiv(wt, 32), cdiv(ht, 8));
+            if (opts->blending == APS_BLEND_NONE) {
                 APS_HIP(hipMemsetAsync(F, 0, T * sizeof(float4), stream()));
                 APS_HIP(hipMemsetAsync(cov, 0, T, stream()));
-                if (opts->blending == APS_BLEND_NONE) {
-                    for (int i = 0; i < n_img; ++i)
-                        none_fuse_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, i, r0, c0, ht, wt, opts->angle_power,
-                                                                   opts->none_policy, F, cov);
-                    check_launch("none_fuse_kernel");
+                for (int i = 0; i < n_img; ++i)
+                    none_fuse_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, i, r0, c0, ht, wt, opts->angle_power,
+                                                               opts->none_policy, F, cov);
+                check_launch("none_fuse_kernel");
+            } else {
+                std::vector<int> contrib;
+                for (int i = 0; i < n_img; ++i)
+                    if (hflags[(size_t)t * n_img + i]) contrib.push_back(i);
+                const int K = (int)contrib.size();
+                if (K == 0) {
+                    APS_HIP(hipMemsetAsync(F, 0, T * sizeof(float4), stream()));
+                    APS_HIP(hipMemsetAsync(cov, 0, T, stream()));
                 } else {
-                    // contributors of this tile (the reference skips images with ~any(Mi), :989)
-                    APS_HIP(hipMemsetAsync(flags, 0, n_img * sizeof(uint32_t), stream()));
+                    if ((int)store.size() < K) store.resize(K);
+                    std::vector<float4*> layers(K);
+                    const float wf_floor = opts->blending == APS_BLEND_LINEAR ? 1e-4f : 0.f;
                     {
-                        Prof prof("cover");
-                        cover_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, n_img, r0, c0, ht, wt, opts->angle_power, flags);
-                    }
-                    check_launch("cover_kernel");
-                    APS_HIP(hipMemcpyAsync(hflags.data(), flags, n_img * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-                    APS_HIP(hipStreamSynchronize(stream()));
-                    std::vector<int> contrib;
-                    for (int i = 0; i < n_img; ++i)
-                        if (hflags[i]) contrib.push_back(i);
-                    const int K = (int)contrib.size();
-                    if (K > 0) {
-                        if ((int)store.size() < K) store.resize(K);
-                        std::vector<float4*> layers(K);
-                        const float wf_floor = opts->blending == APS_BLEND_LINEAR ? 1e-4f : 0.f;
+                        Prof prof("warp_layer");
                         for (int k = 0; k < K; ++k) {
                             if (store[k].n < T) store[k].alloc(tmax);
                             layers[k] = store[k];
-                            Prof prof("warp_layer");
                             warp_layer_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, contrib[k], r0, c0, ht, wt,
                                                                         opts->angle_power, wf_floor, layers[k]);
                         }
-                        check_launch("warp_layer_kernel");
-                        Ws<float4*> dl(K);
-                        APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
-                        if (opts->blending == APS_BLEND_LINEAR) {
-                            linear_fuse_kernel<<<cdiv(T, 256), 256, 0, stream()>>>(dl, K, T, F, cov);
+                    }
+                    check_launch("warp_layer_kernel");
+                    if (opts->blending == APS_BLEND_LINEAR) {
+                        if (K <= kMaxK) {
+                            linear_fuse_kernel<PtrTab><<<cdiv(T, 256), 256, 0, stream()>>>(make_tab(layers.data(), K), K, T, F, cov);
+                            check_launch("linear_fuse_kernel");
+                        } else {
+                            Ws<float4*> dl(K);
+                            APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
+                            linear_fuse_kernel<float4* const*><<<cdiv(T, 256), 256, 0, stream()>>>(dl.get(), K, T, F, cov);
                             check_launch("linear_fuse_kernel");
                             APS_HIP(hipStreamSynchronize(stream()));
-                        } else {
-                            norm_weights_kernel<<<cdiv(T, 256), 256, 0, stream()>>>(dl, K, T, 1, 0, cov);
-                            check_launch("norm_weights_kernel");
-                            multiband_device(layers, ht, wt, opts->pyr_levels, opts->pyr_sigma, F);
                         }
+                    } else {
+                        // fuseTile's normalisation (:991-1006) and multiBandBlending's own (:72-85), one pass
+                        normalize_weights(layers, T, 1, 1, cov);
+                        multiband_device(layers, ht, wt, opts->pyr_levels, opts->pyr_sigma, F);
                     }
                 }
-                paint_kernel<<<dim3(cdiv(wt, 256), ht), 256, 0, stream()>>>(
-                    F, cov, r0, c0, ht, wt, H, W, opts->canvas_white, out_layout, oP,
-                    oC.present() ? oC.get() : nullptr);
-                check_launch("paint_kernel");
             }
+            paint_kernel<<<dim3(cdiv(wt, 256), ht), 256, 0, stream()>>>(
+                F, cov, r0, c0, ht, wt, H, W, opts->canvas_white, out_layout, oP,
+                oC.present() ? oC.get() : nullptr);
+            check_launch("paint_kernel");
+        }
         oP.commit();
         oC.commit();
         APS_HIP(hipStreamSynchronize(stream()));
