@@ -496,6 +496,248 @@ __global__ __launch_bounds__(512, 2) void match_cand_bf16_kernel(const MatchJob*
     }
 }
 
+// ---- v2 of the candidate kernel ------------------------------------------------------------------
+// Same contract as match_cand_bf16_kernel.  Differences, all about keeping the matrix pipe fed:
+//  * the B tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
+//    pass, no vmcnt stall at the top of a tile.  The LDS image is lane-linear (256-B rows, no pad); bank
+//    conflicts are avoided by an XOR swizzle of the 16-B chunk position with (row & 15), applied to the
+//    per-lane SOURCE address of the DMA and to the ds_read_b128 address (the same involution on both sides);
+//  * the accumulator starts from -||b||^2/2 (the MFMA C operand), so acc = a.b - b2/2 and the row's best
+//    columns are the LARGEST acc: no per-element VALU besides the compare; d~ - a2 = -2 acc (exact scalings);
+//  * operand reads run one k-step ahead in their own registers and the issue order is pinned.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef const __attribute__((address_space(1))) float gbl_f32;
+
+__device__ __forceinline__ void top4_insert_max(float t, int j, float& u0, float& u1, float& u2, float& u3,
+                                                int& i0, int& i1, int& i2) {
+    // u0 >= u1 >= u2 >= u3; ties keep the earlier entry ahead (strict compares for the indices)
+    const bool g2 = t > u2, g1 = t > u1, g0 = t > u0;
+    u3 = __builtin_amdgcn_fmed3f(u2, t, u3);
+    i2 = g1 ? i1 : (g2 ? j : i2);
+    u2 = __builtin_amdgcn_fmed3f(u1, t, u2);
+    i1 = g0 ? i0 : (g1 ? j : i1);
+    u1 = __builtin_amdgcn_fmed3f(u0, t, u1);
+    i0 = g0 ? j : i0;
+    u0 = fmaxf(u0, t);
+}
+
+constexpr int kTileBytes = kTNB * 256;  // one bf16 half (hi or lo) of a B tile in LDS
+
+__global__ __launch_bounds__(512) void match_cand_bf16_v2_kernel(const MatchJob* __restrict__ jobs,
+                                                                 const WgJob* __restrict__ wgs, int n_wg,
+                                                                 uint32_t* __restrict__ cand,  // 3 per slot
+                                                                 float* __restrict__ bound, int ablate) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kTileBytes];  // [buf][hi|lo][128][256 B]
+    // -b2/2 of each B row as three bf16 pieces (hi + mid + lo == the f32 value exactly) + five zeros: one extra
+    // 16-wide k-step against the constant [1 1 1 0 ...] puts it into the accumulator (padded column: -1e30)
+    __shared__ __attribute__((aligned(16))) uint4 s_aug[2][kTNB];
+
+    // XCD-aware order: consecutive workgroup ids go to different XCDs (one L2 each); give each XCD a
+    // contiguous run of the job-major list so that the workgroups sharing a B set share an L2
+    int wg = blockIdx.x;
+    if (!(ablate & 4)) {
+        const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const WgJob w = wgs[wg];
+    const MatchJob jb = jobs[w.job];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31;
+    const int h = lane >> 5;
+    const int nA = jb.nA, nB = jb.nB;
+    const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
+
+    bf16x8 ah[2][8], al[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int arow = min(row0 + 32 * rb, nA - 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ah[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AH + (size_t)arow * kDim + 16 * s + 8 * h);
+            al[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AL + (size_t)arow * kDim + 16 * s + 8 * h);
+        }
+    }
+    float u0[2], u1[2], u2[2], u3[2];  // a.b - b2/2, descending, per owned row
+    int i0[2], i1[2], i2[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        u0[rb] = u1[rb] = u2[rb] = u3[rb] = -INFINITY;
+        i0[rb] = i1[rb] = i2[rb] = -1;
+    }
+
+    const int ntiles = (nB + kTNB - 1) / kTNB;
+    // DMA pieces: 64 per tile (32 hi + 32 lo), 1 KiB = 4 LDS rows each; wave w issues pieces 8w .. 8w+7.
+    // lane -> LDS row 4*(piece&31) + lane/16, chunk position lane&15, which must hold source chunk pos ^ (row&15)
+    const int dma_sub = lane >> 4, dma_pos = lane & 15;
+    // The DMA is issued from inline asm on purpose: for the builtin the compiler cannot tell the two LDS
+    // buffers apart and drains vmcnt before the first ds_read that follows, which exposes the whole DMA
+    // latency once per tile.  The DMA of tile t+1 is retired by the explicit vmcnt(0) before the barrier that
+    // ends tile t; nothing reads that buffer earlier.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    float stage_b2 = 0.f;
+    auto issue_tile = [&](int t, int buf) {
+        // ordinary load first (it is consumed at the end of the tile, behind the same vmcnt(0))
+        stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int piece = wave * 8 + u;
+            const int half = piece >> 5;
+            const int lrow = 4 * (piece & 31) + dma_sub;
+            const int brow = min(t * kTNB + lrow, nB - 1);
+            const unsigned short* src = (half ? jb.BL : jb.BH) + (size_t)brow * kDim + ((dma_pos ^ (lrow & 15)) << 3);
+            const uint32_t dst = lds_base + buf * (2 * kTileBytes) + half * kTileBytes + (piece & 31) * 1024;
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+    auto store_aug = [&](int t) {
+        const int j = t * kTNB + tid;
+        if (tid < kTNB) {
+            const float x = j < nB ? -0.5f * stage_b2 : -1e30f;
+            const uint32_t xb = __float_as_uint(x);
+            const float hi = __uint_as_float(xb & 0xffff0000u);
+            const float r1 = x - hi;  // exact
+            const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            const float lo = r1 - mid;  // exact, fits 8 significant bits
+            uint4 v;
+            v.x = (xb >> 16) | (__float_as_uint(mid) & 0xffff0000u);
+            v.y = __float_as_uint(lo) >> 16;
+            v.z = 0u;
+            v.w = 0u;
+            s_aug[t & 1][tid] = v;
+        }
+    };
+    const bool late = wave >= 4;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = -INFINITY;
+    // Selection.  thr = the larger of the two half-waves' fourth-best of a row (they see disjoint columns of the
+    // same row): the union's fourth-best is >= either half's, so a value <= thr can neither be one of the
+    // union's best three nor exceed the final bound, and each half's list still ends up holding every element
+    // of the union's top four that fell into its columns, which is all the final merge needs.
+    float thr[2] = {-INFINITY, -INFINITY};
+    auto epilogue = [&](int t, int cb) {
+        if (ablate & 1) {
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+            return;
+        }
+        // acc[r] <-> B column (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb)
+        const int jbase = t * kTNB + cb * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2);
+            const bool c0 = acc0[r] > thr[0], c1 = acc1[r] > thr[1];
+            if (__any(c0 || c1)) {
+                if (__any(c0)) top4_insert_max(acc0[r], jbase + jj, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
+                if (__any(c1)) top4_insert_max(acc1[r], jbase + jj, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
+            }
+        }
+        thr[0] = fmaxf(u3[0], __shfl_xor(u3[0], 32));
+        thr[1] = fmaxf(u3[1], __shfl_xor(u3[1], 32));
+    };
+
+    if (ntiles > 0) {
+        issue_tile(0, 0);
+        store_aug(0);
+    }
+    // touch the resident operand here: otherwise the compiler's pending-load state for these registers
+    // reaches the loop header and it drains vmcnt (DMA included) at their first use in EVERY iteration
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        asm volatile("" ::"v"(ah[0][s]), "v"(ah[1][s]), "v"(al[0][s]), "v"(al[1][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-lane read offsets: row c of a 32-row block, chunk (2s + h) ^ (c & 15)
+    const int hx = (16 * h) ^ (16 * (c & 15));
+    // constant operand of the extra k-step: k = 0,1,2 -> 1.0 (held by the h == 0 half), everything else 0
+    bf16x8 aug_a;
+    {
+        const uint4 v = make_uint4(h ? 0u : 0x3f803f80u, h ? 0u : 0x00003f80u, 0u, 0u);
+        aug_a = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles && !(ablate & 2)) issue_tile(t + 1, (t + 1) & 1);
+        const unsigned char* tile = lds + (t & 1) * (2 * kTileBytes) + c * 256;
+        const uint4* augp = &s_aug[t & 1][c];
+        // operands of the first k-step of block 0 (later blocks: fetched during the previous block's last step)
+        bf16x8 bh[2], bl[2], aug_b;
+        aug_b = *reinterpret_cast<const bf16x8*>(augp);
+        bh[0] = *reinterpret_cast<const bf16x8*>(tile + (0 ^ hx));
+        bl[0] = *reinterpret_cast<const bf16x8*>(tile + kTileBytes + (0 ^ hx));
+#pragma unroll
+        for (int cb = 0; cb < kTNB / 32; ++cb) {
+            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kTNB / 32 - 1);
+            const unsigned char* blk = tile + cb * 32 * 256;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aug_b, aug_a, zero16, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aug_b, aug_a, zero16, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 xh = bh[s & 1], xl = bl[s & 1];
+                if (s < 7) {
+                    bh[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(blk + ((32 * (s + 1)) ^ hx));
+                    bl[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(blk + kTileBytes + ((32 * (s + 1)) ^ hx));
+                } else if (cb + 1 < kTNB / 32) {
+                    aug_b = *reinterpret_cast<const bf16x8*>(augp + 32 * (cb + 1));
+                    bh[0] = *reinterpret_cast<const bf16x8*>(blk + 32 * 256 + (0 ^ hx));
+                    bl[0] = *reinterpret_cast<const bf16x8*>(blk + 32 * 256 + kTileBytes + (0 ^ hx));
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ah[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ah[1][s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, al[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, al[1][s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, ah[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, ah[1][s], acc1, 0, 0, 0);
+            }
+            // pinned issue order: the reads of the next step go out ahead of the MFMAs of this one
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+            for (int s = 1; s < 7; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            if (cb + 1 < kTNB / 32) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late) epilogue(t, cb);
+        }
+        if (t + 1 < ntiles && !(ablate & 2)) store_aug(t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t+1 have landed
+        __syncthreads();                                   // ... and every reader is behind that
+    }
+    if (late && ntiles > 0) epilogue(ntiles - 1, kTNB / 32 - 1);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
+                    p3 = __shfl_xor(u3[rb], 32);
+        const int q0 = __shfl_xor(i0[rb], 32), q1 = __shfl_xor(i1[rb], 32), q2 = __shfl_xor(i2[rb], 32);
+        top4_insert_max(p0, q0, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        top4_insert_max(p1, q1, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        top4_insert_max(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+        u3[rb] = fmaxf(u3[rb], p3);
+        const int row = row0 + 32 * rb;
+        if (h == 0 && row < nA) {
+            const int64_t o = jb.out_off + row;
+            cand[3 * o + 0] = (uint32_t)i0[rb];
+            cand[3 * o + 1] = (uint32_t)i1[rb];
+            cand[3 * o + 2] = (uint32_t)i2[rb];
+            bound[o] = jb.sqA[row] - 2.0f * u3[rb];  // approximate 4th-smallest distance (inf if < 4 columns)
+        }
+    }
+}
+
 // exact canonical distance of A row `pa` and B row `pb` (both in the permuted f32 layout of prep_desc_kernel):
 // G = k-ascending fma chain, d = (a2 + b2) - 2G — the same arithmetic as match2nn_kernel / the oracle.
 __device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const float* __restrict__ pb, float a2,
@@ -819,7 +1061,12 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     {
         Prof prof("match_cand_bf16");
         const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
-        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, cand, bound, ab ? std::atoi(ab) : 0);
+        const char* kv = std::getenv("APS_MATCH_CAND");
+        if (kv && std::strcmp(kv, "v1") == 0)
+            match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, cand, bound, ab ? std::atoi(ab) : 0);
+        else
+            match_cand_bf16_v2_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), cand, bound,
+                                                                             ab ? std::atoi(ab) : 0);
     }
     check_launch("match_cand_bf16_kernel");
     std::vector<FilterJobLite> fl(jobs.size());

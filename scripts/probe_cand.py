@@ -1,0 +1,32 @@
+"""Kernel-time probe of the split-precision candidate kernel (profile API), for A/B runs:
+   APS_MATCH_CAND=v1|v2, APS_MATCH_ABLATE=<bits> python scripts/probe_cand.py [n_img] [features]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import apsamd
+from importlib import import_module
+
+fm = import_module(apsamd.__name__ + ".featureMatching")
+capi = apsamd._capi
+n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+kf = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+g = torch.Generator(device="cuda").manual_seed(0)
+descs = []
+for i in range(n_img):
+    d = torch.rand(kf, 128, device="cuda", generator=g) ** 3
+    d = d / d.norm(dim=1, keepdim=True)
+    descs.append(d.contiguous())
+torch.cuda.synchronize()
+capi.profile_enable(True)
+for it in range(3):
+    capi.profile_reset()
+    fm.match_pairwise_csr(descs, 0.6, 1.5, True)
+    capi.check(apsamd.lib.aps_synchronize())
+    p = capi.profile_all()
+npairs = n_img * (n_img - 1) // 2
+ms = p["match_cand_bf16"][0]
+fl = 2 * 128 * npairs * kf * kf
+print(f"cand {ms:.2f} ms  ({ms/npairs*1e3:.1f} us/pair)  algorithmic {fl/ms/1e9:.1f} TF  pipe(3x) {3*fl/ms/1e9:.0f} TF;"
+      f" rescore {p['match_rescore'][0]:.2f} fallback {p.get('match2nn_fallback',(0,0))[0]:.2f}")
