@@ -319,192 +319,31 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
 //
 // Operands are swapped w.r.t. match2nn_kernel: the streamed B-descriptor tile is the MFMA "A" operand and
 // the resident A rows are the MFMA "B" operand, so that in the 32x32 accumulator a lane owns ONE A row
-// (col = lane&31) and sees 16 B columns per block: the running top-4 of a row is 7 registers, and the
-// common case is two VALU ops per element (fma + compare against the row's current fourth-best).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kLdsRowB = 272;        // bytes per bf16 LDS row: 256 + one 16-B pad (conflict-free b128 reads)
-constexpr float kSplitEps = 2.44140625e-4f;  // 2^-12
-
-__device__ __forceinline__ void top4_insert(float t, int j, float& u0, float& u1, float& u2, float& u3,
-                                            int& i0, int& i1, int& i2) {
-    const bool lt3 = t < u3, lt2 = t < u2, lt1 = t < u1, lt0 = t < u0;
-    u3 = lt2 ? u2 : (lt3 ? t : u3);
-    i2 = lt1 ? i1 : (lt2 ? j : i2);
-    u2 = lt1 ? u1 : (lt2 ? t : u2);
-    i1 = lt0 ? i0 : (lt1 ? j : i1);
-    u1 = lt0 ? u0 : (lt1 ? t : u1);
-    i0 = lt0 ? j : i0;
-    u0 = lt0 ? t : u0;
-}
-
-constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
-constexpr int kTNB = 128;   // B rows per LDS tile of the split-precision kernel (4 column blocks per barrier)
-
-__global__ __launch_bounds__(512, 2) void match_cand_bf16_kernel(const MatchJob* __restrict__ jobs,
-                                                                  const WgJob* __restrict__ wgs,
-                                                                  uint32_t* __restrict__ cand,  // 3 per slot
-                                                                  float* __restrict__ bound, int ablate) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTNB * kLdsRowB];
-    __shared__ float s_b2[4][kTNB];  // 4-deep: the deferred epilogue of waves 4-7 reads the previous tile's values
-
-    const WgJob w = wgs[blockIdx.x];
-    const MatchJob jb = jobs[w.job];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int c = lane & 31;
-    const int h = lane >> 5;
-    const int nA = jb.nA, nB = jb.nB;
-    const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
-
-    // resident operand: the lane's two A rows, k = 16 s + 8 h + (0..7), hi and lo
-    bf16x8 ah[2][8], al[2][8];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int arow = min(row0 + 32 * rb, nA - 1);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            ah[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AH + (size_t)arow * kDim + 16 * s + 8 * h);
-            al[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AL + (size_t)arow * kDim + 16 * s + 8 * h);
-        }
-    }
-    float u0[2], u1[2], u2[2], u3[2];  // d~ - a2, ascending, per owned row
-    int i0[2], i1[2], i2[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        u0[rb] = u1[rb] = u2[rb] = u3[rb] = INFINITY;
-        i0[rb] = i1[rb] = i2[rb] = -1;
-    }
-
-    const int ntiles = (nB + kTNB - 1) / kTNB;
-    uint4 stage[8];
-    float stage_b2 = 0.f;
-    auto load_tile = [&](int t) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 512 * u;  // 16-B chunk index: 128 rows x 16 chunks
-            const int brow = min(t * kTNB + (f >> 4), nB - 1);
-            stage[u] = *reinterpret_cast<const uint4*>(jb.BH + (size_t)brow * kDim + (f & 15) * 8);
-            stage[4 + u] = *reinterpret_cast<const uint4*>(jb.BL + (size_t)brow * kDim + (f & 15) * 8);
-        }
-        if (tid < kTNB) {
-            const int j = t * kTNB + tid;
-            stage_b2 = j < nB ? jb.sqB[j] : INFINITY;
-        }
-    };
-    auto store_tile = [&](int buf, int buf_t) {
-        unsigned char* base = lds + buf * (2 * kTNB * kLdsRowB);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = tid + 512 * u;
-            *reinterpret_cast<uint4*>(base + (f >> 4) * kLdsRowB + (f & 15) * 16) = stage[u];
-            *reinterpret_cast<uint4*>(base + kTNB * kLdsRowB + (f >> 4) * kLdsRowB + (f & 15) * 16) = stage[4 + u];
-        }
-        if (tid < kTNB) s_b2[(buf_t) & 3][tid] = stage_b2;
-    };
-    // Stagger (MI355X_MICROARCH "Two waves per SIMD", item 9): the two waves that share a SIMD would run
-    // their MFMA blocks and their VALU epilogues in lockstep (one barrier per tile).  Waves 4-7 therefore run
-    // the epilogue of block k-1 BEFORE the MFMAs of block k (the accumulators simply stay in registers across
-    // the barrier), so one wave's VALU work always sits beside its partner's matrix work.
-    const bool late = __builtin_amdgcn_readfirstlane(tid) >= 256;
-    f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc1 = acc0;
-    auto epilogue = [&](int t, int cb) {
-        if (ablate & 1) {  // timing experiment only: keep the accumulators alive, skip the selection
-            asm volatile("" ::"v"(acc0), "v"(acc1));
-            return;
-        }
-        // acc[r] <-> B column jj = (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb)
-        const float* b2p = &s_b2[t & 3][cb * 32 + 4 * h];
-        const int jbase = t * kTNB + cb * 32 + 4 * h;
-        // the 16 b2 values of this lane's columns: four 16-B reads up front (no LDS latency inside the loop)
-        f32x4 b2v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b2v[g] = *reinterpret_cast<const f32x4*>(b2p + 8 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jj = (r & 3) + 8 * (r >> 2);
-            const float b2 = b2v[r >> 2][r & 3];
-            const float t0 = fmaf(-2.0f, acc0[r], b2);  // d~ - a2 (inf for padded columns)
-            const float t1 = fmaf(-2.0f, acc1[r], b2);
-            if (__any(t0 < u3[0] || t1 < u3[1])) {
-                top4_insert(t0, jbase + jj, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
-                top4_insert(t1, jbase + jj, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
-            }
-        }
-    };
-
-    load_tile(0);
-    store_tile(0, 0);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles && !(ablate & 2)) load_tile(t + 1);
-        const unsigned char* tile = lds + (t & 1) * (2 * kTNB * kLdsRowB);
-#pragma unroll
-        for (int cb = 0; cb < kTNB / 32; ++cb) {
-            const unsigned char* ph = tile + (cb * 32 + c) * kLdsRowB + 16 * h;
-            const unsigned char* pl = ph + kTNB * kLdsRowB;
-            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kTNB / 32 - 1);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc0[e] = 0.f;
-                acc1[e] = 0.f;
-            }
-            // operand reads run one k-step ahead of the MFMAs that consume them
-            bf16x8 bh_n = *reinterpret_cast<const bf16x8*>(ph);
-            bf16x8 bl_n = *reinterpret_cast<const bf16x8*>(pl);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bf16x8 bh = bh_n, bl = bl_n;
-                if (s < 7) {
-                    bh_n = *reinterpret_cast<const bf16x8*>(ph + 32 * (s + 1));
-                    bl_n = *reinterpret_cast<const bf16x8*>(pl + 32 * (s + 1));
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[1][s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[1][s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[1][s], acc1, 0, 0, 0);
-            }
-            if (!late) epilogue(t, cb);
-        }
-        if (t + 1 < ntiles && !(ablate & 2)) store_tile((t + 1) & 1, t + 1);
-        __syncthreads();
-    }
-    if (late && ntiles > 0) epilogue(ntiles - 1, kTNB / 32 - 1);
-
-    // the two half-waves saw disjoint column sets of the same rows: merge
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
-                    p3 = __shfl_xor(u3[rb], 32);
-        const int q0 = __shfl_xor(i0[rb], 32), q1 = __shfl_xor(i1[rb], 32), q2 = __shfl_xor(i2[rb], 32);
-        top4_insert(p0, q0, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
-        top4_insert(p1, q1, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
-        top4_insert(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
-        u3[rb] = fminf(u3[rb], p3);
-        const int row = row0 + 32 * rb;
-        if (h == 0 && row < nA) {
-            const int64_t o = jb.out_off + row;
-            cand[3 * o + 0] = (uint32_t)i0[rb];
-            cand[3 * o + 1] = (uint32_t)i1[rb];
-            cand[3 * o + 2] = (uint32_t)i2[rb];
-            bound[o] = jb.sqA[row] + u3[rb];  // approximate 4th-smallest distance (inf if < 4 columns)
-        }
-    }
-}
-
-// ---- v2 of the candidate kernel ------------------------------------------------------------------
-// Same contract as match_cand_bf16_kernel.  Differences, all about keeping the matrix pipe fed:
+// (col = lane&31) and sees 16 B columns per block: the running top-4 of a row is 7 registers.
+//
+// Keeping the matrix pipe fed (measured on MI355X, scripts/probe_cand.py + scripts/pmc_run.sh):
 //  * the B tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
 //    pass, no vmcnt stall at the top of a tile.  The LDS image is lane-linear (256-B rows, no pad); bank
 //    conflicts are avoided by an XOR swizzle of the 16-B chunk position with (row & 15), applied to the
 //    per-lane SOURCE address of the DMA and to the ds_read_b128 address (the same involution on both sides);
-//  * the accumulator starts from -||b||^2/2 (the MFMA C operand), so acc = a.b - b2/2 and the row's best
-//    columns are the LARGEST acc: no per-element VALU besides the compare; d~ - a2 = -2 acc (exact scalings);
-//  * operand reads run one k-step ahead in their own registers and the issue order is pinned.
+//  * -||b||^2/2 enters the accumulator through one extra 16-wide k-step (three exact bf16 pieces against
+//    the constant [1 1 1 0 ...]), so acc = a.b - b2/2, the row's best columns are the LARGEST acc and the
+//    selection needs no arithmetic per element; d~ - a2 = -2 acc (exact scalings);
+//  * operand reads run one k-step ahead (the first step of the next block during the last of this one) in
+//    their own registers and the issue order is pinned with sched_group_barrier;
+//  * workgroups are renumbered so that the ones sharing a B set run on one XCD (one L2).
+// Under this kernel's sustained MFMA load the chip clocks at 1.65-2.0 GHz, not 2.4 (scripts/probe/mfma_clock.hip):
+// the loop without selection and DMA runs at 96 % of the MFMA issue rate in cycles.  What remains is the
+// selection: its VALU/branch work overlaps the partner wave's MFMAs only partly (SQ_VALU_MFMA_COEXEC ~40 %).
+// Tried and measured slower: per-value branch-free sorted lists (5 VALU/value), four-value group inserts,
+// and a one-wave-per-SIMD variant with the selection interleaved into the MFMA stream (register allocation
+// forces 32-row blocks x2 per wave, which doubles the B traffic per flop).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float kSplitEps = 2.44140625e-4f;  // 2^-12
+
+constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
+constexpr int kTNB = 128;   // B rows per LDS tile of the split-precision kernel (4 column blocks per barrier)
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 typedef const __attribute__((address_space(1))) float gbl_f32;
@@ -524,7 +363,7 @@ __device__ __forceinline__ void top4_insert_max(float t, int j, float& u0, float
 
 constexpr int kTileBytes = kTNB * 256;  // one bf16 half (hi or lo) of a B tile in LDS
 
-__global__ __launch_bounds__(512) void match_cand_bf16_v2_kernel(const MatchJob* __restrict__ jobs,
+__global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __restrict__ jobs,
                                                                  const WgJob* __restrict__ wgs, int n_wg,
                                                                  uint32_t* __restrict__ cand,  // 3 per slot
                                                                  float* __restrict__ bound, int ablate) {
@@ -536,7 +375,7 @@ __global__ __launch_bounds__(512) void match_cand_bf16_v2_kernel(const MatchJob*
     // XCD-aware order: consecutive workgroup ids go to different XCDs (one L2 each); give each XCD a
     // contiguous run of the job-major list so that the workgroups sharing a B set share an L2
     int wg = blockIdx.x;
-    if (!(ablate & 4)) {
+    {
         const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
     }
@@ -630,17 +469,30 @@ __global__ __launch_bounds__(512) void match_cand_bf16_v2_kernel(const MatchJob*
         }
         // acc[r] <-> B column (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb)
         const int jbase = t * kTNB + cb * 32 + 4 * h;
+        // two-level screen: the max of four values against thr (one branch per group), then value by value
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jj = (r & 3) + 8 * (r >> 2);
-            const bool c0 = acc0[r] > thr[0], c1 = acc1[r] > thr[1];
-            if (__any(c0 || c1)) {
-                if (__any(c0)) top4_insert_max(acc0[r], jbase + jj, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
-                if (__any(c1)) top4_insert_max(acc1[r], jbase + jj, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
+        for (int g = 0; g < 4; ++g) {
+            const float m0 = fmaxf(fmaxf(fmaxf(acc0[4 * g], acc0[4 * g + 1]), acc0[4 * g + 2]), acc0[4 * g + 3]);
+            const float m1 = fmaxf(fmaxf(fmaxf(acc1[4 * g], acc1[4 * g + 1]), acc1[4 * g + 2]), acc1[4 * g + 3]);
+            if (__any(m0 > thr[0] || m1 > thr[1])) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * g + q, j = jbase + 8 * g + q;
+                    const bool c0 = acc0[r] > thr[0], c1 = acc1[r] > thr[1];
+                    if (__any(c0 || c1)) {
+                        if (__any(c0)) top4_insert_max(acc0[r], j, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
+                        if (__any(c1)) top4_insert_max(acc1[r], j, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
+                    }
+                }
             }
         }
-        thr[0] = fmaxf(u3[0], __shfl_xor(u3[0], 32));
-        thr[1] = fmaxf(u3[1], __shfl_xor(u3[1], 32));
+        // own fourth-best every block; the other half's (a cross-lane exchange and its wait) once per tile
+        thr[0] = fmaxf(thr[0], u3[0]);
+        thr[1] = fmaxf(thr[1], u3[1]);
+        if (cb == kTNB / 32 - 1) {
+            thr[0] = fmaxf(thr[0], __shfl_xor(thr[0], 32));
+            thr[1] = fmaxf(thr[1], __shfl_xor(thr[1], 32));
+        }
     };
 
     if (ntiles > 0) {
@@ -1061,12 +913,8 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     {
         Prof prof("match_cand_bf16");
         const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
-        const char* kv = std::getenv("APS_MATCH_CAND");
-        if (kv && std::strcmp(kv, "v1") == 0)
-            match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, cand, bound, ab ? std::atoi(ab) : 0);
-        else
-            match_cand_bf16_v2_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), cand, bound,
-                                                                             ab ? std::atoi(ab) : 0);
+        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), cand, bound,
+                                                                          ab ? std::atoi(ab) : 0);
     }
     check_launch("match_cand_bf16_kernel");
     std::vector<FilterJobLite> fl(jobs.size());
