@@ -14,6 +14,7 @@
 // All tap sums are k-ascending f32 fma chains (the oracle's order); toolbox semantics (interp2,
 // imgaussfilt, imresize) are the ones written down in oracle/render_oracle.c.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -148,6 +149,25 @@ __device__ __forceinline__ Sample sample_one(const DevImage& im, const float d[3
     return r;
 }
 
+// Footprint of a layer inside its tile, half-open [x0,x1) x [y0,y1).  A layer is EXACTLY zero (colour and
+// weight) outside its rect, at every pyramid level (the rect grows by the filter radius per blur and is
+// mapped through the resize taps per level), so kernels neither store nor load there: a load outside the
+// rect is replaced by 0, which is the value the full-tile computation would have read.  Results are the
+// same bits as processing full tiles; the traffic is that of the footprints.
+struct Rect {
+    int x0, y0, x1, y1;
+};
+constexpr int kMaxK = 16;  // layers per kernel-argument table
+struct RectTab {
+    Rect r[kMaxK];
+};
+__device__ __forceinline__ bool in_rect(const Rect& r, int x, int y) {
+    return x >= r.x0 && x < r.x1 && y >= r.y0 && y < r.y1;
+}
+__device__ __forceinline__ float4 ld_rect(const float4* __restrict__ p, int w, const Rect& r, int x, int y) {
+    return in_rect(r, x, y) ? p[(size_t)y * w + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // image conversion
 // ------------------------------------------------------------------------------------------------
@@ -169,33 +189,82 @@ __global__ void to_rgba_kernel(const uint8_t* __restrict__ src, int h, int w, in
 // ------------------------------------------------------------------------------------------------
 // coverage prepass: which images touch which tile (exact: the same predicate as the sampler)
 // ------------------------------------------------------------------------------------------------
+// Coverage pre-pass of one tile.  Each 32 x 8-pixel block records, per image, whether any of its pixels maps
+// into that image: rowmask[img][block row] |= bit(block column >> xshift).  The few-way contended 64-bit ORs
+// replace a per-image bounding-box min/max that every wave would fight over; footprint_kernel turns the masks
+// into boxes.  The footprint therefore has block granularity (a superset of the mask, which is all it must be).
 __global__ __launch_bounds__(256) void cover_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
                                                      int n_img, int r0, int c0, int ht, int wt,
-                                                     float angle_pow, uint32_t* __restrict__ flags) {
+                                                     float angle_pow, int nby, int xshift,
+                                                     unsigned long long* __restrict__ rowmask) {
+    __shared__ unsigned long long s_any;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool in_tile = x < wt && y < ht;
     float d[3] = {0.f, 0.f, 1.f};
     if (in_tile) canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
-    for (int i = 0; i < n_img; ++i) {
-        float u, v, wa;
-        const bool m = in_tile && project(imgs[i], d, angle_pow, u, v, wa);
-        if (__any(m)) {
-            if ((threadIdx.x & 63) == 0) flags[i] = 1u;  // benign race: every writer stores 1
+    const unsigned long long colbit = 1ull << (blockIdx.x >> xshift);
+    for (int base = 0; base < n_img; base += 64) {
+        if (threadIdx.x == 0) s_any = 0ull;
+        __syncthreads();
+        unsigned long long mine = 0ull;  // wave-uniform: images (of this group of 64) seen by this wave
+        const int cnt = min(64, n_img - base);
+        for (int i = 0; i < cnt; ++i) {
+            float u, v, wa;
+            const bool m = in_tile && project(imgs[base + i], d, angle_pow, u, v, wa);
+            if (__any(m)) mine |= 1ull << i;
+        }
+        if ((threadIdx.x & 63) == 0 && mine) atomicOr(&s_any, mine);
+        __syncthreads();
+        const unsigned long long all = s_any;
+        if (threadIdx.x < cnt && ((all >> threadIdx.x) & 1ull))
+            atomicOr(&rowmask[(size_t)(base + threadIdx.x) * nby + blockIdx.y], colbit);
+        __syncthreads();
+    }
+}
+
+// rowmask -> {x0, y0, x1, y1} per (tile, image), pixels of the tile, half-open; x1 <= x0 when nothing is covered
+__global__ void footprint_kernel(const unsigned long long* __restrict__ rowmask, const int* __restrict__ tile_dims,
+                                 int n_img, int nby_max, int total, int* __restrict__ bbox) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // tile * n_img + image
+    if (e >= total) return;
+    const int t = e / n_img;
+    const int ht = tile_dims[4 * t + 0], wt = tile_dims[4 * t + 1], nby = tile_dims[4 * t + 2], xshift = tile_dims[4 * t + 3];
+    const unsigned long long* m = rowmask + (size_t)e * nby_max;
+    unsigned long long cols = 0ull;
+    int y0 = INT_MAX, y1 = 0;
+    for (int by = 0; by < nby; ++by) {
+        const unsigned long long r = m[by];
+        if (r) {
+            cols |= r;
+            y0 = min(y0, by * 8);
+            y1 = max(y1, min(by * 8 + 8, ht));
         }
     }
+    int x0 = 0, x1 = 0;
+    if (cols) {
+        const int lo = __ffsll((long long)cols) - 1, hi = 63 - __clzll((long long)cols);
+        x0 = (lo << xshift) * 32;
+        x1 = min(((hi + 1) << xshift) * 32, wt);
+    } else {
+        y0 = 0;
+    }
+    bbox[4 * e + 0] = x0;
+    bbox[4 * e + 1] = y0;
+    bbox[4 * e + 2] = x1;
+    bbox[4 * e + 3] = y1;
 }
 
 // ------------------------------------------------------------------------------------------------
 // warp: one layer (tile x image) as float4 (r,g,b,w = Wang*Wf)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void warp_layer_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
-                                                          int img, int r0, int c0, int ht, int wt,
+                                                          int img, int r0, int c0, int wt, Rect rc,
                                                           float angle_pow, float wf_floor,
                                                           float4* __restrict__ layer) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= wt || y >= ht) return;
+    const int x = rc.x0 + blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = rc.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= rc.x1 || y >= rc.y1) return;
     float d[3];
     canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
     const Sample s = sample_one(imgs[img], d, angle_pow);
@@ -235,10 +304,10 @@ __global__ __launch_bounds__(256) void warp_tile_kernel(DevCanvas cv, const DevI
 // ------------------------------------------------------------------------------------------------
 // Up to kMaxK layer pointers travel as a kernel argument (no table upload, no host sync); tiles with more
 // contributors take the uploaded-table path.
-constexpr int kMaxK = 16;
 struct PtrTab {
     float4* p[kMaxK];
 };
+
 
 // fuse_norm: renderPanorama.m:1009-1017 (w *= 1/sum where sum > 1e-8), coverage = any(w > 0)
 // mbb_norm : multiBandBlending.m:72-85   (w = max(0,w)/sum where sum > 1e-8)
@@ -249,31 +318,39 @@ __device__ __forceinline__ float4* tab_get<PtrTab>(const PtrTab& t, int k) { ret
 template <>
 __device__ __forceinline__ float4* tab_get<float4* const*>(float4* const* const& t, int k) { return t[k]; }
 
+// use_rects == 0: every layer covers the whole tile (also the only form for K > kMaxK)
 template <class Tab>
-__global__ void norm_weights_kernel(Tab layers_tab, int K, size_t n, int fuse_norm,
-                                    int mbb_norm, uint8_t* __restrict__ cov) {
+__global__ void norm_weights_kernel(Tab layers_tab, RectTab rects, int use_rects, int K, int w, size_t n,
+                                    int fuse_norm, int mbb_norm, uint8_t* __restrict__ cov) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
+    const int y = (int)(p / (size_t)w), x = (int)(p - (size_t)y * w);
+    // bit k: the pixel lies in layer k's footprint (K <= 64 per call: callers chunk above that)
+    unsigned long long inside = 0ull;
+    for (int k = 0; k < K; ++k)
+        if (!use_rects || in_rect(rects.r[k], x, y)) inside |= 1ull << k;
     bool any = false;
     if (fuse_norm) {
         float s = 0.f;
         for (int k = 0; k < K; ++k) {
-            const float w = tab_get<Tab>(layers_tab, k)[p].w;
-            s = s + w;
-            any |= w > 0.f;
+            const float wv = (inside >> k) & 1 ? tab_get<Tab>(layers_tab, k)[p].w : 0.f;
+            s = s + wv;
+            any |= wv > 0.f;
         }
         const float inv = s > 1e-8f ? 1.0f / s : 0.f;
-        for (int k = 0; k < K; ++k) tab_get<Tab>(layers_tab, k)[p].w = tab_get<Tab>(layers_tab, k)[p].w * inv;
+        for (int k = 0; k < K; ++k)
+            if ((inside >> k) & 1) tab_get<Tab>(layers_tab, k)[p].w = tab_get<Tab>(layers_tab, k)[p].w * inv;
     }
     if (mbb_norm) {
         float s = 0.f;
         for (int k = 0; k < K; ++k) {
-            const float w = tab_get<Tab>(layers_tab, k)[p].w;
-            s = s + (w > 0.f ? w : 0.f);
+            const float wv = (inside >> k) & 1 ? tab_get<Tab>(layers_tab, k)[p].w : 0.f;
+            s = s + (wv > 0.f ? wv : 0.f);
         }
         for (int k = 0; k < K; ++k) {
-            const float w = tab_get<Tab>(layers_tab, k)[p].w > 0.f ? tab_get<Tab>(layers_tab, k)[p].w : 0.f;
-            tab_get<Tab>(layers_tab, k)[p].w = s > 1e-8f ? w / s : 0.f;
+            if (!((inside >> k) & 1)) continue;
+            const float wv = tab_get<Tab>(layers_tab, k)[p].w > 0.f ? tab_get<Tab>(layers_tab, k)[p].w : 0.f;
+            tab_get<Tab>(layers_tab, k)[p].w = s > 1e-8f ? wv / s : 0.f;
         }
     }
     if (cov) cov[p] = any ? 1 : 0;
@@ -436,13 +513,15 @@ __global__ void unpack_clamp_kernel(const float4* __restrict__ in, size_t n, int
 
 // 'linear' (:916-978) over K layers that already hold w = Wang*max(Wf,1e-4) (0 outside the mask)
 template <class Tab>
-__global__ void linear_fuse_kernel(Tab layers_tab, int K, size_t n,
+__global__ void linear_fuse_kernel(Tab layers_tab, RectTab rects, int use_rects, int K, int w, size_t n,
                                    float4* __restrict__ F, uint8_t* __restrict__ cov) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
+    const int y = (int)(p / (size_t)w), x = (int)(p - (size_t)y * w);
     float acc[3] = {0.f, 0.f, 0.f}, ws = 0.f, bestw = 0.f, best[3] = {0.f, 0.f, 0.f};
     bool anyv = false;
     for (int k = 0; k < K; ++k) {
+        if (use_rects && !in_rect(rects.r[k], x, y)) continue;  // an all-zero term
         const float4 g = tab_get<Tab>(layers_tab, k)[p];
         acc[0] = acc[0] + g.x * g.w;
         acc[1] = acc[1] + g.y * g.w;
@@ -654,17 +733,20 @@ static void imresize4(const float4* in, int h, int w, int oh, int ow, float4* ou
 // imgaussfilt: column (vertical) pass then row pass through one LDS tile; replicate padding.
 constexpr int kBW = 32, kBH = 16;  // output tile of mb_blur_kernel
 template <int R>
-__global__ __launch_bounds__(256) void mb_blur_kernel(PtrTab ins, int h, int w, Taps tp, PtrTab outs) {
+__global__ __launch_bounds__(256) void mb_blur_kernel(PtrTab ins, RectTab irs, int h, int w, Taps tp, PtrTab outs,
+                                                      RectTab ors) {
     const float4* __restrict__ in = ins.p[blockIdx.z];
     float4* __restrict__ out = outs.p[blockIdx.z];
+    const Rect ir = irs.r[blockIdx.z], orc = ors.r[blockIdx.z];
     constexpr int IW = kBW + 2 * R, IH = kBH + 2 * R;
+    const int x0 = orc.x0 + blockIdx.x * kBW, y0 = orc.y0 + blockIdx.y * kBH, tid = threadIdx.x;
+    if (x0 >= orc.x1 || y0 >= orc.y1) return;  // the grid is sized for the largest output rect of the launch
     __shared__ float4 s_in[IH * IW];
     __shared__ float4 s_v[kBH * IW];
-    const int x0 = blockIdx.x * kBW, y0 = blockIdx.y * kBH, tid = threadIdx.x;
     for (int e = tid; e < IH * IW; e += 256) {
         const int ly = e / IW, lx = e - ly * IW;
         const int gy = min(max(y0 + ly - R, 0), h - 1), gx = min(max(x0 + lx - R, 0), w - 1);
-        s_in[e] = in[(size_t)gy * w + gx];
+        s_in[e] = ld_rect(in, w, ir, gx, gy);
     }
     __syncthreads();
     for (int e = tid; e < kBH * IW; e += 256) {  // vertical pass for every column of the haloed tile
@@ -678,7 +760,7 @@ __global__ __launch_bounds__(256) void mb_blur_kernel(PtrTab ins, int h, int w, 
     for (int e = tid; e < kBH * kBW; e += 256) {  // horizontal pass
         const int ly = e / kBW, lx = e - ly * kBW;
         const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= w || gy >= h) continue;
+        if (gx >= orc.x1 || gy >= orc.y1) continue;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], s_v[ly * IW + lx + t], a);
@@ -691,48 +773,48 @@ __global__ __launch_bounds__(256) void mb_blur_kernel(PtrTab ins, int h, int w, 
 // The intermediate value depends only on its own position, so this equals materialising the intermediate image.
 // ROWS_FIRST = the reference's rule (smaller scale factor first, ties -> rows).
 template <bool ROWS_FIRST>
-__global__ void mb_resize_kernel(PtrTab ins, int h, int w, int oh, int ow, PtrTab outs) {
-    const float4* __restrict__ in = ins.p[blockIdx.z];
-    float4* __restrict__ out = outs.p[blockIdx.z];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= ow) return;
-    int lr, lc;
-    float wr[12], wc[12];
-    const int Pr = resize_taps(h, oh, y, lr, wr);
-    const int Pc = resize_taps(w, ow, x, lc, wc);
+__device__ __forceinline__ float4 resize_at(const float4* __restrict__ in, int h, int w, const Rect& ir, int Pr, int lr,
+                                            const float* wr, int Pc, int lc, const float* wc) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ROWS_FIRST) {  // pass 1 resizes rows (at full width), pass 2 resizes columns
         for (int tc = 0; tc < Pc; ++tc) {
             const int xx = min(max(lc + tc, 1), w) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tr = 0; tr < Pr; ++tr) {
-                const int yy = min(max(lr + tr, 1), h) - 1;
-                v = fma4(wr[tr], in[(size_t)yy * w + xx], v);
-            }
+            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], ld_rect(in, w, ir, xx, min(max(lr + tr, 1), h) - 1), v);
             a = fma4(wc[tc], v, a);
         }
     } else {
         for (int tr = 0; tr < Pr; ++tr) {
             const int yy = min(max(lr + tr, 1), h) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tc = 0; tc < Pc; ++tc) {
-                const int xx = min(max(lc + tc, 1), w) - 1;
-                v = fma4(wc[tc], in[(size_t)yy * w + xx], v);
-            }
+            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], ld_rect(in, w, ir, min(max(lc + tc, 1), w) - 1, yy), v);
             a = fma4(wr[tr], v, a);
         }
     }
-    out[(size_t)y * ow + x] = a;
+    return a;
+}
+
+template <bool ROWS_FIRST>
+__global__ void mb_resize_kernel(PtrTab ins, RectTab irs, int h, int w, int oh, int ow, PtrTab outs, RectTab ors) {
+    const float4* __restrict__ in = ins.p[blockIdx.z];
+    float4* __restrict__ out = outs.p[blockIdx.z];
+    const Rect ir = irs.r[blockIdx.z], orc = ors.r[blockIdx.z];
+    const int x = orc.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = orc.y0 + blockIdx.y;
+    if (x >= orc.x1 || y >= orc.y1) return;
+    int lr, lc;
+    float wr[12], wc[12];
+    const int Pr = resize_taps(h, oh, y, lr, wr);
+    const int Pc = resize_taps(w, ow, x, lc, wc);
+    out[(size_t)y * ow + x] = resize_at<ROWS_FIRST>(in, h, w, ir, Pr, lr, wr, Pc, lc, wc);
 }
 
 // Level l of multiBandBlending.m:136-144 for ALL K layers in one pass:
 //   Num_l = sum_k (G_k - imresize(D_k, size_l)) .* w_k      (accumulated in layer order, from zero)
 // or, with D == nullptr, the coarsest level (:159): Num_L = sum_k G_k .* w_k.
+// A layer whose footprint does not contain the pixel contributes (0 - u) * 0: skipped.
 template <bool ROWS_FIRST>
-__global__ void mb_lap_all_kernel(PtrTab Gt, PtrTab Dt, int has_d, int cont, int K, int h, int w,
+__global__ void mb_lap_all_kernel(PtrTab Gt, RectTab Gr, PtrTab Dt, RectTab Dr, int has_d, int cont, int K, int h, int w,
                                   int dh, int dw, float4* __restrict__ num) {
-    float4* const* G = Gt.p;
-    float4* const* D = has_d ? Dt.p : nullptr;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -742,37 +824,27 @@ __global__ void mb_lap_all_kernel(PtrTab Gt, PtrTab Dt, int has_d, int cont, int
         acc[1] = p.y;
         acc[2] = p.z;
     }
-    if (D == nullptr) {
+    if (!has_d) {
         for (int k = 0; k < K; ++k) {
-            const float4 g = G[k][(size_t)y * w + x];
+            if (!in_rect(Gr.r[k], x, y)) continue;
+            const float4 g = Gt.p[k][(size_t)y * w + x];
             acc[0] = acc[0] + g.x * g.w;
             acc[1] = acc[1] + g.y * g.w;
             acc[2] = acc[2] + g.z * g.w;
         }
     } else {
-        int lr, lc;
+        int lr = 0, lc = 0, Pr = 0, Pc = 0;
         float wr[12], wc[12];
-        const int Pr = resize_taps(dh, h, y, lr, wr);
-        const int Pc = resize_taps(dw, w, x, lc, wc);
+        bool have_taps = false;
         for (int k = 0; k < K; ++k) {
-            const float4* d = D[k];
-            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ROWS_FIRST) {
-                for (int tc = 0; tc < Pc; ++tc) {
-                    const int xx = min(max(lc + tc, 1), dw) - 1;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], d[(size_t)(min(max(lr + tr, 1), dh) - 1) * dw + xx], v);
-                    u = fma4(wc[tc], v, u);
-                }
-            } else {
-                for (int tr = 0; tr < Pr; ++tr) {
-                    const int yy = min(max(lr + tr, 1), dh) - 1;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], d[(size_t)yy * dw + min(max(lc + tc, 1), dw) - 1], v);
-                    u = fma4(wr[tr], v, u);
-                }
+            if (!in_rect(Gr.r[k], x, y)) continue;
+            if (!have_taps) {
+                Pr = resize_taps(dh, h, y, lr, wr);
+                Pc = resize_taps(dw, w, x, lc, wc);
+                have_taps = true;
             }
-            const float4 g = G[k][(size_t)y * w + x];
+            const float4 u = resize_at<ROWS_FIRST>(Dt.p[k], dh, dw, Dr.r[k], Pr, lr, wr, Pc, lc, wc);
+            const float4 g = Gt.p[k][(size_t)y * w + x];
             acc[0] = acc[0] + (g.x - u.x) * g.w;
             acc[1] = acc[1] + (g.y - u.y) * g.w;
             acc[2] = acc[2] + (g.z - u.z) * g.w;
@@ -818,17 +890,58 @@ static PtrTab make_tab(float4* const* p, int count) {
     for (int k = 0; k < kMaxK; ++k) t.p[k] = k < count ? p[k] : nullptr;
     return t;
 }
+static RectTab make_rtab(const Rect* r, int count) {
+    RectTab t;
+    for (int k = 0; k < kMaxK; ++k) t.r[k] = k < count ? r[k] : Rect{0, 0, 0, 0};
+    return t;
+}
+static Rect clip_rect(Rect r, int w, int h) {
+    r.x0 = std::max(r.x0, 0);
+    r.y0 = std::max(r.y0, 0);
+    r.x1 = std::min(r.x1, w);
+    r.y1 = std::min(r.y1, h);
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) r = Rect{0, 0, 0, 0};
+    return r;
+}
+// Output pixels of imresize (in_len -> out_len, antialiased triangle of half-width max(1, 1/scale)) that can see
+// the input interval [a, b): o in [a*s + 0.5*s - 1.5, (b-1)*s + 0.5*s + 0.5] for s < 1; padded by one more pixel.
+static void map_interval(int a, int b, int in_len, int out_len, int& oa, int& ob) {
+    if (b <= a) {
+        oa = ob = 0;
+        return;
+    }
+    const double s = (double)out_len / in_len;
+    const double half = s < 1.0 ? 1.0 : s;  // support in output pixels
+    oa = (int)std::floor(a * s - half - 2.0);
+    ob = (int)std::ceil(b * s + half + 2.0);
+    oa = std::max(oa, 0);
+    ob = std::min(ob, out_len);
+    if (ob <= oa) oa = ob = 0;
+}
+static Rect map_rect(const Rect& r, int h, int w, int oh, int ow) {
+    Rect o;
+    map_interval(r.x0, r.x1, w, ow, o.x0, o.x1);
+    map_interval(r.y0, r.y1, h, oh, o.y0, o.y1);
+    if (o.x1 <= o.x0 || o.y1 <= o.y0) o = Rect{0, 0, 0, 0};
+    return o;
+}
 
-// fuseTile's and multiBandBlending's weight normalisations over K layers (either or both), coverage optional
-static void normalize_weights(const std::vector<float4*>& layers, size_t n, int fuse_norm, int mbb_norm, uint8_t* cov) {
+// fuseTile's and multiBandBlending's weight normalisations over K layers (either or both), coverage optional.
+// rects (optional, K <= kMaxK only): the layers' footprints in the h x w tile.
+static void normalize_weights(const std::vector<float4*>& layers, const Rect* rects, int h, int w, int fuse_norm,
+                              int mbb_norm, uint8_t* cov) {
     const int K = (int)layers.size();
+    const size_t n = (size_t)h * w;
     if (K <= kMaxK) {
-        norm_weights_kernel<PtrTab><<<cdiv(n, 256), 256, 0, stream()>>>(make_tab(layers.data(), K), K, n, fuse_norm, mbb_norm, cov);
+        norm_weights_kernel<PtrTab><<<cdiv(n, 256), 256, 0, stream()>>>(
+            make_tab(layers.data(), K), make_rtab(rects, rects ? K : 0), rects ? 1 : 0, K, w, n, fuse_norm, mbb_norm, cov);
         check_launch("norm_weights_kernel");
     } else {
+        APS_REQUIRE(K <= 64, APS_E_DIM, "more than 64 layers in one tile (%d)", K);
         Ws<float4*> dl(K);
         APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
-        norm_weights_kernel<float4* const*><<<cdiv(n, 256), 256, 0, stream()>>>(dl.get(), K, n, fuse_norm, mbb_norm, cov);
+        norm_weights_kernel<float4* const*><<<cdiv(n, 256), 256, 0, stream()>>>(dl.get(), RectTab{}, 0, K, w, n, fuse_norm,
+                                                                               mbb_norm, cov);
         check_launch("norm_weights_kernel");
         APS_HIP(hipStreamSynchronize(stream()));
     }
@@ -837,7 +950,9 @@ static void normalize_weights(const std::vector<float4*>& layers, size_t n, int 
 // multiBandBlending on K float4 layers whose weights are ALREADY normalised (normalize_weights(..., mbb=1));
 // result float4 in F (unclamped).  Level-major: per level one launch blurs up to 16 layers, one launch
 // downsamples them, one pass forms their Laplacians and accumulates them in layer order.  No host sync.
-static void multiband_device(const std::vector<float4*>& layers, int h, int w, int levels, float sigma, float4* F) {
+// rects (optional): footprints of the layers; every kernel then works on footprints only (see struct Rect).
+static void multiband_device(const std::vector<float4*>& layers, const Rect* rects, int h, int w, int levels, float sigma,
+                             float4* F) {
     const int K = (int)layers.size();
     const size_t hw = (size_t)h * w;
     Prof prof("multiband");
@@ -867,6 +982,23 @@ static void multiband_device(const std::vector<float4*>& layers, int h, int w, i
     for (int l = 0; l < levels; ++l) num[l].alloc((size_t)lh[l] * lw[l]);
     const Taps tp = make_taps(sigma);
     APS_REQUIRE(tp.r >= 1 && tp.r <= 4, APS_E_ARG, "pyrSigma %g needs a %d-tap filter; 3..9 taps are built", (double)sigma, 2 * tp.r + 1);
+    // footprints per level: G_l, blurred G_l (grown by the filter radius), G_{l+1} (mapped through the resize)
+    std::vector<std::vector<Rect>> gr(levels, std::vector<Rect>(K)), br(levels, std::vector<Rect>(K));
+    for (int k = 0; k < K; ++k) gr[0][k] = rects ? clip_rect(rects[k], w, h) : Rect{0, 0, w, h};
+    for (int l = 0; l < levels; ++l)
+        for (int k = 0; k < K; ++k) {
+            const Rect g = gr[l][k];
+            const bool empty = g.x1 <= g.x0;
+            br[l][k] = empty ? g : clip_rect(Rect{g.x0 - tp.r, g.y0 - tp.r, g.x1 + tp.r, g.y1 + tp.r}, lw[l], lh[l]);
+            if (l + 1 < levels) gr[l + 1][k] = empty ? g : map_rect(br[l][k], lh[l], lw[l], lh[l + 1], lw[l + 1]);
+        }
+    auto span = [](const Rect* r, int count, int& mw, int& mh) {
+        mw = mh = 0;
+        for (int k = 0; k < count; ++k) {
+            mw = std::max(mw, r[k].x1 - r[k].x0);
+            mh = std::max(mh, r[k].y1 - r[k].y0);
+        }
+    };
     for (int l = 0; l < levels; ++l) {
         const int hl = lh[l], wl = lw[l];
         const bool last = l == levels - 1;
@@ -875,28 +1007,39 @@ static void multiband_device(const std::vector<float4*>& layers, int h, int w, i
         for (int k0 = 0; k0 < K; k0 += kMaxK) {
             const int kc = std::min(kMaxK, K - k0);
             const PtrTab gt = make_tab(lev[l].data() + k0, kc);
+            const RectTab grt = make_rtab(gr[l].data() + k0, kc);
             PtrTab dt = gt;
+            RectTab drt = grt;
             if (!last) {
                 const PtrTab bt = make_tab(bl.data(), kc);
+                const RectTab brt = make_rtab(br[l].data() + k0, kc);
                 dt = make_tab(lev[l + 1].data() + k0, kc);
-                const dim3 bg(cdiv(wl, kBW), cdiv(hl, kBH), kc);
-                switch (tp.r) {
-                    case 1: mb_blur_kernel<1><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
-                    case 2: mb_blur_kernel<2><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
-                    case 3: mb_blur_kernel<3><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
-                    default: mb_blur_kernel<4><<<bg, 256, 0, stream()>>>(gt, hl, wl, tp, bt); break;
+                drt = make_rtab(gr[l + 1].data() + k0, kc);
+                int mw, mh;
+                span(br[l].data() + k0, kc, mw, mh);
+                if (mw > 0 && mh > 0) {
+                    const dim3 bg(cdiv(mw, kBW), cdiv(mh, kBH), kc);
+                    switch (tp.r) {
+                        case 1: mb_blur_kernel<1><<<bg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, bt, brt); break;
+                        case 2: mb_blur_kernel<2><<<bg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, bt, brt); break;
+                        case 3: mb_blur_kernel<3><<<bg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, bt, brt); break;
+                        default: mb_blur_kernel<4><<<bg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, bt, brt); break;
+                    }
                 }
-                const dim3 rg(cdiv(nw, 128), nh, kc);
-                if (rows_first(hl, wl, nh, nw))
-                    mb_resize_kernel<true><<<rg, 128, 0, stream()>>>(bt, hl, wl, nh, nw, dt);
-                else
-                    mb_resize_kernel<false><<<rg, 128, 0, stream()>>>(bt, hl, wl, nh, nw, dt);
+                span(gr[l + 1].data() + k0, kc, mw, mh);
+                if (mw > 0 && mh > 0) {
+                    const dim3 rg(cdiv(mw, 128), mh, kc);
+                    if (rows_first(hl, wl, nh, nw))
+                        mb_resize_kernel<true><<<rg, 128, 0, stream()>>>(bt, brt, hl, wl, nh, nw, dt, drt);
+                    else
+                        mb_resize_kernel<false><<<rg, 128, 0, stream()>>>(bt, brt, hl, wl, nh, nw, dt, drt);
+                }
             }
             const dim3 lg(cdiv(wl, 128), hl);
             if (last || rows_first(nh, nw, hl, wl))
-                mb_lap_all_kernel<true><<<lg, 128, 0, stream()>>>(gt, dt, last ? 0 : 1, k0 > 0, kc, hl, wl, nh, nw, dst);
+                mb_lap_all_kernel<true><<<lg, 128, 0, stream()>>>(gt, grt, dt, drt, last ? 0 : 1, k0 > 0, kc, hl, wl, nh, nw, dst);
             else
-                mb_lap_all_kernel<false><<<lg, 128, 0, stream()>>>(gt, dt, 1, k0 > 0, kc, hl, wl, nh, nw, dst);
+                mb_lap_all_kernel<false><<<lg, 128, 0, stream()>>>(gt, grt, dt, drt, 1, k0 > 0, kc, hl, wl, nh, nw, dst);
             check_launch("multiband level");
         }
     }
@@ -1039,8 +1182,8 @@ int aps_multiband_blend(const float* C, const float* Wt, int k, int h, int w, in
         }
         check_launch("pack_layer_kernel");
         Ws<float4> F4(hw);
-        normalize_weights(layers, hw, 0, 1, nullptr);  // multiBandBlending.m:72-85
-        multiband_device(layers, h, w, levels, sigma, F4);
+        normalize_weights(layers, nullptr, h, w, 0, 1, nullptr);  // multiBandBlending.m:72-85
+        multiband_device(layers, nullptr, h, w, levels, sigma, F4);
         unpack_clamp_kernel<<<cdiv(hw, 256), 256, 0, stream()>>>(F4, hw, 1, oF);
         check_launch("unpack_clamp_kernel");
         oF.commit();
@@ -1125,22 +1268,38 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                 tiles.push_back({r0, c0, std::min(TH, H - r0), std::min(TW, W - c0)});
             }
         const int nt = (int)tiles.size();
-        // phase 1: contributors of every tile (the reference skips images with ~any(Mi), :989); one read-back
-        std::vector<uint32_t> hflags((size_t)nt * n_img, 0);
+        // phase 1: footprint of every image in every tile (the reference skips images with ~any(Mi), :989;
+        // here the bounding box of Mi also bounds all later work on that layer); one read-back
+        std::vector<int> hbox((size_t)nt * n_img * 4, 0);
         if (opts->blending != APS_BLEND_NONE && nt > 0) {
-            Ws<uint32_t> flags((size_t)nt * n_img);
-            APS_HIP(hipMemsetAsync(flags, 0, (size_t)nt * n_img * sizeof(uint32_t), stream()));
+            const int nby_max = cdiv(std::min(TH, H), 8);
+            std::vector<int> dims((size_t)nt * 4);
+            for (int t = 0; t < nt; ++t) {
+                int xs = 0;
+                while ((cdiv(tiles[t].wt, 32) >> xs) > 64 || (((cdiv(tiles[t].wt, 32) - 1) >> xs) > 63)) ++xs;
+                dims[4 * t + 0] = tiles[t].ht;
+                dims[4 * t + 1] = tiles[t].wt;
+                dims[4 * t + 2] = cdiv(tiles[t].ht, 8);
+                dims[4 * t + 3] = xs;
+            }
+            Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
+            Ws<int> bbox(hbox.size()), ddims(dims.size());
+            APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
+            APS_HIP(hipMemcpyAsync(ddims, dims.data(), dims.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
             {
                 Prof prof("cover");
                 for (int t = 0; t < nt; ++t) {
                     const Tile& tl = tiles[t];
                     cover_kernel<<<dim3(cdiv(tl.wt, 32), cdiv(tl.ht, 8)), 256, 0, stream()>>>(
-                        cv, P.dev, n_img, tl.r0, tl.c0, tl.ht, tl.wt, opts->angle_power, flags.get() + (size_t)t * n_img);
+                        cv, P.dev, n_img, tl.r0, tl.c0, tl.ht, tl.wt, opts->angle_power, nby_max, dims[4 * t + 3],
+                        rowmask.get() + (size_t)t * n_img * nby_max);
                 }
+                footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, ddims, n_img, nby_max,
+                                                                                     nt * n_img, bbox);
             }
             check_launch("cover_kernel");
-            APS_HIP(hipMemcpyAsync(hflags.data(), flags, hflags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-            APS_HIP(hipStreamSynchronize(stream()));
+            APS_HIP(hipMemcpyAsync(hbox.data(), bbox, hbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));  // also keeps `dims` alive until its upload has run
         }
         // phase 2: tiles back to back on the stream, no host round trip in between
         for (int t = 0; t < nt; ++t) {
@@ -1157,9 +1316,19 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                 check_launch("none_fuse_kernel");
             } else {
                 std::vector<int> contrib;
-                for (int i = 0; i < n_img; ++i)
-                    if (hflags[(size_t)t * n_img + i]) contrib.push_back(i);
+                std::vector<Rect> rects;
+                for (int i = 0; i < n_img; ++i) {
+                    const int* b = &hbox[((size_t)t * n_img + i) * 4];
+                    if (b[2] > b[0] && b[3] > b[1]) {
+                        contrib.push_back(i);
+                        rects.push_back(Rect{b[0], b[1], b[2], b[3]});
+                    }
+                }
                 const int K = (int)contrib.size();
+                // above kMaxK layers the per-pixel kernels take an uploaded pointer table and no footprints
+                const bool culled = K <= kMaxK && !std::getenv("APS_RENDER_NO_CULL");
+                if (!culled)
+                    for (auto& r : rects) r = Rect{0, 0, wt, ht};
                 if (K == 0) {
                     APS_HIP(hipMemsetAsync(F, 0, T * sizeof(float4), stream()));
                     APS_HIP(hipMemsetAsync(cov, 0, T, stream()));
@@ -1172,26 +1341,28 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                         for (int k = 0; k < K; ++k) {
                             if (store[k].n < T) store[k].alloc(tmax);
                             layers[k] = store[k];
-                            warp_layer_kernel<<<g2, 256, 0, stream()>>>(cv, P.dev, contrib[k], r0, c0, ht, wt,
-                                                                        opts->angle_power, wf_floor, layers[k]);
+                            const Rect& rc = rects[k];
+                            warp_layer_kernel<<<dim3(cdiv(rc.x1 - rc.x0, 32), cdiv(rc.y1 - rc.y0, 8)), 256, 0, stream()>>>(
+                                cv, P.dev, contrib[k], r0, c0, wt, rc, opts->angle_power, wf_floor, layers[k]);
                         }
                     }
                     check_launch("warp_layer_kernel");
                     if (opts->blending == APS_BLEND_LINEAR) {
                         if (K <= kMaxK) {
-                            linear_fuse_kernel<PtrTab><<<cdiv(T, 256), 256, 0, stream()>>>(make_tab(layers.data(), K), K, T, F, cov);
+                            linear_fuse_kernel<PtrTab><<<cdiv(T, 256), 256, 0, stream()>>>(
+                                make_tab(layers.data(), K), make_rtab(rects.data(), K), culled ? 1 : 0, K, wt, T, F, cov);
                             check_launch("linear_fuse_kernel");
                         } else {
                             Ws<float4*> dl(K);
                             APS_HIP(hipMemcpyAsync(dl, layers.data(), K * sizeof(float4*), hipMemcpyHostToDevice, stream()));
-                            linear_fuse_kernel<float4* const*><<<cdiv(T, 256), 256, 0, stream()>>>(dl.get(), K, T, F, cov);
+                            linear_fuse_kernel<float4* const*><<<cdiv(T, 256), 256, 0, stream()>>>(dl.get(), RectTab{}, 0, K, wt, T, F, cov);
                             check_launch("linear_fuse_kernel");
                             APS_HIP(hipStreamSynchronize(stream()));
                         }
                     } else {
                         // fuseTile's normalisation (:991-1006) and multiBandBlending's own (:72-85), one pass
-                        normalize_weights(layers, T, 1, 1, cov);
-                        multiband_device(layers, ht, wt, opts->pyr_levels, opts->pyr_sigma, F);
+                        normalize_weights(layers, culled ? rects.data() : nullptr, ht, wt, 1, 1, cov);
+                        multiband_device(layers, culled ? rects.data() : nullptr, ht, wt, opts->pyr_levels, opts->pyr_sigma, F);
                     }
                 }
             }
