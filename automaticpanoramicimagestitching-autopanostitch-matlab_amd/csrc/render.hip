@@ -33,6 +33,7 @@ struct DevImage {
     float R[9];  // column-major, single(cam.R)
     float fx, fy, cx, cy;
     float gain[3];
+    float cmin;  // cos of the largest angle between the optical axis and a ray that hits the pixel rectangle (minus a margin)
 };
 
 struct DevCanvas {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void cover_kernel(DevCanvas cv, const DevImage
     const bool in_tile = x < wt && y < ht;
     float d[3] = {0.f, 0.f, 1.f};
     if (in_tile) canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
+    const float dn = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
     const unsigned long long colbit = 1ull << (blockIdx.x >> xshift);
     for (int base = 0; base < n_img; base += 64) {
         if (threadIdx.x == 0) s_any = 0ull;
@@ -210,8 +212,13 @@ __global__ __launch_bounds__(256) void cover_kernel(DevCanvas cv, const DevImage
         unsigned long long mine = 0ull;  // wave-uniform: images (of this group of 64) seen by this wave
         const int cnt = min(64, n_img - base);
         for (int i = 0; i < cnt; ++i) {
+            const DevImage& im = imgs[base + i];
+            // necessary condition first (three fmas): the ray must lie inside the image's cone about its optical
+            // axis; a wave that is wholly outside skips the projection.  cam2 is project()'s own expression.
+            const float cam2 = fmaf(d[2], im.R[8], fmaf(d[1], im.R[5], d[0] * im.R[2]));
+            if (!__any(in_tile && cam2 >= im.cmin * dn)) continue;
             float u, v, wa;
-            const bool m = in_tile && project(imgs[base + i], d, angle_pow, u, v, wa);
+            const bool m = in_tile && project(im, d, angle_pow, u, v, wa);
             if (__any(m)) mine |= 1ull << i;
         }
         if ((threadIdx.x & 63) == 0 && mine) atomicOr(&s_any, mine);
@@ -1067,6 +1074,7 @@ struct PreparedImages {
     std::vector<Ws<float>> wx, wy;
     std::vector<In<uint8_t>> src;
     std::vector<DevImage> host;
+    std::vector<std::vector<float>> tents;  // host tent tables, alive until their uploads have run
     Ws<DevImage> dev;
 };
 
@@ -1076,6 +1084,7 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
     P.wy.resize(n);
     P.src.resize(n);
     P.host.resize(n);
+    P.tents.resize(2 * (size_t)n);
     for (int i = 0; i < n; ++i) {
         const aps_image& im = images[i];
         APS_REQUIRE(im.data != nullptr, APS_E_ARG, "image %d: NULL data", i);
@@ -1089,14 +1098,14 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
         to_rgba_kernel<<<dim3(cdiv(im.width, 256), im.height), 256, 0, stream()>>>(
             P.src[i], im.height, im.width, im.channels, im.layout, P.rgba[i]);
         check_launch("to_rgba_kernel");
-        std::vector<float> tx, ty;
+        std::vector<float>& tx = P.tents[2 * i];
+        std::vector<float>& ty = P.tents[2 * i + 1];
         host_tent(im.width, tx);
         host_tent(im.height, ty);
         P.wx[i].alloc(im.width);
         P.wy[i].alloc(im.height);
         APS_HIP(hipMemcpyAsync(P.wx[i], tx.data(), tx.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
         APS_HIP(hipMemcpyAsync(P.wy[i], ty.data(), ty.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
-        APS_HIP(hipStreamSynchronize(stream()));  // tx/ty are stack-lifetime host buffers
         DevImage& d = P.host[i];
         d.rgba = P.rgba[i];
         d.wx = P.wx[i];
@@ -1109,6 +1118,12 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
         d.cx = (float)im.K[6];
         d.cy = (float)im.K[7];
         for (int c = 0; c < 3; ++c) d.gain[c] = im.gain[c];
+        {
+            const double ax = std::max(std::fabs(1.0 - im.K[6]), std::fabs((double)im.width - im.K[6])) / std::fabs(im.K[0]);
+            const double ay = std::max(std::fabs(1.0 - im.K[7]), std::fabs((double)im.height - im.K[7])) / std::fabs(im.K[4]);
+            const double c = 1.0 / std::sqrt(1.0 + ax * ax + ay * ay);
+            d.cmin = std::isfinite(c) ? (float)(c * (1.0 - 1e-4) - 1e-6) : -1.0f;
+        }
     }
     P.dev.alloc(n);
     APS_HIP(hipMemcpyAsync(P.dev, P.host.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, stream()));

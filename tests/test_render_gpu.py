@@ -145,6 +145,25 @@ def test_render_five_bands_gains_white_canvas_and_partial_tiles(rp):
     assert np.all(pano[cov == 0] == 255)
 
 
+@pytest.mark.parametrize("blending,mode", [("multiband", "spherical"), ("linear", "spherical"),
+                                           ("multiband", "cylindrical"), ("multiband", "planar")])
+def test_footprint_culling_changes_no_bit(rp, monkeypatch, blending, mode):
+    """Layers are processed on their footprint rectangles only; the result must equal full-tile processing
+    (APS_RENDER_NO_CULL=1) in every byte, including tiles where footprints are slivers, and coverage too."""
+    rng = np.random.default_rng(11)
+    imgs, cams = _scene(rng, n=6, W=220, H=140, f=300.0)
+    sizes = [(140, 220, 3)] * 6
+    opts = {"anglePower": 2, "blending": blending, "pyrLevels": 5, "pyrSigma": 1.0, "tile": (72, 104),
+            "cropBorder": False}
+    monkeypatch.delenv("APS_RENDER_NO_CULL", raising=False)
+    a, _, ca, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, return_covered=True)
+    monkeypatch.setenv("APS_RENDER_NO_CULL", "1")
+    b, _, cb, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, return_covered=True)
+    assert a.shape == b.shape and ca.sum() > 10000
+    assert np.array_equal(ca, cb)
+    assert np.array_equal(a, b)
+
+
 def test_canvas_geometry_and_crop(rp):
     rng = np.random.default_rng(6)
     imgs, cams = _scene(rng)
