@@ -145,13 +145,22 @@ def ransac_score(Hs, p1, p2, thr):
 
 def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
     """Batched form used by imageMatching and the resident pipeline.
-    pts_src/pts_dst: total x 2 float64; pair_ptr: int64[P+1]; samples: uint32[P, S, 4].
+    pts_src/pts_dst: total x 2 float64 (numpy) or 2 x total float64 CUDA tensors; pair_ptr: int64[P+1];
+    samples: uint32[P, S, 4] (numpy or CUDA tensor).
     Returns (models [P,3,3], mask uint8[total], found int32[P], n_inl int32[P])."""
-    a = np.asfortranarray(np.asarray(pts_src, np.float64))
-    b = np.asfortranarray(np.asarray(pts_dst, np.float64))
     pair_ptr = np.ascontiguousarray(pair_ptr, np.int64)
     P = pair_ptr.size - 1
     total = int(pair_ptr[-1])
+    if _capi.is_torch(pts_src):
+        # resident form: 2 x total float64 CUDA tensors (row 0 = x, row 1 = y), i.e. column-major total x 2
+        import torch
+        a, b = pts_src.contiguous(), pts_dst.contiguous()
+        assert a.dtype == torch.float64 and b.dtype == torch.float64 and a.shape == (2, total) and b.shape == (2, total)
+        ld = max(total, 1)
+    else:
+        a = np.asfortranarray(np.asarray(pts_src, np.float64))
+        b = np.asfortranarray(np.asarray(pts_dst, np.float64))
+        ld = max(total, 1) if a.shape[0] == 0 else a.shape[0]
     if not _capi.is_torch(samples):
         samples = np.ascontiguousarray(samples, np.uint32)
     assert samples.shape[0] == P and samples.shape[2] == 4
@@ -160,7 +169,7 @@ def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
     found = np.zeros(P, np.int32)
     ninl = np.zeros(P, np.int32)
     o = _ransac_opts(input)
-    check(lib.aps_ransac_homography_batch(ptr(a), ptr(b), max(total, 1) if a.shape[0] == 0 else a.shape[0],
+    check(lib.aps_ransac_homography_batch(ptr(a), ptr(b), ld,
                                           ptr(pair_ptr), P, ptr(samples), samples.shape[1], C.byref(o),
                                           ptr(models), ptr(mask), ptr(found), ptr(ninl)))
     return models.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mask[:total], found, ninl

@@ -191,14 +191,16 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     if mine:
         cnts = [len(allm[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
-        # one gather over the concatenated keypoint table instead of one fancy-index per pair
+        # one device gather over the concatenated keypoint table (the keypoints are resident already; a host
+        # fancy-index of ~1e6 rows costs tens of milliseconds)
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        kp_all = np.concatenate(kps)
+        kp_all = torch.cat([k.to(dev) for k in kps_t]).to(torch.float64)
         cat = np.concatenate([allm[p] for p in mine])
-        img_i = np.repeat(np.asarray([order[p][0] for p in mine], np.int64), cnts)
-        img_j = np.repeat(np.asarray([order[p][1] for p in mine], np.int64), cnts)
-        dst = kp_all[offs[img_i] + cat[:, 0] - 1]
-        src = kp_all[offs[img_j] + cat[:, 1] - 1]
+        img_i = np.repeat(offs[[order[p][0] for p in mine]], cnts)
+        img_j = np.repeat(offs[[order[p][1] for p in mine]], cnts)
+        idx = torch.from_numpy(np.stack([img_i + cat[:, 0] - 1, img_j + cat[:, 1] - 1])).to(dev)
+        dst = kp_all.index_select(0, idx[0]).t().contiguous()
+        src = kp_all.index_select(0, idx[1]).t().contiguous()
         samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
         times.add("im_gather", t0)
         t0 = time.perf_counter()
