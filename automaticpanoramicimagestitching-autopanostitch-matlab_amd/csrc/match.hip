@@ -37,6 +37,17 @@ constexpr int kLdsRow = 132;  // floats per LDS row: 128 + one 16-B pad => ds_re
 // ------------------------------------------------------------------------------------------------
 // |x| maximum per descriptor set (the reference's "looks unnormalised" probe, :105)
 // ------------------------------------------------------------------------------------------------
+// contiguous rows (the common case): a flat float4 sweep, no index arithmetic
+__global__ void absmax_flat_kernel(const float4* __restrict__ X, int64_t n4, float* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = X[e];
+        m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
 __global__ void absmax_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int dim,
                               int layout, float* __restrict__ out) {
     float m = 0.f;
@@ -486,12 +497,18 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
                 }
             }
         }
-        // own fourth-best every block; the other half's (a cross-lane exchange and its wait) once per tile
+        // own fourth-best every block; the union with the other half's list (cross-lane exchange) once per tile
         thr[0] = fmaxf(thr[0], u3[0]);
         thr[1] = fmaxf(thr[1], u3[1]);
         if (cb == kTNB / 32 - 1) {
-            thr[0] = fmaxf(thr[0], __shfl_xor(thr[0], 32));
-            thr[1] = fmaxf(thr[1], __shfl_xor(thr[1], 32));
+            // the fourth-best of the union of the two halves' sorted fours: max over i+j=3 of min(a_i, b_j)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const float o0 = __shfl_xor(u0[rb], 32), o1 = __shfl_xor(u1[rb], 32), o2 = __shfl_xor(u2[rb], 32),
+                            o3 = __shfl_xor(u3[rb], 32);
+                const float m = fmaxf(fmaxf(fminf(u0[rb], o2), fminf(u1[rb], o1)), fminf(u2[rb], o0));
+                thr[rb] = fmaxf(thr[rb], fmaxf(fmaxf(u3[rb], o3), m));
+            }
         }
     };
 
@@ -847,7 +864,11 @@ static float absmax(const float* X_dev, int64_t n, int64_t ld, int layout, float
     APS_HIP(hipMemsetAsync(d_slot, 0, sizeof(float), stream()));
     if (n > 0) {
         const unsigned grid = std::min<unsigned>(cdiv((size_t)n * kDim, 256), 2048);
-        absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
+        if (layout == APS_ROWMAJOR && ld == kDim && (reinterpret_cast<uintptr_t>(X_dev) & 15) == 0)
+            absmax_flat_kernel<<<std::min<unsigned>(cdiv((size_t)n * kDim / 4, 256), 2048), 256, 0, stream()>>>(
+                reinterpret_cast<const float4*>(X_dev), n * (kDim / 4), d_slot);
+        else
+            absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
         check_launch("absmax_kernel");
     }
     float h = 0.f;
