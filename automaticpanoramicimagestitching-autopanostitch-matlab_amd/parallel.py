@@ -201,6 +201,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         idx = torch.from_numpy(np.stack([img_i + cat[:, 0] - 1, img_j + cat[:, 1] - 1])).to(dev)
         dst = kp_all.index_select(0, idx[0]).t().contiguous()
         src = kp_all.index_select(0, idx[1]).t().contiguous()
+        torch.cuda.current_stream().synchronize()  # torch's stream produced dst/src; the library runs on its own
         samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
         times.add("im_gather", t0)
         t0 = time.perf_counter()
