@@ -265,5 +265,5 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         dist.all_reduce(pano, op=dist.ReduceOp.MAX)
     times.add("render", t0)
     info = {"times": dict(times), "n_features": counts, "n_pairs_verified": len(pairs), "n_components": int(ncomp),
-            "members": members, "cameras": cameras, "pairs": pairs, "models": models_l}
+            "panorama_shape": tuple(int(v) for v in pano.shape), "members": members, "cameras": cameras, "pairs": pairs, "models": models_l}
     return pano, info

@@ -172,6 +172,11 @@ def main():
 
     if rank == 0:
         info = infos[-1]
+        # same input, seeded draws: every step must reproduce the same result (a race between streams shows up here)
+        for other in infos[:-1]:
+            if (other["n_pairs_verified"], tuple(other["panorama_shape"])) != \
+                    (info["n_pairs_verified"], tuple(info["panorama_shape"])):
+                raise RuntimeError("non-deterministic stitch: steps disagree on verified pairs / panorama size")
         mpix_in = n * w * h / 1e6
         value = mpix_in * args.steps / dt
         counts = info["n_features"]
