@@ -1,0 +1,22 @@
+#!/bin/bash
+# Produces the judged artefacts of a round on the GPU box (run through gpurun):
+#   gpurun_out/<tag>_bench.json                 the bench line (un-profiled run)
+#   gpurun_out/<tag>_bench_under_rocprofv3.json the bench line of the --kernel-trace --stats run
+#   gpurun_out/<tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats summary of that same command
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+cd "$ROOT"
+python3 bench.py > gpurun_out/${TAG}_bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
+rm -rf /tmp/prof_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python3 bench.py --cpu-baseline off \
+    > gpurun_out/${TAG}_bench_under_rocprofv3.json 2> /tmp/prof_stats.err
+cp /tmp/prof_stats/p_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
+# HBM traffic (FETCH_SIZE / WRITE_SIZE): NOT collected here.  Round 1 tried twice (on bench.py and on the small matching
+# probe, each in its own --pmc pass): the TCC-derived counters did not finish within 40 and 10 minutes on this pool, while
+# SQ_* counters on the same probe take seconds (scripts/pmc_run.sh).  bench.py therefore reports "traffic": null.
+python3 - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_bench.json"))
+print(d["value"], d["unit"], d["ms_per_step"], d["roofline"], d["cpu_baseline"])
+PY
