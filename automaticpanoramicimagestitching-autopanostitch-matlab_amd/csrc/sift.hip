@@ -183,7 +183,7 @@ constexpr int kTW = 64, kTH = 32;  // output tile per 256-thread workgroup
 
 template <int R>
 __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
-                                                   float* __restrict__ out, float* __restrict__ dog) {
+                                                   float* __restrict__ out) {
     constexpr int IW = kTW + 2 * R, IH = kTH + 2 * R;
     __shared__ float s_in[IH * IW];
     __shared__ float s_row[IH * kTW];
@@ -234,7 +234,6 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
                 const int gy = y0 + yb + j;
                 if (gy < h) {
                     out[(size_t)gy * w + gx] = acc[j];
-                    if (dog) dog[(size_t)gy * w + gx] = acc[j] - s_in[(yb + j + R) * IW + lx + R];
                 }
             }
         }
@@ -250,21 +249,18 @@ __global__ void blur_row_generic(const float* __restrict__ in, int h, int w, Gau
     for (int t = 0; t < gk.n; ++t) acc = fmaf(gk.k[t], in[(size_t)y * w + reflect101(x + t - r, w)], acc);
     out[(size_t)y * w + x] = acc;
 }
-__global__ void blur_col_generic(const float* __restrict__ tmp, const float* __restrict__ in, int h, int w,
-                                 GaussK gk, float* __restrict__ out, float* __restrict__ dog) {
+__global__ void blur_col_generic(const float* __restrict__ tmp, int h, int w, GaussK gk, float* __restrict__ out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const int r = gk.n / 2;
     float acc = 0.f;
     for (int t = 0; t < gk.n; ++t) acc = fmaf(gk.k[t], tmp[(size_t)reflect101(y + t - r, h) * w + x], acc);
     out[(size_t)y * w + x] = acc;
-    if (dog) dog[(size_t)y * w + x] = acc - in[(size_t)y * w + x];
 }
 
 // ---- pyramid description on the device ------------------------------------------------------------------
 struct OctaveDesc {
-    const float* G[8];  // nl + 3 <= 8 Gaussian planes
-    const float* D[7];  // nl + 2 DoG planes
+    const float* G[8];  // nl + 3 <= 8 Gaussian planes (DoG_p = G[p+1] - G[p] is formed by its consumers)
     int w, h;
 };
 
@@ -273,7 +269,9 @@ struct KpRec {
     float xc, xr, xi, contr;
 };
 
-#define AT(p, rr, cc) ((p)[(size_t)(rr) * w + (cc)])
+// DoG value of plane L at (rr, cc): G[L+1] - G[L].  The DoG planes are never stored: every consumer subtracts
+// the two Gaussian planes itself, which is the same single f32 subtraction a stored plane would hold.
+#define AT(L, rr, cc) (od.G[(L) + 1][(size_t)(rr) * w + (cc)] - od.G[(L)][(size_t)(rr) * w + (cc)])
 
 __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, int r, int c, float contr_thr,
                                 float edge_thr, KpRec& kp) {
@@ -283,7 +281,7 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
     float xi = 0, xr = 0, xc = 0;
     int i = 0;
     for (; i < kMaxInterp; ++i) {
-        const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
+        const int im = layer, pv = layer - 1, nx = layer + 1;
         const float dD0 = (AT(im, r, c + 1) - AT(im, r, c - 1)) * deriv_scale;
         const float dD1 = (AT(im, r + 1, c) - AT(im, r - 1, c)) * deriv_scale;
         const float dD2 = (AT(nx, r, c) - AT(pv, r, c)) * deriv_scale;
@@ -345,7 +343,7 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
         if (layer < 1 || layer > nl || c < kBorder || c >= w - kBorder || r < kBorder || r >= h - kBorder) return false;
     }
     if (i >= kMaxInterp) return false;
-    const float *im = od.D[layer], *pv = od.D[layer - 1], *nx = od.D[layer + 1];
+    const int im = layer, pv = layer - 1, nx = layer + 1;
     const float dD0 = (AT(im, r, c + 1) - AT(im, r, c - 1)) * deriv_scale;
     const float dD1 = (AT(im, r + 1, c) - AT(im, r - 1, c)) * deriv_scale;
     const float dD2 = (AT(nx, r, c) - AT(pv, r, c)) * deriv_scale;
@@ -379,12 +377,18 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
     const int x0 = blockIdx.x * kEW, y0 = blockIdx.y * kEH;
     const int tid = threadIdx.x;
     constexpr int TW = kEW + 2, TH = kEH + 2;
-    for (int p = 0; p < nl + 2; ++p) {
-        const float* src = od.D[p];
-        for (int e = tid; e < TW * TH; e += 256) {
-            const int ly = e / TW, lx = e - ly * TW;
-            const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = min(max(x0 + lx - 1, 0), w - 1);
-            s_d[p][e] = src[(size_t)gy * w + gx];
+    // DoG planes of the tile, formed here from the nl + 3 Gaussian planes (they are not stored anywhere)
+    for (int e = tid; e < TW * TH; e += 256) {
+        const int ly = e / TW, lx = e - ly * TW;
+        const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = min(max(x0 + lx - 1, 0), w - 1);
+        const size_t off = (size_t)gy * w + gx;
+        float prev = od.G[0][off];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            if (p >= nl + 2) break;
+            const float cur = od.G[p + 1][off];
+            s_d[p][e] = cur - prev;
+            prev = cur;
         }
     }
     __syncthreads();
@@ -758,7 +762,7 @@ static GaussK make_gauss(double sigma) {
     return g;
 }
 
-static void launch_blur(const float* in, int h, int w, double sigma, float* out, float* dog, Ws<float>& scratch) {
+static void launch_blur(const float* in, int h, int w, double sigma, float* out, Ws<float>& scratch) {
     const GaussK gk = make_gauss(sigma);
     const int r = gk.n / 2;
     Prof prof("sift_blur");
@@ -766,7 +770,7 @@ static void launch_blur(const float* in, int h, int w, double sigma, float* out,
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
-        blur_kernel<R><<<grid, 256, 0, stream()>>>(in, h, w, gk, out, dog); \
+        blur_kernel<R><<<grid, 256, 0, stream()>>>(in, h, w, gk, out); \
         break;
         APS_BLUR_CASE(1)
         APS_BLUR_CASE(2)
@@ -784,7 +788,7 @@ static void launch_blur(const float* in, int h, int w, double sigma, float* out,
         default: {
             if (scratch.n < (size_t)h * w) scratch.alloc((size_t)h * w);
             blur_row_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(in, h, w, gk, scratch);
-            blur_col_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(scratch, in, h, w, gk, out, dog);
+            blur_col_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(scratch, h, w, gk, out);
         }
     }
     check_launch("blur_kernel");
@@ -827,7 +831,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         const int n_oct = std::min(num_octaves(H, W), 16);
         if (n_oct <= 0) return;
         // pyramid storage
-        std::vector<Ws<float>> G((size_t)n_oct * (nl + 3)), D((size_t)n_oct * (nl + 2));
+        std::vector<Ws<float>> G((size_t)n_oct * (nl + 3));
         PyrTable table;
         std::memset(&table, 0, sizeof table);
         table.n_oct = n_oct;
@@ -851,11 +855,10 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             od.h = oh;
             const size_t px = (size_t)ow * oh;
             for (int i = 0; i < nl + 3; ++i) G[o * (nl + 3) + i].alloc(px);
-            for (int i = 0; i < nl + 2; ++i) D[o * (nl + 2) + i].alloc(px);
             if (o == 0) {
                 double sd = params->sigma * params->sigma - 4.0 * 0.5 * 0.5;
                 if (sd < 0.01) sd = 0.01;
-                launch_blur(up, oh, ow, std::sqrt(sd), G[0], nullptr, scratch);
+                launch_blur(up, oh, ow, std::sqrt(sd), G[0], scratch);
             } else {
                 const OctaveDesc& pd = table.oct[o - 1];
                 decimate_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(G[(o - 1) * (nl + 3) + nl], pd.h, pd.w,
@@ -863,9 +866,8 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                 check_launch("decimate_kernel");
             }
             for (int i = 1; i < nl + 3; ++i)
-                launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], D[o * (nl + 2) + i - 1], scratch);
+                launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], scratch);
             for (int i = 0; i < nl + 3; ++i) od.G[i] = G[o * (nl + 3) + i];
-            for (int i = 0; i < nl + 2; ++i) od.D[i] = D[o * (nl + 2) + i];
         }
         // extrema: detection sweep per octave -> packed cells; then one dense refinement launch
         Ws<PyrTable> d_table(1);
