@@ -184,15 +184,30 @@ constexpr int kTW = 64, kTH = 32;  // output tile per 256-thread workgroup
 template <int R>
 __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
                                                    float* __restrict__ out) {
-    constexpr int IW = kTW + 2 * R, IH = kTH + 2 * R;
-    __shared__ float s_in[IH * IW];
-    __shared__ float s_row[IH * kTW];
+    // The haloed input tile is fetched in 16-byte pieces: the horizontal halo is rounded up to a multiple of four
+    // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
+    // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
+    constexpr int RP = (R + 3) & ~3, OFF = RP - R;
+    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
+    __shared__ __attribute__((aligned(16))) float s_in[IH * IW];
+    __shared__ __attribute__((aligned(16))) float s_row[IH * kTW];
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
-    for (int e = tid; e < IH * IW; e += 256) {
-        const int ly = e / IW, lx = e - ly * IW;
-        const int gy = reflect101(y0 + ly - R, h), gx = reflect101(x0 + lx - R, w);
-        s_in[e] = in[(size_t)gy * w + gx];
+    const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    for (int e = tid; e < IH * NV; e += 256) {
+        const int ly = e / NV, v = e - ly * NV;
+        const int gy = reflect101(y0 + ly - R, h), gx = x0 - RP + 4 * v;
+        const float* row = in + (size_t)gy * w;
+        float4 val;
+        if (vec_ok && gx >= 0 && gx + 3 < w) {
+            val = *reinterpret_cast<const float4*>(row + gx);
+        } else {
+            val.x = row[reflect101(gx, w)];
+            val.y = row[reflect101(gx + 1, w)];
+            val.z = row[reflect101(gx + 2, w)];
+            val.w = row[reflect101(gx + 3, w)];
+        }
+        *reinterpret_cast<float4*>(&s_in[ly * IW + 4 * v]) = val;
     }
     __syncthreads();
     // row pass: IH rows x 64 cols, 8 consecutive outputs per thread
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
         const int ly = u / (kTW / 8), xb = (u - ly * (kTW / 8)) * 8;
         float v[8 + 2 * R], acc[8];
 #pragma unroll
-        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IW + xb + j];
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IW + OFF + xb + j];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
@@ -209,13 +224,13 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_row[ly * kTW + xb + j] = acc[j];
+        *reinterpret_cast<float4*>(&s_row[ly * kTW + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(&s_row[ly * kTW + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
-    // column pass: 64 cols x 4 groups of 8 rows
-    {
-        const int lx = tid & 63, yb = (tid >> 6) * 8;
+    // column pass: 64 cols x kTH/8 groups of 8 rows
+    for (int u = tid; u < kTW * (kTH / 8); u += 256) {
+        const int lx = u & (kTW - 1), yb = (u / kTW) * 8;
         float v[8 + 2 * R], acc[8];
 #pragma unroll
         for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(yb + j) * kTW + lx];
@@ -232,9 +247,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gy = y0 + yb + j;
-                if (gy < h) {
-                    out[(size_t)gy * w + gx] = acc[j];
-                }
+                if (gy < h) out[(size_t)gy * w + gx] = acc[j];
             }
         }
     }
