@@ -385,23 +385,41 @@ constexpr int kEW = 64, kEH = 16;
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr,
                                                       unsigned long long* __restrict__ cells,
                                                       unsigned int* __restrict__ count, unsigned int cap) {
-    __shared__ float s_d[7][(kEH + 2) * (kEW + 2)];
+    // LDS rows hold pixels x0-4 .. x0+kEW+3 (the 1-pixel halo rounded out to 16-byte pieces; pitch TW)
+    constexpr int TW = kEW + 8, TH = kEH + 2, NV = TW / 4, HX = 3;  // HX: LDS column of pixel x0-1
+    __shared__ __attribute__((aligned(16))) float s_d[7][TH * TW];
     const int w = od.w, h = od.h;
     const int x0 = blockIdx.x * kEW, y0 = blockIdx.y * kEH;
     const int tid = threadIdx.x;
-    constexpr int TW = kEW + 2, TH = kEH + 2;
     // DoG planes of the tile, formed here from the nl + 3 Gaussian planes (they are not stored anywhere)
-    for (int e = tid; e < TW * TH; e += 256) {
-        const int ly = e / TW, lx = e - ly * TW;
-        const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = min(max(x0 + lx - 1, 0), w - 1);
-        const size_t off = (size_t)gy * w + gx;
-        float prev = od.G[0][off];
+    const bool vec_ok = (w & 3) == 0;
+    for (int e = tid; e < TH * NV; e += 256) {
+        const int ly = e / NV, v = e - ly * NV;
+        const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = x0 - 4 + 4 * v;
+        const size_t rowoff = (size_t)gy * w;
+        if (vec_ok && gx >= 0 && gx + 3 < w) {
+            float4 prev = *reinterpret_cast<const float4*>(od.G[0] + rowoff + gx);
 #pragma unroll
-        for (int p = 0; p < 7; ++p) {
-            if (p >= nl + 2) break;
-            const float cur = od.G[p + 1][off];
-            s_d[p][e] = cur - prev;
-            prev = cur;
+            for (int p = 0; p < 7; ++p) {
+                if (p >= nl + 2) break;
+                const float4 cur = *reinterpret_cast<const float4*>(od.G[p + 1] + rowoff + gx);
+                *reinterpret_cast<float4*>(&s_d[p][ly * TW + 4 * v]) =
+                    make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
+                prev = cur;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t off = rowoff + min(max(gx + q, 0), w - 1);
+                float prev = od.G[0][off];
+#pragma unroll
+                for (int p = 0; p < 7; ++p) {
+                    if (p >= nl + 2) break;
+                    const float cur = od.G[p + 1][off];
+                    s_d[p][ly * TW + 4 * v + q] = cur - prev;
+                    prev = cur;
+                }
+            }
         }
     }
     __syncthreads();
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         float hmx[6], hmn[6];
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr) {
-            const float* row = &s_d[p][(4 * g + rr) * TW + lx];
+            const float* row = &s_d[p][(4 * g + rr) * TW + lx + HX];
             hmx[rr] = fmaxf(fmaxf(row[0], row[1]), row[2]);
             hmn[rr] = fminf(fminf(row[0], row[1]), row[2]);
         }
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         const int ry = 4 * g + k;
         const int r = y0 + ry;
         if (r < kBorder || r >= h - kBorder) continue;
-        const int ctr = (ry + 1) * TW + lx + 1;
+        const int ctr = (ry + 1) * TW + lx + HX + 1;
 #pragma unroll
         for (int layer = 1; layer <= 5; ++layer) {
             if (layer > nl) break;

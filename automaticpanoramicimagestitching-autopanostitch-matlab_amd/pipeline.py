@@ -52,15 +52,18 @@ def _sync():
 _SIFT_POOL = None
 
 
-def sift_many(input, images, workers=4):
+def sift_many(input, images, workers=8):
     """getFeaturePoints for many images — the reference runs this loop as a parfor (loadImages.m:82-99).
     Here a few host threads each drive their own HIP stream (the C ABI is thread-safe with per-thread streams
     and workspaces), so the small-octave launches and the count read-backs of one image overlap with the
     large-octave kernels of another.  Results are returned in input order and are independent of the
     interleaving (every kernel is deterministic)."""
     global _SIFT_POOL
+    import os
     import torch
     from concurrent.futures import ThreadPoolExecutor
+
+    workers = int(os.environ.get("APS_SIFT_WORKERS", workers))
 
     dev = _capi.is_torch(images[0]) and images[0].is_cuda
     if len(images) <= 1 or workers <= 1:
