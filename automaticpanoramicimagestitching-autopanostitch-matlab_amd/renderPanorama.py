@@ -260,6 +260,98 @@ def make_render_opts(opts):
     return ro
 
 
+def warpWeights(images):
+    """srcWeights = warpWeights(images, numImages) (renderPanorama.m:1282-1312): the separable tent map
+    wy * wx of every image, single.  (The tiled render path never materialises it: the device samples the
+    two 1-D tables; the planar-scan path below warps the map itself, as the reference does.)"""
+    out = []
+    for im in images:
+        h, w = np.asarray(im).shape[:2]
+
+        def tent(n):
+            t = np.zeros(n, np.float32)
+            a = (n + 1) // 2
+            t[:a] = np.linspace(0, 1, a, dtype=np.float64).astype(np.float32) if a > 1 else 1.0
+            b = n - n // 2
+            t[n // 2:] = np.linspace(1, 0, b, dtype=np.float64).astype(np.float32) if b > 1 else 0.0
+            return t
+
+        out.append(np.outer(tent(h), tent(w)).astype(np.float32))
+    return out
+
+
+def _matlab_round(x):
+    return float(np.sign(x) * np.floor(abs(x) + 0.5))
+
+
+def pureNonRotationalImagesToCanvas(images, tforms, outputView, srcWeights, opts=None):
+    """[Iw, Ww, xBoxes, yBoxes, centers] = pureNonRotationalImagesToCanvas(...) (renderPanorama.m:701-822):
+    every image and its weight map warped to the common canvas with the device imageWarp (bilinear, fill 0,
+    valid only where all four taps are inside, imageWarp.m:125-168); weights clamped to [0,1]."""
+    from .imageProcessing import imageWarp, transformPointsForwardScratch
+
+    Iw, Ww, xB, yB = [], [], [], []
+    centers = np.zeros((len(images), 2))
+    Hc, Wc = outputView["ImageSize"]
+    for k, im in enumerate(images):
+        Ik = np.asarray(im)
+        r, c = Ik.shape[:2]
+        corners = np.array([[1, 1], [c, 1], [c, r], [1, r], [1, 1]], np.float64)  # (x, y) of :751
+        q = transformPointsForwardScratch(tforms[k], corners)
+        xB.append(q[:, 0] - outputView["XWorldLimits"][0])
+        yB.append(q[:, 1] - outputView["YWorldLimits"][0])
+        centers[k] = (xB[-1].mean(), yB[-1].mean())
+        Ik = Ik.astype(np.float32) / 255.0 if Ik.dtype == np.uint8 else Ik.astype(np.float32)
+        Iwk = imageWarp(Ik, tforms[k], outputView)[:Hc, :Wc]
+        Ws = np.ones((r, c), np.float32) if not srcWeights else np.asarray(srcWeights[k], np.float32)
+        Wk = imageWarp(Ws, tforms[k], outputView)[:Hc, :Wc]
+        Iw.append(Iwk if Iwk.ndim == 3 else Iwk[..., None])
+        Ww.append(np.clip(Wk, 0.0, 1.0).astype(np.float32))
+    return Iw, Ww, xB, yB, centers
+
+
+def pureNonRotationalPanoramas(images, cameras, numImages, opts, gains=None):
+    """[panorama, rgbAnnotation] = pureNonRotationalPanoramas(images, cameras, numImages, opts)
+    (renderPanorama.m:519-699): planar-scan compositing.  Canvas = bounding box of all H2refined corner
+    maps with MATLAB-rounded size (:547-575); every image warped to the FULL canvas; then whole-canvas
+    'none' (winner-take-all by weight, first maximum) / 'linear' / 'multiband'; void pixels painted; uint8.
+    Gain compensation (gainCompensationH) stays on the host: pass `gains` (N x 3) or ones are used."""
+    from .blending import linearBlending, multiBandBlending
+    from .imageProcessing import imref2dScratch, outputLimitsScratch
+
+    o = {"blending": "multiband", "pyrLevels": 3, "pyrSigma": 1.0, "canvasColor": "black"}
+    o.update(opts or {})
+    tforms = [np.asarray(cam["H2refined"], np.float64) for cam in cameras[:numImages]]
+    lims = [outputLimitsScratch(T, (1, np.asarray(im).shape[1]), (1, np.asarray(im).shape[0]))
+            for T, im in zip(tforms, images)]
+    xMin, xMax = min(l[0][0] for l in lims), max(l[0][1] for l in lims)
+    yMin, yMax = min(l[1][0] for l in lims), max(l[1][1] for l in lims)
+    width, height = int(_matlab_round(xMax - xMin)), int(_matlab_round(yMax - yMin))
+    if width < 1 or height < 1:
+        raise ValueError("degenerate planar canvas")
+    view = imref2dScratch((height, width), (xMin, xMax), (yMin, yMax))
+    Iw, Ww, _, _, _ = pureNonRotationalImagesToCanvas(images, tforms, view, warpWeights(images), o)
+    if gains is not None:
+        Iw = [I * np.asarray(g, np.float32).reshape(1, 1, -1) for I, g in zip(Iw, gains)]
+    mode = str(o["blending"]).lower()
+    if mode == "none":
+        Wst = np.stack(Ww, 2)
+        idx = np.argmax(Wst, 2)  # first maximum, like MATLAB's max
+        pano = np.take_along_axis(np.stack(Iw, 3), idx[:, :, None, None], 3)[..., 0]
+    elif mode == "linear":
+        pano = linearBlending(Iw, Ww)
+    elif mode == "multiband":
+        pano = multiBandBlending(Iw, Ww, int(o["pyrLevels"]), True, float(o["pyrSigma"]))
+    else:
+        raise ValueError("Wrong blening mode.")
+    pano = np.array(pano, np.float32, copy=True)
+    void = ~(np.stack(Ww, 2) > 0).any(2)
+    pano[void] = 1.0 if str(o["canvasColor"]).lower() == "white" else 0.0
+    v = 255.0 * pano.astype(np.float64)
+    out = np.sign(v) * np.floor(np.abs(v) + 0.5)  # MATLAB round
+    return np.clip(out, 0, 255).astype(np.uint8), None
+
+
 def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gains=None,
                    return_covered=False, device_out=False, tile_subset=None):
     """[panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts)
@@ -270,7 +362,9 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
       * gain compensation stays on the host (north star): pass `gains` (N x 3) or ones are used.
       * annotations (insertShape/insertText) are not produced: rgbAnnotation is always None."""
     if cameras and (cameras[0].get("noRotation", 0) == 1 or input.get("forcePlanarScan", False)):
-        raise NotImplementedError("planar-scan path (pureNonRotationalPanoramas) is served by imageWarp + blending")
+        # renderPanorama.m:78-90: planar scans bypass the tiled ray renderer
+        pano, ann = pureNonRotationalPanoramas(images, cameras, len(images), opts or {}, gains)
+        return (pano, ann, None, None) if return_covered else (pano, ann)
     o = default_opts(opts, cameras, refIdx)
     imgSize = [tuple(int(v) for v in s) for s in imgSize]
     geo = canvas_geometry(cameras, imgSize, mode, refIdx, o)

@@ -164,6 +164,45 @@ def test_footprint_culling_changes_no_bit(rp, monkeypatch, blending, mode):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("blending", ["multiband", "linear", "none"])
+def test_planar_scan_compositing_matches_oracle_pieces(rp, ip, blending):
+    """pureNonRotationalPanoramas (renderPanorama.m:519-699): canvas from the H2refined corner maps, every image
+    and its tent map warped to the full canvas, whole-canvas blend.  Every step is bit-exact against the oracle's
+    pieces, so the final uint8 canvas must be identical."""
+    rng = np.random.default_rng(21)
+    imgs = [rng.integers(0, 256, (60, 90, 3), dtype=np.uint8) for _ in range(3)]
+    Hs = [np.eye(3), np.array([[1.0, 0.01, 55.0], [-0.01, 1.0, 4.0], [1e-5, 0, 1.0]]),
+          np.array([[0.98, 0.0, 108.5], [0.02, 1.01, -6.0], [0, 2e-5, 1.0]])]
+    cams = [{"H2refined": H, "noRotation": 1} for H in Hs]
+    opts = {"blending": blending, "pyrLevels": 3, "pyrSigma": 1.0, "canvasColor": "white"}
+    pano, ann = rp.renderPanorama({"forcePlanarScan": True}, imgs, [(60, 90, 3)] * 3, cams, "planar", 0, opts)
+    # restatement from oracle pieces
+    lims = [ip.outputLimitsScratch(H, (1, 90), (1, 60)) for H in Hs]
+    xMin, xMax = min(l[0][0] for l in lims), max(l[0][1] for l in lims)
+    yMin, yMax = min(l[1][0] for l in lims), max(l[1][1] for l in lims)
+    width, height = int(np.floor(xMax - xMin + 0.5)), int(np.floor(yMax - yMin + 0.5))
+    assert pano.shape == (height, width, 3) and ann is None
+    sx, sy = (xMax - xMin) / width, (yMax - yMin) / height
+    Iw, Ww = [], []
+    for im, H in zip(imgs, Hs):
+        Iw.append(oracle.image_warp_h(im.astype(np.float32) / 255.0, H, height, width, xMin, yMin, sx, sy, 0.0))
+        tent = np.outer(oracle.tent(60), oracle.tent(90)).astype(np.float32)
+        Ww.append(np.clip(oracle.image_warp_h(tent, H, height, width, xMin, yMin, sx, sy, 0.0), 0, 1))
+    assert all(np.array_equal(a, b) for a, b in zip(rp.warpWeights(imgs), [np.outer(oracle.tent(60), oracle.tent(90)).astype(np.float32)] * 3))
+    C, W = np.stack(Iw), np.stack(Ww)
+    if blending == "multiband":
+        F = oracle.multiband_blend(C, W, 3, 1.0)
+    elif blending == "linear":
+        F = oracle.linear_blend(C, W)
+    else:
+        F = np.take_along_axis(np.moveaxis(C, 0, 3), np.argmax(W, 0)[:, :, None, None], 3)[..., 0]
+    F = np.array(F, np.float32)
+    F[~(W > 0).any(0)] = 1.0
+    ref = np.clip(np.floor(255.0 * F.astype(np.float64) + 0.5), 0, 255).astype(np.uint8)
+    assert (W > 0).any(0).mean() > 0.5
+    assert np.array_equal(pano, ref)
+
+
 def test_canvas_geometry_and_crop(rp):
     rng = np.random.default_rng(6)
     imgs, cams = _scene(rng)
