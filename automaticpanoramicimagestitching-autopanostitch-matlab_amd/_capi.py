@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaps_hip.so")
 APS_OK, APS_E_ARG, APS_E_DIM, APS_E_TYPE, APS_E_OOM, APS_E_DEVICE, APS_E_INTERNAL, APS_E_CAP = (
     0, -1, -2, -3, -4, -5, -6, -7)
 APS_COLMAJOR, APS_ROWMAJOR = 0, 1
+APS_ROBUST_RANSAC, APS_ROBUST_MLESAC = 0, 1
 APS_TFORM_PROJECTIVE = 0
 APS_PROJ_CYLINDRICAL, APS_PROJ_SPHERICAL, APS_PROJ_PLANAR, APS_PROJ_STEREOGRAPHIC = 0, 1, 2, 3
 APS_BLEND_NONE, APS_BLEND_LINEAR, APS_BLEND_MULTIBAND = 0, 1, 2
@@ -46,7 +47,7 @@ class aps_match_opts(C.Structure):
 
 class aps_ransac_opts(C.Structure):
     _fields_ = [("max_distance", C.c_double), ("confidence", C.c_double), ("max_iter", C.c_int),
-                ("tform_type", C.c_int)]
+                ("tform_type", C.c_int), ("method", C.c_int)]
 
 
 class aps_image(C.Structure):

@@ -144,7 +144,7 @@ __device__ __forceinline__ double dlt_entry(int k, int half, double x, double y,
 }
 
 // From the filled Gram matrix to the denormalised H (:214-224).  Returns false if not finite.
-__device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, const Norm& n2, Mat3& H) {
+__device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, const Norm& n2, Mat3& H, int mlesac = 0) {
     for (int p = 0; p < 9; ++p)
         for (int q = 0; q < p; ++q) GE(p, q) = GE(q, p);
     jacobi9(sG, sV, lane);
@@ -167,9 +167,20 @@ __device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, cons
         M3(H, r, 1) = M3(M, r, 1) * n1.s;
         M3(H, r, 2) = (M3(M, r, 0) * n1.tx + M3(M, r, 1) * n1.ty) + M3(M, r, 2);
     }
+    if (mlesac) {  // denormalizeTform: tform ./ tform(end) (estimateTransformationMLESAC.m:713-714)
+        const double d = H.m[8];
+        for (int e = 0; e < 9; ++e) H.m[e] = H.m[e] / d;
+    }
     for (int e = 0; e < 9; ++e)
         if (!isfinite(H.m[e])) return false;
     return true;
+}
+
+// normalisation scale from the mean distance to the centroid: RANSAC 1/md (:592), MLESAC sqrt(2)/md guarded
+// against md == 0 (normalizePointsHartleyZisserman, estimateTransformationMLESAC.m:653-657)
+__device__ __forceinline__ double norm_scale(double md, int mlesac) {
+    if (!mlesac) return 1.0 / md;
+    return md > 0 ? sqrt(2.0) / md : 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                                                          int n_pairs,
                                                          const uint32_t* __restrict__ sample_idx,
                                                          int n_samples, double* __restrict__ Hs,
-                                                         uint8_t* __restrict__ valid) {
+                                                         uint8_t* __restrict__ valid, int mlesac) {
     extern __shared__ __attribute__((aligned(16))) double lds_fit[];
     double* sG = lds_fit;
     double* sV = lds_fit + 81 * 64;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                 const double dx = x1[k] - cx, dy = y1[k] - cy;
                 sd = sd + sqrt(dx * dx + dy * dy);
             }
-            n1.s = 1.0 / (sd / 4.0);
+            n1.s = norm_scale(sd / 4.0, mlesac);
             n1.tx = -n1.s * cx;
             n1.ty = -n1.s * cy;
         }
@@ -237,22 +248,25 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                 const double dx = x2[k] - cx, dy = y2[k] - cy;
                 sd = sd + sqrt(dx * dx + dy * dy);
             }
-            n2.s = 1.0 / (sd / 4.0);
+            n2.s = norm_scale(sd / 4.0, mlesac);
             n2.tx = -n2.s * cx;
             n2.ty = -n2.s * cy;
         }
         for (int a = 0; a < 9; ++a)
             for (int b = a; b < 9; ++b) GE(a, b) = 0.0;
-        for (int half = 0; half < 2; ++half)
-            for (int k = 0; k < 4; ++k) {
-                const double x = n1.s * x1[k] + n1.tx, y = n1.s * y1[k] + n1.ty;
-                const double u = n2.s * x2[k] + n2.tx, v = n2.s * y2[k] + n2.ty;
-                double a[9];
-                for (int e = 0; e < 9; ++e) a[e] = dlt_entry(e, half, x, y, u, v);
-                for (int pp = 0; pp < 9; ++pp)
-                    for (int qq = pp; qq < 9; ++qq) GE(pp, qq) = GE(pp, qq) + a[pp] * a[qq];
-            }
-        ok = gram_to_h(sG, sV, lane, n1, n2, H) && check_model(H);
+        // Gram sums in the reference's row order: RANSAC all "x" rows then all "y" rows (:209-212); MLESAC per
+        // point its "v" row then its "u" row (estimateTransformationMLESAC.m:368-373; a a' is sign-blind)
+        for (int step = 0; step < 8; ++step) {
+            const int half = mlesac ? 1 - (step & 1) : step >> 2;
+            const int k = mlesac ? step >> 1 : step & 3;
+            const double x = n1.s * x1[k] + n1.tx, y = n1.s * y1[k] + n1.ty;
+            const double u = n2.s * x2[k] + n2.tx, v = n2.s * y2[k] + n2.ty;
+            double a[9];
+            for (int e = 0; e < 9; ++e) a[e] = dlt_entry(e, half, x, y, u, v);
+            for (int pp = 0; pp < 9; ++pp)
+                for (int qq = pp; qq < 9; ++qq) GE(pp, qq) = GE(pp, qq) + a[pp] * a[qq];
+        }
+        ok = gram_to_h(sG, sV, lane, n1, n2, H, mlesac) && (mlesac || check_model(H));
     }
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
     valid[gid] = ok ? 1 : 0;
@@ -332,6 +346,62 @@ __device__ int wave_find_inliers(const Mat3& H, const double* __restrict__ x1,
     return n;
 }
 
+// MLESAC evaluateModel (estimateTransformationMLESAC.m:258-295, :534-562): one-way distance of H*x1 to x2,
+// truncated at thr; returns the sum of the truncated distances (wave order), *n_inl = #(d < thr).
+__device__ __forceinline__ double oneway_dist(const Mat3& H, double x1, double y1, double x2, double y2) {
+    const double X = (M3(H, 0, 0) * x1 + M3(H, 0, 1) * y1) + M3(H, 0, 2);
+    const double Y = (M3(H, 1, 0) * x1 + M3(H, 1, 1) * y1) + M3(H, 1, 2);
+    const double W = (M3(H, 2, 0) * x1 + M3(H, 2, 1) * y1) + M3(H, 2, 2);
+    const double dx = X / W - x2, dy = Y / W - y2;
+    double d = sqrt(dx * dx + dy * dy);
+    if (fabs(W) < kDblEps) d = INFINITY;
+    return d;
+}
+__device__ double wave_mlesac_eval(const Mat3& H, const double* __restrict__ x1, const double* __restrict__ y1,
+                                   const double* __restrict__ x2, const double* __restrict__ y2, int64_t m, double thr,
+                                   uint8_t* __restrict__ mask, int* n_inl) {
+    const int lane = threadIdx.x & 63;
+    double ps = 0, pc = 0;
+    for (int64_t i = lane; i < m; i += 64) {
+        double d = oneway_dist(H, x1[i], y1[i], x2[i], y2[i]);
+        if (d > thr) d = thr;  // NaN stays NaN
+        const bool in = d < thr;
+        if (mask) mask[i] = in ? 1 : 0;
+        ps = ps + d;
+        if (in) pc += 1.0;
+    }
+    *n_inl = (int)wave_sum(pc);
+    return wave_sum(ps);
+}
+
+__global__ __launch_bounds__(256) void mlesac_score_kernel(
+    const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
+    const int64_t* __restrict__ pair_ptr, int n_pairs, int n_samples, const double* __restrict__ Hs,
+    const uint8_t* __restrict__ valid, double thr, int32_t* __restrict__ n_inl, double* __restrict__ acc_dis) {
+    const int64_t gid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (gid >= (int64_t)n_pairs * n_samples) return;
+    const int lane = threadIdx.x & 63;
+    if (!valid[gid]) {
+        if (lane == 0) {
+            n_inl[gid] = 0;
+            acc_dis[gid] = NAN;
+        }
+        return;
+    }
+    const int p = (int)(gid / n_samples);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = Hs[gid * 9 + e];
+    int n;
+    const double acc = wave_mlesac_eval(H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr, nullptr, &n);
+    if (lane == 0) {
+        n_inl[gid] = n;
+        acc_dis[gid] = acc;
+    }
+}
+
 // one wave per (pair, draw); 4 waves per block
 __global__ __launch_bounds__(256) void ransac_score_kernel(
     const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
@@ -390,7 +460,7 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     const int64_t* __restrict__ pair_ptr, int n_samples, const double* __restrict__ Hs,
     const int32_t* __restrict__ best_it, double thr, double* __restrict__ models,
     uint8_t* __restrict__ mask, uint8_t* __restrict__ scratch_mask, int32_t* __restrict__ found,
-    int32_t* __restrict__ n_final) {
+    int32_t* __restrict__ n_final, int mlesac) {
     extern __shared__ __attribute__((aligned(16))) double lds_fin[];
     double* sG = lds_fin;
     double* sV = lds_fin + 81 * 64;
@@ -414,7 +484,21 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     Mat3 Hb;
     for (int e = 0; e < 9; ++e) Hb.m[e] = Hs[((int64_t)p * n_samples + bi) * 9 + e];
     double me;
-    const int nb = wave_find_inliers(Hb, x1, y1, x2, y2, m, thr, out_mask, &me);
+    int nb;
+    if (mlesac) {
+        (void)wave_mlesac_eval(Hb, x1, y1, x2, y2, m, thr, out_mask, &nb);
+        if (nb < 4) {  // isFound needs sum(bestInliers) >= sampleSize (estimateTransformationMLESAC.m:213-214)
+            for (int64_t i = lane; i < m; i += 64) out_mask[i] = 0;
+            if (lane < 9) models[(int64_t)p * 9 + lane] = NAN;
+            if (lane == 0) {
+                found[p] = 0;
+                n_final[p] = 0;
+            }
+            return;
+        }
+    } else {
+        nb = wave_find_inliers(Hb, x1, y1, x2, y2, m, thr, out_mask, &me);
+    }
     __threadfence_block();
     // refit on the inliers: sums in ascending index order, identical in every lane (uniform branches)
     Norm n1, n2;
@@ -437,10 +521,10 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
                 const double bx = x2[i] - dx2, by = y2[i] - dy2;
                 ud = ud + sqrt(bx * bx + by * by);
             }
-        n1.s = 1.0 / (sd / dn);
+        n1.s = norm_scale(sd / dn, mlesac);
         n1.tx = -n1.s * cx;
         n1.ty = -n1.s * cy;
-        n2.s = 1.0 / (ud / dn);
+        n2.s = norm_scale(ud / dn, mlesac);
         n2.tx = -n2.s * dx2;
         n2.ty = -n2.s * dy2;
     }
@@ -456,19 +540,29 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         qq = row + e;
     }
     double g = 0;
-    for (int half = 0; half < 2; ++half)
+    if (mlesac) {  // per inlier: its "v" row, then its "u" row
         for (int64_t i = 0; i < m; ++i)
             if (out_mask[i]) {
                 const double x = n1.s * x1[i] + n1.tx, y = n1.s * y1[i] + n1.ty;
                 const double u = n2.s * x2[i] + n2.tx, v = n2.s * y2[i] + n2.ty;
-                g = g + dlt_entry(pp, half, x, y, u, v) * dlt_entry(qq, half, x, y, u, v);
+                g = g + dlt_entry(pp, 1, x, y, u, v) * dlt_entry(qq, 1, x, y, u, v);
+                g = g + dlt_entry(pp, 0, x, y, u, v) * dlt_entry(qq, 0, x, y, u, v);
             }
+    } else {
+        for (int half = 0; half < 2; ++half)
+            for (int64_t i = 0; i < m; ++i)
+                if (out_mask[i]) {
+                    const double x = n1.s * x1[i] + n1.tx, y = n1.s * y1[i] + n1.ty;
+                    const double u = n2.s * x2[i] + n2.tx, v = n2.s * y2[i] + n2.ty;
+                    g = g + dlt_entry(pp, half, x, y, u, v) * dlt_entry(qq, half, x, y, u, v);
+                }
+    }
     if (lane < 45) sG[(pp * 9 + qq) * 64 + 0] = g;  // lane 0's column of the work matrix
     __syncthreads();
     Mat3 Hr;
     int ok = 0;
     if (lane == 0) {
-        ok = gram_to_h(sG, sV, 0, n1, n2, Hr) && check_model(Hr) ? 1 : 0;
+        ok = gram_to_h(sG, sV, 0, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr)) ? 1 : 0;
         for (int e = 0; e < 9; ++e) sV[e * 64 + 1] = Hr.m[e];  // broadcast through a free LDS column
         sV[9 * 64 + 1] = (double)ok;
     }
@@ -477,7 +571,20 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     ok = sV[9 * 64 + 1] != 0.0;
     bool use_refit = false;
     int nr = 0;
-    if (ok) {
+    if (mlesac) {  // :216-236: the refit is the answer; invalid or no inlier left -> not found
+        if (ok) (void)wave_mlesac_eval(Hr, x1, y1, x2, y2, m, thr, tmp_mask, &nr);
+        if (!ok || nr < 1) {
+            __threadfence_block();
+            for (int64_t i = lane; i < m; i += 64) out_mask[i] = 0;
+            if (lane < 9) models[(int64_t)p * 9 + lane] = NAN;
+            if (lane == 0) {
+                found[p] = 0;
+                n_final[p] = 0;
+            }
+            return;
+        }
+        use_refit = true;
+    } else if (ok) {
         nr = wave_find_inliers(Hr, x1, y1, x2, y2, m, thr, tmp_mask, &me);
         use_refit = nr >= 4;
     }
@@ -547,6 +654,7 @@ __global__ void draw_samples_kernel(const int64_t* __restrict__ counts, const un
 static void check_opts(const aps_ransac_opts& o) {
     APS_REQUIRE(o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
                 "only transformationType 'projective' is built (inputs.m:74)");
+    APS_REQUIRE(o.method == APS_ROBUST_RANSAC || o.method == APS_ROBUST_MLESAC, APS_E_ARG, "unknown robust estimator %d", o.method);
     APS_REQUIRE(o.max_iter > 0, APS_E_ARG, "maxIter must be positive");
     APS_REQUIRE(o.max_distance > 0, APS_E_ARG, "maxDistance must be positive");
     APS_REQUIRE(o.confidence > 0 && o.confidence < 100, APS_E_ARG, "inliersConfidence must be in (0,100)");
@@ -591,12 +699,50 @@ static int replay_loop(const uint8_t* valid, const int32_t* n_inl, const double*
     return best_it;
 }
 
+// vision.internal.ransac.computeLoopNumber restated (toolbox-internal, unpinned): sample size 4
+static int mlesac_loop_number(double confidence, int64_t num_pts, int inlier_num) {
+    const double pr = std::pow((double)inlier_num / (double)num_pts, 4.0);
+    if (pr < 2.220446049250313e-16) return 2147483647;
+    const double n = std::ceil(std::log10(1.0 - 0.01 * confidence) / std::log10(1.0 - pr));
+    if (!(n < 2147483647.0)) return 2147483647;
+    return n < 0 ? 0 : (int)n;
+}
+
+// The sequential part of mlesac() (estimateTransformationMLESAC.m:157-211) over pre-scored draws
+static int replay_mlesac(const uint8_t* valid, const int32_t* n_inl, const double* acc_dis, int n_samples, int64_t m,
+                         const aps_ransac_opts& o, int* trials_used) {
+    if (m < 4) {
+        if (trials_used) *trials_used = 0;
+        return -1;
+    }
+    int num_trials = o.max_iter;
+    const int max_skip = 10000;  // setDefaultParams: maxIterations (1000) * 10; the caller cannot override it (:72)
+    int idx = 1, skip = 0, it = 0, best_it = -1;
+    double best_dis = o.max_distance * (double)m;
+    while (idx <= num_trials && skip < max_skip && it < n_samples) {
+        const int cur = it++;
+        if (!valid[cur]) {
+            ++skip;
+            continue;
+        }
+        if (acc_dis[cur] < best_dis) {
+            best_dis = acc_dis[cur];
+            best_it = cur;
+            num_trials = std::min(num_trials, mlesac_loop_number(o.confidence, m, n_inl[cur]));
+        }
+        ++idx;
+    }
+    if (trials_used) *trials_used = it;
+    return best_it;
+}
+
 static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                          const std::vector<int64_t>& h_ptr, const uint32_t* d_samples, int n_samples,
                          const aps_ransac_opts& o, double* d_models, uint8_t* d_mask, int32_t* d_found,
                          int32_t* d_ninl, std::vector<int>* trials_out) {
     const int n_pairs = (int)h_ptr.size() - 1;
     if (n_pairs <= 0) return;
+    const int mlesac = o.method == APS_ROBUST_MLESAC ? 1 : 0;
     const int64_t total_rows = h_ptr.back();
     const int64_t nh = (int64_t)n_pairs * n_samples;
     Ws<int64_t> d_ptr(n_pairs + 1);
@@ -617,13 +763,17 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     {
         Prof prof("ransac_fit");
     ransac_fit_kernel<<<cdiv(nh, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs,
-                                                                  d_samples, n_samples, Hs, valid);
+                                                                  d_samples, n_samples, Hs, valid, mlesac);
     }
     check_launch("ransac_fit_kernel");
     {
         Prof prof("ransac_score");
-    ransac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples,
-                                                            Hs, valid, o.max_distance, ninl, merr);
+    if (mlesac)
+        mlesac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples, Hs, valid,
+                                                                o.max_distance, ninl, merr);
+    else
+        ransac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples,
+                                                                Hs, valid, o.max_distance, ninl, merr);
     }
     check_launch("ransac_score_kernel");
     std::vector<uint8_t> h_valid(nh);
@@ -636,10 +786,10 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     if (trials_out) trials_out->assign(n_pairs, 0);
     for (int p = 0; p < n_pairs; ++p) {
         int used = 0;
-        h_best[p] = replay_loop(h_valid.data() + (int64_t)p * n_samples,
-                                h_ninl.data() + (int64_t)p * n_samples,
-                                h_merr.data() + (int64_t)p * n_samples, n_samples,
-                                h_ptr[p + 1] - h_ptr[p], o, &used);
+        h_best[p] = (mlesac ? replay_mlesac : replay_loop)(h_valid.data() + (int64_t)p * n_samples,
+                                                           h_ninl.data() + (int64_t)p * n_samples,
+                                                           h_merr.data() + (int64_t)p * n_samples, n_samples,
+                                                           h_ptr[p + 1] - h_ptr[p], o, &used);
         if (trials_out) (*trials_out)[p] = used;
     }
     APS_HIP(hipMemcpyAsync(best, h_best.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice,
@@ -648,7 +798,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         Prof prof("ransac_finalize");
     ransac_finalize_kernel<<<n_pairs, 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
                                                                   best, o.max_distance, d_models,
-                                                                  d_mask, scratch, d_found, d_ninl);
+                                                                  d_mask, scratch, d_found, d_ninl, mlesac);
     }
     check_launch("ransac_finalize_kernel");
     APS_HIP(hipStreamSynchronize(stream()));

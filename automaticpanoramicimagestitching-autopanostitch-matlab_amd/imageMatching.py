@@ -79,12 +79,18 @@ def draw_samples_device(counts, n_samples, seed=0, keys=None):
     return out
 
 
-def _ransac_opts(input):
+def _ransac_opts(input, method=None):
+    """aps_ransac_opts from the reference's `input` struct.  method: 'ransac' | 'mlesac' (default:
+    input.imageMatchingMethod, inputs.m:66); MLESAC's own defaults are maxDistance 2, 1000 trials (:740-765)."""
+    method = str(method if method is not None else input.get("imageMatchingMethod", "ransac")).lower()
+    if method not in ("ransac", "mlesac"):
+        raise ValueError(f"unknown imageMatchingMethod '{method}'")
     o = _capi.aps_ransac_opts()
     o.max_distance = float(input.get("maxDistance", 2.0))
     o.confidence = float(input.get("inliersConfidence", 99.9))
-    o.max_iter = int(input.get("maxIter", 500))
+    o.max_iter = int(input.get("maxIter", 1000 if method == "mlesac" else 500))
     o.tform_type = _capi.APS_TFORM_PROJECTIVE
+    o.method = _capi.APS_ROBUST_MLESAC if method == "mlesac" else _capi.APS_ROBUST_RANSAC
     return o
 
 
@@ -95,14 +101,9 @@ def _check_type(transformType):
                          "only transformationType 'projective' runs on the device path (inputs.m:74)")
 
 
-def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, input=None,
-                                 sample_idx=None, seed=0):
-    """[model, inliers, isFound] = estimateTransformationRANSAC(matchedPoints1, matchedPoints2,
-    transformType, input) (estimateTransformationRANSAC.m:1-183).
-
-    model maps matchedPoints1 -> matchedPoints2.  Returns (3x3 float64 or None, bool[M], bool)."""
+def _estimate_robust(matchedPoints1, matchedPoints2, transformType, input, sample_idx, seed, method):
     _check_type(transformType)
-    input = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 500} if input is None else input
+    input = {} if input is None else input
     p1 = np.asfortranarray(np.asarray(matchedPoints1, np.float64))
     p2 = np.asfortranarray(np.asarray(matchedPoints2, np.float64))
     if p1.ndim != 2 or p1.shape[1] != 2 or p2.ndim != 2 or p2.shape[1] != 2:
@@ -112,7 +113,7 @@ def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, 
     m = p1.shape[0]
     if m < 4:  # :71-76
         return None, np.zeros(m, bool), False
-    o = _ransac_opts(input)
+    o = _ransac_opts(input, method)
     if sample_idx is None:
         sample_idx = draw_samples([m], o.max_iter + 64, seed)[0]
     s = np.ascontiguousarray(sample_idx, np.uint32)
@@ -125,6 +126,25 @@ def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, 
     if not found.value:
         return None, mask.astype(bool), False
     return model.reshape(3, 3).T.copy(), mask.astype(bool), True
+
+
+def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, input=None,
+                                 sample_idx=None, seed=0):
+    """[model, inliers, isFound] = estimateTransformationRANSAC(matchedPoints1, matchedPoints2,
+    transformType, input) (estimateTransformationRANSAC.m:1-183).
+
+    model maps matchedPoints1 -> matchedPoints2.  Returns (3x3 float64 or None, bool[M], bool)."""
+    if input is None:
+        input = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 500}
+    return _estimate_robust(matchedPoints1, matchedPoints2, transformType, input, sample_idx, seed, "ransac")
+
+
+def estimateTransformationMLESAC(points1, points2, transformationType, input=None, sample_idx=None, seed=0):
+    """[tform, inlierIdx, isFound] = estimateTransformationMLESAC(points1, points2, transformationType, input)
+    (estimateTransformationMLESAC.m:1-254): truncated-loss consensus on the one-way reprojection distance,
+    the refit on the best model's inliers is the answer.  'projective' on the device; draws are explicit
+    (sample_idx, uint32 n x 4, 1-based) or seeded.  Returns (3x3 float64 or None, bool[M], bool)."""
+    return _estimate_robust(points1, points2, transformationType, input, sample_idx, seed, "mlesac")
 
 
 def ransac_score(Hs, p1, p2, thr):

@@ -178,11 +178,16 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
                      int64_t ldp, double thr, int tform_type, int32_t* n_inl, double* mean_err,
                      uint8_t* mask);
 
+enum { APS_ROBUST_RANSAC = 0, APS_ROBUST_MLESAC = 1 };
+
 typedef struct aps_ransac_opts {
     double max_distance; /* input.maxDistance        (inputs.m:69: 5.5)  */
     double confidence;   /* input.inliersConfidence  (inputs.m:72: 99.9) */
     int max_iter;        /* input.maxIter            (inputs.m:68: 500)  */
     int tform_type;      /* APS_TFORM_PROJECTIVE                          */
+    int method;          /* APS_ROBUST_RANSAC: estimateTransformationRANSAC.m (input.imageMatchingMethod 'ransac');
+                            APS_ROBUST_MLESAC: estimateTransformationMLESAC.m:94-254 ('mlesac'): one-way distance,
+                            truncated-loss score, refit on the inliers is the answer                */
 } aps_ransac_opts;
 
 /* a12 whole loop: [model, inliers, isFound] = estimateTransformationRANSAC(p1, p2, 'projective', input)

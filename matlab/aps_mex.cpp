@@ -174,16 +174,17 @@ static void cmd_hamming(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs
     if (nlhs > 2) plhs[2] = d2; else mxDestroyArray(d2);
 }
 
-// [model, inliers, isFound] = aps_mex('ransac_homography', p1 Mx2, p2 Mx2, input, sampleIdx uint32 4xS)
-static void cmd_ransac(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+// [model, inliers, isFound] = aps_mex('ransac_homography' | 'mlesac_homography', p1 Mx2, p2 Mx2, input, sampleIdx uint32 4xS)
+static void cmd_ransac(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[], bool mlesac) {
     need(nrhs == 5 && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsUint32(prhs[4]), "aps:type", "usage: p1, p2 double Mx2; sampleIdx uint32 4xS");
     const int64_t m = mxGetM(prhs[1]);
     need(mxGetM(prhs[2]) == (mwSize)m, "aps:dim", "matchedPoints1 and matchedPoints2 must have the same number of rows.");
     aps_ransac_opts o;
     o.max_distance = field(prhs[3], "maxDistance", 2.0);
     o.confidence = field(prhs[3], "inliersConfidence", 99.9);
-    o.max_iter = (int)field(prhs[3], "maxIter", 500);
+    o.max_iter = (int)field(prhs[3], "maxIter", mlesac ? 1000 : 500);
     o.tform_type = APS_TFORM_PROJECTIVE;
+    o.method = mlesac ? APS_ROBUST_MLESAC : APS_ROBUST_RANSAC;
     plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
     std::vector<uint8_t> mask(m ? m : 1);
     int found = 0;
@@ -287,7 +288,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "match_pairwise") cmd_pairwise(nlhs, plhs, nrhs, prhs);
     else if (cmd == "knn_global") cmd_knn(nlhs, plhs, nrhs, prhs);
     else if (cmd == "hamming_2nn") cmd_hamming(nlhs, plhs, nrhs, prhs);
-    else if (cmd == "ransac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "ransac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, false);
+    else if (cmd == "mlesac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, true);
     else if (cmd == "multiband_blend") cmd_blend(true, nlhs, plhs, nrhs, prhs);
     else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);

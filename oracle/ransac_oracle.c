@@ -353,3 +353,192 @@ ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m
     free(cur);
     free(best_mask);
 }
+
+/* ================================================================================================
+ * MLESAC (PP/imageMatching/estimateTransformationMLESAC.m, projective).  PARITY UNPINNED, like RANSAC
+ * above, plus: vision.internal.ransac.computeLoopNumber (:201) is toolbox-internal; it is restated as
+ * N = ceil(log10(1 - 0.01*confidence) / log10(1 - (inliers/points)^4)), intmax when the power is < eps.
+ * Fixed here and mirrored by the HIP path:
+ *   - draws are an INPUT (one column per iteration of :157-211);
+ *   - estimateHomography (:345-387): Hartley-Zisserman normalisation scale sqrt(2)/meanDist (:653-657),
+ *     Gram sums of the DLT rows in the reference's row order (per point: the "v" row, then the "u" row),
+ *     null vector by the same cyclic Jacobi, T = (N2 \ (Hn / Hn(3,3))) * N1, then T ./ T(end) (:713-714);
+ *   - evaluateTransform2d (:534-562): hypot is evaluated as sqrt(dx*dx + dy*dy); |w| < eps -> inf;
+ *   - sum(dis) after truncation (:283-285) in wave order.
+ * ================================================================================================ */
+static void normalize_sel_hz(const double* x, const double* y, const int64_t* sel, int64_t n,
+                             double* scale, double* tx, double* ty) {
+    double sx = 0, sy = 0;
+    for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    const double cx = sx / (double)n, cy = sy / (double)n;
+    double sd = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+        sd = sd + sqrt(dx * dx + dy * dy);
+    }
+    const double md = sd / (double)n;
+    const double s = md > 0 ? sqrt(2.0) / md : 1.0;
+    *scale = s;
+    *tx = -s * cx;
+    *ty = -s * cy;
+}
+
+static int fit_homography_mlesac(const double* x1, const double* y1, const double* x2, const double* y2,
+                                 const int64_t* sel, int64_t n, double* H) {
+    double s1, t1x, t1y, s2, t2x, t2y;
+    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y);
+    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y);
+    double G[81];
+    for (int e = 0; e < 81; ++e) G[e] = 0;
+    for (int64_t e = 0; e < n; ++e)
+        for (int half = 1; half >= 0; --half) { /* rows 2i-1 (v) and 2i (u) of :368-373; a a' is sign-blind */
+            const double x = s1 * x1[sel[e]] + t1x, y = s1 * y1[sel[e]] + t1y;
+            const double u = s2 * x2[sel[e]] + t2x, v = s2 * y2[sel[e]] + t2y;
+            double a[9];
+            if (half == 0) {
+                a[0] = -x; a[1] = -y; a[2] = -1; a[3] = 0; a[4] = 0; a[5] = 0;
+                a[6] = x * u; a[7] = y * u; a[8] = u;
+            } else {
+                a[0] = 0; a[1] = 0; a[2] = 0; a[3] = -x; a[4] = -y; a[5] = -1;
+                a[6] = x * v; a[7] = y * v; a[8] = v;
+            }
+            for (int p = 0; p < 9; ++p)
+                for (int q = p; q < 9; ++q) G[9 * p + q] = G[9 * p + q] + a[p] * a[q];
+        }
+    for (int p = 0; p < 9; ++p)
+        for (int q = 0; q < p; ++q) G[9 * p + q] = G[9 * q + p];
+    double V[81];
+    jacobi9(G, V);
+    int kmin = 0;
+    for (int k = 1; k < 9; ++k)
+        if (G[9 * k + k] < G[9 * kmin + kmin]) kmin = k;
+    double h[9];
+    for (int k = 0; k < 9; ++k) h[k] = V[9 * k + kmin];
+    double Hn[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Hn[r + 3 * c] = h[3 * r + c] / h[8];
+    double M[9];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Hn[2 + 3 * c];
+        M[2 + 3 * c] = m2;
+        M[1 + 3 * c] = (Hn[1 + 3 * c] - t2y * m2) / s2;
+        M[0 + 3 * c] = (Hn[0 + 3 * c] - t2x * m2) / s2;
+    }
+    double T[9];
+    for (int r = 0; r < 3; ++r) {
+        T[r + 3 * 0] = M[r + 3 * 0] * s1;
+        T[r + 3 * 1] = M[r + 3 * 1] * s1;
+        T[r + 3 * 2] = (M[r + 3 * 0] * t1x + M[r + 3 * 1] * t1y) + M[r + 3 * 2];
+    }
+    for (int e = 0; e < 9; ++e) H[e] = T[e] / T[8];
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0; /* checkTForm (:721-738) */
+    return 1;
+}
+
+static double oneway_dist(const double* H, double x1, double y1, double x2, double y2) {
+    const double X = (H_(0, 0) * x1 + H_(0, 1) * y1) + H_(0, 2);
+    const double Y = (H_(1, 0) * x1 + H_(1, 1) * y1) + H_(1, 2);
+    const double W = (H_(2, 0) * x1 + H_(2, 1) * y1) + H_(2, 2);
+    const double dx = X / W - x2, dy = Y / W - y2;
+    double d = sqrt(dx * dx + dy * dy);
+    if (fabs(W) < DBL_EPS) d = INFINITY;
+    return d;
+}
+
+/* evaluateModel (:258-295): truncated distances, their sum (wave order) and the inlier count */
+static double mlesac_eval(const double* H, const double* x1, const double* y1, const double* x2,
+                          const double* y2, int64_t m, double thr, uint8_t* mask, int* n_inl) {
+    double ps[64], pc[64];
+    for (int l = 0; l < 64; ++l) ps[l] = pc[l] = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        double d = oneway_dist(H, x1[i], y1[i], x2[i], y2[i]);
+        if (d > thr) d = thr; /* NaN stays NaN and poisons the sum, as in MATLAB */
+        const int in = d < thr;
+        if (mask) mask[i] = (uint8_t)in;
+        const int l = (int)(i & 63);
+        ps[l] = ps[l] + d;
+        if (in) pc[l] += 1.0;
+    }
+    *n_inl = (int)wave_reduce(pc);
+    return wave_reduce(ps);
+}
+
+static int mlesac_loop_number(double confidence, int64_t num_pts, int inlier_num) {
+    const double pr = pow((double)inlier_num / (double)num_pts, 4.0);
+    if (pr < DBL_EPS) return 2147483647;
+    const double num = log10(1.0 - 0.01 * confidence), den = log10(1.0 - pr);
+    const double n = ceil(num / den);
+    if (!(n < 2147483647.0)) return 2147483647;
+    return n < 0 ? 0 : (int)n;
+}
+
+ORC_API double orc_mlesac_eval(const double* H, const double* p1, const double* p2, int64_t m, int64_t ldp,
+                               double thr, uint8_t* mask, int* n_inl) {
+    return mlesac_eval(H, p1, p1 + ldp, p2, p2 + ldp, m, thr, mask, n_inl);
+}
+
+ORC_API int orc_fit_homography_mlesac(const double* p1, const double* p2, int64_t ldp, const int64_t* sel,
+                                      int64_t n, double* H) {
+    return fit_homography_mlesac(p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+}
+
+ORC_API void orc_mlesac_homography(const double* p1, const double* p2, int64_t m, int64_t ldp,
+                                   const uint32_t* sample_idx, int n_samples, double max_distance,
+                                   double confidence, int max_num_trials, double* model,
+                                   uint8_t* inlier_mask, int* is_found, int* trials_used) {
+    const double *x1 = p1, *y1 = p1 + ldp, *x2 = p2, *y2 = p2 + ldp;
+    memset(inlier_mask, 0, (size_t)m);
+    for (int e = 0; e < 9; ++e) model[e] = NAN;
+    *is_found = 0;
+    if (trials_used) *trials_used = 0;
+    if (m < 4) return;
+    int num_trials = max_num_trials;
+    const int max_skip = 10000; /* setDefaultParams: maxIterations(1000) * 10, not overridable (:72) */
+    int idx = 1, skip = 0, it = 0, have_best = 0;
+    double best_dis = max_distance * (double)m, bestH[9];
+    uint8_t* cur = (uint8_t*)malloc((size_t)m);
+    uint8_t* best_mask = (uint8_t*)calloc((size_t)m, 1);
+    while (idx <= num_trials && skip < max_skip && it < n_samples) {
+        int64_t sel[4];
+        for (int k = 0; k < 4; ++k) sel[k] = (int64_t)sample_idx[4 * it + k] - 1;
+        ++it;
+        double H[9];
+        if (!fit_homography_mlesac(x1, y1, x2, y2, sel, 4, H)) {
+            ++skip;
+            continue;
+        }
+        int n;
+        const double acc = mlesac_eval(H, x1, y1, x2, y2, m, max_distance, cur, &n);
+        if (acc < best_dis) {
+            best_dis = acc;
+            have_best = 1;
+            memcpy(bestH, H, sizeof bestH);
+            memcpy(best_mask, cur, (size_t)m);
+            const int num = mlesac_loop_number(confidence, m, n);
+            if (num < num_trials) num_trials = num;
+        }
+        ++idx;
+    }
+    if (trials_used) *trials_used = it;
+    int64_t c = 0;
+    for (int64_t i = 0; i < m; ++i) c += best_mask[i];
+    if (have_best && c >= 4) { /* :216-241, recomputeModelFromInliers = true */
+        int64_t* sel = (int64_t*)malloc(sizeof(int64_t) * (size_t)c);
+        int64_t k = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (best_mask[i]) sel[k++] = i;
+        double R[9];
+        const int ok = fit_homography_mlesac(x1, y1, x2, y2, sel, c, R);
+        free(sel);
+        int n = 0;
+        if (ok) mlesac_eval(R, x1, y1, x2, y2, m, max_distance, cur, &n);
+        if (ok && n > 0) {
+            memcpy(model, R, sizeof R);
+            memcpy(inlier_mask, cur, (size_t)m);
+            *is_found = 1;
+        }
+    }
+    free(cur);
+    free(best_mask);
+}

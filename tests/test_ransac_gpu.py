@@ -127,3 +127,35 @@ def test_device_draws_equal_host_draws(im):
     dev = im.draw_samples_device(counts, 700, seed=11, keys=keys).cpu().numpy().astype(np.uint32)
     assert np.array_equal(host, dev)
     assert np.array_equal(im.draw_samples(counts, 64, seed=3), im.draw_samples_device(counts, 64, seed=3).cpu().numpy().astype(np.uint32))
+
+
+# ---- MLESAC --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,m,n_out", [(0, 300, 80), (1, 64, 10), (2, 1000, 600), (3, 5, 0)])
+def test_mlesac_bit_identical_to_oracle(gpu, seed, m, n_out):
+    from test_ransac_oracle import _mlesac_scene
+    im = import_module(gpu.__name__ + ".imageMatching")
+    _, p1, p2, samples = _mlesac_scene(seed, m, n_out)
+    inp = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 1000}
+    H, mask, found = im.estimateTransformationMLESAC(p1, p2, "projective", inp, sample_idx=samples)
+    oH, omask, ofound, _ = oracle.mlesac_homography(p1, p2, samples, 2.0, 99.9, 1000)
+    assert found == ofound and np.array_equal(mask, omask)
+    if found:
+        assert np.array_equal(H.view(np.uint64), oH.view(np.uint64))
+    else:
+        assert H is None
+
+
+def test_mlesac_degenerate_draws_and_method_switch(gpu):
+    from test_ransac_oracle import _mlesac_scene
+    im = import_module(gpu.__name__ + ".imageMatching")
+    _, p1, p2, samples = _mlesac_scene(4)
+    H, mask, found = im.estimateTransformationMLESAC(p1, p2, "projective", {}, sample_idx=np.ones((40, 4), np.uint32))
+    assert not found and H is None and not mask.any()
+    # the batched entry follows input.imageMatchingMethod (inputs.m:66)
+    inp = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 1000, "imageMatchingMethod": "mlesac"}
+    models, bmask, bfound, ninl = im.ransac_batch(p1, p2, np.array([0, len(p1)]), samples[None], inp)
+    oH, omask, ofound, _ = oracle.mlesac_homography(p1, p2, samples, 2.0, 99.9, 1000)
+    assert bool(bfound[0]) == ofound and np.array_equal(bmask.astype(bool), omask) and ninl[0] == omask.sum()
+    assert np.array_equal(models[0].view(np.uint64), oH.view(np.uint64))
+    with pytest.raises(ValueError):
+        im.estimateTransformationMLESAC(p1, p2, "affine", {})

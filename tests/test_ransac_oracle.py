@@ -104,3 +104,47 @@ def test_draw_samples_are_distinct_in_range_and_reproducible():
     assert np.array_equal(s, samples_for(7, 2000, seed=5))
     counts = np.bincount(s.reshape(-1), minlength=8)[1:]
     assert counts.min() > 0.8 * counts.mean()  # roughly uniform
+
+
+# ---- MLESAC (estimateTransformationMLESAC.m) ---------------------------------------------------------------
+def _mlesac_scene(seed=0, m=300, n_out=80, noise=0.3):
+    rng = np.random.default_rng(seed)
+    Ht = np.array([[1.02, 0.03, 12.0], [-0.02, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    p1 = rng.uniform(0, 500, (m, 2))
+    q = np.c_[p1, np.ones(m)] @ Ht.T
+    p2 = q[:, :2] / q[:, 2:]
+    p2[:n_out] += rng.uniform(-60, 60, (n_out, 2))
+    p2 += rng.normal(0, noise, p2.shape)
+    samples = np.stack([rng.choice(m, 4, replace=False) + 1 for _ in range(1200)]).astype(np.uint32)
+    return Ht, p1, p2, samples
+
+
+def test_mlesac_recovers_model_and_stops_adaptively():
+    Ht, p1, p2, samples = _mlesac_scene()
+    H, mask, found, used = oracle.mlesac_homography(p1, p2, samples, 2.0, 99.9, 1000)
+    assert found and mask[80:].mean() > 0.97 and mask[:80].mean() < 0.1
+    assert np.allclose(H[:, :2], Ht[:, :2], atol=2e-3) and np.allclose(H[:, 2], Ht[:, 2], atol=0.3) and H[2, 2] == 1.0
+    assert used < 200  # computeLoopNumber with ~73 % inliers needs a few dozen trials
+
+
+def test_mlesac_eval_is_truncated_one_way_loss():
+    Ht, p1, p2, _ = _mlesac_scene(seed=1)
+    acc, n, mask = oracle.mlesac_eval(Ht, p1, p2, 2.0)
+    q = np.c_[p1, np.ones(len(p1))] @ Ht.T
+    d = np.hypot(*(q[:, :2] / q[:, 2:] - p2).T)
+    assert n == int((d < 2.0).sum()) and np.array_equal(mask, d < 2.0)
+    assert abs(acc - np.minimum(d, 2.0).sum()) < 1e-9 * acc
+
+
+def test_mlesac_edge_cases():
+    Ht, p1, p2, samples = _mlesac_scene(seed=2)
+    H, mask, found, used = oracle.mlesac_homography(p1[:3], p2[:3], samples, 2.0, 99.9, 1000)
+    assert not found and used == 0 and not mask.any()
+    # all draws degenerate (repeated point): every fit is non-finite -> skipped -> nothing found
+    bad = np.ones((50, 4), np.uint32)
+    H, mask, found, used = oracle.mlesac_homography(p1, p2, bad, 2.0, 99.9, 1000)
+    assert not found and used == 50 and not mask.any()
+    # the HZ-normalised fit on 4 exact correspondences reproduces the homography
+    Hf, ok = oracle.fit_homography_mlesac(p1, (np.c_[p1, np.ones(len(p1))] @ Ht.T)[:, :2] /
+                                          (np.c_[p1, np.ones(len(p1))] @ Ht.T)[:, 2:], [0, 50, 120, 280])
+    assert ok and np.allclose(Hf, Ht, atol=1e-8)
