@@ -68,19 +68,145 @@ def nearest2SSDExhaustive(A, B):
     return np.arange(1, n1 + 1, dtype=np.float64), idx2, d1, d2
 
 
+def _normalize_like_reference(A, B):
+    """matchFeaturesScratch.m:105-110: both sets are L2-row-normalised (x ./ (||x|| + eps('single')), :232-233)
+    iff either has an entry above 2 in magnitude."""
+    A = np.asarray(A, np.float32)
+    B = np.asarray(B, np.float32)
+    if (A.size and np.abs(A).max() > 2) or (B.size and np.abs(B).max() > 2):
+        eps = np.float32(np.finfo(np.float32).eps)
+        A = A / (np.sqrt((A * A).sum(1, dtype=np.float32, keepdims=True)) + eps)
+        B = B / (np.sqrt((B * B).sum(1, dtype=np.float32, keepdims=True)) + eps)
+    return np.ascontiguousarray(A, np.float32), np.ascontiguousarray(B, np.float32)
+
+
+def _pad_dim(X):
+    """The device 2-NN kernel is built for 128-D rows; shorter rows are zero-padded (distances unchanged)."""
+    X = np.ascontiguousarray(X, np.float32)
+    if X.shape[1] == DIM:
+        return X
+    if X.shape[1] > DIM:
+        raise ValueError(f"descriptor length {X.shape[1]} > {DIM}")
+    out = np.zeros((X.shape[0], DIM), np.float32)
+    out[:, : X.shape[1]] = X
+    return out
+
+
+def nearest2KDTree(A, B, bucketSize=40):
+    """[idx1, idx2, d1, d2] = nearest2KDTree(A, B, bucketSize) (matchFeaturesScratch.m:411-440).  knnsearch on a
+    kd-tree is EXACT, so this is the exhaustive device search; d are Euclidean distances (the caller squares
+    them, :152-153).  bucketSize only shapes the reference's tree and has no effect on the result."""
+    idx1, idx2, d1, d2 = nearest2SSDExhaustive(_pad_dim(A), _pad_dim(B))
+    return idx1, idx2, np.sqrt(np.maximum(d1, 0)), np.sqrt(np.maximum(d2, 0))
+
+
+def nearest2SubsetPdist2(A, B, subset=12000, candB=None, seed=0):
+    """[idx1, idx2, d1, d2] = nearest2SubsetPdist2(A, B, subset) (matchFeaturesScratch.m:368-409): exact 2-NN
+    (Euclidean) against a random `subset`-row sample of B, indices mapped back into B.  The sample is an
+    explicit input here (candB, 1-based) or drawn from `seed`; the reference uses the unseeded randperm (:377)."""
+    B = np.asarray(B, np.float32)
+    n2 = B.shape[0]
+    subset = min(int(subset), n2)
+    if candB is None:
+        candB = np.random.default_rng(seed).permutation(n2)[:subset] + 1
+    candB = np.asarray(candB, np.int64).reshape(-1)
+    if candB.size != subset or candB.min() < 1 or candB.max() > n2 or np.unique(candB).size != subset:
+        raise ValueError("candB must hold `subset` distinct 1-based rows of B")
+    idx1, i2, d1, d2 = nearest2SSDExhaustive(_pad_dim(A), _pad_dim(B[candB - 1]))
+    e1, e2 = np.sqrt(np.maximum(d1, 0)), np.sqrt(np.maximum(d2, 0))
+    if subset == 1:  # :385-388: a second "neighbour" one ulp away
+        e2 = e1 + np.spacing(e1)
+    return idx1, candB[i2.astype(np.int64) - 1].astype(np.uint32), e1, e2
+
+
+def pca_coeff(Bc, k):
+    """pca(X, 'NumComponents', k) coefficients for centred X (toolbox, unpinned): eigenvectors of the covariance
+    by descending variance, each column signed so that its largest-magnitude entry is positive."""
+    cov = (Bc.astype(np.float64).T @ Bc.astype(np.float64)) / max(Bc.shape[0] - 1, 1)
+    w, V = np.linalg.eigh(cov)
+    V = V[:, np.argsort(-w, kind="stable")[:k]]
+    sgn = np.sign(V[np.abs(V).argmax(0), np.arange(V.shape[1])])
+    sgn[sgn == 0] = 1
+    return (V * sgn).astype(np.float32)
+
+
+def nearest2ApproxFloatFast(A, B, opts=None):
+    """[idx1, idx2, dBest, dSecond] = nearest2ApproxFloatFast(A, B, opts) (matchFeaturesScratch.m:442-573): PCA of B
+    to ApproxNumComponents (48) dimensions, both sets projected and L2-normalised, then the top two cosine
+    similarities per row, returned as d = 2 - 2*sim.  On unit rows that is the squared distance, so the top-2
+    search is the device's exhaustive SSD kernel on the projected, zero-padded rows (d = a2 + b2 - 2ab equals
+    2 - 2 sim up to the ulp-level deviation of a2, b2 from 1).  The PCA itself stays on the host."""
+    o = {"ApproxNumComponents": 48, "UsePCA": True}
+    o.update(opts or {})
+    A = np.asarray(A, np.float32)
+    B = np.asarray(B, np.float32)
+    k = int(o["ApproxNumComponents"])
+    if o["UsePCA"] and A.shape[1] > k:
+        mu = np.nanmean(B, 0, dtype=np.float32)
+        coeff = pca_coeff(B - mu, k)
+        B = (B - mu) @ coeff
+        A = (A - mu) @ coeff
+    eps = np.float32(np.finfo(np.float32).eps)
+    A = A / (np.sqrt((A * A).sum(1, dtype=np.float32, keepdims=True)) + eps)
+    B = B / (np.sqrt((B * B).sum(1, dtype=np.float32, keepdims=True)) + eps)
+    return nearest2SSDExhaustive(_pad_dim(A), _pad_dim(B))
+
+
+def filter_matches(idx2, dBest, dSecond, n2, MaxRatio, MatchThreshold, Unique):
+    """matchFeaturesScratch.m:170-211 on the host (used by the approximate back ends, whose 2-NN lists live on
+    the host): ratio on SSD (r^2), threshold, finiteness, greedy one-to-one by ascending distance (stable)."""
+    dBest = np.asarray(dBest, np.float32)
+    dSecond = np.asarray(dSecond, np.float32)
+    r2 = np.float32(MaxRatio * MaxRatio)
+    keep = (dBest <= r2 * dSecond) & (dBest <= np.float32(MatchThreshold)) & np.isfinite(dBest) & np.isfinite(dSecond)
+    i1 = np.flatnonzero(keep).astype(np.uint32) + 1
+    i2 = np.asarray(idx2, np.uint32)[keep]
+    d = dBest[keep]
+    if Unique and i1.size:
+        order = np.argsort(d, kind="stable")
+        i1, i2, d = i1[order], i2[order], d[order]
+        used2 = np.zeros(n2 + 1, bool)
+        sel = np.zeros(i1.size, bool)
+        for k in range(i1.size):  # rows are unique already; first come, first served on the columns
+            if not used2[i2[k]]:
+                used2[i2[k]] = True
+                sel[k] = True
+        i1, i2, d = i1[sel], i2[sel], d[sel]
+    return np.stack([i1, i2], axis=1), d.astype(np.float32)
+
+
 def matchFeaturesScratch(F1, F2, Method="Exhaustive", MatchThreshold=3.5, MaxRatio=0.6, Unique=True,
+                         ApproxFloatNNMethod="pca2nn", ApproxKDBucketSize=40, candB=None, seed=0,
                          **_ignored_approx_args):
     """[matches, matchMetric] = matchFeaturesScratch(F1, F2, 'Method', ..., 'MatchThreshold', ...,
     'MaxRatio', ..., 'Unique', ...) for float descriptors (matchFeaturesScratch.m:1-215).
 
-    Only the exhaustive float back end runs on the device (the north-star path); 'Approximate' float
-    methods of the reference are approximations OF this exhaustive search (random subset / PCA /
-    kd-tree, :142-160) and are served by the same exact kernel.
+    'Exhaustive' (the north-star path): 2-NN + ratio/threshold/uniqueness fused on the device.
+    'Approximate' float back ends (:142-160), selected by ApproxFloatNNMethod: 'pca2nn' (PCA-48 + cosine),
+    'kdtree' (exact), 'subsetpdist2' (random 12000-row subset of F2; pass candB or seed): their 2-NN search is
+    the same device kernel on the transformed data, the filter runs on the host.
     Returns (matches K x 2 uint32 1-based, matchMetric K float32)."""
-    if str(Method).lower() not in ("exhaustive", "approximate"):
+    method = str(Method).lower()
+    if method not in ("exhaustive", "approximate"):
         raise ValueError(f"Unknown Method: {Method}")
     if not (0 < MaxRatio <= 1) or MatchThreshold < 0:
         raise ValueError("invalid MaxRatio/MatchThreshold")
+    if method == "approximate":
+        An, Bn = _normalize_like_reference(F1, F2)
+        if An.shape[0] == 0 or Bn.shape[0] == 0:
+            raise ValueError("Expected input to be nonempty.")
+        am = str(ApproxFloatNNMethod).lower()
+        if am == "pca2nn":
+            _, idx2, d1, d2 = nearest2ApproxFloatFast(An, Bn, {"ApproxNumComponents": 48, "UsePCA": True})
+        elif am == "kdtree":
+            _, idx2, e1, e2 = nearest2KDTree(An, Bn, ApproxKDBucketSize)
+            d1, d2 = e1 * e1, e2 * e2  # :152-153
+        elif am == "subsetpdist2":
+            _, idx2, e1, e2 = nearest2SubsetPdist2(An, Bn, 12000, candB, seed)
+            d1, d2 = e1 * e1, e2 * e2  # :156-157
+        else:
+            raise ValueError("Select a approximate method")
+        return filter_matches(idx2, d1, d2, Bn.shape[0], MaxRatio, MatchThreshold, Unique)
     A, n1, ld1, la = _as_desc(F1)
     B, n2, ld2, lb = _as_desc(F2)
     if n1 == 0 or n2 == 0:

@@ -175,3 +175,67 @@ def test_split_path_unnormalised_descriptors(fm, monkeypatch):
     m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=1.5, MaxRatio=0.6)
     om, omet = oracle.match_features(a, b, 0.6, 1.5, True, 2)
     assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
+# ---- the 'Approximate' float back ends of matchFeaturesScratch.m:142-160 ---------------------------------------
+def _approx_sets(seed=0, n1=600, n2=900, planted=250):
+    rng = np.random.default_rng(seed)
+    B = rng.gamma(0.6, 1.0, (n2, 128)).astype(np.float32) * 40  # unnormalised, like raw SIFT bins
+    A = rng.gamma(0.6, 1.0, (n1, 128)).astype(np.float32) * 40
+    A[:planted] = B[rng.permutation(n2)[:planted]] + rng.normal(0, 1.0, (planted, 128)).astype(np.float32)
+    return np.maximum(A, 0), B
+
+
+def test_kdtree_backend_equals_exhaustive(gpu):
+    """knnsearch on a kd-tree is exact: same pairs as 'Exhaustive'; the metric differs only by the
+    sqrt-then-square round trip of :152-153 (<= 2 ulp)."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    A, B = _approx_sets()
+    me, de = fm.matchFeaturesScratch(A, B, Method="Exhaustive", MatchThreshold=1.5, MaxRatio=0.6)
+    mk, dk = fm.matchFeaturesScratch(A, B, Method="Approximate", ApproxFloatNNMethod="kdtree", MatchThreshold=1.5, MaxRatio=0.6)
+    # same pairs; order and metric may move by a few ulp: the back end normalises rows on the host (numpy
+    # summation order) and takes sqrt-then-square of the distances (:152-153)
+    assert len(me) > 200 and len(me) == len(mk)
+    oe, ok = np.lexsort((me[:, 1], me[:, 0])), np.lexsort((mk[:, 1], mk[:, 0]))
+    assert np.array_equal(me[oe], mk[ok])
+    assert np.allclose(de[oe], dk[ok], rtol=2e-6, atol=1e-6)  # d = a2 + b2 - 2ab: a few ulp of 2 in absolute terms
+    assert np.all(np.diff(dk) >= 0)
+
+
+def test_subset_backend_is_exact_on_the_subset(gpu):
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    A, B = _approx_sets(1)
+    cand = np.random.default_rng(5).permutation(len(B))[:400] + 1
+    idx1, idx2, e1, e2 = fm.nearest2SubsetPdist2(*fm._normalize_like_reference(A, B), 400, candB=cand)
+    An, Bn = fm._normalize_like_reference(A, B)
+    oi, od1, od2 = oracle.match_2nn_ssd(An, Bn[cand - 1])
+    assert np.array_equal(idx2, cand[oi.astype(np.int64) - 1]) and np.array_equal(idx1, np.arange(1, len(A) + 1))
+    assert np.array_equal(e1, np.sqrt(od1)) and np.array_equal(e2, np.sqrt(od2))
+    m, d = fm.matchFeaturesScratch(A, B, Method="Approximate", ApproxFloatNNMethod="subsetpdist2", MatchThreshold=1.5,
+                                   MaxRatio=0.6, seed=3)
+    assert m.shape[1] == 2 and len(np.unique(m[:, 1])) == len(m) and np.all(np.diff(d) >= 0)
+    with pytest.raises(ValueError):
+        fm.nearest2SubsetPdist2(An, Bn, 400, candB=np.ones(400, np.int64))
+
+
+def test_pca_backend_finds_the_planted_matches(gpu):
+    """PCA-48 + cosine is an approximation OF the exhaustive search (pca is toolbox code: unpinned); the planted
+    near-duplicates must still come out, and the host restatement of the same projection must agree exactly."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    A, B = _approx_sets(2)
+    me, _ = fm.matchFeaturesScratch(A, B, Method="Exhaustive", MatchThreshold=1.5, MaxRatio=0.6)
+    mp, dp = fm.matchFeaturesScratch(A, B, Method="Approximate", ApproxFloatNNMethod="pca2nn", MatchThreshold=1.5, MaxRatio=0.6)
+    se, sp = {tuple(r) for r in me.tolist()}, {tuple(r) for r in mp.tolist()}
+    assert len(se & sp) >= 0.9 * len(se)
+    An, Bn = fm._normalize_like_reference(A, B)
+    mu = Bn.mean(0, dtype=np.float32)
+    co = fm.pca_coeff(Bn - mu, 48)
+    Ap, Bp = (An - mu) @ co, (Bn - mu) @ co
+    eps = np.float32(np.finfo(np.float32).eps)
+    Ap = Ap / (np.sqrt((Ap * Ap).sum(1, dtype=np.float32, keepdims=True)) + eps)
+    Bp = Bp / (np.sqrt((Bp * Bp).sum(1, dtype=np.float32, keepdims=True)) + eps)
+    pad = lambda X: np.concatenate([X, np.zeros((len(X), 80), np.float32)], 1)  # noqa: E731
+    oi, od1, od2 = oracle.match_2nn_ssd(pad(Ap), pad(Bp))
+    _, idx2, d1, d2 = fm.nearest2ApproxFloatFast(An, Bn)
+    assert np.array_equal(idx2, oi) and np.array_equal(d1, od1) and np.array_equal(d2, od2)
+    assert np.abs(d1 - (2 - 2 * (pad(Ap) * pad(Bp)[oi.astype(np.int64) - 1]).sum(1))).max() < 1e-5
