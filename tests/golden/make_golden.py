@@ -56,5 +56,51 @@ def main():
     print("wrote golden_v1.npz:", {k: v.shape for k, v in out.items()})
 
 
+def main_v2():
+    """golden_v2.npz: the rows of SURVEY section 8(c) that v1 does not hold -- Hamming 2-NN (with ties and an
+    all-equal row), exact global kNN + the per-query filter on a 3-image toy pool, MLESAC, the planar image warp."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    A = rng.integers(0, 256, (90, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, (130, 32), dtype=np.uint8)
+    B[7] = A[3]            # exact duplicate: d1 = 0
+    B[20] = B[21] = A[5]   # tie: the first index wins (nearest2HammingExhaustiveMEX.cpp:63-68)
+    A[11] = 0
+    out["ham_A"], out["ham_B"] = A, B
+    out["ham_idx"], out["ham_d1"], out["ham_d2"] = oracle.hamming_2nn(A, B)
+    base = rng.gamma(0.6, 1.0, (260, 128)).astype(np.float32)
+    descs = [np.maximum(base[rng.permutation(260)[:n]] + 0.02 * rng.standard_normal((n, 128)).astype(np.float32), 0)
+             for n in (120, 140, 100)]
+    pool = np.concatenate(descs).astype(np.float32)
+    sq = np.zeros(len(pool), np.float32)
+    for kk in range(128):
+        sq = sq + pool[:, kk] * pool[:, kk]
+    pool = (pool / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    img = np.repeat(np.arange(1, 4, dtype=np.uint32), [120, 140, 100])
+    loc = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in (120, 140, 100)])
+    ni, nd = oracle.knn(pool, pool, 4)
+    out.update(knn_pool=pool, knn_idx=ni, knn_dist=nd, gf_img=img, gf_loc=loc,
+               gf_rows=oracle.global_filter(ni, nd, img, loc, 0.6))
+    Ht = np.array([[1.02, 0.03, 12.0], [-0.02, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    p1 = rng.uniform(0, 500, (300, 2))
+    q = np.c_[p1, np.ones(300)] @ Ht.T
+    p2 = q[:, :2] / q[:, 2:]
+    p2[:80] += rng.uniform(-60, 60, (80, 2))
+    p2 += rng.normal(0, 0.3, p2.shape)
+    samples = np.stack([rng.choice(300, 4, replace=False) + 1 for _ in range(1064)]).astype(np.uint32)
+    model, mask, found, trials = oracle.mlesac_homography(p1, p2, samples, 2.0, 99.9, 1000)
+    out.update(ml_p1=p1, ml_p2=p2, ml_samples=samples, ml_model=model, ml_mask=mask, ml_found=np.array([found]),
+               ml_trials=np.array([trials]))
+    imgw = rng.integers(0, 256, (70, 100, 3), dtype=np.uint8)
+    Hw = np.array([[1.01, 0.02, 7.5], [-0.015, 0.99, -3.25], [1e-5, -2e-5, 1.0]])
+    out.update(iw_img=imgw, iw_H=Hw, iw_view=np.array([80.0, 120.0, -5.5, -4.5, 1.0, 1.0]),
+               iw_u8=oracle.image_warp_h(imgw, Hw, 80, 120, -5.5, -4.5, 1.0, 1.0, 9),
+               iw_f32=oracle.image_warp_h(imgw[..., 0].astype(np.float32) / 255, Hw, 80, 120, -5.5, -4.5, 1.0, 1.0, 0.0))
+    np.savez_compressed(os.path.join(HERE, "golden_v2.npz"), **out)
+    print("wrote golden_v2.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if not os.path.exists(os.path.join(HERE, "golden_v1.npz")) or "--v1" in sys.argv:
+        main()
+    main_v2()
