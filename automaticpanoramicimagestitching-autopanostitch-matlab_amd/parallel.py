@@ -151,6 +151,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         descs = gather_by_owner(ldesc, owner, n, torch.empty((0, 128), dtype=torch.float32, device=dev), None)
         kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
         descs = [d.contiguous() for d in descs]
+        torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
     else:
         descs = [ldesc[i] for i in range(n)]
         kps_t = [lkps[i] for i in range(n)]
@@ -247,6 +248,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         flat = {i: t.reshape(1, -1) for i, t in local_images.items()}
         allimg = gather_by_owner(flat, owner, n, torch.empty((0, H * W * 3), dtype=torch.uint8, device=dev), None)
         images = [a.reshape(H, W, 3) for a in allimg]
+        torch.cuda.synchronize()  # the collective ran on RCCL's stream; the library reads the images on its own
     else:
         images = [local_images[i] for i in range(n)]
     times.add("exchange", t0)

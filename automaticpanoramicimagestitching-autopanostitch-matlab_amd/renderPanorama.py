@@ -387,8 +387,11 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
         check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
     else:  # (first, step): only tiles t with t % step == first — the multi-GPU shard of the tile loop
         if device_out:
+            import torch
+
             pano.zero_()
             cov.zero_()
+            torch.cuda.current_stream().synchronize()  # torch's fills must land before the library's stream paints tiles
         check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
                                    int(tile_subset[0]), int(tile_subset[1]), ptr(pano), ptr(cov)))
     del keep
