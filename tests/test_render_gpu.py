@@ -203,6 +203,31 @@ def test_planar_scan_compositing_matches_oracle_pieces(rp, ip, blending):
     assert np.array_equal(pano, ref)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_shards_compose_to_the_full_render(rp, world):
+    """The multi-GPU render: rank r paints tiles t with t % world == r into a zeroed canvas and the canvases are
+    combined with max (parallel.py step 6).  The union must equal the one-process render in every byte, for
+    host buffers and for resident (torch) outputs alike."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    imgs, cams = _scene(rng, n=5, W=200, H=130, f=280.0)
+    sizes = [(130, 200, 3)] * 5
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 4, "pyrSigma": 1.0, "tile": (64, 80), "cropBorder": False}
+    full, _, cov, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, return_covered=True)
+    acc = np.zeros_like(full)
+    acc_t = None
+    for r in range(world):
+        part, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, tile_subset=(r, world))
+        acc = np.maximum(acc, part)
+        dimgs = [torch.from_numpy(i).cuda() for i in imgs]
+        torch.cuda.synchronize()
+        pt, _ = rp.renderPanorama({}, dimgs, sizes, cams, "spherical", 2, opts, tile_subset=(r, world), device_out=True)
+        acc_t = pt if acc_t is None else torch.maximum(acc_t, pt)
+    assert cov.sum() > 10000 and np.array_equal(acc, full)
+    assert np.array_equal(acc_t.cpu().numpy(), full)
+
+
 def test_canvas_geometry_and_crop(rp):
     rng = np.random.default_rng(6)
     imgs, cams = _scene(rng)
