@@ -239,3 +239,32 @@ def test_pca_backend_finds_the_planted_matches(gpu):
     _, idx2, d1, d2 = fm.nearest2ApproxFloatFast(An, Bn)
     assert np.array_equal(idx2, oi) and np.array_equal(d1, od1) and np.array_equal(d2, od2)
     assert np.abs(d1 - (2 - 2 * (pad(Ap) * pad(Bp)[oi.astype(np.int64) - 1]).sum(1))).max() < 1e-5
+
+
+def test_pair_shards_compose_to_the_all_pairs_result(fm):
+    """The multi-GPU matcher: the pair list is partitioned over ranks and each rank calls aps_match_pairs on its
+    part (parallel.py step 3).  Any partition must reproduce the all-pairs CSR exactly, with resident inputs too."""
+    import torch
+
+    rng = np.random.default_rng(15)
+    base = sift_like(rng, 700)
+    descs = []
+    for i in range(5):
+        keep = rng.permutation(700)[: 380 + 29 * i]
+        d = np.maximum(base[keep] + 0.02 * rng.standard_normal((len(keep), 128)).astype(np.float32), 0)
+        descs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
+    pp, ia, ib, met = fm.match_pairwise_csr(descs, 0.6, 1.5, True)
+    order = fm.pair_order(5)
+    assert len(order) == 10 and pp[-1] > 500
+    dd = [torch.from_numpy(d).cuda() for d in descs]
+    torch.cuda.synchronize()
+    for world in (2, 3):
+        for r in range(world):
+            mine = [p for p in range(len(order)) if p % world == r]
+            for inputs in (descs, dd):
+                qp, qa, qb, qm = fm.match_pairs_csr(inputs, [order[p] for p in mine], 0.6, 1.5, True)
+                for k, p in enumerate(mine):
+                    s0, s1 = int(pp[p]), int(pp[p + 1])
+                    t0, t1 = int(qp[k]), int(qp[k + 1])
+                    assert np.array_equal(ia[s0:s1], qa[t0:t1]) and np.array_equal(ib[s0:s1], qb[t0:t1])
+                    assert np.array_equal(met[s0:s1].view(np.uint32), qm[t0:t1].view(np.uint32))

@@ -159,3 +159,36 @@ def test_mlesac_degenerate_draws_and_method_switch(gpu):
     assert np.array_equal(models[0].view(np.uint64), oH.view(np.uint64))
     with pytest.raises(ValueError):
         im.estimateTransformationMLESAC(p1, p2, "affine", {})
+
+
+def test_ransac_shards_do_not_depend_on_the_partition(gpu):
+    """The multi-GPU verifier: candidate pairs go round-robin over ranks and the draws are keyed by the GLOBAL pair id
+    (parallel.py step 4), so a pair's model must not depend on which other pairs share its batch."""
+    im = import_module(gpu.__name__ + ".imageMatching")
+    rng = np.random.default_rng(8)
+    pts1, pts2, ptr = [], [], [0]
+    for p in range(5):
+        m = 120 + 40 * p
+        a = rng.uniform(0, 800, (m, 2))
+        H = np.array([[1 + 0.01 * p, 0.02, 30.0 * p], [-0.01, 1.0, -12.0], [1e-5, 0, 1.0]])
+        q = np.c_[a, np.ones(m)] @ H.T
+        b = q[:, :2] / q[:, 2:] + rng.normal(0, 0.4, (m, 2))
+        b[: m // 4] = rng.uniform(0, 800, (m // 4, 2))
+        pts1.append(a)
+        pts2.append(b)
+        ptr.append(ptr[-1] + m)
+    cnts = np.diff(ptr)
+    inp = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 500}
+    keys = np.arange(100, 105)  # global pair ids
+    samples = im.draw_samples(cnts, 564, seed=7, keys=keys)
+    assert np.array_equal(im.draw_samples_device(cnts, 564, seed=7, keys=keys).cpu().numpy().astype(np.uint32), samples)
+    models, mask, found, ninl = im.ransac_batch(np.concatenate(pts1), np.concatenate(pts2), np.asarray(ptr), samples, inp)
+    assert found.all() and (ninl > 0.6 * cnts).all()
+    for shard in ([0, 2, 4], [1, 3], [4], [3, 0]):
+        s_ptr = np.concatenate([[0], np.cumsum(cnts[shard])])
+        s_samples = im.draw_samples(cnts[shard], 564, seed=7, keys=keys[shard])
+        m2, k2, f2, n2 = im.ransac_batch(np.concatenate([pts1[p] for p in shard]), np.concatenate([pts2[p] for p in shard]),
+                                         s_ptr, s_samples, inp)
+        for k, p in enumerate(shard):
+            assert np.array_equal(m2[k].view(np.uint64), models[p].view(np.uint64)) and n2[k] == ninl[p]
+            assert np.array_equal(k2[s_ptr[k]:s_ptr[k + 1]], mask[ptr[p]:ptr[p + 1]])
