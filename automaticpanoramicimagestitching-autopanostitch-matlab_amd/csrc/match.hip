@@ -37,15 +37,20 @@ constexpr int kLdsRow = 132;  // floats per LDS row: 128 + one 16-B pad => ds_re
 // ------------------------------------------------------------------------------------------------
 // |x| maximum per descriptor set (the reference's "looks unnormalised" probe, :105)
 // ------------------------------------------------------------------------------------------------
-// contiguous rows (the common case): a flat float4 sweep, no index arithmetic
-__global__ void absmax_flat_kernel(const float4* __restrict__ X, int64_t n4, float* __restrict__ out) {
+// contiguous rows (the common case): a flat float4 sweep, no index arithmetic; one atomic per workgroup
+// (thousands of same-address atomics cost more than the sweep itself)
+__global__ __launch_bounds__(256) void absmax_flat_kernel(const float4* __restrict__ X, int64_t n4, float* __restrict__ out) {
+    __shared__ float s_m[4];
     float m = 0.f;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = X[e];
         m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
 __global__ void absmax_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int dim,
@@ -374,10 +379,75 @@ __device__ __forceinline__ void top4_insert_max(float t, int j, float& u0, float
 
 constexpr int kTileBytes = kTNB * 256;  // one bf16 half (hi or lo) of a B tile in LDS
 
+// exact canonical distance of A row `pa` and B row `pb` (both in the permuted f32 layout of prep_desc_kernel):
+// G = k-ascending fma chain, d = (a2 + b2) - 2G — the same arithmetic as match2nn_kernel / the oracle.
+__device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const float* __restrict__ pb, float a2,
+                                            float b2) {
+    float g = 0.f;
+#pragma unroll 4
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
+        const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(pb + 4 * s4);
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(pb + 64 + 4 * s4);
+        g = fmaf(ae.x, be.x, g);
+        g = fmaf(ao.x, bo.x, g);
+        g = fmaf(ae.y, be.y, g);
+        g = fmaf(ao.y, bo.y, g);
+        g = fmaf(ae.z, be.z, g);
+        g = fmaf(ao.z, bo.z, g);
+        g = fmaf(ae.w, be.w, g);
+        g = fmaf(ao.w, bo.w, g);
+    }
+    return __fsub_rn(__fadd_rn(a2, b2), __fmul_rn(2.0f, g));
+}
+
+// Exact rescoring of one row's three candidates and the certification test (see the header comment): writes the
+// final (idx, d1, d2) of a certified row, or appends the row to the fallback list.
+__device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0, int c1, int c2, float bnd,
+                                            uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
+                                            float* __restrict__ out_d2, uint32_t* __restrict__ fb_list,
+                                            unsigned int* __restrict__ fb_count) {
+    const int64_t slot = jb.out_off + row;
+    const float a2 = jb.sqA[row];
+    const float* pa = jb.PA + (size_t)row * kDim;
+    float d[3];
+    int id[3] = {c0, c1, c2};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int j = id[e];
+        const bool ok = j >= 0 && j < jb.nB;
+        d[e] = ok ? exact_dist(pa, jb.PB + (size_t)j * kDim, a2, jb.sqB[j]) : INFINITY;
+        if (!ok) id[e] = 0x7fffffff;
+    }
+    // order the three by (d, idx): exact best and exact second
+#define APS_CSWAP(a, b)                                                    \
+    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
+        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
+        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
+    }
+    APS_CSWAP(0, 1)
+    APS_CSWAP(1, 2)
+    APS_CSWAP(0, 1)
+#undef APS_CSWAP
+    const float eps = kSplitEps * sqrtf(a2 * (*jb.maxsqB)) + 9.5367431640625e-07f;
+    const bool certified = jb.nB <= 3 || (d[1] < bnd - eps);
+    if (certified) {
+        out_idx[slot] = jb.nB > 0 ? (uint32_t)id[0] + 1u : 0u;
+        out_d1[slot] = d[0];
+        out_d2[slot] = d[1];
+    } else {
+        const unsigned int p = atomicAdd(fb_count, 1u);
+        fb_list[p] = (uint32_t)slot;
+    }
+}
+
 __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __restrict__ jobs,
                                                                  const WgJob* __restrict__ wgs, int n_wg,
-                                                                 uint32_t* __restrict__ cand,  // 3 per slot
-                                                                 float* __restrict__ bound, int ablate) {
+                                                                 uint32_t* __restrict__ out_idx,
+                                                                 float* __restrict__ out_d1, float* __restrict__ out_d2,
+                                                                 uint32_t* __restrict__ fb_list,
+                                                                 unsigned int* __restrict__ fb_count, int ablate) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kTileBytes];  // [buf][hi|lo][128][256 B]
     // -b2/2 of each B row as three bf16 pieces (hi + mid + lo == the f32 value exactly) + five zeros: one extra
     // 16-wide k-step against the constant [1 1 1 0 ...] puts it into the accumulator (padded column: -1e30)
@@ -596,91 +666,20 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
         top4_insert_max(p1, q1, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
         top4_insert_max(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
         u3[rb] = fmaxf(u3[rb], p3);
-        const int row = row0 + 32 * rb;
-        if (h == 0 && row < nA) {
-            const int64_t o = jb.out_off + row;
-            cand[3 * o + 0] = (uint32_t)i0[rb];
-            cand[3 * o + 1] = (uint32_t)i1[rb];
-            cand[3 * o + 2] = (uint32_t)i2[rb];
-            bound[o] = jb.sqA[row] - 2.0f * u3[rb];  // approximate 4th-smallest distance (inf if < 4 columns)
+    }
+    // Exact rescoring in place (it used to be a separate, purely gather-bound launch): the h == 0 half holds the
+    // merged lists of both owned rows; its lanes rescore row block 0 while the h == 1 lanes take over row block 1.
+    {
+        const int src = lane & 31;  // every lane takes part in the exchange (a masked-off source lane would read as 0)
+        const int s0 = __shfl(i0[1], src), s1 = __shfl(i1[1], src), s2 = __shfl(i2[1], src);
+        const float sb = __shfl(u3[1], src);
+        const int c0 = h ? s0 : i0[0], c1 = h ? s1 : i1[0], c2 = h ? s2 : i2[0];
+        const float ub = h ? sb : u3[0];
+        const int row = row0 + 32 * h;
+        if (row < nA) {
+            const float bnd = jb.sqA[row] - 2.0f * ub;  // approximate 4th-smallest distance (inf if < 4 columns)
+            rescore_row(jb, row, c0, c1, c2, bnd, out_idx, out_d1, out_d2, fb_list, fb_count);
         }
-    }
-}
-
-// exact canonical distance of A row `pa` and B row `pb` (both in the permuted f32 layout of prep_desc_kernel):
-// G = k-ascending fma chain, d = (a2 + b2) - 2G — the same arithmetic as match2nn_kernel / the oracle.
-__device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const float* __restrict__ pb, float a2,
-                                            float b2) {
-    float g = 0.f;
-#pragma unroll 4
-    for (int s4 = 0; s4 < 16; ++s4) {
-        const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
-        const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(pb + 4 * s4);
-        const f32x4 bo = *reinterpret_cast<const f32x4*>(pb + 64 + 4 * s4);
-        g = fmaf(ae.x, be.x, g);
-        g = fmaf(ao.x, bo.x, g);
-        g = fmaf(ae.y, be.y, g);
-        g = fmaf(ao.y, bo.y, g);
-        g = fmaf(ae.z, be.z, g);
-        g = fmaf(ao.z, bo.z, g);
-        g = fmaf(ae.w, be.w, g);
-        g = fmaf(ao.w, bo.w, g);
-    }
-    return __fsub_rn(__fadd_rn(a2, b2), __fmul_rn(2.0f, g));
-}
-
-struct FilterJobLite {
-    int64_t row_off;
-};
-
-__global__ void rescore_kernel(const MatchJob* __restrict__ jobs, const FilterJobLite* __restrict__ fj, int njobs,
-                               int64_t total_rows, const uint32_t* __restrict__ cand,
-                               const float* __restrict__ bound, uint32_t* __restrict__ out_idx,
-                               float* __restrict__ out_d1, float* __restrict__ out_d2,
-                               uint32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
-    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (slot >= total_rows) return;
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (fj[mid].row_off <= slot)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    const MatchJob jb = jobs[lo];
-    const int row = (int)(slot - jb.out_off);
-    const float a2 = jb.sqA[row];
-    const float* pa = jb.PA + (size_t)row * kDim;
-    float d[3];
-    int id[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const int j = (int)cand[3 * slot + e];
-        id[e] = j;
-        d[e] = (j >= 0 && j < jb.nB) ? exact_dist(pa, jb.PB + (size_t)j * kDim, a2, jb.sqB[j]) : INFINITY;
-        if (!(j >= 0 && j < jb.nB)) id[e] = 0x7fffffff;
-    }
-    // order the three by (d, idx): exact best and exact second
-#define APS_CSWAP(a, b)                                                    \
-    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
-        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
-        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
-    }
-    APS_CSWAP(0, 1)
-    APS_CSWAP(1, 2)
-    APS_CSWAP(0, 1)
-#undef APS_CSWAP
-    const float eps = kSplitEps * sqrtf(a2 * (*jb.maxsqB)) + 9.5367431640625e-07f;
-    const bool certified = jb.nB <= 3 || (d[1] < bound[slot] - eps);
-    if (certified) {
-        out_idx[slot] = jb.nB > 0 ? (uint32_t)id[0] + 1u : 0u;
-        out_d1[slot] = d[0];
-        out_d2[slot] = d[1];
-    } else {
-        const unsigned int p = atomicAdd(fb_count, 1u);
-        fb_list[p] = (uint32_t)slot;
     }
 }
 
@@ -865,7 +864,7 @@ static float absmax(const float* X_dev, int64_t n, int64_t ld, int layout, float
     if (n > 0) {
         const unsigned grid = std::min<unsigned>(cdiv((size_t)n * kDim, 256), 2048);
         if (layout == APS_ROWMAJOR && ld == kDim && (reinterpret_cast<uintptr_t>(X_dev) & 15) == 0)
-            absmax_flat_kernel<<<std::min<unsigned>(cdiv((size_t)n * kDim / 4, 256), 2048), 256, 0, stream()>>>(
+            absmax_flat_kernel<<<std::min<unsigned>(cdiv((size_t)n * kDim / 4, 256), 512), 256, 0, stream()>>>(
                 reinterpret_cast<const float4*>(X_dev), n * (kDim / 4), d_slot);
         else
             absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
@@ -922,8 +921,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         return;
     }
     const int64_t total_rows = jobs.back().out_off + jobs.back().nA;
-    Ws<uint32_t> cand((size_t)total_rows * 3), fb_list((size_t)total_rows);
-    Ws<float> bound((size_t)total_rows);
+    Ws<uint32_t> fb_list((size_t)total_rows);
     Ws<unsigned int> fb_count(1);
     APS_HIP(hipMemsetAsync(fb_count, 0, sizeof(unsigned int), stream()));
     std::vector<WgJob> bw;
@@ -934,20 +932,10 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     {
         Prof prof("match_cand_bf16");
         const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
-        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), cand, bound,
-                                                                          ab ? std::atoi(ab) : 0);
+        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
+                                                                          fb_count, ab ? std::atoi(ab) : 0);
     }
     check_launch("match_cand_bf16_kernel");
-    std::vector<FilterJobLite> fl(jobs.size());
-    for (size_t j = 0; j < jobs.size(); ++j) fl[j].row_off = jobs[j].out_off;
-    Ws<FilterJobLite> dfl(jobs.size());
-    APS_HIP(hipMemcpyAsync(dfl, fl.data(), fl.size() * sizeof(FilterJobLite), hipMemcpyHostToDevice, stream()));
-    {
-        Prof prof("match_rescore");
-        rescore_kernel<<<cdiv(total_rows, 256), 256, 0, stream()>>>(djobs, dfl, (int)jobs.size(), total_rows, cand,
-                                                                    bound, idx, d1, d2, fb_list, fb_count);
-    }
-    check_launch("rescore_kernel");
     unsigned int n_fb = 0;
     APS_HIP(hipMemcpyAsync(&n_fb, fb_count, sizeof n_fb, hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));

@@ -29,4 +29,4 @@ npairs = n_img * (n_img - 1) // 2
 ms = p["match_cand_bf16"][0]
 fl = 2 * 128 * npairs * kf * kf
 print(f"cand {ms:.2f} ms  ({ms/npairs*1e3:.1f} us/pair)  algorithmic {fl/ms/1e9:.1f} TF  pipe(3x) {3*fl/ms/1e9:.0f} TF;"
-      f" rescore {p['match_rescore'][0]:.2f} fallback {p.get('match2nn_fallback',(0,0))[0]:.2f}")
+      f" fallback {p.get('match2nn_fallback',(0,0))[0]:.2f}")
