@@ -806,7 +806,8 @@ __global__ void mb_resize_kernel(PtrTab ins, RectTab irs, int h, int w, int oh, 
     const float4* __restrict__ in = ins.p[blockIdx.z];
     float4* __restrict__ out = outs.p[blockIdx.z];
     const Rect ir = irs.r[blockIdx.z], orc = ors.r[blockIdx.z];
-    const int x = orc.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = orc.y0 + blockIdx.y;
+    // 32 x 4 outputs per 128-thread block: vertically adjacent outputs share most of their input rows (L1 hits)
+    const int x = orc.x0 + blockIdx.x * 32 + (threadIdx.x & 31), y = orc.y0 + blockIdx.y * 4 + (threadIdx.x >> 5);
     if (x >= orc.x1 || y >= orc.y1) return;
     int lr, lc;
     float wr[12], wc[12];
@@ -822,8 +823,8 @@ __global__ void mb_resize_kernel(PtrTab ins, RectTab irs, int h, int w, int oh, 
 template <bool ROWS_FIRST>
 __global__ void mb_lap_all_kernel(PtrTab Gt, RectTab Gr, PtrTab Dt, RectTab Dr, int has_d, int cont, int K, int h, int w,
                                   int dh, int dw, float4* __restrict__ num) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 4 + (threadIdx.x >> 5);  // 32 x 4 per block
+    if (x >= w || y >= h) return;
     float acc[3] = {0.f, 0.f, 0.f};
     if (cont) {  // continue the layer-ordered sum of a previous chunk of layers
         const float4 p = num[(size_t)y * w + x];
@@ -864,8 +865,8 @@ __global__ void mb_lap_all_kernel(PtrTab Gt, RectTab Gr, PtrTab Dt, RectTab Dr, 
 template <bool ROWS_FIRST>
 __global__ void mb_collapse_kernel(const float4* __restrict__ Fc, int ch, int cw, const float4* __restrict__ num, int h,
                                    int w, float4* __restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 4 + (threadIdx.x >> 5);  // 32 x 4 per block
+    if (x >= w || y >= h) return;
     int lr, lc;
     float wr[12], wc[12];
     const int Pr = resize_taps(ch, h, y, lr, wr);
@@ -1035,14 +1036,14 @@ static void multiband_device(const std::vector<float4*>& layers, const Rect* rec
                 }
                 span(gr[l + 1].data() + k0, kc, mw, mh);
                 if (mw > 0 && mh > 0) {
-                    const dim3 rg(cdiv(mw, 128), mh, kc);
+                    const dim3 rg(cdiv(mw, 32), cdiv(mh, 4), kc);
                     if (rows_first(hl, wl, nh, nw))
                         mb_resize_kernel<true><<<rg, 128, 0, stream()>>>(bt, brt, hl, wl, nh, nw, dt, drt);
                     else
                         mb_resize_kernel<false><<<rg, 128, 0, stream()>>>(bt, brt, hl, wl, nh, nw, dt, drt);
                 }
             }
-            const dim3 lg(cdiv(wl, 128), hl);
+            const dim3 lg(cdiv(wl, 32), cdiv(hl, 4));
             if (last || rows_first(nh, nw, hl, wl))
                 mb_lap_all_kernel<true><<<lg, 128, 0, stream()>>>(gt, grt, dt, drt, last ? 0 : 1, k0 > 0, kc, hl, wl, nh, nw, dst);
             else
@@ -1060,9 +1061,9 @@ static void multiband_device(const std::vector<float4*>& layers, const Rect* rec
             dst = fl[l];
         }
         if (rows_first(lh[l + 1], lw[l + 1], lh[l], lw[l]))
-            mb_collapse_kernel<true><<<dim3(cdiv(lw[l], 128), lh[l]), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
+            mb_collapse_kernel<true><<<dim3(cdiv(lw[l], 32), cdiv(lh[l], 4)), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
         else
-            mb_collapse_kernel<false><<<dim3(cdiv(lw[l], 128), lh[l]), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
+            mb_collapse_kernel<false><<<dim3(cdiv(lw[l], 32), cdiv(lh[l], 4)), 128, 0, stream()>>>(cur, lh[l + 1], lw[l + 1], num[l], lh[l], lw[l], dst);
         check_launch("mb_collapse_kernel");
         cur = dst;
     }

@@ -193,6 +193,24 @@ def main():
         a_cov = n * w * h / world
         a_pano = float(pano.shape[0] * pano.shape[1]) / world
 
+        # HBM-side bytes per launch from the committed PMC pass of THIS workload (scripts/hbm_traffic.sh ->
+        # profiles/*_hbm_traffic.json: L2 memory-side requests x 64 B, one bench step); null for other configs
+        traffic_db = {}
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_hbm_traffic.json")
+        if world == 1 and (nx, ny, w, h, args.bands) == (8, 8, W, H, 5) and os.path.exists(tpath):
+            traffic_db = json.load(open(tpath))
+
+        def traffic_of(prefixes):
+            rows = [v for k, v in traffic_db.items() if any(p in k for p in prefixes)]
+            launches = sum(r["launches_per_step"] for r in rows)
+            if not rows or launches == 0:
+                return None
+            return round(sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows) / launches)
+
+        TRAFFIC_KEYS = {"match_cand_bf16": ["match_cand_bf16_kernel"], "match2nn": ["match2nn_kernel"],
+                        "sift_blur": ["aps::blur_kernel<"], "warp_layer": ["warp_layer_kernel"],
+                        "multiband": ["mb_blur_kernel", "mb_resize_kernel", "mb_lap_all_kernel", "mb_collapse_kernel"]}
+
         def roof(kernel, name, bound, work_per_step, peak, unit, note=""):
             ms, launches = prof.get(kernel, (0.0, 0))
             if ms <= 0:
@@ -200,8 +218,12 @@ def main():
             scale = 1e12 if unit == "TFLOP/s" else 1e9
             ach = work_per_step * args.steps / (ms * 1e-3) / scale
             r = {"bound": bound, "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                 "frac": round(ach / peak, 4), "traffic": None, "algorithmic_work_per_step": work_per_step,
+                 "frac": round(ach / peak, 4), "traffic": traffic_of(TRAFFIC_KEYS.get(kernel, ["\0"])),
+                 "algorithmic_work_per_step": work_per_step,
                  "launches_per_step": launches // max(args.steps, 1), "ms_per_step": round(ms / args.steps, 3)}
+            if r["traffic"] is not None:
+                r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
+                                     "pass of this workload (profiles/r01d_hbm_traffic.txt)")
             if note:
                 r["note"] = note
             return r
@@ -213,8 +235,9 @@ def main():
                  "pipe (MFMA pipe utilisation = 3*frac); results are certified bit-identical to the f32 path"),
             roof("match2nn", "match2nn_kernel (v_mfma_f32_32x32x2_f32, exact f32)", "mfma", flops_rank0,
                  MFMA_F32_PEAK_TFLOPS, "TFLOP/s"),
-            roof("sift_blur", "blur_kernel<R> (separable Gaussian + DoG through LDS)", "hbm", 574.0 * npix_rank0,
-                 HBM_PEAK_GBS, "GB/s", "574 B per input pixel is the whole materialised-pyramid model"),
+            roof("sift_blur", "blur_kernel<R> (separable Gaussian through LDS)", "hbm", 574.0 * npix_rank0,
+                 HBM_PEAK_GBS, "GB/s", "574 B per input pixel is SURVEY 8(d)'s materialised-pyramid model (G and DoG "
+                 "written and re-read); the build no longer stores DoG planes, so its real traffic is lower"),
             roof("multiband", "multiband chain (blur/resize/Laplacian kernels, per tile)", "hbm", 64.0 * a_cov + 32.0 * a_pano,
                  HBM_PEAK_GBS, "GB/s"),
             roof("warp_layer", "warp_layer_kernel (ray -> project -> bilinear gather)", "hbm", 16.0 * a_cov + 3.0 * npix_rank0,
