@@ -816,6 +816,71 @@ __global__ void mb_resize_kernel(PtrTab ins, RectTab irs, int h, int w, int oh, 
     out[(size_t)y * ow + x] = resize_at<ROWS_FIRST>(in, h, w, ir, Pr, lr, wr, Pc, lc, wc);
 }
 
+// Blur + downsample in one pass for levels whose next size is exactly half (h == 2*oh, w == 2*ow): a 32 x 8
+// tile of the half-resolution output needs a 68 x 20 patch of the blurred image (taps 2o-2 .. 2o+3), which needs
+// that patch plus the filter radius of the input.  The blurred full-resolution plane is never stored: it was
+// written once and read (twice, measured) by nothing but the downsampler.  Same fma chains in the same order as
+// mb_blur_kernel followed by mb_resize_kernel; blurred values outside the blurred footprint are sums of zeros.
+constexpr int kFOW = 32, kFOH = 8;
+template <int R, bool ROWS_FIRST>
+__global__ __launch_bounds__(256) void mb_blur_resize_kernel(PtrTab ins, RectTab irs, int h, int w, Taps tp, int oh,
+                                                             int ow, PtrTab outs, RectTab ors) {
+    constexpr int BC = 2 * kFOW + 4, BR = 2 * kFOH + 4, IC = BC + 2 * R, IR = BR + 2 * R;
+    __shared__ float4 s_a[IR * IC];  // input patch; later the blurred patch [BR][BC]
+    __shared__ float4 s_b[BR * IC];  // after the vertical pass
+    const float4* __restrict__ in = ins.p[blockIdx.z];
+    float4* __restrict__ out = outs.p[blockIdx.z];
+    const Rect ir = irs.r[blockIdx.z], orc = ors.r[blockIdx.z];
+    const int ox0 = orc.x0 + blockIdx.x * kFOW, oy0 = orc.y0 + blockIdx.y * kFOH, tid = threadIdx.x;
+    if (ox0 >= orc.x1 || oy0 >= orc.y1) return;
+    const int bx0 = 2 * ox0 - 2, by0 = 2 * oy0 - 2;  // image position of the blurred patch's corner (may be -2)
+    for (int e = tid; e < IR * IC; e += 256) {
+        const int ly = e / IC, lx = e - ly * IC;
+        const int gy = min(max(by0 + ly - R, 0), h - 1), gx = min(max(bx0 + lx - R, 0), w - 1);
+        s_a[e] = ld_rect(in, w, ir, gx, gy);
+    }
+    __syncthreads();
+    for (int e = tid; e < BR * IC; e += 256) {  // vertical pass
+        const int ly = e / IC, lx = e - ly * IC;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], s_a[(ly + t) * IC + lx], a);
+        s_b[e] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < BR * BC; e += 256) {  // horizontal pass -> blurred patch (reuses s_a)
+        const int ly = e / BC, lx = e - ly * BC;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], s_b[ly * IC + lx + t], a);
+        s_a[e] = a;
+    }
+    __syncthreads();
+    const int x = ox0 + (tid & 31), y = oy0 + (tid >> 5);
+    if (x >= orc.x1 || y >= orc.y1) return;
+    int lr, lc;
+    float wr[12], wc[12];
+    const int Pr = resize_taps(h, oh, y, lr, wr);
+    const int Pc = resize_taps(w, ow, x, lc, wc);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ROWS_FIRST) {
+        for (int tc = 0; tc < Pc; ++tc) {
+            const int xx = min(max(lc + tc, 1), w) - 1 - bx0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], s_a[(min(max(lr + tr, 1), h) - 1 - by0) * BC + xx], v);
+            a = fma4(wc[tc], v, a);
+        }
+    } else {
+        for (int tr = 0; tr < Pr; ++tr) {
+            const int yy = min(max(lr + tr, 1), h) - 1 - by0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], s_a[yy * BC + min(max(lc + tc, 1), w) - 1 - bx0], v);
+            a = fma4(wr[tr], v, a);
+        }
+    }
+    out[(size_t)y * ow + x] = a;
+}
+
 // Level l of multiBandBlending.m:136-144 for ALL K layers in one pass:
 //   Num_l = sum_k (G_k - imresize(D_k, size_l)) .* w_k      (accumulated in layer order, from zero)
 // or, with D == nullptr, the coarsest level (:159): Num_L = sum_k G_k .* w_k.
@@ -1024,8 +1089,31 @@ static void multiband_device(const std::vector<float4*>& layers, const Rect* rec
                 dt = make_tab(lev[l + 1].data() + k0, kc);
                 drt = make_rtab(gr[l + 1].data() + k0, kc);
                 int mw, mh;
+                const bool fused = hl == 2 * nh && wl == 2 * nw && !std::getenv("APS_RENDER_NO_FUSE");
+                if (fused) {
+                    span(gr[l + 1].data() + k0, kc, mw, mh);
+                    if (mw > 0 && mh > 0) {
+                        const dim3 fg(cdiv(mw, kFOW), cdiv(mh, kFOH), kc);
+                        const bool rf = rows_first(hl, wl, nh, nw);
+#define APS_FUSE_CASE(RR)                                                                                              \
+    case RR:                                                                                                           \
+        if (rf)                                                                                                        \
+            mb_blur_resize_kernel<RR, true><<<fg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, nh, nw, dt, drt);           \
+        else                                                                                                           \
+            mb_blur_resize_kernel<RR, false><<<fg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, nh, nw, dt, drt);          \
+        break;
+                        switch (tp.r) {
+                            APS_FUSE_CASE(1)
+                            APS_FUSE_CASE(2)
+                            APS_FUSE_CASE(3)
+                            default:
+                                APS_FUSE_CASE(4)
+                        }
+#undef APS_FUSE_CASE
+                    }
+                }
                 span(br[l].data() + k0, kc, mw, mh);
-                if (mw > 0 && mh > 0) {
+                if (!fused && mw > 0 && mh > 0) {
                     const dim3 bg(cdiv(mw, kBW), cdiv(mh, kBH), kc);
                     switch (tp.r) {
                         case 1: mb_blur_kernel<1><<<bg, 256, 0, stream()>>>(gt, grt, hl, wl, tp, bt, brt); break;
@@ -1035,7 +1123,7 @@ static void multiband_device(const std::vector<float4*>& layers, const Rect* rec
                     }
                 }
                 span(gr[l + 1].data() + k0, kc, mw, mh);
-                if (mw > 0 && mh > 0) {
+                if (!fused && mw > 0 && mh > 0) {
                     const dim3 rg(cdiv(mw, 32), cdiv(mh, 4), kc);
                     if (rows_first(hl, wl, nh, nw))
                         mb_resize_kernel<true><<<rg, 128, 0, stream()>>>(bt, brt, hl, wl, nh, nw, dt, drt);

@@ -54,6 +54,24 @@ def test_multiband_bit_exact(bl, K, h, w, levels):
     assert np.array_equal(bits(F), bits(O))
 
 
+@pytest.mark.parametrize("K,h,w,levels,sigma", [(2, 64, 96, 4, 1.0), (3, 128, 64, 5, 1.0), (2, 96, 160, 3, 1.5),
+                                                 (1, 32, 32, 5, 0.8), (3, 72, 136, 3, 1.0)])
+def test_fused_blur_downsample_levels_are_bit_exact(bl, monkeypatch, K, h, w, levels, sigma):
+    """Levels whose next size is exactly half take the fused blur+downsample kernel; it must give the oracle's bits
+    and the bits of the unfused kernels (APS_RENDER_NO_FUSE=1), including mixed pyramids (72 -> 36 -> 18 -> 9)."""
+    rng = np.random.default_rng(K * 100 + h + w)
+    C = rng.random((K, h, w, 3), dtype=np.float32)
+    W = rng.random((K, h, w), dtype=np.float32)
+    W[0, : h // 2] = 0
+    W[-1, :, w // 3:] = 0
+    monkeypatch.delenv("APS_RENDER_NO_FUSE", raising=False)
+    F = bl.multiBandBlending(list(C), list(W), levels, True, sigma)
+    monkeypatch.setenv("APS_RENDER_NO_FUSE", "1")
+    U = bl.multiBandBlending(list(C), list(W), levels, True, sigma)
+    O = oracle.multiband_blend(C, W, levels, sigma)
+    assert np.array_equal(bits(F), bits(O)) and np.array_equal(bits(U), bits(O))
+
+
 def test_multiband_other_sigma_and_gray(bl):
     rng = np.random.default_rng(1)
     C = rng.random((2, 40, 56), dtype=np.float32)
