@@ -1483,6 +1483,203 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------------------
+// gain-compensation overlap statistics (gainCompensationRKf.m:96-149,239-367)
+// ------------------------------------------------------------------------------------------------
+namespace aps {
+// panoDirsGridTile (:369-430): 1-based canvas coordinates, no normalisation
+__device__ __forceinline__ void gain_ray(const DevCanvas& cv, float xp, float yp, float d[3]) {
+    if (cv.mode == APS_PROJ_CYLINDRICAL) {
+        const float th = cv.o0 + xp / cv.f, hl = cv.o1 + yp / cv.f;
+        d[0] = sinf(th);
+        d[1] = hl;
+        d[2] = cosf(th);
+    } else if (cv.mode == APS_PROJ_SPHERICAL) {
+        const float th = cv.o0 + xp / cv.f, ph = cv.o1 + yp / cv.f;
+        const float cp = cosf(ph), sp = sinf(ph);
+        d[0] = cp * sinf(th);
+        d[1] = sp;
+        d[2] = cp * cosf(th);
+    } else {
+        float rx, ry, rz;
+        if (cv.mode == APS_PROJ_PLANAR) {
+            rx = cv.o0 + xp / cv.f;
+            ry = cv.o1 + yp / cv.f;
+            rz = 1.0f;
+        } else {
+            const float a = cv.o0 + xp / cv.f, b = cv.o1 + yp / cv.f;
+            const float r2 = a * a + b * b, den = 1.0f + r2;
+            rx = 2.0f * a / den;
+            ry = 2.0f * b / den;
+            rz = (1.0f - r2) / den;
+        }
+        d[0] = (cv.Rref[0] * rx + cv.Rref[1] * ry) + cv.Rref[2] * rz;
+        d[1] = (cv.Rref[3] * rx + cv.Rref[4] * ry) + cv.Rref[5] * rz;
+        d[2] = (cv.Rref[6] * rx + cv.Rref[7] * ry) + cv.Rref[8] * rz;
+    }
+}
+
+// projectToImage + sampleLinear(weights) > 0 + sampleLinearRGB on the raw 0..255 values (:432-579)
+__device__ __forceinline__ bool gain_sample(const DevImage& im, const float d[3], float col[3]) {
+    float cam[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cam[c] = fmaf(d[2], im.R[c + 6], fmaf(d[1], im.R[c + 3], d[0] * im.R[c]));
+    const bool front = cam[2] > 1e-6f;
+    const float u = im.fx * (cam[0] / cam[2]) + im.cx;
+    const float v = im.fy * (cam[1] / cam[2]) + im.cy;
+    const int w = im.w, h = im.h;
+    if (!front || !isfinite(u) || !isfinite(v)) return false;
+    if (!((u >= 1.0f) && (u <= (float)w) && (v >= 1.0f) && (v <= (float)h))) return false;
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    x0 = max(1, min(x0, w - 1));
+    y0 = max(1, min(y0, h - 1));
+    const int x1 = min(x0 + 1, w), y1 = min(y0 + 1, h);
+    const float s = u - (float)x0, t = v - (float)y0;
+    const float wy0 = im.wy[y0 - 1], wy1 = im.wy[y1 - 1], wx0 = im.wx[x0 - 1], wx1 = im.wx[x1 - 1];
+    const float f00 = wy0 * wx0, f10 = wy0 * wx1, f01 = wy1 * wx0, f11 = wy1 * wx1;
+    const float wtop = (1.0f - s) * f00 + s * f10, wbot = (1.0f - s) * f01 + s * f11;
+    if (!((wtop * (1.0f - t) + wbot * t) > 0.0f)) return false;
+    const uint32_t p00 = im.rgba[(size_t)(y0 - 1) * w + (x0 - 1)], p10 = im.rgba[(size_t)(y0 - 1) * w + (x1 - 1)];
+    const uint32_t p01 = im.rgba[(size_t)(y1 - 1) * w + (x0 - 1)], p11 = im.rgba[(size_t)(y1 - 1) * w + (x1 - 1)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v00 = (float)((p00 >> (8 * c)) & 255u), v10 = (float)((p10 >> (8 * c)) & 255u);
+        const float v01 = (float)((p01 >> (8 * c)) & 255u), v11 = (float)((p11 >> (8 * c)) & 255u);
+        const float top = (1.0f - s) * v00 + s * v10;
+        const float bot = (1.0f - s) * v01 + s * v11;
+        col[c] = top * (1.0f - t) + bot * t;
+    }
+    return true;
+}
+
+constexpr int kGainSlots = 128;  // per-workgroup pair table
+constexpr int kGainMaxCover = 16;
+
+// One thread per sampled canvas point.  Pair sums go through a small LDS hash table per workgroup (the points of a
+// 16 x 16 patch share a handful of pairs), flushed with one double atomicAdd per entry.
+__global__ __launch_bounds__(256) void gain_stats_kernel(DevCanvas cv, const DevImage* __restrict__ imgs, int n_img,
+                                                         int stride, int ws, int hs, double* __restrict__ Nij,
+                                                         double* __restrict__ sCi, double* __restrict__ sCj) {
+    __shared__ unsigned int s_key[kGainSlots];
+    __shared__ unsigned int s_cnt[kGainSlots];
+    __shared__ double s_sum[kGainSlots][6];
+    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
+        s_key[e] = 0u;
+        s_cnt[e] = 0u;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_sum[e][c] = 0.0;
+    }
+    __syncthreads();
+    const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const size_t nn = (size_t)n_img * n_img;
+    auto add_pair = [&](int i, int j, const float* ci, const float* cj) {
+        const unsigned int key = (unsigned int)(i * n_img + j) + 1u;
+        unsigned int slot = (key * 2654435761u) >> 25;
+        for (int probe = 0; probe < kGainSlots; ++probe) {
+            const unsigned int old = atomicCAS(&s_key[slot], 0u, key);
+            if (old == 0u || old == key) {
+                atomicAdd(&s_cnt[slot], 1u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    atomicAdd(&s_sum[slot][c], (double)ci[c]);
+                    atomicAdd(&s_sum[slot][3 + c], (double)cj[c]);
+                }
+                return;
+            }
+            slot = (slot + 1) & (kGainSlots - 1);
+        }
+        const size_t e = (size_t)i + (size_t)n_img * j;  // table full: straight to memory
+        atomicAdd(&Nij[e], 1.0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(&sCi[e + nn * c], (double)ci[c]);
+            atomicAdd(&sCj[e + nn * c], (double)cj[c]);
+        }
+    };
+    if (ix < ws && iy < hs) {
+        float d[3];
+        gain_ray(cv, (float)(1 + stride * ix), (float)(1 + stride * iy), d);
+        const float dn = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+        int cov[kGainMaxCover];
+        float col[kGainMaxCover][3];
+        int k = 0;
+        bool overflow = false;
+        for (int i = 0; i < n_img; ++i) {
+            const DevImage& im = imgs[i];
+            const float cam2 = fmaf(d[2], im.R[8], fmaf(d[1], im.R[5], d[0] * im.R[2]));
+            if (!(cam2 >= im.cmin * dn)) continue;  // outside the image's cone: cannot project inside
+            float c3[3];
+            if (!gain_sample(im, d, c3)) continue;
+            if (k < kGainMaxCover) {
+                cov[k] = i;
+                col[k][0] = c3[0];
+                col[k][1] = c3[1];
+                col[k][2] = c3[2];
+                ++k;
+            } else {
+                overflow = true;
+            }
+        }
+        if (!overflow) {
+            for (int a = 0; a < k; ++a)
+                for (int b = a + 1; b < k; ++b) add_pair(cov[a], cov[b], col[a], col[b]);
+        } else {  // more than kGainMaxCover images see this point: recompute pair by pair
+            for (int i = 0; i < n_img; ++i) {
+                float ci[3];
+                if (!gain_sample(imgs[i], d, ci)) continue;
+                for (int j = i + 1; j < n_img; ++j) {
+                    float cj[3];
+                    if (gain_sample(imgs[j], d, cj)) add_pair(i, j, ci, cj);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
+        const unsigned int key = s_key[e];
+        if (!key) continue;
+        const int i = (int)((key - 1u) / (unsigned int)n_img), j = (int)((key - 1u) % (unsigned int)n_img);
+        const size_t o = (size_t)i + (size_t)n_img * j;
+        atomicAdd(&Nij[o], (double)s_cnt[e]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(&sCi[o + nn * c], s_sum[e][c]);
+            atomicAdd(&sCj[o + nn * c], s_sum[e][3 + c]);
+        }
+    }
+}
+}  // namespace aps
+
+extern "C" int aps_gain_overlap_stats(const aps_image* images, int n_img, const aps_canvas* canvas, int stride,
+                                      double* n_ij, double* sum_ci, double* sum_cj) {
+    using namespace aps;
+    return guarded([&] {
+        APS_REQUIRE(images && canvas && n_ij && sum_ci && sum_cj, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(n_img >= 1 && n_img <= 46340, APS_E_ARG, "bad image count");
+        APS_REQUIRE(stride >= 1, APS_E_ARG, "overlapStride must be >= 1");
+        ctx();
+        PreparedImages P;
+        prepare_images(images, n_img, P);
+        const DevCanvas cv = make_canvas(*canvas);
+        const size_t nn = (size_t)n_img * n_img;
+        Out<double> oN(n_ij, nn), oI(sum_ci, 3 * nn), oJ(sum_cj, 3 * nn);
+        APS_HIP(hipMemsetAsync(oN.get(), 0, nn * sizeof(double), stream()));
+        APS_HIP(hipMemsetAsync(oI.get(), 0, 3 * nn * sizeof(double), stream()));
+        APS_HIP(hipMemsetAsync(oJ.get(), 0, 3 * nn * sizeof(double), stream()));
+        const int ws = (cv.W - 1) / stride + 1, hs = (cv.H - 1) / stride + 1;  // numel(1:stride:W), numel(1:stride:H)
+        {
+            Prof prof("gain_stats");
+            gain_stats_kernel<<<dim3(cdiv(ws, 16), cdiv(hs, 16)), 256, 0, stream()>>>(cv, P.dev, n_img, stride, ws, hs, oN.get(),
+                                                                                   oI.get(), oJ.get());
+        }
+        check_launch("gain_stats_kernel");
+        oN.commit();
+        oI.commit();
+        oJ.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
 static void make_hwarp(const double* H, HWarp& hw) {
     double h[9];
     for (int e = 0; e < 9; ++e) h[e] = H[8] != 0 ? H[e] / H[8] : H[e];

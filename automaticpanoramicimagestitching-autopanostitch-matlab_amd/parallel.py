@@ -258,8 +258,26 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     sizes = [(int(images[k].shape[0]), int(images[k].shape[1]), 3) for k in members]
     opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
             "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": False}
+    gains = None
+    tg = time.perf_counter()
+    if input.get("gainCompensation"):
+        # gainCompensationRKf between cameras and render (renderPanorama.m:303-330).  The device sums in an
+        # unspecified order, so rank 0's gains are broadcast: every tile must be rendered with the same numbers.
+        from . import gainCompensation as gc
+
+        mem_cams = [cameras[k] for k in members]
+        o_ = rp.default_opts(opts, mem_cams, members.index(ref))
+        geo = rp.canvas_geometry(mem_cams, sizes, input["panorama2DisplaynSave"], members.index(ref), o_)
+        gains = gc.gainCompensationRKf([images[k] for k in members], mem_cams, input["panorama2DisplaynSave"],
+                                       members.index(ref), input, geo)
+        if ws > 1:
+            gt_ = torch.from_numpy(np.ascontiguousarray(gains)).to(dev)
+            dist.broadcast(gt_, 0)
+            gains = gt_.cpu().numpy()
+        times.add("gain_compensation", tg)
+        t0 = time.perf_counter()
     pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, [cameras[k] for k in members],
-                                input["panorama2DisplaynSave"], members.index(ref), opts, device_out=True,
+                                input["panorama2DisplaynSave"], members.index(ref), opts, gains=gains, device_out=True,
                                 tile_subset=(rank, ws) if ws > 1 else None)
     pl._sync()
     if ws > 1:

@@ -359,7 +359,8 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
       * opts['tile'] must be explicit; the reference derives it from free GPU/CPU memory (:269-298),
         which makes its multiband output machine dependent.  Default here: [2048 2048] clamped to the
         canvas — the value the reference's auto-tiler reaches whenever memory is plentiful.
-      * gain compensation stays on the host (north star): pass `gains` (N x 3) or ones are used.
+      * gains: pass `gains` (N x 3), or set opts['gainCompensation'] explicitly to have gainCompensationRKf run
+        (statistics on the device, solve on the host); otherwise ones.
       * annotations (insertShape/insertText) are not produced: rgbAnnotation is always None."""
     if cameras and (cameras[0].get("noRotation", 0) == 1 or input.get("forcePlanarScan", False)):
         # renderPanorama.m:78-90: planar scans bypass the tiled ray renderer
@@ -371,6 +372,12 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
     if o["tile"] is None:
         side = max(512, min(2048, geo["H"], geo["W"])) if min(geo["H"], geo["W"]) >= 512 else min(geo["H"], geo["W"])
         o["tile"] = (side, side)
+    if gains is None and opts and opts.get("gainCompensation"):
+        # renderPanorama.m:303-330: overlap statistics on the device, N x N solve on the host.  Only when the
+        # caller asks for it explicitly; otherwise gains are ones (or the caller's own).
+        from .gainCompensation import gainCompensationRKf
+
+        gains = gainCompensationRKf(images, cameras, mode, refIdx, opts, geo)
     arr, keep = make_image_structs(images, cameras, gains)
     cv = make_canvas_struct(geo)
     ro = make_render_opts(o)

@@ -51,6 +51,9 @@ def parse():
                     help="cameras for the render stage: initialised from the verified homographies (default) "
                          "or the synthetic ground truth")
     ap.add_argument("--save-pano", type=str, default="", help="write a downscaled PNG of the panorama (debug)")
+    ap.add_argument("--gain-compensation", action="store_true",
+                    help="also run gainCompensationRKf (device overlap statistics + host solve) before the render; "
+                         "off in the headline configuration, which follows BASELINE.json configs[2]")
     return ap.parse_args()
 
 
@@ -131,6 +134,8 @@ def main():
     n = nx * ny
     f = FOCAL * w / W
     input_ = pl.default_input(bands=args.bands)
+    if args.gain_compensation:
+        input_["gainCompensation"] = 1
 
     # synthetic inputs, resident in HBM before anything is timed (each rank renders only its shard)
     cams = synth.grid_cameras(nx, ny, w, h, f, 2 * np.arctan(w / (2 * f)) * (1 - OVERLAP),

@@ -280,6 +280,15 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                      const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
                      uint8_t* pano, uint8_t* covered);
 
+/* SURVEY 8(f) rank 1 -- the overlap statistics of gainCompensationRKf (PP/gainCompensation/gainCompensationRKf.m:96-149,
+ * 239-367): every `stride`-th canvas point (1-based coordinates, :106-107) that two images i < j both cover
+ * (front, inside, tent weight > 0) adds 1 to n_ij(i,j) and the two bilinear RAW (0..255) colour samples to
+ * sum_ci(i,j,:) / sum_cj(i,j,:).  Outputs: f64 N x N and N x N x 3, column-major, upper triangle, zero elsewhere.
+ * The N x N solve for the gains (:151-238) stays on the host.  Sums are added in an unspecified order: compare
+ * them with a relative tolerance (the reference itself sums in single per tile); counts are exact. */
+int aps_gain_overlap_stats(const aps_image* images, int n_img, const aps_canvas* canvas, int stride,
+                           double* n_ij, double* sum_ci, double* sum_cj);
+
 /* a15/a16 for ONE tile, layers out (for tests): rows r0..r0+ht-1, cols c0..c0+wt-1 (0-based) of
  * the canvas sampled from ONE image.  S: f32 ht x wt x 3 row-major interleaved, Wang/Wf: f32 ht x wt,
  * M: uint8 ht x wt (sampleOneTile, renderPanorama.m:1063-1146). */

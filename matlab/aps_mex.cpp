@@ -278,6 +278,42 @@ static void cmd_render(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
     if (nlhs > 1) plhs[1] = cov; else mxDestroyArray(cov);
 }
 
+// [Nij, sumCi, sumCj] = aps_mex('gain_overlap_stats', images cell, cameras struct, canvas struct, stride)
+static void cmd_gain(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 5 && mxIsCell(prhs[1]) && mxIsStruct(prhs[2]), "aps:type", "usage: images cell, cameras struct, canvas, stride");
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    std::vector<aps_image> im(n);
+    for (int i = 0; i < n; ++i) {
+        const mxArray* a = mxGetCell(prhs[1], i);
+        need(mxIsUint8(a), "aps:type", "images must be uint8");
+        const mwSize* d = mxGetDimensions(a);
+        im[i].data = (const uint8_t*)mxGetData(a);
+        im[i].height = (int)d[0];
+        im[i].width = (int)d[1];
+        im[i].channels = mxGetNumberOfDimensions(a) > 2 ? (int)d[2] : 1;
+        im[i].layout = APS_IMG_U8_MATLAB;
+        std::memcpy(im[i].K, mxGetPr(mxGetField(prhs[2], i, "K")), 9 * sizeof(double));
+        std::memcpy(im[i].R, mxGetPr(mxGetField(prhs[2], i, "R")), 9 * sizeof(double));
+        for (int c = 0; c < 3; ++c) im[i].gain[c] = 1.0f;
+    }
+    aps_canvas cv;
+    cv.mode = (int)field(prhs[3], "mode", APS_PROJ_SPHERICAL);
+    cv.height = (int)field(prhs[3], "H", 0);
+    cv.width = (int)field(prhs[3], "W", 0);
+    cv.f_pan = field(prhs[3], "fPan", 1);
+    cv.origin0 = field(prhs[3], "origin0", 0);
+    cv.origin1 = field(prhs[3], "origin1", 0);
+    const mxArray* rr = mxGetField(prhs[3], 0, "Rref");
+    for (int e = 0; e < 9; ++e) cv.R_ref[e] = rr ? mxGetPr(rr)[e] : (e % 4 == 0);
+    const mwSize d3[3] = {(mwSize)n, (mwSize)n, 3};
+    plhs[0] = mxCreateDoubleMatrix(n, n, mxREAL);
+    mxArray* si = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+    mxArray* sj = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+    check(aps_gain_overlap_stats(im.data(), n, &cv, (int)mxGetScalar(prhs[4]), mxGetPr(plhs[0]), mxGetPr(si), mxGetPr(sj)));
+    if (nlhs > 1) plhs[1] = si; else mxDestroyArray(si);
+    if (nlhs > 2) plhs[2] = sj; else mxDestroyArray(sj);
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
     const std::string cmd = str(prhs[0]);
@@ -293,5 +329,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "multiband_blend") cmd_blend(true, nlhs, plhs, nrhs, prhs);
     else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "gain_overlap_stats") cmd_gain(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
 }

@@ -385,6 +385,22 @@ def render(images, cameras, geo, tile, angle_power=2.0, blending="multiband", py
     return pano, cov
 
 
+_orc_gain_overlap_stats = _sig("orc_gain_overlap_stats", [_vp, _i, C.POINTER(orc_canvas), _i, _vp, _vp, _vp])
+
+
+def gain_overlap_stats(images, cameras, geo, stride=5):
+    """gainCompensationRKf's overlap statistics: (Nij [N,N], sumCi [N,N,3], sumCj [N,N,3]), upper triangle."""
+    arr, keep = _images(images, cameras)
+    cv = _canvas(geo)
+    n = len(images)
+    Nij = np.zeros((n, n), np.float64, order="F")
+    sCi = np.zeros((n, n, 3), np.float64, order="F")
+    sCj = np.zeros((n, n, 3), np.float64, order="F")
+    _orc_gain_overlap_stats(arr, n, C.byref(cv), int(stride), Nij.ctypes.data, sCi.ctypes.data, sCj.ctypes.data)
+    del keep
+    return np.ascontiguousarray(Nij), np.ascontiguousarray(sCi), np.ascontiguousarray(sCj)
+
+
 def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
     a = np.asarray(img)
     is_u8 = a.dtype == np.uint8

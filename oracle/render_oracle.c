@@ -570,3 +570,116 @@ ORC_API void orc_image_warp_h(const float* in, int in_h, int in_w, int C, const 
             }
         }
 }
+
+/* ================================================================================================
+ * Gain-compensation overlap statistics (PP/gainCompensation/gainCompensationRKf.m:96-149, 239-367,
+ * 369-579): for every stride-th canvas point (1-BASED coordinates, :106-107), every image pair (i < j)
+ * that both cover it contributes one count and the two bilinear RAW (0..255) colour samples.
+ * PARITY UNPINNED (interp2 is toolbox code).  Fixed here and mirrored by the HIP path: rays as in
+ * panoDirsGridTile (no normalisation), projection as in projectToImage (cz not clamped), coverage =
+ * finite(u,v) & front & inside [1,w]x[1,h] & bilinear(wy*wx) > 0, colours by the same bilinear form as
+ * sampleOneTile.  Sums are accumulated in double; the reference sums each tile in single first, and the
+ * device adds in an unspecified order, so consumers compare sums with a relative tolerance (counts are exact).
+ * Outputs are N x N (x 3) column-major, upper triangle.
+ * ================================================================================================ */
+static void gain_ray(const orc_canvas* cv, float xp, float yp, float* d) {
+    const float f = (float)cv->f_pan, o0 = (float)cv->origin0, o1 = (float)cv->origin1;
+    if (cv->mode == 0) {
+        const float th = o0 + xp / f, hl = o1 + yp / f;
+        d[0] = sinf(th); d[1] = hl; d[2] = cosf(th);
+    } else if (cv->mode == 1) {
+        const float th = o0 + xp / f, ph = o1 + yp / f;
+        const float cp = cosf(ph), sp = sinf(ph);
+        d[0] = cp * sinf(th); d[1] = sp; d[2] = cp * cosf(th);
+    } else {
+        float rx, ry, rz;
+        if (cv->mode == 2) {
+            rx = o0 + xp / f; ry = o1 + yp / f; rz = 1.0f;
+        } else {
+            const float a = o0 + xp / f, b = o1 + yp / f;
+            const float r2 = a * a + b * b, den = 1.0f + r2;
+            rx = 2.0f * a / den; ry = 2.0f * b / den; rz = (1.0f - r2) / den;
+        }
+        const double* R = cv->R_ref; /* Rt(r,c) = R(c,r): dw(r) = sum_c R(c,r) * dref(c) */
+        d[0] = ((float)R[0] * rx + (float)R[1] * ry) + (float)R[2] * rz;
+        d[1] = ((float)R[3] * rx + (float)R[4] * ry) + (float)R[5] * rz;
+        d[2] = ((float)R[6] * rx + (float)R[7] * ry) + (float)R[8] * rz;
+    }
+}
+
+static int gain_sample(const orc_image* im, const float* wx, const float* wy, const float* d, float* Cc) {
+    float R[9], fx = (float)im->K[0], fy = (float)im->K[4], cxp = (float)im->K[6], cyp = (float)im->K[7];
+    for (int e = 0; e < 9; ++e) R[e] = (float)im->R[e];
+    float cam[3];
+    for (int c = 0; c < 3; ++c) cam[c] = fmaf(d[2], R[c + 6], fmaf(d[1], R[c + 3], d[0] * R[c]));
+    const int front = cam[2] > 1e-6f;
+    const float u = fx * (cam[0] / cam[2]) + cxp;
+    const float v = fy * (cam[1] / cam[2]) + cyp;
+    const int w = im->width, h = im->height;
+    if (!front || !isfinite(u) || !isfinite(v)) return 0;
+    if (!((u >= 1.0f) && (u <= (float)w) && (v >= 1.0f) && (v <= (float)h))) return 0; /* interp2 -> NaN */
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    if (x0 > w - 1) x0 = w - 1;
+    if (y0 > h - 1) y0 = h - 1;
+    if (x0 < 1) x0 = 1;
+    if (y0 < 1) y0 = 1;
+    const int x1 = x0 + 1 <= w ? x0 + 1 : w, y1 = y0 + 1 <= h ? y0 + 1 : h;
+    const float s = u - (float)x0, t = v - (float)y0;
+    const float f00 = wy[y0 - 1] * wx[x0 - 1], f10 = wy[y0 - 1] * wx[x1 - 1];
+    const float f01 = wy[y1 - 1] * wx[x0 - 1], f11 = wy[y1 - 1] * wx[x1 - 1];
+    const float wtop = (1.0f - s) * f00 + s * f10, wbot = (1.0f - s) * f01 + s * f11;
+    const float wf = wtop * (1.0f - t) + wbot * t;
+    if (!(wf > 0.0f)) return 0;
+    const int C = im->channels;
+    for (int c = 0; c < 3; ++c) {
+        const int cc = C == 1 ? 0 : c;
+#define RAW(xx, yy) ((float)im->data[((size_t)((yy)-1) * w + ((xx)-1)) * C + cc])
+        const float v00 = RAW(x0, y0), v10 = RAW(x1, y0), v01 = RAW(x0, y1), v11 = RAW(x1, y1);
+#undef RAW
+        const float top = (1.0f - s) * v00 + s * v10;
+        const float bot = (1.0f - s) * v01 + s * v11;
+        Cc[c] = top * (1.0f - t) + bot * t;
+    }
+    return 1;
+}
+
+ORC_API void orc_gain_overlap_stats(const orc_image* imgs, int n, const orc_canvas* cv, int stride, double* Nij,
+                                    double* sumCi, double* sumCj) {
+    const size_t nn = (size_t)n * n;
+    memset(Nij, 0, nn * sizeof(double));
+    memset(sumCi, 0, 3 * nn * sizeof(double));
+    memset(sumCj, 0, 3 * nn * sizeof(double));
+    float** wx = (float**)malloc(sizeof(float*) * n);
+    float** wy = (float**)malloc(sizeof(float*) * n);
+    for (int i = 0; i < n; ++i) {
+        wx[i] = (float*)malloc(sizeof(float) * imgs[i].width);
+        wy[i] = (float*)malloc(sizeof(float) * imgs[i].height);
+        tent(imgs[i].width, wx[i]);
+        tent(imgs[i].height, wy[i]);
+    }
+    int* cov = (int*)malloc(sizeof(int) * n);
+    float* col = (float*)malloc(sizeof(float) * 3 * n);
+    if (stride < 1) stride = 1;
+    for (int yp = 1; yp <= cv->height; yp += stride)
+        for (int xp = 1; xp <= cv->width; xp += stride) {
+            float d[3];
+            gain_ray(cv, (float)xp, (float)yp, d);
+            int k = 0;
+            for (int i = 0; i < n; ++i)
+                if (gain_sample(&imgs[i], wx[i], wy[i], d, col + 3 * k)) cov[k++] = i;
+            for (int a = 0; a < k; ++a)
+                for (int b = a + 1; b < k; ++b) {
+                    const size_t e = (size_t)cov[a] + (size_t)n * cov[b];
+                    Nij[e] += 1.0;
+                    for (int c = 0; c < 3; ++c) {
+                        sumCi[e + nn * c] += (double)col[3 * a + c];
+                        sumCj[e + nn * c] += (double)col[3 * b + c];
+                    }
+                }
+        }
+    for (int i = 0; i < n; ++i) {
+        free(wx[i]);
+        free(wy[i]);
+    }
+    free(wx); free(wy); free(cov); free(col);
+}

@@ -274,3 +274,46 @@ def test_image_warp_bit_exact(ip):
     assert np.array_equal(bits(outf), bits(reff))
     (xl, yl) = ip.outputLimitsScratch(H, (0.5, 120.5), (0.5, 90.5))
     assert xl[0] < 10 and xl[1] > 120 and yl[0] < 0
+
+
+# ---- gain-compensation overlap statistics ---------------------------------------------------
+@pytest.mark.parametrize("mode,stride", [("spherical", 3), ("cylindrical", 5), ("planar", 2), ("stereographic", 1)])
+def test_gain_overlap_stats_match_oracle(gpu, rp, mode, stride):
+    gc = import_module(gpu.__name__ + ".gainCompensation")
+    rng = np.random.default_rng(41)
+    imgs, cams = _scene(rng, n=5, W=180, H=120, f=260.0)
+    gains_true = np.array([1.0, 0.8, 1.25, 0.9, 1.1])
+    imgs = [np.clip(im.astype(np.float32) * g, 0, 255).astype(np.uint8) for im, g in zip(imgs, gains_true)]
+    sizes = [(120, 180, 3)] * 5
+    o = rp.default_opts({"anglePower": 2}, cams, 2)
+    geo = rp.canvas_geometry(cams, sizes, mode, 2, o)
+    Nij, sCi, sCj = gc.gain_overlap_stats(imgs, cams, geo, stride)
+    oN, oI, oJ = oracle.gain_overlap_stats(imgs, cams, geo, stride)
+    # counts: the rays differ only through sinf/cosf (<= 2 ulp), so a sample within rounding of an image border may flip
+    assert Nij.shape == (5, 5) and np.all(np.tril(Nij) == 0) and oN.sum() > 500
+    assert np.abs(Nij - oN).sum() <= 2e-3 * oN.sum()
+    big = oN >= 50
+    assert big.sum() >= 3
+    assert np.allclose((sCi / np.maximum(Nij, 1)[..., None])[big], (oI / np.maximum(oN, 1)[..., None])[big], rtol=2e-3)
+    assert np.allclose((sCj / np.maximum(Nij, 1)[..., None])[big], (oJ / np.maximum(oN, 1)[..., None])[big], rtol=2e-3)
+    g = gc.solve_gains(Nij, sCi, sCj, {"minOverlapSamples": 50})
+    go = gc.solve_gains(oN, oI, oJ, {"minOverlapSamples": 50})
+    assert g.shape == (5, 3) and np.allclose(g, go, rtol=2e-3) and np.all((g >= 0.25) & (g <= 4.0))
+
+
+def test_gain_compensation_recovers_planted_gains(gpu, rp):
+    """Views of one scene scaled by known factors: the solved gains must undo them (up to the common scale the
+    sigma_g prior fixes near 1) and the compensated render must be more uniform than the raw one."""
+    gc = import_module(gpu.__name__ + ".gainCompensation")
+    rng = np.random.default_rng(43)
+    imgs, cams = _scene(rng, n=4, W=200, H=140, f=300.0)
+    smooth = [np.clip(60 + 0.5 * im.astype(np.float32), 0, 255) for im in imgs]
+    planted = np.array([1.0, 0.7, 1.3, 0.85])
+    imgs2 = [np.clip(s * p, 0, 255).astype(np.uint8) for s, p in zip(smooth, planted)]
+    sizes = [(140, 200, 3)] * 4
+    o = rp.default_opts({"anglePower": 2}, cams, 1)
+    geo = rp.canvas_geometry(cams, sizes, "spherical", 1, o)
+    g = gc.gainCompensationRKf(imgs2, cams, "spherical", 1, {"overlapStride": 2, "minOverlapSamples": 30}, geo)
+    prod = g[:, 0] * planted
+    assert prod.std() / prod.mean() < 0.08  # g_i * planted_i is (nearly) one constant
+    assert np.allclose(g[:, 0], g[:, 1], rtol=0.05)
