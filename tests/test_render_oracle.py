@@ -186,3 +186,25 @@ def test_image_warp_identity_and_shift():
     out = oracle.image_warp_h(img, T, 20, 30, 1.0, 1.0, 1.0, 1.0, fill=0)
     assert np.array_equal(out[2:-1, 4:-1], img[:-3, :-5])
     assert np.all(out[:2] == 0) and np.all(out[:, :4] == 0)
+
+
+def test_gain_overlap_statistics_analytic_cases():
+    """gainCompensationRKf.m:239-367 on cases with a known answer: two identical cameras looking at constant images
+    count every sampled point whose tent weight is positive, sums are count x the constants; a third image that
+    looks the other way never pairs; the canvas is sampled at 1-based 1:stride:W (:106-107)."""
+    W, H, f = 64, 48, 80.0
+    imgs = [np.full((H, W, 3), v, np.uint8) for v in (100, 150, 200)]
+    for k in range(3):
+        imgs[k][..., 1] = imgs[k][..., 0] // 2
+    cams = [cam(f, W, H), cam(f, W, H), cam(f, W, H, yaw=math.pi)]
+    # planar canvas whose 1-based point (xp, yp) is image pixel (xp, yp): u = f*(u0 + xp/f) + W/2 = xp  =>  u0 = -W/(2f)
+    geo = geo_planar(f, W, H, -W / (2 * f), -H / (2 * f))
+    for stride in (1, 3):
+        N, sI, sJ = oracle.gain_overlap_stats(imgs, cams, geo, stride)
+        xs, ys = np.arange(1, W + 1, stride), np.arange(1, H + 1, stride)
+        wx, wy = oracle.tent(W), oracle.tent(H)
+        expect = int(((wx[xs - 1] > 0)[None, :] & (wy[ys - 1] > 0)[:, None]).sum())  # border rows/cols have weight 0
+        assert N[0, 1] == expect and N.sum() == expect  # only the pair (0, 1); image 2 faces away
+        assert np.allclose(sI[0, 1], [100 * expect, 50 * expect, 100 * expect])
+        assert np.allclose(sJ[0, 1], [150 * expect, 75 * expect, 150 * expect])
+        assert np.all(np.tril(N) == 0)
