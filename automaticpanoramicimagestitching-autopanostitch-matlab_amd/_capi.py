@@ -19,6 +19,7 @@ APS_OK, APS_E_ARG, APS_E_DIM, APS_E_TYPE, APS_E_OOM, APS_E_DEVICE, APS_E_INTERNA
     0, -1, -2, -3, -4, -5, -6, -7)
 APS_COLMAJOR, APS_ROWMAJOR = 0, 1
 APS_ROBUST_RANSAC, APS_ROBUST_MLESAC = 0, 1
+APS_RESIZE_BILINEAR, APS_RESIZE_BICUBIC = 0, 1
 APS_TFORM_PROJECTIVE = 0
 APS_PROJ_CYLINDRICAL, APS_PROJ_SPHERICAL, APS_PROJ_PLANAR, APS_PROJ_STEREOGRAPHIC = 0, 1, 2, 3
 APS_BLEND_NONE, APS_BLEND_LINEAR, APS_BLEND_MULTIBAND = 0, 1, 2
@@ -113,6 +114,7 @@ _SIGNATURES = {
     "aps_warp_tile": [C.POINTER(aps_image), C.POINTER(aps_canvas), _i, _i, _i, _i, _f, _vp, _vp, _vp,
                       _vp],
     "aps_gain_overlap_stats": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), _i, _vp, _vp, _vp],
+    "aps_imresize_u8": [_vp, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp],
     "aps_multiband_blend": [_vp, _vp, _i, _i, _i, _i, _f, _vp],
     "aps_linear_blend": [_vp, _vp, _i, _i, _i, _vp],
     "aps_image_warp_h_u8": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, C.c_uint8, _vp],

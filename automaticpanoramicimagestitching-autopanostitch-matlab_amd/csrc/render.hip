@@ -1680,6 +1680,95 @@ extern "C" int aps_gain_overlap_stats(const aps_image* images, int n_img, const 
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// imresize on uint8 images (resizeImagesToLimits.m:49-106) -- see oracle/render_oracle.c
+// ------------------------------------------------------------------------------------------------
+namespace aps {
+__device__ __forceinline__ double cubic_kernel(double x) {  // Keys, a = -0.5
+    const double a = fabs(x), a2 = a * a, a3 = a2 * a;
+    if (a <= 1.0) return (1.5 * a3 - 2.5 * a2) + 1.0;
+    if (a <= 2.0) return ((-0.5 * a3 + 2.5 * a2) - 4.0 * a) + 2.0;
+    return 0.0;
+}
+__device__ __forceinline__ size_t u8_index(int layout, int h, int w, int C, int y, int x, int c) {
+    return layout == APS_IMG_U8_HWC ? ((size_t)y * w + x) * C + c : (size_t)y + (size_t)h * ((size_t)x + (size_t)w * c);
+}
+// one output sample per thread along `dim` (0: rows, 1: columns); all channels
+__global__ void imresize_u8_dim_kernel(const uint8_t* __restrict__ in, int h, int w, int C, int layout, int dim,
+                                       int out_len, double scale, int bicubic, uint8_t* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // position along the other dimension
+    const int o = blockIdx.y;                             // output sample along `dim`
+    const int in_len = dim == 0 ? h : w, other = dim == 0 ? w : h;
+    if (q >= other) return;
+    const int oh = dim == 0 ? out_len : h, ow = dim == 0 ? w : out_len;
+    const double kw0 = bicubic ? 4.0 : 2.0;
+    const double kw = scale < 1.0 ? kw0 / scale : kw0;
+    const double u = (double)(o + 1) / scale + 0.5 * (1.0 - 1.0 / scale);
+    const int left = (int)floor(u - kw / 2.0);
+    int P = (int)ceil(kw) + 2;
+    if (P > 64) P = 64;
+    double s = 0;
+    for (int t = 0; t < P; ++t) {
+        const double dx = u - (double)(left + t);
+        const double arg = scale < 1.0 ? scale * dx : dx;
+        double v = bicubic ? cubic_kernel(arg) : (fabs(arg) < 1.0 ? 1.0 - fabs(arg) : 0.0);
+        if (scale < 1.0) v = scale * v;
+        s += v;
+    }
+    for (int c = 0; c < C; ++c) {
+        double acc = 0;
+        for (int t = 0; t < P; ++t) {
+            const double dx = u - (double)(left + t);
+            const double arg = scale < 1.0 ? scale * dx : dx;
+            double v = bicubic ? cubic_kernel(arg) : (fabs(arg) < 1.0 ? 1.0 - fabs(arg) : 0.0);
+            if (scale < 1.0) v = scale * v;
+            const double wt = v / s;
+            const int idx = min(max(left + t, 1), in_len) - 1;
+            const uint8_t px = dim == 0 ? in[u8_index(layout, h, w, C, idx, q, c)] : in[u8_index(layout, h, w, C, q, idx, c)];
+            acc = acc + wt * (double)px;
+        }
+        double r = acc < 0 ? -floor(-acc + 0.5) : floor(acc + 0.5);
+        r = r > 0 ? r : 0;
+        r = r > 255 ? 255 : r;
+        const size_t oi = dim == 0 ? u8_index(layout, oh, ow, C, o, q, c) : u8_index(layout, oh, ow, C, q, o, c);
+        out[oi] = (uint8_t)r;
+    }
+}
+}  // namespace aps
+
+extern "C" int aps_imresize_u8(const uint8_t* img, int h, int w, int c, int layout, int oh, int ow, double scale_r,
+                               double scale_c, int method, uint8_t* out) {
+    using namespace aps;
+    return guarded([&] {
+        APS_REQUIRE(img && out, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(h > 0 && w > 0 && oh > 0 && ow > 0 && c >= 1 && c <= 4, APS_E_DIM, "bad image size");
+        APS_REQUIRE(layout == APS_IMG_U8_HWC || layout == APS_IMG_U8_MATLAB, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(method == APS_RESIZE_BICUBIC || method == APS_RESIZE_BILINEAR, APS_E_ARG, "unknown method");
+        APS_REQUIRE(scale_r > 0 && scale_c > 0 && std::isfinite(scale_r) && std::isfinite(scale_c), APS_E_ARG, "bad scale");
+        APS_REQUIRE(4.0 / std::min(1.0, std::min(scale_r, scale_c)) + 2 <= 64, APS_E_ARG, "scale below 1/15 is not built");
+        ctx();
+        In<uint8_t> di(img, (size_t)h * w * c);
+        Out<uint8_t> dout(out, (size_t)oh * ow * c);
+        const int bic = method == APS_RESIZE_BICUBIC;
+        Prof prof("imresize_u8");
+        if (scale_r <= scale_c) {  // the dimension with the smaller scale first (ties: rows)
+            Ws<uint8_t> tmp((size_t)oh * w * c);
+            imresize_u8_dim_kernel<<<dim3(cdiv(w, 128), oh), 128, 0, stream()>>>(di, h, w, c, layout, 0, oh, scale_r, bic, tmp);
+            imresize_u8_dim_kernel<<<dim3(cdiv(oh, 128), ow), 128, 0, stream()>>>(tmp, oh, w, c, layout, 1, ow, scale_c, bic, dout.get());
+            check_launch("imresize_u8_dim_kernel");
+            dout.commit();
+            APS_HIP(hipStreamSynchronize(stream()));
+        } else {
+            Ws<uint8_t> tmp((size_t)h * ow * c);
+            imresize_u8_dim_kernel<<<dim3(cdiv(h, 128), ow), 128, 0, stream()>>>(di, h, w, c, layout, 1, ow, scale_c, bic, tmp);
+            imresize_u8_dim_kernel<<<dim3(cdiv(ow, 128), oh), 128, 0, stream()>>>(tmp, h, ow, c, layout, 0, oh, scale_r, bic, dout.get());
+            check_launch("imresize_u8_dim_kernel");
+            dout.commit();
+            APS_HIP(hipStreamSynchronize(stream()));
+        }
+    });
+}
+
 static void make_hwarp(const double* H, HWarp& hw) {
     double h[9];
     for (int e = 0; e < 9; ++e) h[e] = H[8] != 0 ? H[e] / H[8] : H[e];

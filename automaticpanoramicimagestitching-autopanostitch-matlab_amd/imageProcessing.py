@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _capi
 from ._capi import check, lib, ptr
 
 
@@ -60,3 +61,73 @@ def imageWarp(image, tform, outputView, method="bilinear", fillValue=0):
                                        float(fillValue), ptr(out)))
         out = out.astype(img.dtype) if img.dtype != np.float32 else out
     return out[..., 0] if squeeze else out
+
+
+def imresize(I, scale_or_size, method="bicubic"):
+    """J = imresize(I, s, method) / imresize(I, [oh ow], method) for uint8 images on the device (toolbox semantics
+    as restated in oracle/render_oracle.c).  The scalar form gives ceil(s * size) with scale s in both dimensions."""
+    import math
+
+    a = np.ascontiguousarray(I)
+    if a.dtype != np.uint8:
+        raise TypeError("uint8 images only")
+    sq = a.ndim == 2
+    if sq:
+        a = a[..., None]
+    h, w, c = a.shape
+    if np.isscalar(scale_or_size):
+        s = float(scale_or_size)
+        oh, ow, sr, sc = int(math.ceil(h * s)), int(math.ceil(w * s)), s, s
+    else:
+        oh, ow = int(scale_or_size[0]), int(scale_or_size[1])
+        sr, sc = oh / h, ow / w
+    m = {"bicubic": _capi.APS_RESIZE_BICUBIC, "bilinear": _capi.APS_RESIZE_BILINEAR}[str(method).lower()]
+    out = np.zeros((oh, ow, c), np.uint8)
+    check(lib.aps_imresize_u8(ptr(a), h, w, c, _capi.APS_IMG_U8_HWC, oh, ow, sr, sc, m, ptr(out)))
+    return out[..., 0] if sq else out
+
+
+def _center_crop(J, Ht, Wt):
+    h, w = J.shape[:2]
+    r0, c0 = (h - Ht) // 2, (w - Wt) // 2
+    return J[r0:r0 + Ht, c0:c0 + Wt]
+
+
+def resizeImagesToLimits(imageFiles, heightLimit, widthLimit, mode="fit"):
+    """imageFilesResized = resizeImagesToLimits(imageFiles, heightLimit, widthLimit, mode)
+    (resizeImagesToLimits.m:1-160): 'fit' (isotropic shrink to the box, then all images to the common largest size),
+    'pad' (fit, then replicate-pad to the box) or 'fillcrop' (cover, then centre crop).  Resizing runs on the device."""
+    mode = str(mode).lower()
+    if mode not in ("fit", "pad", "fillcrop"):
+        raise ValueError(f"unknown mode '{mode}'")
+    stage1 = []
+    for I in imageFiles:
+        I = np.asarray(I)
+        if I.size == 0:
+            stage1.append(I)
+            continue
+        h, w = I.shape[:2]
+        if mode in ("fit", "pad"):
+            s = min(heightLimit / h, widthLimit / w)
+            if not np.isfinite(s) or s <= 0:
+                s = 1
+            J = imresize(I, s, "bicubic") if s < 1 else I
+            if mode == "pad":
+                if J.shape[0] > heightLimit or J.shape[1] > widthLimit:
+                    J = _center_crop(J, min(heightLimit, J.shape[0]), min(widthLimit, J.shape[1]))
+                ph, pw = heightLimit - J.shape[0], widthLimit - J.shape[1]
+                pad = ((ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)) + (((0, 0),) if J.ndim == 3 else ())
+                J = np.pad(J, pad, mode="edge")
+        else:
+            s = max(heightLimit / h, widthLimit / w)
+            if not np.isfinite(s) or s <= 0:
+                s = 1
+            J = _center_crop(imresize(I, s, "bicubic"), heightLimit, widthLimit)
+        stage1.append(J)
+    if mode != "fit":
+        return stage1
+    sizes = {(J.shape[0], J.shape[1]) for J in stage1 if J.size}
+    if len(sizes) <= 1:
+        return stage1
+    Hmax, Wmax = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    return [J if J.size == 0 else imresize(J, (Hmax, Wmax), "bicubic") for J in stage1]

@@ -280,6 +280,14 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                      const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
                      uint8_t* pano, uint8_t* covered);
 
+/* SURVEY 8(f) rank 2 -- imresize(I, s | [oh ow], 'bicubic' | 'bilinear') on a uint8 image, the preprocessing step in
+ * front of SIFT (PP/imageProcessing/resizeImagesToLimits.m:57-61,103; loadImages.m:66-68).  Antialiased on shrink,
+ * half-pixel centres, replicate borders, the smaller-scale dimension first, uint8 rounding after each pass.
+ * scale_r/scale_c: the per-dimension scales imresize uses (s, s for the scalar form; oh/h, ow/w for the size form). */
+enum { APS_RESIZE_BILINEAR = 0, APS_RESIZE_BICUBIC = 1 };
+int aps_imresize_u8(const uint8_t* img, int h, int w, int c, int layout, int oh, int ow, double scale_r, double scale_c,
+                    int method, uint8_t* out);
+
 /* SURVEY 8(f) rank 1 -- the overlap statistics of gainCompensationRKf (PP/gainCompensation/gainCompensationRKf.m:96-149,
  * 239-367): every `stride`-th canvas point (1-based coordinates, :106-107) that two images i < j both cover
  * (front, inside, tent weight > 0) adds 1 to n_ij(i,j) and the two bilinear RAW (0..255) colour samples to

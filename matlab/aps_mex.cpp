@@ -314,6 +314,19 @@ static void cmd_gain(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     if (nlhs > 2) plhs[2] = sj; else mxDestroyArray(sj);
 }
 
+// J = aps_mex('imresize_u8', I uint8 HxWxC, [oh ow], [scale_r scale_c], bicubic(0/1))
+static void cmd_imresize(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 5 && mxIsUint8(prhs[1]), "aps:type", "usage: I uint8, [oh ow], [scale_r scale_c], bicubic");
+    const mwSize* d = mxGetDimensions(prhs[1]);
+    const int h = (int)d[0], w = (int)d[1], c = mxGetNumberOfDimensions(prhs[1]) > 2 ? (int)d[2] : 1;
+    const double* sz = mxGetPr(prhs[2]);
+    const double* sc = mxGetPr(prhs[3]);
+    const mwSize od[3] = {(mwSize)sz[0], (mwSize)sz[1], (mwSize)c};
+    plhs[0] = mxCreateNumericArray(c > 1 ? 3 : 2, od, mxUINT8_CLASS, mxREAL);
+    check(aps_imresize_u8((const uint8_t*)mxGetData(prhs[1]), h, w, c, APS_IMG_U8_MATLAB, (int)sz[0], (int)sz[1], sc[0], sc[1],
+                          mxGetScalar(prhs[4]) != 0 ? APS_RESIZE_BICUBIC : APS_RESIZE_BILINEAR, (uint8_t*)mxGetData(plhs[0])));
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
     const std::string cmd = str(prhs[0]);
@@ -330,5 +343,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);
     else if (cmd == "gain_overlap_stats") cmd_gain(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "imresize_u8") cmd_imresize(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
 }

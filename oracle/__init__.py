@@ -401,6 +401,27 @@ def gain_overlap_stats(images, cameras, geo, stride=5):
     return np.ascontiguousarray(Nij), np.ascontiguousarray(sCi), np.ascontiguousarray(sCj)
 
 
+_orc_imresize_u8 = _sig("orc_imresize_u8", [_vp, _i, _i, _i, _i, _i, _d, _d, _i, _vp])
+
+
+def imresize_u8(img, scale_or_size, method="bicubic"):
+    """imresize(I, s) / imresize(I, [oh ow]) for uint8 images (resizeImagesToLimits.m:57-61,103)."""
+    a = np.ascontiguousarray(img, np.uint8)
+    sq = a.ndim == 2
+    if sq:
+        a = a[..., None]
+    h, w, c = a.shape
+    if np.isscalar(scale_or_size):
+        s = float(scale_or_size)
+        oh, ow, sr, sc = int(np.ceil(h * s)), int(np.ceil(w * s)), s, s
+    else:
+        oh, ow = int(scale_or_size[0]), int(scale_or_size[1])
+        sr, sc = oh / h, ow / w
+    out = np.zeros((oh, ow, c), np.uint8)
+    _orc_imresize_u8(a.ctypes.data, h, w, c, oh, ow, sr, sc, 1 if method == "bicubic" else 0, out.ctypes.data)
+    return out[..., 0] if sq else out
+
+
 def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
     a = np.asarray(img)
     is_u8 = a.dtype == np.uint8

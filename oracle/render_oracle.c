@@ -683,3 +683,90 @@ ORC_API void orc_gain_overlap_stats(const orc_image* imgs, int n, const orc_canv
     }
     free(wx); free(wy); free(cov); free(col);
 }
+
+/* ================================================================================================
+ * imresize(I, s | [oh ow], 'bicubic' | 'bilinear') on uint8 images -- the preprocessing step in front of SIFT
+ * (PP/imageProcessing/resizeImagesToLimits.m:49-106).  imresize is toolbox code: PARITY
+ * UNPINNED.  Fixed here and mirrored by the HIP path (public documentation of imresize/contributions):
+ * antialiasing on shrink (kernel stretched by 1/scale), half-pixel centres u = x/scale + 0.5(1 - 1/scale), P =
+ * ceil(width)+2 taps from floor(u - width/2), weights normalised to sum 1, indices clamped (replicate), the dimension
+ * with the smaller scale first (ties: rows), the intermediate image rounded and saturated back to uint8 (the mex
+ * kernel returns the input class), sums in double in tap order, round half away from zero.
+ * ================================================================================================ */
+static double cubic_kernel(double x) { /* Keys, a = -0.5 */
+    const double a = fabs(x), a2 = a * a, a3 = a2 * a;
+    if (a <= 1.0) return (1.5 * a3 - 2.5 * a2) + 1.0;
+    if (a <= 2.0) return ((-0.5 * a3 + 2.5 * a2) - 4.0 * a) + 2.0;
+    return 0.0;
+}
+static double tri_kernel(double x) {
+    const double a = fabs(x);
+    return a < 1.0 ? 1.0 - a : 0.0;
+}
+/* taps of output sample x (0-based): returns P, first 1-based index in *left, weights (sum 1) */
+static int u8_taps(int in_len, int x, double scale, int bicubic, int* left, double* wts /* >= 64 */) {
+    (void)in_len;
+    const double kw0 = bicubic ? 4.0 : 2.0;
+    const double kw = scale < 1.0 ? kw0 / scale : kw0;
+    const double u = (double)(x + 1) / scale + 0.5 * (1.0 - 1.0 / scale);
+    *left = (int)floor(u - kw / 2.0);
+    int P = (int)ceil(kw) + 2;
+    if (P > 64) P = 64;
+    double s = 0;
+    for (int t = 0; t < P; ++t) {
+        const double dx = u - (double)(*left + t);
+        const double arg = scale < 1.0 ? scale * dx : dx;
+        double v = bicubic ? cubic_kernel(arg) : tri_kernel(arg);
+        if (scale < 1.0) v = scale * v;
+        wts[t] = v;
+        s += v;
+    }
+    for (int t = 0; t < P; ++t) wts[t] = wts[t] / s;
+    return P;
+}
+static uint8_t sat_u8(double v) {
+    double r = v < 0 ? -floor(-v + 0.5) : floor(v + 0.5);
+    if (!(r > 0)) r = 0;
+    if (r > 255) r = 255;
+    return (uint8_t)r;
+}
+static void u8_resize_dim(const uint8_t* in, int h, int w, int C, int dim, int out_len, double scale, int bicubic,
+                          uint8_t* out) {
+    const int in_len = dim == 0 ? h : w;
+    const int oh = dim == 0 ? out_len : h, ow = dim == 0 ? w : out_len;
+    for (int o = 0; o < out_len; ++o) {
+        int left;
+        double wts[64];
+        const int P = u8_taps(in_len, o, scale, bicubic, &left, wts);
+        const int other = dim == 0 ? w : h;
+        for (int q = 0; q < other; ++q)
+            for (int c = 0; c < C; ++c) {
+                double acc = 0;
+                for (int t = 0; t < P; ++t) {
+                    int idx = left + t;
+                    idx = idx < 1 ? 1 : (idx > in_len ? in_len : idx);
+                    const uint8_t v = dim == 0 ? in[((size_t)(idx - 1) * w + q) * C + c] : in[((size_t)q * w + (idx - 1)) * C + c];
+                    acc = acc + wts[t] * (double)v;
+                }
+                if (dim == 0)
+                    out[((size_t)o * ow + q) * C + c] = sat_u8(acc);
+                else
+                    out[((size_t)q * ow + o) * C + c] = sat_u8(acc);
+            }
+    }
+    (void)oh;
+}
+ORC_API void orc_imresize_u8(const uint8_t* in, int h, int w, int C, int oh, int ow, double scale_r, double scale_c,
+                             int bicubic, uint8_t* out) {
+    if (scale_r <= scale_c) {
+        uint8_t* tmp = (uint8_t*)malloc((size_t)oh * w * C);
+        u8_resize_dim(in, h, w, C, 0, oh, scale_r, bicubic, tmp);
+        u8_resize_dim(tmp, oh, w, C, 1, ow, scale_c, bicubic, out);
+        free(tmp);
+    } else {
+        uint8_t* tmp = (uint8_t*)malloc((size_t)h * ow * C);
+        u8_resize_dim(in, h, w, C, 1, ow, scale_c, bicubic, tmp);
+        u8_resize_dim(tmp, h, ow, C, 0, oh, scale_r, bicubic, out);
+        free(tmp);
+    }
+}

@@ -317,3 +317,35 @@ def test_gain_compensation_recovers_planted_gains(gpu, rp):
     prod = g[:, 0] * planted
     assert prod.std() / prod.mean() < 0.08  # g_i * planted_i is (nearly) one constant
     assert np.allclose(g[:, 0], g[:, 1], rtol=0.05)
+
+
+# ---- preprocessing: imresize / resizeImagesToLimits ------------------------------------------
+@pytest.mark.parametrize("shape,arg,method", [((90, 130, 3), 0.37, "bicubic"), ((64, 48, 3), (40, 100), "bicubic"),
+                                              ((75, 75), 0.5, "bilinear"), ((33, 200, 3), 2.0, "bicubic"),
+                                              ((216, 384, 3), 800 / 3840, "bicubic"), ((50, 70, 3), (50, 35), "bilinear")])
+def test_imresize_u8_bit_exact(ip, shape, arg, method):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    out = ip.imresize(img, arg, method)
+    ref = oracle.imresize_u8(img, arg, method)
+    assert out.shape == ref.shape and out.dtype == np.uint8 and np.array_equal(out, ref)
+
+
+def test_resize_images_to_limits_modes(ip):
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (120, 200, 3), dtype=np.uint8), rng.integers(0, 256, (90, 90, 3), dtype=np.uint8),
+            rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)]
+    fit = ip.resizeImagesToLimits(imgs, 80, 100, "fit")
+    # 'fit': s = min(80/h, 100/w) < 1 shrinks, small images stay; then everything goes to the common largest size
+    assert {f.shape for f in fit} == {(80, 100, 3)} or len({f.shape for f in fit}) == 1
+    s0 = min(80 / 120, 100 / 200)
+    first = oracle.imresize_u8(imgs[0], s0, "bicubic")
+    Hm = max(first.shape[0], oracle.imresize_u8(imgs[1], min(80 / 90, 100 / 90), "bicubic").shape[0], 40)
+    Wm = max(first.shape[1], oracle.imresize_u8(imgs[1], min(80 / 90, 100 / 90), "bicubic").shape[1], 50)
+    assert fit[0].shape == (Hm, Wm, 3) and np.array_equal(fit[0], oracle.imresize_u8(first, (Hm, Wm), "bicubic"))
+    pad = ip.resizeImagesToLimits(imgs, 80, 100, "pad")
+    assert all(p.shape == (80, 100, 3) for p in pad) and np.array_equal(pad[2][20:60, 25:75], imgs[2])
+    crop = ip.resizeImagesToLimits(imgs, 80, 100, "fillcrop")
+    assert all(c.shape == (80, 100, 3) for c in crop)
+    with pytest.raises(ValueError):
+        ip.resizeImagesToLimits(imgs, 80, 100, "stretch")

@@ -208,3 +208,22 @@ def test_gain_overlap_statistics_analytic_cases():
         assert np.allclose(sI[0, 1], [100 * expect, 50 * expect, 100 * expect])
         assert np.allclose(sJ[0, 1], [150 * expect, 75 * expect, 150 * expect])
         assert np.all(np.tril(N) == 0)
+
+
+def test_imresize_u8_analytic_cases():
+    """imresize on uint8 (resizeImagesToLimits.m:57-61): a constant stays constant at any scale (weights are
+    normalised), the scalar form yields ceil(s * size), halving a linear ramp averages neighbouring pairs, and
+    upscaling by an integer factor keeps monotone ramps monotone (bicubic overshoot is clamped by uint8 saturation)."""
+    const = np.full((37, 53, 3), 91, np.uint8)
+    for s in (0.21, 0.5, 1.0, 1.7):
+        out = oracle.imresize_u8(const, s)
+        assert out.shape == (int(np.ceil(37 * s)), int(np.ceil(53 * s)), 3) and np.all(out == 91)
+    ramp = np.tile((np.arange(64, dtype=np.uint8) * 4)[None, :], (8, 1))
+    half = oracle.imresize_u8(ramp, (8, 32), "bilinear")
+    assert np.array_equal(half[0, 1:-1], ((ramp[0, 2:-2:2].astype(int) + ramp[0, 3:-1:2]) // 2).astype(np.uint8))
+    up = oracle.imresize_u8(ramp, 2.0, "bicubic")
+    assert up.shape == (16, 128) and np.all(np.diff(up[3].astype(int)) >= 0)
+    sat = np.zeros((4, 16), np.uint8)
+    sat[:, 8:] = 255  # a step: the cubic overshoot must saturate, not wrap
+    o = oracle.imresize_u8(sat, 3.0, "bicubic")
+    assert o.min() == 0 and o.max() == 255
