@@ -122,10 +122,82 @@ def exchange_items(local_ids, local_arrays, n_items, owner_of, width, dtype, dev
     return out
 
 
-def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None):
+class ImageGather:
+    """The all-gather of the uint8 source images, started early and collected late: the images exist before
+    anything is computed, the render needs them at the very end, and the ~1.6 GB (64 x 4K) it moves over xGMI
+    would otherwise sit on the critical path between RANSAC and render.  Equal-size images; rank r owns i % world."""
+
+    def __init__(self, local_images, n):
+        self.ws, self.rank = world()
+        self.n = n
+        self.local = local_images
+        self.work = None
+        if self.ws == 1:
+            return
+        first = next(iter(local_images.values()))
+        self.shape = tuple(first.shape)
+        per = (n + self.ws - 1) // self.ws  # slots per rank (the last ones may stay empty)
+        flat = first.numel()
+        self.send = torch.zeros((per, flat), dtype=torch.uint8, device=first.device)
+        for slot, i in enumerate(sorted(local_images)):
+            self.send[slot] = local_images[i].reshape(-1)
+        self.recv = torch.empty((self.ws * per, flat), dtype=torch.uint8, device=first.device)
+        self.per = per
+        self.work = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+
+    def wait(self):
+        if self.ws == 1:
+            return [self.local[i] for i in range(self.n)]
+        self.work.wait()
+        return [self.recv[(i % self.ws) * self.per + i // self.ws].reshape(self.shape) for i in range(self.n)]
+
+
+def tile_rects(H, W, tile):
+    """The tile loop of renderPanorama.m:342-406 / aps_render_tiles: rows outer, columns inner."""
+    TH, TW = int(tile[0]), int(tile[1])
+    return [(r0, c0, min(TH, H - r0), min(TW, W - c0)) for r0 in range(0, H, TH) for c0 in range(0, W, TW)]
+
+
+def gather_tiles_to_root(pano, tile, root=0):
+    """Rank r holds the tiles t % world == r of `pano` (H x W x C, zero elsewhere).  Instead of an all-reduce of
+    the whole canvas, every rank sends exactly its tiles to `root` (xGMI is point to point: the transfers of
+    the other ranks run side by side), which copies them into place.  Returns pano (complete on root only)."""
+    ws, rank = world()
+    if ws == 1:
+        return pano
+    H, W = int(pano.shape[0]), int(pano.shape[1])
+    rects = tile_rects(H, W, tile)
+    C_ = int(pano.shape[2])
+    sizes = [sum(ht * wt * C_ for t, (_, _, ht, wt) in enumerate(rects) if t % ws == r) for r in range(ws)]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=pano.dtype, device=pano.device)
+    off = 0
+    for t, (r0, c0, ht, wt) in enumerate(rects):
+        if t % ws == rank:
+            m = ht * wt * C_
+            buf[off:off + m] = pano[r0:r0 + ht, c0:c0 + wt].reshape(-1)
+            off += m
+    parts = [torch.empty_like(buf) for _ in range(ws)] if rank == root else None
+    dist.gather(buf, parts, dst=root)
+    if rank == root:
+        for r in range(ws):
+            if r == root:
+                continue
+            off = 0
+            for t, (r0, c0, ht, wt) in enumerate(rects):
+                if t % ws == r:
+                    m = ht * wt * C_
+                    pano[r0:r0 + ht, c0:c0 + wt] = parts[r][off:off + m].reshape(ht, wt, C_)
+                    off += m
+    return pano
+
+
+def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None):
     """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
     local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
-    Returns (panorama uint8 H x W x 3 CUDA tensor, identical on every rank; info dict)."""
+    pano_root: None = the panorama is combined on every rank (all-reduce); r = only rank r receives the tiles of
+    the others (cheaper; the other ranks return their own tiles only).
+    Returns (panorama uint8 H x W x 3 CUDA tensor; info dict)."""
     from . import _capi
     from . import featureMatching as fm
     from . import imageMatching as im
@@ -136,6 +208,11 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     dev = next(iter(local_images.values())).device if local_images else torch.device("cuda")
     times = pl.StageTimes()
     owner = lambda i: i % ws  # noqa: E731
+
+    # 0) the render will need every source image everywhere: start that all-gather now, collect it at step 6
+    t0 = time.perf_counter()
+    img_gather = ImageGather(local_images, n)
+    times.add("exchange", t0)
 
     # 1) SIFT on the local shard
     t0 = time.perf_counter()
@@ -243,14 +320,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
 
     # 6) render: all images everywhere, tiles t % world == rank, one all-reduce(MAX) of the canvas
     t0 = time.perf_counter()
+    images = img_gather.wait()
     if ws > 1:
-        H, W = next(iter(local_images.values())).shape[:2]
-        flat = {i: t.reshape(1, -1) for i, t in local_images.items()}
-        allimg = gather_by_owner(flat, owner, n, torch.empty((0, H * W * 3), dtype=torch.uint8, device=dev), None)
-        images = [a.reshape(H, W, 3) for a in allimg]
         torch.cuda.synchronize()  # the collective ran on RCCL's stream; the library reads the images on its own
-    else:
-        images = [local_images[i] for i in range(n)]
     times.add("exchange", t0)
     t0 = time.perf_counter()
     comp = labels[ref]
@@ -282,7 +354,11 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     pl._sync()
     if ws > 1:
         torch.cuda.synchronize()
-        dist.all_reduce(pano, op=dist.ReduceOp.MAX)
+        if pano_root is None:
+            dist.all_reduce(pano, op=dist.ReduceOp.MAX)  # disjoint tiles, zero elsewhere
+        else:
+            pano = gather_tiles_to_root(pano, tile, pano_root)
+        torch.cuda.synchronize()
     times.add("render", t0)
     info = {"times": dict(times), "n_features": counts, "n_pairs_verified": len(pairs), "n_components": int(ncomp),
             "panorama_shape": tuple(int(v) for v in pano.shape), "members": members, "cameras": cameras, "pairs": pairs, "models": models_l}

@@ -154,7 +154,7 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        return par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt)
+        return par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0)
 
     for _ in range(args.warmup):
         step()

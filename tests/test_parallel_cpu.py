@@ -52,6 +52,28 @@ def _worker(rank, world, port, q):
         arrays = [np.full((k + 1, 1), float(k)) for k in mine]
         allit = par.exchange_items(mine, arrays, len(w), lambda k: int(own[k]), 1, np.float64, dev)
         assert all(a.shape == (k + 1, 1) and (a == k).all() for k, a in enumerate(allit))
+        # the early image all-gather: 5 images of 6x4x3, image i on rank i % world
+        imgs = {i: torch.full((6, 4, 3), 10 * i + 1, dtype=torch.uint8) for i in par.shard_indices(5, world, rank)}
+        ig = par.ImageGather(imgs, 5)
+        got = ig.wait()
+        assert len(got) == 5 and all(g.shape == (6, 4, 3) and int(g[0, 0, 0]) == 10 * i + 1 and bool((g == g[0, 0, 0]).all())
+                                     for i, g in enumerate(got))
+        # tiles to the root: canvas 7x10x3 with 3x4 tiles (ragged edge tiles), tile t painted with t+1 by rank t % world
+        H, W = 7, 10
+        rects = par.tile_rects(H, W, (3, 4))
+        assert len(rects) == 9 and rects[0] == (0, 0, 3, 4) and rects[-1] == (6, 8, 1, 2)
+        pano = torch.zeros((H, W, 3), dtype=torch.uint8)
+        for t, (r0, c0, ht, wt) in enumerate(rects):
+            if t % world == rank:
+                pano[r0:r0 + ht, c0:c0 + wt] = t + 1
+        full = par.gather_tiles_to_root(pano.clone(), (3, 4), root=0)
+        if rank == 0:
+            for t, (r0, c0, ht, wt) in enumerate(rects):
+                assert bool((full[r0:r0 + ht, c0:c0 + wt] == t + 1).all()), t
+        red = pano.clone()
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)  # the all-ranks form gives the same canvas
+        if rank == 0:
+            assert torch.equal(red, full)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
