@@ -785,16 +785,20 @@ __device__ __forceinline__ float4 resize_at(const float4* __restrict__ in, int h
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ROWS_FIRST) {  // pass 1 resizes rows (at full width), pass 2 resizes columns
         for (int tc = 0; tc < Pc; ++tc) {
+            if (wc[tc] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int xx = min(max(lc + tc, 1), w) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], ld_rect(in, w, ir, xx, min(max(lr + tr, 1), h) - 1), v);
+            for (int tr = 0; tr < Pr; ++tr)
+                if (wr[tr] != 0.f) v = fma4(wr[tr], ld_rect(in, w, ir, xx, min(max(lr + tr, 1), h) - 1), v);
             a = fma4(wc[tc], v, a);
         }
     } else {
         for (int tr = 0; tr < Pr; ++tr) {
+            if (wr[tr] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int yy = min(max(lr + tr, 1), h) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], ld_rect(in, w, ir, min(max(lc + tc, 1), w) - 1, yy), v);
+            for (int tc = 0; tc < Pc; ++tc)
+                if (wc[tc] != 0.f) v = fma4(wc[tc], ld_rect(in, w, ir, min(max(lc + tc, 1), w) - 1, yy), v);
             a = fma4(wr[tr], v, a);
         }
     }
@@ -865,16 +869,20 @@ __global__ __launch_bounds__(256) void mb_blur_resize_kernel(PtrTab ins, RectTab
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ROWS_FIRST) {
         for (int tc = 0; tc < Pc; ++tc) {
+            if (wc[tc] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int xx = min(max(lc + tc, 1), w) - 1 - bx0;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], s_a[(min(max(lr + tr, 1), h) - 1 - by0) * BC + xx], v);
+            for (int tr = 0; tr < Pr; ++tr)
+                if (wr[tr] != 0.f) v = fma4(wr[tr], s_a[(min(max(lr + tr, 1), h) - 1 - by0) * BC + xx], v);
             a = fma4(wc[tc], v, a);
         }
     } else {
         for (int tr = 0; tr < Pr; ++tr) {
+            if (wr[tr] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int yy = min(max(lr + tr, 1), h) - 1 - by0;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], s_a[yy * BC + min(max(lc + tc, 1), w) - 1 - bx0], v);
+            for (int tc = 0; tc < Pc; ++tc)
+                if (wc[tc] != 0.f) v = fma4(wc[tc], s_a[yy * BC + min(max(lc + tc, 1), w) - 1 - bx0], v);
             a = fma4(wr[tr], v, a);
         }
     }
@@ -939,16 +947,20 @@ __global__ void mb_collapse_kernel(const float4* __restrict__ Fc, int ch, int cw
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ROWS_FIRST) {
         for (int tc = 0; tc < Pc; ++tc) {
+            if (wc[tc] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int xx = min(max(lc + tc, 1), cw) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tr = 0; tr < Pr; ++tr) v = fma4(wr[tr], Fc[(size_t)(min(max(lr + tr, 1), ch) - 1) * cw + xx], v);
+            for (int tr = 0; tr < Pr; ++tr)
+                if (wr[tr] != 0.f) v = fma4(wr[tr], Fc[(size_t)(min(max(lr + tr, 1), ch) - 1) * cw + xx], v);
             u = fma4(wc[tc], v, u);
         }
     } else {
         for (int tr = 0; tr < Pr; ++tr) {
+            if (wr[tr] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
             const int yy = min(max(lr + tr, 1), ch) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int tc = 0; tc < Pc; ++tc) v = fma4(wc[tc], Fc[(size_t)yy * cw + min(max(lc + tc, 1), cw) - 1], v);
+            for (int tc = 0; tc < Pc; ++tc)
+                if (wc[tc] != 0.f) v = fma4(wc[tc], Fc[(size_t)yy * cw + min(max(lc + tc, 1), cw) - 1], v);
             u = fma4(wr[tr], v, u);
         }
     }
