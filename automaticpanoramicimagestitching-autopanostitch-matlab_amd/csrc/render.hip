@@ -196,22 +196,60 @@ __global__ void to_rgba_kernel(const uint8_t* __restrict__ src, int h, int w, in
 // into boxes.  The footprint therefore has block granularity (a superset of the mask, which is all it must be).
 __global__ __launch_bounds__(256) void cover_kernel(DevCanvas cv, const DevImage* __restrict__ imgs,
                                                      int n_img, int r0, int c0, int ht, int wt,
-                                                     float angle_pow, int nby, int xshift,
+                                                     float angle_pow, int nby, int xshift, int block_cull,
                                                      unsigned long long* __restrict__ rowmask) {
-    __shared__ unsigned long long s_any;
+    __shared__ unsigned long long s_any, s_cand;
+    __shared__ float s_dc[3];
+    __shared__ int s_cosb;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool in_tile = x < wt && y < ht;
     float d[3] = {0.f, 0.f, 1.f};
     if (in_tile) canvas_ray(cv, (float)(c0 + x), (float)(r0 + y), d);
     const float dn = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+    // Block-level cull: the ray of the block's centre pixel and the widest angle theta_b between it and any ray of
+    // the block; image i can be seen from the block only if angle(centre, axis_i) <= theta_i + theta_b.  The
+    // per-pixel loop then runs over those candidates only (typically 2-6 of 64 images).
+    if (threadIdx.x == 0) {
+        float dc[3];
+        canvas_ray(cv, (float)(c0 + min(blockIdx.x * 32 + 16, (unsigned)wt - 1)), (float)(r0 + min(blockIdx.y * 8 + 4, (unsigned)ht - 1)), dc);
+        s_dc[0] = dc[0];
+        s_dc[1] = dc[1];
+        s_dc[2] = dc[2];
+        s_cosb = __float_as_int(1.0f);
+    }
+    __syncthreads();
+    {
+        float cb = in_tile ? fmaf(d[2], s_dc[2], fmaf(d[1], s_dc[1], d[0] * s_dc[0])) / fmaxf(dn, 1e-8f) : 1.0f;
+        cb = fminf(fmaxf(cb, 0.0f), 1.0f);  // non-negative floats order like their bit patterns
+        for (int off = 32; off > 0; off >>= 1) cb = fminf(cb, __shfl_xor(cb, off));
+        if ((threadIdx.x & 63) == 0) atomicMin(&s_cosb, __float_as_int(cb));
+    }
+    __syncthreads();
+    const float cosb = fmaxf(__int_as_float(s_cosb) - 1e-6f, 0.0f), sinb = sqrtf(fmaxf(0.0f, 1.0f - cosb * cosb));
     const unsigned long long colbit = 1ull << (blockIdx.x >> xshift);
     for (int base = 0; base < n_img; base += 64) {
-        if (threadIdx.x == 0) s_any = 0ull;
+        const int cnt = min(64, n_img - base);
+        if (threadIdx.x < 64) {
+            bool cand = false;
+            if (threadIdx.x < cnt) {
+                const DevImage& im = imgs[base + threadIdx.x];
+                const float ca = fmaf(s_dc[2], im.R[8], fmaf(s_dc[1], im.R[5], s_dc[0] * im.R[2]));
+                const float ci = im.cmin, si = sqrtf(fmaxf(0.0f, 1.0f - ci * ci));
+                // cos(theta_i + theta_b), valid while the sum stays below 90 degrees; otherwise keep the image
+                cand = !block_cull || ci <= 0.0f || cosb <= 0.0f || ci * cosb - si * sinb <= 0.0f ||
+                       ca >= (ci * cosb - si * sinb) - 1e-5f;
+            }
+            const unsigned long long b = __ballot(cand);
+            if (threadIdx.x == 0) {
+                s_cand = b;
+                s_any = 0ull;
+            }
+        }
         __syncthreads();
         unsigned long long mine = 0ull;  // wave-uniform: images (of this group of 64) seen by this wave
-        const int cnt = min(64, n_img - base);
-        for (int i = 0; i < cnt; ++i) {
+        for (unsigned long long todo = s_cand; todo; todo &= todo - 1) {
+            const int i = __ffsll((long long)todo) - 1;
             const DevImage& im = imgs[base + i];
             // necessary condition first (three fmas): the ray must lie inside the image's cone about its optical
             // axis; a wave that is wholly outside skips the projection.  cam2 is project()'s own expression.
@@ -1408,7 +1446,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                     const Tile& tl = tiles[t];
                     cover_kernel<<<dim3(cdiv(tl.wt, 32), cdiv(tl.ht, 8)), 256, 0, stream()>>>(
                         cv, P.dev, n_img, tl.r0, tl.c0, tl.ht, tl.wt, opts->angle_power, nby_max, dims[4 * t + 3],
-                        rowmask.get() + (size_t)t * n_img * nby_max);
+                        std::getenv("APS_RENDER_NO_CULL") ? 0 : 1, rowmask.get() + (size_t)t * n_img * nby_max);
                 }
                 footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, ddims, n_img, nby_max,
                                                                                      nt * n_img, bbox);
