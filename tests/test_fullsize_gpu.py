@@ -1,0 +1,84 @@
+"""Size-independent properties at the sizes BASELINE.json quotes (the oracle would need minutes to hours here):
+~20k-feature all-pairs matching, a 4K SIFT, a multi-tile 4K render.  These complement the bit-exact parity tests,
+which run at sizes the oracle finishes in seconds."""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(gpu):
+    g = gpu.__name__
+    return {k: import_module(g + "." + k) for k in ("featureMatching", "synth", "renderPanorama")}
+
+
+def test_matching_20k_permutation_and_mode_equality(mods, monkeypatch):
+    """A x permuted(A) at Kf = 19828: every row's nearest neighbour is its own copy at distance 0 (to rounding), the one-to-one
+    filter keeps all rows, and the certified split-bf16 path returns the same bits as the all-f32 path."""
+    import torch
+
+    fm = mods["featureMatching"]
+    n = 19828
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.rand(n, 128, device="cuda", generator=g) ** 3
+    A = (A / A.norm(dim=1, keepdim=True)).contiguous()
+    perm = torch.randperm(n, device="cuda", generator=g)
+    B = A[perm].contiguous()
+    torch.cuda.synchronize()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device="cuda")
+    res = {}
+    for mode in ("split", "f32"):
+        monkeypatch.setenv("APS_MATCH_MODE", mode)
+        _, idx, d1, d2 = fm.nearest2SSDExhaustive(A, B)
+        res[mode] = (idx, d1, d2)
+    monkeypatch.delenv("APS_MATCH_MODE")
+    idx, d1, d2 = res["split"]
+    assert np.array_equal(idx.astype(np.int64) - 1, inv.cpu().numpy())
+    # a2 and b2 come from a mul/add chain, the dot product from an fma chain: a copy is at distance 0 up to a few ulp of 2
+    assert np.all(np.abs(d1) <= 1e-6) and np.all(d2 > 1e-3)
+    for a, b in zip(res["split"], res["f32"]):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    m, met = fm.matchFeaturesScratch(A, B, MatchThreshold=1.5, MaxRatio=0.6)
+    assert len(m) == n and np.array_equal(m[:, 1].astype(np.int64) - 1, inv.cpu().numpy()[m[:, 0].astype(np.int64) - 1])
+    assert np.all(np.abs(met) <= 1e-6)
+
+
+def test_sift_4k_is_deterministic_and_well_formed(mods):
+    fm, synth = mods["featureMatching"], mods["synth"]
+    imgs, _ = synth.make_scene(1, 1, 3840, 2160, 8000.0, device="cuda", finest_px=16.0)
+    inp = {"detector": "SIFT", "Sigma": 1.6, "NumLayersInOctave": 4, "ContrastThreshold": 0.00133, "EdgeThreshold": 6}
+    f1, p1 = fm.sift_extract(inp, imgs[0])
+    f2, p2 = fm.sift_extract(inp, imgs[0])
+    assert f1.shape == f2.shape and np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and np.array_equal(p1, p2)
+    assert f1.shape[0] > 10000 and f1.shape[1] == 128 and f1.dtype == np.float32 and p1.dtype == np.float64
+    assert np.allclose(np.linalg.norm(f1, axis=1), 1.0, atol=1e-5) and f1.min() >= 0
+    assert p1[:, 0].min() >= 1 and p1[:, 0].max() <= 3840 and p1[:, 1].min() >= 1 and p1[:, 1].max() <= 2160
+
+
+def test_render_4k_multitile_culls_change_no_byte(mods, monkeypatch):
+    """16 4K views (4 x 4 grid), 2048^2 tiles, 5 bands: the footprint culls, the block-level image cull and the fused
+    pyramid levels on, against all of them off."""
+    import torch
+
+    synth, rp = mods["synth"], mods["renderPanorama"]
+    W, H, f = 3840, 2160, 8000.0
+    cams = synth.grid_cameras(4, 4, W, H, f, 2 * np.arctan(W / (2 * f)) * 0.6, 2 * np.arctan(H / (2 * f)) * 0.6, 1.0, 12345)
+    imgs = [synth.render_view(c, H, W, 12345, "cuda", finest_px=16.0) for c in cams]
+    torch.cuda.synchronize()
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
+    sizes = [(H, W, 3)] * 16
+    outs = []
+    for env in ({}, {"APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
+        for k in ("APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pano, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 5, opts, device_out=True)
+        outs.append(pano)
+    assert outs[0].shape[0] > 4096 and outs[0].shape[1] > 8192 and int((outs[0] > 0).sum()) > 5e7
+    assert torch.equal(outs[0], outs[1])
