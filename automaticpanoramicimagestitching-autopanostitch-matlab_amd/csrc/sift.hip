@@ -397,28 +397,28 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         const int ly = e / NV, v = e - ly * NV;
         const int gy = min(max(y0 + ly - 1, 0), h - 1), gx = x0 - 4 + 4 * v;
         const size_t rowoff = (size_t)gy * w;
+        // All plane loads are issued back to back (planes beyond nl + 3 re-read plane 0 and are ignored): with an
+        // early exit between the loads the compiler waits for each one before testing the next, and the seven
+        // round trips in series made this kernel latency-bound (83 % of its wave cycles sat in s_waitcnt).
         if (vec_ok && gx >= 0 && gx + 3 < w) {
-            float4 prev = *reinterpret_cast<const float4*>(od.G[0] + rowoff + gx);
+            float4 g[8];
 #pragma unroll
-            for (int p = 0; p < 7; ++p) {
-                if (p >= nl + 2) break;
-                const float4 cur = *reinterpret_cast<const float4*>(od.G[p + 1] + rowoff + gx);
-                *reinterpret_cast<float4*>(&s_d[p][ly * TW + 4 * v]) =
-                    make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
-                prev = cur;
-            }
+            for (int p = 0; p < 8; ++p) g[p] = *reinterpret_cast<const float4*>(od.G[p < nl + 3 ? p : 0] + rowoff + gx);
+#pragma unroll
+            for (int p = 0; p < 7; ++p)
+                if (p < nl + 2)
+                    *reinterpret_cast<float4*>(&s_d[p][ly * TW + 4 * v]) =
+                        make_float4(g[p + 1].x - g[p].x, g[p + 1].y - g[p].y, g[p + 1].z - g[p].z, g[p + 1].w - g[p].w);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const size_t off = rowoff + min(max(gx + q, 0), w - 1);
-                float prev = od.G[0][off];
+                float g[8];
 #pragma unroll
-                for (int p = 0; p < 7; ++p) {
-                    if (p >= nl + 2) break;
-                    const float cur = od.G[p + 1][off];
-                    s_d[p][ly * TW + 4 * v + q] = cur - prev;
-                    prev = cur;
-                }
+                for (int p = 0; p < 8; ++p) g[p] = od.G[p < nl + 3 ? p : 0][off];
+#pragma unroll
+                for (int p = 0; p < 7; ++p)
+                    if (p < nl + 2) s_d[p][ly * TW + 4 * v + q] = g[p + 1] - g[p];
             }
         }
     }
