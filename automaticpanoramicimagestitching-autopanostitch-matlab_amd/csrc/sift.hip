@@ -189,8 +189,15 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
     constexpr int RP = (R + 3) & ~3, OFF = RP - R;
     constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
-    __shared__ __attribute__((aligned(16))) float s_in[IH * IW];
-    __shared__ __attribute__((aligned(16))) float s_row[IH * kTW];
+    // LDS pitches.  In the row pass the lanes of a wave take CONSECUTIVE ROWS of one 8-output segment, so a read
+    // instruction touches addresses P*ly + const: the pitch is chosen so that those land on distinct banks for the
+    // read width the segment start allows (OFF % 4 == 0: 16-byte reads, P = 4 mod 8; OFF even: 8-byte reads,
+    // P = 2 mod 4; OFF odd: 4-byte reads, P odd).  With eight threads side by side on one row (the previous mapping)
+    // every read was an 8-way bank conflict (SQ_LDS_BANK_CONFLICT was 3.5x the LDS-active cycles).
+    constexpr int IP = IW + (OFF % 4 == 0 ? 4 : (OFF % 2 == 0 ? 2 : 1));
+    constexpr int RPITCH = kTW + 4;  // s_row: 16-byte writes from consecutive rows, column reads by consecutive lanes
+    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
+    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
     const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
@@ -207,15 +214,19 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
             val.z = row[reflect101(gx + 2, w)];
             val.w = row[reflect101(gx + 3, w)];
         }
-        *reinterpret_cast<float4*>(&s_in[ly * IW + 4 * v]) = val;
+        float* dst = &s_in[ly * IP + 4 * v];
+        dst[0] = val.x;
+        dst[1] = val.y;
+        dst[2] = val.z;
+        dst[3] = val.w;
     }
     __syncthreads();
-    // row pass: IH rows x 64 cols, 8 consecutive outputs per thread
+    // row pass: IH rows x 64 cols, 8 consecutive outputs per thread; consecutive lanes = consecutive rows
     for (int u = tid; u < IH * (kTW / 8); u += 256) {
-        const int ly = u / (kTW / 8), xb = (u - ly * (kTW / 8)) * 8;
+        const int seg = u / IH, ly = u - seg * IH, xb = seg * 8;
         float v[8 + 2 * R], acc[8];
 #pragma unroll
-        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IW + OFF + xb + j];
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IP + OFF + xb + j];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
@@ -224,8 +235,8 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
         }
-        *reinterpret_cast<float4*>(&s_row[ly * kTW + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(&s_row[ly * kTW + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        *reinterpret_cast<float4*>(&s_row[ly * RPITCH + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(&s_row[ly * RPITCH + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
     // column pass: 64 cols x kTH/8 groups of 8 rows
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
         const int lx = u & (kTW - 1), yb = (u / kTW) * 8;
         float v[8 + 2 * R], acc[8];
 #pragma unroll
-        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(yb + j) * kTW + lx];
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(yb + j) * RPITCH + lx];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
