@@ -77,16 +77,23 @@ __global__ void absmax_kernel(const float* __restrict__ X, int64_t n, int64_t ld
 // ------------------------------------------------------------------------------------------------
 // prep: one thread per descriptor row (the canonical sums are serial k-ascending chains)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {  // round to nearest even (finite inputs)
-    const uint32_t u = __float_as_uint(f);
-    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+// f32 -> f16, round to nearest even, saturated to the finite range and with subnormal results flushed to zero
+// (the matrix pipe is never asked to honour f16 subnormals); `back` = the value the f16 stands for
+__device__ __forceinline__ unsigned short f32_to_f16_flush(float f, float& back) {
+    const float c = fminf(fmaxf(f, -65504.f), 65504.f);
+    _Float16 hv = (_Float16)c;
+    back = (float)hv;
+    if (fabsf(back) < 6.103515625e-05f) {
+        hv = (_Float16)0.f;
+        back = 0.f;
+    }
+    return __builtin_bit_cast(unsigned short, hv);
 }
-__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
 
 __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
-                                 unsigned short* __restrict__ Hh, unsigned short* __restrict__ Hl,
-                                 float* __restrict__ maxsq) {
+                                 unsigned short* __restrict__ Hf, float* __restrict__ dn,
+                                 float* __restrict__ maxsq, float* __restrict__ maxdn) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x[kDim];
@@ -121,32 +128,33 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         *reinterpret_cast<f32x4*>(p + 4 * s4) = e;
         *reinterpret_cast<f32x4*>(p + 64 + 4 * s4) = o;
     }
-    // split-precision copies in natural k order: x ~= hi + lo, each bf16 (|x - hi - lo| <= 2^-16 |x|)
-    if (Hh) {
-        unsigned short* ph = Hh + i * kDim;
-        unsigned short* pl = Hl + i * kDim;
+    // screening copy in natural k order: xf = f16(x), and the norm of what the rounding dropped, ||x - xf||
+    // (rounded up): the candidate kernel's error bound is built from these norms, not from a worst case
+    if (Hf) {
+        unsigned short* ph = Hf + i * kDim;
+        float ds = 0.f;
 #pragma unroll
         for (int k8 = 0; k8 < kDim / 8; ++k8) {
-            unsigned short hv[8], lv[8];
+            unsigned short hv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = x[8 * k8 + j];
-                hv[j] = f32_to_bf16_rn(v);
-                lv[j] = f32_to_bf16_rn(v - bf16_to_f32(hv[j]));
+                float back;
+                hv[j] = f32_to_f16_flush(v, back);
+                const float d = v - back;  // exact when not saturated
+                ds = fmaf(d, d, ds);
             }
-            uint4 a, b;
+            uint4 a;
             a.x = hv[0] | ((uint32_t)hv[1] << 16);
             a.y = hv[2] | ((uint32_t)hv[3] << 16);
             a.z = hv[4] | ((uint32_t)hv[5] << 16);
             a.w = hv[6] | ((uint32_t)hv[7] << 16);
-            b.x = lv[0] | ((uint32_t)lv[1] << 16);
-            b.y = lv[2] | ((uint32_t)lv[3] << 16);
-            b.z = lv[4] | ((uint32_t)lv[5] << 16);
-            b.w = lv[6] | ((uint32_t)lv[7] << 16);
             *reinterpret_cast<uint4*>(ph + 8 * k8) = a;
-            *reinterpret_cast<uint4*>(pl + 8 * k8) = b;
         }
+        const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 roundings of 2^-24 in ds, one in the root: 2^-10 covers
+        dn[i] = dnv;
         atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
+        atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
     }
 }
 
@@ -161,12 +169,13 @@ struct MatchJob {
     int nA;
     int nB;
     int64_t out_off;  // first output slot of this job's rows
-    // split-precision operands (natural k order) and max ||b||^2 of the B set, for the bf16x3 path
-    const unsigned short* AH;
-    const unsigned short* AL;
-    const unsigned short* BH;
-    const unsigned short* BL;
+    // screening operands of the candidate kernel: f16 copies (natural k order), the per-row rounding-loss norm of
+    // the A rows, and max ||b||^2 / max ||b - f16(b)|| of the B set
+    const unsigned short* AF;
+    const unsigned short* BF;
+    const float* dnA;
     const float* maxsqB;
+    const float* maxdnB;
 };
 
 struct WgJob {
@@ -354,8 +363,7 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
 // Tried and measured slower: per-value branch-free sorted lists (5 VALU/value), four-value group inserts,
 // and a one-wave-per-SIMD variant with the selection interleaved into the MFMA stream (register allocation
 // forces 32-row blocks x2 per wave, which doubles the B traffic per flop).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr float kSplitEps = 2.44140625e-4f;  // 2^-12
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
 constexpr int kTNB = 128;   // B rows per LDS tile of the split-precision kernel (4 column blocks per barrier)
@@ -377,7 +385,7 @@ __device__ __forceinline__ void top4_insert_max(float t, int j, float& u0, float
     u0 = fmaxf(u0, t);
 }
 
-constexpr int kTileBytes = kTNB * 256;  // one bf16 half (hi or lo) of a B tile in LDS
+constexpr int kTileBytes = kTNB * 256;  // one f16 B tile in LDS
 
 // exact canonical distance of A row `pa` and B row `pb` (both in the permuted f32 layout of prep_desc_kernel):
 // G = k-ascending fma chain, d = (a2 + b2) - 2G — the same arithmetic as match2nn_kernel / the oracle.
@@ -405,7 +413,7 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const 
 // Exact rescoring of one row's three candidates and the certification test (see the header comment): writes the
 // final (idx, d1, d2) of a certified row, or appends the row to the fallback list.
 __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0, int c1, int c2, float bnd,
-                                            uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
+                                            float aug_res, uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
                                             float* __restrict__ out_d2, uint32_t* __restrict__ fb_list,
                                             unsigned int* __restrict__ fb_count) {
     const int64_t slot = jb.out_off + row;
@@ -430,7 +438,16 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0,
     APS_CSWAP(1, 2)
     APS_CSWAP(0, 1)
 #undef APS_CSWAP
-    const float eps = kSplitEps * sqrtf(a2 * (*jb.maxsqB)) + 9.5367431640625e-07f;
+    // error of the screened value s~ = a^.b^ - y~ against s = a.b - b2/2, for ANY column of the B set:
+    //   |a.b - a^.b^| <= ||a - a^|| ||b^|| + ||a|| ||b - b^||        (Cauchy-Schwarz on the two rounding losses)
+    //   + the largest residual of the three-piece b2/2 the workgroup has staged
+    //   + f32 accumulation in the matrix pipe: 2^-15 (sum|a_k b_k| + y), measured <= 2^-22 (scripts/probe/mfma_f16_err.hip)
+    // and in distance units twice that, plus the roundings of the canonical f32 evaluation itself.
+    const float msb = *jb.maxsqB, mdb = *jb.maxdnB;
+    const float nb = sqrtf(msb) * 1.000001f + mdb;
+    const float na = sqrtf(a2) * 1.000001f;
+    const float eg = jb.dnA[row] * nb + na * mdb + aug_res + 3.0517578125e-05f * (na * nb + 0.5f * msb);
+    const float eps = 2.002f * eg + 1.52587890625e-05f * (a2 + msb + 2.0f * na * nb) + 1e-37f;
     const bool certified = jb.nB <= 3 || (d[1] < bnd - eps);
     if (certified) {
         out_idx[slot] = jb.nB > 0 ? (uint32_t)id[0] + 1u : 0u;
@@ -442,16 +459,18 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0,
     }
 }
 
-__global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __restrict__ jobs,
-                                                                 const WgJob* __restrict__ wgs, int n_wg,
-                                                                 uint32_t* __restrict__ out_idx,
-                                                                 float* __restrict__ out_d1, float* __restrict__ out_d2,
-                                                                 uint32_t* __restrict__ fb_list,
-                                                                 unsigned int* __restrict__ fb_count, int ablate) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * 2 * kTileBytes];  // [buf][hi|lo][128][256 B]
-    // -b2/2 of each B row as three bf16 pieces (hi + mid + lo == the f32 value exactly) + five zeros: one extra
-    // 16-wide k-step against the constant [1 1 1 0 ...] puts it into the accumulator (padded column: -1e30)
+__global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __restrict__ jobs,
+                                                                const WgJob* __restrict__ wgs, int n_wg,
+                                                                uint32_t* __restrict__ out_idx,
+                                                                float* __restrict__ out_d1, float* __restrict__ out_d2,
+                                                                uint32_t* __restrict__ fb_list,
+                                                                unsigned int* __restrict__ fb_count, int ablate) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTileBytes];  // [buf][128][256 B]
+    // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
+    // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
+    // accumulator (padded column: -65504 c0)
     __shared__ __attribute__((aligned(16))) uint4 s_aug[2][kTNB];
+    __shared__ unsigned int s_aug_res;  // largest |b2/2 - pieces| staged by this workgroup (bits of a float >= 0)
 
     // XCD-aware order: consecutive workgroup ids go to different XCDs (one L2 each); give each XCD a
     // contiguous run of the job-major list so that the workgroups sharing a B set share an L2
@@ -469,16 +488,15 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
     const int h = lane >> 5;
     const int nA = jb.nA, nB = jb.nB;
     const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
+    if (tid == 0) s_aug_res = 0u;
 
-    bf16x8 ah[2][8], al[2][8];
+    f16x8 ah[2][8];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int arow = min(row0 + 32 * rb, nA - 1);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            ah[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AH + (size_t)arow * kDim + 16 * s + 8 * h);
-            al[rb][s] = *reinterpret_cast<const bf16x8*>(jb.AL + (size_t)arow * kDim + 16 * s + 8 * h);
-        }
+        for (int s = 0; s < 8; ++s)
+            ah[rb][s] = *reinterpret_cast<const f16x8*>(jb.AF + (size_t)arow * kDim + 16 * s + 8 * h);
     }
     float u0[2], u1[2], u2[2], u3[2];  // a.b - b2/2, descending, per owned row
     int i0[2], i1[2], i2[2];
@@ -488,9 +506,24 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
         i0[rb] = i1[rb] = i2[rb] = -1;
     }
 
+    // scales of the three b2/2 pieces: b2/2 <= 2^e; piece i carries bits [e-11i-11, e-11i) and is stored as
+    // p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16 and p_i is one whenever the
+    // B set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows up in the residual)
+    float ca[3], cinv[3];
+    {
+        int e;
+        (void)frexpf(0.5f * (*jb.maxsqB), &e);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ea = min(max(e - 11 * i, -14), 15);
+            ca[i] = ldexpf(1.0f, ea);
+            cinv[i] = ldexpf(1.0f, -ea);
+        }
+    }
+
     const int ntiles = (nB + kTNB - 1) / kTNB;
-    // DMA pieces: 64 per tile (32 hi + 32 lo), 1 KiB = 4 LDS rows each; wave w issues pieces 8w .. 8w+7.
-    // lane -> LDS row 4*(piece&31) + lane/16, chunk position lane&15, which must hold source chunk pos ^ (row&15)
+    // DMA pieces: 32 per tile, 1 KiB = 4 LDS rows each; wave w issues pieces 4w .. 4w+3, one per column block.
+    // lane -> LDS row 4*piece + lane/16, chunk position lane&15, which must hold source chunk pos ^ (row&15)
     const int dma_sub = lane >> 4, dma_pos = lane & 15;
     // The DMA is issued from inline asm on purpose: for the builtin the compiler cannot tell the two LDS
     // buffers apart and drains vmcnt before the first ds_read that follows, which exposes the whole DMA
@@ -498,42 +531,41 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
     // ends tile t; nothing reads that buffer earlier.
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     float stage_b2 = 0.f;
-    // pieces [u0, u1) of this wave's eight; u0 == 0 also fetches the tile's ||b||^2
-    auto issue_pieces = [&](int t, int buf, int u0, int u1) {
+    float aug_res = 0.f;
+    // piece u of this wave's four; u == 0 also fetches the tile's ||b||^2
+    auto issue_piece = [&](int t, int buf, int u) {
         // ordinary load first (it is consumed at the end of the tile, behind the same vmcnt(0))
-        if (u0 == 0) stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
-#pragma unroll
-        for (int u = u0; u < u1; ++u) {
-            const int piece = wave * 8 + u;
-            const int half = piece >> 5;
-            const int lrow = 4 * (piece & 31) + dma_sub;
-            const int brow = min(t * kTNB + lrow, nB - 1);
-            const unsigned short* src = (half ? jb.BL : jb.BH) + (size_t)brow * kDim + ((dma_pos ^ (lrow & 15)) << 3);
-            const uint32_t dst = lds_base + buf * (2 * kTileBytes) + half * kTileBytes + (piece & 31) * 1024;
-            uint32_t keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(src), "s"(dst)
-                : "memory");
-        }
+        if (u == 0) stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
+        const int piece = wave * 4 + u;
+        const int lrow = 4 * piece + dma_sub;
+        const int brow = min(t * kTNB + lrow, nB - 1);
+        const unsigned short* src = jb.BF + (size_t)brow * kDim + ((dma_pos ^ (lrow & 15)) << 3);
+        const uint32_t dst = lds_base + buf * kTileBytes + piece * 1024;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
     };
-    auto issue_tile = [&](int t, int buf) { issue_pieces(t, buf, 0, 8); };
     auto store_aug = [&](int t) {
         const int j = t * kTNB + tid;
         if (tid < kTNB) {
-            const float x = j < nB ? -0.5f * stage_b2 : -1e30f;
-            const uint32_t xb = __float_as_uint(x);
-            const float hi = __uint_as_float(xb & 0xffff0000u);
-            const float r1 = x - hi;  // exact
-            const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-            const float lo = r1 - mid;  // exact, fits 8 significant bits
-            uint4 v;
-            v.x = (xb >> 16) | (__float_as_uint(mid) & 0xffff0000u);
-            v.y = __float_as_uint(lo) >> 16;
-            v.z = 0u;
-            v.w = 0u;
-            s_aug[t & 1][tid] = v;
+            float r = 0.5f * stage_b2;
+            unsigned short pc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float back;
+                pc[i] = f32_to_f16_flush(r * cinv[i], back);
+                r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
+            }
+            if (j >= nB) {
+                pc[0] = 0x7bffu;  // 65504: -65504 c0 loses against every real column
+                pc[1] = pc[2] = 0u;
+                r = 0.f;
+            }
+            aug_res = fmaxf(aug_res, fabsf(r));
+            s_aug[t & 1][tid] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2], 0u, 0u);
         }
     };
     const bool late = wave >= 4;
@@ -585,83 +617,95 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
     };
 
     if (ntiles > 0) {
-        issue_tile(0, 0);
-        store_aug(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
     }
     // touch the resident operand here: otherwise the compiler's pending-load state for these registers
     // reaches the loop header and it drains vmcnt (DMA included) at their first use in EVERY iteration
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-        asm volatile("" ::"v"(ah[0][s]), "v"(ah[1][s]), "v"(al[0][s]), "v"(al[1][s]));
+    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(ah[0][s]), "v"(ah[1][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ntiles > 0) store_aug(0);
     __syncthreads();
 
     // per-lane read offsets: row c of a 32-row block, chunk (2s + h) ^ (c & 15)
     const int hx = (16 * h) ^ (16 * (c & 15));
-    // constant operand of the extra k-step: k = 0,1,2 -> 1.0 (held by the h == 0 half), everything else 0
-    bf16x8 aug_a;
-    {
-        const uint4 v = make_uint4(h ? 0u : 0x3f803f80u, h ? 0u : 0x00003f80u, 0u, 0u);
-        aug_a = *reinterpret_cast<const bf16x8*>(&v);
+    // constant operand of the extra k-step: k = 0,1,2 -> -c_i (held by the h == 0 half), everything else 0
+    f16x8 aug_a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aug_a[e] = (_Float16)0.f;
+    if (h == 0) {
+        aug_a[0] = (_Float16)(-ca[0]);
+        aug_a[1] = (_Float16)(-ca[1]);
+        aug_a[2] = (_Float16)(-ca[2]);
     }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // Software pipeline, one column block deep: while block g multiplies, the eight operand vectors (+ the b2/2
+    // pieces) of block g+1 are read from LDS into the other register set, so no MFMA ever waits on an LDS round
+    // trip (with a one-k-step lookahead the single-product loop spent half its time in lgkmcnt waits).  For that
+    // the tile hand-over sits one block early: tile t+1 must have landed, and tile t must not be read any more,
+    // at the barrier between blocks 2 and 3 of tile t; the DMA of tile t+1 is issued during blocks
+    // (t-1,3), (t,0), (t,1), (t,2) into the buffer tile t-1 vacated at the previous hand-over.
+    f16x8 bq[2][8], aug_q[2];
+    if (ntiles > 0) {
+        if (ntiles > 1 && !(ablate & 2)) issue_piece(1, 1, 0);
+        const unsigned char* blk = lds + c * 256;
+        aug_q[0] = *reinterpret_cast<const f16x8*>(&s_aug[0][c]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bq[0][s] = *reinterpret_cast<const f16x8*>(blk + ((32 * s) ^ hx));
+    }
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles && !(ablate & 2);
-        const unsigned char* tile = lds + (t & 1) * (2 * kTileBytes) + c * 256;
-        const uint4* augp = &s_aug[t & 1][c];
-        // operands of the first k-step of block 0 (later blocks: fetched during the previous block's last step)
-        bf16x8 bh[2], bl[2], aug_b;
-        aug_b = *reinterpret_cast<const bf16x8*>(augp);
-        bh[0] = *reinterpret_cast<const bf16x8*>(tile + (0 ^ hx));
-        bl[0] = *reinterpret_cast<const bf16x8*>(tile + kTileBytes + (0 ^ hx));
+        const bool more2 = t + 2 < ntiles && !(ablate & 2);
+        const unsigned char* tile = lds + (t & 1) * kTileBytes + c * 256;
+        const unsigned char* tile_n = lds + ((t + 1) & 1) * kTileBytes + c * 256;
 #pragma unroll
         for (int cb = 0; cb < kTNB / 32; ++cb) {
-            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kTNB / 32 - 1);
-            // the next tile's DMA, two of this wave's eight pieces per block (one burst of eight at the top of the
-            // tile measured 3 % slower)
-            if (more) issue_pieces(t + 1, (t + 1) & 1, 2 * cb, 2 * cb + 2);
-            const unsigned char* blk = tile + cb * 32 * 256;
+            constexpr int kLast = kTNB / 32 - 1;
+            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kLast);
+            // one DMA piece per block: pieces 1..3 of tile t+1 in blocks 0..2, piece 0 of tile t+2 in block 3
+            if (cb < kLast ? more : more2) issue_piece(cb < kLast ? t + 1 : t + 2, cb < kLast ? (t + 1) & 1 : t & 1,
+                                                       cb < kLast ? cb + 1 : 0);
+            // operands of the next block: same tile, or block 0 of the tile that was handed over one block ago
+            const unsigned char* nblk = cb < kLast ? tile + (cb + 1) * 32 * 256 : tile_n;
+            const uint4* naug = cb < kLast ? &s_aug[t & 1][c + 32 * (cb + 1)] : &s_aug[(t + 1) & 1][c];
+            const bool fetch = cb < kLast || t + 1 < ntiles;
+            const int cur = cb & 1, nxt = cur ^ 1;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aug_b, aug_a, zero16, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aug_b, aug_a, zero16, 0, 0, 0);
+            if (fetch) aug_q[nxt] = *reinterpret_cast<const f16x8*>(naug);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[cur], aug_a, zero16, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[cur], aug_a, zero16, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const bf16x8 xh = bh[s & 1], xl = bl[s & 1];
-                if (s < 7) {
-                    bh[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(blk + ((32 * (s + 1)) ^ hx));
-                    bl[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(blk + kTileBytes + ((32 * (s + 1)) ^ hx));
-                } else if (cb + 1 < kTNB / 32) {
-                    aug_b = *reinterpret_cast<const bf16x8*>(augp + 32 * (cb + 1));
-                    bh[0] = *reinterpret_cast<const bf16x8*>(blk + 32 * 256 + (0 ^ hx));
-                    bl[0] = *reinterpret_cast<const bf16x8*>(blk + 32 * 256 + kTileBytes + (0 ^ hx));
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ah[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ah[1][s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, al[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, al[1][s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, ah[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, ah[1][s], acc1, 0, 0, 0);
+                if (fetch) bq[nxt][s] = *reinterpret_cast<const f16x8*>(nblk + ((32 * s) ^ hx));
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[cur][s], ah[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[cur][s], ah[1][s], acc1, 0, 0, 0);
             }
-            // pinned issue order: the reads of the next step go out ahead of the MFMAs of this one
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#pragma unroll
-            for (int s = 1; s < 7; ++s) {
+            // pinned issue order: one LDS read per pair of MFMAs
+            if (fetch) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int s = 1; s < 8; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
             }
-            if (cb + 1 < kTNB / 32) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (!late) epilogue(t, cb);
+            if (cb == kLast - 1) {
+                // hand-over: this wave's DMA pieces of tile t+1 (and its b2) have landed, its reads of tile t are
+                // complete (block 3's operands are in registers); after the barrier that holds for every wave
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (more) store_aug(t + 1);
+                __syncthreads();
+            }
         }
-        if (t + 1 < ntiles && !(ablate & 2)) store_aug(t + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t+1 have landed
-        __syncthreads();                                   // ... and every reader is behind that
     }
     if (late && ntiles > 0) epilogue(ntiles - 1, kTNB / 32 - 1);
+    if (tid < kTNB) atomicMax(&s_aug_res, __float_as_uint(aug_res));
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
@@ -672,6 +716,7 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
         top4_insert_max(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
         u3[rb] = fmaxf(u3[rb], p3);
     }
+    __syncthreads();  // s_aug_res is complete
     // Exact rescoring in place (it used to be a separate, purely gather-bound launch): the h == 0 half holds the
     // merged lists of both owned rows; its lanes rescore row block 0 while the h == 1 lanes take over row block 1.
     {
@@ -683,7 +728,8 @@ __global__ __launch_bounds__(512) void match_cand_bf16_kernel(const MatchJob* __
         const int row = row0 + 32 * h;
         if (row < nA) {
             const float bnd = jb.sqA[row] - 2.0f * ub;  // approximate 4th-smallest distance (inf if < 4 columns)
-            rescore_row(jb, row, c0, c1, c2, bnd, out_idx, out_d1, out_d2, fb_list, fb_count);
+            rescore_row(jb, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), out_idx, out_d1, out_d2, fb_list,
+                        fb_count);
         }
     }
 }
@@ -825,8 +871,8 @@ __global__ void scan_counts_kernel(const unsigned long long* __restrict__ cnt, i
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 struct Prepared {
-    Ws<float> P, sq, maxsq;
-    Ws<unsigned short> H, L;
+    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, maxsq[1] = max ||x - f16(x)||
+    Ws<unsigned short> H;
     int64_t n = 0;
 };
 
@@ -837,13 +883,14 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.P.alloc(rows * kDim);
     out.sq.alloc(rows);
     out.H.alloc(rows * kDim);
-    out.L.alloc(rows * kDim);
-    out.maxsq.alloc(1);
-    APS_HIP(hipMemsetAsync(out.maxsq, 0, sizeof(float), stream()));
+    out.dn.alloc(rows);
+    out.maxsq.alloc(2);
+    APS_HIP(hipMemsetAsync(out.maxsq, 0, 2 * sizeof(float), stream()));
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
-                                                        out.P, out.sq, out.H, out.L, out.maxsq);
+                                                        out.P, out.sq, out.H, out.dn, out.maxsq,
+                                                        (float*)out.maxsq + 1);
     check_launch("prep_desc_kernel");
 }
 
@@ -856,11 +903,11 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.nA = nA;
     j.nB = nB;
     j.out_off = out_off;
-    j.AH = a.H;
-    j.AL = a.L;
-    j.BH = b.H;
-    j.BL = b.L;
+    j.AF = a.H;
+    j.BF = b.H;
+    j.dnA = a.dn;
     j.maxsqB = b.maxsq;
+    j.maxdnB = (const float*)b.maxsq + 1;
     return j;
 }
 
@@ -935,12 +982,12 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     Ws<WgJob> dbw(bw.size());
     APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
     {
-        Prof prof("match_cand_bf16");
+        Prof prof("match_cand_f16");
         const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
-        match_cand_bf16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
+        match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
                                                                           fb_count, ab ? std::atoi(ab) : 0);
     }
-    check_launch("match_cand_bf16_kernel");
+    check_launch("match_cand_f16_kernel");
     unsigned int n_fb = 0;
     APS_HIP(hipMemcpyAsync(&n_fb, fb_count, sizeof n_fb, hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));

@@ -212,7 +212,7 @@ def main():
                 return None
             return round(sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows) / launches)
 
-        TRAFFIC_KEYS = {"match_cand_bf16": ["match_cand_bf16_kernel"], "match2nn": ["match2nn_kernel"],
+        TRAFFIC_KEYS = {"match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
                         "sift_blur": ["aps::blur_kernel<"], "warp_layer": ["warp_layer_kernel"],
                         "multiband": ["mb_blur_kernel", "mb_resize_kernel", "mb_lap_all_kernel", "mb_collapse_kernel"]}
 
@@ -234,7 +234,7 @@ def main():
             return r
 
         cands = [
-            roof("match_cand_bf16", "match_cand_bf16_kernel (v_mfma_f32_32x32x16_bf16, hi/lo split: 3 products)", "mfma",
+            roof("match_cand_f16", "match_cand_f16_kernel (v_mfma_f32_32x32x16_f16 screening product + exact f32 rescoring)", "mfma",
                  flops_rank0, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
                  "achieved counts the ALGORITHMIC 2*128*Ni*Nj flops once; the kernel executes 3x that on the bf16 "
                  "pipe (MFMA pipe utilisation = 3*frac); results are certified bit-identical to the f32 path"),

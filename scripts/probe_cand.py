@@ -26,7 +26,7 @@ for it in range(3):
     capi.check(apsamd.lib.aps_synchronize())
     p = capi.profile_all()
 npairs = n_img * (n_img - 1) // 2
-ms = p["match_cand_bf16"][0]
+ms = p["match_cand_f16"][0]
 fl = 2 * 128 * npairs * kf * kf
-print(f"cand {ms:.2f} ms  ({ms/npairs*1e3:.1f} us/pair)  algorithmic {fl/ms/1e9:.1f} TF  pipe(3x) {3*fl/ms/1e9:.0f} TF;"
+print(f"cand {ms:.2f} ms  ({ms/npairs*1e3:.1f} us/pair)  algorithmic {fl/ms/1e9:.1f} TF  pipe(9/8x) {1.125*fl/ms/1e9:.0f} TF;"
       f" fallback {p.get('match2nn_fallback',(0,0))[0]:.2f}")

@@ -29,5 +29,5 @@ npairs = n_img * (n_img - 1) // 2
 flops = 2 * 128 * npairs * kf * kf
 prof = capi.profile_all()
 print(f"total {dt*1e3:.1f} ms, matches={len(ii)}; " + ", ".join(f"{k}={v[0]:.2f}ms" for k, v in prof.items()))
-k = "match_cand_bf16" if "match_cand_bf16" in prof else "match2nn"
+k = "match_cand_f16" if "match_cand_f16" in prof else "match2nn"
 print(f"{k}: {flops/prof[k][0]/1e9:.1f} TFLOP/s algorithmic")

@@ -160,7 +160,7 @@ def test_split_path_fallback_rows_on_near_ties(fm, gpu, monkeypatch):
     gpu._capi.profile_enable(False)
     oi, o1, o2 = oracle.match_2nn_ssd(a, b)
     assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
-    assert "match2nn_fallback" in prof and "match_cand_bf16" in prof  # the fallback really ran
+    assert "match2nn_fallback" in prof and "match_cand_f16" in prof  # the fallback really ran
 
 
 def test_split_path_unnormalised_descriptors(fm, monkeypatch):
