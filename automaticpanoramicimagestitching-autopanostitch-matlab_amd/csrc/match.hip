@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 
 #include "aps_internal.h"
 
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
-constexpr int kTNB = 128;   // B rows per LDS tile of the split-precision kernel (4 column blocks per barrier)
+constexpr int kTNB = 128;   // B rows per LDS tile of the candidate kernel (4 column blocks per hand-over)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -383,6 +384,40 @@ __device__ __forceinline__ void top4_insert_max(float t, int j, float& u0, float
     u1 = __builtin_amdgcn_fmed3f(u0, t, u1);
     i0 = g0 ? j : i0;
     u0 = fmaxf(u0, t);
+}
+
+// the same insertion written as plain selects (no nested conditionals for the compiler to turn into branches)
+__device__ __forceinline__ void top4_insert_sel(float t, int j, float& u0, float& u1, float& u2, float& u3,
+                                                int& i0, int& i1, int& i2) {
+    const bool g2 = t > u2, g1 = t > u1, g0 = t > u0;
+    u3 = __builtin_amdgcn_fmed3f(u2, t, u3);
+    u2 = __builtin_amdgcn_fmed3f(u1, t, u2);
+    u1 = __builtin_amdgcn_fmed3f(u0, t, u1);
+    u0 = __builtin_amdgcn_fmed3f(u0, t, INFINITY);  // max without a canonicalising pre-pass
+    int n2 = g2 ? j : i2;
+    n2 = g1 ? i1 : n2;
+    int n1 = g1 ? j : i1;
+    n1 = g0 ? i0 : n1;
+    i0 = g0 ? j : i0;
+    i1 = n1;
+    i2 = n2;
+}
+
+// compile-time loop: the body receives std::integral_constant<int, I>, so register arrays are indexed by constants
+// by construction (an index the optimiser fails to fold sends the whole array to scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float max4_raw(float a, float b, float c, float d) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+    return m;
 }
 
 constexpr int kTileBytes = kTNB * 256;  // one f16 B tile in LDS
@@ -465,7 +500,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                                                                 float* __restrict__ out_d1, float* __restrict__ out_d2,
                                                                 uint32_t* __restrict__ fb_list,
                                                                 unsigned int* __restrict__ fb_count, int ablate) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kTileBytes];  // [buf][128][256 B]
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kTileBytes];  // [buf][128][256 B], tile t in buf t % 3
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
     // accumulator (padded column: -65504 c0)
@@ -536,7 +571,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     auto issue_piece = [&](int t, int buf, int u) {
         // ordinary load first (it is consumed at the end of the tile, behind the same vmcnt(0))
         if (u == 0) stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
-        const int piece = wave * 4 + u;
+        const int piece = wave * (kTNB / 32) + u;
         const int lrow = 4 * piece + dma_sub;
         const int brow = min(t * kTNB + lrow, nB - 1);
         const unsigned short* src = jb.BF + (size_t)brow * kDim + ((dma_pos ^ (lrow & 15)) << 3);
@@ -568,57 +603,89 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
             s_aug[t & 1][tid] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2], 0u, 0u);
         }
     };
-    const bool late = wave >= 4;
-    f32x16 acc0, acc1;
+    f32x16 acc[2][2];  // [block parity][owned row]: one set is being accumulated while the other is being searched
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = -INFINITY;
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = -INFINITY;
     // Selection.  thr = the larger of the two half-waves' fourth-best of a row (they see disjoint columns of the
     // same row): the union's fourth-best is >= either half's, so a value <= thr can neither be one of the
     // union's best three nor exceed the final bound, and each half's list still ends up holding every element
     // of the union's top four that fell into its columns, which is all the final merge needs.
+    //
+    // With a single product per column the selection, not the matrix pipe, sets the pace (VALU issued next to a
+    // dense MFMA stream runs at a third of its rate, scripts/probe/mfma_valu_coexec.hip), and late in the stream
+    // nearly every "some lane has a hit" event serves one lane of 64.  So a hit is not inserted on the spot: the
+    // lane PARKS the whole group of four values (+ its first column) in five registers, and the sorted insertion of
+    // all four runs for every lane at once only when a lane that is already holding a parked group hits again
+    // (every ~10 events), with no per-value tests at all: inserting a value <= the list's fourth entry, or the
+    // -inf of an empty slot, changes nothing.  A parked group only delays the tightening of that lane's threshold.
     float thr[2] = {-INFINITY, -INFINITY};
-    auto epilogue = [&](int t, int cb) {
-        if (ablate & 1) {
-            asm volatile("" ::"v"(acc0), "v"(acc1));
+#ifdef APS_MATCH_TIMING
+    if (ablate & 4) thr[0] = thr[1] = INFINITY;  // timing experiment: the screen never fires
+#endif
+    float pv[2][4];
+    int pj[2] = {-1, -1};
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[rb][q] = -INFINITY;
+    auto drain = [&](int rb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            top4_insert_sel(pv[rb][q], pj[rb] + q, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
+            pv[rb][q] = -INFINITY;
+        }
+        pj[rb] = -1;
+        thr[rb] = __builtin_amdgcn_fmed3f(thr[rb], u3[rb], INFINITY);
+    };
+    // One eighth of the search of a finished block: group g = sl / 2 (four columns) of owned row rb = sl % 2.
+    // acc[par][rb][r] <-> B column (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb).
+    float m_scr = 0.f;
+    auto select_slice = [&](auto PAR, int t, auto CB, auto SL) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value, cb = decltype(CB)::value, sl = decltype(SL)::value;
+#ifdef APS_MATCH_TIMING
+        if (__builtin_expect(ablate & 1, 0)) {
+            asm volatile("" ::"v"(acc[par][0]), "v"(acc[par][1]));
             return;
         }
-        // acc[r] <-> B column (r&3) + 8*(r>>2) + 4*h of block (t, cb), A row = the lane's row (rb)
-        const int jbase = t * kTNB + cb * 32 + 4 * h;
-        // two-level screen: the max of four values against thr (one branch per group), then value by value
+#endif
+        constexpr int g = sl >> 1, rb = sl & 1;
+        const f32x16& a = acc[par][rb];
+        // max of the four, compared against the row's threshold: three VALU instructions and a scalar branch are
+        // all that sits between two MFMA pairs in the common case (every further instruction there costs matrix
+        // time: a wave issues in order, and the next MFMA pair cannot start before the slice is through)
+        // (the result register is one that stays live through the whole loop ("+v"): left to itself the allocator
+        // puts the temporary into the operand register the two MFMAs just issued are still reading, and the
+        // write-after-read interlock holds the VALU - and with it the in-order wave - until the MFMA is through)
+        unsigned long long any_hit;
+        asm("v_max3_f32 %1, %2, %3, %4\n\tv_max_f32 %1, %1, %5\n\tv_cmp_gt_f32 %0, %1, %6"
+            : "=s"(any_hit), "+v"(m_scr)
+            : "v"(a[4 * g]), "v"(a[4 * g + 1]), "v"(a[4 * g + 2]), "v"(a[4 * g + 3]), "v"(thr[rb]));
+        if (__builtin_expect(any_hit != 0, 0)) {  // cold: the common case must be the fall-through (a taken branch
+                                                  // per slice costs an instruction refetch the MFMAs cannot hide)
+            const bool hit = m_scr > thr[rb];
+            if (__any(hit && pj[rb] >= 0)) drain(rb);
+            if (hit) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float m0 = fmaxf(fmaxf(fmaxf(acc0[4 * g], acc0[4 * g + 1]), acc0[4 * g + 2]), acc0[4 * g + 3]);
-            const float m1 = fmaxf(fmaxf(fmaxf(acc1[4 * g], acc1[4 * g + 1]), acc1[4 * g + 2]), acc1[4 * g + 3]);
-            if (__any(m0 > thr[0] || m1 > thr[1])) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 4 * g + q, j = jbase + 8 * g + q;
-                    const bool c0 = acc0[r] > thr[0], c1 = acc1[r] > thr[1];
-                    if (__any(c0 || c1)) {
-                        if (__any(c0)) top4_insert_max(acc0[r], j, u0[0], u1[0], u2[0], u3[0], i0[0], i1[0], i2[0]);
-                        if (__any(c1)) top4_insert_max(acc1[r], j, u0[1], u1[1], u2[1], u3[1], i0[1], i1[1], i2[1]);
-                    }
-                }
+                for (int q = 0; q < 4; ++q) pv[rb][q] = a[4 * g + q];
+                pj[rb] = t * kTNB + cb * 32 + 4 * h + 8 * g;
             }
         }
-        // own fourth-best every block; the union with the other half's list (cross-lane exchange) once per tile
-        thr[0] = fmaxf(thr[0], u3[0]);
-        thr[1] = fmaxf(thr[1], u3[1]);
-        if (cb == kTNB / 32 - 1) {
-            // the fourth-best of the union of the two halves' sorted fours: max over i+j=3 of min(a_i, b_j)
+        if (sl == 7 && cb == kTNB / 32 - 1) {
+            // once per tile: the fourth-best of the union of the two halves' sorted fours = max over i+j=3 of
+            // min(a_i, b_j) (parked groups are not in the lists yet: the threshold is merely a little stale)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const float o0 = __shfl_xor(u0[rb], 32), o1 = __shfl_xor(u1[rb], 32), o2 = __shfl_xor(u2[rb], 32),
-                            o3 = __shfl_xor(u3[rb], 32);
-                const float m = fmaxf(fmaxf(fminf(u0[rb], o2), fminf(u1[rb], o1)), fminf(u2[rb], o0));
-                thr[rb] = fmaxf(thr[rb], fmaxf(fmaxf(u3[rb], o3), m));
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const float o0 = __shfl_xor(u0[r2], 32), o1 = __shfl_xor(u1[r2], 32), o2 = __shfl_xor(u2[r2], 32),
+                            o3 = __shfl_xor(u3[r2], 32);
+                const float mm = fmaxf(fmaxf(fminf(u0[r2], o2), fminf(u1[r2], o1)), fminf(u2[r2], o0));
+                thr[r2] = fmaxf(thr[r2], fmaxf(fmaxf(u3[r2], o3), mm));
             }
         }
     };
 
     if (ntiles > 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+        for (int u = 0; u < kTNB / 32; ++u) issue_piece(0, 0, u);
     }
     // touch the resident operand here: otherwise the compiler's pending-load state for these registers
     // reaches the loop header and it drains vmcnt (DMA included) at their first use in EVERY iteration
@@ -639,72 +706,110 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         aug_a[1] = (_Float16)(-ca[1]);
         aug_a[2] = (_Float16)(-ca[2]);
     }
+    // a second copy the compiler cannot see through: otherwise it folds the two initial MFMAs of a block into one
+    // and chains the second accumulator's first MFMA behind it (a dependent issue, one MFMA latency per block)
+    f16x8 aug_a2 = aug_a;
+    asm volatile("" : "+v"(aug_a2));
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // Software pipeline, one column block deep: while block g multiplies, the eight operand vectors (+ the b2/2
-    // pieces) of block g+1 are read from LDS into the other register set, so no MFMA ever waits on an LDS round
-    // trip (with a one-k-step lookahead the single-product loop spent half its time in lgkmcnt waits).  For that
-    // the tile hand-over sits one block early: tile t+1 must have landed, and tile t must not be read any more,
-    // at the barrier between blocks 2 and 3 of tile t; the DMA of tile t+1 is issued during blocks
-    // (t-1,3), (t,0), (t,1), (t,2) into the buffer tile t-1 vacated at the previous hand-over.
-    f16x8 bq[2][8], aug_q[2];
+    // Software pipeline.  (1) The search of block g-1 is cut into eight slices that sit BETWEEN the MFMA pairs of
+    // block g in the same wave (two accumulator sets): VALU work issued next to one's own MFMAs is nearly free
+    // up to ~3 operations per MFMA, whereas a wave that alternates a pure-MFMA phase with a pure-VALU phase finds
+    // its VALU phase throttled to a third by the partner wave's MFMAs (scripts/probe/mfma_valu_coexec.hip: 1056
+    // vs 1412 cycles per block pair).  (2) Operand reads run one k-step ahead, across block and tile boundaries:
+    // the tile hand-over sits one block early - tile t+1 must have landed at the barrier between blocks 2 and 3 of
+    // tile t, so that block 3 can already read ahead into it.  Tile t itself is still being read during block 3,
+    // hence three LDS buffers: the DMA of tile t+1 is issued during blocks (t-1,3), (t,0), (t,1), (t,2) into the
+    // buffer of tile t-2, which every wave left for good before it passed the hand-over of tile t-1.
+    constexpr int kAhead = 3;  // an LDS round trip under load is longer than one k-step (two MFMAs + a slice)
+    f16x8 bh[4], aug_q[2];
     if (ntiles > 0) {
         if (ntiles > 1 && !(ablate & 2)) issue_piece(1, 1, 0);
-        const unsigned char* blk = lds + c * 256;
         aug_q[0] = *reinterpret_cast<const f16x8*>(&s_aug[0][c]);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) bq[0][s] = *reinterpret_cast<const f16x8*>(blk + ((32 * s) ^ hx));
+        for (int s = 0; s < kAhead; ++s) bh[s] = *reinterpret_cast<const f16x8*>(lds + c * 256 + ((32 * s) ^ hx));
     }
+#ifdef APS_MATCH_TIMING  // phase timing of one workgroup (make EXTRA=-DAPS_MATCH_TIMING, APS_MATCH_ABLATE=8)
+    unsigned long long T_mf = 0, T_bar = 0;
+    const unsigned long long T_c0 = __builtin_readcyclecounter(), T_w0 = wall_clock64();
+    unsigned long long T_prev = T_c0;
+#define APS_TICK(acc_)                                              \
+    {                                                               \
+        const unsigned long long n_ = __builtin_readcyclecounter(); \
+        acc_ += n_ - T_prev;                                        \
+        T_prev = n_;                                                \
+    }
+#else
+#define APS_TICK(acc_)
+#endif
+    int b_cur = 0;  // t % 3
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles && !(ablate & 2);
         const bool more2 = t + 2 < ntiles && !(ablate & 2);
-        const unsigned char* tile = lds + (t & 1) * kTileBytes + c * 256;
-        const unsigned char* tile_n = lds + ((t + 1) & 1) * kTileBytes + c * 256;
-#pragma unroll
-        for (int cb = 0; cb < kTNB / 32; ++cb) {
+        const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
+        const unsigned char* tile = lds + b_cur * kTileBytes + c * 256;
+        const unsigned char* tile_n = lds + b_nxt * kTileBytes + c * 256;
+        b_cur = b_nxt;
+        static_for<0, kTNB / 32>([&](auto CB) {
+            constexpr int cb = decltype(CB)::value;
             constexpr int kLast = kTNB / 32 - 1;
-            if (late && (t > 0 || cb > 0)) epilogue(cb ? t : t - 1, cb ? cb - 1 : kLast);
+            constexpr int par = cb & 1;
+            APS_TICK(T_bar)
             // one DMA piece per block: pieces 1..3 of tile t+1 in blocks 0..2, piece 0 of tile t+2 in block 3
-            if (cb < kLast ? more : more2) issue_piece(cb < kLast ? t + 1 : t + 2, cb < kLast ? (t + 1) & 1 : t & 1,
+            if (cb < kLast ? more : more2) issue_piece(cb < kLast ? t + 1 : t + 2, cb < kLast ? b_nxt : b_nxt2,
                                                        cb < kLast ? cb + 1 : 0);
-            // operands of the next block: same tile, or block 0 of the tile that was handed over one block ago
-            const unsigned char* nblk = cb < kLast ? tile + (cb + 1) * 32 * 256 : tile_n;
+            const unsigned char* blk = tile + cb * 32 * 256;
+            // first operands of the next block: same tile, or block 0 of the tile handed over one block ago
+            const unsigned char* nblk = cb < kLast ? blk + 32 * 256 : tile_n;
             const uint4* naug = cb < kLast ? &s_aug[t & 1][c + 32 * (cb + 1)] : &s_aug[(t + 1) & 1][c];
             const bool fetch = cb < kLast || t + 1 < ntiles;
-            const int cur = cb & 1, nxt = cur ^ 1;
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-            if (fetch) aug_q[nxt] = *reinterpret_cast<const f16x8*>(naug);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[cur], aug_a, zero16, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[cur], aug_a, zero16, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (fetch) bq[nxt][s] = *reinterpret_cast<const f16x8*>(nblk + ((32 * s) ^ hx));
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[cur][s], ah[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[cur][s], ah[1][s], acc1, 0, 0, 0);
-            }
-            // pinned issue order: one LDS read per pair of MFMAs
-            if (fetch) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-                for (int s = 1; s < 8; ++s) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            const int pt = cb ? t : t - 1;
+            constexpr int pcb = cb ? cb - 1 : kLast;
+            acc[par][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[par], aug_a, zero16, 0, 0, 0);
+            acc[par][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aug_q[par], aug_a2, zero16, 0, 0, 0);
+            static_for<0, 8>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const f16x8 xh = bh[s & 3];
+                if (s + kAhead < 8) {
+                    bh[(s + kAhead) & 3] = *reinterpret_cast<const f16x8*>(blk + ((32 * (s + kAhead)) ^ hx));
+                } else if (fetch) {
+                    bh[(s + kAhead) & 3] = *reinterpret_cast<const f16x8*>(nblk + ((32 * (s + kAhead - 8)) ^ hx));
+                    if (s == 8 - kAhead) aug_q[par ^ 1] = *reinterpret_cast<const f16x8*>(naug);
                 }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!late) epilogue(t, cb);
+                acc[par][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ah[0][s], acc[par][0], 0, 0, 0);
+                acc[par][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, ah[1][s], acc[par][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // (before the first block the other set holds -inf, which never passes the screen)
+                select_slice(std::integral_constant<int, par ^ 1>{}, pt, std::integral_constant<int, pcb>{}, S);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            APS_TICK(T_mf)
             if (cb == kLast - 1) {
-                // hand-over: this wave's DMA pieces of tile t+1 (and its b2) have landed, its reads of tile t are
-                // complete (block 3's operands are in registers); after the barrier that holds for every wave
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // hand-over: this wave's DMA pieces of tile t+1 (and its b2) have landed; after the barrier that
+                // holds for every wave, and every wave has left tile t-1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (more) store_aug(t + 1);
                 __syncthreads();
+                APS_TICK(T_bar)
             }
-        }
+        });
     }
-    if (late && ntiles > 0) epilogue(ntiles - 1, kTNB / 32 - 1);
+#ifdef APS_MATCH_TIMING
+    if ((ablate & 8) && blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4)) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+        printf("wave %d: %.3f GHz, %d blocks, cycles per block: total %.0f = mfma+selection %.0f + hand-over %.0f\n",
+               wave, (double)(c1 - T_c0) / ((double)(w1 - T_w0) * 10.0), ntiles * (kTNB / 32),
+               (double)(c1 - T_c0) / (ntiles * (kTNB / 32)), (double)T_mf / (ntiles * (kTNB / 32)),
+               (double)T_bar / (ntiles * (kTNB / 32)));
+    }
+#endif
+    if (ntiles > 0) {
+        static_for<0, 8>([&](auto S) {
+            select_slice(std::integral_constant<int, (kTNB / 32 - 1) & 1>{}, ntiles - 1,
+                         std::integral_constant<int, kTNB / 32 - 1>{}, S);
+        });
+    }
+    drain(0);
+    drain(1);
     if (tid < kTNB) atomicMax(&s_aug_res, __float_as_uint(aug_res));
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
