@@ -91,6 +91,19 @@ __device__ __forceinline__ unsigned short f32_to_f16_flush(float f, float& back)
     return __builtin_bit_cast(unsigned short, hv);
 }
 
+// smallest f16 >= f for f >= 0 (saturating at 65504; a nonzero f below the normal range becomes 2^-14)
+__device__ __forceinline__ unsigned short f16_round_up(float f, float& back) {
+    if (!(f > 0.f)) {
+        back = 0.f;
+        return 0;
+    }
+    const float c = fminf(fmaxf(f, 6.103515625e-05f), 65504.f);
+    unsigned short bits = __builtin_bit_cast(unsigned short, (_Float16)c);
+    if ((float)__builtin_bit_cast(_Float16, bits) < c) ++bits;  // positive finite: the next pattern is the next value
+    back = (float)__builtin_bit_cast(_Float16, bits);
+    return bits;
+}
+
 __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
@@ -175,6 +188,7 @@ struct MatchJob {
     const unsigned short* AF;
     const unsigned short* BF;
     const float* dnA;
+    const float* dnB;
     const float* maxsqB;
     const float* maxdnB;
 };
@@ -448,7 +462,7 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const 
 // Exact rescoring of one row's three candidates and the certification test (see the header comment): writes the
 // final (idx, d1, d2) of a certified row, or appends the row to the fallback list.
 __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0, int c1, int c2, float bnd,
-                                            float aug_res, uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
+                                            float aug_res, float dn_res, uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
                                             float* __restrict__ out_d2, uint32_t* __restrict__ fb_list,
                                             unsigned int* __restrict__ fb_count) {
     const int64_t slot = jb.out_off + row;
@@ -473,15 +487,21 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0,
     APS_CSWAP(1, 2)
     APS_CSWAP(0, 1)
 #undef APS_CSWAP
-    // error of the screened value s~ = a^.b^ - y~ against s = a.b - b2/2, for ANY column of the B set:
-    //   |a.b - a^.b^| <= ||a - a^|| ||b^|| + ||a|| ||b - b^||        (Cauchy-Schwarz on the two rounding losses)
-    //   + the largest residual of the three-piece b2/2 the workgroup has staged
-    //   + f32 accumulation in the matrix pipe: 2^-15 (sum|a_k b_k| + y), measured <= 2^-22 (scripts/probe/mfma_f16_err.hip)
-    // and in distance units twice that, plus the roundings of the canonical f32 evaluation itself.
+    // The screened value of column j is U_j = a^.b^_j - y~_j + na^ dn^_j, an UPPER bound (up to the row-wise terms
+    // below) of s_j = a.b_j - b2_j/2:
+    //   |a.b - a^.b^| <= ||a - a^|| ||b^|| + ||a|| ||b - b^||   (Cauchy-Schwarz on the two rounding losses);
+    //   the second term, ||a|| dn_j, is column specific and is added by the matrix pipe itself (k-slot 3 of the
+    //   extra step: na^ >= ||a|| on the A side, dn^_j >= ||b_j - b^_j|| on the B side, both rounded UP to f16);
+    //   row-wise remainder: ||a - a^|| max||b^|| + the largest residual of the three-piece b2/2 the workgroup has
+    //   staged + any saturation loss of dn^ + f32 accumulation in the matrix pipe, bounded by 2^-15 (sum|a_k b_k|
+    //   + y) (measured <= 7 x 2^-24, scripts/probe/mfma_f16_err.hip).
+    // Every non-candidate has U_j <= u3, hence s_j <= u3 + eg; in distance units twice that, plus the roundings of
+    // the canonical f32 evaluation itself.
     const float msb = *jb.maxsqB, mdb = *jb.maxdnB;
     const float nb = sqrtf(msb) * 1.000001f + mdb;
     const float na = sqrtf(a2) * 1.000001f;
-    const float eg = jb.dnA[row] * nb + na * mdb + aug_res + 3.0517578125e-05f * (na * nb + 0.5f * msb);
+    float eg = jb.dnA[row] * nb + aug_res + na * dn_res + 3.0517578125e-05f * (na * (nb + mdb) + 0.5f * msb);
+    if (!(na < 65000.f)) eg = INFINITY;  // ||a|| does not fit the f16 slot: nothing is certified
     const float eps = 2.002f * eg + 1.52587890625e-05f * (a2 + msb + 2.0f * na * nb) + 1e-37f;
     const bool certified = jb.nB <= 3 || (d[1] < bnd - eps);
     if (certified) {
@@ -506,6 +526,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     // accumulator (padded column: -65504 c0)
     __shared__ __attribute__((aligned(16))) uint4 s_aug[2][kTNB];
     __shared__ unsigned int s_aug_res;  // largest |b2/2 - pieces| staged by this workgroup (bits of a float >= 0)
+    __shared__ unsigned int s_dn_res;   // largest saturation loss dn_j - dn^_j (0 unless a loss norm exceeds 65504)
 
     // XCD-aware order: consecutive workgroup ids go to different XCDs (one L2 each); give each XCD a
     // contiguous run of the job-major list so that the workgroups sharing a B set share an L2
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     const int h = lane >> 5;
     const int nA = jb.nA, nB = jb.nB;
     const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
-    if (tid == 0) s_aug_res = 0u;
+    if (tid == 0) s_aug_res = s_dn_res = 0u;
 
     f16x8 ah[2][8];
 #pragma unroll
@@ -565,12 +586,15 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     // latency once per tile.  The DMA of tile t+1 is retired by the explicit vmcnt(0) before the barrier that
     // ends tile t; nothing reads that buffer earlier.
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    float stage_b2 = 0.f;
-    float aug_res = 0.f;
+    float stage_b2 = 0.f, stage_dn = 0.f;
+    float aug_res = 0.f, dn_res = 0.f;
     // piece u of this wave's four; u == 0 also fetches the tile's ||b||^2
     auto issue_piece = [&](int t, int buf, int u) {
         // ordinary load first (it is consumed at the end of the tile, behind the same vmcnt(0))
-        if (u == 0) stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
+        if (u == 0) {
+            stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
+            stage_dn = ((gbl_f32*)jb.dnB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
+        }
         const int piece = wave * (kTNB / 32) + u;
         const int lrow = 4 * piece + dma_sub;
         const int brow = min(t * kTNB + lrow, nB - 1);
@@ -594,13 +618,17 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                 pc[i] = f32_to_f16_flush(r * cinv[i], back);
                 r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
             }
+            float dn_back;
+            unsigned short pd = f16_round_up(stage_dn, dn_back);
+            float rd = fmaxf(stage_dn - dn_back, 0.f);
             if (j >= nB) {
                 pc[0] = 0x7bffu;  // 65504: -65504 c0 loses against every real column
-                pc[1] = pc[2] = 0u;
-                r = 0.f;
+                pc[1] = pc[2] = pd = 0u;
+                r = rd = 0.f;
             }
             aug_res = fmaxf(aug_res, fabsf(r));
-            s_aug[t & 1][tid] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2], 0u, 0u);
+            dn_res = fmaxf(dn_res, rd);
+            s_aug[t & 1][tid] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2] | ((uint32_t)pd << 16), 0u, 0u);
         }
     };
     f32x16 acc[2][2];  // [block parity][owned row]: one set is being accumulated while the other is being searched
@@ -706,9 +734,17 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         aug_a[1] = (_Float16)(-ca[1]);
         aug_a[2] = (_Float16)(-ca[2]);
     }
+    // k-slot 3: ||a|| of the lane's row (rounded up) against the column's rounding-loss norm
+    f16x8 aug_a2 = aug_a;
+    if (h == 0) {
+        float unused;
+        const unsigned short n0 = f16_round_up(sqrtf(jb.sqA[min(row0, nA - 1)]) * 1.000001f, unused);
+        const unsigned short n1 = f16_round_up(sqrtf(jb.sqA[min(row0 + 32, nA - 1)]) * 1.000001f, unused);
+        aug_a[3] = __builtin_bit_cast(_Float16, n0);
+        aug_a2[3] = __builtin_bit_cast(_Float16, n1);
+    }
     // a second copy the compiler cannot see through: otherwise it folds the two initial MFMAs of a block into one
     // and chains the second accumulator's first MFMA behind it (a dependent issue, one MFMA latency per block)
-    f16x8 aug_a2 = aug_a;
     asm volatile("" : "+v"(aug_a2));
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Software pipeline.  (1) The search of block g-1 is cut into eight slices that sit BETWEEN the MFMA pairs of
@@ -810,7 +846,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     }
     drain(0);
     drain(1);
-    if (tid < kTNB) atomicMax(&s_aug_res, __float_as_uint(aug_res));
+    if (tid < kTNB) {
+        atomicMax(&s_aug_res, __float_as_uint(aug_res));
+        atomicMax(&s_dn_res, __float_as_uint(dn_res));
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
@@ -833,7 +872,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const int row = row0 + 32 * h;
         if (row < nA) {
             const float bnd = jb.sqA[row] - 2.0f * ub;  // approximate 4th-smallest distance (inf if < 4 columns)
-            rescore_row(jb, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), out_idx, out_d1, out_d2, fb_list,
+            rescore_row(jb, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
                         fb_count);
         }
     }
@@ -1011,6 +1050,7 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.AF = a.H;
     j.BF = b.H;
     j.dnA = a.dn;
+    j.dnB = b.dn;
     j.maxsqB = b.maxsq;
     j.maxdnB = (const float*)b.maxsq + 1;
     return j;

@@ -236,8 +236,9 @@ def main():
         cands = [
             roof("match_cand_f16", "match_cand_f16_kernel (v_mfma_f32_32x32x16_f16 screening product + exact f32 rescoring)", "mfma",
                  flops_rank0, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
-                 "achieved counts the ALGORITHMIC 2*128*Ni*Nj flops once; the kernel executes 3x that on the bf16 "
-                 "pipe (MFMA pipe utilisation = 3*frac); results are certified bit-identical to the f32 path"),
+                 "achieved counts the ALGORITHMIC 2*128*Ni*Nj flops; the kernel executes 9/8 of that on the f16 pipe (one "
+                 "extra 16-wide k-step carries -b2/2 and the column's rounding-loss bound); the exact f32 rescoring of "
+                 "three candidates per row runs in the kernel's tail; results are certified bit-identical to the f32 path"),
             roof("match2nn", "match2nn_kernel (v_mfma_f32_32x32x2_f32, exact f32)", "mfma", flops_rank0,
                  MFMA_F32_PEAK_TFLOPS, "TFLOP/s"),
             roof("sift_blur", "blur_kernel<R> (separable Gaussian through LDS)", "hbm", 574.0 * npix_rank0,
