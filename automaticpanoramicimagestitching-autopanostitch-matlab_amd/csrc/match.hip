@@ -361,23 +361,20 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
 // the resident A rows are the MFMA "B" operand, so that in the 32x32 accumulator a lane owns ONE A row
 // (col = lane&31) and sees 16 B columns per block: the running top-4 of a row is 7 registers.
 //
-// Keeping the matrix pipe fed (measured on MI355X, scripts/probe_cand.py + scripts/pmc_run.sh):
+// The candidate kernel (see DESIGN.md section 4 for the measurements behind each point):
+//  * ONE f16 product per column (v_mfma_f32_32x32x16_f16) screens the distance matrix; the bound that certifies a
+//    row is built from the measured rounding loss ||x - f16(x)|| of its operands, the exact f32 distance of the three
+//    best candidates is evaluated in the kernel's tail, uncertified rows (0.3 %) go to the exact f32 kernel;
 //  * the B tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
-//    pass, no vmcnt stall at the top of a tile.  The LDS image is lane-linear (256-B rows, no pad); bank
-//    conflicts are avoided by an XOR swizzle of the 16-B chunk position with (row & 15), applied to the
-//    per-lane SOURCE address of the DMA and to the ds_read_b128 address (the same involution on both sides);
-//  * -||b||^2/2 enters the accumulator through one extra 16-wide k-step (three exact bf16 pieces against
-//    the constant [1 1 1 0 ...]), so acc = a.b - b2/2, the row's best columns are the LARGEST acc and the
-//    selection needs no arithmetic per element; d~ - a2 = -2 acc (exact scalings);
-//  * operand reads run one k-step ahead (the first step of the next block during the last of this one) in
-//    their own registers and the issue order is pinned with sched_group_barrier;
+//    pass.  The LDS image is lane-linear (256-B rows, no pad); bank conflicts are avoided by an XOR swizzle of the
+//    16-B chunk position with (row & 15), applied to the per-lane SOURCE address of the DMA and to the
+//    ds_read_b128 address (the same involution on both sides); three buffers, hand-over one block early;
+//  * -||b||^2/2 (three f16 pieces, per-set power-of-two scales) and ||a|| ||b - f16(b)|| enter the accumulator
+//    through one extra 16-wide k-step, so the row's best columns are the LARGEST acc and the selection needs no
+//    arithmetic per element;
+//  * the search of block g-1 is cut into eight three-instruction slices placed between the MFMA pairs of block g
+//    (two accumulator sets); hits are parked and inserted in bulk from a cold path;
 //  * workgroups are renumbered so that the ones sharing a B set run on one XCD (one L2).
-// Under this kernel's sustained MFMA load the chip clocks at 1.65-2.0 GHz, not 2.4 (scripts/probe/mfma_clock.hip):
-// the loop without selection and DMA runs at 96 % of the MFMA issue rate in cycles.  What remains is the
-// selection: its VALU/branch work overlaps the partner wave's MFMAs only partly (SQ_VALU_MFMA_COEXEC ~40 %).
-// Tried and measured slower: per-value branch-free sorted lists (5 VALU/value), four-value group inserts,
-// and a one-wave-per-SIMD variant with the selection interleaved into the MFMA stream (register allocation
-// forces 32-row blocks x2 per wave, which doubles the B traffic per flop).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kTMB = 512;  // A rows per workgroup of the split-precision kernel: 8 waves x 64 rows
