@@ -15,7 +15,9 @@
 //                          resolution as a per-column atomicMin on an order-preserving 64-bit key,
 //                          segmented radix sort (rocPRIM) to the reference's stable ascending order.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -1131,8 +1133,10 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     }
     check_launch("match_cand_f16_kernel");
     unsigned int n_fb = 0;
+    const auto R0 = std::chrono::steady_clock::now();
     APS_HIP(hipMemcpyAsync(&n_fb, fb_count, sizeof n_fb, hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
+    const auto R1 = std::chrono::steady_clock::now();
     if (n_fb == 0) return;
     // rows that could not be certified: exact f32 kernel in row-list mode, tiles grouped per job
     std::vector<uint32_t> h_fb(n_fb);
@@ -1155,7 +1159,13 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_list, idx, d1, d2);
     }
     check_launch("match2nn_kernel<list>");
+    const auto R2 = std::chrono::steady_clock::now();
     APS_HIP(hipStreamSynchronize(stream()));
+    if (std::getenv("APS_TRACE"))
+        std::fprintf(stderr, "[aps] 2-NN: candidates (wait) %.2f ms, fallback list %u rows: host %.2f ms, kernel (wait) %.2f ms\n",
+                     std::chrono::duration<double, std::milli>(R1 - R0).count(), n_fb,
+                     std::chrono::duration<double, std::milli>(R2 - R1).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - R2).count());
 }
 
 // ratio/threshold/unique for a list of jobs; returns total kept.  Outputs are device pointers.
@@ -1317,6 +1327,12 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
         }
         return;
     }
+    const bool trace = std::getenv("APS_TRACE") != nullptr;
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto T0 = t_now();
     // upload + probe (only images that take part in some pair)
     std::vector<char> used(n_img, 0);
     for (int64_t p = 0; p < n_pairs; ++p) used[pa[p]] = used[pb[p]] = 1;
@@ -1344,6 +1360,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
         if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i]);
         if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i]);
     }
+    const auto T1 = t_now();
     std::vector<MatchJob> jobs;
     std::vector<FilterJob> fjobs;
     int64_t rows = 0, cols = 0;
@@ -1363,7 +1380,9 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     APS_REQUIRE(rows < ((int64_t)1 << 32), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
     Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
     Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
+    const auto T2 = t_now();
     run_match_jobs(jobs, idx, d1, d2);
+    const auto T3 = t_now();
 
     Out<uint32_t> oi(idx_i, cap), oj(idx_j, cap);
     Out<float> om(metric, cap);
@@ -1384,6 +1403,9 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     oi.commit(total);
     oj.commit(total);
     om.commit(total);
+    if (trace)
+        std::fprintf(stderr, "[aps] match_pairs: probe+prepare %.2f ms, jobs %.2f, 2-NN %.2f, filter+out %.2f\n", t_ms(T0, T1),
+                     t_ms(T1, T2), t_ms(T2, T3), t_ms(T3, t_now()));
 }
 
 extern "C" {

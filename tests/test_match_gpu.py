@@ -130,7 +130,7 @@ def test_argument_errors(fm, gpu):
 
 
 def test_split_precision_path_equals_f32_path_and_oracle(fm, monkeypatch):
-    """Default mode = bf16x3 candidate search + exact rescoring + exact fallback rows; APS_MATCH_MODE=f32 = the
+    """Default mode = f16 screening product + exact rescoring + exact fallback rows; APS_MATCH_MODE=f32 = the
     all-f32 MFMA kernel.  Both must be bit-identical to the oracle."""
     rng = np.random.default_rng(21)
     a, b, _, _ = planted_pair(rng, 3000, 5000, 1200, noise=0.02)
@@ -175,6 +175,58 @@ def test_split_path_unnormalised_descriptors(fm, monkeypatch):
     m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=1.5, MaxRatio=0.6)
     om, omet = oracle.match_features(a, b, 0.6, 1.5, True, 2)
     assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
+@pytest.mark.parametrize("scale", [1e-7, 3e-5, 1.0 / 512, 37.0, 2000.0, 7e4, 3e9])
+def test_split_path_any_magnitude(fm, monkeypatch, scale):
+    """The screening product is f16: magnitudes that under- or overflow it (entries below 2^-14, above 65504, norms
+    beyond the f16 slot) must only widen the per-row bound - every row then takes the exact fallback - never change
+    a bit of the result."""
+    rng = np.random.default_rng(31)
+    a, b, _, _ = planted_pair(rng, 600, 1100, 250, noise=0.02)
+    a = (a * np.float32(scale)).astype(np.float32)
+    b = (b * np.float32(scale)).astype(np.float32)
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+
+
+def test_split_path_mixed_norms_signed_and_zero_rows(fm, monkeypatch):
+    """Rows whose norms differ by six orders of magnitude inside one set (the three-piece b2/2 loses its low pieces
+    for the small ones), signed entries, all-zero rows on both sides, and a B set smaller than the candidate list."""
+    rng = np.random.default_rng(32)
+    b = rng.standard_normal((700, 128)).astype(np.float32)
+    b *= (10.0 ** rng.uniform(-3, 3, (700, 1))).astype(np.float32)
+    b[5] = 0
+    b[77] = 0
+    a = np.concatenate([b[rng.permutation(700)[:200]] * np.float32(1.001), rng.standard_normal((150, 128)).astype(np.float32)])
+    a[3] = 0
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    for bb in (b, b[:3], b[:4], b[:5]):
+        _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, bb)
+        oi, o1, o2 = oracle.match_2nn_ssd(a, bb)
+        assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+
+
+def test_split_path_certifies_most_rows_of_unit_sift(fm, monkeypatch, capfd):
+    """On unit-norm SIFT-like sets the f16 bound must leave only a small share of the rows to the fallback (design
+    point: well under 1 %); a regression of the bound would show up as time, not as a wrong bit, so the row count the
+    library reports under APS_TRACE is checked here."""
+    import re
+
+    rng = np.random.default_rng(33)
+    a, b, _, _ = planted_pair(rng, 4096, 6000, 1500, noise=0.02)
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    monkeypatch.setenv("APS_TRACE", "1")
+    capfd.readouterr()
+    _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    err = capfd.readouterr().err
+    oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
+    m = re.search(r"fallback list (\d+) rows", err)
+    rows = int(m.group(1)) if m else 0  # no line at all = every row certified
+    assert rows <= 0.02 * len(a), (rows, err)
 
 
 # ---- the 'Approximate' float back ends of matchFeaturesScratch.m:142-160 ---------------------------------------
