@@ -460,7 +460,7 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const 
 
 // Exact rescoring of one row's three candidates and the certification test (see the header comment): writes the
 // final (idx, d1, d2) of a certified row, or appends the row to the fallback list.
-__device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0, int c1, int c2, float bnd,
+__device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row, int c0, int c1, int c2, float bnd,
                                             float aug_res, float dn_res, uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
                                             float* __restrict__ out_d2, uint32_t* __restrict__ fb_list,
                                             unsigned int* __restrict__ fb_count) {
@@ -508,8 +508,9 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int row, int c0,
         out_d1[slot] = d[0];
         out_d2[slot] = d[1];
     } else {
-        const unsigned int p = atomicAdd(fb_count, 1u);
-        fb_list[p] = (uint32_t)slot;
+        // the job's segment of the list starts at its first output slot (a job has at most nA uncertified rows)
+        const unsigned int p = atomicAdd(fb_count + job, 1u);
+        fb_list[jb.out_off + p] = (uint32_t)slot;
     }
 }
 
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const int row = row0 + 32 * h;
         if (row < nA) {
             const float bnd = jb.sqA[row] - 2.0f * ub;  // approximate 4th-smallest distance (inf if < 4 columns)
-            rescore_row(jb, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
+            rescore_row(jb, w.job, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
                         fb_count);
         }
     }
@@ -1055,17 +1056,21 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     return j;
 }
 
+// max |x| of one descriptor set into *d_slot (device); the caller reads all slots back in one copy
+static void absmax_async(const float* X_dev, int64_t n, int64_t ld, int layout, float* d_slot) {
+    if (n <= 0) return;
+    const unsigned grid = std::min<unsigned>(cdiv((size_t)n * kDim, 256), 2048);
+    if (layout == APS_ROWMAJOR && ld == kDim && (reinterpret_cast<uintptr_t>(X_dev) & 15) == 0)
+        absmax_flat_kernel<<<std::min<unsigned>(cdiv((size_t)n * kDim / 4, 256), 512), 256, 0, stream()>>>(
+            reinterpret_cast<const float4*>(X_dev), n * (kDim / 4), d_slot);
+    else
+        absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
+    check_launch("absmax_kernel");
+}
+
 static float absmax(const float* X_dev, int64_t n, int64_t ld, int layout, float* d_slot) {
     APS_HIP(hipMemsetAsync(d_slot, 0, sizeof(float), stream()));
-    if (n > 0) {
-        const unsigned grid = std::min<unsigned>(cdiv((size_t)n * kDim, 256), 2048);
-        if (layout == APS_ROWMAJOR && ld == kDim && (reinterpret_cast<uintptr_t>(X_dev) & 15) == 0)
-            absmax_flat_kernel<<<std::min<unsigned>(cdiv((size_t)n * kDim / 4, 256), 512), 256, 0, stream()>>>(
-                reinterpret_cast<const float4*>(X_dev), n * (kDim / 4), d_slot);
-        else
-            absmax_kernel<<<grid, 256, 0, stream()>>>(X_dev, n, ld, kDim, layout, d_slot);
-        check_launch("absmax_kernel");
-    }
+    absmax_async(X_dev, n, ld, layout, d_slot);
     float h = 0.f;
     APS_HIP(hipMemcpyAsync(&h, d_slot, sizeof(float), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
@@ -1117,9 +1122,11 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         return;
     }
     const int64_t total_rows = jobs.back().out_off + jobs.back().nA;
+    // uncertified rows: one list segment per job (at the job's first output slot) and one counter per job, so the
+    // host only reads the counters back - no sort, no second copy of the list
     Ws<uint32_t> fb_list((size_t)total_rows);
-    Ws<unsigned int> fb_count(1);
-    APS_HIP(hipMemsetAsync(fb_count, 0, sizeof(unsigned int), stream()));
+    Ws<unsigned int> fb_count(jobs.size());
+    APS_HIP(hipMemsetAsync(fb_count, 0, jobs.size() * sizeof(unsigned int), stream()));
     std::vector<WgJob> bw;
     for (int j = 0; j < (int)jobs.size(); ++j)
         for (int r = 0; r < jobs[j].nA; r += kTMB) bw.push_back({j, r, 0});
@@ -1127,32 +1134,26 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
     {
         Prof prof("match_cand_f16");
-        const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing experiments only (results invalid)
+        const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing builds only (results invalid)
         match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
                                                                           fb_count, ab ? std::atoi(ab) : 0);
     }
     check_launch("match_cand_f16_kernel");
-    unsigned int n_fb = 0;
+    std::vector<unsigned int> h_cnt(jobs.size());
     const auto R0 = std::chrono::steady_clock::now();
-    APS_HIP(hipMemcpyAsync(&n_fb, fb_count, sizeof n_fb, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipMemcpyAsync(h_cnt.data(), fb_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
     const auto R1 = std::chrono::steady_clock::now();
-    if (n_fb == 0) return;
-    // rows that could not be certified: exact f32 kernel in row-list mode, tiles grouped per job
-    std::vector<uint32_t> h_fb(n_fb);
-    APS_HIP(hipMemcpy(h_fb.data(), fb_list, n_fb * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::sort(h_fb.begin(), h_fb.end());
+    // exact f32 kernel in row-list mode, tiles grouped per job
     std::vector<WgJob> fwgs;
-    size_t p = 0;
-    for (int j = 0; j < (int)jobs.size() && p < h_fb.size(); ++j) {
-        const int64_t lo = jobs[j].out_off, hi = lo + jobs[j].nA;
-        size_t q = p;
-        while (q < h_fb.size() && (int64_t)h_fb[q] < hi) ++q;
-        for (size_t b = p; b < q; b += kTM) fwgs.push_back({j, (int)b, (int)std::min<size_t>(kTM, q - b)});
-        p = q;
+    size_t n_fb = 0;
+    for (int j = 0; j < (int)jobs.size(); ++j) {
+        const size_t base = (size_t)jobs[j].out_off, cnt = h_cnt[j];
+        n_fb += cnt;
+        for (size_t b = 0; b < cnt; b += kTM) fwgs.push_back({j, (int)(base + b), (int)std::min<size_t>(kTM, cnt - b)});
     }
+    if (fwgs.empty()) return;
     Ws<WgJob> dfw(fwgs.size());
-    APS_HIP(hipMemcpyAsync(fb_list, h_fb.data(), n_fb * sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
     APS_HIP(hipMemcpyAsync(dfw, fwgs.data(), fwgs.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
     {
         Prof prof("match2nn_fallback");
@@ -1162,7 +1163,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     const auto R2 = std::chrono::steady_clock::now();
     APS_HIP(hipStreamSynchronize(stream()));
     if (std::getenv("APS_TRACE"))
-        std::fprintf(stderr, "[aps] 2-NN: candidates (wait) %.2f ms, fallback list %u rows: host %.2f ms, kernel (wait) %.2f ms\n",
+        std::fprintf(stderr, "[aps] 2-NN: candidates (wait) %.2f ms, fallback list %zu rows: host %.2f ms, kernel (wait) %.2f ms\n",
                      std::chrono::duration<double, std::milli>(R1 - R0).count(), n_fb,
                      std::chrono::duration<double, std::milli>(R2 - R1).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - R2).count());
@@ -1338,13 +1339,18 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     for (int64_t p = 0; p < n_pairs; ++p) used[pa[p]] = used[pb[p]] = 1;
     std::vector<In<float>> din(n_img);
     std::vector<float> amax(n_img, 0.f);
-    Ws<float> slot(1);
+    Ws<float> slots((size_t)std::max(n_img, 1));
+    APS_HIP(hipMemsetAsync(slots, 0, (size_t)std::max(n_img, 1) * sizeof(float), stream()));
     for (int i = 0; i < n_img; ++i) {
         if (!used[i]) continue;
         const int64_t n = counts[i];
         const size_t elems = n == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld[i] + dim : (size_t)(dim - 1) * ld[i] + n);
         din[i].bind(desc[i], elems);
-        if (o.normalize == 2) amax[i] = absmax(din[i], n, ld[i], layout, slot);
+        if (o.normalize == 2) absmax_async(din[i], n, ld[i], layout, (float*)slots + i);
+    }
+    if (o.normalize == 2) {  // one read-back for all images (a round trip per image cost ~50 us each)
+        APS_HIP(hipMemcpyAsync(amax.data(), slots, (size_t)n_img * sizeof(float), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
     }
     // which variants (raw / normalised) of each image are needed: the reference decides per pair
     // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
