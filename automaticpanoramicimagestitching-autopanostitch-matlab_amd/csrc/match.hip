@@ -688,7 +688,12 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         asm("v_max3_f32 %1, %2, %3, %4\n\tv_max_f32 %1, %1, %5\n\tv_cmp_gt_f32 %0, %1, %6"
             : "=s"(any_hit), "+v"(m_scr)
             : "v"(a[4 * g]), "v"(a[4 * g + 1]), "v"(a[4 * g + 2]), "v"(a[4 * g + 3]), "v"(thr[rb]));
+#ifdef APS_NO_EVENTS  // timing experiment: what the event code costs by merely being there
+        asm volatile("" ::"s"(any_hit));
+        if (false) {
+#else
         if (__builtin_expect(any_hit != 0, 0)) {  // cold: the common case must be the fall-through (a taken branch
+#endif
                                                   // per slice costs an instruction refetch the MFMAs cannot hide)
             const bool hit = m_scr > thr[rb];
             if (__any(hit && pj[rb] >= 0)) drain(rb);
