@@ -469,12 +469,40 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
     const float* pa = jb.PA + (size_t)row * kDim;
     float d[3];
     int id[3] = {c0, c1, c2};
+    // the three candidates' k-ascending fma chains side by side (each chain in the canonical order; the A row is
+    // read once and three gathers are in flight instead of one: this tail is pure memory latency)
+    const float* pb[3];
+    bool ok[3];
+    float g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        const int j = id[e];
-        const bool ok = j >= 0 && j < jb.nB;
-        d[e] = ok ? exact_dist(pa, jb.PB + (size_t)j * kDim, a2, jb.sqB[j]) : INFINITY;
-        if (!ok) id[e] = 0x7fffffff;
+        ok[e] = id[e] >= 0 && id[e] < jb.nB;
+        pb[e] = ok[e] ? jb.PB + (size_t)id[e] * kDim : pa;
+    }
+#pragma unroll 2
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
+        const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const f32x4 be = *reinterpret_cast<const f32x4*>(pb[e] + 4 * s4);
+            const f32x4 bo = *reinterpret_cast<const f32x4*>(pb[e] + 64 + 4 * s4);
+            float t = g[e];
+            t = fmaf(ae.x, be.x, t);
+            t = fmaf(ao.x, bo.x, t);
+            t = fmaf(ae.y, be.y, t);
+            t = fmaf(ao.y, bo.y, t);
+            t = fmaf(ae.z, be.z, t);
+            t = fmaf(ao.z, bo.z, t);
+            t = fmaf(ae.w, be.w, t);
+            t = fmaf(ao.w, bo.w, t);
+            g[e] = t;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        d[e] = ok[e] ? __fsub_rn(__fadd_rn(a2, jb.sqB[ok[e] ? id[e] : 0]), __fmul_rn(2.0f, g[e])) : INFINITY;
+        if (!ok[e]) id[e] = 0x7fffffff;
     }
     // order the three by (d, idx): exact best and exact second
 #define APS_CSWAP(a, b)                                                    \
