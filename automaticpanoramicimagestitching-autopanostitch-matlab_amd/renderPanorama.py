@@ -390,23 +390,55 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
     else:
         pano = np.zeros((H, W, 3), np.uint8)
         cov = np.zeros((H, W), np.uint8)
-    if tile_subset is None:
+    workers = _render_workers() if device_out else 1
+    if tile_subset is None and workers <= 1:
         check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
     else:  # (first, step): only tiles t with t % step == first — the multi-GPU shard of the tile loop
-        if device_out:
+        first, step = (0, 1) if tile_subset is None else (int(tile_subset[0]), int(tile_subset[1]))
+        if device_out and tile_subset is not None:
             import torch
 
             pano.zero_()
             cov.zero_()
             torch.cuda.current_stream().synchronize()  # torch's fills must land before the library's stream paints tiles
-        check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
-                                   int(tile_subset[0]), int(tile_subset[1]), ptr(pano), ptr(cov)))
+        if workers <= 1:
+            check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
+                                       first, step, ptr(pano), ptr(cov)))
+        else:
+            # The tile loop of renderPanorama.m:342-406 is a parfor candidate: tiles are independent and paint
+            # disjoint canvas rectangles.  A few host threads each drive their own stream over an interleaved
+            # share of this rank's tiles (t % (step*workers) == first + step*k), so the many small pyramid
+            # launches of one tile overlap with another tile's; every tile's arithmetic is unchanged.
+            def work(k):
+                check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
+                                           first + step * k, step * workers, ptr(pano), ptr(cov)))
+                check(lib.aps_synchronize())  # this thread's stream
+
+            list(_render_pool(workers).map(work, range(workers)))
     del keep
     if o["cropBorder"] and not device_out:
         pano, _, _ = cropNonzeroBbox(pano, o["canvasColor"])
     if return_covered:
         return pano, None, cov, geo
     return pano, None
+
+
+_RENDER_POOL = None
+
+
+def _render_workers():
+    import os
+
+    return max(1, int(os.environ.get("APS_RENDER_WORKERS", "2")))
+
+
+def _render_pool(workers):
+    global _RENDER_POOL
+    from concurrent.futures import ThreadPoolExecutor
+
+    if _RENDER_POOL is None or _RENDER_POOL._max_workers < workers:
+        _RENDER_POOL = ThreadPoolExecutor(max_workers=workers)
+    return _RENDER_POOL
 
 
 def warp_tile(image, camera, geo, r0, c0, ht, wt, anglePower=2.0, gain=(1.0, 1.0, 1.0)):

@@ -246,6 +246,27 @@ def test_tile_shards_compose_to_the_full_render(rp, world):
     assert np.array_equal(acc_t.cpu().numpy(), full)
 
 
+@pytest.mark.parametrize("workers", [1, 2, 3])
+@pytest.mark.parametrize("subset", [None, (1, 2)])
+def test_threaded_tile_loop_changes_no_byte(rp, monkeypatch, workers, subset):
+    """Resident renders drive the tile loop from a few host threads (own stream each, interleaved tile shares,
+    APS_RENDER_WORKERS): the canvas must equal the single-stream render in every byte, for the full tile set and
+    for a multi-GPU shard of it."""
+    import torch
+
+    rng = np.random.default_rng(32)
+    imgs, cams = _scene(rng, n=5, W=200, H=130, f=280.0)
+    sizes = [(130, 200, 3)] * 5
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 4, "pyrSigma": 1.0, "tile": (64, 80), "cropBorder": False}
+    ref, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, tile_subset=subset)
+    dimgs = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    monkeypatch.setenv("APS_RENDER_WORKERS", str(workers))
+    for _ in range(2):  # twice: the second call reuses the pool and the per-thread workspaces
+        got, _ = rp.renderPanorama({}, dimgs, sizes, cams, "spherical", 2, opts, tile_subset=subset, device_out=True)
+        assert ref.any() and np.array_equal(got.cpu().numpy(), ref)
+
+
 def test_canvas_geometry_and_crop(rp):
     rng = np.random.default_rng(6)
     imgs, cams = _scene(rng)
