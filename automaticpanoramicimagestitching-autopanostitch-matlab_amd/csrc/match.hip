@@ -479,7 +479,7 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
         ok[e] = id[e] >= 0 && id[e] < jb.nB;
         pb[e] = ok[e] ? jb.PB + (size_t)id[e] * kDim : pa;
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int s4 = 0; s4 < 16; ++s4) {
         const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
         const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
