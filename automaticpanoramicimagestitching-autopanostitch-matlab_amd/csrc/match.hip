@@ -460,31 +460,18 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ pa, const 
 
 // Exact rescoring of one row's three candidates and the certification test (see the header comment): writes the
 // final (idx, d1, d2) of a certified row, or appends the row to the fallback list.
-__device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row, int c0, int c1, int c2, float bnd,
-                                            float aug_res, float dn_res, uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
-                                            float* __restrict__ out_d2, uint32_t* __restrict__ fb_list,
-                                            unsigned int* __restrict__ fb_count) {
-    const int64_t slot = jb.out_off + row;
-    const float a2 = jb.sqA[row];
-    const float* pa = jb.PA + (size_t)row * kDim;
-    float d[3];
-    int id[3] = {c0, c1, c2};
-    // the three candidates' k-ascending fma chains side by side (each chain in the canonical order; the A row is
-    // read once and three gathers are in flight instead of one: this tail is pure memory latency)
-    const float* pb[3];
-    bool ok[3];
-    float g[3] = {0.f, 0.f, 0.f};
+// k-ascending fma chains of N candidate rows against the A row, side by side (each chain in the canonical order; the
+// A row is read once and N gathers are in flight: this tail is pure memory traffic)
+template <int N>
+__device__ __forceinline__ void exact_chains(const float* __restrict__ pa, const float* const* pb, float* g) {
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        ok[e] = id[e] >= 0 && id[e] < jb.nB;
-        pb[e] = ok[e] ? jb.PB + (size_t)id[e] * kDim : pa;
-    }
+    for (int e = 0; e < N; ++e) g[e] = 0.f;
 #pragma unroll 4
     for (int s4 = 0; s4 < 16; ++s4) {
         const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4);
         const f32x4 ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < N; ++e) {
             const f32x4 be = *reinterpret_cast<const f32x4*>(pb[e] + 4 * s4);
             const f32x4 bo = *reinterpret_cast<const f32x4*>(pb[e] + 64 + 4 * s4);
             float t = g[e];
@@ -499,21 +486,27 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
             g[e] = t;
         }
     }
+}
+
+// Exact rescoring of one row's candidates and the certification test (see the header comment): writes the final
+// (idx, d1, d2) of a certified row, or appends the row to the fallback list.  bnd3 / bnd4 = a2 - 2 u for the third- /
+// fourth-largest screened value of the row.
+__device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row, int c0, int c1, int c2, float bnd3,
+                                            float bnd4, float aug_res, float dn_res, uint32_t* __restrict__ out_idx,
+                                            float* __restrict__ out_d1, float* __restrict__ out_d2,
+                                            uint32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    const int64_t slot = jb.out_off + row;
+    const float a2 = jb.sqA[row];
+    const float* pa = jb.PA + (size_t)row * kDim;
+    float d[3];
+    int id[3] = {c0, c1, c2};
+    const float* pb[3];
+    bool ok[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        d[e] = ok[e] ? __fsub_rn(__fadd_rn(a2, jb.sqB[ok[e] ? id[e] : 0]), __fmul_rn(2.0f, g[e])) : INFINITY;
-        if (!ok[e]) id[e] = 0x7fffffff;
+        ok[e] = id[e] >= 0 && id[e] < jb.nB;
+        pb[e] = ok[e] ? jb.PB + (size_t)id[e] * kDim : pa;
     }
-    // order the three by (d, idx): exact best and exact second
-#define APS_CSWAP(a, b)                                                    \
-    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
-        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
-        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
-    }
-    APS_CSWAP(0, 1)
-    APS_CSWAP(1, 2)
-    APS_CSWAP(0, 1)
-#undef APS_CSWAP
     // The screened value of column j is U_j = a^.b^_j - y~_j + na^ dn^_j, an UPPER bound (up to the row-wise terms
     // below) of s_j = a.b_j - b2_j/2:
     //   |a.b - a^.b^| <= ||a - a^|| ||b^|| + ||a|| ||b - b^||   (Cauchy-Schwarz on the two rounding losses);
@@ -522,15 +515,42 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
     //   row-wise remainder: ||a - a^|| max||b^|| + the largest residual of the three-piece b2/2 the workgroup has
     //   staged + any saturation loss of dn^ + f32 accumulation in the matrix pipe, bounded by 2^-15 (sum|a_k b_k|
     //   + y) (measured <= 7 x 2^-24, scripts/probe/mfma_f16_err.hip).
-    // Every non-candidate has U_j <= u3, hence s_j <= u3 + eg; in distance units twice that, plus the roundings of
-    // the canonical f32 evaluation itself.
+    // Every column outside the best K has U_j <= u_(K+1), hence s_j <= u_(K+1) + eg; in distance units twice that,
+    // plus the roundings of the canonical f32 evaluation itself.
     const float msb = *jb.maxsqB, mdb = *jb.maxdnB;
     const float nb = sqrtf(msb) * 1.000001f + mdb;
     const float na = sqrtf(a2) * 1.000001f;
     float eg = jb.dnA[row] * nb + aug_res + na * dn_res + 3.0517578125e-05f * (na * (nb + mdb) + 0.5f * msb);
     if (!(na < 65000.f)) eg = INFINITY;  // ||a|| does not fit the f16 slot: nothing is certified
     const float eps = 2.002f * eg + 1.52587890625e-05f * (a2 + msb + 2.0f * na * nb) + 1e-37f;
-    const bool certified = jb.nB <= 3 || (d[1] < bnd - eps);
+
+#define APS_CSWAP(a, b)                                                    \
+    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
+        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
+        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
+    }
+    // Stage 1: the best two alone.  If their exact second-best beats the bound of everything else - the third
+    // candidate included, through ITS screened value - the row is done after two 512-byte gathers instead of three
+    // (the gathers of this tail are 60 % of the kernel's HBM traffic).
+    float g[3];
+    exact_chains<2>(pa, pb, g);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        d[e] = ok[e] ? __fsub_rn(__fadd_rn(a2, jb.sqB[ok[e] ? id[e] : 0]), __fmul_rn(2.0f, g[e])) : INFINITY;
+        if (!ok[e]) id[e] = 0x7fffffff;
+    }
+    APS_CSWAP(0, 1)
+    bool certified = jb.nB > 3 && d[1] < bnd3 - eps;
+    if (!certified) {
+        // Stage 2: the third candidate joins; the bound is the fourth screened value
+        exact_chains<1>(pa, pb + 2, g + 2);
+        d[2] = ok[2] ? __fsub_rn(__fadd_rn(a2, jb.sqB[ok[2] ? id[2] : 0]), __fmul_rn(2.0f, g[2])) : INFINITY;
+        if (!ok[2]) id[2] = 0x7fffffff;
+        APS_CSWAP(1, 2)
+        APS_CSWAP(0, 1)
+        certified = jb.nB <= 3 || (d[1] < bnd4 - eps);
+    }
+#undef APS_CSWAP
     if (certified) {
         out_idx[slot] = jb.nB > 0 ? (uint32_t)id[0] + 1u : 0u;
         out_d1[slot] = d[0];
@@ -563,6 +583,9 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
     }
+#ifdef APS_MATCH_TIMING
+    const unsigned long long T_entry = __builtin_readcyclecounter();
+#endif
     const WgJob w = wgs[wg];
     const MatchJob jb = jobs[w.job];
     const int tid = threadIdx.x;
@@ -863,8 +886,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         });
     }
 #ifdef APS_MATCH_TIMING
+    const unsigned long long T_loop_end = __builtin_readcyclecounter();
     if ((ablate & 8) && blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4)) {
         const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+        printf("wave %d: prologue %llu cycles (entry -> first block)\n", wave, T_c0 - T_entry);
         printf("wave %d: %.3f GHz, %d blocks, cycles per block: total %.0f = mfma+selection %.0f + hand-over %.0f\n",
                wave, (double)(c1 - T_c0) / ((double)(w1 - T_w0) * 10.0), ntiles * (kTNB / 32),
                (double)(c1 - T_c0) / (ntiles * (kTNB / 32)), (double)T_mf / (ntiles * (kTNB / 32)),
@@ -899,16 +924,21 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     {
         const int src = lane & 31;  // every lane takes part in the exchange (a masked-off source lane would read as 0)
         const int s0 = __shfl(i0[1], src), s1 = __shfl(i1[1], src), s2 = __shfl(i2[1], src);
-        const float sb = __shfl(u3[1], src);
+        const float sb = __shfl(u3[1], src), sb2 = __shfl(u2[1], src);
         const int c0 = h ? s0 : i0[0], c1 = h ? s1 : i1[0], c2 = h ? s2 : i2[0];
-        const float ub = h ? sb : u3[0];
+        const float ub = h ? sb : u3[0], ub2 = h ? sb2 : u2[0];
         const int row = row0 + 32 * h;
-        if (row < nA) {
-            const float bnd = jb.sqA[row] - 2.0f * ub;  // approximate 4th-smallest distance (inf if < 4 columns)
-            rescore_row(jb, w.job, row, c0, c1, c2, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
+        if (row < nA && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
+            const float bnd = jb.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
+            const float bnd3 = jb.sqA[row] - 2.0f * ub2;  // ... and the 3rd
+            rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
                         fb_count);
         }
     }
+#ifdef APS_MATCH_TIMING
+    if ((ablate & 8) && blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4))
+        printf("wave %d: tail %llu cycles (last block -> exit)\n", wave, __builtin_readcyclecounter() - T_loop_end);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
