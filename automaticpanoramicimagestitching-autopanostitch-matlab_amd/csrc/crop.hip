@@ -1,0 +1,365 @@
+// crop.hip — the panorama crop rectangle on gfx950.
+//
+// Restates PP/imageProcessing/panoramaCropper.m:73-165: rgb2gray + imbinarize, imfill(.,'holes'), and the
+// line-by-line "largest rectangle under a histogram" scan whose serial MATLAB loops visit every pixel of a
+// >= 100 MPix canvas several times.  Semantics of the three toolbox calls and every quirk of the scan are fixed in
+// oracle/crop_oracle.c (parity unpinned for the toolbox calls); results are integers and must be identical.
+//
+// Device formulation (all byte/bit work, HBM- and latency-bound; nothing here is a GEMM):
+//   mask    : one wave per 64 pixels -> one 64-bit word of the background mask (ballot), 1 bit per pixel from here on
+//   imfill  : "reachable background" grows from the border by alternating row passes (Kogge-Stone fill inside a word,
+//             carry between words, one thread per row) and column passes (bitwise carry down/up a word column) until
+//             a full round changes nothing; at the fixed point this is the 4-connected flood fill
+//   heights : one thread per column counts the run of inside pixels ending at each line (u16)
+//   scan    : one workgroup per line with the line's heights in LDS plus block minima over 32 and 1024 elements;
+//             each element finds its nearest strictly smaller neighbour on both sides through those minima, which is
+//             what the reference's pointer-jumping left/right arrays compute; (area, -k) max per line, then
+//             (area, -line) max over lines = the reference's first maximum in (line, k) order
+#include <algorithm>
+#include <cstdint>
+
+#include "aps_internal.h"
+
+namespace aps {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint8_t crop_gray(uint8_t r, uint8_t g, uint8_t b) {
+    double v = 0.298936021293775 * (double)r;
+    v = v + 0.587043074451121 * (double)g;
+    v = v + 0.114020904255103 * (double)b;
+    v = v + 0.5;
+    const int q = (int)v;
+    return (uint8_t)(q > 255 ? 255 : q);
+}
+
+// bg[r][wd]: bit j set iff pixel (r, 64 wd + j) exists and is background (panoramaCropper.m:73-84)
+__global__ __launch_bounds__(256) void crop_mask_kernel(const uint8_t* __restrict__ img, int64_t h, int64_t w, int layout,
+                                                        int white, double t, int64_t W64, u64* __restrict__ bg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wd = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r = blockIdx.y;
+    if (wd >= W64) return;
+    const int64_t col = wd * 64 + lane;
+    bool isbg = false;
+    if (col < w) {
+        uint8_t p[3];
+        if (layout == APS_IMG_U8_HWC) {
+            const uint8_t* q = img + (r * w + col) * 3;
+            p[0] = q[0];
+            p[1] = q[1];
+            p[2] = q[2];
+        } else {  // MATLAB h x w x 3, column-major planes
+            const int64_t plane = h * w, o = col * h + r;
+            p[0] = img[o];
+            p[1] = img[plane + o];
+            p[2] = img[2 * plane + o];
+        }
+        const bool fg = (double)crop_gray(p[0], p[1], p[2]) > t;
+        isbg = white ? fg : !fg;  // "white": BW = complement
+    }
+    const u64 m = __ballot(isbg);
+    if (lane == 0) bg[r * W64 + wd] = m;
+}
+
+// seeds: background pixels on the image border
+__global__ void crop_seed_kernel(const u64* __restrict__ bg, int64_t h, int64_t w, int64_t W64, u64* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * W64) return;
+    const int64_t r = i / W64, wd = i - r * W64;
+    u64 m = 0;
+    if (r == 0 || r == h - 1) m = ~0ull;
+    if (wd == 0) m |= 1ull;
+    if (wd == (w - 1) >> 6) m |= 1ull << ((w - 1) & 63);
+    out[i] = bg[i] & m;
+}
+
+// bits reachable from `seed` through `prop` moving towards higher (UP) or lower bit positions
+template <bool UP>
+__device__ __forceinline__ u64 fill_dir(u64 seed, u64 prop) {
+    u64 g = seed & prop, p = prop;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        g |= p & (UP ? g << s : g >> s);
+        p &= UP ? p << s : p >> s;
+    }
+    return g;
+}
+
+// one thread per row: left-to-right then right-to-left through the words of the row
+__global__ void crop_fill_rows_kernel(const u64* __restrict__ bg, int64_t h, int64_t W64, u64* __restrict__ out,
+                                      int* __restrict__ changed) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= h) return;
+    const u64* b = bg + r * W64;
+    u64* o = out + r * W64;
+    bool ch = false;
+    u64 carry = 0;
+    for (int64_t wd = 0; wd < W64; ++wd) {
+        const u64 old = o[wd];
+        const u64 nw = old | fill_dir<true>(old | carry, b[wd]);
+        carry = nw >> 63;
+        if (nw != old) {
+            o[wd] = nw;
+            ch = true;
+        }
+    }
+    carry = 0;
+    for (int64_t wd = W64 - 1; wd >= 0; --wd) {
+        const u64 old = o[wd];
+        const u64 nw = old | fill_dir<false>(old | (carry << 63), b[wd]);
+        carry = nw & 1ull;
+        if (nw != old) {
+            o[wd] = nw;
+            ch = true;
+        }
+    }
+    if (ch) *changed = 1;
+}
+
+// one thread per word column: top-to-bottom then bottom-to-top (64 pixel columns at once, bitwise)
+__global__ void crop_fill_cols_kernel(const u64* __restrict__ bg, int64_t h, int64_t W64, u64* __restrict__ out,
+                                      int* __restrict__ changed) {
+    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= W64) return;
+    bool ch = false;
+    u64 prev = 0;
+    for (int64_t r = 0; r < h; ++r) {
+        const u64 old = out[r * W64 + wd];
+        const u64 nw = old | (prev & bg[r * W64 + wd]);
+        if (nw != old) {
+            out[r * W64 + wd] = nw;
+            ch = true;
+        }
+        prev = nw;
+    }
+    prev = 0;
+    for (int64_t r = h - 1; r >= 0; --r) {
+        const u64 old = out[r * W64 + wd];
+        const u64 nw = old | (prev & bg[r * W64 + wd]);
+        if (nw != old) {
+            out[r * W64 + wd] = nw;
+            ch = true;
+        }
+        prev = nw;
+    }
+    if (ch) *changed = 1;
+}
+
+// height(line, k) of panoramaCropper.m:111-121: run length of inside pixels (BW2) ending at this line
+__global__ void crop_heights_kernel(const u64* __restrict__ out, int64_t h, int64_t w, int64_t W64,
+                                    uint16_t* __restrict__ H) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= w) return;
+    const int64_t wd = col >> 6;
+    const int bit = (int)(col & 63);
+    uint32_t cnt = 0;
+    for (int64_t r = 0; r < h; ++r) {
+        const bool outside = (out[r * W64 + wd] >> bit) & 1ull;
+        cnt = outside ? 0u : cnt + 1u;
+        H[r * w + col] = (uint16_t)cnt;
+    }
+}
+
+struct LineBest {
+    u64 key;           // (area << 16) | (0xFFFF - k0): the maximum is the reference's first maximum of the line
+    int32_t ll, rr, hh;  // 1-based left, right and the height of that element
+    int32_t pad;
+};
+
+// panoramaCropper.m:123-149 for one line
+__global__ __launch_bounds__(256) void crop_scan_kernel(const uint16_t* __restrict__ H, int64_t w, LineBest* __restrict__ best) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_h[];
+    const int n = (int)w;
+    const int n1 = (n + 31) >> 5, n2 = (n + 1023) >> 10;
+    uint16_t* m1 = s_h + ((n + 7) & ~7);
+    uint16_t* m2 = m1 + ((n1 + 7) & ~7);
+    __shared__ u64 s_key[4];
+    __shared__ u64 s_win;
+    const int64_t line = blockIdx.x;
+    const uint16_t* row = H + line * w;
+    for (int k = threadIdx.x; k < n; k += 256) s_h[k] = k == n - 1 ? (uint16_t)0xFFFF : row[k];
+    __syncthreads();
+    // the last column never bounds or joins a rectangle: `right` is built for k = w-1..1 only and stops at w-1
+    for (int b = threadIdx.x; b < n1; b += 256) {
+        uint16_t m = 0xFFFF;
+        for (int k = b * 32; k < min(n, b * 32 + 32); ++k) m = min(m, s_h[k]);
+        m1[b] = m;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n2; b += 256) {
+        uint16_t m = 0xFFFF;
+        for (int q = b * 32; q < min(n1, b * 32 + 32); ++q) m = min(m, m1[q]);
+        m2[b] = m;
+    }
+    __syncthreads();
+    u64 key = 0;
+    int my_l = 0, my_r = 0, my_h = 0;
+    for (int k = threadIdx.x; k < n - 1; k += 256) {
+        const uint16_t v = s_h[k];
+        if (v == 0) continue;
+        // nearest j < k with s_h[j] < v
+        int j = k - 1;
+        while (j >= 0 && (j & 31) != 31 && s_h[j] >= v) --j;
+        if (j >= 0 && (j & 31) == 31 && s_h[j] >= v) {
+            int b = j >> 5;  // j is the last element of block b
+            while (b >= 0 && m1[b] >= v) {
+                if ((b & 31) == 31 && m2[b >> 5] >= v) b -= 32;
+                else --b;
+            }
+            if (b < 0) {
+                j = -1;
+            } else {
+                j = b * 32 + 31;
+                while (s_h[j] >= v) --j;  // the block holds a smaller element
+            }
+        }
+        const int left0 = j + 1;
+        // nearest j > k with s_h[j] < v (the sentinel in column n-1 is never smaller)
+        j = k + 1;
+        while (j < n && (j & 31) != 0 && s_h[j] >= v) ++j;
+        if (j < n && (j & 31) == 0 && s_h[j] >= v) {
+            int b = j >> 5;  // j is the first element of block b
+            while (b < n1 && m1[b] >= v) {
+                if ((b & 31) == 0 && m2[b >> 5] >= v) b += 32;
+                else ++b;
+            }
+            if (b >= n1) {
+                j = n;
+            } else {
+                j = b * 32;
+                while (s_h[j] >= v) ++j;
+            }
+        }
+        const int right0 = min(j, n - 1) - 1;  // never beyond column w-1 (1-based), i.e. 0-based n-2
+        const u64 area = (u64)(right0 - left0 + 1) * (u64)v;
+        const u64 kk = (area << 16) | (u64)(0xFFFF - k);
+        if (kk > key) {
+            key = kk;
+            my_l = left0 + 1;
+            my_r = right0 + 1;
+            my_h = v;
+        }
+    }
+    u64 wk = key;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u64 o = __shfl_xor(wk, s);
+        wk = o > wk ? o : wk;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = wk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 m = s_key[0];
+        for (int q = 1; q < 4; ++q) m = s_key[q] > m ? s_key[q] : m;
+        s_win = m;
+        if (m == 0) best[line] = LineBest{0, 0, 0, 0, 0};
+    }
+    __syncthreads();
+    if (key != 0 && key == s_win) best[line] = LineBest{key, my_l, my_r, my_h, 0};
+}
+
+// first maximum over the lines (panoramaCropper.m:139-147: strict `<`), then the crop indices (:153-157)
+__global__ __launch_bounds__(256) void crop_pick_kernel(const LineBest* __restrict__ best, int64_t h, int64_t w,
+                                                        int32_t* __restrict__ rect) {
+    __shared__ u64 s_key[4];
+    u64 key = 0;
+    for (int64_t l = threadIdx.x; l < h; l += 256) {
+        const u64 area = best[l].key >> 16;
+        if (area == 0) continue;
+        const u64 kk = (area << 16) | (u64)(0xFFFF - l);
+        key = kk > key ? kk : key;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u64 o = __shfl_xor(key, s);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 m = s_key[0];
+        for (int q = 1; q < 4; ++q) m = s_key[q] > m ? s_key[q] : m;
+        int64_t ll = 0, rr = 0, hh = 0, nl = 0;
+        if (m != 0) {
+            const int64_t l = 0xFFFF - (int64_t)(m & 0xFFFF);
+            ll = best[l].ll;
+            rr = best[l].rr;
+            hh = best[l].hh;
+            nl = l + 1;
+        }
+        const int64_t cropH = hh + 1, cropW = rr - ll + 1, offsetx = ll, offsety = nl - hh + 1;
+        rect[0] = (int32_t)offsetx;
+        rect[1] = (int32_t)offsety;
+        rect[2] = (int32_t)cropW;
+        rect[3] = (int32_t)cropH;
+        rect[4] = offsetx >= 1 && offsety >= 1 && offsety + cropH <= h && offsetx + cropW <= w;
+    }
+}
+
+}  // namespace aps
+
+using namespace aps;
+
+extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layout, int canvas_white, double range,
+                             int32_t* rect, int32_t* valid) {
+    return guarded([&] {
+        APS_REQUIRE(img && rect && valid, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(h >= 1 && w >= 1, APS_E_DIM, "empty image");
+        APS_REQUIRE(h <= 65534 && w <= 60000, APS_E_DIM,
+                    "crop is built for canvases up to 65534 rows x 60000 columns (got %lld x %lld)", (long long)h, (long long)w);
+        APS_REQUIRE(layout == APS_IMG_U8_HWC || layout == APS_IMG_U8_MATLAB, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(canvas_white == 0 || canvas_white == 1, APS_E_ARG, "canvas_white must be 0 or 1");
+        APS_REQUIRE(range >= 0.0 && range <= 255.0, APS_E_ARG, "range must be in [0,255]");
+        ctx();
+        const int64_t W64 = (w + 63) / 64;
+        In<uint8_t> di(img, (size_t)h * w * 3);
+        Ws<u64> bg((size_t)h * W64), out((size_t)h * W64);
+        Ws<int> changed(1);
+        Ws<uint16_t> H((size_t)h * w);
+        Ws<LineBest> best((size_t)h);
+        Ws<int32_t> drect(5);
+        const double t = (range / 255.0) * 255.0;
+        {
+            Prof prof("crop_mask");
+            crop_mask_kernel<<<dim3(cdiv(W64, 4), (unsigned)h), 256, 0, stream()>>>(di, h, w, layout, canvas_white, t, W64, bg);
+            crop_seed_kernel<<<cdiv((size_t)h * W64, 256), 256, 0, stream()>>>(bg, h, w, W64, out);
+        }
+        check_launch("crop_mask_kernel");
+        {
+            // rounds of (row pass, column pass) until one changes nothing; the count is the "winding depth" of the
+            // background, 2-4 for a panorama outline, bounded by the pixel count for a maze
+            Prof prof("crop_fill");
+            const int64_t max_rounds = h * W64 * 64 + 2;
+            for (int64_t it = 0; it < max_rounds; ++it) {
+                APS_HIP(hipMemsetAsync(changed, 0, sizeof(int), stream()));
+                crop_fill_rows_kernel<<<cdiv(h, 64), 64, 0, stream()>>>(bg, h, W64, out, changed);
+                crop_fill_cols_kernel<<<cdiv(W64, 64), 64, 0, stream()>>>(bg, h, W64, out, changed);
+                int hc = 0;
+                APS_HIP(hipMemcpyAsync(&hc, changed, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                APS_HIP(hipStreamSynchronize(stream()));
+                if (!hc) break;
+            }
+        }
+        check_launch("crop_fill_kernel");
+        {
+            Prof prof("crop_scan");
+            crop_heights_kernel<<<cdiv(w, 256), 256, 0, stream()>>>(out, h, w, W64, H);
+            const int n1 = (int)((w + 31) >> 5), n2 = (int)((w + 1023) >> 10);
+            const size_t lds = sizeof(uint16_t) * (size_t)(((w + 7) & ~7) + ((n1 + 7) & ~7) + ((n2 + 7) & ~7));
+            static thread_local size_t attr_set = 0;
+            if (lds > 48 * 1024 && lds > attr_set) {
+                APS_HIP(hipFuncSetAttribute((const void*)crop_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = lds;
+            }
+            crop_scan_kernel<<<(unsigned)h, 256, lds, stream()>>>(H, w, best);
+            crop_pick_kernel<<<1, 256, 0, stream()>>>(best, h, w, drect);
+        }
+        check_launch("crop_scan_kernel");
+        int32_t hr[5];
+        APS_HIP(hipMemcpyAsync(hr, drect, sizeof hr, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        for (int e = 0; e < 4; ++e) rect[e] = hr[e];
+        *valid = hr[4];
+    });
+}

@@ -131,3 +131,51 @@ def resizeImagesToLimits(imageFiles, heightLimit, widthLimit, mode="fit"):
         return stage1
     Hmax, Wmax = max(s[0] for s in sizes), max(s[1] for s in sizes)
     return [J if J.size == 0 else imresize(J, (Hmax, Wmax), "bicubic") for J in stage1]
+
+
+def cropRectangle(stitchedImage, canvasColor="black", blackRange=0, whiteRange=250):
+    """The crop indices of panoramaCropper.m:73-157 on the device: (offsetx, offsety, cropW, cropH) 1-based as in the
+    reference, and whether rows offsety..offsety+cropH / columns offsetx..offsetx+cropW lie inside the image."""
+    white = str(canvasColor).lower() == "white"
+    if _capi.is_torch(stitchedImage):
+        img = stitchedImage.contiguous()
+        if str(img.dtype) != "torch.uint8" or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("stitchedImage must be M-by-N-by-3 uint8")
+        h, w = int(img.shape[0]), int(img.shape[1])
+    else:
+        img = np.ascontiguousarray(stitchedImage)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("stitchedImage must be M-by-N-by-3 uint8")
+        h, w = img.shape[:2]
+    rect = np.zeros(4, np.int32)
+    valid = np.zeros(1, np.int32)
+    check(lib.aps_crop_rect(ptr(img), h, w, _capi.APS_IMG_U8_HWC, int(white), float(whiteRange if white else blackRange),
+                            ptr(rect), ptr(valid)))
+    return tuple(int(v) for v in rect), bool(valid[0])
+
+
+def panoramaCropper(input, stitchedImage):
+    """croppedImage = panoramaCropper(input, stitchedImage) (panoramaCropper.m:1-178): same field checks, same crop
+    (offsety:offsety+cropH, offsetx:offsetx+cropW, 1-based inclusive), the input unchanged with a warning when the
+    rectangle leaves the image ("Image has background holes")."""
+    import warnings
+
+    req = ["canvasColor", "blackRange", "whiteRange", "showCropBoundingBox", "displayPanoramas"]
+    missing = [f for f in req if f not in input]
+    if missing:
+        raise ValueError("panoramaCropper:MissingField: Missing required input fields: " + ", ".join(missing))
+    color = str(input["canvasColor"]).lower()
+    if color not in ("black", "white"):
+        raise ValueError('panoramaCropper:InvalidCanvasColor: input.canvasColor must be "black" or "white".')
+    for f in ("blackRange", "whiteRange"):
+        v = input[f]
+        if not (np.isscalar(v) and np.isfinite(v) and 0 <= v <= 255):
+            raise ValueError(f"panoramaCropper:Invalid{f[0].upper() + f[1:]}: input.{f} must be a numeric scalar in [0,255].")
+    for f in ("showCropBoundingBox", "displayPanoramas"):
+        if not isinstance(input[f], (bool, np.bool_)):
+            raise ValueError(f"panoramaCropper:InvalidFlag: input.{f} must be a logical scalar.")
+    (ox, oy, cw, ch), ok = cropRectangle(stitchedImage, color, input["blackRange"], input["whiteRange"])
+    if not ok:
+        warnings.warn("Cannot crop the image. Image has background holes.")
+        return stitchedImage
+    return stitchedImage[oy - 1:oy + ch, ox - 1:ox + cw]

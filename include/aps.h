@@ -288,6 +288,15 @@ enum { APS_RESIZE_BILINEAR = 0, APS_RESIZE_BICUBIC = 1 };
 int aps_imresize_u8(const uint8_t* img, int h, int w, int c, int layout, int oh, int ow, double scale_r, double scale_c,
                     int method, uint8_t* out);
 
+/* SURVEY 8(f) rank 4 -- the crop rectangle of PP/imageProcessing/panoramaCropper.m:73-165: rgb2gray + imbinarize against
+ * `range` (input.blackRange, or input.whiteRange with canvas_white = 1 and the mask complemented), imfill(.,'holes'), and
+ * the line-by-line largest-rectangle scan (first maximum in (line, column) order, the last column never part of a
+ * rectangle, as in the reference).  img: h x w x 3 uint8 (layout as for the renderers).  rect[0..3] = offsetx, offsety,
+ * cropW, cropH, 1-based as in :153-157; the reference then takes rows offsety..offsety+cropH and columns
+ * offsetx..offsetx+cropW.  *valid = 0 when that range leaves the image (the reference warns and returns the input). */
+int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layout, int canvas_white, double range, int32_t* rect,
+                  int32_t* valid);
+
 /* SURVEY 8(f) rank 1 -- the overlap statistics of gainCompensationRKf (PP/gainCompensation/gainCompensationRKf.m:96-149,
  * 239-367): every `stride`-th canvas point (1-based coordinates, :106-107) that two images i < j both cover
  * (front, inside, tent weight > 0) adds 1 to n_ij(i,j) and the two bilinear RAW (0..255) colour samples to

@@ -327,6 +327,20 @@ static void cmd_imresize(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
                           mxGetScalar(prhs[4]) != 0 ? APS_RESIZE_BICUBIC : APS_RESIZE_BILINEAR, (uint8_t*)mxGetData(plhs[0])));
 }
 
+// [rect, valid] = aps_mex('crop_rect', I uint8 HxWx3, canvasWhite(0/1), range) ; rect = [offsetx offsety cropW cropH] (1-based)
+static void cmd_crop(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 4 && mxIsUint8(prhs[1]) && mxGetNumberOfDimensions(prhs[1]) == 3, "aps:type",
+         "usage: I uint8 HxWx3, canvasWhite, range");
+    const mwSize* d = mxGetDimensions(prhs[1]);
+    need(d[2] == 3, "aps:dim", "I must have three channels");
+    int32_t rect[4], valid = 0;
+    check(aps_crop_rect((const uint8_t*)mxGetData(prhs[1]), (int64_t)d[0], (int64_t)d[1], APS_IMG_U8_MATLAB,
+                        mxGetScalar(prhs[2]) != 0, mxGetScalar(prhs[3]), rect, &valid));
+    plhs[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
+    for (int e = 0; e < 4; ++e) mxGetPr(plhs[0])[e] = rect[e];
+    if (nlhs > 1) plhs[1] = mxCreateLogicalScalar(valid != 0);
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
     const std::string cmd = str(prhs[0]);
@@ -344,5 +358,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);
     else if (cmd == "gain_overlap_stats") cmd_gain(nlhs, plhs, nrhs, prhs);
     else if (cmd == "imresize_u8") cmd_imresize(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "crop_rect") cmd_crop(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
 }

