@@ -288,6 +288,18 @@ enum { APS_RESIZE_BILINEAR = 0, APS_RESIZE_BICUBIC = 1 };
 int aps_imresize_u8(const uint8_t* img, int h, int w, int c, int layout, int oh, int ow, double scale_r, double scale_c,
                     int method, uint8_t* out);
 
+/* SURVEY 8(f) rank 3 -- the per-pair blocks of the bundle adjustment's normal equations: the parfor body of
+ * accumulateNormalEqnsBlock (PP/bundleAdjustment/bundleAdjustmentRKf.m:717-741) with jacobianPair (:793-899),
+ * computeSingleResidual (:1641-1686), computeJacobianWrtCamera (:1688-1783) and huberWeight (:1806-1829).
+ * Ui, Uj: total x 2 f64, column-major with leading dimension ldu (x at [k], y at [ldu + k]): the matched points on image
+ * i and j of all pairs back to back; pair p owns rows pair_ptr[p] .. pair_ptr[p+1]-1.  cams: per pair four cameras
+ * (base i, base j, incremented i, incremented j), 12 f64 each: f, cx, cy, R (3 x 3 column-major, world -> camera).
+ * out: per pair 59 f64 = Hii, Hjj, Hij (4 x 4 column-major over [dthx dthy dthz df]), gi, gj (4), E, r2sum, rcnt.
+ * A camera with fewer parameters uses the leading rows/columns, as the reference's J(:, 1:numel(cols)) does.
+ * both_directions = !opts.OneDirection.  The LM loop, prior, sparse assembly and solve stay with the caller. */
+int aps_ba_pair_blocks(const double* Ui, const double* Uj, int64_t ldu, const int64_t* pair_ptr, int n_pairs,
+                       const double* cams, double sigma_huber, int both_directions, double* out);
+
 /* SURVEY 8(f) rank 4 -- the crop rectangle of PP/imageProcessing/panoramaCropper.m:73-165: rgb2gray + imbinarize against
  * `range` (input.blackRange, or input.whiteRange with canvas_white = 1 and the mask complemented), imfill(.,'holes'), and
  * the line-by-line largest-rectangle scan (first maximum in (line, column) order, the last column never part of a

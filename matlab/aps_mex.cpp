@@ -341,6 +341,25 @@ static void cmd_crop(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     if (nlhs > 1) plhs[1] = mxCreateLogicalScalar(valid != 0);
 }
 
+// out = aps_mex('ba_pair_blocks', Ui total x 2, Uj total x 2, pairPtr (P+1, 0-based), cams 12 x 4 x P, sigmaHuber, bothDirections)
+// out: 59 x P double = Hii, Hjj, Hij (4x4 column-major), gi, gj, E, r2sum, rcnt per pair
+static void cmd_ba(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 7 && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsDouble(prhs[4]), "aps:type",
+         "usage: Ui, Uj (double total x 2), pairPtr, cams (12 x 4 x P double), sigmaHuber, bothDirections");
+    const int64_t total = (int64_t)mxGetM(prhs[1]);
+    need(mxGetN(prhs[1]) == 2 && mxGetN(prhs[2]) == 2 && (int64_t)mxGetM(prhs[2]) == total, "aps:dim", "Ui, Uj must be total x 2");
+    const size_t np1 = mxGetNumberOfElements(prhs[3]);
+    need(np1 >= 1, "aps:dim", "pairPtr must have P+1 entries");
+    const int P = (int)np1 - 1;
+    need(mxGetNumberOfElements(prhs[4]) == (size_t)48 * P, "aps:dim", "cams must be 12 x 4 x P");
+    std::vector<int64_t> pp(np1);
+    const double* src = mxGetPr(prhs[3]);
+    for (size_t e = 0; e < np1; ++e) pp[e] = (int64_t)src[e];
+    plhs[0] = mxCreateDoubleMatrix(59, P, mxREAL);
+    check(aps_ba_pair_blocks(mxGetPr(prhs[1]), mxGetPr(prhs[2]), total, pp.data(), P, mxGetPr(prhs[4]), mxGetScalar(prhs[5]),
+                             mxGetScalar(prhs[6]) != 0, mxGetPr(plhs[0])));
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
     const std::string cmd = str(prhs[0]);
@@ -359,5 +378,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "gain_overlap_stats") cmd_gain(nlhs, plhs, nrhs, prhs);
     else if (cmd == "imresize_u8") cmd_imresize(nlhs, plhs, nrhs, prhs);
     else if (cmd == "crop_rect") cmd_crop(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "ba_pair_blocks") cmd_ba(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
 }

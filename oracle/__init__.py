@@ -422,6 +422,22 @@ def imresize_u8(img, scale_or_size, method="bicubic"):
     return out[..., 0] if sq else out
 
 
+_orc_ba_pair_blocks = _sig("orc_ba_pair_blocks", [_vp, _vp, C.c_int64, _vp, _i, _vp, _d, _i, _vp])
+
+
+def ba_pair_blocks(Ui, Uj, pair_ptr, cams, sigma, both=True):
+    """The parfor body of accumulateNormalEqnsBlock (bundleAdjustmentRKf.m:717-741): (n_pairs, 59) blocks.
+    Ui, Uj: total x 2; cams: (n_pairs, 4, 12) = base i, base j, incremented i, incremented j as (f, cx, cy, R col-major)."""
+    Ui = np.asfortranarray(np.asarray(Ui, np.float64).reshape(-1, 2))
+    Uj = np.asfortranarray(np.asarray(Uj, np.float64).reshape(-1, 2))
+    pp = np.ascontiguousarray(pair_ptr, np.int64)
+    cc = np.ascontiguousarray(cams, np.float64)
+    out = np.zeros((len(pp) - 1, 59), np.float64)
+    _orc_ba_pair_blocks(Ui.ctypes.data, Uj.ctypes.data, Ui.shape[0], pp.ctypes.data, len(pp) - 1, cc.ctypes.data,
+                        float(sigma), int(both), out.ctypes.data)
+    return out
+
+
 _orc_crop_rect = _sig("orc_crop_rect", [_vp, C.c_int64, C.c_int64, _i, _d, _vp])
 _orc_crop_inside = _sig("orc_crop_inside", [_vp, C.c_int64, C.c_int64, _i, _d, _vp])
 
