@@ -8,9 +8,10 @@
 // Device formulation (all byte/bit work, HBM- and latency-bound; nothing here is a GEMM):
 //   mask    : one wave per 64 pixels -> one 64-bit word of the background mask (ballot), 1 bit per pixel from here on
 //   imfill  : "reachable background" grows from the border by alternating row passes (Kogge-Stone fill inside a word,
-//             carry between words, one thread per row) and column passes (bitwise carry down/up a word column) until
-//             a full round changes nothing; at the fixed point this is the 4-connected flood fill
-//   heights : one thread per column counts the run of inside pixels ending at each line (u16)
+//             carry between words, one thread per row) and column passes (bitwise carry down/up a word column, split
+//             into row chunks with a carry scan between them) until a full round changes nothing; at the fixed point
+//             this is the 4-connected flood fill
+//   heights : run length of inside pixels ending at each line (u16), per column, chunked the same way
 //   scan    : one workgroup per line with the line's heights in LDS plus block minima over 32 and 1024 elements;
 //             each element finds its nearest strictly smaller neighbour on both sides through those minima, which is
 //             what the reference's pointer-jumping left/right arrays compute; (area, -k) max per line, then
@@ -117,44 +118,135 @@ __global__ void crop_fill_rows_kernel(const u64* __restrict__ bg, int64_t h, int
     if (ch) *changed = 1;
 }
 
-// one thread per word column: top-to-bottom then bottom-to-top (64 pixel columns at once, bitwise)
-__global__ void crop_fill_cols_kernel(const u64* __restrict__ bg, int64_t h, int64_t W64, u64* __restrict__ out,
-                                      int* __restrict__ changed) {
-    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wd >= W64) return;
-    bool ch = false;
-    u64 prev = 0;
-    for (int64_t r = 0; r < h; ++r) {
-        const u64 old = out[r * W64 + wd];
-        const u64 nw = old | (prev & bg[r * W64 + wd]);
-        if (nw != old) {
-            out[r * W64 + wd] = nw;
-            ch = true;
+// Column passes, 64 pixel columns at once (bitwise), in three steps so that the sequential depth is the chunk length
+// and the chunk count instead of the image height: (A) per chunk of kChunk rows and word column, what reaches the
+// chunk's far end from seeds inside it (G) and which bits pass straight through (P = AND of the background);
+// (B) per word column a serial carry scan over the chunks, carry' = G | (P & carry); (C) per chunk the pass itself
+// with its carry-in.  DOWN = top-to-bottom.
+constexpr int kChunk = 64;
+
+template <bool DOWN>
+__global__ void crop_col_gp_kernel(const u64* __restrict__ bg, const u64* __restrict__ out, int64_t h, int64_t W64,
+                                   int64_t n_chunks, u64* __restrict__ G, u64* __restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks * W64) return;
+    const int64_t ch = i / W64, wd = i - ch * W64;
+    const int64_t r_lo = ch * kChunk, r_hi = min(h, r_lo + kChunk);
+    u64 g = 0, p = ~0ull;
+    if (DOWN) {
+        for (int64_t r = r_lo; r < r_hi; ++r) {
+            const u64 b = bg[r * W64 + wd];
+            g = out[r * W64 + wd] | (g & b);
+            p &= b;
         }
-        prev = nw;
-    }
-    prev = 0;
-    for (int64_t r = h - 1; r >= 0; --r) {
-        const u64 old = out[r * W64 + wd];
-        const u64 nw = old | (prev & bg[r * W64 + wd]);
-        if (nw != old) {
-            out[r * W64 + wd] = nw;
-            ch = true;
+    } else {
+        for (int64_t r = r_hi - 1; r >= r_lo; --r) {
+            const u64 b = bg[r * W64 + wd];
+            g = out[r * W64 + wd] | (g & b);
+            p &= b;
         }
-        prev = nw;
     }
-    if (ch) *changed = 1;
+    G[i] = g;
+    P[i] = p;
 }
 
-// height(line, k) of panoramaCropper.m:111-121: run length of inside pixels (BW2) ending at this line
-__global__ void crop_heights_kernel(const u64* __restrict__ out, int64_t h, int64_t w, int64_t W64,
-                                    uint16_t* __restrict__ H) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= w) return;
+// carry INTO every chunk (overwrites G with it)
+template <bool DOWN>
+__global__ void crop_col_scan_kernel(u64* __restrict__ G, const u64* __restrict__ P, int64_t W64, int64_t n_chunks) {
+    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= W64) return;
+    u64 carry = 0;
+    if (DOWN) {
+        for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            const u64 g = G[ch * W64 + wd], p = P[ch * W64 + wd];
+            G[ch * W64 + wd] = carry;
+            carry = g | (p & carry);
+        }
+    } else {
+        for (int64_t ch = n_chunks - 1; ch >= 0; --ch) {
+            const u64 g = G[ch * W64 + wd], p = P[ch * W64 + wd];
+            G[ch * W64 + wd] = carry;
+            carry = g | (p & carry);
+        }
+    }
+}
+
+template <bool DOWN>
+__global__ void crop_col_apply_kernel(const u64* __restrict__ bg, int64_t h, int64_t W64, int64_t n_chunks,
+                                      const u64* __restrict__ Cin, u64* __restrict__ out, int* __restrict__ changed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks * W64) return;
+    const int64_t ch = i / W64, wd = i - ch * W64;
+    const int64_t r_lo = ch * kChunk, r_hi = min(h, r_lo + kChunk);
+    u64 prev = Cin[i];
+    bool chg = false;
+    if (DOWN) {
+        for (int64_t r = r_lo; r < r_hi; ++r) {
+            const u64 old = out[r * W64 + wd];
+            const u64 nw = old | (prev & bg[r * W64 + wd]);
+            if (nw != old) {
+                out[r * W64 + wd] = nw;
+                chg = true;
+            }
+            prev = nw;
+        }
+    } else {
+        for (int64_t r = r_hi - 1; r >= r_lo; --r) {
+            const u64 old = out[r * W64 + wd];
+            const u64 nw = old | (prev & bg[r * W64 + wd]);
+            if (nw != old) {
+                out[r * W64 + wd] = nw;
+                chg = true;
+            }
+            prev = nw;
+        }
+    }
+    if (chg) *changed = 1;
+}
+
+// height(line, k) of panoramaCropper.m:111-121: run length of inside pixels (BW2) ending at this line.  Same three
+// steps as the column passes: per chunk of rows the run length at its end (and whether the whole chunk is inside),
+// a serial scan over the chunks per column, then the chunk itself with its carried-in run length.
+__global__ void crop_height_gp_kernel(const u64* __restrict__ out, int64_t h, int64_t w, int64_t W64, int64_t n_chunks,
+                                      uint32_t* __restrict__ carry) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks * w) return;
+    const int64_t ch = i / w, col = i - ch * w;
     const int64_t wd = col >> 6;
     const int bit = (int)(col & 63);
+    const int64_t r_lo = ch * kChunk, r_hi = min(h, r_lo + kChunk);
     uint32_t cnt = 0;
-    for (int64_t r = 0; r < h; ++r) {
+    bool all_in = true;
+    for (int64_t r = r_lo; r < r_hi; ++r) {
+        const bool outside = (out[r * W64 + wd] >> bit) & 1ull;
+        cnt = outside ? 0u : cnt + 1u;
+        all_in = all_in && !outside;
+    }
+    carry[i] = cnt | (all_in ? 0x80000000u : 0u);
+}
+
+// run length carried INTO every chunk
+__global__ void crop_height_scan_kernel(uint32_t* __restrict__ carry, int64_t w, int64_t n_chunks) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= w) return;
+    uint32_t run = 0;
+    for (int64_t ch = 0; ch < n_chunks; ++ch) {
+        const uint32_t v = carry[ch * w + col];
+        carry[ch * w + col] = run;
+        run = (v & 0x80000000u) ? run + (v & 0x7fffffffu) : (v & 0x7fffffffu);
+    }
+}
+
+__global__ void crop_heights_kernel(const u64* __restrict__ out, int64_t h, int64_t w, int64_t W64, int64_t n_chunks,
+                                    const uint32_t* __restrict__ carry, uint16_t* __restrict__ H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks * w) return;
+    const int64_t ch = i / w, col = i - ch * w;
+    const int64_t wd = col >> 6;
+    const int bit = (int)(col & 63);
+    const int64_t r_lo = ch * kChunk, r_hi = min(h, r_lo + kChunk);
+    uint32_t cnt = carry[i];
+    for (int64_t r = r_lo; r < r_hi; ++r) {
         const bool outside = (out[r * W64 + wd] >> bit) & 1ull;
         cnt = outside ? 0u : cnt + 1u;
         H[r * w + col] = (uint16_t)cnt;
@@ -316,6 +408,8 @@ extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layou
         In<uint8_t> di(img, (size_t)h * w * 3);
         Ws<u64> bg((size_t)h * W64), out((size_t)h * W64);
         Ws<int> changed(1);
+        const int64_t n_chunks = (h + kChunk - 1) / kChunk;
+        Ws<u64> cG((size_t)n_chunks * W64), cP((size_t)n_chunks * W64);
         Ws<uint16_t> H((size_t)h * w);
         Ws<LineBest> best((size_t)h);
         Ws<int32_t> drect(5);
@@ -334,7 +428,13 @@ extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layou
             for (int64_t it = 0; it < max_rounds; ++it) {
                 APS_HIP(hipMemsetAsync(changed, 0, sizeof(int), stream()));
                 crop_fill_rows_kernel<<<cdiv(h, 64), 64, 0, stream()>>>(bg, h, W64, out, changed);
-                crop_fill_cols_kernel<<<cdiv(W64, 64), 64, 0, stream()>>>(bg, h, W64, out, changed);
+                const unsigned gc = cdiv((size_t)n_chunks * W64, 256), gs = cdiv(W64, 64);
+                crop_col_gp_kernel<true><<<gc, 256, 0, stream()>>>(bg, out, h, W64, n_chunks, cG, cP);
+                crop_col_scan_kernel<true><<<gs, 64, 0, stream()>>>(cG, cP, W64, n_chunks);
+                crop_col_apply_kernel<true><<<gc, 256, 0, stream()>>>(bg, h, W64, n_chunks, cG, out, changed);
+                crop_col_gp_kernel<false><<<gc, 256, 0, stream()>>>(bg, out, h, W64, n_chunks, cG, cP);
+                crop_col_scan_kernel<false><<<gs, 64, 0, stream()>>>(cG, cP, W64, n_chunks);
+                crop_col_apply_kernel<false><<<gc, 256, 0, stream()>>>(bg, h, W64, n_chunks, cG, out, changed);
                 int hc = 0;
                 APS_HIP(hipMemcpyAsync(&hc, changed, sizeof(int), hipMemcpyDeviceToHost, stream()));
                 APS_HIP(hipStreamSynchronize(stream()));
@@ -344,7 +444,11 @@ extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layou
         check_launch("crop_fill_kernel");
         {
             Prof prof("crop_scan");
-            crop_heights_kernel<<<cdiv(w, 256), 256, 0, stream()>>>(out, h, w, W64, H);
+            Ws<uint32_t> hc((size_t)n_chunks * w);
+            const unsigned gh = cdiv((size_t)n_chunks * w, 256);
+            crop_height_gp_kernel<<<gh, 256, 0, stream()>>>(out, h, w, W64, n_chunks, hc);
+            crop_height_scan_kernel<<<cdiv(w, 256), 256, 0, stream()>>>(hc, w, n_chunks);
+            crop_heights_kernel<<<gh, 256, 0, stream()>>>(out, h, w, W64, n_chunks, hc, H);
             const int n1 = (int)((w + 31) >> 5), n2 = (int)((w + 1023) >> 10);
             const size_t lds = sizeof(uint16_t) * (size_t)(((w + 7) & ~7) + ((n1 + 7) & ~7) + ((n2 + 7) & ~7));
             static thread_local size_t attr_set = 0;
