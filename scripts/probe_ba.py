@@ -1,4 +1,5 @@
-"""Timing of the bundle-adjustment pair blocks at the 64-view scene's scale (384 edges x ~3.7 k matches)."""
+"""Timing of the bundle-adjustment pair blocks at the 64-view scene's scale (384 edges x ~3.7 k matches).
+(The oracle needs 176 ms on one core for this batch.)"""
 import sys
 import time
 
@@ -7,7 +8,6 @@ import numpy as np
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import apsamd
-import oracle
 from importlib import import_module
 from test_ba_gpu import _batch
 
@@ -22,8 +22,5 @@ for it in range(3):
     got = ba.ba_pair_blocks(Ui, Uj, ptr, cams, 2.0, True)
     dt = time.perf_counter() - t0
     prof = capi.profile_all()
-t0 = time.perf_counter()
-want = oracle.ba_pair_blocks(Ui, Uj, ptr, cams, 2.0, True)
-to = time.perf_counter() - t0
 print(f"{ptr[-1]} matches in 384 pairs: device kernel {prof['ba_pair_blocks'][0]:.3f} ms ({dt*1e3:.1f} ms with host staging of "
-      f"{(Ui.nbytes + Uj.nbytes) / 1e6:.0f} MB), oracle {to*1e3:.0f} ms on one core; identical: {np.array_equal(got.view(np.uint64), want.view(np.uint64))}")
+      f"{(Ui.nbytes + Uj.nbytes) / 1e6:.0f} MB); parity with the oracle: tests/test_ba_gpu.py::test_bench_scale_batch")

@@ -1,5 +1,5 @@
-"""Timing of the crop rectangle on a bench-sized canvas (21123 x 11632), with the oracle beside it.
-python scripts/probe_crop.py [--oracle]"""
+"""Timing of the crop rectangle on a bench-sized canvas (21123 x 11632).  (The same shape at 60 MPix is checked against
+the oracle in tests/test_fullsize_gpu.py; the oracle needs 1.16 s on one core for this canvas.)"""
 import sys
 import time
 
@@ -31,11 +31,3 @@ for it in range(3):
     dt = time.perf_counter() - t0
     prof = capi.profile_all()
 print(f"device: rect {rect} valid {ok}; {dt*1e3:.1f} ms wall; " + ", ".join(f"{k}={v[0]:.2f}ms" for k, v in prof.items() if k.startswith("crop")))
-if "--oracle" in sys.argv:
-    import oracle
-
-    host = img.cpu().numpy()
-    t0 = time.perf_counter()
-    want = oracle.crop_rect(host)
-    print(f"oracle: rect {want[0]} valid {want[1]}; {time.perf_counter() - t0:.2f} s on one core")
-    assert want[0] == rect and want[1] == ok
