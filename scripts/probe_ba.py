@@ -6,10 +6,35 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
 import apsamd
 from importlib import import_module
-from test_ba_gpu import _batch
+
+
+def _rot(rng, scale=0.2):
+    w = rng.normal(0, scale, 3)
+    a = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / a
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
+def _batch(rng, sizes):
+    """Random two-view scenes: per pair two cameras (+ slightly incremented copies) and noisy projections of m points."""
+    packs, Uis, Ujs, ptr = [], [], [], [0]
+    for m in sizes:
+        cams = [{"f": float(rng.uniform(500, 900)), "cx": 320.0, "cy": 240.0, "R": _rot(rng)} for _ in range(2)]
+        cams += [dict(c, f=c["f"] + rng.normal(0, 2), R=_rot(rng, 0.01) @ c["R"]) for c in cams]
+        X = rng.normal(0, 1, (m, 3)) + np.array([0, 0, 4.0])
+        pts = []
+        for c in cams[:2]:
+            K = np.array([[c["f"], 0, c["cx"]], [0, c["f"], c["cy"]], [0, 0, 1.0]])
+            p = (K @ c["R"] @ X.T).T
+            pts.append(p[:, :2] / p[:, 2:3] + rng.normal(0, 1.5, (m, 2)))
+        packs.append(np.stack([np.concatenate([[c["f"], c["cx"], c["cy"]], c["R"].ravel(order="F")]) for c in cams]))
+        Uis.append(pts[0])
+        Ujs.append(pts[1])
+        ptr.append(ptr[-1] + m)
+    return np.concatenate(Uis), np.concatenate(Ujs), ptr, np.stack(packs)
+
 
 ba = import_module(apsamd.__name__ + ".bundleAdjustment")
 capi = apsamd._capi
