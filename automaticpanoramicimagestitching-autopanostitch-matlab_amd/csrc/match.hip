@@ -1198,9 +1198,14 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
     {
         Prof prof("match_cand_f16");
-        const char* ab = std::getenv("APS_MATCH_ABLATE");  // timing builds only (results invalid)
+#ifdef APS_MATCH_TIMING  // ablation bits are honoured by timing builds only (they invalidate the results)
+        const char* ab = std::getenv("APS_MATCH_ABLATE");
+        const int ablate = ab ? std::atoi(ab) : 0;
+#else
+        const int ablate = 0;
+#endif
         match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
-                                                                          fb_count, ab ? std::atoi(ab) : 0);
+                                                                          fb_count, ablate);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());

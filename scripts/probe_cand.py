@@ -1,5 +1,6 @@
 """Kernel-time probe of the split-precision candidate kernel (profile API), for A/B runs:
-   APS_MATCH_CAND=v1|v2, APS_MATCH_ABLATE=<bits> python scripts/probe_cand.py [n_img] [features]"""
+   python scripts/probe_cand.py [n_img] [features]   (APS_MATCH_ABLATE=<bits> is honoured by builds made with
+   make EXTRA=-DAPS_MATCH_TIMING only: 1 no selection, 2 no DMA, 4 screen never fires, 8 print phase timings, 32 no rescoring)"""
 import sys
 
 import torch
