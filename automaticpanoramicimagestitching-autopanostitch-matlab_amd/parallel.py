@@ -216,9 +216,10 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
 
     # 1) SIFT on the local shard
     t0 = time.perf_counter()
-    ldesc, lkps = {}, {}
+    ldesc, lkps, lkps_host = {}, {}, {}
     for i, (d, p) in zip(sorted(local_images), pl.sift_many(input, [local_images[i] for i in sorted(local_images)])):
         ldesc[i] = d
+        lkps_host[i] = p
         lkps[i] = torch.from_numpy(p).to(dev)
     times.add("features", t0)
 
@@ -229,10 +230,11 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
         descs = [d.contiguous() for d in descs]
         torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
+        kps = [k.cpu().numpy() for k in kps_t]
     else:
         descs = [ldesc[i] for i in range(n)]
         kps_t = [lkps[i] for i in range(n)]
-    kps = [k.cpu().numpy() for k in kps_t]
+        kps = [lkps_host[i] for i in range(n)]  # the host copies SIFT returned: no read-back
     counts = [int(d.shape[0]) for d in descs]
     times.add("exchange", t0)
 
