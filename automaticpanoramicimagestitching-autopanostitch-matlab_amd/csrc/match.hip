@@ -174,6 +174,52 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
     }
 }
 
+// Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
+// [e-11i-11, e-11i) and is stored as p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16
+// and p_i is one whenever the set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows
+// up in the residual).  The candidate kernel derives the same c_i for the A-side constants.
+__device__ __forceinline__ void aug_scales(float maxsq, float* ca, float* cinv) {
+    int e;
+    (void)frexpf(0.5f * maxsq, &e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ea = min(max(e - 11 * i, -14), 15);
+        ca[i] = ldexpf(1.0f, ea);
+        cinv[i] = ldexpf(1.0f, -ea);
+    }
+}
+
+// The extra k-step's B-side operand of every column, ready to be DMA'd into LDS: 16 bytes per descriptor =
+// [p0 p1 p2 dn^ 0 0 0 0] (f16): b2/2 in three pieces and the rounding-loss norm rounded up.  Rows n .. n_pad-1 (the
+// ragged end of the last 128-column tile) hold 65504 in p0: -65504 c0 loses against every real column.  Runs after
+// prep_desc_kernel of the same set on the same stream (it needs the set's max ||x||^2).  res[0] / res[1] = the largest
+// |b2/2 - pieces| and the largest saturation loss dn - dn^ over the set (both 0 for ordinary data).
+__global__ void aug_desc_kernel(const float* __restrict__ sq, const float* __restrict__ dn, int64_t n, int64_t n_pad,
+                                const float* __restrict__ maxsq, uint4* __restrict__ aug, float* __restrict__ res) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    if (j >= n) {
+        aug[j] = make_uint4(0x7bffu, 0u, 0u, 0u);
+        return;
+    }
+    float ca[3], cinv[3];
+    aug_scales(*maxsq, ca, cinv);
+    float r = 0.5f * sq[j];
+    unsigned short pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float back;
+        pc[i] = f32_to_f16_flush(r * cinv[i], back);
+        r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
+    }
+    float dn_back;
+    const unsigned short pd = f16_round_up(dn[j], dn_back);
+    const float rd = fmaxf(dn[j] - dn_back, 0.f);
+    aug[j] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2] | ((uint32_t)pd << 16), 0u, 0u);
+    if (r != 0.f) atomicMax(reinterpret_cast<unsigned*>(res), __float_as_uint(fabsf(r)));
+    if (rd > 0.f) atomicMax(reinterpret_cast<unsigned*>(res) + 1, __float_as_uint(rd));
+}
+
 // ------------------------------------------------------------------------------------------------
 // the distance GEMM + fused top-2
 // ------------------------------------------------------------------------------------------------
@@ -190,7 +236,8 @@ struct MatchJob {
     const unsigned short* AF;
     const unsigned short* BF;
     const float* dnA;
-    const float* dnB;
+    const uint4* augB;    // per B row the extra k-step's operand (aug_desc_kernel), padded to a multiple of 128 rows
+    const float* augresB;  // [0] largest b2/2 residual, [1] largest dn saturation loss of the B set
     const float* maxsqB;
     const float* maxdnB;
 };
@@ -573,9 +620,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
     // accumulator (padded column: -65504 c0)
-    __shared__ __attribute__((aligned(16))) uint4 s_aug[2][kTNB];
-    __shared__ unsigned int s_aug_res;  // largest |b2/2 - pieces| staged by this workgroup (bits of a float >= 0)
-    __shared__ unsigned int s_dn_res;   // largest saturation loss dn_j - dn^_j (0 unless a loss norm exceeds 65504)
+    __shared__ __attribute__((aligned(1024))) uint4 s_aug[3][kTNB];  // filled by DMA with the B tile (aug_desc_kernel's rows)
 
     // XCD-aware order: consecutive workgroup ids go to different XCDs (one L2 each); give each XCD a
     // contiguous run of the job-major list so that the workgroups sharing a B set share an L2
@@ -596,7 +641,6 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     const int h = lane >> 5;
     const int nA = jb.nA, nB = jb.nB;
     const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
-    if (tid == 0) s_aug_res = s_dn_res = 0u;
 
     f16x8 ah[2][8];
 #pragma unroll
@@ -614,20 +658,9 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         i0[rb] = i1[rb] = i2[rb] = -1;
     }
 
-    // scales of the three b2/2 pieces: b2/2 <= 2^e; piece i carries bits [e-11i-11, e-11i) and is stored as
-    // p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16 and p_i is one whenever the
-    // B set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows up in the residual)
     float ca[3], cinv[3];
-    {
-        int e;
-        (void)frexpf(0.5f * (*jb.maxsqB), &e);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int ea = min(max(e - 11 * i, -14), 15);
-            ca[i] = ldexpf(1.0f, ea);
-            cinv[i] = ldexpf(1.0f, -ea);
-        }
-    }
+    aug_scales(*jb.maxsqB, ca, cinv);
+    (void)cinv;
 
     const int ntiles = (nB + kTNB - 1) / kTNB;
     // DMA pieces: 32 per tile, 1 KiB = 4 LDS rows each; wave w issues pieces 4w .. 4w+3, one per column block.
@@ -638,15 +671,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     // latency once per tile.  The DMA of tile t+1 is retired by the explicit vmcnt(0) before the barrier that
     // ends tile t; nothing reads that buffer earlier.
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    float stage_b2 = 0.f, stage_dn = 0.f;
-    float aug_res = 0.f, dn_res = 0.f;
-    // piece u of this wave's four; u == 0 also fetches the tile's ||b||^2
+    const uint32_t aug_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&s_aug[0][0];
+    // piece u of this wave's four; with its piece 0, wave 0 / wave 1 also fetch one half of the tile's 2 KiB of extra
+    // k-step operands (64 columns x 16 B each, lane-linear)
     auto issue_piece = [&](int t, int buf, int u) {
-        // ordinary load first (it is consumed at the end of the tile, behind the same vmcnt(0))
-        if (u == 0) {
-            stage_b2 = ((gbl_f32*)jb.sqB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
-            stage_dn = ((gbl_f32*)jb.dnB)[min(t * kTNB + (tid & (kTNB - 1)), nB - 1)];
-        }
         const int piece = wave * (kTNB / 32) + u;
         const int lrow = 4 * piece + dma_sub;
         const int brow = min(t * kTNB + lrow, nB - 1);
@@ -658,29 +686,14 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
             : "=&s"(keep)
             : "v"(src), "s"(dst)
             : "memory");
-    };
-    auto store_aug = [&](int t) {
-        const int j = t * kTNB + tid;
-        if (tid < kTNB) {
-            float r = 0.5f * stage_b2;
-            unsigned short pc[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float back;
-                pc[i] = f32_to_f16_flush(r * cinv[i], back);
-                r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
-            }
-            float dn_back;
-            unsigned short pd = f16_round_up(stage_dn, dn_back);
-            float rd = fmaxf(stage_dn - dn_back, 0.f);
-            if (j >= nB) {
-                pc[0] = 0x7bffu;  // 65504: -65504 c0 loses against every real column
-                pc[1] = pc[2] = pd = 0u;
-                r = rd = 0.f;
-            }
-            aug_res = fmaxf(aug_res, fabsf(r));
-            dn_res = fmaxf(dn_res, rd);
-            s_aug[t & 1][tid] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2] | ((uint32_t)pd << 16), 0u, 0u);
+        if (u == 0 && wave < 2) {
+            const uint4* asrc = jb.augB + (size_t)t * kTNB + wave * 64 + lane;  // the array is padded to whole tiles
+            const uint32_t adst = aug_base + buf * (kTNB * 16) + wave * 1024;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(asrc), "s"(adst)
+                : "memory");
         }
     };
     f32x16 acc[2][2];  // [block parity][owned row]: one set is being accumulated while the other is being searched
@@ -777,7 +790,6 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(ah[0][s]), "v"(ah[1][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ntiles > 0) store_aug(0);
     __syncthreads();
 
     // per-lane read offsets: row c of a 32-row block, chunk (2s + h) ^ (c & 15)
@@ -841,6 +853,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
         const unsigned char* tile = lds + b_cur * kTileBytes + c * 256;
         const unsigned char* tile_n = lds + b_nxt * kTileBytes + c * 256;
+        const int b_this = b_cur;
         b_cur = b_nxt;
         static_for<0, kTNB / 32>([&](auto CB) {
             constexpr int cb = decltype(CB)::value;
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
             const unsigned char* blk = tile + cb * 32 * 256;
             // first operands of the next block: same tile, or block 0 of the tile handed over one block ago
             const unsigned char* nblk = cb < kLast ? blk + 32 * 256 : tile_n;
-            const uint4* naug = cb < kLast ? &s_aug[t & 1][c + 32 * (cb + 1)] : &s_aug[(t + 1) & 1][c];
+            const uint4* naug = cb < kLast ? &s_aug[b_this][c + 32 * (cb + 1)] : &s_aug[b_nxt][c];
             const bool fetch = cb < kLast || t + 1 < ntiles;
             const int pt = cb ? t : t - 1;
             constexpr int pcb = cb ? cb - 1 : kLast;
@@ -880,7 +893,6 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                 // hand-over: this wave's DMA pieces of tile t+1 (and its b2) have landed; after the barrier that
                 // holds for every wave, and every wave has left tile t-1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (more) store_aug(t + 1);
                 __syncthreads();
                 APS_TICK(T_bar)
             }
@@ -905,10 +917,6 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     }
     drain(0);
     drain(1);
-    if (tid < kTNB) {
-        atomicMax(&s_aug_res, __float_as_uint(aug_res));
-        atomicMax(&s_dn_res, __float_as_uint(dn_res));
-    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float p0 = __shfl_xor(u0[rb], 32), p1 = __shfl_xor(u1[rb], 32), p2 = __shfl_xor(u2[rb], 32),
@@ -919,7 +927,6 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         top4_insert_max(p2, q2, u0[rb], u1[rb], u2[rb], u3[rb], i0[rb], i1[rb], i2[rb]);
         u3[rb] = fmaxf(u3[rb], p3);
     }
-    __syncthreads();  // s_aug_res is complete
     // Exact rescoring in place (it used to be a separate, purely gather-bound launch): the h == 0 half holds the
     // merged lists of both owned rows; its lanes rescore row block 0 while the h == 1 lanes take over row block 1.
     {
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         if (row < nA && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
             const float bnd = jb.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
             const float bnd3 = jb.sqA[row] - 2.0f * ub2;  // ... and the 3rd
-            rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, __uint_as_float(s_aug_res), __uint_as_float(s_dn_res), out_idx, out_d1, out_d2, fb_list,
+            rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, jb.augresB[0], jb.augresB[1], out_idx, out_d1, out_d2, fb_list,
                         fb_count);
         }
     }
@@ -1079,8 +1086,9 @@ __global__ void scan_counts_kernel(const unsigned long long* __restrict__ cnt, i
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 struct Prepared {
-    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, maxsq[1] = max ||x - f16(x)||
+    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals
     Ws<unsigned short> H;
+    Ws<uint4> aug;
     int64_t n = 0;
 };
 
@@ -1092,13 +1100,16 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.sq.alloc(rows);
     out.H.alloc(rows * kDim);
     out.dn.alloc(rows);
-    out.maxsq.alloc(2);
-    APS_HIP(hipMemsetAsync(out.maxsq, 0, 2 * sizeof(float), stream()));
+    out.maxsq.alloc(4);
+    APS_HIP(hipMemsetAsync(out.maxsq, 0, 4 * sizeof(float), stream()));
+    const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
+    out.aug.alloc((size_t)n_pad);
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
                                                         out.P, out.sq, out.H, out.dn, out.maxsq,
                                                         (float*)out.maxsq + 1);
+    aug_desc_kernel<<<cdiv(n_pad, 256), 256, 0, stream()>>>(out.sq, out.dn, n, n_pad, out.maxsq, out.aug, (float*)out.maxsq + 2);
     check_launch("prep_desc_kernel");
 }
 
@@ -1114,7 +1125,8 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.AF = a.H;
     j.BF = b.H;
     j.dnA = a.dn;
-    j.dnB = b.dn;
+    j.augB = b.aug;
+    j.augresB = (const float*)b.maxsq + 2;
     j.maxsqB = b.maxsq;
     j.maxdnB = (const float*)b.maxsq + 1;
     return j;
