@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
 //    16-B chunk position with (row & 15), applied to the per-lane SOURCE address of the DMA and to the
 //    ds_read_b128 address (the same involution on both sides); three buffers, hand-over one block early;
 //  * -||b||^2/2 (three f16 pieces, per-set power-of-two scales) and ||a|| ||b - f16(b)|| enter the accumulator
-//    through one extra 16-wide k-step, so the row's best columns are the LARGEST acc and the selection needs no
+//    through one extra 16-wide k-step (B-side operands precomputed per set, aug_desc_kernel, and DMA'd with the tile), so the row's best columns are the LARGEST acc and the selection needs no
 //    arithmetic per element;
 //  * the search of block g-1 is cut into eight three-instruction slices placed between the MFMA pairs of block g
 //    (two accumulator sets); hits are parked and inserted in bulk from a cold path;
