@@ -836,7 +836,7 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
 #ifdef APS_MATCH_TIMING  // phase timing of one workgroup (make EXTRA=-DAPS_MATCH_TIMING, APS_MATCH_ABLATE=8)
     unsigned long long T_mf = 0, T_bar = 0;
     const unsigned long long T_c0 = __builtin_readcyclecounter(), T_w0 = wall_clock64();
-    unsigned long long T_prev = T_c0;
+    unsigned long long T_prev = T_c0, T_mark = T_c0;
 #define APS_TICK(acc_)                                              \
     {                                                               \
         const unsigned long long n_ = __builtin_readcyclecounter(); \
@@ -850,6 +850,9 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles && !(ablate & 2);
         const bool more2 = t + 2 < ntiles && !(ablate & 2);
+#ifdef APS_MATCH_TIMING
+        if (t == 128) T_mark = __builtin_readcyclecounter();
+#endif
         const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
         const unsigned char* tile = lds + b_cur * kTileBytes + c * 256;
         const unsigned char* tile_n = lds + b_nxt * kTileBytes + c * 256;
@@ -893,7 +896,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                 // hand-over: this wave's DMA pieces of tile t+1 (and its b2) have landed; after the barrier that
                 // holds for every wave, and every wave has left tile t-1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+#ifdef APS_MATCH_TIMING
+                if (!(ablate & 32))  // (bit 32 in timing builds: no hand-over barrier, no rescoring - racy, timing only)
+#endif
+                    __syncthreads();
                 APS_TICK(T_bar)
             }
         });
@@ -902,7 +908,8 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     const unsigned long long T_loop_end = __builtin_readcyclecounter();
     if ((ablate & 8) && blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4)) {
         const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
-        printf("wave %d: prologue %llu cycles (entry -> first block)\n", wave, T_c0 - T_entry);
+        printf("wave %d: prologue %llu cycles (entry -> first block); steady state (tiles 128..end): %.0f cycles per block\n", wave,
+               T_c0 - T_entry, ntiles > 128 ? (double)(c1 - T_mark) / ((ntiles - 128) * 4) : 0.0);
         printf("wave %d: %.3f GHz, %d blocks, cycles per block: total %.0f = mfma+selection %.0f + hand-over %.0f\n",
                wave, (double)(c1 - T_c0) / ((double)(w1 - T_w0) * 10.0), ntiles * (kTNB / 32),
                (double)(c1 - T_c0) / (ntiles * (kTNB / 32)), (double)T_mf / (ntiles * (kTNB / 32)),
