@@ -192,6 +192,22 @@ def test_split_path_any_magnitude(fm, monkeypatch, scale):
     assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2))
 
 
+@pytest.mark.parametrize("n2", [1, 3, 4, 5, 31, 32, 33, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640])
+def test_split_path_tile_boundaries(fm, monkeypatch, n2):
+    """Column counts around the 32-column block and 128-column tile sizes (one, two, three ... LDS buffers in flight, ragged
+    last tile) against row counts around the 64-row wave and 512-row workgroup sizes."""
+    rng = np.random.default_rng(4000 + n2)
+    b = sift_like(rng, n2)
+    monkeypatch.setenv("APS_MATCH_MODE", "split")
+    for n1 in (1, 63, 64, 65, 511, 512, 513):
+        a = sift_like(rng, n1)
+        if n2 >= 2:
+            a[0] = b[n2 - 1]  # the last column is somebody's nearest neighbour
+        _, idx, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+        oi, o1, o2 = oracle.match_2nn_ssd(a, b)
+        assert np.array_equal(idx, oi) and np.array_equal(bits(d1), bits(o1)) and np.array_equal(bits(d2), bits(o2)), (n1, n2)
+
+
 def test_split_path_mixed_norms_signed_and_zero_rows(fm, monkeypatch):
     """Rows whose norms differ by six orders of magnitude inside one set (the three-piece b2/2 loses its low pieces
     for the small ones), signed entries, all-zero rows on both sides, and a B set smaller than the candidate list."""
