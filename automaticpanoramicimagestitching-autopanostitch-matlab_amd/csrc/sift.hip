@@ -29,6 +29,12 @@ constexpr int kBorder = 5;
 constexpr int kMaxInterp = 5;
 constexpr int kOriBins = 36;
 constexpr float kFix = 1048576.0f;
+
+// (long long)rintf(v * kFix), the fixed-point addend of the orientation / descriptor histograms.  The pyramid comes
+// from 8-bit pixels, so every plane stays inside [0, 255] (the blurs are convex combinations), a gradient magnitude is
+// at most 255 sqrt(2) and every addend's magnitude is below 361 * 2^20 < 2^31: the one-instruction i32 conversion gives
+// the same integer as the generic f32 -> i64 sequence (a dozen VALU instructions, eight times per sample).
+__device__ __forceinline__ long long to_fix(float v) { return (long long)(int)rintf(v * kFix); }
 constexpr float kFltEps = 1.1920928955078125e-07f;
 
 // ---- elementary functions (identical formulas to oracle/sift_oracle.c) --------------------------
@@ -579,7 +585,8 @@ __global__ __launch_bounds__(256) void orient_kernel(const PyrTable* __restrict_
         xi = kp.xi;
     }
     const OctaveDesc& od = pt->oct[o];
-    const float* g = od.G[layer];
+    // (global address space stated explicitly: a pointer read from the pyramid table otherwise compiles to flat loads)
+    const __attribute__((address_space(1))) float* g = (const __attribute__((address_space(1))) float*)od.G[layer];
     const int w = od.w, h = od.h;
     const float scl = kp_scale(pt->sigma, layer, xi, pt->nl);
     const int radius = (int)rintf(4.5f * scl);
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(256) void orient_kernel(const PyrTable* __restrict_
             int bin = (int)rintf(((float)kOriBins / 360.0f) * ori);
             if (bin >= kOriBins) bin -= kOriBins;
             if (bin < 0) bin += kOriBins;
-            const long long q = (long long)rintf((wgt * mag) * kFix);
+            const long long q = to_fix(wgt * mag);
             atomicAdd(&s_hist[wv][bin], (unsigned long long)q);
         }
     }
@@ -691,7 +698,8 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
         kangle = ok.angle;
     }
     const OctaveDesc& od = pt->oct[o];
-    const float* g = od.G[layer];
+    // (global address space stated explicitly: a pointer read from the pyramid table otherwise compiles to flat loads)
+    const __attribute__((address_space(1))) float* g = (const __attribute__((address_space(1))) float*)od.G[layer];
     const int w = od.w, h = od.h;
     const float scl = kp_scale(pt->sigma, layer, xi, pt->nl);
     float ori = 360.0f - kangle;
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
             const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
             const int idx = ((rr0 + 1) * (kD + 2) + cc0 + 1) * (kN + 2) + o0;
             unsigned long long* hb = &s_hist[wv][idx];
-#define ADDQ(off, v) atomicAdd(hb + (off), (unsigned long long)(long long)rintf((v) * kFix))
+#define ADDQ(off, v) atomicAdd(hb + (off), (unsigned long long)to_fix(v))
             ADDQ(0, v000);
             ADDQ(1, v001);
             ADDQ(kN + 2, v010);
