@@ -598,8 +598,9 @@ __global__ __launch_bounds__(256) void orient_kernel(const PyrTable* __restrict_
             const int i = s / side - radius, j = s % side - radius;
             const int y = r0 + i, x = c0 + j;
             if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
-            const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1];
-            const float dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
+            const int ctr = y * w + x;
+            const float dx = g[ctr + 1] - g[ctr - 1];
+            const float dy = g[ctr - w] - g[ctr + w];
             const float wgt = my_exp((float)(i * i + j * j) * expf_scale);
             const float ori = fast_atan2_deg(dy, dx);
             const float mag = sqrtf(dx * dx + dy * dy);
@@ -726,8 +727,9 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
             float cbin = c_rot + (float)(kD / 2) - 0.5f;
             const int r = py + i, c = px + j;
             if (!(rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
-            const float dx = g[(size_t)r * w + c + 1] - g[(size_t)r * w + c - 1];
-            const float dy = g[(size_t)(r - 1) * w + c] - g[(size_t)(r + 1) * w + c];
+            const int ctr = r * w + c;  // a plane holds < 2^31 floats: 32-bit offsets from the (scalar) plane base
+            const float dx = g[ctr + 1] - g[ctr - 1];
+            const float dy = g[ctr - w] - g[ctr + w];
             const float wgt = my_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
             const float o_deg = fast_atan2_deg(dy, dx);
             const float mag = sqrtf(dx * dx + dy * dy) * wgt;
