@@ -62,16 +62,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f;
     const float p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + 2.220446049250313e-16f);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + 2.220446049250313e-16f);
-        c2 = c * c;
-        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // one division for both octants: min / (max + eps) is ay / (ax + eps) when ax >= ay and ax / (ay + eps) otherwise
+    // (written as two branches, both quotients were computed for every sample)
+    const bool steep = !(ax >= ay);
+    const float c = (steep ? ax : ay) / ((steep ? ay : ax) + 2.220446049250313e-16f);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (steep) a = 90.0f - a;
     if (x < 0) a = 180.0f - a;
     if (y < 0) a = 360.0f - a;
     return a;
