@@ -269,9 +269,10 @@ def match_pairwise_csr(allDescriptors, MaxRatio, MatchThreshold, Unique=True, no
     return pair_ptr, i_i[:k], i_j[:k], met[:k]
 
 
-def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True, normalize=2):
+def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True, normalize=2, device_out=False):
     """aps_match_pairs: the matcher on an explicit list of (a, b) image pairs (0-based) — the unit that is
-    sharded across GPUs.  Returns (pair_ptr int64[P+1], idx_a, idx_b, metric) as numpy arrays."""
+    sharded across GPUs.  Returns (pair_ptr int64[P+1], idx_a, idx_b, metric) as numpy arrays, or with
+    device_out=True the three match arrays as resident torch tensors (int32, int32, float32)."""
     n = len(allDescriptors)
     prepared = [_as_desc(d) for d in allDescriptors]
     layouts = {p[3] for p in prepared if p[1] > 0}
@@ -289,9 +290,16 @@ def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True
     cnt = C.c_int64(0)
     cap = max(1, sum(prepared[a][1] for a in pa.tolist()) // 16)
     while True:
-        i_a = np.zeros(cap, np.uint32)
-        i_b = np.zeros(cap, np.uint32)
-        met = np.zeros(cap, np.float32)
+        if device_out:
+            import torch
+
+            i_a = torch.empty(cap, dtype=torch.int32, device="cuda")
+            i_b = torch.empty(cap, dtype=torch.int32, device="cuda")
+            met = torch.empty(cap, dtype=torch.float32, device="cuda")
+        else:
+            i_a = np.zeros(cap, np.uint32)
+            i_b = np.zeros(cap, np.uint32)
+            met = np.zeros(cap, np.float32)
         rc = lib.aps_match_pairs(ptrs, counts, lds, n, DIM, layout, ptr(pa), ptr(pb), P, C.byref(o), ptr(pair_ptr),
                                  ptr(i_a), ptr(i_b), ptr(met), cap, C.byref(cnt))
         if rc == _capi.APS_E_CAP:

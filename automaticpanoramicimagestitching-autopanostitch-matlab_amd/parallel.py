@@ -17,6 +17,7 @@ There is no other collective on the data path.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -244,17 +245,26 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
     pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
     my = [p for p in range(len(order)) if pown[p] == rank]
-    pp, ia, ib, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"], input["Matchingthreshold"], True)
-    mine_m = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
-              for k in range(len(my))]
-    allm = exchange_items(my, mine_m, len(order), lambda p: int(pown[p]), 2, np.int64, dev)
+    # one rank: the match lists never leave the device (no exchange, no host index arithmetic); APS_PARALLEL_HOST_LISTS=1
+    # forces the multi-rank code path (host lists) for A/B tests
+    resident = ws == 1 and not os.environ.get("APS_PARALLEL_HOST_LISTS")
+    if resident:
+        pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
+                                               input["Matchingthreshold"], True, device_out=True)
+        n_match = np.diff(pp)  # my == every pair, in `order`
+    else:
+        pp, ia, ib, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"], input["Matchingthreshold"], True)
+        mine_m = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
+                  for k in range(len(my))]
+        allm = exchange_items(my, mine_m, len(order), lambda p: int(pown[p]), 2, np.int64, dev)
+        n_match = np.array([len(m) for m in allm], np.int64)
     times.add("matching", t0)
 
     # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
     t0 = time.perf_counter()
     put = np.zeros((n, n), np.int64)
     for p, (i, j) in enumerate(order):
-        put[i, j] = len(allm[p])
+        put[i, j] = n_match[p]
     sym = put + put.T
     srt = np.argsort(-sym, axis=1, kind="stable")[:, : min(int(input["mBrownLowe"]), n - 1)]
     cand = np.zeros((n, n), bool)
@@ -262,25 +272,37 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     cand = np.triu(cand | cand.T, 1)
     pidx = {ij: p for p, ij in enumerate(order)}
     cj, ci = np.nonzero(cand.T)
-    work = [pidx[(i, j)] for (i, j) in zip(ci.tolist(), cj.tolist()) if len(allm[pidx[(i, j)]]) >= 4]
+    work = [pidx[(i, j)] for (i, j) in zip(ci.tolist(), cj.tolist()) if n_match[pidx[(i, j)]] >= 4]
     mine = [p for k, p in enumerate(work) if k % ws == rank]
     times.add("im_select", t0)
     t0 = time.perf_counter()
     n_samples = int(input["maxIter"]) + 64
     recs = []
     if mine:
-        cnts = [len(allm[p]) for p in mine]
+        cnts = [int(n_match[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
         # one device gather over the concatenated keypoint table (the keypoints are resident already; a host
         # fancy-index of ~1e6 rows costs tens of milliseconds)
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         kp_all = torch.cat([k.to(dev) for k in kps_t]).to(torch.float64)
-        cat = np.concatenate([allm[p] for p in mine])
-        img_i = np.repeat(offs[[order[p][0] for p in mine]], cnts)
-        img_j = np.repeat(offs[[order[p][1] for p in mine]], cnts)
-        idx = torch.from_numpy(np.stack([img_i + cat[:, 0] - 1, img_j + cat[:, 1] - 1])).to(dev)
-        dst = kp_all.index_select(0, idx[0]).t().contiguous()
-        src = kp_all.index_select(0, idx[1]).t().contiguous()
+        if resident:
+            # segment p of the CSR lists -> rows of the concatenated keypoint table, all on the device
+            cnt_t = torch.tensor(cnts, dtype=torch.int64, device=dev)
+            seg0 = torch.tensor([int(pp[p]) for p in mine], dtype=torch.int64, device=dev)
+            pos = torch.arange(int(wptr[-1]), dtype=torch.int64, device=dev) + \
+                torch.repeat_interleave(seg0 - torch.from_numpy(wptr[:-1]).to(dev), cnt_t)
+            off_i = torch.repeat_interleave(torch.from_numpy(offs[[order[p][0] for p in mine]]).to(dev), cnt_t)
+            off_j = torch.repeat_interleave(torch.from_numpy(offs[[order[p][1] for p in mine]]).to(dev), cnt_t)
+            row_i = off_i + ia_d.index_select(0, pos).to(torch.int64) - 1
+            row_j = off_j + ib_d.index_select(0, pos).to(torch.int64) - 1
+        else:
+            cat = np.concatenate([allm[p] for p in mine])
+            img_i = np.repeat(offs[[order[p][0] for p in mine]], cnts)
+            img_j = np.repeat(offs[[order[p][1] for p in mine]], cnts)
+            idx = torch.from_numpy(np.stack([img_i + cat[:, 0] - 1, img_j + cat[:, 1] - 1])).to(dev)
+            row_i, row_j = idx[0], idx[1]
+        dst = kp_all.index_select(0, row_i).t().contiguous()
+        src = kp_all.index_select(0, row_j).t().contiguous()
         torch.cuda.current_stream().synchronize()  # torch's stream produced dst/src; the library runs on its own
         samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
         times.add("im_gather", t0)
@@ -301,7 +323,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     pairs, models_l, num_matches = [], [], np.zeros((n, n))
     for k, p in enumerate(work):
         rec = allr[k]
-        nf = len(allm[p])
+        nf = int(n_match[p])
         ni = int(rec[10]) if rec[9] else 0
         if ni > 8 + 0.3 * nf:
             i, j = order[p]
