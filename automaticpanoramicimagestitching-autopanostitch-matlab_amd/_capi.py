@@ -183,8 +183,9 @@ def use_torch_stream() -> None:
     check(lib.aps_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
-def profile_enable(on: bool = True) -> None:
-    check(lib.aps_profile_enable(1 if on else 0))
+def profile_enable(on=True) -> None:
+    """True/1: every launch site; 2: only the per-batch sites (matching, RANSAC, coverage ...); False/0: off."""
+    check(lib.aps_profile_enable(2 if on == 2 else (1 if on else 0)))
 
 
 def profile_reset() -> None:

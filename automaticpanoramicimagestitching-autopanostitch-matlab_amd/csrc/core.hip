@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <mutex>
 
+#include <cstring>
+
 #include "aps_internal.h"
 
 namespace aps {
@@ -124,7 +126,7 @@ struct ProfRec {
 };
 // The profile store is process-wide (worker threads with their own streams all record into it); each record
 // carries the two events of one launch site on the stream it ran on.
-static std::atomic<bool> g_prof_on{false};
+static std::atomic<int> g_prof_on{0};  // 0 off, 1 every launch site, 2 only the low-frequency sites (see aps.h)
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -141,7 +143,16 @@ static hipEvent_t prof_event_locked() {
 }
 
 Prof::Prof(const char* name) {
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    const int mode = g_prof_on.load(std::memory_order_relaxed);
+    if (!mode) return;
+    if (mode == 2) {
+        // selective: the per-image / per-tile chains issue thousands of launches per stitch, and two event records
+        // per launch are a measurable share of it (2.7 % of the 64-view step); the per-batch kernels are kept
+        static const char* const keep[] = {"match", "ransac", "cover", "ba_", "crop", "gain"};
+        bool ok = false;
+        for (const char* k : keep) ok = ok || std::strncmp(name, k, std::strlen(k)) == 0;
+        if (!ok) return;
+    }
     hipStream_t st = stream();
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{name, prof_event_locked(), prof_event_locked()};
@@ -212,7 +223,7 @@ int aps_release_workspace(void) {
 int aps_profile_enable(int on) {
     return guarded([&] {
         ctx();
-        g_prof_on.store(on != 0);
+        g_prof_on.store(on == 2 ? 2 : (on != 0 ? 1 : 0));
     });
 }
 

@@ -156,9 +156,22 @@ def main():
     def step():
         return par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0)
 
-    for _ in range(args.warmup):
+    # Kernel timing by HIP events on the library's streams.  Two event records per launch are not free when a step
+    # issues ~5000 launches (2.7 % of the step), so the timed region brackets only the per-batch launch sites - which
+    # include the dominant kernel, whose `roofline` is therefore measured live over the timed steps - and the
+    # per-image / per-tile chains (SIFT, warp, pyramid) are bracketed during the last warm-up step instead.
+    warm_prof, warm_steps = {}, 0
+    for k in range(args.warmup):
+        last = k == args.warmup - 1
+        if last:
+            capi.profile_enable(1)
+            capi.profile_reset()
         step()
-    capi.profile_enable(True)
+        if last:
+            barrier()
+            warm_prof, warm_steps = capi.profile_all(), 1
+            capi.profile_enable(False)
+    capi.profile_enable(2 if warm_steps else 1)
     capi.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -170,6 +183,12 @@ def main():
     dt = time.perf_counter() - t0
     prof = capi.profile_all()
     capi.profile_enable(False)
+    # per-step view of both passes: live numbers win
+    live = set(prof)
+    prof = {k: (v[0], v[1]) for k, v in prof.items()}
+    for k, v in warm_prof.items():
+        if k not in prof:
+            prof[k] = (v[0] * args.steps / warm_steps, v[1] * args.steps // warm_steps)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,7 +247,8 @@ def main():
                  "launches_per_step": launches // max(args.steps, 1), "ms_per_step": round(ms / args.steps, 3),
                  # kernels issued from several concurrent streams: their event intervals overlap, so the summed
                  # duration over-counts wall time by up to the stream count
-                 "concurrent_streams": streams, "wall_share_ms": round(ms / args.steps / streams, 3)}
+                 "concurrent_streams": streams, "wall_share_ms": round(ms / args.steps / streams, 3),
+                 "timed": "live over the timed steps" if kernel in live else "during the last warm-up step"}
             if r["traffic"] is not None:
                 r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
                                      "pass of this workload (profiles/r01k_hbm_traffic.txt)")

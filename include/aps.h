@@ -76,7 +76,10 @@ int aps_timer_end(float* ms);
 /* Per-kernel timing on the stream the kernels are launched on (what bench.py's `roofline` entry uses):
  * while enabled, every launch site of a named hot kernel is bracketed by HIP events.
  * aps_profile_get sums the elapsed time of all recorded launches whose name equals `name`
- * (e.g. "match2nn", "sift_blur", "warp_layer", "mb_blur", ...) and returns the launch count. */
+ * (e.g. "match2nn", "sift_blur", "warp_layer", "mb_blur", ...) and returns the launch count.
+ * on = 1: every launch site; on = 2: only the per-batch sites (matching, RANSAC, coverage, crop, BA, gain) - the
+ * per-image and per-tile chains issue thousands of launches per stitch and their event records cost a few percent;
+ * on = 0: off. */
 int aps_profile_enable(int on);
 int aps_profile_reset(void);
 int aps_profile_get(const char* name, double* total_ms, int* launches);
