@@ -85,11 +85,13 @@ __device__ __forceinline__ bool check_model(const Mat3& H) {
     return rc > kDblEps;
 }
 
-// LDS work matrices: element e of lane l at [e*64 + l]
-#define GE(p, q) sG[((p) * 9 + (q)) * 64 + lane]
-#define VE(p, q) sV[((p) * 9 + (q)) * 64 + lane]
+// LDS work matrices: element e of lane l at [e*S + l] (S = 64 in the fit kernel, one problem per lane; S = 2 in the
+// refit, one problem per workgroup)
+#define GE(p, q) sG[((p) * 9 + (q)) * S + lane]
+#define VE(p, q) sV[((p) * 9 + (q)) * S + lane]
 
 // Cyclic Jacobi on the symmetric 9x9 in GE; eigenvectors in the columns of VE.
+template <int S>
 __device__ void jacobi9(double* sG, double* sV, int lane) {
     for (int p = 0; p < 9; ++p)
         for (int q = 0; q < 9; ++q) VE(p, q) = (p == q) ? 1.0 : 0.0;
@@ -144,10 +146,11 @@ __device__ __forceinline__ double dlt_entry(int k, int half, double x, double y,
 }
 
 // From the filled Gram matrix to the denormalised H (:214-224).  Returns false if not finite.
+template <int S>
 __device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, const Norm& n2, Mat3& H, int mlesac = 0) {
     for (int p = 0; p < 9; ++p)
         for (int q = 0; q < p; ++q) GE(p, q) = GE(q, p);
-    jacobi9(sG, sV, lane);
+    jacobi9<S>(sG, sV, lane);
     int kmin = 0;
     for (int k = 1; k < 9; ++k)
         if (GE(k, k) < GE(kmin, kmin)) kmin = k;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                                                          int n_samples, double* __restrict__ Hs,
                                                          uint8_t* __restrict__ valid, int mlesac) {
     extern __shared__ __attribute__((aligned(16))) double lds_fit[];
+    constexpr int S = 64;  // one 9x9 problem per lane
     double* sG = lds_fit;
     double* sV = lds_fit + 81 * 64;
     const int lane = threadIdx.x;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
             for (int pp = 0; pp < 9; ++pp)
                 for (int qq = pp; qq < 9; ++qq) GE(pp, qq) = GE(pp, qq) + a[pp] * a[qq];
         }
-        ok = gram_to_h(sG, sV, lane, n1, n2, H, mlesac) && (mlesac || check_model(H));
+        ok = gram_to_h<64>(sG, sV, lane, n1, n2, H, mlesac) && (mlesac || check_model(H));
     }
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
     valid[gid] = ok ? 1 : 0;
@@ -461,9 +465,11 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     const int32_t* __restrict__ best_it, double thr, double* __restrict__ models,
     uint8_t* __restrict__ mask, uint8_t* __restrict__ scratch_mask, int32_t* __restrict__ found,
     int32_t* __restrict__ n_final, int mlesac) {
-    extern __shared__ __attribute__((aligned(16))) double lds_fin[];
+    // one 9x9 problem per workgroup: two columns (work matrix / broadcast scratch), 2.6 KB - with the fit kernel's
+    // 64-column layout (83 KB) only one workgroup fitted a CU and the pairs ran in two rounds
+    __shared__ __attribute__((aligned(16))) double lds_fin[2 * 81 * 2];
     double* sG = lds_fin;
-    double* sV = lds_fin + 81 * 64;
+    double* sV = lds_fin + 81 * 2;
     const int p = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t r0 = pair_ptr[p];
@@ -588,18 +594,18 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
                 g = g + dlt_entry(pp, half, x, y, u, v) * dlt_entry(qq, half, x, y, u, v);
             });
     }
-    if (lane < 45) sG[(pp * 9 + qq) * 64 + 0] = g;  // lane 0's column of the work matrix
+    if (lane < 45) sG[(pp * 9 + qq) * 2 + 0] = g;  // column 0 of the work matrix
     __syncthreads();
     Mat3 Hr;
     int ok = 0;
     if (lane == 0) {
-        ok = gram_to_h(sG, sV, 0, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr)) ? 1 : 0;
-        for (int e = 0; e < 9; ++e) sV[e * 64 + 1] = Hr.m[e];  // broadcast through a free LDS column
-        sV[9 * 64 + 1] = (double)ok;
+        ok = gram_to_h<2>(sG, sV, 0, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr)) ? 1 : 0;
+        for (int e = 0; e < 9; ++e) sV[e * 2 + 1] = Hr.m[e];  // broadcast through the free LDS column
+        sV[9 * 2 + 1] = (double)ok;
     }
     __syncthreads();
-    for (int e = 0; e < 9; ++e) Hr.m[e] = sV[e * 64 + 1];
-    ok = sV[9 * 64 + 1] != 0.0;
+    for (int e = 0; e < 9; ++e) Hr.m[e] = sV[e * 2 + 1];
+    ok = sV[9 * 2 + 1] != 0.0;
     bool use_refit = false;
     int nr = 0;
     if (mlesac) {  // :216-236: the refit is the answer; invalid or no inlier left -> not found
@@ -827,7 +833,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                            stream()));
     {
         Prof prof("ransac_finalize");
-    ransac_finalize_kernel<<<n_pairs, 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
+    ransac_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
                                                                   best, o.max_distance, d_models,
                                                                   d_mask, scratch, d_found, d_ninl, mlesac);
     }
