@@ -264,12 +264,16 @@ __device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob,
 template <bool LIST>
 __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __restrict__ jobs,
                                                            const WgJob* __restrict__ wgs,
-                                                           const uint32_t* __restrict__ row_list,
+                                                           const uint32_t* __restrict__ row_list, int n_jobs,
                                                            uint32_t* __restrict__ out_idx,
                                                            float* __restrict__ out_d1,
                                                            float* __restrict__ out_d2) {
     __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
+    // list mode: a tile's rows may come from different jobs that share the B set (w.job names one of them); per row
+    // the output slot, its A row (pointer into that job's permuted copy) and ||a||^2
     __shared__ int s_rows[kTM];
+    __shared__ const float* s_pa[kTM];
+    __shared__ float s_a2[kTM];
 
     const WgJob w = wgs[blockIdx.x];
     const MatchJob jb = jobs[w.job];
@@ -280,11 +284,30 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     const int h = lane >> 5;
     const int nA = jb.nA, nB = jb.nB;
     if (LIST) {
-        if (tid < kTM) s_rows[tid] = tid < w.list_cnt ? (int)((int64_t)row_list[w.row0 + tid] - jb.out_off) : -1;
+        if (tid < kTM) {
+            int slot = -1;
+            const float* pa = jb.PA;
+            float a2v = 0.f;
+            if (tid < w.list_cnt) {
+                slot = (int)row_list[w.row0 + tid];
+                int lo = 0, hi = n_jobs - 1;  // the job whose output range holds the slot (ranges ascend with the job index)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (jobs[mid].out_off <= (int64_t)slot) lo = mid;
+                    else hi = mid - 1;
+                }
+                const int ar = (int)((int64_t)slot - jobs[lo].out_off);
+                pa = jobs[lo].PA + (size_t)ar * kDim;
+                a2v = jobs[lo].sqA[ar];
+            }
+            s_rows[tid] = slot;
+            s_pa[tid] = pa;
+            s_a2[tid] = a2v;
+        }
         __syncthreads();
     }
     const int rowbase = LIST ? wave * 32 : w.row0 + wave * 32;
-    auto a_row = [&](int local) -> int {  // A row index of tile-local row `local`, or -1
+    auto a_row = [&](int local) -> int {  // A row index (dense mode) / output slot (list mode) of a tile row, or -1
         if (LIST) return s_rows[local];
         return local < nA ? local : -1;
     };
@@ -293,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     f32x4 av[16];
     {
         const int ar = a_row(rowbase + c);
-        const int arow = ar >= 0 ? ar : (LIST ? max(s_rows[0], 0) : nA - 1);
-        const f32x4* ap = reinterpret_cast<const f32x4*>(jb.PA + (size_t)arow * kDim + h * 64);
+        const float* prow = LIST ? s_pa[ar >= 0 ? rowbase + c : 0] : jb.PA + (size_t)(ar >= 0 ? ar : nA - 1) * kDim;
+        const f32x4* ap = reinterpret_cast<const f32x4*>(prow + h * 64);
 #pragma unroll
         for (int q = 0; q < 16; ++q) av[q] = ap[q];
     }
@@ -303,8 +326,9 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     int bidx[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int ar = a_row(rowbase + (r & 3) + 8 * (r >> 2) + 4 * h);
-        a2[r] = jb.sqA[ar >= 0 ? ar : 0];
+        const int lr = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ar = a_row(lr);
+        a2[r] = LIST ? s_a2[lr] : jb.sqA[ar >= 0 ? ar : 0];
         best[r] = INFINITY;
         second[r] = INFINITY;
         bidx[r] = c;
@@ -384,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
         for (int r = 0; r < 16; ++r) {
             const int row = a_row(rowbase + (r & 3) + 8 * (r >> 2) + 4 * h);
             if (row >= 0) {
-                const int64_t o = jb.out_off + row;
+                const int64_t o = LIST ? (int64_t)row : jb.out_off + row;
                 out_idx[o] = nB > 0 ? (uint32_t)bidx[r] + 1u : 0u;
                 out_d1[o] = best[r];
                 out_d2[o] = second[r];
@@ -1183,6 +1207,17 @@ static bool use_split_path() {
     return !(e && std::strcmp(e, "f32") == 0);
 }
 
+// job j's list segment (at its first output slot) -> its place in the pooled list
+__global__ void fb_compact_kernel(const MatchJob* __restrict__ jobs, const uint32_t* __restrict__ fb_list,
+                                  const unsigned int* __restrict__ fb_count, const long long* __restrict__ dst,
+                                  uint32_t* __restrict__ pool) {
+    const int j = blockIdx.x;
+    const unsigned int cnt = fb_count[j];
+    const uint32_t* src = fb_list + jobs[j].out_off;
+    uint32_t* out = pool + dst[j];
+    for (unsigned int e = threadIdx.x; e < cnt; e += blockDim.x) out[e] = src[e];
+}
+
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2) {
     std::vector<WgJob> wgs;
@@ -1198,7 +1233,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     if (!use_split_path()) {
         {
             Prof prof("match2nn");
-            match2nn_kernel<false><<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, nullptr, idx, d1, d2);
+            match2nn_kernel<false><<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, nullptr, (int)jobs.size(), idx, d1, d2);
         }
         check_launch("match2nn_kernel");
         APS_HIP(hipStreamSynchronize(stream()));  // the pageable host vectors must outlive the copies
@@ -1232,20 +1267,39 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     APS_HIP(hipMemcpyAsync(h_cnt.data(), fb_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
     const auto R1 = std::chrono::steady_clock::now();
-    // exact f32 kernel in row-list mode, tiles grouped per job
+    // Exact f32 kernel in row-list mode.  The uncertified rows of all jobs that share a B set are pooled into common
+    // 128-row tiles (a pair leaves ~80 such rows at 20 k features: one mostly empty tile each otherwise): the segments
+    // are compacted in group order on the device, the kernel finds every row's job by its output slot.
+    std::vector<int> order((size_t)jobs.size());
+    for (int j = 0; j < (int)jobs.size(); ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return std::less<const void*>()(jobs[a].PB, jobs[b].PB) ||
+               (jobs[a].PB == jobs[b].PB && jobs[a].nB < jobs[b].nB);
+    });
+    std::vector<long long> h_dst(jobs.size(), 0);
     std::vector<WgJob> fwgs;
     size_t n_fb = 0;
-    for (int j = 0; j < (int)jobs.size(); ++j) {
-        const size_t base = (size_t)jobs[j].out_off, cnt = h_cnt[j];
-        n_fb += cnt;
-        for (size_t b = 0; b < cnt; b += kTM) fwgs.push_back({j, (int)(base + b), (int)std::min<size_t>(kTM, cnt - b)});
+    for (size_t a = 0; a < order.size();) {
+        size_t b = a;
+        const size_t g0 = n_fb;
+        while (b < order.size() && jobs[order[b]].PB == jobs[order[a]].PB && jobs[order[b]].nB == jobs[order[a]].nB) {
+            h_dst[order[b]] = (long long)n_fb;
+            n_fb += h_cnt[order[b]];
+            ++b;
+        }
+        for (size_t r = g0; r < n_fb; r += kTM) fwgs.push_back({order[a], (int)r, (int)std::min<size_t>(kTM, n_fb - r)});
+        a = b;
     }
     if (fwgs.empty()) return;
+    Ws<long long> d_dst(jobs.size());
+    Ws<uint32_t> fb_pool(n_fb);
     Ws<WgJob> dfw(fwgs.size());
+    APS_HIP(hipMemcpyAsync(d_dst, h_dst.data(), jobs.size() * sizeof(long long), hipMemcpyHostToDevice, stream()));
     APS_HIP(hipMemcpyAsync(dfw, fwgs.data(), fwgs.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
     {
         Prof prof("match2nn_fallback");
-        match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_list, idx, d1, d2);
+        fb_compact_kernel<<<(unsigned)jobs.size(), 64, 0, stream()>>>(djobs, fb_list, fb_count, d_dst, fb_pool);
+        match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_pool, (int)jobs.size(), idx, d1, d2);
     }
     check_launch("match2nn_kernel<list>");
     const auto R2 = std::chrono::steady_clock::now();
@@ -1471,7 +1525,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
         rows += nA;
         cols += counts[j];
     }
-    APS_REQUIRE(rows < ((int64_t)1 << 32), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
+    APS_REQUIRE(rows < ((int64_t)1 << 31), APS_E_DIM, "too many pair-rows for one batch (%lld)", (long long)rows);
     Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
     Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
     const auto T2 = t_now();
