@@ -100,7 +100,64 @@ def main_v2():
     print("wrote golden_v2.npz:", {k: v.shape for k, v in out.items()})
 
 
+def main_v3():
+    """golden_v3.npz: the rows of SURVEY section 8(f) -- imresize (bicubic shrink + bilinear size form), the bundle
+    adjustment's per-pair normal-equation blocks (both directions, Huber outliers, a degenerate depth), and the crop
+    rectangle (holes, a bay, content up to the last column, white canvas)."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    out["rs_img"] = textured(rng, 97, 131)
+    out["rs_bicubic_037"] = oracle.imresize_u8(out["rs_img"], 0.37, "bicubic")
+    out["rs_bilinear_40x150"] = oracle.imresize_u8(out["rs_img"], (40, 150), "bilinear")
+
+    def rot(scale):
+        w = rng.normal(0, scale, 3)
+        a = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / a
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+    packs, Uis, Ujs, ptr = [], [], [], [0]
+    for m in (5, 70, 0, 129):
+        cams = [{"f": float(rng.uniform(500, 900)), "cx": 320.0, "cy": 240.0, "R": rot(0.2)} for _ in range(2)]
+        cams += [dict(c, f=c["f"] + rng.normal(0, 2), R=rot(0.01) @ c["R"]) for c in cams]
+        X = rng.normal(0, 1, (max(m, 1), 3)) + np.array([0, 0, 4.0])
+        pts = []
+        for c in cams[:2]:
+            K = np.array([[c["f"], 0, c["cx"]], [0, c["f"], c["cy"]], [0, 0, 1.0]])
+            p = (K @ c["R"] @ X.T).T
+            pts.append((p[:, :2] / p[:, 2:3] + rng.normal(0, 1.5, (max(m, 1), 2)))[:m])
+        if m > 4:
+            pts[0][1] += 150.0  # beyond sigmaHuber
+        packs.append(np.stack([np.concatenate([[c["f"], c["cx"], c["cy"]], c["R"].ravel(order="F")]) for c in cams]))
+        Uis.append(pts[0])
+        Ujs.append(pts[1])
+        ptr.append(ptr[-1] + m)
+    out["ba_Ui"], out["ba_Uj"] = np.concatenate(Uis), np.concatenate(Ujs)
+    out["ba_ptr"], out["ba_cams"] = np.array(ptr, np.int64), np.stack(packs)
+    out["ba_both"] = oracle.ba_pair_blocks(out["ba_Ui"], out["ba_Uj"], ptr, out["ba_cams"], 2.0, True)
+    out["ba_one"] = oracle.ba_pair_blocks(out["ba_Ui"], out["ba_Uj"], ptr, out["ba_cams"], 2.0, False)
+
+    h, w = 120, 190
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = ((yy - 60) / 50.0) ** 2 + ((xx - 100) / 92.0) ** 2 < 1
+    m &= ~(((yy - 50) ** 2 + (xx - 60) ** 2) < 64)        # enclosed hole
+    m &= ~((yy < 35) & (np.abs(xx - 120) < 6))              # bay open to the top
+    m[40:80, 150:190] = True                                # content up to the last column
+    crop = np.zeros((h, w, 3), np.uint8)
+    crop[m] = rng.integers(1, 256, (int(m.sum()), 3), dtype=np.uint8)
+    out["crop_img"] = crop
+    r, ok, dbg = oracle.crop_rect(crop, False, 0)
+    out["crop_black"] = np.array(list(r) + [int(ok)] + list(dbg), np.int64)
+    white = 255 - crop
+    r, ok, dbg = oracle.crop_rect(white, True, 250)
+    out["crop_white"] = np.array(list(r) + [int(ok)] + list(dbg), np.int64)
+    np.savez_compressed(os.path.join(HERE, "golden_v3.npz"), **out)
+    print("wrote golden_v3.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(HERE, "golden_v1.npz")) or "--v1" in sys.argv:
         main()
-    main_v2()
+    if not os.path.exists(os.path.join(HERE, "golden_v2.npz")) or "--v2" in sys.argv:
+        main_v2()
+    main_v3()
