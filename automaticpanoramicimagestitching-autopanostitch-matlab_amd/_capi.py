@@ -42,7 +42,7 @@ class ApsError(RuntimeError):
 
 
 class aps_match_opts(C.Structure):
-    _fields_ = [("max_ratio", C.c_float), ("match_threshold", C.c_float), ("unique", C.c_int),
+    _fields_ = [("max_ratio", C.c_double), ("match_threshold", C.c_double), ("unique", C.c_int),
                 ("normalize", C.c_int)]
 
 

@@ -11,6 +11,9 @@ namespace aps {
 
 static thread_local std::string g_err;
 static thread_local Ctx g_ctx;
+// The device the most recent aps_set_device() call selected, in any thread.  A thread that has not chosen a device
+// itself (worker pools of the host layer, parfor 'Threads' workers) starts on it instead of falling back to device 0.
+static std::atomic<int> g_default_device{-1};
 
 void set_last_error(const char* s) { g_err = s ? s : ""; }
 
@@ -67,8 +70,11 @@ static void bind_device(Ctx& c, int dev) {
 Ctx& ctx() {
     Ctx& c = g_ctx;
     if (c.device < 0) {
-        int dev = 0;
-        if (const char* e = std::getenv("APS_DEVICE")) dev = std::atoi(e);
+        int dev = g_default_device.load(std::memory_order_acquire);
+        if (dev < 0) {
+            dev = 0;
+            if (const char* e = std::getenv("APS_DEVICE")) dev = std::atoi(e);
+        }
         bind_device(c, dev);
     } else {
         APS_HIP(hipSetDevice(c.device));
@@ -189,7 +195,10 @@ const char* aps_last_error(void) { return g_err.c_str(); }
 int aps_device_count(void) { return count_devices(); }
 
 int aps_set_device(int device) {
-    return guarded([&] { bind_device(g_ctx, device); });
+    return guarded([&] {
+        bind_device(g_ctx, device);
+        g_default_device.store(device, std::memory_order_release);
+    });
 }
 
 int aps_set_stream(void* hip_stream) {

@@ -1327,11 +1327,11 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
     APS_HIP(hipMemsetAsync(winner, 0xff, std::max<int64_t>(total_cols, 1) * sizeof(unsigned long long),
                            stream()));
     APS_HIP(hipMemsetAsync(cnt, 0, njobs * sizeof(unsigned long long), stream()));
-    const double r2 = (double)o.max_ratio * (double)o.max_ratio;
+    const double r2 = o.max_ratio * o.max_ratio;  // opt.MaxRatio^2 in double (matchFeaturesScratch.m:170-173)
     Prof prof("match_filter");
     const unsigned grid = cdiv(total_rows, 256);
     filter_mark_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, d1, d2, r2,
-                                                    (double)o.match_threshold, o.unique, keys, winner);
+                                                    o.match_threshold, o.unique, keys, winner);
     check_launch("filter_mark_kernel");
     filter_select_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, o.unique, keys,
                                                       winner, cnt);
@@ -1378,8 +1378,8 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
 
 static aps_match_opts default_opts() {
     aps_match_opts o;
-    o.max_ratio = 0.6f;
-    o.match_threshold = 3.5f;
+    o.max_ratio = 0.6;
+    o.match_threshold = 3.5;
     o.unique = 1;
     o.normalize = 2;
     return o;
@@ -1451,8 +1451,8 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     APS_REQUIRE(n_img == 0 || (desc && counts && ld), APS_E_ARG, "NULL descriptor table");
     APS_REQUIRE(cap >= 0, APS_E_ARG, "negative capacity");
     const aps_match_opts o = opts ? *opts : default_opts();
-    APS_REQUIRE(o.max_ratio > 0.f && o.max_ratio <= 1.f, APS_E_ARG, "MaxRatio must be in (0,1]");
-    APS_REQUIRE(o.match_threshold >= 0.f, APS_E_ARG, "MatchThreshold must be >= 0");
+    APS_REQUIRE(o.max_ratio > 0.0 && o.max_ratio <= 1.0, APS_E_ARG, "MaxRatio must be in (0,1]");
+    APS_REQUIRE(o.match_threshold >= 0.0, APS_E_ARG, "MatchThreshold must be >= 0");
     APS_REQUIRE(o.normalize >= 0 && o.normalize <= 2, APS_E_ARG, "normalize must be 0, 1 or 2");
     for (int i = 0; i < n_img; ++i) check_desc_args(desc[i], counts[i], ld[i], dim, layout, "desc");
     const int64_t n_pairs = (int64_t)pa.size();

@@ -157,8 +157,10 @@ def filter_matches(idx2, dBest, dSecond, n2, MaxRatio, MatchThreshold, Unique):
     the host): ratio on SSD (r^2), threshold, finiteness, greedy one-to-one by ascending distance (stable)."""
     dBest = np.asarray(dBest, np.float32)
     dSecond = np.asarray(dSecond, np.float32)
-    r2 = np.float32(MaxRatio * MaxRatio)
-    keep = (dBest <= r2 * dSecond) & (dBest <= np.float32(MatchThreshold)) & np.isfinite(dBest) & np.isfinite(dSecond)
+    # the reference holds dBest/dSecond in double arrays (inf(N1,1), :344) and evaluates MaxRatio^2 in double
+    r2 = float(MaxRatio) * float(MaxRatio)
+    b64, s64 = dBest.astype(np.float64), dSecond.astype(np.float64)
+    keep = (b64 <= r2 * s64) & (b64 <= float(MatchThreshold)) & np.isfinite(b64) & np.isfinite(s64)
     i1 = np.flatnonzero(keep).astype(np.uint32) + 1
     i2 = np.asarray(idx2, np.uint32)[keep]
     d = dBest[keep]

@@ -59,7 +59,9 @@ int aps_version(void);
 const char* aps_last_error(void);
 /* Number of usable gfx950 devices (0 if none; never fails). */
 int aps_device_count(void);
-/* Select the device for the calling thread (default: env APS_DEVICE, else 0). */
+/* Select the device for the calling thread.  The selection also becomes the process-wide default that threads which
+ * never called aps_set_device start on (worker pools, parpool('Threads') workers); before any call the default is env
+ * APS_DEVICE, else 0. */
 int aps_set_device(int device);
 /* Run the calling thread's work on an existing HIP stream (e.g. torch's current stream);
  * NULL restores the library's own per-thread stream. */
@@ -103,8 +105,10 @@ int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, i
 
 /* Options of the a4 driver (matchFeaturesScratch.m:59-78 name/value pairs). */
 typedef struct aps_match_opts {
-    float max_ratio;       /* 'MaxRatio'       (inputs.m:59  Ratiothreshold = 0.6)                 */
-    float match_threshold; /* 'MatchThreshold' (inputs.m:55  Matchingthreshold = 1.5; raw SSD)     */
+    double max_ratio;       /* 'MaxRatio'       (inputs.m:59  Ratiothreshold = 0.6).  f64 like MATLAB's scalars:
+                               the test is d1 <= MaxRatio^2 * d2 with MaxRatio^2 evaluated in double
+                               (matchFeaturesScratch.m:170-173); a float field would move the boundary. */
+    double match_threshold; /* 'MatchThreshold' (inputs.m:55  Matchingthreshold = 1.5; raw SSD), f64   */
     int unique;            /* 'Unique'         (featureMatchingPairwise.m:113: true)               */
     int normalize;         /* 0 never, 1 always, 2 = the reference's rule: L2-normalise both sets
                               iff max|A| > 2 or max|B| > 2 (matchFeaturesScratch.m:105-110)        */

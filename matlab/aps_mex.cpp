@@ -76,8 +76,8 @@ static void cmd_sift(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
 
 static aps_match_opts match_opts(const mxArray* s) {
     aps_match_opts o;
-    o.max_ratio = (float)field(s, "MaxRatio", 0.6);
-    o.match_threshold = (float)field(s, "MatchThreshold", 3.5);
+    o.max_ratio = field(s, "MaxRatio", 0.6);
+    o.match_threshold = field(s, "MatchThreshold", 3.5);
     o.unique = field(s, "Unique", 1) != 0;
     o.normalize = 2;
     return o;

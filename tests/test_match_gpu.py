@@ -336,3 +336,66 @@ def test_pair_shards_compose_to_the_all_pairs_result(fm):
                     t0, t1 = int(qp[k]), int(qp[k + 1])
                     assert np.array_equal(ia[s0:s1], qa[t0:t1]) and np.array_equal(ib[s0:s1], qb[t0:t1])
                     assert np.array_equal(met[s0:s1].view(np.uint32), qm[t0:t1].view(np.uint32))
+
+
+def _boundary_sets(t_center, n=201):
+    """A_i = (t_i, 0, ...) with t_i the f32 neighbours of t_center; B = {0, e2}: d1 = t^2, d2 = t^2 + 1."""
+    c = np.float32(t_center)
+    t = np.full(n, c, np.float32)
+    for k in range(n // 2):  # walk +-k ulps
+        t[n // 2 + 1 + k] = np.nextafter(t[n // 2 + k], np.float32(2))
+        t[n // 2 - 1 - k] = np.nextafter(t[n // 2 - k], np.float32(0))
+    a = np.zeros((n, 128), np.float32)
+    a[:, 0] = t
+    b = np.zeros((2, 128), np.float32)
+    b[1, 1] = 1.0
+    return a, b
+
+
+def test_ratio_test_uses_double_r2_on_the_boundary(fm):
+    """matchFeaturesScratch.m:170-173 evaluates MaxRatio^2 in double: rows whose d1/d2 falls between 0.36 and
+    (double)0.6f^2 must be dropped, exactly as the oracle does (a float MaxRatio kept them)."""
+    a, b = _boundary_sets(0.75)  # t^2/(t^2+1) = 0.36 at t = 0.75
+    _, _, d1, d2 = fm.nearest2SSDExhaustive(a, b)
+    dd1, dd2 = d1.astype(np.float64), d2.astype(np.float64)
+    keep64 = dd1 <= (0.6 * 0.6) * dd2
+    keep32 = dd1 <= (float(np.float32(0.6)) ** 2) * dd2
+    assert keep64.any() and (~keep64).any() and (keep64 != keep32).any(), "the fixture must straddle the boundary"
+    m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=3.5, MaxRatio=0.6, Unique=False)
+    om, omet = oracle.match_features(a, b, 0.6, 3.5, False, 0)
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+    assert np.array_equal(m[:, 0], np.flatnonzero(keep64) + 1)
+
+
+def test_match_threshold_is_compared_in_double(fm):
+    """MatchThreshold = 0.1 is not representable in f32: d1 values between 0.1 and (double)0.1f are dropped."""
+    a, b = _boundary_sets(np.sqrt(0.1))
+    b[1, 1] = 1.9  # d2 far away: only the threshold decides (max|B| <= 2, so the reference's rule does not normalise)
+    _, _, d1, _ = fm.nearest2SSDExhaustive(a, b)
+    dd1 = d1.astype(np.float64)
+    assert (dd1 <= 0.1).any() and (dd1 > 0.1).any()
+    assert ((dd1 <= 0.1) != (dd1 <= float(np.float32(0.1)))).any(), "the fixture must straddle the boundary"
+    m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=0.1, MaxRatio=1.0, Unique=False)
+    om, omet = oracle.match_features(a, b, 1.0, 0.1, False, 0)
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+    assert np.array_equal(m[:, 0], np.flatnonzero(dd1 <= 0.1) + 1)
+
+
+def test_worker_threads_inherit_the_selected_device(gpu, monkeypatch):
+    """aps_set_device also sets the process-wide default: a thread that never selected a device must not fall back
+    to APS_DEVICE / device 0.  On a one-GPU box the fallback is made to fail by an invalid APS_DEVICE."""
+    import threading
+
+    capi = gpu._capi
+    capi.check(capi.lib.aps_set_device(0))
+    monkeypatch.setenv("APS_DEVICE", "63")
+    out = {}
+
+    def work():
+        out["rc"] = capi.lib.aps_synchronize()
+        out["err"] = capi.lib.aps_last_error()
+
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    assert out["rc"] == 0, out
