@@ -1,0 +1,1050 @@
+// render_batch.hip — the multiband render path for ALL tiles of a canvas at once (renderPanorama.m:342-425 tile
+// loop, fuseTile :825-1060, sampleOneTile :1063-1146, multiBandBlending.m:45-171), laid out for MI355X:
+//
+//   * level-major over the whole canvas: every pyramid step is ONE launch covering all (tile, layer) footprints
+//     (13 launches per panorama with 5 bands instead of ~22 per tile); work items are 32 x 8 output blocks found
+//     through a prefix table, XCD-contiguous so that neighbouring blocks (which share halos) share an L2;
+//   * the inverse warp is fused into pyramid level 0: the level-0 layer (16 B per covered pixel) is never written.
+//     The blur + downsample pass warps its haloed patch straight into LDS, and the Laplacian/collapse pass of
+//     level 0 re-evaluates the same sample (bit-identical: same code on the same inputs) instead of re-reading it;
+//   * the fuseTile + multiBandBlending weight normalisations (two sums over the tile's layers, in layer order)
+//     are produced by the coverage pass as two floats per canvas pixel and applied inside the warp;
+//   * Laplacian accumulation over the layers, the collapse step and (at level 0) the uint8 paint are one pass
+//     per level, coarse to fine: Num_l is never stored;
+//   * imresize tap positions/weights come from small per-length tables built once per call by the same f64
+//     formula the per-tile kernels evaluate per pixel;
+//   * pyramid levels are stored compactly over each layer's footprint rectangle (the layer is exactly zero
+//     outside it, see struct Rect).
+//
+// The arithmetic (operation order, roundings) of every value is that of render.hip's per-tile kernels, which
+// are the restatement checked against oracle/render_oracle.c: tests/test_render_gpu.py compares both paths
+// bit for bit (APS_RENDER_LEGACY=1 selects the per-tile path).
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "render_dev.h"
+
+namespace aps {
+
+namespace {
+
+constexpr int kML = 8;        // pyramid levels supported by the batched path
+constexpr int kTD = 6;        // non-zero taps kept per output sample of a shrink (scale in [1/3, 1/2]: <= 6)
+constexpr int kTU = 2;        // ... of an enlargement (scale >= 2: <= 2)
+constexpr int kNT = 512;                             // threads of the shrink kernels
+constexpr int kBW = 32, kBH = 16;                    // their output block (one output pixel per thread)
+constexpr int kBC = 2 * kBW + 8, kBR = 2 * kBH + 8;  // blurred patch a block of the shrink can need
+constexpr int kUW = 32, kUH = 8;                     // output block of the collapse kernels (256 threads)
+
+struct RwTile {
+    int r0, c0, ht, wt;
+    int e0, ne;  // entries [e0, e0 + ne), ascending image index
+    int nl;      // pyramid levels of this tile: clamp(levels, 1, floor(log2(min(ht, wt))))
+    int rf_down, rf_up;  // bit l: imresize(level l -> l+1) / (l+1 -> l) resizes rows first
+    long long plane;     // pixel offset of the tile in the canvas-sized planes (norm, cov), pitch wt
+    long long f[kML];    // float4 offset of F_l (l >= 1), pitch lw[l]
+    int lh[kML], lw[kML];
+    int tdr[kML], tdc[kML];  // tap-table offsets (in output samples) of the shrink l -> l+1: rows, columns
+    int tur[kML], tuc[kML];  // ... of the enlargement l+1 -> l
+};
+
+struct RwEntry {
+    int tile, img;
+    Rect g[kML];        // footprint of G_l in level-l tile coordinates
+    long long off[kML];  // float4 offset of the compact G_l store, pitch g[l].x1 - g[l].x0
+};
+
+struct RwArgs {
+    const RwTile* tiles;
+    const RwEntry* entries;
+    int n_tiles, n_entries;
+    const DevImage* imgs;
+    DevCanvas cv;
+    float angle_pow;
+    Taps tp;
+    const int* td_idx;    // [sample][kTD] clamped 0-based source index
+    const float* td_w;    // [sample][kTD]
+    const int* tu_idx;    // [sample][kTU]
+    const float* tu_w;
+    float4* G;            // compact pyramid store
+    float4* F;            // collapse planes, levels >= 1
+    uint8_t* cov;         // per canvas pixel: any(w > 0)
+    int* status;          // sticky error flag raised by a kernel whose assumptions do not hold
+    uint8_t* pano;
+    uint8_t* covered;
+    int H, W, out_layout, white;
+};
+
+// largest s with ptr[s] <= bid (ptr nondecreasing, ptr[0] = 0, n segments); every wave evaluates it for itself
+__device__ __forceinline__ int find_segment(const int* __restrict__ ptr, int n, int bid) {
+    const int lane = threadIdx.x & 63;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool le = i < n && ptr[i] <= bid;
+        cnt += __popcll(__ballot(le));
+    }
+    return __builtin_amdgcn_readfirstlane(cnt - 1);  // wave-uniform by construction: let the compiler know
+}
+
+// blockIdx -> work item: consecutive work items stay on one XCD (workgroups are dealt round-robin to the 8 XCDs)
+__device__ __forceinline__ int xcd_contiguous_id(int n_items) {
+    const int per = (n_items + 7) >> 3;
+    return (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tap tables
+// ------------------------------------------------------------------------------------------------
+struct TapJob {
+    int in_len, out_len, T, off;  // off in output samples
+};
+
+// One thread per output sample: the non-zero taps of resize_taps, in order, with their clamped source index.
+__global__ void rw_taps_kernel(const TapJob* __restrict__ jobs, int* __restrict__ d_idx, float* __restrict__ d_w,
+                               int* __restrict__ u_idx, float* __restrict__ u_w, int* __restrict__ status) {
+    const TapJob j = jobs[blockIdx.y];
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= j.out_len) return;
+    int left;
+    float wts[12];
+    const int P = resize_taps(j.in_len, j.out_len, o, left, wts);
+    int* ti = j.T == kTD ? d_idx : u_idx;
+    float* tw = j.T == kTD ? d_w : u_w;
+    const size_t base = (size_t)(j.off + o) * j.T;
+    int n = 0, lastidx = min(max(left, 1), j.in_len) - 1;
+    for (int t = 0; t < P; ++t) {
+        if (wts[t] == 0.f) continue;  // a zero tap adds 0 * v: nothing (finite data)
+        lastidx = min(max(left + t, 1), j.in_len) - 1;
+        if (n < j.T) {
+            ti[base + n] = lastidx;
+            tw[base + n] = wts[t];
+        }
+        ++n;
+    }
+    if (n > j.T) atomicOr(status, 1);
+    for (; n < j.T; ++n) {
+        ti[base + n] = lastidx;
+        tw[base + n] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling with per-block trig tables and a u8 -> [0,1] table (same values as canvas_ray / sample_one)
+// ------------------------------------------------------------------------------------------------
+struct ColTrig {
+    float s, c;  // sin/cos of theta (cylindrical, spherical)
+};
+struct RowTrig {
+    float s, c;  // spherical: sin/cos of phi; cylindrical: s = height
+};
+
+__device__ __forceinline__ ColTrig col_trig(const DevCanvas& cv, float xp) {
+    ColTrig t;
+    const float th = cv.o0 + xp / cv.f;
+    t.s = sinf(th);
+    t.c = cosf(th);
+    return t;
+}
+__device__ __forceinline__ RowTrig row_trig(const DevCanvas& cv, float yp) {
+    RowTrig t;
+    const float ph = cv.o1 + yp / cv.f;
+    if (cv.mode == APS_PROJ_SPHERICAL) {
+        t.c = cosf(ph);
+        t.s = sinf(ph);
+    } else {
+        t.s = ph;
+        t.c = 1.0f;
+    }
+    return t;
+}
+
+// canvas_ray with the transcendental parts taken from the tables (cylindrical / spherical) or evaluated in
+// place (planar / stereographic have none)
+__device__ __forceinline__ void ray_from_tables(const DevCanvas& cv, const ColTrig& ct, const RowTrig& rt, float xp,
+                                                float yp, float d[3]) {
+    if (cv.mode == APS_PROJ_CYLINDRICAL || cv.mode == APS_PROJ_SPHERICAL) {
+        float x, y, z;
+        if (cv.mode == APS_PROJ_CYLINDRICAL) {
+            x = ct.s;
+            y = rt.s;
+            z = ct.c;
+        } else {
+            x = rt.c * ct.s;
+            y = rt.s;
+            z = rt.c * ct.c;
+        }
+        float n = sqrtf((x * x + y * y) + z * z);
+        if (!(n > 1e-8f)) n = 1e-8f;
+        d[0] = x / n;
+        d[1] = y / n;
+        d[2] = z / n;
+    } else {
+        canvas_ray(cv, xp, yp, d);
+    }
+}
+
+// sample_one with (float)b / 255.0f looked up; returns (r, g, b, Wang * Wf) with zeros outside the mask
+__device__ __forceinline__ float4 sample_lut(const DevImage& im, const float d[3], float angle_pow,
+                                             const float* __restrict__ u8f) {
+    float u, v, wa;
+    if (!project(im, d, angle_pow, u, v, wa)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int w = im.w, h = im.h;
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    x0 = max(1, min(x0, w - 1));
+    y0 = max(1, min(y0, h - 1));
+    const int x1 = min(x0 + 1, w), y1 = min(y0 + 1, h);
+    const float s = u - (float)x0, t = v - (float)y0;
+    const uint32_t* __restrict__ r0p = im.rgba + (size_t)(y0 - 1) * w;
+    const uint32_t* __restrict__ r1p = im.rgba + (size_t)(y1 - 1) * w;
+    const uint32_t p00 = r0p[x0 - 1], p10 = r0p[x1 - 1], p01 = r1p[x0 - 1], p11 = r1p[x1 - 1];
+    const float wy0 = im.wy[y0 - 1], wy1 = im.wy[y1 - 1], wx0 = im.wx[x0 - 1], wx1 = im.wx[x1 - 1];
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = im.gain[c];
+        const float v00 = u8f[(p00 >> (8 * c)) & 255u] * g;
+        const float v10 = u8f[(p10 >> (8 * c)) & 255u] * g;
+        const float v01 = u8f[(p01 >> (8 * c)) & 255u] * g;
+        const float v11 = u8f[(p11 >> (8 * c)) & 255u] * g;
+        const float top = (1.0f - s) * v00 + s * v10;
+        const float bot = (1.0f - s) * v01 + s * v11;
+        o[c] = top * (1.0f - t) + bot * t;
+    }
+    const float f00 = wy0 * wx0, f10 = wy0 * wx1, f01 = wy1 * wx0, f11 = wy1 * wx1;
+    const float top = (1.0f - s) * f00 + s * f10;
+    const float bot = (1.0f - s) * f01 + s * f11;
+    const float wf = top * (1.0f - t) + bot * t;
+    return make_float4(o[0], o[1], o[2], wa * wf);
+}
+
+// sample_lut in two halves, so that a thread can put the gathers of several samples in flight before it consumes
+// any of them: sample_issue projects and loads (from a safe address when the ray misses the image), sample_finish
+// interpolates.  Same operations on the same values as sample_lut.
+struct SampleLoads {
+    uint32_t p00, p10, p01, p11;
+    float wy0, wy1, wx0, wx1;
+    float s, t, wa;
+    bool m;
+};
+__device__ __forceinline__ void sample_issue(const DevImage& im, const float d[3], float angle_pow, bool active,
+                                             SampleLoads& L) {
+    float u = 1.0f, v = 1.0f, wa = 0.0f;
+    L.m = active && project(im, d, angle_pow, u, v, wa);
+    if (!L.m) {
+        u = 1.0f;
+        v = 1.0f;
+    }
+    const int w = im.w, h = im.h;
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    x0 = max(1, min(x0, w - 1));
+    y0 = max(1, min(y0, h - 1));
+    const int x1 = min(x0 + 1, w), y1 = min(y0 + 1, h);
+    L.s = u - (float)x0;
+    L.t = v - (float)y0;
+    L.wa = wa;
+    const uint32_t* __restrict__ r0p = im.rgba + (size_t)(y0 - 1) * w;
+    const uint32_t* __restrict__ r1p = im.rgba + (size_t)(y1 - 1) * w;
+    L.p00 = r0p[x0 - 1];
+    L.p10 = r0p[x1 - 1];
+    L.p01 = r1p[x0 - 1];
+    L.p11 = r1p[x1 - 1];
+    L.wy0 = im.wy[y0 - 1];
+    L.wy1 = im.wy[y1 - 1];
+    L.wx0 = im.wx[x0 - 1];
+    L.wx1 = im.wx[x1 - 1];
+}
+__device__ __forceinline__ float4 sample_finish(const DevImage& im, const SampleLoads& L, const float* __restrict__ u8f) {
+    const float s = L.s, t = L.t;
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = im.gain[c];
+        const float v00 = u8f[(L.p00 >> (8 * c)) & 255u] * g;
+        const float v10 = u8f[(L.p10 >> (8 * c)) & 255u] * g;
+        const float v01 = u8f[(L.p01 >> (8 * c)) & 255u] * g;
+        const float v11 = u8f[(L.p11 >> (8 * c)) & 255u] * g;
+        const float top = (1.0f - s) * v00 + s * v10;
+        const float bot = (1.0f - s) * v01 + s * v11;
+        o[c] = top * (1.0f - t) + bot * t;
+    }
+    const float f00 = L.wy0 * L.wx0, f10 = L.wy0 * L.wx1, f01 = L.wy1 * L.wx0, f11 = L.wy1 * L.wx1;
+    const float top = (1.0f - s) * f00 + s * f10;
+    const float bot = (1.0f - s) * f01 + s * f11;
+    const float wf = top * (1.0f - t) + bot * t;
+    return L.m ? make_float4(o[0], o[1], o[2], L.wa * wf) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// geometry + tent weight only (what the normalisation sums need): Wang * Wf, 0 outside the mask
+__device__ __forceinline__ float sample_weight(const DevImage& im, const float d[3], float angle_pow) {
+    float u, v, wa;
+    if (!project(im, d, angle_pow, u, v, wa)) return 0.f;
+    const int w = im.w, h = im.h;
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    x0 = max(1, min(x0, w - 1));
+    y0 = max(1, min(y0, h - 1));
+    const int x1 = min(x0 + 1, w), y1 = min(y0 + 1, h);
+    const float s = u - (float)x0, t = v - (float)y0;
+    const float wy0 = im.wy[y0 - 1], wy1 = im.wy[y1 - 1], wx0 = im.wx[x0 - 1], wx1 = im.wx[x1 - 1];
+    const float f00 = wy0 * wx0, f10 = wy0 * wx1, f01 = wy1 * wx0, f11 = wy1 * wx1;
+    const float top = (1.0f - s) * f00 + s * f10;
+    const float bot = (1.0f - s) * f01 + s * f11;
+    return wa * (top * (1.0f - t) + bot * t);
+}
+
+// fuseTile's rescale (renderPanorama.m:1009-1017) followed by multiBandBlending's own (multiBandBlending.m:72-85)
+__device__ __forceinline__ float norm_weight(float w, const float2 nrm) {
+    const float w1 = w * nrm.x;
+    const float wv = w1 > 0.f ? w1 : 0.f;
+    return nrm.y > 1e-8f ? wv / nrm.y : 0.f;
+}
+
+__device__ __forceinline__ float4 ld_compact(const float4* __restrict__ p, const Rect& r, int x, int y) {
+    return in_rect(r, x, y) ? p[(size_t)(y - r.y0) * (r.x1 - r.x0) + (x - r.x0)] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1a: coverage, all tiles (blockIdx.z = tile)
+// ------------------------------------------------------------------------------------------------
+// Per 32 x 8 block and image: does any pixel map into the image (rowmask; as cover_kernel in render.hip, with the
+// transcendental parts of the rays from per-block tables).  The footprints bound all later work on a layer.
+__global__ __launch_bounds__(256) void rw_cover_kernel(RwArgs A, int n_img, int nby_max, const int* __restrict__ xshift,
+                                                       unsigned long long* __restrict__ rowmask) {
+    __shared__ unsigned long long s_any, s_cand;
+    __shared__ float s_dc[3];
+    __shared__ int s_cosb;
+    __shared__ ColTrig s_ct[32];
+    __shared__ RowTrig s_rt[8];
+    const RwTile& T = A.tiles[blockIdx.z];
+    const int ht = T.ht, wt = T.wt;
+    if ((int)(blockIdx.x * 32) >= wt || (int)(blockIdx.y * 8) >= ht) return;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const bool in_tile = x < wt && y < ht;
+    if (threadIdx.x < 32) s_ct[threadIdx.x] = col_trig(A.cv, (float)(T.c0 + min((int)(blockIdx.x * 32 + threadIdx.x), wt - 1)));
+    if (threadIdx.x >= 64 && threadIdx.x < 72)
+        s_rt[threadIdx.x - 64] = row_trig(A.cv, (float)(T.r0 + min((int)(blockIdx.y * 8 + threadIdx.x - 64), ht - 1)));
+    if (threadIdx.x == 128) {
+        float dc[3];
+        canvas_ray(A.cv, (float)(T.c0 + min(blockIdx.x * 32 + 16, (unsigned)wt - 1)),
+                   (float)(T.r0 + min(blockIdx.y * 8 + 4, (unsigned)ht - 1)), dc);
+        s_dc[0] = dc[0];
+        s_dc[1] = dc[1];
+        s_dc[2] = dc[2];
+        s_cosb = __float_as_int(1.0f);
+    }
+    __syncthreads();
+    float d[3] = {0.f, 0.f, 1.f};
+    if (in_tile) ray_from_tables(A.cv, s_ct[threadIdx.x & 31], s_rt[threadIdx.x >> 5], (float)(T.c0 + x), (float)(T.r0 + y), d);
+    const float dn = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+    {
+        float cb = in_tile ? fmaf(d[2], s_dc[2], fmaf(d[1], s_dc[1], d[0] * s_dc[0])) / fmaxf(dn, 1e-8f) : 1.0f;
+        cb = fminf(fmaxf(cb, 0.0f), 1.0f);
+        for (int off = 32; off > 0; off >>= 1) cb = fminf(cb, __shfl_xor(cb, off));
+        if ((threadIdx.x & 63) == 0) atomicMin(&s_cosb, __float_as_int(cb));
+    }
+    __syncthreads();
+    const float cosb = fmaxf(__int_as_float(s_cosb) - 1e-6f, 0.0f), sinb = sqrtf(fmaxf(0.0f, 1.0f - cosb * cosb));
+    const unsigned long long colbit = 1ull << (blockIdx.x >> xshift[blockIdx.z]);
+    unsigned long long* rm = rowmask + (size_t)blockIdx.z * n_img * nby_max;
+    for (int base = 0; base < n_img; base += 64) {
+        const int cnt = min(64, n_img - base);
+        if (threadIdx.x < 64) {
+            bool cand = false;
+            if ((int)threadIdx.x < cnt) {
+                const DevImage& im = A.imgs[base + threadIdx.x];
+                const float ca = fmaf(s_dc[2], im.R[8], fmaf(s_dc[1], im.R[5], s_dc[0] * im.R[2]));
+                const float ci = im.cmin, si = sqrtf(fmaxf(0.0f, 1.0f - ci * ci));
+                cand = ci <= 0.0f || cosb <= 0.0f || ci * cosb - si * sinb <= 0.0f || ca >= (ci * cosb - si * sinb) - 1e-5f;
+            }
+            const unsigned long long b = __ballot(cand);
+            if (threadIdx.x == 0) {
+                s_cand = b;
+                s_any = 0ull;
+            }
+        }
+        __syncthreads();
+        unsigned long long mine = 0ull;
+        for (unsigned long long todo = s_cand; todo; todo &= todo - 1) {
+            const int i = __ffsll((long long)todo) - 1;
+            const DevImage& im = A.imgs[base + i];
+            const float cam2 = fmaf(d[2], im.R[8], fmaf(d[1], im.R[5], d[0] * im.R[2]));
+            if (!__any(in_tile && cam2 >= im.cmin * dn)) continue;
+            float u, v, wa;
+            const bool m = in_tile && project(im, d, A.angle_pow, u, v, wa);
+            if (__any(m)) mine |= 1ull << i;
+        }
+        if ((threadIdx.x & 63) == 0 && mine) atomicOr(&s_any, mine);
+        __syncthreads();
+        const unsigned long long all = s_any;
+        if ((int)threadIdx.x < cnt && ((all >> threadIdx.x) & 1ull))
+            atomicOr(&rm[(size_t)(base + threadIdx.x) * nby_max + blockIdx.y], colbit);
+        __syncthreads();
+    }
+}
+
+// rowmask -> {x0, y0, x1, y1} per (tile, image), pixels of the tile, half-open; x1 <= x0 when nothing is covered
+__global__ void rw_footprint_kernel(const unsigned long long* __restrict__ rowmask, const RwTile* __restrict__ tiles,
+                                    const int* __restrict__ xshift, int n_img, int nby_max, int total,
+                                    int* __restrict__ bbox) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // tile * n_img + image
+    if (e >= total) return;
+    const int t = e / n_img;
+    const int ht = tiles[t].ht, wt = tiles[t].wt, nby = (ht + 7) / 8, xs = xshift[t];
+    const unsigned long long* m = rowmask + (size_t)e * nby_max;
+    unsigned long long cols = 0ull;
+    int y0 = INT_MAX, y1 = 0;
+    for (int by = 0; by < nby; ++by) {
+        const unsigned long long r = m[by];
+        if (r) {
+            cols |= r;
+            y0 = min(y0, by * 8);
+            y1 = max(y1, min(by * 8 + 8, ht));
+        }
+    }
+    int x0 = 0, x1 = 0;
+    if (cols) {
+        const int lo = __ffsll((long long)cols) - 1, hi = 63 - __clzll((long long)cols);
+        x0 = (lo << xs) * 32;
+        x1 = min(((hi + 1) << xs) * 32, wt);
+    } else {
+        y0 = 0;
+    }
+    bbox[4 * e + 0] = x0;
+    bbox[4 * e + 1] = y0;
+    bbox[4 * e + 2] = x1;
+    bbox[4 * e + 3] = y1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1b: the level-0 layers of every tile: sampleOneTile for each (pixel, layer) exactly once
+// ------------------------------------------------------------------------------------------------
+// One workgroup per 32 x 8 block of a tile, looping over the tile's layers in order: ray once per pixel, then per
+// layer project -> bilinear gather -> Wang * Wf (gathers of a layer are issued before the previous layer's sample is
+// finished).  The samples wait in LDS until the two normalisation sums of the pixel are known (fuseTile's
+// renderPanorama.m:1009-1017, then multiBandBlending.m:72-85, both in layer order) and go to the compact G_0 store
+// with their final weight: the level-0 layer is written once and the weights are never re-read for normalising.
+constexpr int kWL = 6;  // layers of a block whose samples are parked in LDS; further ones are re-sampled
+__global__ __launch_bounds__(256) void rw_warp_kernel(RwArgs A, const int* __restrict__ blk_ptr, int n_blocks) {
+    __shared__ ColTrig s_ct[kUW];
+    __shared__ RowTrig s_rt[kUH];
+    __shared__ float s_u8[256];
+    __shared__ float4 s_g[kWL][256];
+    const int bid = xcd_contiguous_id(n_blocks);
+    if (bid >= n_blocks) return;
+    const int t = find_segment(blk_ptr, A.n_tiles, bid);
+    const RwTile& T = A.tiles[t];
+    const int tid = threadIdx.x;
+    const int h = T.ht, w = T.wt;
+    const int local = bid - blk_ptr[t], nbx = (w + kUW - 1) / kUW;
+    const int x0 = (local % nbx) * kUW, y0 = (local / nbx) * kUH;
+    if (tid < kUW) s_ct[tid] = col_trig(A.cv, (float)(T.c0 + min(x0 + tid, w - 1)));
+    if (tid >= 64 && tid < 64 + kUH) s_rt[tid - 64] = row_trig(A.cv, (float)(T.r0 + min(y0 + tid - 64, h - 1)));
+    s_u8[tid] = (float)tid / 255.0f;
+    __syncthreads();
+    const int x = x0 + (tid & (kUW - 1)), y = y0 + tid / kUW;
+    const bool in_tile = x < w && y < h;
+    float d[3] = {0.f, 0.f, 1.f};
+    if (in_tile) ray_from_tables(A.cv, s_ct[tid & (kUW - 1)], s_rt[tid / kUW], (float)(T.c0 + x), (float)(T.r0 + y), d);
+    const int bx1 = min(x0 + kUW, w), by1 = min(y0 + kUH, h);
+    // pass A: samples and the first sum
+    float ssum = 0.f;
+    bool any = false;
+    int kc = 0;  // layers met so far (block-uniform)
+    for (int k = 0; k < T.ne; ++k) {
+        const RwEntry& E = A.entries[T.e0 + k];
+        const Rect g = E.g[0];
+        if (!(max(x0, g.x0) < min(bx1, g.x1) && max(y0, g.y0) < min(by1, g.y1))) continue;  // block-uniform
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_tile && in_rect(g, x, y)) v = sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8);
+        ssum = ssum + v.w;
+        any |= v.w > 0.f;
+        if (kc < kWL) s_g[kc][tid] = v;
+        ++kc;
+    }
+    const float inv = ssum > 1e-8f ? 1.0f / ssum : 0.f;
+    // pass B: the second sum over the rescaled weights
+    float s2 = 0.f;
+    kc = 0;
+    for (int k = 0; k < T.ne; ++k) {
+        const RwEntry& E = A.entries[T.e0 + k];
+        const Rect g = E.g[0];
+        if (!(max(x0, g.x0) < min(bx1, g.x1) && max(y0, g.y0) < min(by1, g.y1))) continue;
+        float wv;
+        if (kc < kWL)
+            wv = s_g[kc][tid].w;
+        else
+            wv = (in_tile && in_rect(g, x, y)) ? sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8).w : 0.f;
+        const float w1 = wv * inv;
+        s2 = s2 + (w1 > 0.f ? w1 : 0.f);
+        ++kc;
+    }
+    const float2 nrm = make_float2(inv, s2);
+    // pass C: store with the final weight
+    kc = 0;
+    for (int k = 0; k < T.ne; ++k) {
+        const RwEntry& E = A.entries[T.e0 + k];
+        const Rect g = E.g[0];
+        if (!(max(x0, g.x0) < min(bx1, g.x1) && max(y0, g.y0) < min(by1, g.y1))) continue;
+        if (in_tile && in_rect(g, x, y)) {
+            float4 v = kc < kWL ? s_g[kc][tid] : sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8);
+            v.w = norm_weight(v.w, nrm);
+            A.G[E.off[0] + (size_t)(y - g.y0) * (g.x1 - g.x0) + (x - g.x0)] = v;
+        }
+        ++kc;
+    }
+    if (in_tile) A.cov[(size_t)T.plane + (size_t)y * w + x] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: G_{l+1} = imresize(imgaussfilt(G_l)); at l = 0 G_0 is the warp, evaluated straight into LDS
+// ------------------------------------------------------------------------------------------------
+// Both kernels produce one kBW x kBH block of G_{l+1} per layer from the blurred patch its taps reach (<= kBR x kBC,
+// plus the filter radius): column pass, row pass, then the two resize passes, all out of LDS.  Same fma chains as
+// mb_blur_resize_kernel (render.hip); the resize runs as two passes through LDS - the first-pass value of an
+// (output row, patch column) is one chain whichever output pixel consumes it - instead of once per consumer.
+template <int R>
+struct DownShape {
+    static constexpr int IC = kBC + 2 * R, IR = kBR + 2 * R;
+    static constexpr int T1 = kBH * IC > kBR * kBW ? kBH * IC : kBR * kBW;  // first-pass buffer of the resize
+};
+
+// s_a holds the haloed input patch (nir x nic, pitch IC); on return the block's outputs have been written.
+template <int R>
+__device__ __forceinline__ void blur_resize_block(float4* __restrict__ s_a, float4* __restrict__ s_b, const Taps& tp,
+                                                  int nbr, int nbc, int bx0, int by0, int ox0, int oy0, int ox1, int oy1,
+                                                  const int* __restrict__ tci, const float* __restrict__ tcw,
+                                                  const int* __restrict__ tri, const float* __restrict__ trw, bool rows_first,
+                                                  float4* __restrict__ out, const Rect& go) {
+    constexpr int IC = DownShape<R>::IC;
+    const int tid = threadIdx.x, nic = nbc + 2 * R;
+    // Both Gaussian passes run IN PLACE through a register window (load, barrier, compute + store): the patch is the
+    // only large LDS buffer, so two workgroups fit a CU and one's barriers are covered by the other's work.
+    {  // column (vertical) pass: thread = (row segment, column)
+        constexpr int SEG = kNT / IC, RS = (kBR + SEG - 1) / SEG;
+        const int col = tid % IC, r0 = (tid / IC) * RS;
+        const bool act = tid < SEG * IC && col < nic && r0 < nbr;
+        float4 win[RS + 2 * R];
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < RS + 2 * R; ++i)
+                win[i] = r0 + i < nbr + 2 * R ? s_a[(r0 + i) * IC + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < RS; ++i) {
+                if (r0 + i >= nbr) break;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], win[i + t], a);
+                s_a[(r0 + i) * IC + col] = a;
+            }
+        }
+    }
+    {  // row (horizontal) pass: thread = (row, column segment of CS columns; CS odd keeps the b128 accesses spread)
+        constexpr int CS = 7, SEG = (kBC + CS - 1) / CS;
+        static_assert(SEG * kBR <= kNT, "row pass needs one thread per (row, segment)");
+        const int row = tid / SEG, c0 = (tid % SEG) * CS;
+        const bool act = row < nbr && c0 < nbc;
+        float4 win[CS + 2 * R];
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < CS + 2 * R; ++i)
+                win[i] = c0 + i < nic ? s_a[row * IC + c0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < CS; ++i) {
+                if (c0 + i >= nbc) break;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t <= 2 * R; ++t) a = fma4(tp.k[t], win[i + t], a);
+                s_a[row * IC + c0 + i] = a;
+            }
+        }
+    }
+    __syncthreads();
+    // zero-weight table slots (always trailing) add 0 * finite to a finished chain: the value is unchanged
+    const int now = ox1 - ox0, noh = oy1 - oy0;
+    if (rows_first) {
+        // first pass over rows: t1[yo][c] = sum_tr rw * B[ri][c]  (s_b, pitch IC); second over columns
+        for (int ee = tid; ee < kBH * IC; ee += kNT) {
+            const int yo = ee / IC, c = ee - yo * IC;
+            if (yo >= noh || c >= nbc) continue;
+            const size_t ro = (size_t)(oy0 + yo) * kTD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < kTD; ++t) v = fma4(trw[ro + t], s_a[(tri[ro + t] - by0) * IC + c], v);
+            s_b[ee] = v;
+        }
+        __syncthreads();
+        const int xo = tid & (kBW - 1), yo = tid / kBW;
+        if (xo < now && yo < noh) {
+            const size_t co = (size_t)(ox0 + xo) * kTD;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < kTD; ++t) a = fma4(tcw[co + t], s_b[yo * IC + (tci[co + t] - bx0)], a);
+            out[(size_t)(oy0 + yo - go.y0) * (go.x1 - go.x0) + (ox0 + xo - go.x0)] = a;
+        }
+    } else {
+        // first pass over columns: t1[r][xo] = sum_tc cw * B[r][ci]  (s_b, pitch kBW); second over rows
+        for (int ee = tid; ee < kBR * kBW; ee += kNT) {
+            const int r = ee / kBW, xo = ee - r * kBW;
+            if (r >= nbr || xo >= now) continue;
+            const size_t co = (size_t)(ox0 + xo) * kTD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < kTD; ++t) v = fma4(tcw[co + t], s_a[r * IC + (tci[co + t] - bx0)], v);
+            s_b[ee] = v;
+        }
+        __syncthreads();
+        const int xo = tid & (kBW - 1), yo = tid / kBW;
+        if (xo < now && yo < noh) {
+            const size_t ro = (size_t)(oy0 + yo) * kTD;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < kTD; ++t) a = fma4(trw[ro + t], s_b[(tri[ro + t] - by0) * kBW + xo], a);
+            out[(size_t)(oy0 + yo - go.y0) * (go.x1 - go.x0) + (ox0 + xo - go.x0)] = a;
+        }
+    }
+}
+
+// One workgroup per kBW x kBH block of one layer's G_{l+1} footprint, input from the compact store of G_l.
+template <int R>
+__global__ __launch_bounds__(kNT, 4) void rw_down_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
+    constexpr int IC = DownShape<R>::IC, IR = DownShape<R>::IR;
+    extern __shared__ float4 s_dyn[];
+    float4* s_a = s_dyn;
+    float4* s_b = s_dyn + IR * IC;
+    const int bid = xcd_contiguous_id(n_blocks);
+    if (bid >= n_blocks) return;
+    const int e = find_segment(blk_ptr, A.n_entries, bid);
+    const RwEntry& E = A.entries[e];
+    const RwTile& T = A.tiles[E.tile];
+    const int tid = threadIdx.x;
+    const int h = T.lh[l], w = T.lw[l];
+    const Rect gi = E.g[l], go = E.g[l + 1];
+    const int gow = go.x1 - go.x0;
+    const int local = bid - blk_ptr[e], nbx = (gow + kBW - 1) / kBW;
+    const int ox0 = go.x0 + (local % nbx) * kBW, oy0 = go.y0 + (local / nbx) * kBH;
+    const int ox1 = min(ox0 + kBW, go.x1), oy1 = min(oy0 + kBH, go.y1);
+    const int* __restrict__ tci = A.td_idx + (size_t)T.tdc[l] * kTD;
+    const int* __restrict__ tri = A.td_idx + (size_t)T.tdr[l] * kTD;
+    const float* __restrict__ tcw = A.td_w + (size_t)T.tdc[l] * kTD;
+    const float* __restrict__ trw = A.td_w + (size_t)T.tdr[l] * kTD;
+    const int bx0 = tci[(size_t)ox0 * kTD], bx1 = tci[(size_t)(ox1 - 1) * kTD + kTD - 1];
+    const int by0 = tri[(size_t)oy0 * kTD], by1 = tri[(size_t)(oy1 - 1) * kTD + kTD - 1];
+    const int nbc = bx1 - bx0 + 1, nbr = by1 - by0 + 1;
+    if (nbc > kBC || nbr > kBR) {
+        if (tid == 0) atomicOr(A.status, 2);
+        return;
+    }
+    const int nic = nbc + 2 * R, nir = nbr + 2 * R;
+    const float4* __restrict__ gin = A.G + E.off[l];
+    const int giw = gi.x1 - gi.x0;
+    for (int ee = tid; ee < IR * IC; ee += kNT) {
+        const int ly = ee / IC, lx = ee - ly * IC;
+        if (ly >= nir || lx >= nic) continue;
+        const int gy = min(max(by0 + ly - R, 0), h - 1), gx = min(max(bx0 + lx - R, 0), w - 1);
+        s_a[ee] = in_rect(gi, gx, gy) ? gin[(size_t)(gy - gi.y0) * giw + (gx - gi.x0)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    blur_resize_block<R>(s_a, s_b, A.tp, nbr, nbc, bx0, by0, ox0, oy0, ox1, oy1, tci, tcw, tri, trw, (T.rf_down >> l) & 1,
+                         A.G + E.off[l + 1], go);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 3 (coarse to fine): F_l = imresize(F_{l+1}) + sum_k (G_l,k - imresize(G_{l+1},k)) .* w_l,k ; at the tile's
+// coarsest level F = sum_k G_k .* w_k (multiBandBlending.m:136-167); level 0 paints (renderPanorama.m:408-425)
+// ------------------------------------------------------------------------------------------------
+// An enlargement has at most two non-zero taps per axis (table slots 0, 1; a zero-weight slot adds 0 * finite).
+struct UpTaps {
+    int r0, r1, c0, c1;
+    float wr0, wr1, wc0, wc1;
+};
+template <class LD>
+__device__ __forceinline__ float4 upsample2(const UpTaps& u, bool rows_first, LD ld) {
+    const float4 v00 = ld(u.c0, u.r0), v01 = ld(u.c0, u.r1), v10 = ld(u.c1, u.r0), v11 = ld(u.c1, u.r1);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rows_first) {  // per column tap: the chain over the row taps, then the chain over the columns
+        const float4 a = fma4(u.wr1, v01, fma4(u.wr0, v00, z));
+        const float4 b = fma4(u.wr1, v11, fma4(u.wr0, v10, z));
+        return fma4(u.wc1, b, fma4(u.wc0, a, z));
+    }
+    const float4 a = fma4(u.wc1, v10, fma4(u.wc0, v00, z));
+    const float4 b = fma4(u.wc1, v11, fma4(u.wc0, v01, z));
+    return fma4(u.wr1, b, fma4(u.wr0, a, z));
+}
+
+// load from a compact footprint store, 0 outside the footprint (branch-free: clamped address + select)
+__device__ __forceinline__ float4 ld_compact_sel(const float4* __restrict__ p, const Rect& r, int pw, int x, int y) {
+    const bool ok = in_rect(r, x, y);
+    const int xx = min(max(x, r.x0), r.x1 - 1), yy = min(max(y, r.y0), r.y1 - 1);
+    const float4 v = p[(size_t)(yy - r.y0) * pw + (xx - r.x0)];
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void rw_up_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
+    const int bid = xcd_contiguous_id(n_blocks);
+    if (bid >= n_blocks) return;
+    const int t = find_segment(blk_ptr, A.n_tiles, bid);
+    const RwTile& T = A.tiles[t];
+    const int tid = threadIdx.x;
+    const int h = T.lh[l], w = T.lw[l];
+    const bool last = l == T.nl - 1;
+    const int local = bid - blk_ptr[t], nbx = (w + kUW - 1) / kUW;
+    const int x0 = (local % nbx) * kUW, y0 = (local / nbx) * kUH;
+    const int x = x0 + (tid & (kUW - 1)), y = y0 + tid / kUW;
+    if (x >= w || y >= h) return;
+    UpTaps u;
+    u.r0 = u.r1 = u.c0 = u.c1 = 0;
+    u.wr0 = u.wr1 = u.wc0 = u.wc1 = 0.f;
+    if (!last) {
+        const size_t ro = ((size_t)T.tur[l] + y) * kTU, co = ((size_t)T.tuc[l] + x) * kTU;
+        u.r0 = A.tu_idx[ro];
+        u.r1 = A.tu_idx[ro + 1];
+        u.wr0 = A.tu_w[ro];
+        u.wr1 = A.tu_w[ro + 1];
+        u.c0 = A.tu_idx[co];
+        u.c1 = A.tu_idx[co + 1];
+        u.wc0 = A.tu_w[co];
+        u.wc1 = A.tu_w[co + 1];
+    }
+    const bool rf = (T.rf_up >> l) & 1;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < T.ne; ++k) {
+        const RwEntry& E = A.entries[T.e0 + k];
+        const Rect g = E.g[l];
+        if (!in_rect(g, x, y)) continue;  // contributes (0 - u) * 0
+        const float4 gv = A.G[E.off[l] + (size_t)(y - g.y0) * (g.x1 - g.x0) + (x - g.x0)];
+        if (!last) {
+            const Rect gc = E.g[l + 1];
+            float4 uv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gc.x1 > gc.x0) {
+                const float4* __restrict__ pc = A.G + E.off[l + 1];
+                const int pw = gc.x1 - gc.x0;
+                uv = upsample2(u, rf, [&](int cx, int cy) { return ld_compact_sel(pc, gc, pw, cx, cy); });
+            }
+            acc[0] = acc[0] + (gv.x - uv.x) * gv.w;
+            acc[1] = acc[1] + (gv.y - uv.y) * gv.w;
+            acc[2] = acc[2] + (gv.z - uv.z) * gv.w;
+        } else {
+            acc[0] = acc[0] + gv.x * gv.w;
+            acc[1] = acc[1] + gv.y * gv.w;
+            acc[2] = acc[2] + gv.z * gv.w;
+        }
+    }
+    float f[3] = {acc[0], acc[1], acc[2]};
+    if (!last && T.ne > 0) {
+        const float4* __restrict__ fc = A.F + T.f[l + 1];
+        const int cw1 = T.lw[l + 1];
+        const float4 uv = upsample2(u, rf, [&](int cx, int cy) { return fc[(size_t)cy * cw1 + cx]; });
+        f[0] = uv.x + acc[0];
+        f[1] = uv.y + acc[1];
+        f[2] = uv.z + acc[2];
+    }
+    if (!LEVEL0) {
+        A.F[T.f[l] + (size_t)y * w + x] = make_float4(f[0], f[1], f[2], 0.f);
+    } else {
+        const bool c = A.cov[(size_t)T.plane + (size_t)y * w + x] != 0;
+        const int gy = T.r0 + y, gx = T.c0 + x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float tt = roundf(255.0f * f[k]);  // MATLAB round: half away from zero
+            if (!(tt > 0.f)) tt = 0.f;
+            if (tt > 255.f) tt = 255.f;
+            const uint8_t b = c ? (uint8_t)tt : (A.white ? 255 : 0);
+            if (A.out_layout == APS_IMG_U8_HWC)
+                A.pano[((size_t)gy * A.W + gx) * 3 + k] = b;
+            else
+                A.pano[(size_t)k * A.H * A.W + (size_t)gx * A.H + gy] = b;
+        }
+        if (A.covered) {
+            if (A.out_layout == APS_IMG_U8_HWC)
+                A.covered[(size_t)gy * A.W + gx] = c ? 1 : 0;
+            else
+                A.covered[(size_t)gx * A.H + gy] = c ? 1 : 0;
+        }
+    }
+}
+
+template <int R>
+constexpr size_t down_lds_bytes() {
+    return (size_t)(DownShape<R>::IR * DownShape<R>::IC + DownShape<R>::T1) * sizeof(float4);
+}
+template <int R>
+void launch_down_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
+    static bool once = [] {
+        APS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rw_down_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)down_lds_bytes<R>()));
+        return true;
+    }();
+    (void)once;
+    rw_down_kernel<R><<<8u * (unsigned)((n_blocks + 7) / 8), kNT, down_lds_bytes<R>(), stream()>>>(A, l, blk_ptr, n_blocks);
+}
+void launch_down(int r, const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
+    switch (r) {
+        case 1: launch_down_r<1>(A, l, blk_ptr, n_blocks); break;
+        case 2: launch_down_r<2>(A, l, blk_ptr, n_blocks); break;
+        case 3: launch_down_r<3>(A, l, blk_ptr, n_blocks); break;
+        default: launch_down_r<4>(A, l, blk_ptr, n_blocks); break;
+    }
+}
+
+}  // namespace
+
+bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
+                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered) {
+    const int nt = (int)tiles.size();
+    if (nt == 0) return true;
+    const Taps tp = make_taps(o.pyr_sigma);
+    APS_REQUIRE(tp.r >= 1 && tp.r <= 4, APS_E_ARG, "pyrSigma %g needs a %d-tap filter; 3..9 taps are built",
+                (double)o.pyr_sigma, 2 * tp.r + 1);
+    if (o.pyr_levels > kML) return false;
+    // ---- tiles, level sizes, tap tables --------------------------------------------------------------------
+    std::vector<RwTile> ht_(nt);
+    std::vector<TapJob> jobs;
+    std::map<std::pair<int, int>, int> down_off, up_off;
+    int n_down = 0, n_up = 0;
+    auto tap_table = [&](int in_len, int out_len, bool down) {
+        auto& m = down ? down_off : up_off;
+        int& total = down ? n_down : n_up;
+        auto it = m.find({in_len, out_len});
+        if (it != m.end()) return it->second;
+        const int off = total;
+        m[{in_len, out_len}] = off;
+        jobs.push_back(TapJob{in_len, out_len, down ? kTD : kTU, off});
+        total += out_len;
+        return off;
+    };
+    long long plane_px = 0, f_total = 0;
+    int max_ht = 0, max_wt = 0;
+    std::vector<int> xshift(nt);
+    for (int t = 0; t < nt; ++t) {
+        RwTile& T = ht_[t];
+        std::memset(&T, 0, sizeof T);
+        T.r0 = tiles[t].r0;
+        T.c0 = tiles[t].c0;
+        T.ht = tiles[t].ht;
+        T.wt = tiles[t].wt;
+        max_ht = std::max(max_ht, T.ht);
+        max_wt = std::max(max_wt, T.wt);
+        const int maxl = (int)std::floor(std::log2((double)std::min(T.ht, T.wt)));  // multiBandBlending.m:98-109
+        T.nl = std::max(1, std::min(o.pyr_levels, maxl));
+        T.lh[0] = T.ht;
+        T.lw[0] = T.wt;
+        for (int l = 1; l < T.nl; ++l) {
+            T.lh[l] = std::max(1, T.lh[l - 1] / 2);
+            T.lw[l] = std::max(1, T.lw[l - 1] / 2);
+        }
+        for (int l = 0; l + 1 < T.nl; ++l) {
+            T.tdr[l] = tap_table(T.lh[l], T.lh[l + 1], true);
+            T.tdc[l] = tap_table(T.lw[l], T.lw[l + 1], true);
+            T.tur[l] = tap_table(T.lh[l + 1], T.lh[l], false);
+            T.tuc[l] = tap_table(T.lw[l + 1], T.lw[l], false);
+            if (rows_first(T.lh[l], T.lw[l], T.lh[l + 1], T.lw[l + 1])) T.rf_down |= 1 << l;
+            if (rows_first(T.lh[l + 1], T.lw[l + 1], T.lh[l], T.lw[l])) T.rf_up |= 1 << l;
+        }
+        T.plane = plane_px;
+        plane_px += (long long)T.ht * T.wt;
+        for (int l = 1; l < T.nl; ++l) {
+            T.f[l] = f_total;
+            f_total += (long long)T.lh[l] * T.lw[l];
+        }
+        int xs = 0;
+        while ((cdiv(T.wt, 32) >> xs) > 64 || (((cdiv(T.wt, 32) - 1) >> xs) > 63)) ++xs;
+        xshift[t] = xs;
+    }
+    Ws<int> d_status(1), d_xshift(nt);
+    APS_HIP(hipMemsetAsync(d_status, 0, sizeof(int), stream()));
+    APS_HIP(hipMemcpyAsync(d_xshift, xshift.data(), nt * sizeof(int), hipMemcpyHostToDevice, stream()));
+    Ws<int> td_idx((size_t)std::max(n_down, 1) * kTD), tu_idx((size_t)std::max(n_up, 1) * kTU);
+    Ws<float> td_w((size_t)std::max(n_down, 1) * kTD), tu_w((size_t)std::max(n_up, 1) * kTU);
+    Ws<TapJob> d_jobs(std::max<size_t>(jobs.size(), 1));
+    if (!jobs.empty()) {
+        APS_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(TapJob), hipMemcpyHostToDevice, stream()));
+        int longest = 1;
+        for (const TapJob& j : jobs) longest = std::max(longest, j.out_len);
+        rw_taps_kernel<<<dim3(cdiv(longest, 256), (unsigned)jobs.size()), 256, 0, stream()>>>(d_jobs, td_idx, td_w, tu_idx, tu_w,
+                                                                                              d_status);
+        check_launch("rw_taps_kernel");
+    }
+    Ws<RwTile> d_tiles(nt);
+    APS_HIP(hipMemcpyAsync(d_tiles, ht_.data(), nt * sizeof(RwTile), hipMemcpyHostToDevice, stream()));
+    Ws<uint8_t> d_cov((size_t)plane_px);
+    APS_HIP(hipMemsetAsync(d_cov, 0, (size_t)plane_px, stream()));  // tiles without layers stay uncovered
+
+    RwArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.tiles = d_tiles;
+    A.n_tiles = nt;
+    A.imgs = dimgs;
+    A.cv = cv;
+    A.angle_pow = o.angle_power;
+    A.tp = tp;
+    A.td_idx = td_idx;
+    A.td_w = td_w;
+    A.tu_idx = tu_idx;
+    A.tu_w = tu_w;
+    A.cov = d_cov;
+    A.status = d_status;
+    A.pano = pano;
+    A.covered = covered;
+    A.H = cv.H;
+    A.W = cv.W;
+    A.out_layout = out_layout;
+    A.white = o.canvas_white;
+
+    // ---- pass 1: coverage + weight sums, one read-back of the footprints -------------------------------------
+    const int nby_max = cdiv(max_ht, 8);
+    Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
+    Ws<int> d_bbox((size_t)nt * n_img * 4);
+    std::vector<int> hbox((size_t)nt * n_img * 4);
+    APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
+    {
+        Prof prof("cover");
+        rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
+        rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
+                                                                                nt * n_img, d_bbox);
+    }
+    check_launch("rw_cover_kernel");
+    APS_HIP(hipMemcpyAsync(hbox.data(), d_bbox, hbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+
+    // ---- entries, compact stores, block tables ----------------------------------------------------------------
+    std::vector<RwEntry> ents;
+    long long g_total = 0;
+    int max_nl = 1;
+    for (int t = 0; t < nt; ++t) {
+        RwTile& T = ht_[t];
+        T.e0 = (int)ents.size();
+        max_nl = std::max(max_nl, T.nl);
+        for (int i = 0; i < n_img; ++i) {
+            const int* b = &hbox[((size_t)t * n_img + i) * 4];
+            if (!(b[2] > b[0] && b[3] > b[1])) continue;
+            RwEntry E;
+            std::memset(&E, 0, sizeof E);
+            E.tile = t;
+            E.img = i;
+            E.g[0] = clip_rect(Rect{b[0], b[1], b[2], b[3]}, T.wt, T.ht);
+            for (int l = 0; l + 1 < T.nl; ++l) {
+                const Rect g = E.g[l];
+                const bool empty = g.x1 <= g.x0;
+                const Rect br = empty ? g : clip_rect(Rect{g.x0 - tp.r, g.y0 - tp.r, g.x1 + tp.r, g.y1 + tp.r}, T.lw[l], T.lh[l]);
+                E.g[l + 1] = empty ? g : map_rect(br, T.lh[l], T.lw[l], T.lh[l + 1], T.lw[l + 1]);
+            }
+            for (int l = 0; l < T.nl; ++l) {
+                E.off[l] = g_total;
+                g_total += (long long)(E.g[l].x1 - E.g[l].x0) * (E.g[l].y1 - E.g[l].y0);
+            }
+            ents.push_back(E);
+        }
+        T.ne = (int)ents.size() - T.e0;
+    }
+    const int ne = (int)ents.size();
+    if (std::getenv("APS_RENDER_DEBUG")) {
+        long long rect0 = 0, canvas = 0;
+        for (const RwEntry& E : ents) rect0 += (long long)(E.g[0].x1 - E.g[0].x0) * (E.g[0].y1 - E.g[0].y0);
+        for (const RwTile& T : ht_) canvas += (long long)T.ht * T.wt;
+        std::fprintf(stderr, "[aps render] tiles %d entries %d (%.2f per tile) footprint rect area %.1f MPix canvas %.1f MPix G store %.2f GB\n",
+                     nt, ne, (double)ne / nt, rect0 / 1e6, canvas / 1e6, g_total * 16.0 / 1e9);
+    }
+    // block tables: levels 0 .. max_nl-2 of the shrink over entries, levels 0 .. max_nl-1 of the collapse over tiles
+    std::vector<int> blk((size_t)(max_nl) * (ne + 1) + (size_t)max_nl * (nt + 1), 0);
+    std::vector<int> down_blocks(max_nl, 0), up_blocks(max_nl, 0);
+    // the warp: blocks over the level-0 grid of every tile with layers
+    std::vector<int> blk0(nt + 1, 0);
+    int warp_blocks = 0;
+    {
+        long long run = 0;
+        for (int t = 0; t < nt; ++t) {
+            blk0[t] = (int)run;
+            const RwTile& T = ht_[t];
+            if (T.ne > 0) run += (long long)cdiv(T.wt, kUW) * cdiv(T.ht, kUH);
+        }
+        APS_REQUIRE(run < (1ll << 30), APS_E_DIM, "too many canvas blocks in one render call (%lld)", run);
+        blk0[nt] = (int)run;
+        warp_blocks = (int)run;
+    }
+    for (int l = 0; l + 1 < max_nl; ++l) {
+        int* p = &blk[(size_t)l * (ne + 1)];
+        long long run = 0;
+        for (int e = 0; e < ne; ++e) {
+            p[e] = (int)run;
+            const RwEntry& E = ents[e];
+            if (l + 1 < ht_[E.tile].nl) {
+                const Rect& g = E.g[l + 1];
+                run += (long long)cdiv(std::max(g.x1 - g.x0, 0), kBW) * cdiv(std::max(g.y1 - g.y0, 0), kBH);
+            }
+        }
+        APS_REQUIRE(run < (1ll << 30), APS_E_DIM, "too many pyramid blocks in one render call (%lld)", run);
+        p[ne] = (int)run;
+        down_blocks[l] = (int)run;
+    }
+    const size_t up_base = (size_t)max_nl * (ne + 1);
+    for (int l = 0; l < max_nl; ++l) {
+        int* p = &blk[up_base + (size_t)l * (nt + 1)];
+        long long run = 0;
+        for (int t = 0; t < nt; ++t) {
+            p[t] = (int)run;
+            const RwTile& T = ht_[t];
+            // level 0 always paints; the upper levels exist only for tiles with layers
+            if (l < T.nl && (l == 0 || T.ne > 0)) run += (long long)cdiv(T.lw[l], kUW) * cdiv(T.lh[l], kUH);
+        }
+        APS_REQUIRE(run < (1ll << 30), APS_E_DIM, "too many canvas blocks in one render call (%lld)", run);
+        p[nt] = (int)run;
+        up_blocks[l] = (int)run;
+    }
+    Ws<RwEntry> d_ents(std::max(ne, 1));
+    Ws<int> d_blk(blk.size()), d_blk0(blk0.size());
+    APS_HIP(hipMemcpyAsync(d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    Ws<float4> d_G((size_t)std::max<long long>(g_total, 1)), d_F((size_t)std::max<long long>(f_total, 1));
+    if (ne) APS_HIP(hipMemcpyAsync(d_ents, ents.data(), ne * sizeof(RwEntry), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_tiles, ht_.data(), nt * sizeof(RwTile), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    A.entries = d_ents;
+    A.n_entries = ne;
+    A.G = d_G;
+    A.F = d_F;
+
+    // ---- pass 2: pyramids, fine to coarse ------------------------------------------------------------------------
+    {
+        Prof prof("multiband");
+        if (warp_blocks) {
+            Prof pw("warp_layer");
+            rw_warp_kernel<<<8u * (unsigned)((warp_blocks + 7) / 8), 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+            check_launch("rw_warp_kernel");
+        }
+        for (int l = 0; l + 1 < max_nl; ++l) {
+            if (down_blocks[l] == 0) continue;
+            launch_down(tp.r, A, l, d_blk.get() + (size_t)l * (ne + 1), down_blocks[l]);
+            check_launch("rw_down_kernel");
+        }
+        // ---- pass 3: Laplacian sums + collapse, coarse to fine; level 0 paints ----------------------------------
+        for (int l = max_nl - 1; l >= 0; --l) {
+            if (up_blocks[l] == 0) continue;
+            const int* bp = d_blk.get() + up_base + (size_t)l * (nt + 1);
+            const unsigned grid = 8u * (unsigned)((up_blocks[l] + 7) / 8);
+            if (l == 0)
+                rw_up_kernel<true><<<grid, 256, 0, stream()>>>(A, l, bp, up_blocks[l]);
+            else
+                rw_up_kernel<false><<<grid, 256, 0, stream()>>>(A, l, bp, up_blocks[l]);
+            check_launch("rw_up_kernel");
+        }
+    }
+    int status = 0;
+    APS_HIP(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));  // also keeps the host tables alive until their uploads have run
+    APS_REQUIRE(status == 0, APS_E_INTERNAL, "batched render: tap table assumption violated (status %d)", status);
+    return true;
+}
+
+}  // namespace aps

@@ -370,3 +370,45 @@ def test_resize_images_to_limits_modes(ip):
     assert all(c.shape == (80, 100, 3) for c in crop)
     with pytest.raises(ValueError):
         ip.resizeImagesToLimits(imgs, 80, 100, "stretch")
+
+
+@pytest.mark.parametrize("mode,levels,tile,sigma,white", [
+    ("spherical", 5, (72, 104), 1.0, False), ("cylindrical", 3, (64, 96), 1.0, True),
+    ("planar", 4, (100, 130), 1.5, False), ("stereographic", 5, (61, 77), 1.0, False),
+    ("spherical", 1, (64, 64), 1.0, False), ("spherical", 6, (33, 47), 0.8, False),
+    ("spherical", 5, (512, 512), 1.0, False)])
+def test_batched_multiband_equals_per_tile_path(rp, monkeypatch, mode, levels, tile, sigma, white):
+    """render_batch.hip (all tiles level-major, warp fused into level 0, table-driven resize taps, compact
+    footprint stores) against render.hip's per-tile kernels (APS_RENDER_LEGACY=1): every byte of the panorama and
+    of the coverage must agree - odd tile sizes (non-half pyramid levels), partial edge tiles, tiles whose level
+    count is clamped, tiles without any layer, gains, white canvas."""
+    rng = np.random.default_rng(21)
+    imgs, cams = _scene(rng, n=6, W=220, H=140, f=300.0)
+    sizes = [(140, 220, 3)] * 6
+    gains = [(1.0, 1.0, 1.0), (0.9, 1.1, 1.0), (1.2, 0.8, 1.0), (1.0, 1.0, 0.7), (1.05, 1.0, 0.95), (1, 1, 1)]
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": levels, "pyrSigma": sigma, "tile": tile,
+            "cropBorder": False, "canvasColor": "white" if white else "black", "margin": 0.08}
+    monkeypatch.delenv("APS_RENDER_LEGACY", raising=False)
+    pano, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
+    monkeypatch.setenv("APS_RENDER_LEGACY", "1")
+    ref, _, rcov, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
+    assert cov.sum() > 20000 and (cov == 0).sum() > 100
+    assert np.array_equal(cov, rcov)
+    assert np.array_equal(pano, ref)
+
+
+def test_batched_multiband_tile_subsets_compose(rp, monkeypatch):
+    """aps_render_tiles(first, step) on the batched path: the shards of two 'ranks' paint disjoint tiles whose
+    union is the one-call panorama."""
+    rng = np.random.default_rng(22)
+    imgs, cams = _scene(rng, n=5, W=220, H=140, f=300.0)
+    sizes = [(140, 220, 3)] * 5
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 4, "pyrSigma": 1.0, "tile": (64, 80),
+            "cropBorder": False}
+    monkeypatch.delenv("APS_RENDER_LEGACY", raising=False)
+    full, _, cov, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, return_covered=True)
+    parts = [rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, return_covered=True, tile_subset=(k, 2))
+             for k in range(2)]
+    assert np.array_equal(np.maximum(parts[0][0], parts[1][0]), full)
+    assert np.array_equal(np.maximum(parts[0][2], parts[1][2]), cov)
+    assert not np.any((parts[0][2] == 1) & (parts[1][2] == 1))
