@@ -24,24 +24,6 @@ namespace aps {
 
 
 // ------------------------------------------------------------------------------------------------
-// image conversion
-// ------------------------------------------------------------------------------------------------
-__global__ void to_rgba_kernel(const uint8_t* __restrict__ src, int h, int w, int c, int layout,
-                               uint32_t* __restrict__ dst) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= w) return;
-    uint32_t ch[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int kk = c == 1 ? 0 : k;
-        ch[k] = layout == APS_IMG_U8_HWC ? src[((size_t)y * w + x) * c + kk]
-                                         : src[(size_t)kk * h * w + (size_t)x * h + y];
-    }
-    dst[(size_t)y * w + x] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
-}
-
-// ------------------------------------------------------------------------------------------------
 // coverage prepass: which images touch which tile (exact: the same predicate as the sampler)
 // ------------------------------------------------------------------------------------------------
 // Coverage pre-pass of one tile.  Each 32 x 8-pixel block records, per image, whether any of its pixels maps
@@ -542,23 +524,6 @@ __global__ void image_warp_h_kernel(const T* __restrict__ in, int in_h, int in_w
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
-static void host_tent(int n, std::vector<float>& w) {  // warpWeights (:1282-1312)
-    w.assign(n, 1.0f);
-    const int a = (n + 1) / 2;
-    for (int k = 0; k < a; ++k) {
-        double v = a > 1 ? 0.0 + ((double)k * 1.0) / (double)(a - 1) : 1.0;
-        if (k == a - 1) v = 1.0;
-        w[k] = (float)v;
-    }
-    const int b0 = n / 2, nb = n - n / 2;
-    for (int k = 0; k < nb; ++k) {
-        double v = nb > 1 ? 1.0 + ((double)k * -1.0) / (double)(nb - 1) : 0.0;
-        if (k == 0 && nb > 1) v = 1.0;
-        if (k == nb - 1) v = 0.0;
-        w[b0 + k] = (float)v;
-    }
-}
-
 // imresize(in,[oh ow],'bilinear') on float4 images; dimension with the smaller scale first
 static void imresize4(const float4* in, int h, int w, int oh, int ow, float4* out, Ws<float4>& tmp) {
     const double sr = (double)oh / h, sc = (double)ow / w;
@@ -977,22 +942,90 @@ static void multiband_device(const std::vector<float4*>& layers, const Rect* rec
     // no synchronisation: all buffers are stream-ordered workspace of this thread's stream
 }
 
-struct PreparedImages {
-    std::vector<Ws<uint32_t>> rgba;
-    std::vector<Ws<float>> wx, wy;
-    std::vector<In<uint8_t>> src;
-    std::vector<DevImage> host;
-    std::vector<std::vector<float>> tents;  // host tent tables, alive until their uploads have run
-    Ws<DevImage> dev;
+struct ImgJob {
+    const uint8_t* src;
+    uint32_t* dst;
+    float* wx;
+    float* wy;
+    int h, w, c, layout;
 };
 
+// RGBA8 conversion of ALL images in one launch (blockIdx.y = image).  Interleaved RGB with a 4-byte aligned base is
+// read as three dwords per four pixels and written as one 16-byte store; everything else goes pixel by pixel.
+__global__ __launch_bounds__(256) void to_rgba_batch_kernel(const ImgJob* __restrict__ jobs) {
+    const ImgJob j = jobs[blockIdx.y];
+    const size_t npx = (size_t)j.h * j.w;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j.layout == APS_IMG_U8_HWC && j.c == 3 && (reinterpret_cast<uintptr_t>(j.src) & 3u) == 0) {
+        const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(j.src);
+        const size_t nq = npx / 4;
+        for (size_t q = t0; q < nq; q += stride) {
+            const uint32_t a = s32[3 * q], b = s32[3 * q + 1], c = s32[3 * q + 2];
+            uint4 o;
+            o.x = (a & 0x00ffffffu) | 0xff000000u;
+            o.y = ((a >> 24) | (b << 8)) & 0x00ffffffu;
+            o.y |= 0xff000000u;
+            o.z = ((b >> 16) | (c << 16)) & 0x00ffffffu;
+            o.z |= 0xff000000u;
+            o.w = (c >> 8) | 0xff000000u;
+            reinterpret_cast<uint4*>(j.dst)[q] = o;
+        }
+        for (size_t p = nq * 4 + t0; p < npx; p += stride)
+            j.dst[p] = (uint32_t)j.src[3 * p] | ((uint32_t)j.src[3 * p + 1] << 8) | ((uint32_t)j.src[3 * p + 2] << 16) | 0xff000000u;
+        return;
+    }
+    for (size_t p = t0; p < npx; p += stride) {
+        const int y = (int)(p / (size_t)j.w), x = (int)(p - (size_t)y * j.w);
+        uint32_t ch[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kk = j.c == 1 ? 0 : k;
+            ch[k] = j.layout == APS_IMG_U8_HWC ? j.src[p * j.c + kk] : j.src[(size_t)kk * npx + (size_t)x * j.h + y];
+        }
+        j.dst[p] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
+    }
+}
+
+// warpWeights (renderPanorama.m:1282-1312): wx(1:ceil(w/2)) = linspace(0,1,.), wx(floor(w/2)+1:w) = linspace(1,0,.)
+// (the second assignment wins where they overlap), evaluated in f64 and cast; blockIdx.y = 2*image + (0: wx, 1: wy)
+__device__ __forceinline__ float tent_value(int n, int k) {
+    const int a = (n + 1) / 2, b0 = n / 2, nb = n - n / 2;
+    if (k >= b0) {
+        const int q = k - b0;
+        double v = nb > 1 ? 1.0 + ((double)q * -1.0) / (double)(nb - 1) : 0.0;
+        if (q == 0 && nb > 1) v = 1.0;
+        if (q == nb - 1) v = 0.0;
+        return (float)v;
+    }
+    double v = a > 1 ? 0.0 + ((double)k * 1.0) / (double)(a - 1) : 1.0;
+    if (k == a - 1) v = 1.0;
+    return (float)v;
+}
+__global__ void tent_batch_kernel(const ImgJob* __restrict__ jobs) {
+    const ImgJob j = jobs[blockIdx.y >> 1];
+    const int n = (blockIdx.y & 1) ? j.h : j.w;
+    float* __restrict__ out = (blockIdx.y & 1) ? j.wy : j.wx;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = tent_value(n, k);
+}
+
+struct PreparedImages {
+    Ws<uint32_t> rgba;  // all images back to back (each 16-byte aligned)
+    Ws<float> tent;     // wx, wy of every image back to back
+    std::vector<In<uint8_t>> src;
+    std::vector<DevImage> host;
+    std::vector<ImgJob> jobs;
+    Ws<DevImage> dev;
+    Ws<ImgJob> djobs;
+};
+
+// No synchronisation here: the host tables are members of P and outlive the stream work of the calling entry point.
 static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
-    P.rgba.resize(n);
-    P.wx.resize(n);
-    P.wy.resize(n);
     P.src.resize(n);
     P.host.resize(n);
-    P.tents.resize(2 * (size_t)n);
+    P.jobs.resize(n);
+    size_t px_total = 0, tent_total = 0;
+    int max_len = 1;
     for (int i = 0; i < n; ++i) {
         const aps_image& im = images[i];
         APS_REQUIRE(im.data != nullptr, APS_E_ARG, "image %d: NULL data", i);
@@ -1000,24 +1033,25 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
         APS_REQUIRE(im.channels == 1 || im.channels == 3, APS_E_DIM, "image %d: channels must be 1 or 3", i);
         APS_REQUIRE(im.layout == APS_IMG_U8_HWC || im.layout == APS_IMG_U8_MATLAB, APS_E_TYPE,
                     "image %d: unknown layout", i);
+        px_total += ((size_t)im.height * im.width + 3) & ~size_t(3);
+        tent_total += (size_t)im.height + im.width;
+        max_len = std::max(max_len, std::max(im.height, im.width));
+    }
+    P.rgba.alloc(px_total);
+    P.tent.alloc(tent_total);
+    size_t po = 0, to = 0;
+    for (int i = 0; i < n; ++i) {
+        const aps_image& im = images[i];
         const size_t px = (size_t)im.height * im.width;
         P.src[i].bind(im.data, px * im.channels);
-        P.rgba[i].alloc(px);
-        to_rgba_kernel<<<dim3(cdiv(im.width, 256), im.height), 256, 0, stream()>>>(
-            P.src[i], im.height, im.width, im.channels, im.layout, P.rgba[i]);
-        check_launch("to_rgba_kernel");
-        std::vector<float>& tx = P.tents[2 * i];
-        std::vector<float>& ty = P.tents[2 * i + 1];
-        host_tent(im.width, tx);
-        host_tent(im.height, ty);
-        P.wx[i].alloc(im.width);
-        P.wy[i].alloc(im.height);
-        APS_HIP(hipMemcpyAsync(P.wx[i], tx.data(), tx.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
-        APS_HIP(hipMemcpyAsync(P.wy[i], ty.data(), ty.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
         DevImage& d = P.host[i];
-        d.rgba = P.rgba[i];
-        d.wx = P.wx[i];
-        d.wy = P.wy[i];
+        d.rgba = P.rgba.get() + po;
+        d.wx = P.tent.get() + to;
+        d.wy = P.tent.get() + to + im.width;
+        P.jobs[i] = ImgJob{P.src[i].get(), P.rgba.get() + po, P.tent.get() + to, P.tent.get() + to + im.width,
+                           im.height, im.width, im.channels, im.layout};
+        po += (px + 3) & ~size_t(3);
+        to += (size_t)im.height + im.width;
         d.h = im.height;
         d.w = im.width;
         for (int e = 0; e < 9; ++e) d.R[e] = (float)im.R[e];
@@ -1034,8 +1068,12 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
         }
     }
     P.dev.alloc(n);
+    P.djobs.alloc(n);
     APS_HIP(hipMemcpyAsync(P.dev, P.host.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, stream()));
-    APS_HIP(hipStreamSynchronize(stream()));
+    APS_HIP(hipMemcpyAsync(P.djobs, P.jobs.data(), n * sizeof(ImgJob), hipMemcpyHostToDevice, stream()));
+    to_rgba_batch_kernel<<<dim3(512, n), 256, 0, stream()>>>(P.djobs);
+    tent_batch_kernel<<<dim3(cdiv(max_len, 256), 2 * n), 256, 0, stream()>>>(P.djobs);
+    check_launch("to_rgba_batch_kernel");
 }
 
 static DevCanvas make_canvas(const aps_canvas& c) {

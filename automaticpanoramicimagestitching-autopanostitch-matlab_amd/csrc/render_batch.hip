@@ -910,7 +910,7 @@ bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas&
     std::vector<int> hbox((size_t)nt * n_img * 4);
     APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
     {
-        Prof prof("cover");
+        Prof prof("render_cover");
         rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
         rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
                                                                                 nt * n_img, d_bbox);
@@ -1016,19 +1016,22 @@ bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas&
     A.F = d_F;
 
     // ---- pass 2: pyramids, fine to coarse ------------------------------------------------------------------------
+    if (warp_blocks) {
+        Prof prof("render_warp");
+        rw_warp_kernel<<<8u * (unsigned)((warp_blocks + 7) / 8), 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        check_launch("rw_warp_kernel");
+    }
     {
-        Prof prof("multiband");
-        if (warp_blocks) {
-            Prof pw("warp_layer");
-            rw_warp_kernel<<<8u * (unsigned)((warp_blocks + 7) / 8), 256, 0, stream()>>>(A, d_blk0, warp_blocks);
-            check_launch("rw_warp_kernel");
-        }
+        Prof prof("render_pyr_down");
         for (int l = 0; l + 1 < max_nl; ++l) {
             if (down_blocks[l] == 0) continue;
             launch_down(tp.r, A, l, d_blk.get() + (size_t)l * (ne + 1), down_blocks[l]);
             check_launch("rw_down_kernel");
         }
-        // ---- pass 3: Laplacian sums + collapse, coarse to fine; level 0 paints ----------------------------------
+    }
+    {
+        // Laplacian sums + collapse, coarse to fine; level 0 paints
+        Prof prof("render_collapse");
         for (int l = max_nl - 1; l >= 0; --l) {
             if (up_blocks[l] == 0) continue;
             const int* bp = d_blk.get() + up_base + (size_t)l * (nt + 1);
