@@ -1,18 +1,21 @@
 """Multi-GPU sharding of the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL over
-xGMI on ROCm; "gloo" on CPU for the tests).
+xGMI on ROCm; "gloo" on CPU for the tests, and on device tensors through host staging - see _staged()).
 
 What shards how:
   1. SIFT            : images are independent (loadImages.m:82-99) -> image i on rank i % world.
   2. exchange        : ONE all-gather of the descriptor blocks (+ a small one for keypoint coordinates and
                        counts) so every rank holds all F x 128 descriptors.
   3. match           : the pair list of featureMatchingPairwise.m:48 is partitioned over ranks, balanced by
-                       N_i * N_j; match lists are all-gathered (a few MB).
+                       N_i * N_j; the match index lists are all-gathered on the device (a few MB) and stay there.
   4. RANSAC          : candidate pairs (imageMatching.m:121) round-robin over ranks; draws are keyed by the
-                       global pair index so the result does not depend on the sharding.
-  5. host segment    : every rank repeats the tiny deterministic graph/camera step (no broadcast needed).
-  6. render          : source images are all-gathered once (uint8), panorama tiles (independent in the
-                       reference, renderPanorama.m:342-406) go to rank t % world, and the canvas is combined
-                       with one all-reduce(MAX) over disjoint tiles.
+                       global pair index so the result does not depend on the sharding; the fixed-size verdicts
+                       (model, found, inlier count) are combined with one all-reduce.
+  5. host segment    : every rank repeats the tiny deterministic graph/camera step (no broadcast needed):
+                       connected components, one camera set + reference per component (recognizePanoramas.m).
+  6. render          : source images are all-gathered once (uint8, started before SIFT); EVERY connected component
+                       is rendered (displayPanorama.m:88-116): components first (whole panoramas to ranks, balanced
+                       by canvas area, when there are at least as many as ranks), tiles second (tiles t % world of
+                       one canvas, renderPanorama.m:342-406, when there are fewer).
 There is no other collective on the data path.
 """
 from __future__ import annotations
@@ -29,6 +32,53 @@ def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(), dist.get_rank()
     return 1, 0
+
+
+def _staged(t=None):
+    """gloo moves host memory: collectives on device tensors are staged through the host (used by the 2-rank
+    equality test, which runs both ranks on one GPU; production is "nccl" = RCCL, device to device)."""
+    return dist.get_backend() == "gloo" and (t is None or t.is_cuda)
+
+
+def _all_gather_into(out, inp, async_op=False):
+    if _staged(inp):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, inp.cpu())
+        out.copy_(ho)
+        return None
+    return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+
+
+def _all_reduce(t, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def _broadcast(t, src):
+    if _staged(t):
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+    return t
+
+
+def _gather(t, parts, dst):
+    if _staged(t):
+        hp = [torch.empty(t.shape, dtype=t.dtype) for _ in parts] if parts is not None else None
+        dist.gather(t.cpu(), hp, dst=dst)
+        if parts is not None:
+            for a, b in zip(parts, hp):
+                a.copy_(b)
+    else:
+        dist.gather(t, parts, dst=dst)
 
 
 def shard_indices(n, world_size, rank):
@@ -55,14 +105,14 @@ def allgather_ragged(local, group=None):
     if ws == 1:
         return [local]
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(ws)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    cnt_all = torch.zeros(ws, dtype=torch.int64, device=local.device)
+    _all_gather_into(cnt_all, n_local)
+    counts = [int(c) for c in cnt_all.cpu().tolist()]
     m = max(max(counts), 1)
     pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((ws * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    _all_gather_into(out, pad)
     out = out.view((ws, m) + tuple(local.shape[1:]))
     return [out[r, : counts[r]] for r in range(ws)]
 
@@ -79,7 +129,7 @@ def gather_by_owner(local_items, owner_of, n, make_tensor, split_sizes_local):
     dev = make_tensor.device
     lens = lens.to(dev)
     if ws > 1:
-        dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+        _all_reduce(lens)
     lens = lens.cpu().tolist()
     cat = torch.cat([local_items[i] for i in mine]) if mine else make_tensor[:0]
     parts = allgather_ragged(cat)
@@ -107,7 +157,7 @@ def exchange_items(local_ids, local_arrays, n_items, owner_of, width, dtype, dev
     for i, a in zip(local_ids, local_arrays):
         lens[i] = a.shape[0]
     lens = lens.to(dev)
-    dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+    _all_reduce(lens)
     lens = lens.cpu().numpy()
     order = np.argsort(np.asarray(local_ids, np.int64), kind="stable") if len(local_ids) else np.zeros(0, np.int64)
     cat = (np.concatenate([local_arrays[k].reshape(-1, width) for k in order]) if len(order)
@@ -126,31 +176,44 @@ def exchange_items(local_ids, local_arrays, n_items, owner_of, width, dtype, dev
 class ImageGather:
     """The all-gather of the uint8 source images, started early and collected late: the images exist before
     anything is computed, the render needs them at the very end, and the ~1.6 GB (64 x 4K) it moves over xGMI
-    would otherwise sit on the critical path between RANSAC and render.  Equal-size images; rank r owns i % world."""
+    would otherwise sit on the critical path between RANSAC and render.  Rank r owns the images i % world == r;
+    sizes may differ and a rank may own none (n < world): a small all-reduce of the shapes comes first."""
 
-    def __init__(self, local_images, n):
+    def __init__(self, local_images, n, dev=None):
         self.ws, self.rank = world()
         self.n = n
         self.local = local_images
         self.work = None
         if self.ws == 1:
             return
-        first = next(iter(local_images.values()))
-        self.shape = tuple(first.shape)
+        if dev is None:
+            dev = next(iter(local_images.values())).device if local_images else torch.device("cuda")
+        shp = torch.zeros((n, 3), dtype=torch.int64, device=dev)
+        for i, im_ in local_images.items():
+            shp[i] = torch.tensor([int(im_.shape[0]), int(im_.shape[1]), int(im_.shape[2]) if im_.dim() == 3 else 1],
+                                  dtype=torch.int64, device=dev)
+        _all_reduce(shp)
+        self.shapes = [tuple(int(v) for v in row) for row in shp.cpu().tolist()]
         per = (n + self.ws - 1) // self.ws  # slots per rank (the last ones may stay empty)
-        flat = first.numel()
-        self.send = torch.zeros((per, flat), dtype=torch.uint8, device=first.device)
+        flat = max(max(h * w * c for (h, w, c) in self.shapes), 1)
+        self.send = torch.zeros((per, flat), dtype=torch.uint8, device=dev)
         for slot, i in enumerate(sorted(local_images)):
-            self.send[slot] = local_images[i].reshape(-1)
-        self.recv = torch.empty((self.ws * per, flat), dtype=torch.uint8, device=first.device)
+            v = local_images[i].reshape(-1)
+            self.send[slot, : v.numel()] = v
+        self.recv = torch.empty((self.ws * per, flat), dtype=torch.uint8, device=dev)
         self.per = per
-        self.work = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+        self.work = _all_gather_into(self.recv, self.send, async_op=True)
 
     def wait(self):
         if self.ws == 1:
             return [self.local[i] for i in range(self.n)]
-        self.work.wait()
-        return [self.recv[(i % self.ws) * self.per + i // self.ws].reshape(self.shape) for i in range(self.n)]
+        if self.work is not None:
+            self.work.wait()
+        out = []
+        for i in range(self.n):
+            h, w, c = self.shapes[i]
+            out.append(self.recv[(i % self.ws) * self.per + i // self.ws, : h * w * c].reshape(h, w, c))
+        return out
 
 
 def tile_rects(H, W, tile):
@@ -179,7 +242,7 @@ def gather_tiles_to_root(pano, tile, root=0):
             buf[off:off + m] = pano[r0:r0 + ht, c0:c0 + wt].reshape(-1)
             off += m
     parts = [torch.empty_like(buf) for _ in range(ws)] if rank == root else None
-    dist.gather(buf, parts, dst=root)
+    _gather(buf, parts, root)
     if rank == root:
         for r in range(ws):
             if r == root:
@@ -193,35 +256,26 @@ def gather_tiles_to_root(pano, tile, root=0):
     return pano
 
 
-def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None):
-    """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
-    local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
-    pano_root: None = the panorama is combined on every rank (all-reduce); r = only rank r receives the tiles of
-    the others (cheaper; the other ranks return their own tiles only).
-    Returns (panorama uint8 H x W x 3 CUDA tensor; info dict)."""
-    from . import _capi
+def _match_pass(input, local_images, n, seed, times, dev):
+    """Steps 1-4 on the current images: SIFT on the local shard, the descriptor exchange, the sharded pair matching
+    and the sharded RANSAC verification (main.m:88-107 up to imageMatching).  Everything that is exchanged stays on
+    the device; the host sees counts, candidate lists and the 3 x 3 models.
+    Returns dict(counts, kps_t, pairs, models, num_matches, n_match, order)."""
     from . import featureMatching as fm
     from . import imageMatching as im
     from . import pipeline as pl
-    from . import renderPanorama as rp
 
     ws, rank = world()
-    dev = next(iter(local_images.values())).device if local_images else torch.device("cuda")
-    times = pl.StageTimes()
     owner = lambda i: i % ws  # noqa: E731
-
-    # 0) the render will need every source image everywhere: start that all-gather now, collect it at step 6
-    t0 = time.perf_counter()
-    img_gather = ImageGather(local_images, n)
-    times.add("exchange", t0)
 
     # 1) SIFT on the local shard
     t0 = time.perf_counter()
-    ldesc, lkps, lkps_host = {}, {}, {}
-    for i, (d, p) in zip(sorted(local_images), pl.sift_many(input, [local_images[i] for i in sorted(local_images)])):
-        ldesc[i] = d
-        lkps_host[i] = p
-        lkps[i] = torch.from_numpy(p).to(dev)
+    ldesc, lkps = {}, {}
+    mine_img = sorted(local_images)
+    if mine_img:
+        for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img])):
+            ldesc[i] = d
+            lkps[i] = torch.from_numpy(p).to(dev)
     times.add("features", t0)
 
     # 2) the exchange: descriptors (one all-gather), keypoints (small)
@@ -231,33 +285,44 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
         descs = [d.contiguous() for d in descs]
         torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
-        kps = [k.cpu().numpy() for k in kps_t]
     else:
         descs = [ldesc[i] for i in range(n)]
         kps_t = [lkps[i] for i in range(n)]
-        kps = [lkps_host[i] for i in range(n)]  # the host copies SIFT returned: no read-back
     counts = [int(d.shape[0]) for d in descs]
     times.add("exchange", t0)
 
-    # 3) match: pair list partitioned by N_i * N_j
+    # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
     t0 = time.perf_counter()
     order = fm.pair_order(n)
     w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
+    host_lists = bool(os.environ.get("APS_PARALLEL_HOST_LISTS"))  # A/B switch: lists through the host (round-1 path)
     pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
     my = [p for p in range(len(order)) if pown[p] == rank]
-    # one rank: the match lists never leave the device (no exchange, no host index arithmetic); APS_PARALLEL_HOST_LISTS=1
-    # forces the multi-rank code path (host lists) for A/B tests
-    resident = ws == 1 and not os.environ.get("APS_PARALLEL_HOST_LISTS")
-    if resident:
-        pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
-                                               input["Matchingthreshold"], True, device_out=True)
-        n_match = np.diff(pp)  # my == every pair, in `order`
+    pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
+                                           input["Matchingthreshold"], True, device_out=not host_lists)
+    if host_lists:
+        ia_d = torch.from_numpy(ia_d.astype(np.int32)).to(dev)
+        ib_d = torch.from_numpy(ib_d.astype(np.int32)).to(dev)
+    n_match = np.zeros(len(order), np.int64)
+    n_match[my] = np.diff(pp)
+    if ws > 1:
+        nm = torch.from_numpy(n_match).to(dev)
+        _all_reduce(nm)
+        n_match = nm.cpu().numpy()
+        _sync_lib()
+        parts = allgather_ragged(torch.stack([ia_d, ib_d], 1).contiguous())
+        base = np.concatenate([[0], np.cumsum([int(p_.shape[0]) for p_ in parts])])
+        allidx = torch.cat(parts)
+        ia_d, ib_d = allidx[:, 0], allidx[:, 1]
+        # start of pair p in the concatenated lists: rank base + the lengths of that rank's earlier pairs
+        gpos = np.zeros(len(order), np.int64)
+        run = base[:-1].astype(np.int64).copy()
+        for p in range(len(order)):
+            r = int(pown[p])
+            gpos[p] = run[r]
+            run[r] += n_match[p]
     else:
-        pp, ia, ib, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"], input["Matchingthreshold"], True)
-        mine_m = [np.stack([ia[int(pp[k]):int(pp[k + 1])], ib[int(pp[k]):int(pp[k + 1])]], 1).astype(np.int64)
-                  for k in range(len(my))]
-        allm = exchange_items(my, mine_m, len(order), lambda p: int(pown[p]), 2, np.int64, dev)
-        n_match = np.array([len(m) for m in allm], np.int64)
+        gpos = pp[:-1].astype(np.int64)
     times.add("matching", t0)
 
     # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
@@ -277,7 +342,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     times.add("im_select", t0)
     t0 = time.perf_counter()
     n_samples = int(input["maxIter"]) + 64
-    recs = []
+    rec = torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev)  # model (9), found, inliers
     if mine:
         cnts = [int(n_match[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
@@ -285,22 +350,15 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         # fancy-index of ~1e6 rows costs tens of milliseconds)
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         kp_all = torch.cat([k.to(dev) for k in kps_t]).to(torch.float64)
-        if resident:
-            # segment p of the CSR lists -> rows of the concatenated keypoint table, all on the device
-            cnt_t = torch.tensor(cnts, dtype=torch.int64, device=dev)
-            seg0 = torch.tensor([int(pp[p]) for p in mine], dtype=torch.int64, device=dev)
-            pos = torch.arange(int(wptr[-1]), dtype=torch.int64, device=dev) + \
-                torch.repeat_interleave(seg0 - torch.from_numpy(wptr[:-1]).to(dev), cnt_t)
-            off_i = torch.repeat_interleave(torch.from_numpy(offs[[order[p][0] for p in mine]]).to(dev), cnt_t)
-            off_j = torch.repeat_interleave(torch.from_numpy(offs[[order[p][1] for p in mine]]).to(dev), cnt_t)
-            row_i = off_i + ia_d.index_select(0, pos).to(torch.int64) - 1
-            row_j = off_j + ib_d.index_select(0, pos).to(torch.int64) - 1
-        else:
-            cat = np.concatenate([allm[p] for p in mine])
-            img_i = np.repeat(offs[[order[p][0] for p in mine]], cnts)
-            img_j = np.repeat(offs[[order[p][1] for p in mine]], cnts)
-            idx = torch.from_numpy(np.stack([img_i + cat[:, 0] - 1, img_j + cat[:, 1] - 1])).to(dev)
-            row_i, row_j = idx[0], idx[1]
+        # segment p of the match lists -> rows of the concatenated keypoint table, all on the device
+        cnt_t = torch.tensor(cnts, dtype=torch.int64, device=dev)
+        seg0 = torch.from_numpy(gpos[mine]).to(dev)
+        pos = torch.arange(int(wptr[-1]), dtype=torch.int64, device=dev) + \
+            torch.repeat_interleave(seg0 - torch.from_numpy(wptr[:-1]).to(dev), cnt_t)
+        off_i = torch.repeat_interleave(torch.from_numpy(offs[[order[p][0] for p in mine]]).to(dev), cnt_t)
+        off_j = torch.repeat_interleave(torch.from_numpy(offs[[order[p][1] for p in mine]]).to(dev), cnt_t)
+        row_i = off_i + ia_d.index_select(0, pos).to(torch.int64) - 1
+        row_j = off_j + ib_d.index_select(0, pos).to(torch.int64) - 1
         dst = kp_all.index_select(0, row_i).t().contiguous()
         src = kp_all.index_select(0, row_j).t().contiguous()
         torch.cuda.current_stream().synchronize()  # torch's stream produced dst/src; the library runs on its own
@@ -310,80 +368,190 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
         times.add("im_ransac", t0)
         t0 = time.perf_counter()
-        for k in range(len(mine)):
-            rec = np.empty(11 + cnts[k])
-            rec[:9] = models[k].reshape(-1)
-            rec[9] = found[k]
-            rec[10] = ninl[k]
-            rec[11:] = mask[wptr[k]:wptr[k + 1]]
-            recs.append(rec.reshape(-1, 1))
-    wk = {p: k for k, p in enumerate(work)}
-    allr = exchange_items([wk[p] for p in mine], recs, len(work), lambda k: k % ws, 1, np.float64, dev)
-    allr = [r.reshape(-1) for r in allr]
+        wk = {p: k for k, p in enumerate(work)}
+        rows = torch.tensor([wk[p] for p in mine], dtype=torch.int64, device=dev)
+        vals = np.concatenate([models.reshape(len(mine), 9), found.reshape(-1, 1).astype(np.float64),
+                               ninl.reshape(-1, 1).astype(np.float64)], axis=1)
+        rec[rows] = torch.from_numpy(vals).to(dev)
+    if ws > 1:
+        _all_reduce(rec)  # every row is written by exactly one rank, zero elsewhere
+    rec = rec.cpu().numpy()
     pairs, models_l, num_matches = [], [], np.zeros((n, n))
     for k, p in enumerate(work):
-        rec = allr[k]
         nf = int(n_match[p])
-        ni = int(rec[10]) if rec[9] else 0
-        if ni > 8 + 0.3 * nf:
+        ni = int(rec[k, 10]) if rec[k, 9] else 0
+        if ni > 8 + 0.3 * nf:  # imageMatching.m:150
             i, j = order[p]
             pairs.append((i, j))
-            models_l.append(rec[:9].reshape(3, 3))
+            models_l.append(rec[k, :9].reshape(3, 3).copy())
             num_matches[i, j] = ni
     times.add("im_merge", t0)
+    return {"counts": counts, "kps_t": kps_t, "pairs": pairs, "models": models_l, "num_matches": num_matches,
+            "n_match": n_match, "order": order}
 
-    # 5) host segment (redundant on every rank)
+
+def _sync_lib():
+    from . import pipeline as pl
+
+    pl._sync()
+
+
+def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None,
+                       local_originals=None):
+    """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
+    local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
+    pano_root: None = every panorama is combined on every rank; r = only rank r receives the tiles / panoramas of the
+    others (cheaper; the other ranks return what they rendered themselves).
+    local_originals: the unresized originals of the local images; with input.resizeImage and
+    input.resizeImagePanoramaCluster set and more than one connected component they are resized per component and the
+    extract -> match -> verify chain runs a second time (imageMatchingPanoramaConComps.m:48-91).
+    Returns (panorama of the component that holds the best-connected image, uint8 H x W x 3 CUDA tensor; info dict
+    with info["panoramas"]: one entry per connected component of at least two images, in component order)."""
+    from . import pipeline as pl
+    from . import renderPanorama as rp
+
+    ws, rank = world()
+    dev = next(iter(local_images.values())).device if local_images else torch.device("cuda", torch.cuda.current_device())
+    times = pl.StageTimes()
+
+    # 0) the render will need every source image everywhere: start that all-gather now, collect it at step 6
     t0 = time.perf_counter()
-    ncomp, labels = pl.connected_components(num_matches)
-    if cameras is None:
-        cameras, ref = pl.cameras_from_models(n, pairs, models_l, num_matches, Ks)
-        cameras = pl.straightening(cameras)
-    else:
-        ref = int(np.argmax((num_matches + num_matches.T).sum(1)))
+    img_gather = ImageGather(local_images, n, dev)
+    times.add("exchange", t0)
+
+    res = _match_pass(input, local_images, n, seed, times, dev)
+
+    # 5) host segment (redundant on every rank): components, second pass if asked for, cameras per component
+    t0 = time.perf_counter()
+    ncomp, labels = pl.connected_components(res["num_matches"])
+    times.add("host_cameras", t0)
+    if (int(input.get("resizeImage", 0)) == 1 and int(input.get("resizeImagePanoramaCluster", 0)) == 1 and ncomp > 1
+            and local_originals is not None):
+        # imageMatchingPanoramaConComps.m:48-91: images resized per component (the common size is that of the
+        # component), features re-extracted, everything re-matched and re-verified; the component labels of the
+        # FIRST pass are kept (the reference does not recompute them)
+        t0 = time.perf_counter()
+        szs = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+        for k, im_ in local_originals.items():
+            szs[k, 0], szs[k, 1] = int(im_.shape[0]), int(im_.shape[1])
+        if ws > 1:
+            _all_reduce(szs)
+        local_images = pl.resize_per_component(input, local_originals, labels, szs.cpu().tolist())
+        img_gather.wait()
+        img_gather = ImageGather(local_images, n, dev)
+        times.add("exchange", t0)
+        res = _match_pass(input, local_images, n, seed, times, dev)
+    t0 = time.perf_counter()
+    comps = pl.recognize_panoramas(n, res["pairs"], res["models"], res["num_matches"], Ks, labels, cameras)
     times.add("host_cameras", t0)
 
-    # 6) render: all images everywhere, tiles t % world == rank, one all-reduce(MAX) of the canvas
+    # 6) render every component
     t0 = time.perf_counter()
     images = img_gather.wait()
     if ws > 1:
         torch.cuda.synchronize()  # the collective ran on RCCL's stream; the library reads the images on its own
     times.add("exchange", t0)
     t0 = time.perf_counter()
-    comp = labels[ref]
-    members = [k for k in range(n) if labels[k] == comp and cameras[k] is not None]
-    sizes = [(int(images[k].shape[0]), int(images[k].shape[1]), 3) for k in members]
     opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
-            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": False}
-    gains = None
-    tg = time.perf_counter()
-    if input.get("gainCompensation"):
-        # gainCompensationRKf between cameras and render (renderPanorama.m:303-330).  The device sums in an
-        # unspecified order, so rank 0's gains are broadcast: every tile must be rendered with the same numbers.
-        from . import gainCompensation as gc
+            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": bool(input.get("cropBorder", False))}
+    mode = input["panorama2DisplaynSave"]
+    # geometry of every canvas (host, f64) decides the sharding: components to ranks when there are enough of them
+    geos = []
+    for c in comps:
+        sizes = [(int(images[k].shape[0]), int(images[k].shape[1]), 3) for k in c["members"]]
+        o_ = rp.default_opts(opts, c["cameras"], c["ref"])
+        geos.append((sizes, rp.canvas_geometry(c["cameras"], sizes, mode, c["ref"], o_)))
+    by_component = ws > 1 and len(comps) >= ws
+    comp_owner = partition_weighted([float(g["H"]) * float(g["W"]) for (_, g) in geos], ws) if by_component else None
+    panos = []
+    for ci, c in enumerate(comps):
+        sizes, geo = geos[ci]
+        members = c["members"]
+        gains = None
+        if input.get("gainCompensation"):
+            # gainCompensationRKf between cameras and render (renderPanorama.m:303-330).  The device sums in an
+            # unspecified order, so rank 0's gains are broadcast: every tile must be rendered with the same numbers.
+            from . import gainCompensation as gc
 
-        mem_cams = [cameras[k] for k in members]
-        o_ = rp.default_opts(opts, mem_cams, members.index(ref))
-        geo = rp.canvas_geometry(mem_cams, sizes, input["panorama2DisplaynSave"], members.index(ref), o_)
-        gains = gc.gainCompensationRKf([images[k] for k in members], mem_cams, input["panorama2DisplaynSave"],
-                                       members.index(ref), input, geo)
-        if ws > 1:
-            gt_ = torch.from_numpy(np.ascontiguousarray(gains)).to(dev)
-            dist.broadcast(gt_, 0)
-            gains = gt_.cpu().numpy()
-        times.add("gain_compensation", tg)
-        t0 = time.perf_counter()
-    pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, [cameras[k] for k in members],
-                                input["panorama2DisplaynSave"], members.index(ref), opts, gains=gains, device_out=True,
-                                tile_subset=(rank, ws) if ws > 1 else None)
-    pl._sync()
-    if ws > 1:
-        torch.cuda.synchronize()
-        if pano_root is None:
-            dist.all_reduce(pano, op=dist.ReduceOp.MAX)  # disjoint tiles, zero elsewhere
+            tg = time.perf_counter()
+            gains = gc.gainCompensationRKf([images[k] for k in members], c["cameras"], mode, c["ref"], input, geo)
+            if ws > 1:
+                gt_ = torch.from_numpy(np.ascontiguousarray(gains)).to(dev)
+                _broadcast(gt_, 0)
+                gains = gt_.cpu().numpy()
+            times.add("gain_compensation", tg)
+        if by_component:
+            pano = None
+            if int(comp_owner[ci]) == rank:
+                pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
+                                            gains=gains, device_out=True)
+                pl._sync()
+            root = pano_root if pano_root is not None else None
+            pano = _deliver_panorama(pano, int(comp_owner[ci]), root, dev)
         else:
-            pano = gather_tiles_to_root(pano, tile, pano_root)
-        torch.cuda.synchronize()
+            pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
+                                        gains=gains, device_out=True, tile_subset=(rank, ws) if ws > 1 else None)
+            pl._sync()
+            if ws > 1:
+                torch.cuda.synchronize()
+                if pano_root is None:
+                    _all_reduce(pano, dist.ReduceOp.MAX)  # disjoint tiles, zero elsewhere
+                else:
+                    pano = gather_tiles_to_root(pano, rp.effective_tile(opts, geo), pano_root)
+                torch.cuda.synchronize()
+        panos.append(pano)
     times.add("render", t0)
-    info = {"times": dict(times), "n_features": counts, "n_pairs_verified": len(pairs), "n_components": int(ncomp),
-            "panorama_shape": tuple(int(v) for v in pano.shape), "members": members, "cameras": cameras, "pairs": pairs, "models": models_l}
+    main = 0
+    if comps:
+        deg = (res["num_matches"] + res["num_matches"].T).sum(1)
+        best = int(np.argmax(deg))
+        main = next((ci for ci, c in enumerate(comps) if best in c["members"]), 0)
+    pano = panos[main] if panos else torch.zeros((0, 0, 3), dtype=torch.uint8, device=dev)
+    info = {"times": dict(times), "n_features": res["counts"], "n_pairs_verified": len(res["pairs"]),
+            "n_components": int(ncomp), "panorama_shape": tuple(int(v) for v in pano.shape) if pano is not None else None,
+            "members": comps[main]["members"] if comps else [], "cameras": _scatter_cameras(comps, n),
+            "pairs": res["pairs"], "models": res["models"], "components": comps, "panoramas": panos, "labels": labels}
     return pano, info
+
+
+def _scatter_cameras(comps, n):
+    cams = [None] * n
+    for c in comps:
+        for k, cam in zip(c["members"], c["cameras"]):
+            cams[k] = cam
+    return cams
+
+
+def _deliver_panorama(pano, owner, root, dev):
+    """A panorama rendered whole by `owner`: to `root` only (point to point), or to every rank (broadcast) when root
+    is None.  Ranks that neither rendered nor receive it return None."""
+    ws, rank = world()
+    shp = torch.zeros(3, dtype=torch.int64, device=dev)
+    if rank == owner:
+        shp = torch.tensor([int(v) for v in pano.shape], dtype=torch.int64, device=dev)
+    _broadcast(shp, owner)
+    shape = tuple(int(v) for v in shp.cpu().tolist())
+    if root is None:
+        if rank != owner:
+            pano = torch.empty(shape, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        _broadcast(pano, owner)
+        return pano
+    if owner == root:
+        return pano if rank == root else None
+    if rank == owner:
+        torch.cuda.synchronize()
+        if _staged(pano):
+            dist.send(pano.cpu(), dst=root)
+        else:
+            dist.send(pano, dst=root)
+        return pano
+    if rank == root:
+        if dist.get_backend() == "gloo":
+            h = torch.empty(shape, dtype=torch.uint8)
+            dist.recv(h, src=owner)
+            return h.to(dev)
+        out = torch.empty(shape, dtype=torch.uint8, device=dev)
+        dist.recv(out, src=owner)
+        return out
+    return None

@@ -30,6 +30,7 @@ DEFAULT_INPUT = {
     "maxDistance": 5.5, "inliersConfidence": 99.9, "transformationType": "projective",
     # inputs.m:94-113
     "gainCompensation": 0, "blending": "multiband", "bands": 3, "MBBsigma": 1, "resizeImage": 0,
+    "resizeImagePanoramaCluster": 0, "heightLimit": 800, "widthLimit": 800,
     "panorama2DisplaynSave": "spherical", "canvasColor": "black", "forcePlanarScan": False,
 }
 
@@ -230,41 +231,146 @@ def straightening(cameras, up_angle_t=(60, 60, 105), theta_t=90):
     return out
 
 
-def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, device_out=True, profile=False):
+def recognize_panoramas(n, pairs, models, num_matches, Ks, labels, cameras=None):
+    """recognizePanoramas.m:70-113 + straightening per panorama (main.m:110-118) over the match graph: every connected
+    component with at least two images becomes one panorama with its own cameras and its own reference image.
+    The reference runs bundleAdjustmentRKf per component (host code, out of scope); here the cameras are the
+    caller's (`cameras`, e.g. from that bundle adjustment) or the host stand-in cameras_from_models, run per component
+    from that component's best-connected image.  Components come in conncomp order (by lowest image index).
+    Returns a list of dict(members=[global image indices], ref=index INTO members, cameras=[one per member])."""
+    labels = np.asarray(labels)
+    deg = (np.asarray(num_matches) + np.asarray(num_matches).T).sum(1)
+    comps = []
+    for c in range(int(labels.max()) + 1 if labels.size else 0):
+        members = [int(k) for k in np.nonzero(labels == c)[0]]
+        if len(members) < 2:
+            continue  # 'Skipping bundle adjustment as only one image found' (recognizePanoramas.m:86-89)
+        if cameras is not None:
+            cams = [cameras[k] for k in members]
+            ref = int(np.argmax(deg[members]))
+        else:
+            if Ks is None:
+                raise ValueError("either cameras or the intrinsics Ks must be given (focal estimation/BA are host code out of scope)")
+            inside = set(members)
+            sel = [p for p, (i, j) in enumerate(pairs) if i in inside and j in inside]
+            cams_all, seed = cameras_from_models(n, [pairs[p] for p in sel], [models[p] for p in sel], num_matches, Ks)
+            cams = straightening([cams_all[k] for k in members])
+            ref = members.index(seed)
+        keep = [q for q, cam in enumerate(cams) if cam is not None]
+        if len(keep) < 2:
+            continue
+        if len(keep) != len(members):
+            ref = keep.index(ref) if ref in keep else 0
+            members = [members[q] for q in keep]
+            cams = [cams[q] for q in keep]
+        comps.append({"members": members, "ref": ref, "cameras": cams})
+    return comps
+
+
+def fit_size(h, w, heightLimit, widthLimit):
+    """Stage-1 size of resizeImagesToLimits 'fit' (resizeImagesToLimits.m:57-61): isotropic shrink into the box,
+    imresize's scalar form gives ceil(s * size); images inside the box keep their size."""
+    import math
+
+    sc = min(heightLimit / h, widthLimit / w)
+    if not np.isfinite(sc) or sc <= 0:
+        sc = 1.0
+    return (int(math.ceil(h * sc)), int(math.ceil(w * sc)), sc) if sc < 1 else (int(h), int(w), 1.0)
+
+
+def resize_per_component(input, local_originals, labels, all_sizes):
+    """imageMatchingPanoramaConComps.m:48-56: imagesProcessed(idxs) = resizeImagesToLimits(imagesOriginal(idxs), ...,
+    'fit') for every connected component - the same rule as loadImages.m:66-68, applied per panorama: shrink into the
+    box, then bring the component's images to ITS common largest size (resizeImagesToLimits.m:49-106).
+    local_originals: dict image index -> uint8 image (numpy or CUDA tensor) held by this process; all_sizes: (h, w)
+    of EVERY original (the common size of a component depends on members other processes hold).
+    Returns dict image index -> resized image of the same kind."""
+    from . import imageProcessing as ip
+
+    HL, WL = float(input["heightLimit"]), float(input["widthLimit"])
+    labels = np.asarray(labels)
+    out = {}
+    for c in range(int(labels.max()) + 1):
+        idxs = [int(k) for k in np.nonzero(labels == c)[0]]
+        orig = [tuple(int(v) for v in all_sizes[k][:2]) for k in idxs]
+        too_large = any(h > HL or w > WL for (h, w) in orig)
+        if not too_large and len(set(orig)) == 1:
+            for k in idxs:
+                if k in local_originals:
+                    out[k] = local_originals[k]  # all the same size, nothing to do (:49-55)
+            continue
+        st1 = [fit_size(h, w, HL, WL) for (h, w) in orig]
+        common = None
+        if len({(a, b) for (a, b, _) in st1}) > 1:
+            common = (max(a for (a, _, _) in st1), max(b for (_, b, _) in st1))
+        for k, (h1, w1, sc) in zip(idxs, st1):
+            if k not in local_originals:
+                continue
+            img = local_originals[k]
+            is_t = _capi.is_torch(img)
+            a = img.cpu().numpy() if is_t else np.asarray(img)
+            if sc < 1:
+                a = ip.imresize(a, sc, "bicubic")
+            if common is not None:
+                a = ip.imresize(a, common, "bicubic")
+            if is_t:
+                import torch
+
+                a = torch.from_numpy(np.ascontiguousarray(a)).to(img.device)
+            out[k] = a
+    return out
+
+
+def imageMatchingPanoramaConComps(input, images_original, images_processed, descs, kps, seed=0, times=None):
+    """[allMatchesRefined, numMatches, initialTforms, imagesProcessed, ..., concomps] =
+    imageMatchingPanoramaConComps(...) (imageMatchingPanoramaConComps.m:39-91) in CSR form: first-pass matching and
+    verification, connected components, and - with input.resizeImage and input.resizeImagePanoramaCluster set and
+    more than one component - the second pass on images resized per component.
+    Returns (result dict of match_and_verify, images_processed, descs, kps, ncomp, labels)."""
+    res = match_and_verify(input, descs, kps, seed, times)
+    ncomp, labels = connected_components(res["numMatches"])
+    if int(input.get("resizeImage", 0)) == 1 and int(input.get("resizeImagePanoramaCluster", 0)) == 1 and ncomp > 1:
+        sizes = [(int(im_.shape[0]), int(im_.shape[1])) for im_ in images_original]
+        resized = resize_per_component(input, dict(enumerate(images_original)), labels, sizes)
+        images_processed = [resized[k] for k in range(len(images_original))]
+        descs, kps = extract_features(input, images_processed, times)
+        res = match_and_verify(input, descs, kps, seed, times)
+    return res, images_processed, descs, kps, ncomp, labels
+
+
+def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, device_out=True, profile=False,
+           images_original=None):
     """main.m for one dataset.  images: list of uint8 H x W x 3 (torch CUDA tensors stay resident).
     cameras: optional externally supplied cameras (e.g. from the reference's own bundle adjustment);
     otherwise they are initialised on the host from the verified homographies and the intrinsics Ks.
-    Returns (panoramas [list], info dict with per-stage wall times in seconds)."""
+    Every connected component of at least two images is rendered (displayPanorama.m:88-116).
+    Returns (panoramas [one per component, in component order], info dict with per-stage wall times in seconds)."""
     times = StageTimes()
     n = len(images)
-    sizes = [(int(im_.shape[0]), int(im_.shape[1]), 3) for im_ in images]
     descs, kps = extract_features(input, images, times)
-    res = match_and_verify(input, descs, kps, seed, times)
+    res, images, descs, kps, ncomp, labels = imageMatchingPanoramaConComps(
+        input, images if images_original is None else images_original, images, descs, kps, seed, times)
+    sizes = [(int(im_.shape[0]), int(im_.shape[1]), 3) for im_ in images]
     t0 = time.perf_counter()
-    ncomp, labels = connected_components(res["numMatches"])
-    if cameras is None:
-        if Ks is None:
-            raise ValueError("either cameras or the intrinsics Ks must be given (focal estimation/BA are host code out of scope)")
-        cameras, ref = cameras_from_models(n, res["pairs"], res["models"], res["numMatches"], Ks)
-        cameras = straightening(cameras)
-    else:
-        ref = int(np.argmax((res["numMatches"] + res["numMatches"].T).sum(1)))
+    comps = recognize_panoramas(n, res["pairs"], res["models"], res["numMatches"], Ks, labels, cameras)
     times.add("host_cameras", t0)
     panos = []
     t0 = time.perf_counter()
     opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
             "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": not device_out}
-    for comp in range(ncomp):
-        members = [k for k in range(n) if labels[k] == comp and cameras[k] is not None]
-        if len(members) < 2:
-            continue
-        r = members.index(ref) if ref in members else 0
+    for c in comps:
+        members = c["members"]
         pano, _ = rp.renderPanorama(input, [images[k] for k in members], [sizes[k] for k in members],
-                                    [cameras[k] for k in members], input["panorama2DisplaynSave"], r, opts,
+                                    c["cameras"], input["panorama2DisplaynSave"], c["ref"], opts,
                                     device_out=device_out)
         panos.append(pano)
     _sync()
     times.add("render", t0)
+    cams = [None] * n
+    for c in comps:
+        for k, cam in zip(c["members"], c["cameras"]):
+            cams[k] = cam
     info = {"times": dict(times), "n_features": [len(k) for k in kps], "n_pairs_verified": len(res["pairs"]),
-            "n_components": int(ncomp), "putative": res["putative"], "result": res, "cameras": cameras}
+            "n_components": int(ncomp), "putative": res["putative"], "result": res, "cameras": cams,
+            "components": comps, "labels": labels}
     return panos, info

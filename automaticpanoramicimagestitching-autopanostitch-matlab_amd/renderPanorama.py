@@ -193,6 +193,15 @@ def canvas_geometry(cameras, imgSize, mode, refIdx, opts):
             "Rref": Rref, "refIdx": refIdx}
 
 
+def effective_tile(opts, geo):
+    """The tile side renderPanorama uses for a canvas: opts['tile'] when given, else 2048 clamped to the canvas."""
+    if opts.get("tile") is not None:
+        return tuple(int(v) for v in opts["tile"])
+    H, W = int(geo["H"]), int(geo["W"])
+    side = max(512, min(2048, H, W)) if min(H, W) >= 512 else min(H, W)
+    return (side, side)
+
+
 def cropNonzeroBbox(panorama, canvasColor="black"):
     """renderPanorama.m:1459-1504 (rgb2gray > 0 bounding box, 6 px pad)."""
     p = panorama.astype(np.float64)
@@ -369,9 +378,7 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
     o = default_opts(opts, cameras, refIdx)
     imgSize = [tuple(int(v) for v in s) for s in imgSize]
     geo = canvas_geometry(cameras, imgSize, mode, refIdx, o)
-    if o["tile"] is None:
-        side = max(512, min(2048, geo["H"], geo["W"])) if min(geo["H"], geo["W"]) >= 512 else min(geo["H"], geo["W"])
-        o["tile"] = (side, side)
+    o["tile"] = effective_tile(o, geo)
     if gains is None and opts and opts.get("gainCompensation"):
         # renderPanorama.m:303-330: overlap statistics on the device, N x N solve on the host.  Only when the
         # caller asks for it explicitly; otherwise gains are ones (or the caller's own).

@@ -1,0 +1,162 @@
+"""GPU: every connected component becomes a panorama (displayPanorama.m:88-116, recognizePanoramas.m:70-113), in the
+single-process driver and in the sharded one, and the 2-rank run of the sharded driver equals the 1-rank run."""
+import os
+import socket
+import sys
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, F = 640, 480, 900.0
+
+
+def _worlds(synth, device="cuda"):
+    """Three independent procedural worlds (different seeds) of 2x2, 3x2 and 2x2 views, shuffled into one set."""
+    views, cams, world_of = [], [], []
+    for wi, (nx, ny, seed) in enumerate([(2, 2, 11), (3, 2, 23), (2, 2, 37)]):
+        cs = synth.grid_cameras(nx, ny, W, H, F, 2 * np.arctan(W / (2 * F)) * 0.6, 2 * np.arctan(H / (2 * F)) * 0.6, 1.0, seed)
+        for c in cs:
+            views.append(synth.render_view(c, H, W, seed, device, finest_px=6.0))
+            cams.append(c)
+            world_of.append(wi)
+    perm = np.random.default_rng(5).permutation(len(views))
+    return [views[k] for k in perm], [cams[k] for k in perm], [world_of[k] for k in perm]
+
+
+def test_three_worlds_give_three_panoramas_equal_to_stitching_each_alone(gpu):
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    views, cams, world_of = _worlds(synth)
+    torch.cuda.synchronize()
+    n = len(views)
+    inp = pl.default_input(bands=3)
+    Ks = [c["K"] for c in cams]
+    # sharded driver, one rank, ground-truth cameras: the panorama bytes then depend on the component structure only
+    pano, info = par.stitch_distributed(inp, dict(enumerate(views)), n, Ks, (512, 512), 0, cams, pano_root=0)
+    assert info["n_components"] == 3 and len(info["panoramas"]) == 3
+    for c in info["components"]:
+        assert len({world_of[k] for k in c["members"]}) == 1, "a component mixes worlds"
+    sizes = sorted(len(c["members"]) for c in info["components"])
+    assert sizes == [4, 4, 6]
+    for c, p in zip(info["components"], info["panoramas"]):
+        members = c["members"]
+        sub_views = {q: views[k] for q, k in enumerate(members)}
+        alone, ia = par.stitch_distributed(inp, sub_views, len(members), [Ks[k] for k in members], (512, 512), 0,
+                                           [cams[k] for k in members], pano_root=0)
+        assert ia["n_components"] == 1 and len(ia["panoramas"]) == 1
+        assert tuple(alone.shape) == tuple(p.shape) and bool(torch.equal(alone, p)), "panorama differs from the world alone"
+        assert (p.amax(dim=2) > 0).float().mean().item() > 0.5
+    # the main panorama is the component of the best-connected image
+    assert any(pano is p for p in info["panoramas"])
+    # single-process driver with estimated cameras: the same three panoramas' member sets
+    panos, i2 = pl.stitch(inp, views, Ks=Ks, tile=(512, 512))
+    assert i2["n_components"] == 3 and len(panos) == 3
+    assert [c["members"] for c in i2["components"]] == [c["members"] for c in info["components"]]
+    for c in i2["components"]:
+        assert 0 <= c["ref"] < len(c["members"]) and all(cam is not None for cam in c["cameras"])
+
+
+def test_single_images_and_unmatched_sets_render_nothing(gpu):
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    cams = synth.grid_cameras(2, 1, W, H, F, 2.5, 0.0, 0.0, 3)  # two views that do not overlap at all
+    views = [synth.render_view(c, H, W, 3 + k, "cuda", finest_px=6.0) for k, c in enumerate(cams)]
+    torch.cuda.synchronize()
+    pano, info = par.stitch_distributed(pl.default_input(), dict(enumerate(views)), 2, [c["K"] for c in cams], (512, 512))
+    assert info["n_pairs_verified"] == 0 and info["panoramas"] == [] and pano.numel() == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q, mode):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["APS_DEVICE"] = "0"
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import apsamd
+
+        synth = import_module(apsamd.__name__ + ".synth")
+        pl = import_module(apsamd.__name__ + ".pipeline")
+        par = import_module(apsamd.__name__ + ".parallel")
+        if mode == "worlds":
+            views, cams, _ = _worlds(synth)
+            gt = None
+        else:
+            cams = synth.grid_cameras(3, 2, W, H, F, 2 * np.arctan(W / (2 * F)) * 0.6, 2 * np.arctan(H / (2 * F)) * 0.6, 1.0, 7)
+            views = [synth.render_view(c, H, W, 7, "cuda", finest_px=6.0) for c in cams]
+            gt = None
+        torch.cuda.synchronize()
+        n = len(views)
+        local = {i: views[i] for i in par.shard_indices(n, world, rank)}
+        pano, info = par.stitch_distributed(pl.default_input(bands=3), local, n, [c["K"] for c in cams], (256, 256), 0, gt,
+                                            pano_root=0)
+        torch.cuda.synchronize()
+        out = None
+        if rank == 0:
+            out = {"pairs": info["pairs"], "models": [np.asarray(m).copy() for m in info["models"]],
+                   "panos": [p.cpu().numpy() for p in info["panoramas"]], "ncomp": info["n_components"],
+                   "members": [c["members"] for c in info["components"]]}
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        q.put((rank, "ok", out))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        raise
+
+
+def _spawn(world, mode):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res if r[1] != "ok"]
+    return next(r[2] for r in res if r[0] == 0)
+
+
+@pytest.mark.parametrize("mode", ["grid", "worlds"])
+def test_two_ranks_equal_one_rank(gpu, mode):
+    """stitch_distributed with 2 ranks (both on this GPU, gloo with host-staged collectives) against the 1-rank run:
+    verified pairs, model bits and every panorama byte.  'grid': one panorama, tiles sharded; 'worlds': three
+    panoramas, components sharded (3 components >= 2 ranks)."""
+    one = _spawn(1, mode)
+    two = _spawn(2, mode)
+    assert one["pairs"] == two["pairs"] and len(one["pairs"]) >= 5
+    for a, b in zip(one["models"], two["models"]):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert one["ncomp"] == two["ncomp"] and one["members"] == two["members"]
+    assert len(one["panos"]) == len(two["panos"]) == (3 if mode == "worlds" else 1)
+    for a, b in zip(one["panos"], two["panos"]):
+        assert a.shape == b.shape and np.array_equal(a, b)

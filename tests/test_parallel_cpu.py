@@ -58,6 +58,14 @@ def _worker(rank, world, port, q):
         got = ig.wait()
         assert len(got) == 5 and all(g.shape == (6, 4, 3) and int(g[0, 0, 0]) == 10 * i + 1 and bool((g == g[0, 0, 0]).all())
                                      for i, g in enumerate(got))
+        # ragged sizes and a rank that owns nothing (n < world): 1 image of 3x5x3 on rank 0 only
+        one = {0: torch.full((3, 5, 3), 9, dtype=torch.uint8)} if rank == 0 else {}
+        got1 = par.ImageGather(one, 1, dev).wait()
+        assert len(got1) == 1 and got1[0].shape == (3, 5, 3) and bool((got1[0] == 9).all())
+        mixed = {i: torch.full((2 + i, 3, 3), i + 1, dtype=torch.uint8) for i in par.shard_indices(3, world, rank)}
+        gotm = par.ImageGather(mixed, 3, dev).wait()
+        assert [tuple(g.shape) for g in gotm] == [(2, 3, 3), (3, 3, 3), (4, 3, 3)]
+        assert all(bool((g == i + 1).all()) for i, g in enumerate(gotm))
         # tiles to the root: canvas 7x10x3 with 3x4 tiles (ragged edge tiles), tile t painted with t+1 by rank t % world
         H, W = 7, 10
         rects = par.tile_rects(H, W, (3, 4))
