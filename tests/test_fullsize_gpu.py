@@ -60,9 +60,9 @@ def test_sift_4k_is_deterministic_and_well_formed(mods):
     assert p1[:, 0].min() >= 1 and p1[:, 0].max() <= 3840 and p1[:, 1].min() >= 1 and p1[:, 1].max() <= 2160
 
 
-def test_render_4k_multitile_culls_change_no_byte(mods, monkeypatch):
-    """16 4K views (4 x 4 grid), 2048^2 tiles, 5 bands: the footprint culls, the block-level image cull and the fused
-    pyramid levels on, against all of them off."""
+def test_render_4k_multitile_batched_equals_per_tile_path(mods, monkeypatch):
+    """16 4K views (4 x 4 grid), 2048^2 tiles, 5 bands: the batched level-major path (render_batch.hip) against the
+    per-tile path with its footprint culls, block-level image cull and fused levels all off."""
     import torch
 
     synth, rp = mods["synth"], mods["renderPanorama"]
@@ -73,15 +73,18 @@ def test_render_4k_multitile_culls_change_no_byte(mods, monkeypatch):
     opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
     sizes = [(H, W, 3)] * 16
     outs = []
-    for env in ({}, {"APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
-        for k in ("APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE"):
+    keys = ("APS_RENDER_LEGACY", "APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE")
+    for env in ({}, {"APS_RENDER_LEGACY": "1"}, {"APS_RENDER_LEGACY": "1", "APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
+        for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         pano, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 5, opts, device_out=True)
         outs.append(pano)
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
     assert outs[0].shape[0] > 4096 and outs[0].shape[1] > 8192 and int((outs[0] > 0).sum()) > 5e7
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_crop_rectangle_on_a_large_canvas(mods):

@@ -6,7 +6,7 @@ Tolerance (stated per north star "warped/blended pixels within a stated fp32 tol
   * anything downstream of the ray generator differs only through sinf/cosf (device libm vs glibc, <= 2 ulp):
     sampled colours/weights within 2e-4 absolute on [0,1] data wherever both masks agree, masks may differ on
     at most 0.1 % of pixels (rays that land within rounding of an image border), final uint8 panoramas within
-    1 grey level on >= 99.8 % of pixels.
+    1 grey level on >= 99.8 % of pixels and, for the blended modes, within 2 grey levels on EVERY pixel both sides cover.
 """
 import math
 from importlib import import_module
@@ -144,6 +144,10 @@ def test_render_matches_oracle(rp, blending, policy):
     both = (cov == 1) & (oc == 1)
     diff = np.abs(pano.astype(int) - op.astype(int))[both]
     assert (diff <= 1).mean() >= 0.998
+    if blending != "none":
+        # blended pixels: a border pixel that flips in one layer enters with a vanishing tent weight, so the bound holds
+        # EVERYWHERE both sides cover ('none' picks one image per pixel: a flip swaps the source image there)
+        assert diff.max() <= 2, diff.max()
     assert np.all(pano[cov == 0] == 0)
 
 
@@ -159,7 +163,8 @@ def test_render_five_bands_gains_white_canvas_and_partial_tiles(rp):
     op, oc = oracle.render(imgs, cams, geo, (100, 130), 2.0, "multiband", 5, 1.0, "last", True, gains)
     assert (cov != oc).mean() <= 1e-3
     both = (cov == 1) & (oc == 1)
-    assert (np.abs(pano.astype(int) - op.astype(int))[both] <= 1).mean() >= 0.998
+    d5 = np.abs(pano.astype(int) - op.astype(int))[both]
+    assert (d5 <= 1).mean() >= 0.998 and d5.max() <= 2
     assert np.all(pano[cov == 0] == 255)
 
 
