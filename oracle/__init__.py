@@ -524,3 +524,55 @@ def sift_blur(img, sigma):
 
 def sift_num_octaves(h, w):
     return int(_orc_sift_num_octaves(int(h), int(w)))
+
+
+# ---- canvas geometry (bounds_oracle.c) -----------------------------------------------------------------------------
+_GEO_MODES = {"cylindrical": 0, "spherical": 1, "equirectangular": 1, "planar": 2, "perspective": 2, "stereographic": 3}
+
+
+class _GeoOpts(C.Structure):
+    _fields_ = [("f_pan", _d), ("res_scale", _d), ("margin", _d), ("max_megapixel", _d), ("pct_lo", _d), ("pct_hi", _d),
+                ("uv_abs_cap", _d), ("pixel_pad", _d), ("auto_ref", _i)]
+
+
+def _cams_flat(cameras, sizes):
+    K = np.ascontiguousarray(np.stack([np.asarray(c["K"], np.float64).T.reshape(-1) for c in cameras]))  # column-major
+    R = np.ascontiguousarray(np.stack([np.asarray(c["R"], np.float64).T.reshape(-1) for c in cameras]))
+    S = np.ascontiguousarray(np.asarray([[s[0], s[1]] for s in sizes], np.float64))
+    return K, R, S
+
+
+def bounds(mode, cameras, sizes, Rref=None, robust_pct=(1, 99), abs_cap=8.0):
+    """(aMin, aMax, bMin, bMax) of cylindricalBounds / sphericalBounds / planarBounds / stereographicBounds."""
+    K, R, S = _cams_flat(cameras, sizes)
+    rr = np.ascontiguousarray(np.asarray(np.eye(3) if Rref is None else Rref, np.float64).T.reshape(-1))
+    out = np.zeros(4)
+    lib.orc_bounds.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _d, _d, _d, _vp]
+    lib.orc_bounds(_GEO_MODES[str(mode).lower()], len(cameras), K.ctypes.data, R.ctypes.data, S.ctypes.data, rr.ctypes.data,
+                   float(robust_pct[0]), float(robust_pct[1]), float(abs_cap), out.ctypes.data)
+    return tuple(out.tolist())
+
+
+def canvas_geometry(cameras, sizes, mode, ref_idx, opts):
+    """renderPanorama.m:84-232: dict(W, H, o0, o1, refIdx, resScale)."""
+    K, R, S = _cams_flat(cameras, sizes)
+    o = _GeoOpts(float(opts["fPan"]), float(opts["resScale"]), float(opts["margin"]), float(opts["maxMegapixel"]),
+                 float(opts["robustPct"][0]), float(opts["robustPct"][1]), float(opts["uvAbsCap"]), float(opts["pixelPad"]),
+                 int(bool(opts["autoRef"])))
+    ref = C.c_int(int(ref_idx))
+    out = np.zeros(5)
+    lib.orc_canvas_geometry.argtypes = [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(_GeoOpts), _vp]
+    lib.orc_canvas_geometry(_GEO_MODES[str(mode).lower()], len(cameras), K.ctypes.data, R.ctypes.data, S.ctypes.data,
+                            C.byref(ref), C.byref(o), out.ctypes.data)
+    return {"W": int(out[0]), "H": int(out[1]), "o0": float(out[2]), "o1": float(out[3]), "refIdx": int(ref.value),
+            "resScale": float(out[4])}
+
+
+def crop_nonzero_bbox(img, canvas_white=False):
+    """cropNonzeroBbox (renderPanorama.m:1459-1504): ((r1, r2, c1, c2) 1-based inclusive, didCrop)."""
+    a = np.ascontiguousarray(img, np.uint8)
+    rect = np.zeros(4, np.int64)
+    lib.orc_crop_nonzero_bbox.argtypes = [_vp, _i64, _i64, _i, _vp]
+    lib.orc_crop_nonzero_bbox.restype = _i
+    did = lib.orc_crop_nonzero_bbox(a.ctypes.data, a.shape[0], a.shape[1], int(bool(canvas_white)), rect.ctypes.data)
+    return tuple(int(v) for v in rect), bool(did)
