@@ -17,6 +17,7 @@
 //             what the reference's pointer-jumping left/right arrays compute; (area, -k) max per line, then
 //             (area, -line) max over lines = the reference's first maximum in (line, k) order
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 
 #include "aps_internal.h"
@@ -465,5 +466,91 @@ extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layou
         APS_HIP(hipStreamSynchronize(stream()));
         for (int e = 0; e < 4; ++e) rect[e] = hr[e];
         *valid = hr[4];
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// cropNonzeroBbox (renderPanorama.m:1459-1504): bounding box of rgb2gray(pano) > 0 (black canvas) or < 255 (white)
+// ------------------------------------------------------------------------------------------------
+namespace aps {
+// One thread per pixel of a 64-column x 4-row patch per wave; the wave votes per row, lane 0 of each wave folds the
+// four rows and the column span into the workgroup's box, one global atomic quartet per workgroup that saw foreground.
+__global__ __launch_bounds__(256) void crop_bbox_kernel(const uint8_t* __restrict__ img, int64_t h, int64_t w, int layout,
+                                                        int white, int* __restrict__ box) {
+    __shared__ int s_box[4];  // rmin, rmax, cmin, cmax
+    if (threadIdx.x < 4) s_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : INT_MAX;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool fg = false;
+    if (col < w && r < h) {
+        uint8_t p[3];
+        if (layout == APS_IMG_U8_HWC) {
+            const uint8_t* q = img + (r * w + col) * 3;
+            p[0] = q[0];
+            p[1] = q[1];
+            p[2] = q[2];
+        } else {
+            const int64_t plane = h * w, o = col * h + r;
+            p[0] = img[o];
+            p[1] = img[plane + o];
+            p[2] = img[2 * plane + o];
+        }
+        const uint8_t g = crop_gray(p[0], p[1], p[2]);
+        fg = white ? g < 255 : g > 0;
+    }
+    const u64 m = __ballot(fg);
+    if (lane == 0 && m) {
+        const int c0 = (int)(blockIdx.x * 64) + (__ffsll((long long)m) - 1), c1 = (int)(blockIdx.x * 64) + (63 - __clzll((long long)m));
+        atomicMin(&s_box[0], (int)r);
+        atomicMax(&s_box[1], (int)r);
+        atomicMin(&s_box[2], c0);
+        atomicMax(&s_box[3], c1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_box[1] >= 0) {
+        atomicMin(&box[0], s_box[0]);
+        atomicMax(&box[1], s_box[1]);
+        atomicMin(&box[2], s_box[2]);
+        atomicMax(&box[3], s_box[3]);
+    }
+}
+}  // namespace aps
+
+extern "C" int aps_crop_nonzero_bbox(const uint8_t* img, int64_t h, int64_t w, int layout, int canvas_white, int64_t* rect,
+                                     int* did_crop) {
+    using namespace aps;
+    return guarded([&] {
+        APS_REQUIRE(img && rect && did_crop, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(h >= 1 && w >= 1 && h < INT_MAX && w < INT_MAX, APS_E_DIM, "bad image size");
+        APS_REQUIRE(layout == APS_IMG_U8_HWC || layout == APS_IMG_U8_MATLAB, APS_E_TYPE, "unknown layout");
+        ctx();
+        In<uint8_t> di(img, (size_t)h * w * 3);
+        Ws<int> box(4);
+        const int init[4] = {INT_MAX, -1, INT_MAX, -1};
+        APS_HIP(hipMemcpyAsync(box, init, sizeof init, hipMemcpyHostToDevice, stream()));
+        {
+            Prof prof("crop_bbox");
+            crop_bbox_kernel<<<dim3(cdiv(w, 64), cdiv(h, 4)), 256, 0, stream()>>>(di, h, w, layout, canvas_white, box);
+        }
+        check_launch("crop_bbox_kernel");
+        int hb[4];
+        APS_HIP(hipMemcpyAsync(hb, box, sizeof hb, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (hb[1] < 0) {  // no foreground: the whole image, didCrop = false (:1499-1502)
+            rect[0] = 1;
+            rect[1] = h;
+            rect[2] = 1;
+            rect[3] = w;
+            *did_crop = 0;
+            return;
+        }
+        const int64_t pad = 6;  // :1492
+        rect[0] = std::max<int64_t>(1, (int64_t)hb[0] + 1 - pad);
+        rect[1] = std::min<int64_t>(h, (int64_t)hb[1] + 1 + pad);
+        rect[2] = std::max<int64_t>(1, (int64_t)hb[2] + 1 - pad);
+        rect[3] = std::min<int64_t>(w, (int64_t)hb[3] + 1 + pad);
+        *did_crop = 1;
     });
 }

@@ -453,7 +453,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     times.add("exchange", t0)
     t0 = time.perf_counter()
     opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
-            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": bool(input.get("cropBorder", False))}
+            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": bool(input.get("cropBorder", True))}  # displayPanorama.m:101
     mode = input["panorama2DisplaynSave"]
     # geometry of every canvas (host, f64) decides the sharding: components to ranks when there are enough of them
     geos = []
@@ -499,6 +499,8 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
                 else:
                     pano = gather_tiles_to_root(pano, rp.effective_tile(opts, geo), pano_root)
                 torch.cuda.synchronize()
+                if opts["cropBorder"] and (pano_root is None or rank == pano_root):
+                    pano = rp.cropNonzeroBbox(pano, opts["canvasColor"])[0]  # the combined canvas (renderPanorama.m:430-432)
         panos.append(pano)
     times.add("render", t0)
     main = 0

@@ -357,7 +357,7 @@ def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, devi
     panos = []
     t0 = time.perf_counter()
     opts = {"anglePower": 2, "blending": input["blending"], "pyrLevels": input["bands"], "pyrSigma": input["MBBsigma"],
-            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": not device_out}
+            "canvasColor": input["canvasColor"], "tile": tile, "cropBorder": bool(input.get("cropBorder", True))}  # displayPanorama.m:101
     for c in comps:
         members = c["members"]
         pano, _ = rp.renderPanorama(input, [images[k] for k in members], [sizes[k] for k in members],

@@ -203,17 +203,23 @@ def effective_tile(opts, geo):
 
 
 def cropNonzeroBbox(panorama, canvasColor="black"):
-    """renderPanorama.m:1459-1504 (rgb2gray > 0 bounding box, 6 px pad)."""
-    p = panorama.astype(np.float64)
-    G = np.floor(0.298936021293775 * p[..., 0] + 0.587043074451121 * p[..., 1] + 0.114020904255103 * p[..., 2] + 0.5)
-    fg = (G < 255) if str(canvasColor).lower() == "white" else (G > 0)
-    rr, cc = np.nonzero(fg)
-    if rr.size == 0:
-        return panorama, (1, panorama.shape[0], 1, panorama.shape[1]), False
-    pad = 6
-    H, W = panorama.shape[:2]
-    r1, r2 = max(1, rr.min() + 1 - pad), min(H, rr.max() + 1 + pad)
-    c1, c2 = max(1, cc.min() + 1 - pad), min(W, cc.max() + 1 + pad)
+    """[panoCropped, rect, didCrop] = cropNonzeroBbox(panorama, canvasColor) (renderPanorama.m:1459-1504): bounding box of
+    rgb2gray(panorama) > 0 (or < 255 on a white canvas), 6 px pad; the box is a device reduction (aps_crop_nonzero_bbox),
+    the crop itself a slice (a view of a resident panorama, no copy).  rect = (r1, r2, c1, c2), 1-based inclusive."""
+    H, W = int(panorama.shape[0]), int(panorama.shape[1])
+    if _capi.is_torch(panorama):
+        src = panorama if panorama.is_contiguous() else panorama.contiguous()
+    else:
+        src = np.ascontiguousarray(panorama, np.uint8)
+    if src.ndim == 2:
+        src = src[..., None].repeat(3, axis=2) if not _capi.is_torch(src) else src[..., None].expand(H, W, 3).contiguous()
+    rect = np.zeros(4, np.int64)
+    did = C.c_int(0)
+    check(lib.aps_crop_nonzero_bbox(ptr(src), H, W, _capi.APS_IMG_U8_HWC, 1 if str(canvasColor).lower() == "white" else 0,
+                                    ptr(rect), C.byref(did)))
+    r1, r2, c1, c2 = (int(v) for v in rect)
+    if not did.value:
+        return panorama, (1, H, 1, W), False
     return panorama[r1 - 1:r2, c1 - 1:c2], (r1, r2, c1, c2), True
 
 
@@ -428,7 +434,9 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
 
             list(_render_pool(workers).map(work, range(workers)))
     del keep
-    if o["cropBorder"] and not device_out:
+    if o["cropBorder"] and tile_subset is None:  # renderPanorama.m:430-432 (a tile shard is cropped after it is combined)
+        if device_out:
+            check(lib.aps_synchronize())  # the panorama was painted on the library's stream of this thread
         pano, _, _ = cropNonzeroBbox(pano, o["canvasColor"])
     if return_covered:
         return pano, None, cov, geo

@@ -316,6 +316,14 @@ int aps_ba_pair_blocks(const double* Ui, const double* Uj, int64_t ldu, const in
 int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layout, int canvas_white, double range, int32_t* rect,
                   int32_t* valid);
 
+/* a20: [panoCropped, rect, didCrop] = cropNonzeroBbox(panorama, canvasColor) (renderPanorama.m:1459-1504), the step
+ * renderPanorama runs on its output when opts.cropBorder is set (:430-432; displayPanorama.m:101 sets it): bounding box of
+ * rgb2gray(panorama) > 0 (black canvas) or < 255 (white canvas), padded by 6 pixels and clipped to the image.
+ * img: h x w x 3 uint8 (layout as for the renderers, host or device).  rect = {r1, r2, c1, c2}, 1-based inclusive;
+ * *did_crop = 0 and rect = the whole image when there is no foreground.  The caller slices (no pixels are moved here). */
+int aps_crop_nonzero_bbox(const uint8_t* img, int64_t h, int64_t w, int layout, int canvas_white, int64_t* rect,
+                          int* did_crop);
+
 /* SURVEY 8(f) rank 1 -- the overlap statistics of gainCompensationRKf (PP/gainCompensation/gainCompensationRKf.m:96-149,
  * 239-367): every `stride`-th canvas point (1-based coordinates, :106-107) that two images i < j both cover
  * (front, inside, tent weight > 0) adds 1 to n_ij(i,j) and the two bilinear RAW (0..255) colour samples to

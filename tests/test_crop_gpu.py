@@ -147,3 +147,33 @@ def test_matlab_planar_layout(ip, gpu):
     capi.check(capi.lib.aps_crop_rect(capi.ptr(buf), 120, 200, capi.APS_IMG_U8_MATLAB, 0, 0.0, capi.ptr(rect), capi.ptr(valid)))
     want_rect, want_ok, _ = oracle.crop_rect(img)
     assert tuple(int(v) for v in rect) == want_rect and bool(valid[0]) == want_ok
+
+
+def test_crop_nonzero_bbox_equals_oracle(gpu):
+    """cropNonzeroBbox (renderPanorama.m:1459-1504) as a device reduction: rectangle and didCrop equal the oracle's on
+    host arrays, resident tensors, both canvas colours, grey-rounding edge cases, empty and full images."""
+    import torch
+
+    rp = import_module(gpu.__name__ + ".renderPanorama")
+    rng = np.random.default_rng(12)
+    cases = []
+    img = np.zeros((301, 517, 3), np.uint8)
+    img[40:222, 100:400] = rng.integers(0, 256, (182, 300, 3))
+    img[10, 20] = (0, 0, 4)    # gray rounds to 0: not foreground
+    img[280, 500] = (0, 0, 5)  # gray rounds to 1: foreground
+    cases.append((img, "black"))
+    white = np.full((130, 259, 3), 255, np.uint8)
+    white[50:60, 70:200] = rng.integers(0, 250, (10, 130, 3))
+    white[100, 250] = (255, 255, 252)  # gray 255: canvas
+    cases.append((white, "white"))
+    cases.append((np.zeros((9, 70, 3), np.uint8), "black"))
+    cases.append((np.full((5, 3, 3), 7, np.uint8), "black"))
+    for im_, color in cases:
+        want_rect, want_did = oracle.crop_nonzero_bbox(im_, color == "white")
+        out, rect, did = rp.cropNonzeroBbox(im_, color)
+        assert tuple(rect) == want_rect and did == want_did
+        r1, r2, c1, c2 = want_rect
+        assert np.array_equal(out, im_[r1 - 1:r2, c1 - 1:c2])
+        t = torch.from_numpy(im_).cuda()
+        out_t, rect_t, did_t = rp.cropNonzeroBbox(t, color)
+        assert tuple(rect_t) == want_rect and did_t == want_did and torch.equal(out_t.cpu(), torch.from_numpy(out))

@@ -338,15 +338,23 @@ def test_pair_shards_compose_to_the_all_pairs_result(fm):
                     assert np.array_equal(met[s0:s1].view(np.uint32), qm[t0:t1].view(np.uint32))
 
 
-def _boundary_sets(t_center, n=201):
-    """A_i = (t_i, 0, ...) with t_i the f32 neighbours of t_center; B = {0, e2}: d1 = t^2, d2 = t^2 + 1."""
-    c = np.float32(t_center)
-    t = np.full(n, c, np.float32)
-    for k in range(n // 2):  # walk +-k ulps
-        t[n // 2 + 1 + k] = np.nextafter(t[n // 2 + k], np.float32(2))
-        t[n // 2 - 1 - k] = np.nextafter(t[n // 2 - k], np.float32(0))
+def _boundary_sets(target, n=40000, seed=0):
+    """A_i = (t_i, u_i, 0, ...) against B = {0, e2}: d1 = t^2 + u^2, d2 = d1 + 1 - 2u.  (t, u) are scattered so that
+    d1 / d2 (ratio mode) or d1 (threshold mode, target = (None, thr)) lands within a few 1e-6 of the boundary: dense
+    enough that some rows fall between the f64 boundary and its f32-rounded neighbour."""
+    rng = np.random.default_rng(seed)
     a = np.zeros((n, 128), np.float32)
-    a[:, 0] = t
+    if target[0] is not None:
+        r = target[0] * (1 + 4e-6 * rng.uniform(-1, 1, n))          # wanted d1/d2
+        u = rng.uniform(0.0, 0.02, n)
+        d1 = r * (1 - 2 * u) / (1 - r)                                # d1 = r (d1 + 1 - 2u)
+        a[:, 0] = np.sqrt(np.maximum(d1 - u * u, 0)).astype(np.float32)
+        a[:, 1] = u.astype(np.float32)
+    else:
+        d1 = target[1] * (1 + 4e-6 * rng.uniform(-1, 1, n))
+        u = rng.uniform(0.0, 0.02, n)
+        a[:, 0] = np.sqrt(d1 - u * u).astype(np.float32)
+        a[:, 1] = u.astype(np.float32)
     b = np.zeros((2, 128), np.float32)
     b[1, 1] = 1.0
     return a, b
@@ -355,7 +363,7 @@ def _boundary_sets(t_center, n=201):
 def test_ratio_test_uses_double_r2_on_the_boundary(fm):
     """matchFeaturesScratch.m:170-173 evaluates MaxRatio^2 in double: rows whose d1/d2 falls between 0.36 and
     (double)0.6f^2 must be dropped, exactly as the oracle does (a float MaxRatio kept them)."""
-    a, b = _boundary_sets(0.75)  # t^2/(t^2+1) = 0.36 at t = 0.75
+    a, b = _boundary_sets((0.36, None))
     _, _, d1, d2 = fm.nearest2SSDExhaustive(a, b)
     dd1, dd2 = d1.astype(np.float64), d2.astype(np.float64)
     keep64 = dd1 <= (0.6 * 0.6) * dd2
@@ -369,7 +377,7 @@ def test_ratio_test_uses_double_r2_on_the_boundary(fm):
 
 def test_match_threshold_is_compared_in_double(fm):
     """MatchThreshold = 0.1 is not representable in f32: d1 values between 0.1 and (double)0.1f are dropped."""
-    a, b = _boundary_sets(np.sqrt(0.1))
+    a, b = _boundary_sets((None, 0.1))
     b[1, 1] = 1.9  # d2 far away: only the threshold decides (max|B| <= 2, so the reference's rule does not normalise)
     _, _, d1, _ = fm.nearest2SSDExhaustive(a, b)
     dd1 = d1.astype(np.float64)
