@@ -473,40 +473,61 @@ extern "C" int aps_crop_rect(const uint8_t* img, int64_t h, int64_t w, int layou
 // cropNonzeroBbox (renderPanorama.m:1459-1504): bounding box of rgb2gray(pano) > 0 (black canvas) or < 255 (white)
 // ------------------------------------------------------------------------------------------------
 namespace aps {
-// One thread per pixel of a 64-column x 4-row patch per wave; the wave votes per row, lane 0 of each wave folds the
-// four rows and the column span into the workgroup's box, one global atomic quartet per workgroup that saw foreground.
+// A fixed grid strides over the image; every thread keeps its own box in registers (interleaved RGB with an aligned
+// base: four pixels per step as three dwords), the workgroup folds the boxes through shuffles and LDS, and only then
+// touches the four global words: a few thousand same-address atomics per image instead of one quartet per patch
+// (those serialise in L2: 3.8 M of them cost 40 ms on a 245 MPix canvas).
 __global__ __launch_bounds__(256) void crop_bbox_kernel(const uint8_t* __restrict__ img, int64_t h, int64_t w, int layout,
                                                         int white, int* __restrict__ box) {
     __shared__ int s_box[4];  // rmin, rmax, cmin, cmax
     if (threadIdx.x < 4) s_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : INT_MAX;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool fg = false;
-    if (col < w && r < h) {
-        uint8_t p[3];
-        if (layout == APS_IMG_U8_HWC) {
-            const uint8_t* q = img + (r * w + col) * 3;
-            p[0] = q[0];
-            p[1] = q[1];
-            p[2] = q[2];
-        } else {
-            const int64_t plane = h * w, o = col * h + r;
-            p[0] = img[o];
-            p[1] = img[plane + o];
-            p[2] = img[2 * plane + o];
+    int rmin = INT_MAX, rmax = -1, cmin = INT_MAX, cmax = -1;
+    const int64_t npx = h * w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto see = [&](int64_t p, uint32_t r_, uint32_t g_, uint32_t b_) {
+        const uint8_t g = crop_gray((uint8_t)r_, (uint8_t)g_, (uint8_t)b_);
+        if (white ? g < 255 : g > 0) {
+            const int r = (int)(p / w), c = (int)(p - (int64_t)r * w);
+            rmin = min(rmin, r);
+            rmax = max(rmax, r);
+            cmin = min(cmin, c);
+            cmax = max(cmax, c);
         }
-        const uint8_t g = crop_gray(p[0], p[1], p[2]);
-        fg = white ? g < 255 : g > 0;
+    };
+    if (layout == APS_IMG_U8_HWC && (reinterpret_cast<uintptr_t>(img) & 3u) == 0) {
+        const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(img);
+        const int64_t nq = npx / 4;
+        for (int64_t q = t0; q < nq; q += stride) {
+            const uint32_t a = s32[3 * q], b = s32[3 * q + 1], c = s32[3 * q + 2];
+            if (!white && (a | b | c) == 0) continue;  // twelve zero bytes: four canvas pixels
+            see(4 * q, a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+            see(4 * q + 1, a >> 24, b & 255u, (b >> 8) & 255u);
+            see(4 * q + 2, (b >> 16) & 255u, b >> 24, c & 255u);
+            see(4 * q + 3, (c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+        }
+        for (int64_t p = nq * 4 + t0; p < npx; p += stride) see(p, img[3 * p], img[3 * p + 1], img[3 * p + 2]);
+    } else {
+        for (int64_t p = t0; p < npx; p += stride) {
+            if (layout == APS_IMG_U8_HWC) {
+                see(p, img[3 * p], img[3 * p + 1], img[3 * p + 2]);
+            } else {  // MATLAB h x w x 3 planes, column-major: walk memory order, (row, col) = (p % h, p / h)
+                const int64_t c = p / h, r = p - c * h;
+                see(r * w + c, img[p], img[npx + p], img[2 * npx + p]);
+            }
+        }
     }
-    const u64 m = __ballot(fg);
-    if (lane == 0 && m) {
-        const int c0 = (int)(blockIdx.x * 64) + (__ffsll((long long)m) - 1), c1 = (int)(blockIdx.x * 64) + (63 - __clzll((long long)m));
-        atomicMin(&s_box[0], (int)r);
-        atomicMax(&s_box[1], (int)r);
-        atomicMin(&s_box[2], c0);
-        atomicMax(&s_box[3], c1);
+    for (int off = 32; off > 0; off >>= 1) {
+        rmin = min(rmin, __shfl_xor(rmin, off));
+        rmax = max(rmax, __shfl_xor(rmax, off));
+        cmin = min(cmin, __shfl_xor(cmin, off));
+        cmax = max(cmax, __shfl_xor(cmax, off));
+    }
+    if ((threadIdx.x & 63) == 0 && rmax >= 0) {
+        atomicMin(&s_box[0], rmin);
+        atomicMax(&s_box[1], rmax);
+        atomicMin(&s_box[2], cmin);
+        atomicMax(&s_box[3], cmax);
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_box[1] >= 0) {
@@ -532,7 +553,7 @@ extern "C" int aps_crop_nonzero_bbox(const uint8_t* img, int64_t h, int64_t w, i
         APS_HIP(hipMemcpyAsync(box, init, sizeof init, hipMemcpyHostToDevice, stream()));
         {
             Prof prof("crop_bbox");
-            crop_bbox_kernel<<<dim3(cdiv(w, 64), cdiv(h, 4)), 256, 0, stream()>>>(di, h, w, layout, canvas_white, box);
+            crop_bbox_kernel<<<2048, 256, 0, stream()>>>(di, h, w, layout, canvas_white, box);
         }
         check_launch("crop_bbox_kernel");
         int hb[4];

@@ -256,7 +256,7 @@ def gather_tiles_to_root(pano, tile, root=0):
     return pano
 
 
-def _match_pass(input, local_images, n, seed, times, dev):
+def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
     """Steps 1-4 on the current images: SIFT on the local shard, the descriptor exchange, the sharded pair matching
     and the sharded RANSAC verification (main.m:88-107 up to imageMatching).  Everything that is exchanged stays on
     the device; the host sees counts, candidate lists and the 3 x 3 models.
@@ -273,7 +273,8 @@ def _match_pass(input, local_images, n, seed, times, dev):
     ldesc, lkps = {}, {}
     mine_img = sorted(local_images)
     if mine_img:
-        for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img])):
+        ready = [image_events[i] for i in mine_img] if image_events is not None else None
+        for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
             ldesc[i] = d
             lkps[i] = torch.from_numpy(p).to(dev)
     times.add("features", t0)
@@ -397,7 +398,7 @@ def _sync_lib():
 
 
 def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None,
-                       local_originals=None):
+                       local_originals=None, image_events=None):
     """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
     local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
     pano_root: None = every panorama is combined on every rank; r = only rank r receives the tiles / panoramas of the
@@ -405,6 +406,8 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     local_originals: the unresized originals of the local images; with input.resizeImage and
     input.resizeImagePanoramaCluster set and more than one connected component they are resized per component and the
     extract -> match -> verify chain runs a second time (imageMatchingPanoramaConComps.m:48-91).
+    image_events: dict image index -> torch CUDA event that marks the local image as uploaded (end-to-end runs issue
+    the host-to-device copies on a side stream; SIFT of image k then waits for event k only).
     Returns (panorama of the component that holds the best-connected image, uint8 H x W x 3 CUDA tensor; info dict
     with info["panoramas"]: one entry per connected component of at least two images, in component order)."""
     from . import pipeline as pl
@@ -416,10 +419,14 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
 
     # 0) the render will need every source image everywhere: start that all-gather now, collect it at step 6
     t0 = time.perf_counter()
+    if ws > 1 and image_events is not None:
+        for ev in image_events.values():
+            ev.synchronize()  # the early image all-gather reads every local image
+        image_events = None
     img_gather = ImageGather(local_images, n, dev)
     times.add("exchange", t0)
 
-    res = _match_pass(input, local_images, n, seed, times, dev)
+    res = _match_pass(input, local_images, n, seed, times, dev, image_events)
 
     # 5) host segment (redundant on every rank): components, second pass if asked for, cameras per component
     t0 = time.perf_counter()

@@ -53,12 +53,15 @@ def _sync():
 _SIFT_POOL = None
 
 
-def sift_many(input, images, workers=8):
+def sift_many(input, images, workers=8, ready=None):
     """getFeaturePoints for many images — the reference runs this loop as a parfor (loadImages.m:82-99).
     Here a few host threads each drive their own HIP stream (the C ABI is thread-safe with per-thread streams
     and workspaces), so the small-octave launches and the count read-backs of one image overlap with the
     large-octave kernels of another.  Results are returned in input order and are independent of the
-    interleaving (every kernel is deterministic)."""
+    interleaving (every kernel is deterministic).
+    ready: optional list of torch CUDA events, one per image: the worker of image k waits for ready[k] (e.g. the end
+    of that image's host-to-device copy on a side stream) instead of a device-wide synchronisation, so the uploads of
+    later images overlap with the SIFT kernels of earlier ones."""
     global _SIFT_POOL
     import os
     import torch
@@ -68,20 +71,27 @@ def sift_many(input, images, workers=8):
 
     dev = _capi.is_torch(images[0]) and images[0].is_cuda
     if len(images) <= 1 or workers <= 1:
+        if ready is not None:
+            for ev in ready:
+                ev.synchronize()
+        elif dev:
+            torch.cuda.synchronize()
         out = [fm.sift_extract(input, img, device_out=dev) for img in images]
         _sync()
         return out
-    if dev:
+    if dev and ready is None:
         torch.cuda.synchronize()  # the images were produced on torch's stream; worker streams must see them
     if _SIFT_POOL is None:
         _SIFT_POOL = ThreadPoolExecutor(max_workers=workers)
 
-    def work(img):
-        r = fm.sift_extract(input, img, device_out=dev)
+    def work(k):
+        if ready is not None:
+            ready[k].synchronize()
+        r = fm.sift_extract(input, images[k], device_out=dev)
         _sync()  # this thread's stream
         return r
 
-    return list(_SIFT_POOL.map(work, images))
+    return list(_SIFT_POOL.map(work, range(len(images))))
 
 
 def extract_features(input, images, times=None):
