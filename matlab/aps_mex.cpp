@@ -360,6 +360,57 @@ static void cmd_ba(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                              mxGetScalar(prhs[6]) != 0, mxGetPr(plhs[0])));
 }
 
+// warped = aps_mex('image_warp', image (uint8 or single, h x w x c), H (3x3 double), [oh ow], x0, y0, sx, sy, fillValue)
+// imageWarp.m:39-168 'bilinear'.  MATLAB arrays are planar column-major; the C ABI wants row-major interleaved.
+template <class T>
+static mxArray* warp_typed(const mxArray* img, const double* H, int oh, int ow, double x0, double y0, double sx, double sy,
+                           double fill, mxClassID cls) {
+    const mwSize* d = mxGetDimensions(img);
+    const int h = (int)d[0], w = (int)d[1], c = mxGetNumberOfDimensions(img) > 2 ? (int)d[2] : 1;
+    const T* src = (const T*)mxGetData(img);
+    std::vector<T> in((size_t)h * w * c), out((size_t)oh * ow * c);
+    for (int q = 0; q < c; ++q)
+        for (int x = 0; x < w; ++x)
+            for (int y = 0; y < h; ++y) in[((size_t)y * w + x) * c + q] = src[(size_t)q * h * w + (size_t)x * h + y];
+    if (sizeof(T) == 1)
+        check(aps_image_warp_h_u8((const uint8_t*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (uint8_t)fill, (uint8_t*)out.data()));
+    else
+        check(aps_image_warp_h_f32((const float*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (float)fill, (float*)out.data()));
+    const mwSize dims[3] = {(mwSize)oh, (mwSize)ow, (mwSize)c};
+    mxArray* o = mxCreateNumericArray(c > 1 ? 3 : 2, dims, cls, mxREAL);
+    T* dst = (T*)mxGetData(o);
+    for (int q = 0; q < c; ++q)
+        for (int x = 0; x < ow; ++x)
+            for (int y = 0; y < oh; ++y) dst[(size_t)q * oh * ow + (size_t)x * oh + y] = out[((size_t)y * ow + x) * c + q];
+    return o;
+}
+static void cmd_image_warp(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    (void)nlhs;
+    need(nrhs == 9 && (mxIsUint8(prhs[1]) || mxIsSingle(prhs[1])) && mxIsDouble(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 9,
+         "aps:type", "usage: image (uint8|single), H 3x3 double, [oh ow], x0, y0, sx, sy, fillValue");
+    const double* sz = mxGetPr(prhs[3]);
+    const int oh = (int)sz[0], ow = (int)sz[1];
+    const double x0 = mxGetScalar(prhs[4]), y0 = mxGetScalar(prhs[5]), sx = mxGetScalar(prhs[6]), sy = mxGetScalar(prhs[7]);
+    const double fill = mxGetScalar(prhs[8]);
+    if (mxIsUint8(prhs[1]))
+        plhs[0] = warp_typed<uint8_t>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, mxUINT8_CLASS);
+    else
+        plhs[0] = warp_typed<float>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, mxSINGLE_CLASS);
+}
+
+// [rect, didCrop] = aps_mex('crop_nonzero_bbox', panorama uint8 h x w x 3, canvasWhite)   rect = [r1 r2 c1 c2]
+static void cmd_crop_bbox(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 3 && mxIsUint8(prhs[1]) && mxGetNumberOfDimensions(prhs[1]) == 3, "aps:type", "usage: uint8 h x w x 3 panorama, canvasWhite");
+    const mwSize* d = mxGetDimensions(prhs[1]);
+    int64_t rect[4];
+    int did = 0;
+    check(aps_crop_nonzero_bbox((const uint8_t*)mxGetData(prhs[1]), (int64_t)d[0], (int64_t)d[1], APS_IMG_U8_MATLAB,
+                                mxGetScalar(prhs[2]) != 0, rect, &did));
+    plhs[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
+    for (int e = 0; e < 4; ++e) mxGetPr(plhs[0])[e] = (double)rect[e];
+    if (nlhs > 1) plhs[1] = mxCreateLogicalScalar(did != 0);
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs >= 1 && mxIsChar(prhs[0]), "aps:args", "usage: aps_mex(command, ...)");
     const std::string cmd = str(prhs[0]);
@@ -379,5 +430,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "imresize_u8") cmd_imresize(nlhs, plhs, nrhs, prhs);
     else if (cmd == "crop_rect") cmd_crop(nlhs, plhs, nrhs, prhs);
     else if (cmd == "ba_pair_blocks") cmd_ba(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "image_warp") cmd_image_warp(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "crop_nonzero_bbox") cmd_crop_bbox(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("aps:args", "unknown command '%s'", cmd.c_str());
 }
