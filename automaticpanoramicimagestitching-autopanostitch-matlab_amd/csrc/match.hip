@@ -1056,8 +1056,8 @@ __global__ void filter_emit_kernel(const FilterJob* __restrict__ fj, int njobs,
                                    const unsigned long long* __restrict__ job_ptr,  // exclusive scan
                                    const uint32_t* __restrict__ idx, int unique,
                                    uint32_t* __restrict__ o1, uint32_t* __restrict__ o2,
-                                   float* __restrict__ metric, int64_t cap) {
-    const int j = blockIdx.y;
+                                   float* __restrict__ metric, int64_t cap, int job0) {
+    const int j = job0 + blockIdx.y;  // gridDim.y <= 65535: the host walks the jobs in chunks
     const FilterJob f = fj[j];
     const unsigned long long base = job_ptr[j];
     const unsigned long long cnt = job_ptr[j + 1] - base;
@@ -1080,8 +1080,8 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
                                         const uint32_t* __restrict__ idx,
                                         const float* __restrict__ d1, uint32_t* __restrict__ o1,
                                         uint32_t* __restrict__ o2, float* __restrict__ metric,
-                                        int64_t cap) {
-    const int j = blockIdx.y;
+                                        int64_t cap, int job0) {
+    const int j = job0 + blockIdx.y;
     const FilterJob f = fj[j];
     const unsigned long long base = job_ptr[j];
     const unsigned long long cnt = job_ptr[j + 1] - base;
@@ -1098,19 +1098,6 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
 __global__ void keys_rows_only_kernel(unsigned long long* __restrict__ keys, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n && keys[i] != ~0ull) keys[i] &= 0xffffffffull;
-}
-
-__global__ void scan_counts_kernel(const unsigned long long* __restrict__ cnt, int n,
-                                   unsigned long long* __restrict__ ptr) {
-    // single thread: n is the number of image pairs (<= a few 10^5), run once per call
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (int i = 0; i < n; ++i) {
-            ptr[i] = s;
-            s += cnt[i];
-        }
-        ptr[n] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1323,10 +1310,10 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
     APS_HIP(hipMemcpyAsync(dfj, fjobs.data(), njobs * sizeof(FilterJob), hipMemcpyHostToDevice,
                            stream()));
     Ws<unsigned long long> keys(total_rows), sorted(total_rows), winner(std::max<int64_t>(total_cols, 1)),
-        cnt(njobs);
+        cnt(njobs + 1);
     APS_HIP(hipMemsetAsync(winner, 0xff, std::max<int64_t>(total_cols, 1) * sizeof(unsigned long long),
                            stream()));
-    APS_HIP(hipMemsetAsync(cnt, 0, njobs * sizeof(unsigned long long), stream()));
+    APS_HIP(hipMemsetAsync(cnt, 0, (njobs + 1) * sizeof(unsigned long long), stream()));
     const double r2 = o.max_ratio * o.max_ratio;  // opt.MaxRatio^2 in double (matchFeaturesScratch.m:170-173)
     Prof prof("match_filter");
     const unsigned grid = cdiv(total_rows, 256);
@@ -1340,8 +1327,14 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
         keys_rows_only_kernel<<<grid, 256, 0, stream()>>>(keys, total_rows);
         check_launch("keys_rows_only_kernel");
     }
-    scan_counts_kernel<<<1, 64, 0, stream()>>>(cnt, njobs, d_job_ptr);
-    check_launch("scan_counts_kernel");
+    {  // job_ptr = exclusive scan of the per-job counts, with the total in slot njobs (cnt[njobs] is a zero pad)
+        size_t sb = 0;
+        APS_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.get(), d_job_ptr, 0ull, (size_t)njobs + 1,
+                                        rocprim::plus<unsigned long long>(), stream()));
+        Ws<char> stmp(sb);
+        APS_HIP(rocprim::exclusive_scan(stmp.get(), sb, cnt.get(), d_job_ptr, 0ull, (size_t)njobs + 1,
+                                        rocprim::plus<unsigned long long>(), stream()));
+    }
 
     // segmented ascending sort of each job's keys; dropped rows (~0) sink to the segment's end
     std::vector<int64_t> seg(njobs + 1);
@@ -1363,13 +1356,13 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
     APS_HIP(hipStreamSynchronize(stream()));  // also keeps fjobs/seg alive long enough
     if ((int64_t)total > cap) return (int64_t)total;
     if (total > 0) {
-        dim3 g(64, njobs);
-        if (o.unique)
-            filter_emit_kernel<<<g, 256, 0, stream()>>>(dfj, njobs, sorted, d_job_ptr, idx, 1, o1, o2,
-                                                         metric, cap);
-        else
-            filter_emit_rows_kernel<<<g, 256, 0, stream()>>>(dfj, sorted, d_job_ptr, idx, d1, o1, o2,
-                                                              metric, cap);
+        for (int job0 = 0; job0 < njobs; job0 += 65535) {  // gridDim.y is capped at 65535 (500 images = 124750 pairs)
+            const dim3 g(64, std::min(65535, njobs - job0));
+            if (o.unique)
+                filter_emit_kernel<<<g, 256, 0, stream()>>>(dfj, njobs, sorted, d_job_ptr, idx, 1, o1, o2, metric, cap, job0);
+            else
+                filter_emit_rows_kernel<<<g, 256, 0, stream()>>>(dfj, sorted, d_job_ptr, idx, d1, o1, o2, metric, cap, job0);
+        }
         check_launch("filter_emit_kernel");
     }
     APS_HIP(hipStreamSynchronize(stream()));

@@ -698,6 +698,8 @@ static void check_opts(const aps_ransac_opts& o) {
 }
 
 // The sequential part of the loop (:94-143) over pre-scored draws.  Returns the winning draw or -1.
+static thread_local int g_draws_exhausted = 0;  // pairs of this thread's last call whose draws ran out (see aps.h)
+
 static int replay_loop(const uint8_t* valid, const int32_t* n_inl, const double* mean_err,
                        int n_samples, int64_t m, const aps_ransac_opts& o, int* trials_used) {
     const int min_pts = 4;
@@ -732,6 +734,9 @@ static int replay_loop(const uint8_t* valid, const int32_t* n_inl, const double*
         }
         ++trial;
     }
+    // the reference keeps drawing until trial > maxTrials or skipTrials reaches 10*maxIter (:94); here the draws are
+    // an input, and running out of them first means the sequential loop would have gone on
+    if (it == n_samples && trial <= max_trials && skip < max_skip) ++g_draws_exhausted;
     if (trials_used) *trials_used = it;
     return best_it;
 }
@@ -769,6 +774,7 @@ static int replay_mlesac(const uint8_t* valid, const int32_t* n_inl, const doubl
         }
         ++idx;
     }
+    if (it == n_samples && idx <= num_trials && skip < max_skip) ++g_draws_exhausted;
     if (trials_used) *trials_used = it;
     return best_it;
 }
@@ -821,6 +827,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     APS_HIP(hipMemcpyAsync(h_merr.data(), merr, nh * sizeof(double), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
     if (trials_out) trials_out->assign(n_pairs, 0);
+    g_draws_exhausted = 0;
     for (int p = 0; p < n_pairs; ++p) {
         int used = 0;
         h_best[p] = (mlesac ? replay_mlesac : replay_loop)(h_valid.data() + (int64_t)p * n_samples,
@@ -871,6 +878,8 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
         APS_HIP(hipStreamSynchronize(stream()));
     });
 }
+
+int aps_ransac_draws_exhausted(void) { return g_draws_exhausted; }
 
 int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
                             uint64_t seed, uint32_t* sample_idx) {

@@ -383,9 +383,16 @@ def sift_extract(input, image, device_out=False, want_aux=False):
         break
     n = cnt.value
     pts = np.ascontiguousarray(loc[:, :n].T)
+    # the capacity buffer is sized for the worst case (H*W/64 rows = 66 MB for a 4K view): hand back a right-sized copy
+    # instead of a view that keeps it alive (64 views would pin ~4 GB); the library synchronised its stream above
+    if device_out:
+        d = desc[:n].clone()
+        torch.cuda.current_stream().synchronize()  # the copy ran on torch's stream; consumers run on the library's
+    else:
+        d = np.ascontiguousarray(desc[:n])
     if want_aux:
-        return desc[:n], pts, aux[:n]
-    return desc[:n], pts
+        return d, pts, aux[:n].copy()
+    return d, pts
 
 
 def getFeaturePoints(input, ImageOriginal):

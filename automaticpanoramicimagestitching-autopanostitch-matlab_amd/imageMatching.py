@@ -195,6 +195,21 @@ def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
     return models.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mask[:total], found, ninl
 
 
+def ransac_batch_drawn(pts_src, pts_dst, pair_ptr, counts, input, seed=0, keys=None):
+    """ransac_batch with the draws made here: maxIter + 64 subsets per pair from the counter-based stream, and - when a
+    pair burns through them on invalid / degenerate subsets before the loop's own stopping rule (the reference keeps
+    drawing up to 10*maxIter skipped trials, estimateTransformationRANSAC.m:94) - again with four times as many.  The
+    stream only gets longer, so pairs that did not run out reproduce their result."""
+    max_iter = int(input.get("maxIter", 500))
+    n_samples, limit = max_iter + 64, 11 * max_iter + 64
+    while True:
+        samples = draw_samples_device(counts, n_samples, seed, keys=keys)
+        out = ransac_batch(pts_src, pts_dst, pair_ptr, samples, input)
+        if lib.aps_ransac_draws_exhausted() == 0 or n_samples >= limit:
+            return out
+        n_samples = min(4 * n_samples, limit)
+
+
 def candidate_pairs(matchesAll, n, m):
     """Top-m candidate selection of imageMatching.m:76-100 (Brown-Lowe m = 6): union over images of the m
     partners with the most putative matches (stable descending sort), upper triangle, column-major order."""

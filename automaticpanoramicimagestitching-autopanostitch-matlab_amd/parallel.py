@@ -342,7 +342,6 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
     mine = [p for k, p in enumerate(work) if k % ws == rank]
     times.add("im_select", t0)
     t0 = time.perf_counter()
-    n_samples = int(input["maxIter"]) + 64
     rec = torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev)  # model (9), found, inliers
     if mine:
         cnts = [int(n_match[p]) for p in mine]
@@ -363,10 +362,9 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
         dst = kp_all.index_select(0, row_i).t().contiguous()
         src = kp_all.index_select(0, row_j).t().contiguous()
         torch.cuda.current_stream().synchronize()  # torch's stream produced dst/src; the library runs on its own
-        samples = im.draw_samples_device(cnts, n_samples, seed, keys=mine)
         times.add("im_gather", t0)
         t0 = time.perf_counter()
-        models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
+        models, mask, found, ninl = im.ransac_batch_drawn(src, dst, wptr, cnts, input, seed, keys=mine)
         times.add("im_ransac", t0)
         t0 = time.perf_counter()
         wk = {p: k for k, p in enumerate(work)}

@@ -141,8 +141,7 @@ def match_and_verify(input, descs, kps, seed=0, times=None, pair_subset=None):
         wptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         src = np.concatenate([kps[j][jj[s:e].astype(np.int64) - 1] for (_, j, s, e) in work])
         dst = np.concatenate([kps[i][ii[s:e].astype(np.int64) - 1] for (i, _, s, e) in work])
-        samples = im.draw_samples_device(counts, int(input["maxIter"]) + 64, seed)
-        models, mask, found, ninl = im.ransac_batch(src, dst, wptr, samples, input)
+        models, mask, found, ninl = im.ransac_batch_drawn(src, dst, wptr, counts, input, seed)
         for w, (i, j, s, e) in enumerate(work):
             nf = e - s
             ni = int(ninl[w]) if found[w] else 0

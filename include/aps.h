@@ -209,6 +209,13 @@ int aps_ransac_homography(const double* p1, const double* p2, int64_t m, int64_t
                           const uint32_t* sample_idx, int n_samples, const aps_ransac_opts* opts,
                           double* model, uint8_t* inlier_mask, int* is_found, int* trials_used);
 
+/* Number of pairs in the calling thread's most recent aps_ransac_homography / aps_ransac_homography_batch call whose
+ * n_samples pre-drawn subsets ran out BEFORE the sequential loop's own stopping rule (trial > maxTrials, or 10*maxIter
+ * skipped draws, estimateTransformationRANSAC.m:94): the reference would have kept drawing, so for those pairs the result
+ * is that of a truncated loop.  Callers that want the reference's behaviour re-run with more draws (the counter-based
+ * draw stream of aps_ransac_draw_samples only gets longer: earlier draws do not change). */
+int aps_ransac_draws_exhausted(void);
+
 /* The seeded stand-in for randperm(numPoints, 4) (estimateTransformationRANSAC.m:96): fills sample_idx
  * (uint32 4 x n_samples x n_pairs, 1-based) with distinct 4-subsets of 1..counts[p] from the counter-based
  * stream u = mix64(seed, keys[p] (or p if keys is NULL), 4*iteration + k) — identical to

@@ -192,3 +192,34 @@ def test_ransac_shards_do_not_depend_on_the_partition(gpu):
         for k, p in enumerate(shard):
             assert np.array_equal(m2[k].view(np.uint64), models[p].view(np.uint64)) and n2[k] == ninl[p]
             assert np.array_equal(k2[s_ptr[k]:s_ptr[k + 1]], mask[ptr[p]:ptr[p + 1]])
+
+
+def test_draw_exhaustion_is_reported_and_the_drawn_form_retries(gpu, im):
+    """Matches with non-finite coordinates make nearly every 4-subset unusable: the draw is skipped, and the loop only
+    ends after 10*maxIter skipped draws (estimateTransformationRANSAC.m:94).  With fewer
+    pre-drawn subsets the library stops where the draws stop and says so (aps_ransac_draws_exhausted);
+    ransac_batch_drawn then redraws with a longer stream until the loop's own rule ends it."""
+    capi = gpu._capi
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 400, (40, 2))
+    pts[:36] = np.nan  # a subset that touches a NaN point cannot be fitted: the draw is skipped (:100-104)
+    q = pts + 5.0
+    inp = {"maxDistance": 5.5, "inliersConfidence": 99.9, "maxIter": 20}
+    s = im.draw_samples([40], 84, seed=1)
+    im.ransac_batch(pts, q, np.array([0, 40]), s, inp)
+    assert capi.lib.aps_ransac_draws_exhausted() == 1
+    s = im.draw_samples([40], 300, seed=1)  # 10 * maxIter = 200 skipped draws end the loop first
+    im.ransac_batch(pts, q, np.array([0, 40]), s, inp)
+    assert capi.lib.aps_ransac_draws_exhausted() == 0
+    im.ransac_batch_drawn(pts, q, np.array([0, 40]), [40], inp, seed=1)
+    assert capi.lib.aps_ransac_draws_exhausted() == 0
+    # fewer draws than trials on an ordinary pair is reported too; the drawn form never runs out on one
+    rng = np.random.default_rng(0)
+    p1 = rng.uniform(0, 500, (80, 2))
+    p2 = p1 + [30.0, -12.0] + rng.standard_normal((80, 2)) * 3.0
+    p2[::2] = rng.uniform(0, 500, (40, 2))
+    inp5 = {"maxDistance": 5.5, "inliersConfidence": 99.9, "maxIter": 500}
+    im.ransac_batch(p1, p2, np.array([0, 80]), im.draw_samples([80], 3, seed=2), inp5)
+    assert capi.lib.aps_ransac_draws_exhausted() == 1
+    _, _, found, ninl = im.ransac_batch_drawn(p1, p2, np.array([0, 80]), [80], inp5)
+    assert found[0] == 1 and ninl[0] >= 10 and capi.lib.aps_ransac_draws_exhausted() == 0
