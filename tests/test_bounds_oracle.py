@@ -111,30 +111,20 @@ def test_auto_reference_picks_the_smallest_canvas(rp):
     assert int(np.argmin(areas)) == w["refIdx"]
 
 
-def test_crop_nonzero_bbox_equals_the_oracle_and_known_answers(rp):
+def test_crop_nonzero_bbox_known_answers():
+    """cropNonzeroBbox of the oracle against hand-derived rectangles (the device version is compared with the oracle in
+    tests/test_crop_gpu.py)."""
     img = np.zeros((60, 90, 3), np.uint8)
     img[20:31, 40:56] = (10, 200, 30)
     img[5, 7] = (0, 0, 4)    # rgb2gray = round(0.456) = 0: NOT foreground
     img[50, 80] = (0, 0, 5)  # rgb2gray = round(0.570) = 1: foreground
     rect, did = oracle.crop_nonzero_bbox(img)
     assert did and rect == (15, 57, 35, 87)
-    out, r2, d2 = rp.cropNonzeroBbox(img, "black")
-    assert d2 and tuple(r2) == rect and out.shape == (43, 53, 3)
     white = np.full((40, 50, 3), 255, np.uint8)
     white[10:12, 20:25] = (255, 255, 250)  # gray 254.43 -> 254 < 255: foreground
     white[30, 40] = (255, 255, 252)        # gray 254.66 -> 255: canvas
     rect, did = oracle.crop_nonzero_bbox(white, True)
     assert did and rect == (5, 18, 15, 31)
-    _, r3, d3 = rp.cropNonzeroBbox(white, "white")
-    assert d3 and tuple(r3) == rect
-    empty = np.zeros((8, 9, 3), np.uint8)
-    assert oracle.crop_nonzero_bbox(empty) == ((1, 8, 1, 9), False)
-    assert tuple(rp.cropNonzeroBbox(empty)[1]) == (1, 8, 1, 9) and rp.cropNonzeroBbox(empty)[2] is False
-    rng = np.random.default_rng(9)
-    for _ in range(5):
-        im = np.zeros((70, 110, 3), np.uint8)
-        r0, c0 = rng.integers(0, 50), rng.integers(0, 80)
-        im[r0:r0 + rng.integers(1, 20), c0:c0 + rng.integers(1, 30)] = rng.integers(0, 256, 3)
-        a, da = oracle.crop_nonzero_bbox(im)
-        _, b, db = rp.cropNonzeroBbox(im)
-        assert a == tuple(b) and da == db
+    assert oracle.crop_nonzero_bbox(np.zeros((8, 9, 3), np.uint8)) == ((1, 8, 1, 9), False)
+    full = np.full((8, 9, 3), 9, np.uint8)
+    assert oracle.crop_nonzero_bbox(full) == ((1, 8, 1, 9), True)
