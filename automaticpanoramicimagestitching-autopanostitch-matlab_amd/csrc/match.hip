@@ -634,12 +634,39 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
     }
 }
 
+// Bounds on a row's EXACT (canonical f32) best and second-best distance from its two largest screened values u0 >= u1
+// (columns c0, c1), with the same error terms as rescore_row:
+//   for every column j the computed distance satisfies d_j >= a2 - 2 U_j - eps (that is what certifies a row), and
+//   U_j <= u0 for all j, so   d1 = min_j d_j >= a2 - 2 u0 - eps =: L1;
+//   conversely U_j <= s_j + (na^ dn^_j + ||a|| dn_j) + eg, i.e. s_j >= U_j - slack with slack = eg + 2.02 na (max dn + 1e-6)
+//   (na^, dn^ are na, dn rounded UP to f16: < 0.1 % each), so the computed distances of c0 and c1 are both
+//   <= a2 - 2 (u1 - slack) + delta, and d2, the second smallest of ALL columns, is at most the larger of those two: H2.
+__device__ __forceinline__ void prune_bounds(const MatchJob& jb, int row, float u0r, float u1r, float aug_res, float dn_res,
+                                             float& L1, float& H2) {
+    const float a2 = jb.sqA[row];
+    const float msb = *jb.maxsqB, mdb = *jb.maxdnB;
+    const float nb = sqrtf(msb) * 1.000001f + mdb;
+    const float na = sqrtf(a2) * 1.000001f;
+    float eg = jb.dnA[row] * nb + aug_res + na * dn_res + 3.0517578125e-05f * (na * (nb + mdb) + 0.5f * msb);
+    if (!(na < 65000.f)) eg = INFINITY;
+    const float delta = 1.52587890625e-05f * (a2 + msb + 2.0f * na * nb) + 1e-37f;
+    const float eps = 2.002f * eg + delta;
+    const float slack = eg + 2.02f * na * (mdb + 1e-6f);
+    L1 = a2 - 2.0f * u0r - eps;
+    H2 = a2 - 2.0f * (u1r - slack) + delta;
+    if (!(eg < INFINITY)) {  // data outside the f16 range: nothing is dismissed
+        L1 = -INFINITY;
+        H2 = INFINITY;
+    }
+}
+
 __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __restrict__ jobs,
                                                                 const WgJob* __restrict__ wgs, int n_wg,
                                                                 uint32_t* __restrict__ out_idx,
                                                                 float* __restrict__ out_d1, float* __restrict__ out_d2,
                                                                 uint32_t* __restrict__ fb_list,
-                                                                unsigned int* __restrict__ fb_count, int ablate) {
+                                                                unsigned int* __restrict__ fb_count, int ablate,
+                                                                float prune_r2, float prune_thr) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kTileBytes];  // [buf][128][256 B], tile t in buf t % 3
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
@@ -963,15 +990,33 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     {
         const int src = lane & 31;  // every lane takes part in the exchange (a masked-off source lane would read as 0)
         const int s0 = __shfl(i0[1], src), s1 = __shfl(i1[1], src), s2 = __shfl(i2[1], src);
-        const float sb = __shfl(u3[1], src), sb2 = __shfl(u2[1], src);
+        const float sb = __shfl(u3[1], src), sb2 = __shfl(u2[1], src), sb1 = __shfl(u1[1], src), sb0 = __shfl(u0[1], src);
         const int c0 = h ? s0 : i0[0], c1 = h ? s1 : i1[0], c2 = h ? s2 : i2[0];
-        const float ub = h ? sb : u3[0], ub2 = h ? sb2 : u2[0];
+        const float ub = h ? sb : u3[0], ub2 = h ? sb2 : u2[0], ub1 = h ? sb1 : u1[0], ub0 = h ? sb0 : u0[0];
         const int row = row0 + 32 * h;
         if (row < nA && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
-            const float bnd = jb.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
-            const float bnd3 = jb.sqA[row] - 2.0f * ub2;  // ... and the 3rd
-            rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, jb.augresB[0], jb.augresB[1], out_idx, out_d1, out_d2, fb_list,
-                        fb_count);
+            // Rows that cannot pass the caller's ratio / threshold filter (matchFeaturesScratch.m:170-178) are dismissed
+            // on the screened values alone: d1 >= L1 and d2 <= H2 hold for the exact f32 distances (see prune_bounds), so
+            // L1 > r^2 H2 (or L1 > MatchThreshold) decides the filter's verdict without the exact evaluation - no gathers,
+            // no fallback.  Only the filtered entry points enable this (the raw 2-NN API reports exact distances always).
+            bool pruned = false;
+            if (prune_r2 > 0.f && nB >= 2 && c0 >= 0 && c0 < nB && c1 >= 0 && c1 < nB) {
+                float L1, H2;
+                prune_bounds(jb, row, ub0, ub1, jb.augresB[0], jb.augresB[1], L1, H2);
+                const float lo = L1 * (1.0f - 1e-5f) - 1e-30f;
+                pruned = H2 >= 0.f && (lo > prune_r2 * H2 * (1.0f + 1e-5f) || lo > prune_thr * (1.0f + 1e-5f));
+            }
+            if (pruned) {
+                const int64_t slot = jb.out_off + row;
+                out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter would drop too)
+                out_d1[slot] = INFINITY;
+                out_d2[slot] = INFINITY;
+            } else {
+                const float bnd = jb.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
+                const float bnd3 = jb.sqA[row] - 2.0f * ub2;  // ... and the 3rd
+                rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, jb.augresB[0], jb.augresB[1], out_idx, out_d1, out_d2, fb_list,
+                            fb_count);
+            }
         }
     }
 #ifdef APS_MATCH_TIMING
@@ -1206,7 +1251,10 @@ __global__ void fb_compact_kernel(const MatchJob* __restrict__ jobs, const uint3
 }
 
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
-static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2) {
+// prune_r2 > 0: the caller will apply the ratio / threshold filter with these constants, so rows that cannot pass it
+// may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
+static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2, float prune_r2 = 0.f,
+                           float prune_thr = 0.f) {
     std::vector<WgJob> wgs;
     for (int j = 0; j < (int)jobs.size(); ++j)
         for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r, 0});
@@ -1246,7 +1294,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         const int ablate = 0;
 #endif
         match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
-                                                                          fb_count, ablate);
+                                                                          fb_count, ablate, prune_r2, prune_thr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
@@ -1522,7 +1570,12 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     Ws<uint32_t> idx(std::max<int64_t>(rows, 1));
     Ws<float> d1(std::max<int64_t>(rows, 1)), d2(std::max<int64_t>(rows, 1));
     const auto T2 = t_now();
-    run_match_jobs(jobs, idx, d1, d2);
+    // the filter below keeps a row iff d1 <= r^2 d2 and d1 <= MatchThreshold (f64): the candidate kernel may dismiss rows
+    // that provably fail it.  The constants are rounded so that the kernel's f32 tests err on the side of keeping a row.
+    const bool prune = !std::getenv("APS_MATCH_NO_PRUNE");
+    const float pr2 = prune ? std::nextafter((float)(o.max_ratio * o.max_ratio), INFINITY) : 0.f;
+    const float pthr = std::nextafter((float)o.match_threshold, INFINITY);
+    run_match_jobs(jobs, idx, d1, d2, pr2, pthr);
     const auto T3 = t_now();
 
     Out<uint32_t> oi(idx_i, cap), oj(idx_j, cap);

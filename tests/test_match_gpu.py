@@ -407,3 +407,32 @@ def test_worker_threads_inherit_the_selected_device(gpu, monkeypatch):
     th.start()
     th.join()
     assert out["rc"] == 0, out
+
+
+def test_filter_aware_dismissal_changes_no_match(fm, monkeypatch):
+    """The candidate kernel dismisses rows whose screened values already prove that the ratio / threshold filter drops
+    them (no exact evaluation, no fallback).  The match lists must equal the oracle's and those of a run with the
+    dismissal off (APS_MATCH_NO_PRUNE=1): planted correspondences at every noise level from clear matches to clear
+    non-matches, ratios scattered around the boundary, several MaxRatio / MatchThreshold settings."""
+    rng = np.random.default_rng(31)
+    a, b, ia, ib = planted_pair(rng, 3000, 3500, 1500, noise=0.02)
+    # spread the planted pairs' noise so that their ratios cover 0.05 .. 1
+    noise = rng.uniform(0.0, 0.25, len(ib))[:, None]
+    pert = a[ia] + noise * rng.standard_normal((len(ia), 128)).astype(np.float32)
+    pert = np.maximum(pert, 0)
+    pert /= np.linalg.norm(pert, axis=1, keepdims=True) + 1e-12
+    b[ib] = pert.astype(np.float32)
+    for ratio, thr, unique in ((0.6, 1.5, True), (0.8, 1.5, True), (0.95, 0.4, False), (1.0, 3.5, True), (0.3, 0.05, True)):
+        monkeypatch.delenv("APS_MATCH_NO_PRUNE", raising=False)
+        m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+        monkeypatch.setenv("APS_MATCH_NO_PRUNE", "1")
+        m0, met0 = fm.matchFeaturesScratch(a, b, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+        om, omet = oracle.match_features(a, b, ratio, thr, unique, 2)
+        assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet)), (ratio, thr)
+        assert np.array_equal(m0, om) and np.array_equal(bits(met0), bits(omet))
+    monkeypatch.delenv("APS_MATCH_NO_PRUNE", raising=False)
+    # the boundary fixtures (d1/d2 within a few 1e-6 of r^2): the dismissal must stay clear of them
+    a2, b2 = _boundary_sets((0.36, None))
+    m, met = fm.matchFeaturesScratch(a2, b2, MatchThreshold=3.5, MaxRatio=0.6, Unique=False)
+    om, omet = oracle.match_features(a2, b2, 0.6, 3.5, False, 0)
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
