@@ -260,6 +260,58 @@ __global__ void hamming_kernel(const uint32_t* __restrict__ A, int64_t n1, const
     d2[i] = (float)second;
 }
 
+// ---- Hamming k-NN: the uint8 branches of flann_knn.cpp (:199-223 BFMatcher knnMatch, :235-240 LSH index) ----------
+// one thread per query row (its bytes in registers), train rows through LDS; ascending (distance, index) list of K.
+// A candidate enters in front of every entry with a LARGER distance: among equal distances the lower index stays first.
+template <int NW, int K>
+__global__ void hamming_knn_kernel(const uint32_t* __restrict__ Q, int64_t nq, const uint32_t* __restrict__ T, int64_t nt,
+                                   int k_out, uint32_t* __restrict__ idx, float* __restrict__ dist, int64_t ldo, int layout) {
+    __shared__ uint32_t s_t[256 * NW];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t a[NW];
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) a[wv] = i < nq ? Q[i * NW + wv] : 0u;
+    unsigned v[K];
+    int id[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        v[e] = 0xFFFFFFFFu;
+        id[e] = -1;
+    }
+    for (int64_t j0 = 0; j0 < nt; j0 += 256) {
+        const int cnt = (int)(nt - j0 < 256 ? nt - j0 : 256);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * NW; e += blockDim.x) s_t[e] = T[j0 * NW + e];
+        __syncthreads();
+        for (int jj = 0; jj < cnt; ++jj) {
+            unsigned hsum = 0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) hsum += __popc(a[wv] ^ s_t[jj * NW + wv]);
+            if (hsum < v[K - 1]) {
+                const int j = (int)(j0 + jj);
+                bool lt[K];
+#pragma unroll
+                for (int e = 0; e < K; ++e) lt[e] = hsum < v[e];
+#pragma unroll
+                for (int e = K - 1; e >= 1; --e) {
+                    v[e] = lt[e - 1] ? v[e - 1] : (lt[e] ? hsum : v[e]);
+                    id[e] = lt[e - 1] ? id[e - 1] : (lt[e] ? j : id[e]);
+                }
+                v[0] = lt[0] ? hsum : v[0];
+                id[0] = lt[0] ? j : id[0];
+            }
+        }
+    }
+    if (i >= nq) return;
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        if (e >= k_out) break;
+        const size_t o = layout == APS_ROWMAJOR ? (size_t)i * ldo + e : (size_t)i + (size_t)e * ldo;
+        idx[o] = id[e] >= 0 ? (uint32_t)id[e] + 1u : 0u;           // missing neighbour: index 0 (flann_knn.cpp:217)
+        dist[o] = id[e] >= 0 ? (float)v[e] : INFINITY;              // ... and Inf (:218)
+    }
+}
+
 __global__ void pack_bytes_kernel(const uint8_t* __restrict__ X, int64_t n, int64_t ld, int nbytes, int layout, int nw,
                                   uint32_t* __restrict__ out) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -428,6 +480,50 @@ int aps_hamming_2nn(const uint8_t* A, int64_t n1, int64_t lda, const uint8_t* B,
         oi.commit();
         o1.commit();
         o2.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_knn_hamming(const uint8_t* train, int64_t ft, int64_t ldt, const uint8_t* query, int64_t fq, int64_t ldq, int nbytes,
+                    int layout, int k, uint32_t* idx, float* dist, int64_t ldo) {
+    return guarded([&] {
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(k > 0, APS_E_ARG, "k must be > 0");  // flann_knn:k
+        APS_REQUIRE(k <= 8, APS_E_ARG, "k <= 8 supported (featureMatchingGlobal uses k = 4)");
+        APS_REQUIRE(nbytes > 0 && nbytes <= 64, APS_E_DIM, "byte width must be in 1..64 (ORB 32, BRISK 64)");
+        APS_REQUIRE(ft >= 0 && fq >= 0 && ft < (1ll << 31) && fq < (1ll << 31), APS_E_ARG, "bad sizes");
+        APS_REQUIRE(fq == 0 || (idx && dist && query), APS_E_ARG, "NULL argument");
+        APS_REQUIRE(ft == 0 || train, APS_E_ARG, "NULL train");
+        if (layout == APS_ROWMAJOR)
+            APS_REQUIRE(ldt >= nbytes && ldq >= nbytes && ldo >= k, APS_E_DIM, "query must have same descriptor dimension as train");
+        else
+            APS_REQUIRE(ldt >= ft && ldq >= fq && ldo >= fq, APS_E_DIM, "leading dimension too small");
+        ctx();
+        if (fq == 0) return;
+        const size_t te = ft == 0 ? 0 : (layout == APS_ROWMAJOR ? (size_t)(ft - 1) * ldt + nbytes : (size_t)(nbytes - 1) * ldt + ft);
+        const size_t qe = layout == APS_ROWMAJOR ? (size_t)(fq - 1) * ldq + nbytes : (size_t)(nbytes - 1) * ldq + fq;
+        const size_t oe = layout == APS_ROWMAJOR ? (size_t)(fq - 1) * ldo + k : (size_t)(k - 1) * ldo + fq;
+        In<uint8_t> dT(train, te), dQ(query, qe);
+        Out<uint32_t> oi(idx, oe);
+        Out<float> od(dist, oe);
+        const int nw = nbytes <= 32 ? 8 : 16;
+        Ws<uint32_t> pt((size_t)std::max<int64_t>(ft, 1) * nw), pq((size_t)fq * nw);
+        if (ft > 0) pack_bytes_kernel<<<cdiv((size_t)ft * nw, 256), 256, 0, stream()>>>(dT, ft, ldt, nbytes, layout, nw, pt);
+        pack_bytes_kernel<<<cdiv((size_t)fq * nw, 256), 256, 0, stream()>>>(dQ, fq, ldq, nbytes, layout, nw, pq);
+        {
+            Prof prof("hamming_knn");
+            const unsigned g = cdiv(fq, 256);
+#define APS_HK(NWV, KV) hamming_knn_kernel<NWV, KV><<<g, 256, 0, stream()>>>(pq, fq, pt, ft, k, oi.get(), od.get(), ldo, layout)
+            if (nw == 8) {
+                if (k <= 2) APS_HK(8, 2); else if (k <= 4) APS_HK(8, 4); else APS_HK(8, 8);
+            } else {
+                if (k <= 2) APS_HK(16, 2); else if (k <= 4) APS_HK(16, 4); else APS_HK(16, 8);
+            }
+#undef APS_HK
+        }
+        check_launch("hamming_knn_kernel");
+        oi.commit();
+        od.commit();
         APS_HIP(hipStreamSynchronize(stream()));
     });
 }

@@ -409,14 +409,30 @@ def getFeaturePoints(input, ImageOriginal):
 
 # ---- global matcher (featureMatchingGlobal.m) and the mex contracts it calls ------------------------
 def flann_knn_win(train, query, k, method="flann", trees=4, checks=32):
-    """[idx, dist] = flann_knn_win(train, query, k, 'flann', trees, checks) (PP/mex/flann_knn.cpp:118-253) for
-    float descriptors, computed EXACTLY on the device (the reference's kd-forest is approximate and
+    """[idx, dist] = flann_knn_win(train, query, k, 'flann' | 'bf', trees, checks) (PP/mex/flann_knn.cpp:118-253) for
+    float (single) and binary (uint8) descriptors, computed EXACTLY on the device (the reference's kd-forest is approximate and
     seed-dependent; `trees`/`checks` are accepted and ignored).  idx: Fq x k uint32 1-based, dist: Fq x k
     single squared-L2, ascending."""
     if k != int(k) or k <= 0:
         raise ValueError("k must be > 0")  # flann_knn:k
-    if str(method) != "flann":
-        raise NotImplementedError("'bf' is the binary-descriptor BFMatcher path (see nearest2HammingExhaustiveMEX)")
+    tr = train if _capi.is_torch(train) else np.asarray(train)
+    if str(tr.dtype).endswith("uint8"):
+        # binary descriptors (flann_knn.cpp:199-223 'bf' = BFMatcher knnMatch; :235-240 'flann' = LSH index): ONE exact
+        # brute-force Hamming k-NN serves both; dist = Hamming distance as single, ascending, ties -> lower index
+        T = np.ascontiguousarray(train, np.uint8)
+        Q = np.ascontiguousarray(query, np.uint8)
+        if T.ndim != 2 or Q.ndim != 2:
+            raise ValueError("train must be 2-D")  # flann_knn:dim (checkReal2D)
+        if T.shape[1] != Q.shape[1]:
+            raise ValueError("query must have same descriptor dimension as train")  # flann_knn:dim
+        k = int(k)
+        idx = np.zeros((Q.shape[0], k), np.uint32)
+        dist = np.zeros((Q.shape[0], k), np.float32)
+        check(lib.aps_knn_hamming(ptr(T), T.shape[0], T.shape[1], ptr(Q), Q.shape[0], Q.shape[1], T.shape[1],
+                                  _capi.APS_ROWMAJOR, k, ptr(idx), ptr(dist), k))
+        return idx, dist
+    if str(method) == "bf":
+        raise ValueError("BFMatcher only supports uint8 (binary) descriptors")  # flann_knn:bf
     T, ft, ldt, lt = _as_desc(train)
     Q, fq, ldq, lq = _as_desc(query)
     if (ft and T.shape[1] != DIM) or (fq and Q.shape[1] != DIM) or lt != lq:

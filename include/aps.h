@@ -152,6 +152,14 @@ int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* que
                    int64_t ldq, int dim, int layout, int k, uint32_t* idx, float* dist,
                    int64_t ldo);
 
+/* a8 kNN, binary descriptors: [idx, dist] = flann_knn_win(train_u8, query_u8, k, 'bf' | 'flann', ...) - the uint8 branches
+ * of flann_knn.cpp: cv::BFMatcher(NORM_HAMMING).knnMatch (:199-223) and the LSH index (:235-240), both replaced by ONE exact
+ * brute-force Hamming k-NN (ascending distance, ties -> lower index; the LSH index is approximate and seed dependent).
+ * nbytes <= 64 (ORB 32, BRISK 64).  idx: 1-based uint32 Fq x k, dist: f32 Fq x k in `layout` with leading dimension ldo;
+ * a query with fewer than k train rows gets index 0 / Inf in the missing slots (:217-218). */
+int aps_knn_hamming(const uint8_t* train, int64_t ft, int64_t ldt, const uint8_t* query, int64_t fq, int64_t ldq,
+                    int nbytes, int layout, int k, uint32_t* idx, float* dist, int64_t ldo);
+
 /* a8 filter: the per-query loop of featureMatchingGlobal.m:123-161 (drop self, drop same-image,
  * need >= 2 left, reject iff d1/max(d2,eps('single')) > ratio, append [li lj] to pair (min,max) in
  * query order).  img_idx (1-based image id per row) and local_idx (1-based) are uint32[f].

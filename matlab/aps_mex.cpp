@@ -145,7 +145,9 @@ static void cmd_pairwise(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
 
 // [idx, dist] = aps_mex('knn_global', train, query, k)            (flann_knn_win contract)
 static void cmd_knn(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-    need(nrhs >= 4 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]), "flann_knn:type", "Descriptors must be single (float)");
+    const bool flt = nrhs >= 4 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]);
+    const bool bin = nrhs >= 4 && mxIsUint8(prhs[1]) && mxIsUint8(prhs[2]);
+    need(flt || bin, "flann_knn:type", "Descriptors must be single (float) or uint8 (binary)");
     need(mxIsDouble(prhs[3]) && mxGetNumberOfElements(prhs[3]) == 1, "flann_knn:type", "k must be a scalar double");
     const int k = (int)mxGetScalar(prhs[3]);
     need(k > 0, "flann_knn:k", "k must be > 0");
@@ -153,6 +155,10 @@ static void cmd_knn(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     const int64_t ft = mxGetM(prhs[1]), fq = mxGetM(prhs[2]);
     plhs[0] = mxCreateNumericMatrix(fq, k, mxUINT32_CLASS, mxREAL);
     mxArray* dist = mxCreateNumericMatrix(fq, k, mxSINGLE_CLASS, mxREAL);
+    if (bin)  // flann_knn.cpp:199-223 ('bf') and :235-240 (LSH): one exact Hamming k-NN
+        check(aps_knn_hamming((const uint8_t*)mxGetData(prhs[1]), ft, ft, (const uint8_t*)mxGetData(prhs[2]), fq, fq,
+                              (int)mxGetN(prhs[1]), APS_COLMAJOR, k, (uint32_t*)mxGetData(plhs[0]), (float*)mxGetData(dist), fq));
+    else
     check(aps_knn_global((const float*)mxGetData(prhs[1]), ft, ft, (const float*)mxGetData(prhs[2]), fq, fq, (int)mxGetN(prhs[1]),
                          APS_COLMAJOR, k, (uint32_t*)mxGetData(plhs[0]), (float*)mxGetData(dist), fq));
     if (nlhs > 1) plhs[1] = dist; else mxDestroyArray(dist);

@@ -576,3 +576,16 @@ def crop_nonzero_bbox(img, canvas_white=False):
     lib.orc_crop_nonzero_bbox.restype = _i
     did = lib.orc_crop_nonzero_bbox(a.ctypes.data, a.shape[0], a.shape[1], int(bool(canvas_white)), rect.ctypes.data)
     return tuple(int(v) for v in rect), bool(did)
+
+
+_orc_knn_hamming = _sig("orc_knn_hamming", [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp])
+
+
+def knn_hamming(train, query, k):
+    """Exact Hamming k-NN for packed binary descriptors (the uint8 branches of flann_knn.cpp): (idx 1-based, dist)."""
+    t = np.ascontiguousarray(train, np.uint8)
+    q = np.ascontiguousarray(query, np.uint8)
+    idx = np.zeros((q.shape[0], k), np.uint32)
+    dist = np.zeros((q.shape[0], k), np.float32)
+    _orc_knn_hamming(t.ctypes.data, t.shape[0], q.ctypes.data, q.shape[0], t.shape[1], int(k), idx.ctypes.data, dist.ctypes.data)
+    return idx, dist

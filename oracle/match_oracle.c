@@ -322,3 +322,35 @@ ORC_API void orc_hamming_2nn(const uint8_t* A, int64_t n1, const uint8_t* B, int
         d2[i] = (float)second;
     }
 }
+
+/* The uint8 branches of flann_knn.cpp (:199-223 BFMatcher(NORM_HAMMING).knnMatch, :235-240 LSH index) as ONE exact
+ * Hamming k-NN: ascending distance, ties -> lower train index; missing neighbours: index 0, distance Inf (:217-218).
+ * idx, dist: fq x k row-major. */
+ORC_API void orc_knn_hamming(const uint8_t* train, int64_t ft, const uint8_t* query, int64_t fq, int nb, int k,
+                             uint32_t* idx, float* dist) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < fq; ++i) {
+        int64_t best_i[16];
+        unsigned best_d[16];
+        int n = 0;
+        for (int64_t j = 0; j < ft; ++j) {
+            unsigned d = 0;
+            for (int b = 0; b < nb; ++b) d += (unsigned)__builtin_popcount((unsigned)(query[i * nb + b] ^ train[j * nb + b]));
+            int pos = n;
+            while (pos > 0 && d < best_d[pos - 1]) --pos; /* strictly smaller moves ahead: equal keeps the lower index first */
+            if (pos >= k) continue;
+            const int last = n < k ? n : k - 1;
+            for (int e = last; e > pos; --e) {
+                best_d[e] = best_d[e - 1];
+                best_i[e] = best_i[e - 1];
+            }
+            best_d[pos] = d;
+            best_i[pos] = j;
+            if (n < k) ++n;
+        }
+        for (int e = 0; e < k; ++e) {
+            idx[i * k + e] = e < n ? (uint32_t)(best_i[e] + 1) : 0u;
+            dist[i * k + e] = e < n ? (float)best_d[e] : INFINITY;
+        }
+    }
+}

@@ -94,3 +94,35 @@ def test_hamming_equals_oracle_including_edges(fm):
         fm.nearest2HammingExhaustiveMEX(A, B[:, :8])
     with pytest.raises(TypeError):
         fm.nearest2HammingExhaustiveMEX(A.astype(np.float32), B)
+
+
+@pytest.mark.parametrize("nb,k", [(32, 4), (64, 4), (32, 1), (32, 8), (20, 3)])
+def test_hamming_knn_equals_oracle_and_known_answers(gpu, nb, k):
+    """flann_knn_win on uint8 descriptors ('bf' = BFMatcher knnMatch and 'flann' = LSH in flann_knn.cpp:199-240): exact
+    Hamming k-NN, ascending, ties -> lower index, index 0 / Inf where the train set has fewer than k rows."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    rng = np.random.default_rng(nb * 10 + k)
+    train = rng.integers(0, 256, (700, nb), dtype=np.uint8)
+    query = rng.integers(0, 256, (333, nb), dtype=np.uint8)
+    train[600:610] = train[100:110]                        # duplicated train rows: ties -> the lower index wins
+    query[:50] = train[rng.integers(0, 700, 50)]          # exact copies: distance 0 first
+    query[50:60] = train[100:110]
+    for method in ("bf", "flann"):
+        idx, dist = fm.flann_knn_win(train, query, k, method)
+        oi, od = oracle.knn_hamming(train, query, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert np.all(dist[:50, 0] == 0) and np.all(np.diff(dist, axis=1) >= 0)
+    if k >= 2:
+        assert np.array_equal(idx[50:60, 0], np.arange(101, 111)) and np.array_equal(idx[50:60, 1], np.arange(601, 611))
+    # brute force in numpy on a few rows
+    for i in (0, 77, 332):
+        d = np.unpackbits(train ^ query[i], axis=1).sum(1)
+        order = np.lexsort((np.arange(len(d)), d))[:k]
+        assert np.array_equal(idx[i].astype(np.int64) - 1, order) and np.array_equal(dist[i], d[order].astype(np.float32))
+    # fewer train rows than k
+    idx, dist = fm.flann_knn_win(train[:2], query[:5], 4, "bf")
+    assert np.all(idx[:, 2:] == 0) and np.all(np.isinf(dist[:, 2:])) and np.all(idx[:, :2] > 0)
+    with pytest.raises(ValueError):
+        fm.flann_knn_win(train, query[:, :nb - 1], k, "bf")
+    with pytest.raises(ValueError):
+        fm.flann_knn_win(train.astype(np.float32), query.astype(np.float32), k, "bf")
