@@ -190,6 +190,10 @@ inline void check_launch(const char* what) {
     if (e != hipSuccess) fail(APS_E_DEVICE, "launch of %s failed: %s", what, hipGetErrorString(e));
 }
 
+// match.hip: the screening half of the blocked global k-NN (see the definition)
+int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& block_off,
+                            std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b);
+
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 
 }  // namespace aps

@@ -154,7 +154,7 @@ Prof::Prof(const char* name) {
     if (mode == 2) {
         // selective: the per-image / per-tile chains issue thousands of launches per stitch, and two event records
         // per launch are a measurable share of it (2.7 % of the 64-view step); the per-batch kernels are kept
-        static const char* const keep[] = {"match", "ransac", "cover", "render_", "ba_", "crop", "gain"};
+        static const char* const keep[] = {"match", "ransac", "cover", "render_", "ba_", "crop", "gain", "knn", "global_"};
         bool ok = false;
         for (const char* k : keep) ok = ok || std::strncmp(name, k, std::strlen(k)) == 0;
         if (!ok) return;

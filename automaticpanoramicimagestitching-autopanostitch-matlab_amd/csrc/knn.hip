@@ -10,6 +10,8 @@
 //                       2-NN with the reference's tie rule.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -67,11 +69,19 @@ __global__ __launch_bounds__(256, 2) void knn_f32_kernel(const float* __restrict
                                                          int nq, const float* __restrict__ PT,
                                                          const float* __restrict__ sqT, int nt, int k_out,
                                                          uint32_t* __restrict__ idx, float* __restrict__ dist,
-                                                         int64_t ldo, int layout) {
+                                                         int64_t ldo, int layout, int block_rows) {
     __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
     __shared__ float s_t2[2][kTN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * 128 + wave * 32 + c;
+    if (block_rows > 0) {
+        // blocked form: the workgroup's 128 query rows are searched in their OWN block of the pool only (block_rows is a
+        // multiple of 128), indices come out relative to that block
+        const int base = (int)((blockIdx.x * 128) / block_rows) * block_rows;
+        PT += (size_t)base * kDim;
+        sqT += base;
+        nt = min(block_rows, nt - base);
+    }
     const int qrow = min(row, nq - 1);
     // resident operand (MFMA B): this lane's query row, k = 2s + h
     f32x4 qv[16];
@@ -162,6 +172,206 @@ __global__ __launch_bounds__(256, 2) void knn_f32_kernel(const float* __restrict
             dist[o] = ok ? v[e] : INFINITY;
         }
     }
+}
+
+// ---- blocked global k-NN of a pool against itself: merge of the per-block lists --------------------------------------
+// Row q of block i holds: its exact top-4 inside its own block (self included) and, for every other block j, the three
+// nearest rows of j with exact distances plus a bound below which no further row of j lies (match.hip,
+// screened_block_top3).  The global top-4 is the (distance, index)-ascending head of their union, and it is CERTIFIED when
+// its fourth distance is strictly below every block's bound (no unlisted row can enter or tie).  Uncertified rows - a
+// query with three or more near-identical rows in ANOTHER block - are recomputed against the whole pool.
+__global__ void knn_merge_kernel(const int64_t* __restrict__ block_off, int nb, const int64_t* __restrict__ job_off,
+                                 const uint32_t* __restrict__ self_idx, const float* __restrict__ self_d,
+                                 const uint32_t* __restrict__ t3_idx, const float* __restrict__ t3_d,
+                                 const float* __restrict__ t3_b, int64_t f, int k_out, uint32_t* __restrict__ idx,
+                                 float* __restrict__ dist, int64_t ldo, int layout, uint32_t* __restrict__ unc_list,
+                                 unsigned int* __restrict__ unc_count) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= f) return;
+    int lo = 0, hi = nb - 1;  // block of q
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_off[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int bi = lo;
+    const int64_t r = q - block_off[bi];
+    float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    long long id[4] = {-1, -1, -1, -1};
+    auto put = [&](float d, long long g) {
+        if (g < 0) return;
+        bool lt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lt[e] = id[e] < 0 || d < v[e] || (d == v[e] && g < id[e]);
+        if (!lt[3]) return;
+#pragma unroll
+        for (int e = 3; e >= 1; --e) {
+            v[e] = lt[e - 1] ? v[e - 1] : d;
+            id[e] = lt[e - 1] ? id[e - 1] : g;
+            if (!lt[e - 1]) return;
+        }
+        v[0] = d;
+        id[0] = g;
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t li = self_idx[q * 4 + e];
+        if (li) put(self_d[q * 4 + e], block_off[bi] + (long long)li - 1);
+    }
+    float min_bound = INFINITY;
+    // the own block's list is exact and complete up to its fourth entry: anything unlisted there is at least that far
+    if (self_idx[q * 4 + 3]) min_bound = self_d[q * 4 + 3];
+    for (int j = 0; j < nb; ++j) {
+        if (j == bi) continue;
+        const int64_t slot = job_off[(size_t)bi * nb + j] + r;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const uint32_t li = t3_idx[slot * 3 + e];
+            if (li) put(t3_d[slot * 3 + e], block_off[j] + (long long)li - 1);
+        }
+        min_bound = fminf(min_bound, t3_b[slot]);
+    }
+    // certified: the k-th distance reported is strictly below what any unlisted row can have.  (The own block's fourth
+    // entry may itself be the global fourth: then nothing unlisted of that block matters only if it is strictly farther -
+    // ties are resolved by index, which the exact own-block list already did, so that bound is taken non-strictly.)
+    const int kk = k_out < 4 ? k_out : 4;
+    const float dk = id[kk - 1] >= 0 ? v[kk - 1] : INFINITY;
+    float other_bound = INFINITY;
+    for (int j = 0; j < nb; ++j)
+        if (j != bi) other_bound = fminf(other_bound, t3_b[job_off[(size_t)bi * nb + j] + r]);
+    const bool certified = dk < other_bound || !(other_bound < INFINITY);
+    (void)min_bound;
+    if (certified) {
+        for (int e = 0; e < kk; ++e) {
+            const int64_t o = layout == APS_ROWMAJOR ? q * ldo + e : (int64_t)e * ldo + q;
+            idx[o] = id[e] >= 0 ? (uint32_t)(id[e] + 1) : 0u;
+            dist[o] = id[e] >= 0 ? v[e] : INFINITY;
+        }
+    } else {
+        unc_list[atomicAdd(unc_count, 1u)] = (uint32_t)q;
+    }
+}
+
+// Exact top-4 of one uncertified query row inside ONE block of the pool (one wave per (row, block); lane j takes the
+// block's rows j, j+64, ...).  d = (q2 + t2) - 2 G with G the k-ascending f32 fma chain: the arithmetic of knn_f32_kernel
+// (the MFMA computes that chain) on the k-permuted copies.  Each lane keeps its four nearest - a row among the block's
+// four nearest has at most three rows ahead of it anywhere, so it is in its lane's list - and lane 0 merges them.
+__global__ __launch_bounds__(64) void knn_rows_block_top4_kernel(const float* __restrict__ P, const float* __restrict__ sq,
+                                                                 const uint32_t* __restrict__ rows, int n_rows,
+                                                                 const int64_t* __restrict__ block_off, int nb,
+                                                                 long long* __restrict__ out_i, float* __restrict__ out_d) {
+    __shared__ float s_d[64 * 4];
+    __shared__ int s_i[64 * 4];
+    const int ri = blockIdx.x / nb, b = blockIdx.x % nb;
+    if (ri >= n_rows) return;
+    const int64_t q = rows[ri];
+    const int64_t t0 = block_off[b], nt = block_off[b + 1] - t0;
+    const float* pa = P + (size_t)q * kDim;
+    const float q2 = sq[q];
+    float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int id[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int j = threadIdx.x; j < nt; j += 64) {
+        const float* pb = P + (size_t)(t0 + j) * kDim;
+        float g = 0.f;
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const f32x4 ae = *reinterpret_cast<const f32x4*>(pa + 4 * s4), ao = *reinterpret_cast<const f32x4*>(pa + 64 + 4 * s4);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(pb + 4 * s4), bo = *reinterpret_cast<const f32x4*>(pb + 64 + 4 * s4);
+            g = fmaf(ae.x, be.x, g);
+            g = fmaf(ao.x, bo.x, g);
+            g = fmaf(ae.y, be.y, g);
+            g = fmaf(ao.y, bo.y, g);
+            g = fmaf(ae.z, be.z, g);
+            g = fmaf(ao.z, bo.z, g);
+            g = fmaf(ae.w, be.w, g);
+            g = fmaf(ao.w, bo.w, g);
+        }
+        const float dj = __fsub_rn(__fadd_rn(q2, sq[t0 + j]), __fmul_rn(2.0f, g));
+        if (dj < v[3]) {  // ascending j per lane: a tie stays behind the earlier entry
+            bool lt[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lt[e] = dj < v[e];
+#pragma unroll
+            for (int e = 3; e >= 1; --e) {
+                v[e] = lt[e - 1] ? v[e - 1] : (lt[e] ? dj : v[e]);
+                id[e] = lt[e - 1] ? id[e - 1] : (lt[e] ? j : id[e]);
+            }
+            v[0] = lt[0] ? dj : v[0];
+            id[0] = lt[0] ? j : id[0];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s_d[threadIdx.x * 4 + e] = v[e];
+        s_i[threadIdx.x * 4 + e] = id[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int e2 = 0; e2 < 64 * 4; ++e2) {
+            const float dq = s_d[e2];
+            const int iq = s_i[e2];
+            int pos = 4;
+            while (pos > 0 && (dq < bd[pos - 1] || (dq == bd[pos - 1] && iq < bi[pos - 1]))) --pos;
+            if (pos >= 4) continue;
+            for (int e = 3; e > pos; --e) {
+                bd[e] = bd[e - 1];
+                bi[e] = bi[e - 1];
+            }
+            bd[pos] = dq;
+            bi[pos] = iq;
+        }
+        for (int e = 0; e < 4; ++e) {
+            out_i[((size_t)ri * nb + b) * 4 + e] = bi[e] < nt ? t0 + bi[e] : -1;
+            out_d[((size_t)ri * nb + b) * 4 + e] = bd[e];
+        }
+    }
+}
+
+// global top-k of an uncertified row from its per-block exact top-4 lists
+__global__ void knn_rows_merge_kernel(const uint32_t* __restrict__ rows, int n_rows, int nb, const long long* __restrict__ li,
+                                      const float* __restrict__ ld_, int k_out, uint32_t* __restrict__ idx,
+                                      float* __restrict__ dist, int64_t ldo, int layout) {
+    const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_rows) return;
+    float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    long long id[4] = {-1, -1, -1, -1};
+    for (int e2 = 0; e2 < nb * 4; ++e2) {
+        const long long g = li[(size_t)ri * nb * 4 + e2];
+        const float d = ld_[(size_t)ri * nb * 4 + e2];
+        if (g < 0) continue;
+        int pos = 4;
+        while (pos > 0 && (id[pos - 1] < 0 || d < v[pos - 1] || (d == v[pos - 1] && g < id[pos - 1]))) --pos;
+        if (pos >= 4) continue;
+        for (int e = 3; e > pos; --e) {
+            v[e] = v[e - 1];
+            id[e] = id[e - 1];
+        }
+        v[pos] = d;
+        id[pos] = g;
+    }
+    const int64_t q = rows[ri];
+    for (int e = 0; e < k_out && e < 4; ++e) {
+        const int64_t o = layout == APS_ROWMAJOR ? q * ldo + e : (int64_t)e * ldo + q;
+        idx[o] = id[e] >= 0 ? (uint32_t)(id[e] + 1) : 0u;
+        dist[o] = id[e] >= 0 ? v[e] : INFINITY;
+    }
+}
+
+// allDesc ./ sqrt(sum(allDesc.^2, 2) + eps('single'))  (featureMatchingGlobal.m:83-85: eps INSIDE the root); the sum is
+// the k-ascending chain of separate multiplies and adds, like every other canonical sum of this library
+__global__ void global_normalize_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout, float* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[kDim];
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + k * ld];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
+    const float nrm = sqrtf(__fadd_rn(s, 1.1920928955078125e-07f));
+#pragma unroll
+    for (int k = 0; k < kDim; ++k) out[i * kDim + k] = __fdiv_rn(x[k], nrm);
 }
 
 // ---- featureMatchingGlobal.m:123-161 ------------------------------------------------------------------------
@@ -373,16 +583,86 @@ int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* que
             APS_HIP(hipMemcpyAsync(oi.get(), z.data(), oe * sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
             APS_HIP(hipMemcpyAsync(od.get(), inf.data(), oe * sizeof(float), hipMemcpyHostToDevice, stream()));
             APS_HIP(hipStreamSynchronize(stream()));
+        } else if (same && k <= 4 && ft >= 8192 && !(std::getenv("APS_KNN_MODE") && !std::strcmp(std::getenv("APS_KNN_MODE"), "f32"))) {
+            // Blocked, screened form (featureMatchingGlobal's call: the pool against itself, k = 4).  Inside its own block a
+            // row's top-4 (self included) comes from the exact f32 kernel; against every other block the f16 candidate
+            // kernel of the pairwise matcher finds the three nearest with exact distances and a certified bound; the merge
+            // yields the global top-4, bit-identical to the all-f32 path (APS_KNN_MODE=f32), in ~1/8 of its matrix time.
+            // rows per block: 40 workgroups of the candidate kernel (APS_KNN_BLOCK: smaller blocks for tests)
+            const int64_t bs = std::getenv("APS_KNN_BLOCK") ? std::max<int64_t>(512, std::atoll(std::getenv("APS_KNN_BLOCK")) / 128 * 128) : 20480;
+            const int nb = (int)((ft + bs - 1) / bs);
+            std::vector<int64_t> boff(nb + 1);
+            for (int b = 0; b <= nb; ++b) boff[b] = std::min<int64_t>((int64_t)b * bs, ft);
+            Ws<uint32_t> self_i((size_t)ft * 4);
+            Ws<float> self_d((size_t)ft * 4);
+            {
+                Prof prof("knn_f32");  // every block against itself, one launch (the row tile tells the block)
+                knn_f32_kernel<4><<<cdiv(ft, 128), 256, 0, stream()>>>(PT, sT, (int)ft, PT, sT, (int)ft, 4, self_i, self_d, 4, APS_ROWMAJOR,
+                                                                      (int)bs);
+            }
+            check_launch("knn_f32_kernel");
+            std::vector<int64_t> job_off;
+            const int64_t slots = screened_block_top3(dT, ldt, layout, boff, job_off, nullptr, nullptr, nullptr);
+            Ws<uint32_t> t3i((size_t)std::max<int64_t>(slots, 1) * 3);
+            Ws<float> t3d((size_t)std::max<int64_t>(slots, 1) * 3), t3b((size_t)std::max<int64_t>(slots, 1));
+            if (nb > 1) screened_block_top3(dT, ldt, layout, boff, job_off, t3i, t3d, t3b);
+            Ws<int64_t> d_boff(nb + 1), d_joff((size_t)nb * nb);
+            Ws<uint32_t> unc((size_t)ft);
+            Ws<unsigned int> unc_n(1);
+            APS_HIP(hipMemcpyAsync(d_boff, boff.data(), (nb + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)nb * nb * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+            APS_HIP(hipMemsetAsync(unc_n, 0, sizeof(unsigned int), stream()));
+            {
+                Prof prof("knn_merge");
+                knn_merge_kernel<<<cdiv(ft, 256), 256, 0, stream()>>>(d_boff, nb, d_joff, self_i, self_d, t3i, t3d, t3b, ft, k, oi, od, ldo,
+                                                                     layout, unc, unc_n);
+            }
+            check_launch("knn_merge_kernel");
+            unsigned int n_unc = 0;
+            APS_HIP(hipMemcpyAsync(&n_unc, unc_n, sizeof n_unc, hipMemcpyDeviceToHost, stream()));
+            APS_HIP(hipStreamSynchronize(stream()));
+            if (n_unc) {
+                // the few rows the merge could not certify (four or more near-identical rows in another block): their
+                // exact top-4 in EVERY block, one wave per (row, block), then the global head of those lists
+                Prof prof("knn_exact_rows");
+                Ws<long long> li((size_t)n_unc * nb * 4);
+                Ws<float> ldv((size_t)n_unc * nb * 4);
+                knn_rows_block_top4_kernel<<<(unsigned)((size_t)n_unc * nb), 64, 0, stream()>>>(PT, sT, unc, (int)n_unc, d_boff, nb, li, ldv);
+                knn_rows_merge_kernel<<<cdiv(n_unc, 64), 64, 0, stream()>>>(unc, (int)n_unc, nb, li, ldv, k, oi, od, ldo, layout);
+                check_launch("knn exact rows");
+            }
+            if (std::getenv("APS_TRACE"))
+                std::fprintf(stderr, "[aps] blocked k-NN: %d blocks, %u of %lld rows recomputed against the whole pool\n", nb, n_unc,
+                             (long long)ft);
         } else {
             Prof prof("knn_f32");
             if (k <= 4)
-                knn_f32_kernel<4><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout);
+                knn_f32_kernel<4><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout, 0);
             else
-                knn_f32_kernel<8><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout);
+                knn_f32_kernel<8><<<cdiv(fq, 128), 256, 0, stream()>>>(pq, sq, (int)fq, PT, sT, (int)ft, k, oi, od, ldo, layout, 0);
         }
         check_launch("knn_f32_kernel");
         oi.commit();
         od.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_global_normalize(const float* X, int64_t n, int64_t ld, int dim, int layout, float* out) {
+    return guarded([&] {
+        APS_REQUIRE(dim == kDim, APS_E_DIM, "descriptor length %d not supported (built for %d-D SIFT)", dim, kDim);
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(n >= 0 && (n == 0 || (X && out)), APS_E_ARG, "NULL argument");
+        APS_REQUIRE(layout == APS_ROWMAJOR ? ld >= dim : ld >= n, APS_E_DIM, "leading dimension too small");
+        ctx();
+        if (n == 0) return;
+        const size_t ne = layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld + dim : (size_t)(dim - 1) * ld + n;
+        In<float> dX(X, ne);
+        Out<float> dO(out, (size_t)n * kDim);
+        Prof prof("global_normalize");
+        global_normalize_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(dX, n, ld, layout, dO);
+        check_launch("global_normalize_kernel");
+        dO.commit();
         APS_HIP(hipStreamSynchronize(stream()));
     });
 }
@@ -407,6 +687,7 @@ int aps_global_filter(const uint32_t* nn_idx, const float* nn_dist, int64_t f, i
             Ws<unsigned long long> keys(f), sorted(f), pc(n_pairs);
             Ws<uint32_t> li(f), lj(f);
             APS_HIP(hipMemsetAsync(pc, 0, n_pairs * sizeof(unsigned long long), stream()));
+            Prof prof("global_filter");
             global_filter_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(di, dd, f, k, ldn, layout, dimg, dloc, ratio, keys, li, lj);
             check_launch("global_filter_kernel");
             size_t tb = 0;

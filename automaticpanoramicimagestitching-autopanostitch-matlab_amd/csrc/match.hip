@@ -634,6 +634,126 @@ __device__ __forceinline__ void rescore_row(const MatchJob& jb, int job, int row
     }
 }
 
+// Top-3 form of rescore_row for the blocked global k-NN (aps_knn_global on a pool against itself): the exact canonical
+// distances of the three candidates, ascending by (distance, index), cut to the prefix that is strictly below the bound of
+// every non-candidate of this B set (a2 - 2 u4 - eps).  t3_b receives that bound: every row of the set that is not
+// listed is at least that far away.
+__device__ __forceinline__ void rescore_row3(const MatchJob& jb, int job, int row, int c0, int c1, int c2, float bnd4,
+                                             float aug_res, float dn_res, uint32_t* __restrict__ t3_idx,
+                                             float* __restrict__ t3_d, float* __restrict__ t3_b,
+                                             uint32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    const int64_t slot = jb.out_off + row;
+    const float a2 = jb.sqA[row];
+    const float* pa = jb.PA + (size_t)row * kDim;
+    float d[3];
+    int id[3] = {c0, c1, c2};
+    const float* pb[3];
+    bool ok[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        ok[e] = id[e] >= 0 && id[e] < jb.nB;
+        pb[e] = ok[e] ? jb.PB + (size_t)id[e] * kDim : pa;
+    }
+    const float msb = *jb.maxsqB, mdb = *jb.maxdnB;
+    const float nb = sqrtf(msb) * 1.000001f + mdb;
+    const float na = sqrtf(a2) * 1.000001f;
+    float eg = jb.dnA[row] * nb + aug_res + na * dn_res + 3.0517578125e-05f * (na * (nb + mdb) + 0.5f * msb);
+    if (!(na < 65000.f)) eg = INFINITY;
+    const float eps = 2.002f * eg + 1.52587890625e-05f * (a2 + msb + 2.0f * na * nb) + 1e-37f;
+    float g[3];
+    exact_chains<3>(pa, pb, g);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        d[e] = ok[e] ? __fsub_rn(__fadd_rn(a2, jb.sqB[ok[e] ? id[e] : 0]), __fmul_rn(2.0f, g[e])) : INFINITY;
+        if (!ok[e]) id[e] = 0x7fffffff;
+    }
+#define APS_CSWAP(a, b)                                                    \
+    if (d[b] < d[a] || (d[b] == d[a] && id[b] < id[a])) {                  \
+        const float td = d[a]; d[a] = d[b]; d[b] = td;                     \
+        const int ti = id[a]; id[a] = id[b]; id[b] = ti;                   \
+    }
+    APS_CSWAP(0, 1)
+    APS_CSWAP(1, 2)
+    APS_CSWAP(0, 1)
+#undef APS_CSWAP
+    // Every column that is not one of the three candidates is at least `bound` away.  A candidate whose exact distance is
+    // strictly below the bound is therefore in its final place among the set's nearest; the others (if any) are no
+    // nearer than the bound either, so they are simply left unlisted: the list is a CERTIFIED PREFIX of the set's
+    // nearest rows, and "everything unlisted is >= bound" holds in every case.  The merge decides whether it needs more.
+    const float bound = jb.nB <= 3 ? INFINITY : bnd4 - eps;
+    (void)job; (void)fb_list; (void)fb_count;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const bool keep = id[e] < jb.nB && (jb.nB <= 3 || d[e] < bound);
+        t3_idx[slot * 3 + e] = keep ? (uint32_t)id[e] + 1u : 0u;  // 1-based within the B set, 0 = none
+        t3_d[slot * 3 + e] = keep ? d[e] : INFINITY;
+    }
+    t3_b[slot] = bound;
+}
+
+// Exact top-3 of one A row against its job's whole B set (the fallback of rescore_row3): one wave per listed slot, lane j
+// takes columns j, j+64, ...; every distance is the canonical f32 chain (exact_dist); lists merged through LDS.
+__global__ __launch_bounds__(64) void knn3_rows_kernel(const MatchJob* __restrict__ jobs, const int* __restrict__ job_of,
+                                                       const uint32_t* __restrict__ rows, int n_rows,
+                                                       uint32_t* __restrict__ t3_idx, float* __restrict__ t3_d,
+                                                       float* __restrict__ t3_b) {
+    __shared__ float s_d[64 * 4];
+    __shared__ int s_i[64 * 4];
+    if ((int)blockIdx.x >= n_rows) return;
+    const MatchJob jb = jobs[job_of[blockIdx.x]];
+    const int64_t slot = rows[blockIdx.x];
+    const int row = (int)(slot - jb.out_off);
+    const float a2 = jb.sqA[row];
+    const float* pa = jb.PA + (size_t)row * kDim;
+    // each lane keeps its FOUR nearest: a column among the overall four nearest has at most three columns ahead of it
+    // anywhere, so it is among its own lane's four - the union of the lists holds the exact overall top four
+    float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int id[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int j = threadIdx.x; j < jb.nB; j += 64) {
+        const float dj = exact_dist(pa, jb.PB + (size_t)j * kDim, a2, jb.sqB[j]);
+        if (dj < v[3]) {  // columns arrive in ascending j per lane: a tie stays behind the earlier entry
+            bool lt[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lt[e] = dj < v[e];
+#pragma unroll
+            for (int e = 3; e >= 1; --e) {
+                v[e] = lt[e - 1] ? v[e - 1] : (lt[e] ? dj : v[e]);
+                id[e] = lt[e - 1] ? id[e - 1] : (lt[e] ? j : id[e]);
+            }
+            v[0] = lt[0] ? dj : v[0];
+            id[0] = lt[0] ? j : id[0];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s_d[threadIdx.x * 4 + e] = v[e];
+        s_i[threadIdx.x * 4 + e] = id[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int q = 0; q < 64 * 4; ++q) {
+            const float dq = s_d[q];
+            const int iq = s_i[q];
+            int pos = 4;
+            while (pos > 0 && (dq < bd[pos - 1] || (dq == bd[pos - 1] && iq < bi[pos - 1]))) --pos;
+            if (pos >= 4) continue;
+            for (int e = 3; e > pos; --e) {
+                bd[e] = bd[e - 1];
+                bi[e] = bi[e - 1];
+            }
+            bd[pos] = dq;
+            bi[pos] = iq;
+        }
+        for (int e = 0; e < 3; ++e) {
+            t3_idx[slot * 3 + e] = bi[e] < jb.nB ? (uint32_t)bi[e] + 1u : 0u;
+            t3_d[slot * 3 + e] = bd[e];
+        }
+        t3_b[slot] = bd[3];  // the set's exact fourth distance: nothing unlisted is nearer (inf: nothing else exists)
+    }
+}
+
 // Bounds on a row's EXACT (canonical f32) best and second-best distance from its two largest screened values u0 >= u1
 // (columns c0, c1), with the same error terms as rescore_row:
 //   for every column j the computed distance satisfies d_j >= a2 - 2 U_j - eps (that is what certifies a row), and
@@ -666,7 +786,9 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                                                                 float* __restrict__ out_d1, float* __restrict__ out_d2,
                                                                 uint32_t* __restrict__ fb_list,
                                                                 unsigned int* __restrict__ fb_count, int ablate,
-                                                                float prune_r2, float prune_thr) {
+                                                                float prune_r2, float prune_thr,
+                                                                uint32_t* __restrict__ t3_idx, float* __restrict__ t3_d,
+                                                                float* __restrict__ t3_b) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kTileBytes];  // [buf][128][256 B], tile t in buf t % 3
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
@@ -1006,7 +1128,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                 const float lo = L1 * (1.0f - 1e-5f) - 1e-30f;
                 pruned = H2 >= 0.f && (lo > prune_r2 * H2 * (1.0f + 1e-5f) || lo > prune_thr * (1.0f + 1e-5f));
             }
-            if (pruned) {
+            if (t3_idx) {  // top-3 mode (blocked global k-NN): three exact distances + the set's bound per row
+                const float bnd = jb.sqA[row] - 2.0f * ub;
+                rescore_row3(jb, w.job, row, c0, c1, c2, bnd, jb.augresB[0], jb.augresB[1], t3_idx, t3_d, t3_b, fb_list, fb_count);
+            } else if (pruned) {
                 const int64_t slot = jb.out_off + row;
                 out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter would drop too)
                 out_d1[slot] = INFINITY;
@@ -1294,7 +1419,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         const int ablate = 0;
 #endif
         match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
-                                                                          fb_count, ablate, prune_r2, prune_thr);
+                                                                          fb_count, ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
@@ -1347,6 +1472,92 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
 }
 
 // ratio/threshold/unique for a list of jobs; returns total kept.  Outputs are device pointers.
+// job_of[e] for the pooled fallback list: entry e belongs to job j for dst[j] <= e < dst[j] + cnt[j]
+__global__ void fb_jobs_kernel(const long long* __restrict__ dst, const unsigned int* __restrict__ fb_count, int n_jobs,
+                               int* __restrict__ job_of) {
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const unsigned int cnt = fb_count[j];
+    for (unsigned int e = threadIdx.x; e < cnt; e += blockDim.x) job_of[dst[j] + e] = j;
+}
+
+}  // namespace aps (reopened below)
+
+namespace aps {
+
+// The screening half of the blocked global k-NN (aps_knn_global on a pool against itself, knn.hip): the pool is cut into
+// blocks; for every ordered pair of DIFFERENT blocks (i, j) the candidate kernel finds, for each row of block i, its three
+// nearest rows of block j (exact canonical distances, ascending by (distance, index)) and a bound below which no other
+// row of block j lies.  Rows the f16 screen cannot certify are recomputed exactly (knn3_rows_kernel).
+// Outputs are indexed by slot = job_off[i * nb + j] + local row:  t3_idx[3 slot + e] (1-based within block j, 0 = none),
+// t3_d[3 slot + e], t3_b[slot].  Returns the slot count; call with t3_* == nullptr to get it first.
+int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& block_off,
+                            std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b) {
+    const int nb = (int)block_off.size() - 1;
+    job_off.assign((size_t)nb * nb, -1);
+    int64_t slots = 0;
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) {
+            if (i == j) continue;
+            job_off[(size_t)i * nb + j] = slots;
+            slots += block_off[i + 1] - block_off[i];
+        }
+    if (!t3_idx || slots == 0) return slots;
+    APS_REQUIRE(slots < ((int64_t)1 << 31), APS_E_DIM, "too many (row, block) pairs for one pass (%lld)", (long long)slots);
+    std::vector<Prepared> prep(nb);
+    for (int b = 0; b < nb; ++b) {
+        const float* xb = layout == APS_ROWMAJOR ? X_dev + (size_t)block_off[b] * ld : X_dev + block_off[b];
+        prepare(xb, block_off[b + 1] - block_off[b], ld, layout, false, prep[b]);
+    }
+    std::vector<MatchJob> jobs;
+    std::vector<WgJob> bw;
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) {
+            if (i == j) continue;
+            const int nA = (int)(block_off[i + 1] - block_off[i]), nB = (int)(block_off[j + 1] - block_off[j]);
+            for (int r = 0; r < nA; r += kTMB) bw.push_back({(int)jobs.size(), r, 0});
+            jobs.push_back(make_job(prep[i], prep[j], nA, nB, job_off[(size_t)i * nb + j]));
+        }
+    Ws<MatchJob> djobs(jobs.size());
+    Ws<WgJob> dbw(bw.size());
+    Ws<uint32_t> fb_list((size_t)slots);
+    Ws<unsigned int> fb_count(jobs.size());
+    APS_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemsetAsync(fb_count, 0, jobs.size() * sizeof(unsigned int), stream()));
+    {
+        Prof prof("match_cand_f16");
+        match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
+                                                                          fb_list, fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b);
+    }
+    check_launch("match_cand_f16_kernel");
+    std::vector<unsigned int> h_cnt(jobs.size());
+    APS_HIP(hipMemcpyAsync(h_cnt.data(), fb_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    std::vector<long long> h_dst(jobs.size());
+    size_t n_fb = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        h_dst[j] = (long long)n_fb;
+        n_fb += h_cnt[j];
+    }
+    if (n_fb) {
+        Ws<long long> d_dst(jobs.size());
+        Ws<uint32_t> pool(n_fb);
+        Ws<int> job_of(n_fb);
+        APS_HIP(hipMemcpyAsync(d_dst, h_dst.data(), jobs.size() * sizeof(long long), hipMemcpyHostToDevice, stream()));
+        Prof prof("knn_fallback3");
+        fb_compact_kernel<<<(unsigned)jobs.size(), 64, 0, stream()>>>(djobs, fb_list, fb_count, d_dst, pool);
+        fb_jobs_kernel<<<(unsigned)jobs.size(), 64, 0, stream()>>>(d_dst, fb_count, (int)jobs.size(), job_of);
+        knn3_rows_kernel<<<(unsigned)n_fb, 64, 0, stream()>>>(djobs, job_of, pool, (int)n_fb, t3_idx, t3_d, t3_b);
+        check_launch("knn3_rows_kernel");
+    }
+    APS_HIP(hipStreamSynchronize(stream()));  // the host tables and the Prepared blocks must outlive the launches
+    if (std::getenv("APS_TRACE"))
+        std::fprintf(stderr, "[aps] blocked k-NN screen: %d blocks, %zu jobs, %lld slots, %zu uncertified (%.3f %%)\n", nb, jobs.size(),
+                     (long long)slots, n_fb, 100.0 * (double)n_fb / (double)slots);
+    return slots;
+}
+
 static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_rows, int64_t total_cols,
                           const uint32_t* idx, const float* d1, const float* d2,
                           const aps_match_opts& o, unsigned long long* d_job_ptr /* njobs+1 */,

@@ -466,6 +466,52 @@ def nearest2HammingExhaustiveMEX(Abytes, Bbytes):
 nearest2HammingExhaustiveOMPMEX = nearest2HammingExhaustiveMEX  # same arithmetic (OMP twin)
 
 
+def match_global_csr(allDescriptors, ratio=0.6, k=4, device_out=False):
+    """featureMatchingGlobal.m:69-161 in CSR form, resident when the descriptors are: pool (torch.cat / concatenate),
+    row normalisation with eps inside the root (:83-85, aps_global_normalize), exact k-NN of the pool against itself
+    (aps_knn_global: blocked f16-screened search with exact distances), per-query filter (aps_global_filter).
+    Returns (pair_ptr int64[P+1] in featureMatchingPairwise's pair order, idx_i, idx_j): 1-based local indices in the
+    lower- / higher-numbered image of each pair, query order; device_out=True keeps idx_i/idx_j as int32 CUDA tensors."""
+    numImg = len(allDescriptors)
+    counts = [int(d.shape[0]) for d in allDescriptors]
+    F = sum(counts)
+    npairs = numImg * (numImg - 1) // 2
+    pair_ptr = np.zeros(npairs + 1, np.int64)
+    resident = F > 0 and all(_capi.is_torch(d) and d.is_cuda for d in allDescriptors)
+    if F == 0:
+        z = np.zeros(0, np.uint32)
+        return pair_ptr, z, z.copy()
+    img_idx = np.repeat(np.arange(1, numImg + 1, dtype=np.uint32), counts)
+    local_idx = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
+    if resident:
+        import torch
+
+        raw = torch.cat([d.reshape(-1, DIM) for d in allDescriptors]).contiguous()
+        torch.cuda.current_stream().synchronize()  # torch produced the pool; the library reads it on its own stream
+        pool = torch.empty_like(raw)
+        nn_idx = torch.empty((F, k), dtype=torch.int32, device=raw.device)
+        nn_dist = torch.empty((F, k), dtype=torch.float32, device=raw.device)
+        oi = torch.empty(F, dtype=torch.int32, device=raw.device)
+        oj = torch.empty(F, dtype=torch.int32, device=raw.device)
+    else:
+        raw = np.ascontiguousarray(np.concatenate([np.asarray(d.cpu() if _capi.is_torch(d) else d, np.float32).reshape(-1, DIM)
+                                                   for d in allDescriptors]))
+        pool = np.empty_like(raw)
+        nn_idx = np.zeros((F, k), np.uint32)
+        nn_dist = np.zeros((F, k), np.float32)
+        oi = np.zeros(F, np.uint32)
+        oj = np.zeros(F, np.uint32)
+    check(lib.aps_global_normalize(ptr(raw), F, DIM, DIM, _capi.APS_ROWMAJOR, ptr(pool)))
+    check(lib.aps_knn_global(ptr(pool), F, DIM, ptr(pool), F, DIM, DIM, _capi.APS_ROWMAJOR, k, ptr(nn_idx), ptr(nn_dist), k))
+    cnt = C.c_int64(0)
+    check(lib.aps_global_filter(ptr(nn_idx), ptr(nn_dist), F, k, k, _capi.APS_ROWMAJOR, ptr(img_idx), ptr(local_idx),
+                                numImg, float(ratio), ptr(pair_ptr), ptr(oi), ptr(oj), F, C.byref(cnt)))
+    n = cnt.value
+    if resident and not device_out:
+        return pair_ptr, oi[:n].cpu().numpy().astype(np.uint32), oj[:n].cpu().numpy().astype(np.uint32)
+    return pair_ptr, oi[:n], oj[:n]
+
+
 def featureMatchingGlobal(input, allDescriptors, numImg):
     """matches = featureMatchingGlobal(input, allDescriptors, numImg) (featureMatchingGlobal.m:1-161): pool all
     descriptors, L2-normalise (:80-86), exact kNN (k = input.k) of the pool against itself, per-query filter
@@ -476,24 +522,7 @@ def featureMatchingGlobal(input, allDescriptors, numImg):
     F = sum(counts)
     if F == 0:
         return matches
-    k = int(input.get("k", 4))
-    ratio = float(input.get("Ratiothreshold", 0.6))
-    pool = np.concatenate([np.asarray(d.cpu() if _capi.is_torch(d) else d, np.float32) for d in allDescriptors])
-    # allDesc ./ sqrt(sum(allDesc.^2,2) + eps('single'))  (:83-85) — eps INSIDE the root, unlike normalizeRowsL2
-    sq = np.zeros(F, np.float32)
-    for kk in range(DIM):
-        sq = sq + pool[:, kk] * pool[:, kk]
-    pool = (pool / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
-    img_idx = np.repeat(np.arange(1, numImg + 1, dtype=np.uint32), counts)
-    local_idx = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
-    nn_idx, nn_dist = flann_knn_win(pool, pool, k)
-    npairs = numImg * (numImg - 1) // 2
-    pair_ptr = np.zeros(npairs + 1, np.int64)
-    oi = np.zeros(F, np.uint32)
-    oj = np.zeros(F, np.uint32)
-    cnt = C.c_int64(0)
-    check(lib.aps_global_filter(ptr(nn_idx), ptr(nn_dist), F, k, k, _capi.APS_ROWMAJOR, ptr(img_idx), ptr(local_idx),
-                                numImg, ratio, ptr(pair_ptr), ptr(oi), ptr(oj), F, C.byref(cnt)))
+    pair_ptr, oi, oj = match_global_csr(allDescriptors, float(input.get("Ratiothreshold", 0.6)), int(input.get("k", 4)))
     for p, (i, j) in enumerate(pair_order(numImg)):
         s, e = pair_ptr[p], pair_ptr[p + 1]
         if e > s:

@@ -299,14 +299,21 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
     host_lists = bool(os.environ.get("APS_PARALLEL_HOST_LISTS"))  # A/B switch: lists through the host (round-1 path)
     pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
     my = [p for p in range(len(order)) if pown[p] == rank]
-    pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
-                                           input["Matchingthreshold"], True, device_out=not host_lists)
-    if host_lists:
+    use_global = not int(input.get("matchFeaturesPairwise", 1))  # main.m:95-99
+    if use_global:
+        # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank
+        # holds all descriptors after the exchange and computes the (deterministic) result itself: no further exchange.
+        pp, ia_d, ib_d = fm.match_global_csr(descs, input["Ratiothreshold"], int(input.get("k", 4)), device_out=True)
+        my = list(range(len(order)))
+    else:
+        pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
+                                               input["Matchingthreshold"], True, device_out=not host_lists)
+    if host_lists and not use_global:
         ia_d = torch.from_numpy(ia_d.astype(np.int32)).to(dev)
         ib_d = torch.from_numpy(ib_d.astype(np.int32)).to(dev)
     n_match = np.zeros(len(order), np.int64)
     n_match[my] = np.diff(pp)
-    if ws > 1:
+    if ws > 1 and not use_global:
         nm = torch.from_numpy(n_match).to(dev)
         _all_reduce(nm)
         n_match = nm.cpu().numpy()

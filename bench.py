@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--cameras", choices=["estimated", "truth"], default="estimated",
                     help="cameras for the render stage: initialised from the verified homographies (default) "
                          "or the synthetic ground truth")
+    ap.add_argument("--matcher", choices=["pairwise", "global"], default="pairwise",
+                    help="pairwise = featureMatchingPairwise, all pairs exhaustive (the BASELINE configs[2] workload, default); "
+                         "global = featureMatchingGlobal, the reference's default switch (inputs.m:46): pooled exact k-NN (k = 4) "
+                         "of all descriptors against themselves + per-query filter")
     ap.add_argument("--save-pano", type=str, default="", help="write a downscaled PNG of the panorama (debug)")
     ap.add_argument("--end-to-end", choices=["auto", "off"], default="auto",
                     help="after the resident steps, time the same steps from pinned host images to the cropped uint8 "
@@ -140,6 +144,9 @@ def main():
     input_ = pl.default_input(bands=args.bands)
     if args.gain_compensation:
         input_["gainCompensation"] = 1
+    if args.matcher == "global":
+        input_["matchFeaturesPairwise"] = 0
+        input_["k"] = 4
 
     # synthetic inputs, resident in HBM before anything is timed (each rank renders only its shard)
     cams = synth.grid_cameras(nx, ny, w, h, f, 2 * np.arctan(w / (2 * f)) * (1 - OVERLAP),
@@ -252,6 +259,8 @@ def main():
         wts = [float(counts[i]) * float(counts[j]) for (i, j) in order]
         own = par.partition_weighted(wts, world) if world > 1 else np.zeros(len(order), np.int64)
         flops_rank0 = 2.0 * 128.0 * sum(wt for wt, o in zip(wts, own) if o == 0)
+        if args.matcher == "global":  # 2 * 128 * F^2 for the pooled search (every ordered pair of rows)
+            flops_rank0 = 2.0 * 128.0 * float(sum(counts)) ** 2
         # --- rooflines -------------------------------------------------------------------------------
         # algorithmic work per step: F_match = 2*128*sum N_i*N_j over this rank's pairs;
         # B_sift = 574 B per input pixel (materialised pyramid); B_warp = 16*A_cov + 3*sum(h*w);
@@ -336,7 +345,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
-                            f"{int(OVERLAP * 100)}% overlap): SIFT -> all-pairs exhaustive 2-NN + Lowe ratio -> batched RANSAC -> "
+                            f"{int(OVERLAP * 100)}% overlap): SIFT -> " + ("all-pairs exhaustive 2-NN + Lowe ratio" if args.matcher == "pairwise" else "pooled exact 4-NN of all descriptors + per-query filter (featureMatchingGlobal)") + " -> batched RANSAC -> "
                             f"host match graph/cameras ({args.cameras}) -> spherical inverse warp + {args.bands}-band multiband blend, "
                             f"tile 2048 -> cropNonzeroBbox; BASELINE.json configs[2].  `value` is the HBM-resident rate (inputs "
                             f"uploaded before the timed region, cropped panorama left on the device); value_end_to_end adds "

@@ -160,6 +160,10 @@ int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* que
 int aps_knn_hamming(const uint8_t* train, int64_t ft, int64_t ldt, const uint8_t* query, int64_t fq, int64_t ldq,
                     int nbytes, int layout, int k, uint32_t* idx, float* dist, int64_t ldo);
 
+/* a8 pooling step: allDesc = allDesc ./ sqrt(sum(allDesc.^2, 2) + eps('single')) (featureMatchingGlobal.m:80-86; eps inside
+ * the root, unlike matchFeaturesScratch's normalizeRowsL2).  out: n x dim f32 row-major (ld = dim), host or device. */
+int aps_global_normalize(const float* X, int64_t n, int64_t ld, int dim, int layout, float* out);
+
 /* a8 filter: the per-query loop of featureMatchingGlobal.m:123-161 (drop self, drop same-image,
  * need >= 2 left, reject iff d1/max(d2,eps('single')) > ratio, append [li lj] to pair (min,max) in
  * query order).  img_idx (1-based image id per row) and local_idx (1-based) are uint32[f].

@@ -126,3 +126,42 @@ def test_hamming_knn_equals_oracle_and_known_answers(gpu, nb, k):
         fm.flann_knn_win(train, query[:, :nb - 1], k, "bf")
     with pytest.raises(ValueError):
         fm.flann_knn_win(train.astype(np.float32), query.astype(np.float32), k, "bf")
+
+
+def test_blocked_screened_knn_equals_f32_path_and_oracle(gpu, monkeypatch):
+    """aps_knn_global on a pool against itself (featureMatchingGlobal's call) takes the blocked path: exact own-block lists
+    + f16-screened top-3 of every other block + merge.  Indices and distance bits must equal the all-f32 kernel
+    (APS_KNN_MODE=f32) and the oracle - with planted near-duplicates across blocks (three copies of a row in ANOTHER block
+    defeat the three-per-block lists and must come back through the whole-pool fallback) and exact duplicates (ties)."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    rng = np.random.default_rng(77)
+    x = sift_like(rng, 9000)
+    # near-duplicates in other blocks (block size 2048 below): row 100's copies at 3000, 5000, 7000; three in ONE block
+    for dst, eps in ((3000, 1e-3), (5000, 2e-3), (7000, 3e-3), (4100, 1e-3), (4200, 2e-3), (4300, 3e-3)):
+        src = 100 if dst in (3000, 5000, 7000) else 200
+        v = x[src] + eps * rng.standard_normal(128).astype(np.float32)
+        x[dst] = (np.maximum(v, 0) / np.linalg.norm(np.maximum(v, 0))).astype(np.float32)
+    x[8000] = x[10]      # exact duplicates: tie broken by index
+    x[8001] = x[10]
+    monkeypatch.setenv("APS_KNN_BLOCK", "2048")
+    monkeypatch.delenv("APS_KNN_MODE", raising=False)
+    idx, dist = fm.flann_knn_win(x, x, 4)
+    monkeypatch.setenv("APS_KNN_MODE", "f32")
+    idx0, dist0 = fm.flann_knn_win(x, x, 4)
+    monkeypatch.delenv("APS_KNN_MODE")
+    assert np.array_equal(idx, idx0) and np.array_equal(bits(dist), bits(dist0))
+    oi, od = oracle.knn(x, x, 4)
+    assert np.array_equal(idx, oi) and np.array_equal(bits(dist), bits(od))
+    assert set(idx[100, :4].tolist()) == {101, 3001, 5001, 7001}
+    assert set(idx[200, :4].tolist()) == {201, 4101, 4201, 4301}
+    assert idx[10, 0] == 11 and idx[10, 1] == 8001 and idx[10, 2] == 8002 and dist[10, 1] == dist[10, 0]
+    # k < 4 and the default block size on a larger pool (two blocks of 20480): against the f32 path
+    monkeypatch.delenv("APS_KNN_BLOCK")
+    y = sift_like(rng, 24000)
+    for k in (2, 4):
+        monkeypatch.delenv("APS_KNN_MODE", raising=False)
+        a_i, a_d = fm.flann_knn_win(y, y, k)
+        monkeypatch.setenv("APS_KNN_MODE", "f32")
+        b_i, b_d = fm.flann_knn_win(y, y, k)
+        assert np.array_equal(a_i, b_i) and np.array_equal(bits(a_d), bits(b_d))
+    monkeypatch.delenv("APS_KNN_MODE")
