@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
     // texture lives, tens of thousands of single-address atomics serialised in L2 (the 2 MPix octave took 110 us against
     // 24 us without candidates, longer than the 8 MPix octave).  The order of the cells is irrelevant: they are sorted
     // into the canonical keypoint order later.
-    constexpr int kLocalCap = 1024;
+    constexpr int kLocalCap = 192;  // (1024 cost a fourth workgroup per CU: 44.5 KB of LDS against 38)
     __shared__ unsigned long long s_cells[kLocalCap];
     __shared__ unsigned int s_n, s_base;
     if (tid == 0) s_n = 0u;
