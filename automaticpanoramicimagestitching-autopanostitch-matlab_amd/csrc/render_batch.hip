@@ -513,30 +513,28 @@ struct DownShape {
     static constexpr int T1 = kBH * IC > kBR * kBW ? kBH * IC : kBR * kBW;  // first-pass buffer of the resize
 };
 
-// s_a holds the haloed input patch (nir x nic, pitch IC); on return the block's outputs have been written.
-template <int R>
-__device__ __forceinline__ void blur_resize_block(float4* __restrict__ s_a, float4* __restrict__ s_b, const Taps& tp,
+// `load(ly, lx)` yields the haloed input patch (nir x nic); on return the block's outputs have been written.
+template <int R, class Load>
+__device__ __forceinline__ void blur_resize_block(Load load, float4* __restrict__ s_a, float4* __restrict__ s_b, const Taps& tp,
                                                   int nbr, int nbc, int bx0, int by0, int ox0, int oy0, int ox1, int oy1,
                                                   const int* __restrict__ tci, const float* __restrict__ tcw,
                                                   const int* __restrict__ tri, const float* __restrict__ trw, bool rows_first,
                                                   float4* __restrict__ out, const Rect& go) {
     constexpr int IC = DownShape<R>::IC;
     const int tid = threadIdx.x, nic = nbc + 2 * R;
-    // Both Gaussian passes run IN PLACE through a register window (load, barrier, compute + store): the patch is the
-    // only large LDS buffer, so two workgroups fit a CU and one's barriers are covered by the other's work.
-    {  // column (vertical) pass: thread = (row segment, column)
+    // The column (vertical) Gaussian pass reads its register window straight from the source: the patch itself never
+    // goes through LDS (that cost a fill pass, a barrier, a window load and another barrier).  The row pass then runs IN
+    // PLACE through a register window, so the patch-sized buffer is the only large LDS allocation and two workgroups
+    // fit a CU (one's barriers are covered by the other's work).
+    {  // column pass: thread = (row segment, column); rows shared by two segments are fetched twice (L1/L2 hits)
         constexpr int SEG = kNT / IC, RS = (kBR + SEG - 1) / SEG;
         const int col = tid % IC, r0 = (tid / IC) * RS;
         const bool act = tid < SEG * IC && col < nic && r0 < nbr;
-        float4 win[RS + 2 * R];
-        __syncthreads();
         if (act) {
+            float4 win[RS + 2 * R];
 #pragma unroll
             for (int i = 0; i < RS + 2 * R; ++i)
-                win[i] = r0 + i < nbr + 2 * R ? s_a[(r0 + i) * IC + col] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        if (act) {
+                win[i] = r0 + i < nbr + 2 * R ? load(r0 + i, col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < RS; ++i) {
                 if (r0 + i >= nbr) break;
@@ -620,10 +618,10 @@ __device__ __forceinline__ void blur_resize_block(float4* __restrict__ s_a, floa
 // One workgroup per kBW x kBH block of one layer's G_{l+1} footprint, input from the compact store of G_l.
 template <int R>
 __global__ __launch_bounds__(kNT, 4) void rw_down_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
-    constexpr int IC = DownShape<R>::IC, IR = DownShape<R>::IR;
+    constexpr int IC = DownShape<R>::IC;
     extern __shared__ float4 s_dyn[];
-    float4* s_a = s_dyn;
-    float4* s_b = s_dyn + IR * IC;
+    float4* s_a = s_dyn;             // kBR x IC: column-blurred patch, then (in place) the blurred patch
+    float4* s_b = s_dyn + kBR * IC;  // DownShape<R>::T1: first pass of the resize
     const int bid = xcd_contiguous_id(n_blocks);
     if (bid >= n_blocks) return;
     const int e = find_segment(blk_ptr, A.n_entries, bid);
@@ -647,16 +645,14 @@ __global__ __launch_bounds__(kNT, 4) void rw_down_kernel(RwArgs A, int l, const 
         if (tid == 0) atomicOr(A.status, 2);
         return;
     }
-    const int nic = nbc + 2 * R, nir = nbr + 2 * R;
     const float4* __restrict__ gin = A.G + E.off[l];
     const int giw = gi.x1 - gi.x0;
-    for (int ee = tid; ee < IR * IC; ee += kNT) {
-        const int ly = ee / IC, lx = ee - ly * IC;
-        if (ly >= nir || lx >= nic) continue;
+    // patch position (ly, lx) -> level-l pixel with replicate padding at the tile border, zero outside the footprint
+    auto load = [&](int ly, int lx) {
         const int gy = min(max(by0 + ly - R, 0), h - 1), gx = min(max(bx0 + lx - R, 0), w - 1);
-        s_a[ee] = in_rect(gi, gx, gy) ? gin[(size_t)(gy - gi.y0) * giw + (gx - gi.x0)] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    blur_resize_block<R>(s_a, s_b, A.tp, nbr, nbc, bx0, by0, ox0, oy0, ox1, oy1, tci, tcw, tri, trw, (T.rf_down >> l) & 1,
+        return in_rect(gi, gx, gy) ? gin[(size_t)(gy - gi.y0) * giw + (gx - gi.x0)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    blur_resize_block<R>(load, s_a, s_b, A.tp, nbr, nbc, bx0, by0, ox0, oy0, ox1, oy1, tci, tcw, tri, trw, (T.rf_down >> l) & 1,
                          A.G + E.off[l + 1], go);
 }
 
@@ -778,7 +774,7 @@ __global__ __launch_bounds__(256) void rw_up_kernel(RwArgs A, int l, const int* 
 
 template <int R>
 constexpr size_t down_lds_bytes() {
-    return (size_t)(DownShape<R>::IR * DownShape<R>::IC + DownShape<R>::T1) * sizeof(float4);
+    return (size_t)(kBR * DownShape<R>::IC + DownShape<R>::T1) * sizeof(float4);
 }
 template <int R>
 void launch_down_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {

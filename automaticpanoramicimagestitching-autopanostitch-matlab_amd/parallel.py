@@ -496,13 +496,13 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
             pano = None
             if int(comp_owner[ci]) == rank:
                 pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
-                                            gains=gains, device_out=True)
+                                            gains=gains, device_out=True, geo=geo)
                 pl._sync()
             root = pano_root if pano_root is not None else None
             pano = _deliver_panorama(pano, int(comp_owner[ci]), root, dev)
         else:
             pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
-                                        gains=gains, device_out=True, tile_subset=(rank, ws) if ws > 1 else None)
+                                        gains=gains, device_out=True, tile_subset=(rank, ws) if ws > 1 else None, geo=geo)
             pl._sync()
             if ws > 1:
                 torch.cuda.synchronize()

@@ -35,28 +35,59 @@ def default_opts(opts, cameras, refIdx):
     return o
 
 
+_GRID_CACHE = {}
+
+
+def _grid_points(H, W, nx, ny, border):
+    """The sample pixels of the bounds functions for one image size: 48 x 32 interior grid in MATLAB's U(:) order and,
+    for the planar / stereographic bounds, 4 x `border` edge samples (renderPanorama.m:1524-1530,1612-1625)."""
+    key = (int(H), int(W), nx, ny, border)
+    xy1 = _GRID_CACHE.get(key)
+    if xy1 is None:
+        xs = np.linspace(1, W, nx)
+        ys = np.linspace(1, H, ny)
+        U, V = np.meshgrid(xs, ys)
+        u = U.T.reshape(-1)  # MATLAB U(:) walks column-major
+        v = V.T.reshape(-1)
+        if border:
+            xb = np.linspace(1, W, border)
+            yb = np.linspace(1, H, border)
+            u = np.concatenate([u, xb, xb, np.ones(border), W * np.ones(border)])
+            v = np.concatenate([v, np.ones(border), H * np.ones(border), yb, yb])
+        xy1 = np.stack([u, v, np.ones_like(u)])
+        if len(_GRID_CACHE) > 64:
+            _GRID_CACHE.clear()
+        _GRID_CACHE[key] = xy1
+    return xy1
+
+
 def _grid_rays(cam, H, W, nx=48, ny=32, border=0):
-    xs = np.linspace(1, W, nx)
-    ys = np.linspace(1, H, ny)
-    U, V = np.meshgrid(xs, ys)
-    u = U.T.reshape(-1)  # MATLAB U(:) walks column-major
-    v = V.T.reshape(-1)
-    if border:
-        xb = np.linspace(1, W, border)
-        yb = np.linspace(1, H, border)
-        u = np.concatenate([u, xb, xb, np.ones(border), W * np.ones(border)])
-        v = np.concatenate([v, np.ones(border), H * np.ones(border), yb, yb])
-    xy1 = np.stack([u, v, np.ones_like(u)])
-    rayC = np.linalg.solve(np.asarray(cam["K"], np.float64), xy1)
+    rayC = np.linalg.solve(np.asarray(cam["K"], np.float64), _grid_points(H, W, nx, ny, border))
     return np.asarray(cam["R"], np.float64).T @ rayC
+
+
+def _all_grid_rays(cams, imgSize, border=0):
+    """_grid_rays of every camera, batched per image size (one LAPACK call and one matrix product for all cameras of
+    a size; the per-camera results are the same numbers as the one-at-a-time form)."""
+    out = [None] * len(cams)
+    groups = {}
+    for i in range(len(cams)):
+        groups.setdefault((int(imgSize[i][0]), int(imgSize[i][1])), []).append(i)
+    for (H, W), ids in groups.items():
+        xy1 = _grid_points(H, W, 48, 32, border)
+        Ks = np.stack([np.asarray(cams[i]["K"], np.float64) for i in ids])
+        Rt = np.stack([np.asarray(cams[i]["R"], np.float64).T for i in ids])
+        rays = Rt @ np.linalg.solve(Ks, np.broadcast_to(xy1, (len(ids),) + xy1.shape))
+        for q, i in enumerate(ids):
+            out[i] = rays[q]
+    return out
 
 
 def sphericalBounds(cams, imgSize):
     """renderPanorama.m:1544-1579."""
     tmin = pmin = math.inf
     tmax = pmax = -math.inf
-    for i, cam in enumerate(cams):
-        x, y, z = _grid_rays(cam, imgSize[i][0], imgSize[i][1])
+    for x, y, z in _all_grid_rays(cams, imgSize):
         th = np.arctan2(x, z)
         ph = np.arctan2(y, np.hypot(x, z))
         tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
@@ -68,8 +99,7 @@ def cylindricalBounds(cams, imgSize):
     """renderPanorama.m:1507-1542."""
     tmin = hmin = math.inf
     tmax = hmax = -math.inf
-    for i, cam in enumerate(cams):
-        x, y, z = _grid_rays(cam, imgSize[i][0], imgSize[i][1])
+    for x, y, z in _all_grid_rays(cams, imgSize):
         th = np.arctan2(x, z)
         hh = y / np.hypot(x, z)
         tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
@@ -92,8 +122,8 @@ def planarBounds(cams, imgSize, Rref, robustPct, uvAbsCap):
     """renderPanorama.m:1581-1665."""
     umin = vmin = math.inf
     umax = vmax = -math.inf
-    for i, cam in enumerate(cams):
-        rayR = np.asarray(Rref, np.float64) @ _grid_rays(cam, imgSize[i][0], imgSize[i][1], border=512)
+    for rays in _all_grid_rays(cams, imgSize, border=512):
+        rayR = np.asarray(Rref, np.float64) @ rays
         zr = rayR[2]
         m = zr > 1e-4
         if not m.any():
@@ -115,8 +145,8 @@ def stereographicBounds(cams, imgSize, Rref, robustPct, absCap):
     """renderPanorama.m:1667-1754."""
     amin = bmin = math.inf
     amax = bmax = -math.inf
-    for i, cam in enumerate(cams):
-        rayR = np.asarray(Rref, np.float64) @ _grid_rays(cam, imgSize[i][0], imgSize[i][1], border=512)
+    for rays in _all_grid_rays(cams, imgSize, border=512):
+        rayR = np.asarray(Rref, np.float64) @ rays
         nr = np.sqrt((rayR ** 2).sum(0))
         xr, yr, zr = rayR / nr
         den = 1 + zr
@@ -368,7 +398,7 @@ def pureNonRotationalPanoramas(images, cameras, numImages, opts, gains=None):
 
 
 def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gains=None,
-                   return_covered=False, device_out=False, tile_subset=None):
+                   return_covered=False, device_out=False, tile_subset=None, geo=None):
     """[panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts)
     (renderPanorama.m:1-500).  refIdx is 0-based here.  Differences that are deliberate:
       * opts['tile'] must be explicit; the reference derives it from free GPU/CPU memory (:269-298),
@@ -383,7 +413,8 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
         return (pano, ann, None, None) if return_covered else (pano, ann)
     o = default_opts(opts, cameras, refIdx)
     imgSize = [tuple(int(v) for v in s) for s in imgSize]
-    geo = canvas_geometry(cameras, imgSize, mode, refIdx, o)
+    if geo is None:  # (a caller that has sized the canvas already - the sharded driver - passes it in)
+        geo = canvas_geometry(cameras, imgSize, mode, refIdx, o)
     o["tile"] = effective_tile(o, geo)
     if gains is None and opts and opts.get("gainCompensation"):
         # renderPanorama.m:303-330: overlap statistics on the device, N x N solve on the host.  Only when the
