@@ -1230,7 +1230,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         // multiband: all tiles level-major in one launch sequence (render_batch.hip); APS_RENDER_LEGACY=1 keeps the
         // per-tile path below, whose arithmetic the batched kernels reproduce bit for bit
         if (opts->blending == APS_BLEND_MULTIBAND && !std::getenv("APS_RENDER_LEGACY") &&
-            render_multiband_batched(P.dev, n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr)) {
+            render_multiband_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr)) {
             oP.commit();
             oC.commit();
             APS_HIP(hipStreamSynchronize(stream()));

@@ -797,7 +797,138 @@ void launch_down(int r, const RwArgs& A, int l, const int* blk_ptr, int n_blocks
 
 }  // namespace
 
-bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
+namespace {
+
+// Footprints on the host (cylindrical / spherical canvases): the image rectangle [1,w] x [1,h] maps to a region of the
+// canvas whose outline is the forward image of the rectangle's border (pixel -> K^-1 -> R' -> angles -> canvas pixels,
+// f64 on the f32 camera / canvas values the kernels use).  The outline, sampled in short chords and grown by half a pixel,
+// is clipped against each tile (Sutherland-Hodgman) and the clipped polygon's bounding box, padded by 3 pixels (chord sag
+// < 0.1, f32 vs f64 rounding < 0.01), is a SUPERSET of the tile pixels that sample the image - which is all a footprint must
+// be (kernels evaluate the exact predicate per pixel inside it).  This replaces the coverage kernel and its read-back.
+// Not applicable (returns false, the caller runs rw_cover_kernel): planar / stereographic canvases, an outline that
+// crosses the theta = +-pi seam, an image that contains a pole.
+bool host_footprints(const DevImage* himgs, int n_img, const DevCanvas& cv, const std::vector<RwTile>& tiles, std::vector<int>& hbox) {
+    if (cv.mode != APS_PROJ_SPHERICAL && cv.mode != APS_PROJ_CYLINDRICAL) return false;
+    const double f = (double)cv.f, o0 = (double)cv.o0, o1 = (double)cv.o1;
+    const int nt = (int)tiles.size();
+    std::fill(hbox.begin(), hbox.end(), 0);
+    std::vector<double> px, py, qx, qy, rx, ry;
+    const double kPi = 3.14159265358979323846;
+    for (int i = 0; i < n_img; ++i) {
+        const DevImage& im = himgs[i];
+        if (!(im.fx > 0.f) || !(im.fy > 0.f)) return false;
+        const double R[9] = {im.R[0], im.R[1], im.R[2], im.R[3], im.R[4], im.R[5], im.R[6], im.R[7], im.R[8]};
+        auto to_canvas = [&](double u, double v, double& x, double& y, double& th) {
+            const double c[3] = {(u - im.cx) / im.fx, (v - im.cy) / im.fy, 1.0};
+            // cam = R d  (device: cam[c] = d0 R[c] + d1 R[c+3] + d2 R[c+6])  =>  d = R' cam: d[j] = sum_c R[c + 3j] cam[c]
+            const double d0 = R[0] * c[0] + R[1] * c[1] + R[2] * c[2];
+            const double d1 = R[3] * c[0] + R[4] * c[1] + R[5] * c[2];
+            const double d2 = R[6] * c[0] + R[7] * c[1] + R[8] * c[2];
+            th = std::atan2(d0, d2);
+            const double hz = std::hypot(d0, d2);
+            const double b = cv.mode == APS_PROJ_SPHERICAL ? std::atan2(d1, hz) : d1 / hz;
+            x = (th - o0) * f;
+            y = (b - o1) * f;
+        };
+        // a pole inside the image: the elevation has an interior extremum, the outline does not bound the region
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+            const double cz = R[5] * sgn;  // cam = R (0, sgn, 0)'
+            if (cz > 1e-9) {
+                const double u = im.fx * (R[3] * sgn / cz) + im.cx, v = im.fy * (R[4] * sgn / cz) + im.cy;
+                if (u >= -1 && u <= im.w + 2 && v >= -1 && v <= im.h + 2) return false;
+            }
+        }
+        px.clear();
+        py.clear();
+        // chord length ~ 1/64 of the shorter side (at least 4 px): the sag stays far below the 3-pixel pad
+        const double u0 = 0.5, u1 = im.w + 0.5, v0 = 0.5, v1 = im.h + 0.5, step = std::max(4.0, std::min(im.w, im.h) / 64.0);
+        double prev_th = 0;
+        bool first = true, ok = true;
+        auto add = [&](double u, double v) {
+            double x, y, th;
+            to_canvas(u, v, x, y, th);
+            if (!std::isfinite(x) || !std::isfinite(y)) ok = false;
+            if (!first && std::fabs(th - prev_th) > 0.5 * kPi) ok = false;  // seam crossing (or a degenerate camera)
+            prev_th = th;
+            first = false;
+            px.push_back(x);
+            py.push_back(y);
+        };
+        for (double u = u0; u < u1; u += step) add(u, v0);
+        for (double v = v0; v < v1; v += step) add(u1, v);
+        for (double u = u1; u > u0; u -= step) add(u, v1);
+        for (double v = v1; v > v0; v -= step) add(u0, v);
+        add(u0, v0);
+        if (!ok) return false;
+        double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+        for (size_t q = 0; q < px.size(); ++q) {
+            bx0 = std::min(bx0, px[q]);
+            bx1 = std::max(bx1, px[q]);
+            by0 = std::min(by0, py[q]);
+            by1 = std::max(by1, py[q]);
+        }
+        for (int t = 0; t < nt; ++t) {
+            const RwTile& T = tiles[t];
+            const double tx0 = T.c0 - 0.5, tx1 = T.c0 + T.wt - 0.5, ty0 = T.r0 - 0.5, ty1 = T.r0 + T.ht - 0.5;
+            if (bx1 < tx0 || bx0 > tx1 || by1 < ty0 || by0 > ty1) continue;
+            // Sutherland-Hodgman against the four sides of the tile
+            qx = px;
+            qy = py;
+            for (int side = 0; side < 4 && !qx.empty(); ++side) {
+                rx.clear();
+                ry.clear();
+                const size_t n = qx.size();
+                auto inside = [&](double x, double y) {
+                    return side == 0 ? x >= tx0 : side == 1 ? x <= tx1 : side == 2 ? y >= ty0 : y <= ty1;
+                };
+                for (size_t q = 0; q < n; ++q) {
+                    const double ax = qx[q], ay = qy[q], bx = qx[(q + 1) % n], by = qy[(q + 1) % n];
+                    const bool ia = inside(ax, ay), ib = inside(bx, by);
+                    if (ia != ib) {
+                        double tt;
+                        if (side < 2) {
+                            const double lim = side == 0 ? tx0 : tx1;
+                            tt = (lim - ax) / (bx - ax);
+                            rx.push_back(lim);
+                            ry.push_back(ay + tt * (by - ay));
+                        } else {
+                            const double lim = side == 2 ? ty0 : ty1;
+                            tt = (lim - ay) / (by - ay);
+                            rx.push_back(ax + tt * (bx - ax));
+                            ry.push_back(lim);
+                        }
+                    }
+                    if (ib) {
+                        rx.push_back(bx);
+                        ry.push_back(by);
+                    }
+                }
+                qx.swap(rx);
+                qy.swap(ry);
+            }
+            if (qx.empty()) continue;
+            double cx0 = 1e300, cx1 = -1e300, cy0 = 1e300, cy1 = -1e300;
+            for (size_t q = 0; q < qx.size(); ++q) {
+                cx0 = std::min(cx0, qx[q]);
+                cx1 = std::max(cx1, qx[q]);
+                cy0 = std::min(cy0, qy[q]);
+                cy1 = std::max(cy1, qy[q]);
+            }
+            const double m = 3.0;
+            int* b = &hbox[((size_t)t * n_img + i) * 4];
+            b[0] = std::max(0, (int)std::floor(cx0 - m) - T.c0);
+            b[1] = std::max(0, (int)std::floor(cy0 - m) - T.r0);
+            b[2] = std::min(T.wt, (int)std::ceil(cx1 + m) + 1 - T.c0);
+            b[3] = std::min(T.ht, (int)std::ceil(cy1 + m) + 1 - T.r0);
+            if (b[2] <= b[0] || b[3] <= b[1]) b[0] = b[1] = b[2] = b[3] = 0;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
                               const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered) {
     const int nt = (int)tiles.size();
     if (nt == 0) return true;
@@ -899,21 +1030,43 @@ bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas&
     A.out_layout = out_layout;
     A.white = o.canvas_white;
 
-    // ---- pass 1: coverage + weight sums, one read-back of the footprints -------------------------------------
-    const int nby_max = cdiv(max_ht, 8);
-    Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
-    Ws<int> d_bbox((size_t)nt * n_img * 4);
+    // ---- pass 1: the footprint rectangle of every image in every tile ----------------------------------------------
+    // on the host where the projection allows it (no kernel, no read-back), else by the exact coverage kernel
     std::vector<int> hbox((size_t)nt * n_img * 4);
-    APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
-    {
-        Prof prof("render_cover");
-        rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
-        rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
-                                                                                nt * n_img, d_bbox);
+    const bool check_rects = std::getenv("APS_RENDER_CHECK_RECTS") != nullptr;
+    const bool analytic = !std::getenv("APS_RENDER_DEVICE_COVER") && host_footprints(himgs, n_img, cv, ht_, hbox);
+    if (!analytic || check_rects) {
+        const int nby_max = cdiv(max_ht, 8);
+        Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
+        Ws<int> d_bbox((size_t)nt * n_img * 4);
+        std::vector<int> dbox((size_t)nt * n_img * 4);
+        APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
+        {
+            Prof prof("render_cover");
+            rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
+            rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
+                                                                                    nt * n_img, d_bbox);
+        }
+        check_launch("rw_cover_kernel");
+        APS_HIP(hipMemcpyAsync(dbox.data(), d_bbox, dbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (analytic) {  // test hook: every exact footprint must lie inside its analytic rectangle
+            for (size_t e = 0; e < dbox.size() / 4; ++e) {
+                const int* d = &dbox[4 * e];
+                const int* hb = &hbox[4 * e];
+                if (!(d[2] > d[0] && d[3] > d[1])) continue;
+                // the coverage kernel reports whole 32 x 8 blocks (32 << xshift wide): compare on that grid
+                const int t_ = (int)(e / n_img), gx = 32 << xshift[t_];
+                const bool inside = hb[2] > hb[0] && hb[0] / gx * gx <= d[0] && hb[1] / 8 * 8 <= d[1] &&
+                                    std::min((hb[2] + gx - 1) / gx * gx, ht_[t_].wt) >= d[2] && std::min((hb[3] + 7) / 8 * 8, ht_[t_].ht) >= d[3];
+                APS_REQUIRE(inside, APS_E_INTERNAL,
+                            "analytic footprint [%d %d %d %d] does not contain the exact one [%d %d %d %d] (tile %zu, image %zu)",
+                            hb[0], hb[1], hb[2], hb[3], d[0], d[1], d[2], d[3], e / n_img, e % n_img);
+            }
+        } else {
+            hbox = dbox;
+        }
     }
-    check_launch("rw_cover_kernel");
-    APS_HIP(hipMemcpyAsync(hbox.data(), d_bbox, hbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
-    APS_HIP(hipStreamSynchronize(stream()));
 
     // ---- entries, compact stores, block tables ----------------------------------------------------------------
     std::vector<RwEntry> ents;

@@ -251,9 +251,9 @@ struct TileRect {
     int r0, c0, ht, wt;
 };
 // Renders the given tiles of the canvas with multiband blending, all tiles in one launch sequence.  dimgs: the
-// prepared device image table.  pano/covered are DEVICE pointers.  Returns false when the configuration is outside
+// prepared device image table, himgs its host copy (the analytic footprints read the cameras there).  pano/covered are DEVICE pointers.  Returns false when the configuration is outside
 // what the batched kernels are built for (the caller then takes the per-tile path).
-bool render_multiband_batched(const DevImage* dimgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
+bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
                               const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered);
 
 }  // namespace aps

@@ -73,8 +73,9 @@ def test_render_4k_multitile_batched_equals_per_tile_path(mods, monkeypatch):
     opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
     sizes = [(H, W, 3)] * 16
     outs = []
-    keys = ("APS_RENDER_LEGACY", "APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE")
-    for env in ({}, {"APS_RENDER_LEGACY": "1"}, {"APS_RENDER_LEGACY": "1", "APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
+    keys = ("APS_RENDER_LEGACY", "APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE", "APS_RENDER_CHECK_RECTS")
+    for env in ({"APS_RENDER_CHECK_RECTS": "1"}, {"APS_RENDER_LEGACY": "1"},
+                {"APS_RENDER_LEGACY": "1", "APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

@@ -394,7 +394,15 @@ def test_batched_multiband_equals_per_tile_path(rp, monkeypatch, mode, levels, t
     opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": levels, "pyrSigma": sigma, "tile": tile,
             "cropBorder": False, "canvasColor": "white" if white else "black", "margin": 0.08}
     monkeypatch.delenv("APS_RENDER_LEGACY", raising=False)
+    # APS_RENDER_CHECK_RECTS: the analytic (host) footprints of the cylindrical / spherical canvases are checked against the
+    # exact coverage kernel inside the call - every exact footprint must lie inside its analytic rectangle
+    monkeypatch.setenv("APS_RENDER_CHECK_RECTS", "1")
     pano, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
+    monkeypatch.delenv("APS_RENDER_CHECK_RECTS")
+    monkeypatch.setenv("APS_RENDER_DEVICE_COVER", "1")  # and the panorama must not depend on where the footprints came from
+    pano_d, _, cov_d, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
+    monkeypatch.delenv("APS_RENDER_DEVICE_COVER")
+    assert np.array_equal(pano, pano_d) and np.array_equal(cov, cov_d)
     monkeypatch.setenv("APS_RENDER_LEGACY", "1")
     ref, _, rcov, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
     assert cov.sum() > 20000 and (cov == 0).sum() > 100
@@ -417,3 +425,37 @@ def test_batched_multiband_tile_subsets_compose(rp, monkeypatch):
     assert np.array_equal(np.maximum(parts[0][0], parts[1][0]), full)
     assert np.array_equal(np.maximum(parts[0][2], parts[1][2]), cov)
     assert not np.any((parts[0][2] == 1) & (parts[1][2] == 1))
+
+
+@pytest.mark.parametrize("mode", ["spherical", "cylindrical"])
+def test_analytic_footprints_contain_the_exact_ones_for_tilted_wide_and_near_pole_cameras(rp, monkeypatch, mode):
+    """Host-side footprints (forward image of the image border, clipped per tile) against the exact coverage kernel:
+    rolled and pitched cameras, a wide field of view, views close to a pole and one ACROSS the theta = +-pi seam (for which
+    the analytic path must step aside and the coverage kernel take over) - the check inside the library raises if an exact
+    footprint leaves its analytic rectangle; the panorama must equal the device-cover one in every byte."""
+    rng = np.random.default_rng(41)
+    W, H = 200, 150
+    def rot(yaw, pitch, roll):
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1.0]])
+        return (Ry @ Rx @ Rz).T
+    poses = [(0.0, 0.0, 0.0, 260.0), (0.5, 0.3, 0.4, 260.0), (-0.6, -0.5, -0.7, 180.0), (1.2, 0.9, 0.2, 300.0),
+             (-1.4, -1.0, 1.0, 240.0), (2.2, 0.1, -0.3, 120.0)]
+    if mode == "spherical":
+        poses.append((3.1, 0.2, 0.1, 260.0))  # straddles the seam: analytic path declines, device cover runs
+    imgs, cams = [], []
+    for (yaw, pitch, roll, f) in poses:
+        base = rng.random((H // 8 + 2, W // 8 + 2, 3))
+        imgs.append((np.kron(base, np.ones((8, 8, 1)))[:H, :W] * 255).astype(np.uint8))
+        cams.append({"K": np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]]), "R": rot(yaw, pitch, roll)})
+    sizes = [(H, W, 3)] * len(imgs)
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 4, "pyrSigma": 1.0, "tile": (96, 128), "cropBorder": False}
+    monkeypatch.setenv("APS_RENDER_CHECK_RECTS", "1")
+    pano, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, mode, 0, opts, return_covered=True)
+    monkeypatch.delenv("APS_RENDER_CHECK_RECTS")
+    monkeypatch.setenv("APS_RENDER_DEVICE_COVER", "1")
+    ref, _, rcov, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 0, opts, return_covered=True)
+    monkeypatch.delenv("APS_RENDER_DEVICE_COVER")
+    assert cov.sum() > 20000 and np.array_equal(cov, rcov) and np.array_equal(pano, ref)
