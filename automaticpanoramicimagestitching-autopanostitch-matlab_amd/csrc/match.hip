@@ -1205,19 +1205,29 @@ __global__ void filter_mark_kernel(const FilterJob* __restrict__ fj, int njobs, 
 
 __global__ void filter_select_kernel(const FilterJob* __restrict__ fj, int njobs,
                                      int64_t total_rows, const uint32_t* __restrict__ idx,
-                                     int unique, unsigned long long* __restrict__ keys,
+                                     int unique, const unsigned long long* __restrict__ keys,
                                      const unsigned long long* __restrict__ winner,
+                                     unsigned long long* __restrict__ packed,  // kept keys, dense per job
                                      unsigned long long* __restrict__ job_count) {
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (slot >= total_rows) return;
-    unsigned long long key = keys[slot];
+    const unsigned long long key = keys[slot];
     if (key == ~0ull) return;
     const int j = find_job(fj, njobs, slot);
-    if (unique && winner[fj[j].col_off + (idx[slot] - 1)] != key) {
-        keys[slot] = ~0ull;
-        return;
-    }
-    atomicAdd(&job_count[j], 1ull);
+    if (unique && winner[fj[j].col_off + (idx[slot] - 1)] != key) return;
+    // the kept keys of a job form the head of its own row segment (any order: the sort that follows
+    // works on distinct keys), so the sort touches the survivors only
+    const unsigned long long pos = atomicAdd(&job_count[j], 1ull);
+    packed[fj[j].row_off + pos] = unique ? key : (key & 0xffffffffull);  // non-unique lists are in row order
+}
+
+__global__ void filter_seg_end_kernel(const FilterJob* __restrict__ fj, int njobs,
+                                      const unsigned long long* __restrict__ job_count,
+                                      int64_t* __restrict__ seg_begin, int64_t* __restrict__ seg_end) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
+    seg_begin[j] = fj[j].row_off;
+    seg_end[j] = fj[j].row_off + (int64_t)job_count[j];
 }
 
 // After sorting each job's key segment ascending, the kept entries are the first job_count[j] keys.
@@ -1242,8 +1252,8 @@ __global__ void filter_emit_kernel(const FilterJob* __restrict__ fj, int njobs,
     }
 }
 
-// keys for the non-unique case must sort by row only: rewrite (d,row) -> (0,row) keeping d aside is
-// unnecessary because the emit kernel re-reads d1; handled by a variant below.
+// The non-unique list is emitted in row order: filter_select_kernel reduced its keys to the row, the metric is
+// re-read from d1.
 __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
                                         const unsigned long long* __restrict__ sorted_keys,
                                         const unsigned long long* __restrict__ job_ptr,
@@ -1265,10 +1275,6 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
     }
 }
 
-__global__ void keys_rows_only_kernel(unsigned long long* __restrict__ keys, int64_t n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n && keys[i] != ~0ull) keys[i] &= 0xffffffffull;
-}
 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
@@ -1568,8 +1574,8 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
     Ws<FilterJob> dfj(njobs);
     APS_HIP(hipMemcpyAsync(dfj, fjobs.data(), njobs * sizeof(FilterJob), hipMemcpyHostToDevice,
                            stream()));
-    Ws<unsigned long long> keys(total_rows), sorted(total_rows), winner(std::max<int64_t>(total_cols, 1)),
-        cnt(njobs + 1);
+    Ws<unsigned long long> keys(total_rows), packed(total_rows), sorted(total_rows),
+        winner(std::max<int64_t>(total_cols, 1)), cnt(njobs + 1);
     APS_HIP(hipMemsetAsync(winner, 0xff, std::max<int64_t>(total_cols, 1) * sizeof(unsigned long long),
                            stream()));
     APS_HIP(hipMemsetAsync(cnt, 0, (njobs + 1) * sizeof(unsigned long long), stream()));
@@ -1580,12 +1586,8 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
                                                     o.match_threshold, o.unique, keys, winner);
     check_launch("filter_mark_kernel");
     filter_select_kernel<<<grid, 256, 0, stream()>>>(dfj, njobs, total_rows, idx, o.unique, keys,
-                                                      winner, cnt);
+                                                      winner, packed, cnt);
     check_launch("filter_select_kernel");
-    if (!o.unique) {
-        keys_rows_only_kernel<<<grid, 256, 0, stream()>>>(keys, total_rows);
-        check_launch("keys_rows_only_kernel");
-    }
     {  // job_ptr = exclusive scan of the per-job counts, with the total in slot njobs (cnt[njobs] is a zero pad)
         size_t sb = 0;
         APS_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.get(), d_job_ptr, 0ull, (size_t)njobs + 1,
@@ -1595,24 +1597,21 @@ static int64_t run_filter(const std::vector<FilterJob>& fjobs, int64_t total_row
                                         rocprim::plus<unsigned long long>(), stream()));
     }
 
-    // segmented ascending sort of each job's keys; dropped rows (~0) sink to the segment's end
-    std::vector<int64_t> seg(njobs + 1);
-    for (int j = 0; j < njobs; ++j) seg[j] = fjobs[j].row_off;
-    seg[njobs] = total_rows;
-    Ws<int64_t> dseg(njobs + 1);
-    APS_HIP(hipMemcpyAsync(dseg, seg.data(), (njobs + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
-                           stream()));
+    // segmented ascending sort of each job's kept keys (the head of its row segment)
+    Ws<int64_t> dseg(2 * (int64_t)njobs);
+    filter_seg_end_kernel<<<cdiv(njobs, 256), 256, 0, stream()>>>(dfj, njobs, cnt, dseg.get(), dseg.get() + njobs);
+    check_launch("filter_seg_end_kernel");
     size_t tmp_bytes = 0;
-    APS_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, keys.get(), sorted.get(),
+    APS_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, packed.get(), sorted.get(),
                                                (unsigned)total_rows, (unsigned)njobs, dseg.get(),
-                                               dseg.get() + 1, 0, 64, stream()));
+                                               dseg.get() + njobs, 0, 64, stream()));
     Ws<char> tmp(tmp_bytes);
-    APS_HIP(rocprim::segmented_radix_sort_keys(tmp.get(), tmp_bytes, keys.get(), sorted.get(),
+    APS_HIP(rocprim::segmented_radix_sort_keys(tmp.get(), tmp_bytes, packed.get(), sorted.get(),
                                                (unsigned)total_rows, (unsigned)njobs, dseg.get(),
-                                               dseg.get() + 1, 0, 64, stream()));
+                                               dseg.get() + njobs, 0, 64, stream()));
     unsigned long long total = 0;
     APS_HIP(hipMemcpyAsync(&total, d_job_ptr + njobs, sizeof total, hipMemcpyDeviceToHost, stream()));
-    APS_HIP(hipStreamSynchronize(stream()));  // also keeps fjobs/seg alive long enough
+    APS_HIP(hipStreamSynchronize(stream()));  // also keeps fjobs alive long enough
     if ((int64_t)total > cap) return (int64_t)total;
     if (total > 0) {
         for (int job0 = 0; job0 < njobs; job0 += 65535) {  // gridDim.y is capped at 65535 (500 images = 124750 pairs)

@@ -193,19 +193,23 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                                                          const double* __restrict__ pts2,
                                                          int64_t ldp,
                                                          const int64_t* __restrict__ pair_ptr,
-                                                         int n_pairs,
+                                                         const int* __restrict__ act, int n_act,
+                                                         int c0, int nc,
                                                          const uint32_t* __restrict__ sample_idx,
                                                          int n_samples, double* __restrict__ Hs,
                                                          uint8_t* __restrict__ valid, int mlesac) {
+    // work item = (active pair a, draw c0 + k): the host hands the draws over in growing chunks and stops a pair as
+    // soon as its sequential loop has ended, so most of the n_samples draws of a pair are never fitted or scored.
+    // Hs keeps the [pair][draw] layout (the finalize kernel picks the winner there); valid is chunk-local [a][k].
     extern __shared__ __attribute__((aligned(16))) double lds_fit[];
     constexpr int S = 64;  // one 9x9 problem per lane
     double* sG = lds_fit;
     double* sV = lds_fit + 81 * 64;
     const int lane = threadIdx.x;
-    const int64_t gid = blockIdx.x * (int64_t)64 + lane;
-    const int64_t total = (int64_t)n_pairs * n_samples;
-    if (gid >= total) return;  // no barriers below: every lane works on its own LDS column
-    const int p = (int)(gid / n_samples);
+    const int64_t wid = blockIdx.x * (int64_t)64 + lane;
+    if (wid >= (int64_t)n_act * nc) return;  // no barriers below: every lane works on its own LDS column
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
     const int64_t r0 = pair_ptr[p];
     const int64_t m = pair_ptr[p + 1] - r0;
     double x1[4], y1[4], x2[4], y2[4];
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
         ok = gram_to_h<64>(sG, sV, lane, n1, n2, H, mlesac) && (mlesac || check_model(H));
     }
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
-    valid[gid] = ok ? 1 : 0;
+    valid[wid] = ok ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,19 +384,21 @@ __device__ double wave_mlesac_eval(const Mat3& H, const double* __restrict__ x1,
 
 __global__ __launch_bounds__(256) void mlesac_score_kernel(
     const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
-    const int64_t* __restrict__ pair_ptr, int n_pairs, int n_samples, const double* __restrict__ Hs,
+    const int64_t* __restrict__ pair_ptr, const int* __restrict__ act, int n_act, int c0, int nc,
+    int n_samples, const double* __restrict__ Hs,
     const uint8_t* __restrict__ valid, double thr, int32_t* __restrict__ n_inl, double* __restrict__ acc_dis) {
-    const int64_t gid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
-    if (gid >= (int64_t)n_pairs * n_samples) return;
+    const int64_t wid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);  // (active pair, draw of the chunk)
+    if (wid >= (int64_t)n_act * nc) return;
     const int lane = threadIdx.x & 63;
-    if (!valid[gid]) {
+    if (!valid[wid]) {
         if (lane == 0) {
-            n_inl[gid] = 0;
-            acc_dis[gid] = NAN;
+            n_inl[wid] = 0;
+            acc_dis[wid] = NAN;
         }
         return;
     }
-    const int p = (int)(gid / n_samples);
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
     const int64_t r0 = pair_ptr[p];
     const int64_t m = pair_ptr[p + 1] - r0;
     Mat3 H;
@@ -401,28 +407,30 @@ __global__ __launch_bounds__(256) void mlesac_score_kernel(
     int n;
     const double acc = wave_mlesac_eval(H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr, nullptr, &n);
     if (lane == 0) {
-        n_inl[gid] = n;
-        acc_dis[gid] = acc;
+        n_inl[wid] = n;
+        acc_dis[wid] = acc;
     }
 }
 
 // one wave per (pair, draw); 4 waves per block
 __global__ __launch_bounds__(256) void ransac_score_kernel(
     const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
-    const int64_t* __restrict__ pair_ptr, int n_pairs, int n_samples, const double* __restrict__ Hs,
+    const int64_t* __restrict__ pair_ptr, const int* __restrict__ act, int n_act, int c0, int nc,
+    int n_samples, const double* __restrict__ Hs,
     const uint8_t* __restrict__ valid, double thr, int32_t* __restrict__ n_inl,
     double* __restrict__ mean_err) {
-    const int64_t gid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
-    if (gid >= (int64_t)n_pairs * n_samples) return;
+    const int64_t wid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);  // (active pair, draw of the chunk)
+    if (wid >= (int64_t)n_act * nc) return;
     const int lane = threadIdx.x & 63;
-    if (!valid[gid]) {
+    if (!valid[wid]) {
         if (lane == 0) {
-            n_inl[gid] = 0;
-            mean_err[gid] = NAN;
+            n_inl[wid] = 0;
+            mean_err[wid] = NAN;
         }
         return;
     }
-    const int p = (int)(gid / n_samples);
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
     const int64_t r0 = pair_ptr[p];
     const int64_t m = pair_ptr[p + 1] - r0;
     Mat3 H;
@@ -432,8 +440,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(
     const int n = wave_find_inliers(H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr,
                                     nullptr, &me);
     if (lane == 0) {
-        n_inl[gid] = n;
-        mean_err[gid] = me;
+        n_inl[wid] = n;
+        mean_err[wid] = me;
     }
 }
 
@@ -697,48 +705,46 @@ static void check_opts(const aps_ransac_opts& o) {
     APS_REQUIRE(o.confidence > 0 && o.confidence < 100, APS_E_ARG, "inliersConfidence must be in (0,100)");
 }
 
-// The sequential part of the loop (:94-143) over pre-scored draws.  Returns the winning draw or -1.
+// The sequential part of the loop (:94-143) over pre-scored draws, resumable: the draws of a pair arrive in chunks
+// and the loop state is carried from one chunk to the next, so the outcome is that of one pass over all of them.
 static thread_local int g_draws_exhausted = 0;  // pairs of this thread's last call whose draws ran out (see aps.h)
 
-static int replay_loop(const uint8_t* valid, const int32_t* n_inl, const double* mean_err,
-                       int n_samples, int64_t m, const aps_ransac_opts& o, int* trials_used) {
+struct Replay {
+    int trial = 1, skip = 0, it = 0, best_it = -1, best_n = 0, limit = 0;
+    double best = INFINITY;
+    bool done = false;
+};
+
+// valid/n_inl/mean_err hold draws [st.it, upto) of this pair
+static void replay_loop(Replay& st, const uint8_t* valid, const int32_t* n_inl, const double* mean_err, int upto,
+                        int64_t m, const aps_ransac_opts& o) {
     const int min_pts = 4;
-    int max_trials = o.max_iter;
     const int max_skip = o.max_iter * 10;
-    int trial = 1, skip = 0, it = 0, best_n = 0, best_it = -1;
-    double best_err = INFINITY;
-    if (m < min_pts) {
-        if (trials_used) *trials_used = 0;
-        return -1;
-    }
-    while (trial <= max_trials && skip < max_skip && it < n_samples) {
-        const int cur = it++;
+    const int base = st.it;
+    while (st.trial <= st.limit && st.skip < max_skip && st.it < upto) {
+        const int cur = st.it++ - base;
         if (!valid[cur]) {
-            ++skip;
+            ++st.skip;
             continue;
         }
         const int n = n_inl[cur];
         if (n >= min_pts) {
             const double me = mean_err[cur];
-            if (n > best_n || (n == best_n && me < best_err)) {
-                best_n = n;
-                best_err = me;
-                best_it = cur;
+            if (n > st.best_n || (n == st.best_n && me < st.best)) {
+                st.best_n = n;
+                st.best = me;
+                st.best_it = base + cur;
                 const double ratio = (double)n / (double)m;
                 if (ratio > 0) {
                     const double need = std::ceil(std::log(1 - o.confidence / 100) /
                                                   std::log(1 - std::pow(ratio, min_pts)));
-                    if (need < (double)max_trials) max_trials = (int)need;
+                    if (need < (double)st.limit) st.limit = (int)need;
                 }
             }
         }
-        ++trial;
+        ++st.trial;
     }
-    // the reference keeps drawing until trial > maxTrials or skipTrials reaches 10*maxIter (:94); here the draws are
-    // an input, and running out of them first means the sequential loop would have gone on
-    if (it == n_samples && trial <= max_trials && skip < max_skip) ++g_draws_exhausted;
-    if (trials_used) *trials_used = it;
-    return best_it;
+    st.done = !(st.trial <= st.limit && st.skip < max_skip);
 }
 
 // vision.internal.ransac.computeLoopNumber restated (toolbox-internal, unpinned): sample size 4
@@ -750,33 +756,25 @@ static int mlesac_loop_number(double confidence, int64_t num_pts, int inlier_num
     return n < 0 ? 0 : (int)n;
 }
 
-// The sequential part of mlesac() (estimateTransformationMLESAC.m:157-211) over pre-scored draws
-static int replay_mlesac(const uint8_t* valid, const int32_t* n_inl, const double* acc_dis, int n_samples, int64_t m,
-                         const aps_ransac_opts& o, int* trials_used) {
-    if (m < 4) {
-        if (trials_used) *trials_used = 0;
-        return -1;
-    }
-    int num_trials = o.max_iter;
+// The sequential part of mlesac() (estimateTransformationMLESAC.m:157-211) over pre-scored draws (resumable, as above)
+static void replay_mlesac(Replay& st, const uint8_t* valid, const int32_t* n_inl, const double* acc_dis, int upto,
+                          int64_t m, const aps_ransac_opts& o) {
     const int max_skip = 10000;  // setDefaultParams: maxIterations (1000) * 10; the caller cannot override it (:72)
-    int idx = 1, skip = 0, it = 0, best_it = -1;
-    double best_dis = o.max_distance * (double)m;
-    while (idx <= num_trials && skip < max_skip && it < n_samples) {
-        const int cur = it++;
+    const int base = st.it;
+    while (st.trial <= st.limit && st.skip < max_skip && st.it < upto) {
+        const int cur = st.it++ - base;
         if (!valid[cur]) {
-            ++skip;
+            ++st.skip;
             continue;
         }
-        if (acc_dis[cur] < best_dis) {
-            best_dis = acc_dis[cur];
-            best_it = cur;
-            num_trials = std::min(num_trials, mlesac_loop_number(o.confidence, m, n_inl[cur]));
+        if (acc_dis[cur] < st.best) {
+            st.best = acc_dis[cur];
+            st.best_it = base + cur;
+            st.limit = std::min(st.limit, mlesac_loop_number(o.confidence, m, n_inl[cur]));
         }
-        ++idx;
+        ++st.trial;
     }
-    if (it == n_samples && idx <= num_trials && skip < max_skip) ++g_draws_exhausted;
-    if (trials_used) *trials_used = it;
-    return best_it;
+    st.done = !(st.trial <= st.limit && st.skip < max_skip);
 }
 
 static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
@@ -793,7 +791,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                            stream()));
     Ws<double> Hs(nh * 9), merr(nh);
     Ws<uint8_t> valid(nh), scratch(std::max<int64_t>(total_rows, 1));
-    Ws<int32_t> ninl(nh), best(n_pairs);
+    Ws<int32_t> ninl(nh), best(n_pairs), d_act(n_pairs);
     const size_t lds_bytes = 2 * 81 * 64 * sizeof(double);
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -803,38 +801,73 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    {
-        Prof prof("ransac_fit");
-    ransac_fit_kernel<<<cdiv(nh, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs,
-                                                                  d_samples, n_samples, Hs, valid, mlesac);
-    }
-    check_launch("ransac_fit_kernel");
-    {
-        Prof prof("ransac_score");
-    if (mlesac)
-        mlesac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples, Hs, valid,
-                                                                o.max_distance, ninl, merr);
-    else
-        ransac_score_kernel<<<cdiv(nh, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_pairs, n_samples,
-                                                                Hs, valid, o.max_distance, ninl, merr);
-    }
-    check_launch("ransac_score_kernel");
-    std::vector<uint8_t> h_valid(nh);
-    std::vector<int32_t> h_ninl(nh), h_best(n_pairs);
-    std::vector<double> h_merr(nh);
-    APS_HIP(hipMemcpyAsync(h_valid.data(), valid, nh, hipMemcpyDeviceToHost, stream()));
-    APS_HIP(hipMemcpyAsync(h_ninl.data(), ninl, nh * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
-    APS_HIP(hipMemcpyAsync(h_merr.data(), merr, nh * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    APS_HIP(hipStreamSynchronize(stream()));
-    if (trials_out) trials_out->assign(n_pairs, 0);
-    g_draws_exhausted = 0;
+    // The reference's loop ends adaptively (a pair with 80 % inliers needs 13 trials, not 564), and only its
+    // sequential part knows when.  So the draws are fitted and scored in growing chunks: after each chunk the host
+    // advances every live pair's loop and only the pairs that have not ended yet get the next chunk.  The first
+    // chunk is sized to one round of the fit kernel (one 64-lane workgroup per CU).
+    std::vector<Replay> st(n_pairs);
+    std::vector<int> act;
     for (int p = 0; p < n_pairs; ++p) {
-        int used = 0;
-        h_best[p] = (mlesac ? replay_mlesac : replay_loop)(h_valid.data() + (int64_t)p * n_samples,
-                                                           h_ninl.data() + (int64_t)p * n_samples,
-                                                           h_merr.data() + (int64_t)p * n_samples, n_samples,
-                                                           h_ptr[p + 1] - h_ptr[p], o, &used);
-        if (trials_out) (*trials_out)[p] = used;
+        const int64_t m = h_ptr[p + 1] - h_ptr[p];
+        st[p].limit = o.max_iter;
+        if (mlesac) st[p].best = o.max_distance * (double)m;
+        if (m < 4)
+            st[p].done = true;
+        else
+            act.push_back(p);
+    }
+    std::vector<uint8_t> h_valid;
+    std::vector<int32_t> h_ninl, h_best(n_pairs);
+    std::vector<double> h_merr;
+    g_draws_exhausted = 0;
+    int c0 = 0, nc_prev = 0;
+    while (!act.empty() && c0 < n_samples) {
+        const int n_act = (int)act.size();
+        int nc = std::max(std::max(16, 2 * nc_prev), 16384 / n_act);
+        nc = std::min(nc, n_samples - c0);
+        const int64_t nw = (int64_t)n_act * nc;
+        APS_HIP(hipMemcpyAsync(d_act, act.data(), n_act * sizeof(int), hipMemcpyHostToDevice, stream()));
+        {
+            Prof prof("ransac_fit");
+            ransac_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                          d_samples, n_samples, Hs, valid, mlesac);
+        }
+        check_launch("ransac_fit_kernel");
+        {
+            Prof prof("ransac_score");
+            if (mlesac)
+                mlesac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                        n_samples, Hs, valid, o.max_distance, ninl, merr);
+            else
+                ransac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                        n_samples, Hs, valid, o.max_distance, ninl, merr);
+        }
+        check_launch("ransac_score_kernel");
+        h_valid.resize(nw);
+        h_ninl.resize(nw);
+        h_merr.resize(nw);
+        APS_HIP(hipMemcpyAsync(h_valid.data(), valid, nw, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(h_ninl.data(), ninl, nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(h_merr.data(), merr, nw * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        std::vector<int> next;
+        for (int a = 0; a < n_act; ++a) {
+            const int p = act[a];
+            (mlesac ? replay_mlesac : replay_loop)(st[p], h_valid.data() + (int64_t)a * nc, h_ninl.data() + (int64_t)a * nc,
+                                                   h_merr.data() + (int64_t)a * nc, c0 + nc, h_ptr[p + 1] - h_ptr[p], o);
+            if (!st[p].done) next.push_back(p);
+        }
+        act.swap(next);
+        c0 += nc;
+        nc_prev = nc;
+    }
+    // the reference keeps drawing until trial > maxTrials or skipTrials reaches its cap (:94); here the draws are an
+    // input, and running out of them first means the sequential loop would have gone on
+    g_draws_exhausted = (int)act.size();
+    if (trials_out) trials_out->assign(n_pairs, 0);
+    for (int p = 0; p < n_pairs; ++p) {
+        h_best[p] = st[p].best_it;
+        if (trials_out) (*trials_out)[p] = st[p].it;
     }
     APS_HIP(hipMemcpyAsync(best, h_best.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice,
                            stream()));
