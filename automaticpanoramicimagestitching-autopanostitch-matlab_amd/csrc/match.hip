@@ -109,7 +109,7 @@ __device__ __forceinline__ unsigned short f16_round_up(float f, float& back) {
 __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
-                                 float* __restrict__ maxsq, float* __restrict__ maxdn) {
+                                 float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x[kDim];
@@ -171,6 +171,62 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         dn[i] = dnv;
         atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
         atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
+    }
+    if (qstat) {  // the int8 screen's set statistics: [0] max |x| (its scale), [2] min ||x||^2 (a NaN orders above +inf)
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < kDim; ++k) m = fmaxf(m, fabsf(x[k]));  // fmaxf drops NaNs; they surface in s / maxsq
+        // (a plain look first: after the first few rows hardly any thread still improves on the running extremes, and
+        // thousands of same-address atomics are what such a kernel's time goes into; a stale look only costs an atomic)
+        const unsigned mb = __float_as_uint(m), sb = __float_as_uint(fabsf(s));
+        if (mb > reinterpret_cast<const volatile unsigned*>(qstat)[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), mb);
+        if (sb < reinterpret_cast<const volatile unsigned*>(qstat)[2]) atomicMin(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+    }
+}
+
+// int8 copy of a prepared set for the screening pre-pass (match_screen_i8_kernel): q = round(x S) with S = 127 / max|x|
+// of the set, in P's (permuted) k order - a dot product does not care as long as both sides agree.  The value q stands
+// for is q * invS with invS = max|x| / 127 AS AN F32 NUMBER, so x = q invS + e holds exactly with e the real residual; dnq =
+// ||e|| rounded up (the fma delivers each e_k correctly rounded).  Eight lanes per row, 16 elements each.
+// qstat[1] = max dnq of the set.
+__device__ __forceinline__ float q8_inv_scale(float absmax) { return __fdiv_rn(absmax, 127.f); }
+
+__global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ Q,
+                                                      float* __restrict__ dnq, float* __restrict__ qstat) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = g >> 3;
+    const int part = (int)(g & 7);
+    const float amax = qstat[0];
+    const float inv_s = q8_inv_scale(amax);
+    const float sc = amax > 0.f ? __fdiv_rn(127.f, amax) : 0.f;
+    float ds = 0.f;
+    if (i < n) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(P + i * kDim + 16 * part);
+        uint32_t w[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = src[q4];
+            const float xs[4] = {v.x, v.y, v.z, v.w};
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float qf = rintf(xs[e] * sc);
+                qf = fminf(fmaxf(qf, -127.f), 127.f);  // (a NaN becomes -127; such sets are never screened)
+                const float r = fmaf(-qf, inv_s, xs[e]);
+                ds = fmaf(r, r, ds);
+                pk |= ((uint32_t)(int)qf & 0xffu) << (8 * e);
+            }
+            w[q4] = pk;
+        }
+        *reinterpret_cast<uint4*>(Q + i * kDim + 16 * part) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    ds += __shfl_xor(ds, 1);
+    ds += __shfl_xor(ds, 2);
+    ds += __shfl_xor(ds, 4);
+    if (i < n && part == 0) {
+        const float d = sqrtf(ds) * 1.001f;  // 130 roundings of 2^-24 in ds, one in the root
+        dnq[i] = d;
+        atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(d));
     }
 }
 
@@ -240,6 +296,13 @@ struct MatchJob {
     const float* augresB;  // [0] largest b2/2 residual, [1] largest dn saturation loss of the B set
     const float* maxsqB;
     const float* maxdnB;
+    // int8 screening operands (q8_desc_kernel): quantised copies, the A rows' residual norms, the sets' statistics
+    // ([0] max |x|, [1] max residual norm, [2] min ||x||^2)
+    const signed char* AQ;
+    const signed char* BQ;
+    const float* dnqA;
+    const float* qstatA;
+    const float* qstatB;
 };
 
 struct WgJob {
@@ -780,6 +843,7 @@ __device__ __forceinline__ void prune_bounds(const MatchJob& jb, int row, float 
     }
 }
 
+template <bool LIST>
 __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __restrict__ jobs,
                                                                 const WgJob* __restrict__ wgs, int n_wg,
                                                                 uint32_t* __restrict__ out_idx,
@@ -788,7 +852,8 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                                                                 unsigned int* __restrict__ fb_count, int ablate,
                                                                 float prune_r2, float prune_thr,
                                                                 uint32_t* __restrict__ t3_idx, float* __restrict__ t3_d,
-                                                                float* __restrict__ t3_b) {
+                                                                float* __restrict__ t3_b,
+                                                                const uint32_t* __restrict__ row_list) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kTileBytes];  // [buf][128][256 B], tile t in buf t % 3
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
@@ -813,12 +878,26 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     const int c = lane & 31;
     const int h = lane >> 5;
     const int nA = jb.nA, nB = jb.nB;
-    const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32
+    // this lane owns tile rows wave * 64 + c and + 32.  LIST = false: the tile is the 512 consecutive A rows from w.row0;
+    // LIST = true: it is the w.list_cnt rows row_list[jb.out_off + w.row0 ...] of this job (the survivors of the int8 screen)
+    int rowid[2];
+    bool rvalid[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int local = wave * 64 + c + 32 * rb;
+        if (LIST) {
+            rvalid[rb] = local < w.list_cnt;
+            rowid[rb] = (int)row_list[jb.out_off + w.row0 + (rvalid[rb] ? local : 0)];
+        } else {
+            rvalid[rb] = w.row0 + local < nA;
+            rowid[rb] = min(w.row0 + local, nA - 1);
+        }
+    }
 
     f16x8 ah[2][8];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        const int arow = min(row0 + 32 * rb, nA - 1);
+        const int arow = rowid[rb];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             ah[rb][s] = *reinterpret_cast<const f16x8*>(jb.AF + (size_t)arow * kDim + 16 * s + 8 * h);
@@ -980,8 +1059,8 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     f16x8 aug_a2 = aug_a;
     if (h == 0) {
         float unused;
-        const unsigned short n0 = f16_round_up(sqrtf(jb.sqA[min(row0, nA - 1)]) * 1.000001f, unused);
-        const unsigned short n1 = f16_round_up(sqrtf(jb.sqA[min(row0 + 32, nA - 1)]) * 1.000001f, unused);
+        const unsigned short n0 = f16_round_up(sqrtf(jb.sqA[rowid[0]]) * 1.000001f, unused);
+        const unsigned short n1 = f16_round_up(sqrtf(jb.sqA[rowid[1]]) * 1.000001f, unused);
         aug_a[3] = __builtin_bit_cast(_Float16, n0);
         aug_a2[3] = __builtin_bit_cast(_Float16, n1);
     }
@@ -1115,8 +1194,8 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const float sb = __shfl(u3[1], src), sb2 = __shfl(u2[1], src), sb1 = __shfl(u1[1], src), sb0 = __shfl(u0[1], src);
         const int c0 = h ? s0 : i0[0], c1 = h ? s1 : i1[0], c2 = h ? s2 : i2[0];
         const float ub = h ? sb : u3[0], ub2 = h ? sb2 : u2[0], ub1 = h ? sb1 : u1[0], ub0 = h ? sb0 : u0[0];
-        const int row = row0 + 32 * h;
-        if (row < nA && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
+        const int row = h ? rowid[1] : rowid[0];
+        if ((h ? rvalid[1] : rvalid[0]) && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
             // Rows that cannot pass the caller's ratio / threshold filter (matchFeaturesScratch.m:170-178) are dismissed
             // on the screened values alone: d1 >= L1 and d2 <= H2 hold for the exact f32 distances (see prune_bounds), so
             // L1 > r^2 H2 (or L1 > MatchThreshold) decides the filter's verdict without the exact evaluation - no gathers,
@@ -1148,6 +1227,276 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     if ((ablate & 8) && blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4))
         printf("wave %d: tail %llu cycles (last block -> exit)\n", wave, __builtin_readcyclecounter() - T_loop_end);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8 screening pre-pass of the filtered entry points
+// ------------------------------------------------------------------------------------------------
+// The ratio / threshold filter (matchFeaturesScratch.m:170-178) keeps a few per cent of the rows of an overlapping pair and
+// next to none of a non-overlapping one, and a row it drops needs no exact 2-NN at all - only a PROOF that it will be
+// dropped.  v_mfma_i32_32x32x32_i8 runs at twice the f16 rate and accumulates exactly, so this pass streams every
+// (A row, B column) product once on int8 copies (q8_desc_kernel) and keeps, per row, nothing but the two largest integer
+// dot products D0 >= D1.  With x = q invS + e on both sides,
+//     a.b_j = invSA invSB D_j + (invSA qa).eb_j + ea.b_j,   |a.b_j - invSA invSB D_j| <= E = dnA NB + (||a|| + dnA) DNB
+// (NB >= every ||b_j||, DNB >= every ||eb_j||), hence for the distances the filter will see
+//     d1 >= a2 + min b2 - 2 (sc D0 + E) - delta =: L1        (every column lies below D0)
+//     d2 <= a2 + max b2 - 2 (sc D1 - E) + delta =: H2        (two distinct columns lie at or above D1)
+// and a row with L1 > r^2 H2 or L1 > MatchThreshold is dismissed here (idx 0, the filter's "no match").  The survivors
+// are listed per job and go through match_cand_f16_kernel<LIST> - the exact machinery on a few per cent of the rows.
+// The selection costs 20 VALU instructions per 32 x 64 block and has no branches: m = the largest of a lane's 16 columns
+// of a block (v_max3), D1 = med3(D0, D1, m), D0 = max(D0, m).  Tracking block maxima instead of single values can only
+// lower D1 (when a row's two best columns share a 16-column group), i.e. raise H2: still a bound.
+// Layout: 128-B rows in LDS, DMA'd lane-linear; the 16-B chunk position is XORed with (row >> 1) & 7 on the DMA's
+// source side and on the ds_read_b128 side, which puts each of ds_read_b128's four lane groups on 16 distinct bank
+// quads.  Three buffers of 256 columns, the hand-over one block early, operand reads three k-steps ahead - the scheme of
+// match_cand_f16_kernel.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kQTN = 256;                 // B columns per LDS tile (8 column blocks per hand-over)
+constexpr int kQBlk = kQTN / 32;
+constexpr int kQTileBytes = kQTN * kDim;  // 32 KiB
+
+struct ScreenSet {  // what the tail needs of a job's two sets
+    float inv_sa, inv_sb, nb, dnb, b2min, b2max, msb;
+    bool ok;
+};
+
+__device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
+    ScreenSet q;
+    const float ama = jb.qstatA[0], amb = jb.qstatB[0];
+    q.inv_sa = q8_inv_scale(ama);
+    q.inv_sb = q8_inv_scale(amb);
+    q.msb = *jb.maxsqB;
+    q.nb = sqrtf(q.msb) * 1.00001f;
+    q.dnb = jb.qstatB[1];
+    q.b2min = jb.qstatB[2];
+    q.b2max = q.msb;
+    // finite, non-degenerate data only (a NaN or an infinity anywhere in a set shows in its max ||x||^2)
+    q.ok = ama > 0.f && amb > 0.f && ama < 1e18f && amb < 1e18f && q.msb < 1e37f && q.b2min >= 0.f;
+    return q;
+}
+
+__global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __restrict__ jobs,
+                                                                 const WgJob* __restrict__ wgs, int n_wg,
+                                                                 uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
+                                                                 float* __restrict__ out_d2, uint32_t* __restrict__ surv_list,
+                                                                 unsigned int* __restrict__ surv_count, float prune_r2,
+                                                                 float prune_thr) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes];  // [buf][256][128 B], tile t in buf t % 3
+    int wg = blockIdx.x;
+    {  // XCD-aware order, as in match_cand_f16_kernel
+        const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const WgJob w = wgs[wg];
+    const MatchJob jb = jobs[w.job];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31;
+    const int h = lane >> 5;
+    const int nA = jb.nA, nB = jb.nB;
+    const int row0 = w.row0 + wave * 64 + c;  // this lane owns rows row0 and row0 + 32 (both halves h see them)
+
+    i32x4 aq[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int arow = min(row0 + 32 * rb, nA - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            aq[rb][s] = *reinterpret_cast<const i32x4*>(jb.AQ + (size_t)arow * kDim + 32 * s + 16 * h);
+    }
+    constexpr int kNone = -2147483647 - 1;
+    int d0[2] = {kNone, kNone}, d1[2] = {kNone, kNone};
+
+    const int ntiles = (nB + kQTN - 1) / kQTN;
+    // DMA pieces: 32 per tile, 1 KiB = 8 LDS rows each; wave w issues pieces 4w .. 4w+3.
+    // lane -> LDS row 8*piece + lane/8, chunk position lane&7, which must hold source chunk pos ^ ((row >> 1) & 7)
+    const int dma_sub = lane >> 3, dma_pos = lane & 7;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto issue_piece = [&](int t, int buf, int u) {
+        const int piece = wave * 4 + u;
+        const int lrow = 8 * piece + dma_sub;
+        const int brow = min(t * kQTN + lrow, nB - 1);
+        const signed char* src = jb.BQ + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
+        const uint32_t dst = lds_base + buf * kQTileBytes + piece * 1024;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    };
+    i32x16 acc[2][2];  // [block parity][owned row]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = kNone;
+
+    // One quarter of the search of a finished block: owned row rb = q >> 1, columns 8 (q & 1) .. + 7 of the lane's 16.
+    // acc[par][rb][r] <-> B column (r&3) + 8*(r>>2) + 4*h of the block.  `limit` (ragged last tile only) = number of
+    // valid columns counted from the block's first.
+    int m_run = kNone;
+    auto fold_quarter = [&](auto PAR, auto Q, auto MASK, int limit) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value, q = decltype(Q)::value;
+        constexpr bool mask = decltype(MASK)::value;
+        constexpr int rb = q >> 1, half = q & 1;
+        const i32x16& a = acc[par][rb];
+        int v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = 8 * half + e;
+            v[e] = a[r];
+            if (mask) v[e] = ((r & 3) + 8 * (r >> 2) + 4 * h) < limit ? v[e] : kNone;
+        }
+        // (volatile asm: left to itself the compiler sinks the whole search of a tile's eight blocks behind the tile's last
+        // MFMA - nothing needs the result earlier - and then has eight blocks' accumulators alive at once)
+        int m = m_run;
+        if (half)
+            asm volatile("v_max3_i32 %0, %0, %1, %2\n\tv_max3_i32 %0, %0, %3, %4\n\tv_max3_i32 %0, %0, %5, %6\n\tv_max3_i32 %0, %0, %7, %8"
+                         : "+v"(m)
+                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        else
+            asm volatile("v_max3_i32 %0, %1, %2, %3\n\tv_max3_i32 %0, %0, %4, %5\n\tv_max3_i32 %0, %0, %6, %7\n\tv_max_i32 %0, %0, %8"
+                         : "=&v"(m)
+                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        m_run = m;
+        if (half) {
+            // the runner-up of {d0, d1, m} given d0 >= d1, then the new best
+            int t0 = d0[rb], t1 = d1[rb];
+            asm volatile("v_med3_i32 %0, %1, %0, %2\n\tv_max_i32 %1, %1, %2" : "+v"(t1), "+v"(t0) : "v"(m));
+            d0[rb] = t0;
+            d1[rb] = t1;
+        }
+    };
+
+    if (ntiles > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(aq[0][s]), "v"(aq[1][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-lane read offsets: row c of a 32-row block, chunk (2s + h) ^ ((c >> 1) & 7)
+    const int hx = (16 * h) ^ (16 * ((c >> 1) & 7));
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int kAhead = 3;
+    i32x4 bq[4];
+    if (ntiles > 0) {
+        if (ntiles > 1) issue_piece(1, 1, 0);
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) bq[s] = *reinterpret_cast<const i32x4*>(lds + c * kDim + ((32 * s) ^ hx));
+    }
+    int b_cur = 0;  // t % 3
+    auto run_tile = [&](int t, auto MASK) __attribute__((always_inline)) {
+        constexpr bool mask = decltype(MASK)::value;
+        const bool more = t + 1 < ntiles;
+        const bool more2 = t + 2 < ntiles;
+        const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
+        const unsigned char* tile = lds + b_cur * kQTileBytes + c * kDim;
+        const unsigned char* tile_n = lds + b_nxt * kQTileBytes + c * kDim;
+        b_cur = b_nxt;
+        static_for<0, kQBlk>([&](auto CB) {
+            constexpr int cb = decltype(CB)::value;
+            constexpr int kLast = kQBlk - 1;
+            constexpr int par = cb & 1;
+            // DMA: pieces 1..3 of tile t+1 in blocks 0, 2, 4; piece 0 of tile t+2 in the last block (after the hand-over,
+            // into the buffer tile t-1 has just left for good)
+            if (cb == 0 || cb == 2 || cb == 4) {
+                if (more) issue_piece(t + 1, b_nxt, cb / 2 + 1);
+            } else if (cb == kLast) {
+                if (more2) issue_piece(t + 2, b_nxt2, 0);
+            }
+            const unsigned char* blk = tile + cb * 32 * kDim;
+            const unsigned char* nblk = cb < kLast ? blk + 32 * kDim : tile_n;
+            const bool fetch = cb < kLast || more;
+            // the block being searched is the previous one: (t, cb - 1), or the last block of tile t - 1 (never ragged)
+            const int limit = mask ? nB - (t * kQTN + (cb - 1) * 32) : 0;
+            static_for<0, 4>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const i32x4 xq = bq[s & 3];
+                if (s + kAhead < 4) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(blk + ((32 * (s + kAhead)) ^ hx));
+                } else if (fetch) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(nblk + ((32 * (s + kAhead - 4)) ^ hx));
+                }
+                if (s == 0) {
+                    acc[par][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xq, aq[0][0], zero16, 0, 0, 0);
+                    acc[par][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xq, aq[1][0], zero16, 0, 0, 0);
+                } else {
+                    acc[par][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xq, aq[0][s], acc[par][0], 0, 0, 0);
+                    acc[par][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xq, aq[1][s], acc[par][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (mask && cb > 0)
+                    fold_quarter(std::integral_constant<int, par ^ 1>{}, S, std::true_type{}, limit);
+                else
+                    fold_quarter(std::integral_constant<int, par ^ 1>{}, S, std::false_type{}, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (cb == kLast - 1) {
+                // hand-over: this wave's DMA pieces of tile t+1 have landed; after the barrier that holds for every
+                // wave, and every wave has left tile t-1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        });
+    };
+    // full tiles run unmasked; a ragged last tile (columns >= nB: the DMA re-reads the last row for them) runs the masked copy
+    const int nfull = nB / kQTN;
+    for (int t = 0; t < nfull; ++t) run_tile(t, std::false_type{});
+    if (nfull < ntiles) {
+        run_tile(nfull, std::true_type{});
+        const int limit = nB - (nfull * kQTN + (kQBlk - 1) * 32);
+        static_for<0, 4>([&](auto S) { fold_quarter(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::true_type{}, limit); });
+    } else if (ntiles > 0) {
+        static_for<0, 4>([&](auto S) { fold_quarter(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::false_type{}, 0); });
+    }
+    // the two halves of a wave saw disjoint columns of the same rows
+    int D0[2], D1[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int p0 = __shfl_xor(d0[rb], 32), p1 = __shfl_xor(d1[rb], 32);
+        D0[rb] = max(d0[rb], p0);
+        D1[rb] = max(min(d0[rb], p0), max(d1[rb], p1));
+    }
+    // the h == 0 half decides row block 0, the h == 1 half row block 1
+    const int row = row0 + 32 * h;
+    const int e0 = h ? D0[1] : D0[0], e1 = h ? D1[1] : D1[0];
+    bool survive = false;
+    if (row < nA) {
+        const ScreenSet q = screen_set(jb);
+        bool pruned = false;
+        if (q.ok && nB >= 2 && e1 != kNone) {
+            const double a2 = (double)jb.sqA[row];
+            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
+            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
+            const double sc = (double)q.inv_sa * (double)q.inv_sb;
+            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
+            const double L1 = a2 + (double)q.b2min - 2.0 * (sc * (double)e0 + E) - delta;
+            const double H2 = a2 + (double)q.b2max - 2.0 * (sc * (double)e1 - E) + delta;
+            const double lo = L1 * (1.0 - 1e-5) - 1e-30;
+            pruned = H2 >= 0.0 && (lo > (double)prune_r2 * H2 * (1.0 + 1e-5) || lo > (double)prune_thr * (1.0 + 1e-5));
+        }
+        if (pruned) {
+            const int64_t slot = jb.out_off + row;
+            out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter drops too)
+            out_d1[slot] = INFINITY;
+            out_d2[slot] = INFINITY;
+        } else {
+            survive = true;
+        }
+    }
+    // survivors: one list segment per job (at the job's first output slot), one counter update per wave
+    const unsigned long long sm = __ballot(survive);
+    if (sm) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long)sm) - 1;
+        if (lane == leader) base = atomicAdd(&surv_count[w.job], (unsigned int)__popcll(sm));
+        base = __shfl(base, leader);
+        if (survive) surv_list[jb.out_off + base + __popcll(sm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1283,6 +1632,8 @@ struct Prepared {
     Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals
     Ws<unsigned short> H;
     Ws<uint4> aug;
+    Ws<signed char> Q;   // int8 screening copy, its residual norms, and the set statistics (see MatchJob)
+    Ws<float> dnq, qstat;
     int64_t n = 0;
 };
 
@@ -1298,12 +1649,18 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     APS_HIP(hipMemsetAsync(out.maxsq, 0, 4 * sizeof(float), stream()));
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
     out.aug.alloc((size_t)n_pad);
+    out.Q.alloc(rows * kDim);
+    out.dnq.alloc(rows);
+    out.qstat.alloc(4);
+    static const float kQstatInit[4] = {0.f, 0.f, INFINITY, 0.f};
+    APS_HIP(hipMemcpyAsync(out.qstat, kQstatInit, sizeof kQstatInit, hipMemcpyHostToDevice, stream()));
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
                                                         out.P, out.sq, out.H, out.dn, out.maxsq,
-                                                        (float*)out.maxsq + 1);
+                                                        (float*)out.maxsq + 1, out.qstat);
     aug_desc_kernel<<<cdiv(n_pad, 256), 256, 0, stream()>>>(out.sq, out.dn, n, n_pad, out.maxsq, out.aug, (float*)out.maxsq + 2);
+    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.Q, out.dnq, out.qstat);
     check_launch("prep_desc_kernel");
 }
 
@@ -1323,6 +1680,11 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.augresB = (const float*)b.maxsq + 2;
     j.maxsqB = b.maxsq;
     j.maxdnB = (const float*)b.maxsq + 1;
+    j.AQ = a.Q;
+    j.BQ = b.Q;
+    j.dnqA = a.dnq;
+    j.qstatA = a.qstat;
+    j.qstatB = b.qstat;
     return j;
 }
 
@@ -1416,16 +1778,53 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         for (int r = 0; r < jobs[j].nA; r += kTMB) bw.push_back({j, r, 0});
     Ws<WgJob> dbw(bw.size());
     APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
-    {
-        Prof prof("match_cand_f16");
 #ifdef APS_MATCH_TIMING  // ablation bits are honoured by timing builds only (they invalidate the results)
-        const char* ab = std::getenv("APS_MATCH_ABLATE");
-        const int ablate = ab ? std::atoi(ab) : 0;
+    const char* ab = std::getenv("APS_MATCH_ABLATE");
+    const int ablate = ab ? std::atoi(ab) : 0;
 #else
-        const int ablate = 0;
+    const int ablate = 0;
 #endif
-        match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list,
-                                                                          fb_count, ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr);
+    // Filtered callers: the int8 screen dismisses the rows that provably fail the filter, the candidate kernel then runs
+    // on the survivors only (row lists per job, 512 to a workgroup).  APS_MATCH_NO_SCREEN=1: every row takes the f16 path.
+    const bool screen = prune_r2 > 0.f && !std::getenv("APS_MATCH_NO_SCREEN");
+    if (screen) {
+        Ws<uint32_t> surv_list((size_t)total_rows);
+        Ws<unsigned int> surv_count(jobs.size());
+        APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
+        {
+            Prof prof("match_screen_i8");
+            match_screen_i8_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list, surv_count,
+                                                                               prune_r2, prune_thr);
+        }
+        check_launch("match_screen_i8_kernel");
+        std::vector<unsigned int> h_surv(jobs.size());
+        APS_HIP(hipMemcpyAsync(h_surv.data(), surv_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        std::vector<WgJob> lw;
+        size_t n_surv = 0;
+        for (int j = 0; j < (int)jobs.size(); ++j) {
+            n_surv += h_surv[j];
+            for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
+        }
+        if (std::getenv("APS_TRACE"))
+            std::fprintf(stderr, "[aps] int8 screen: %zu of %lld rows survive (%.2f %%), %zu list tiles\n", n_surv, (long long)total_rows,
+                         100.0 * (double)n_surv / (double)total_rows, lw.size());
+        if (!lw.empty()) {
+            Ws<WgJob> dlw(lw.size());
+            APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+            {
+                Prof prof("match_cand_f16");
+                match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(djobs, dlw, (int)lw.size(), idx, d1, d2, fb_list, fb_count,
+                                                                                        ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr,
+                                                                                        surv_list);
+            }
+            check_launch("match_cand_f16_kernel<list>");
+            APS_HIP(hipStreamSynchronize(stream()));  // lw must outlive its copy
+        }
+    } else {
+        Prof prof("match_cand_f16");
+        match_cand_f16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list, fb_count,
+                                                                                 ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr, nullptr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
@@ -1533,8 +1932,8 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
     APS_HIP(hipMemsetAsync(fb_count, 0, jobs.size() * sizeof(unsigned int), stream()));
     {
         Prof prof("match_cand_f16");
-        match_cand_f16_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
-                                                                          fb_list, fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b);
+        match_cand_f16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr, fb_list,
+                                                                                 fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, nullptr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
