@@ -172,15 +172,15 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
         atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
     }
-    if (qstat) {  // the int8 screen's set statistics: [0] max |x| (its scale), [2] min ||x||^2 (a NaN orders above +inf)
+    if (qstat) {  // the int8 screen's set statistics: [0] max |x| (its scale), [2] ~bits of min ||x||^2 (zero-fill = no rows yet)
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < kDim; ++k) m = fmaxf(m, fabsf(x[k]));  // fmaxf drops NaNs; they surface in s / maxsq
         // (a plain look first: after the first few rows hardly any thread still improves on the running extremes, and
         // thousands of same-address atomics are what such a kernel's time goes into; a stale look only costs an atomic)
-        const unsigned mb = __float_as_uint(m), sb = __float_as_uint(fabsf(s));
+        const unsigned mb = __float_as_uint(m), sb = ~__float_as_uint(fabsf(s));
         if (mb > reinterpret_cast<const volatile unsigned*>(qstat)[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), mb);
-        if (sb < reinterpret_cast<const volatile unsigned*>(qstat)[2]) atomicMin(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+        if (sb > reinterpret_cast<const volatile unsigned*>(qstat)[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
     }
 }
 
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ 
     if (i < n && part == 0) {
         const float d = sqrtf(ds) * 1.001f;  // 130 roundings of 2^-24 in ds, one in the root
         dnq[i] = d;
-        atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(d));
+        if (__float_as_uint(d) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
+            atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(d));
     }
 }
 
@@ -297,7 +298,7 @@ struct MatchJob {
     const float* maxsqB;
     const float* maxdnB;
     // int8 screening operands (q8_desc_kernel): quantised copies, the A rows' residual norms, the sets' statistics
-    // ([0] max |x|, [1] max residual norm, [2] min ||x||^2)
+    // ([0] max |x|, [1] max residual norm, [2] ~bits of min ||x||^2)
     const signed char* AQ;
     const signed char* BQ;
     const float* dnqA;
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
     q.msb = *jb.maxsqB;
     q.nb = sqrtf(q.msb) * 1.00001f;
     q.dnb = jb.qstatB[1];
-    q.b2min = jb.qstatB[2];
+    q.b2min = __uint_as_float(~__float_as_uint(jb.qstatB[2]));  // stored complemented (prep_desc_kernel)
     q.b2max = q.msb;
     // finite, non-degenerate data only (a NaN or an infinity anywhere in a set shows in its max ||x||^2)
     q.ok = ama > 0.f && amb > 0.f && ama < 1e18f && amb < 1e18f && q.msb < 1e37f && q.b2min >= 0.f;
@@ -1652,8 +1653,7 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.Q.alloc(rows * kDim);
     out.dnq.alloc(rows);
     out.qstat.alloc(4);
-    static const float kQstatInit[4] = {0.f, 0.f, INFINITY, 0.f};
-    APS_HIP(hipMemcpyAsync(out.qstat, kQstatInit, sizeof kQstatInit, hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemsetAsync(out.qstat, 0, 4 * sizeof(float), stream()));
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
@@ -1806,9 +1806,16 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
             n_surv += h_surv[j];
             for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
         }
-        if (std::getenv("APS_TRACE"))
-            std::fprintf(stderr, "[aps] int8 screen: %zu of %lld rows survive (%.2f %%), %zu list tiles\n", n_surv, (long long)total_rows,
-                         100.0 * (double)n_surv / (double)total_rows, lw.size());
+        if (std::getenv("APS_TRACE")) {
+            int hist[5] = {0, 0, 0, 0, 0};  // jobs by surviving share: 0, <1 %, <10 %, <50 %, >= 50 %
+            for (int j = 0; j < (int)jobs.size(); ++j) {
+                const double f = jobs[j].nA ? (double)h_surv[j] / jobs[j].nA : 0.0;
+                ++hist[h_surv[j] == 0 ? 0 : f < 0.01 ? 1 : f < 0.1 ? 2 : f < 0.5 ? 3 : 4];
+            }
+            std::fprintf(stderr, "[aps] int8 screen: %zu of %lld rows survive (%.2f %%), %zu list tiles; jobs by surviving share: none %d, <1%% %d, "
+                         "<10%% %d, <50%% %d, >=50%% %d\n", n_surv, (long long)total_rows, 100.0 * (double)n_surv / (double)total_rows,
+                         lw.size(), hist[0], hist[1], hist[2], hist[3], hist[4]);
+        }
         if (!lw.empty()) {
             Ws<WgJob> dlw(lw.size());
             APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));

@@ -436,3 +436,93 @@ def test_filter_aware_dismissal_changes_no_match(fm, monkeypatch):
     m, met = fm.matchFeaturesScratch(a2, b2, MatchThreshold=3.5, MaxRatio=0.6, Unique=False)
     om, omet = oracle.match_features(a2, b2, 0.6, 3.5, False, 0)
     assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
+def _screen_ab(fm, monkeypatch, a, b, ratio, thr, unique, normalize=2):
+    """match list with the int8 screen, without it, and the oracle's"""
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    m, met = fm.matchFeaturesScratch(a, b, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+    monkeypatch.setenv("APS_MATCH_NO_SCREEN", "1")
+    m0, met0 = fm.matchFeaturesScratch(a, b, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    om, omet = oracle.match_features(a, b, ratio, thr, unique, normalize)
+    assert np.array_equal(m0, om) and np.array_equal(bits(met0), bits(omet))
+    assert np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+    return len(om)
+
+
+@pytest.mark.parametrize("n2", [2, 3, 31, 33, 255, 256, 257, 300, 513, 1025])
+def test_int8_screen_ragged_column_counts(fm, monkeypatch, n2):
+    """The int8 pre-pass streams 256-column tiles of 32-column blocks; the columns past the end of the last tile are
+    re-reads of the last row and must never count as a second neighbour.  Planted matches sit in the last columns."""
+    rng = np.random.default_rng(100 + n2)
+    a, b, ia, ib = planted_pair(rng, 700, n2, min(n2, 200), noise=0.03)
+    b[-1] = a[5] + 0.01 * rng.standard_normal(128).astype(np.float32)  # a clear match in the very last column
+    b[-1] = np.maximum(b[-1], 0) / np.linalg.norm(np.maximum(b[-1], 0))
+    k = _screen_ab(fm, monkeypatch, a, b, 0.6, 3.5, True)
+    assert k > 0
+    _screen_ab(fm, monkeypatch, a, b, 0.9, 0.5, False)
+
+
+def test_int8_screen_adversarial_sets(fm, monkeypatch):
+    """Inputs that stress the screen's bounds: signed data, duplicated best columns (ratio exactly 1), near-duplicates
+    whose ratio sits in the band the int8 error cannot resolve, all-zero rows, a huge dynamic range within a set
+    (tiny rows quantise to zero), and unnormalised 0..255 descriptors."""
+    rng = np.random.default_rng(7)
+    # signed unit rows with planted matches
+    a = rng.standard_normal((1500, 128)).astype(np.float32)
+    b = rng.standard_normal((1800, 128)).astype(np.float32)
+    b[:600] = a[:600] + rng.uniform(0.0, 0.4, 600)[:, None].astype(np.float32) * rng.standard_normal((600, 128)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    for ratio, thr, unique in ((0.6, 3.5, True), (0.8, 1.0, False), (1.0, 3.5, True)):
+        _screen_ab(fm, monkeypatch, a, b, ratio, thr, unique)
+    # duplicated and nearly duplicated best columns
+    a2, b2, ia, ib = planted_pair(rng, 1200, 1500, 500, noise=0.01)
+    b2[1000:1100] = b2[ib[:100]]                                   # exact copies: d1 == d2
+    b2[1100:1200] = b2[ib[100:200]] + 0.004 * rng.standard_normal((100, 128)).astype(np.float32)  # d2 barely above d1
+    b2[1100:1200] = np.maximum(b2[1100:1200], 0)
+    b2[1100:1200] /= np.linalg.norm(b2[1100:1200], axis=1, keepdims=True)
+    b2[1200:1300] = b2[ib[200:300]] + rng.uniform(0.02, 0.08, 100)[:, None].astype(np.float32) * rng.standard_normal((100, 128)).astype(np.float32)
+    b2[1200:1300] = np.maximum(b2[1200:1300], 0)
+    b2[1200:1300] /= np.linalg.norm(b2[1200:1300], axis=1, keepdims=True)
+    for ratio in (0.36, 0.6, 0.85, 1.0):
+        _screen_ab(fm, monkeypatch, a2, b2, ratio, 3.5, True)
+        _screen_ab(fm, monkeypatch, a2, b2, ratio, 0.3, False)
+    # zero rows and a 1e6 dynamic range inside both sets (rows far below the set's quantisation step)
+    a3, b3, _, _ = planted_pair(rng, 900, 1100, 400, noise=0.02)
+    a3[::7] *= 1e-6
+    b3[::5] *= 1e-6
+    a3[3] = 0
+    b3[4] = 0
+    for ratio, thr in ((0.6, 3.5), (0.9, 1e-3)):
+        monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+        pp, ii, jj, met = fm.match_pairwise_csr([a3, b3], ratio, thr, True, normalize=0)
+        monkeypatch.setenv("APS_MATCH_NO_SCREEN", "1")
+        pp0, ii0, jj0, met0 = fm.match_pairwise_csr([a3, b3], ratio, thr, True, normalize=0)
+        monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+        om, omet = oracle.match_features(a3, b3, ratio, thr, True, 0)
+        assert np.array_equal(np.stack([ii, jj], 1), om) and np.array_equal(bits(met), bits(omet))
+        assert np.array_equal(np.stack([ii0, jj0], 1), om) and np.array_equal(bits(met0), bits(omet))
+    # unnormalised 0..255 descriptors: the reference normalises them (max > 2), the screen sees the normalised copy
+    a4, b4, _, _ = planted_pair(rng, 1000, 1300, 500, noise=0.03, unit=False)
+    _screen_ab(fm, monkeypatch, a4, b4, 0.6, 3.5, True)
+
+
+def test_int8_screen_is_off_for_non_finite_sets(fm, monkeypatch):
+    """A NaN or an infinity in a set makes every bound of the screen meaningless: such jobs must take the f16 / f32 path
+    for every row (the set's max ||x||^2 is not finite, which switches the screen off)."""
+    rng = np.random.default_rng(11)
+    a, b, _, _ = planted_pair(rng, 600, 800, 300, noise=0.02)
+    for poison in (np.nan, np.inf):
+        bb = b.copy()
+        bb[17, 3] = poison
+        monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+        pp, ii, jj, met = fm.match_pairwise_csr([a, bb], 0.6, 3.5, True, normalize=0)
+        om, omet = oracle.match_features(a, bb, 0.6, 3.5, True, 0)
+        assert np.array_equal(np.stack([ii, jj], 1), om) and np.array_equal(bits(met), bits(omet))
+        aa = a.copy()
+        aa[9, 100] = poison
+        pp, ii, jj, met = fm.match_pairwise_csr([aa, b], 0.6, 3.5, True, normalize=0)
+        om, omet = oracle.match_features(aa, b, 0.6, 3.5, True, 0)
+        assert np.array_equal(np.stack([ii, jj], 1), om) and np.array_equal(bits(met), bits(omet))
