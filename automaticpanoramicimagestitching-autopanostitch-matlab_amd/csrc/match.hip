@@ -106,6 +106,13 @@ __device__ __forceinline__ unsigned short f16_round_up(float f, float& back) {
     return bits;
 }
 
+// order-preserving f32 <-> u32 (larger float <=> larger unsigned)
+__device__ __forceinline__ unsigned ord_f32(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
@@ -172,62 +179,123 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
         atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
     }
-    if (qstat) {  // the int8 screen's set statistics: [0] max |x| (its scale), [2] ~bits of min ||x||^2 (zero-fill = no rows yet)
-        float m = 0.f;
+    if (qstat) {  // the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
+                  // [0] max x, [3] complement of min x (the column-side copy's range), [2] complement of min ||x||^2
+        float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
-        for (int k = 0; k < kDim; ++k) m = fmaxf(m, fabsf(x[k]));  // fmaxf drops NaNs; they surface in s / maxsq
+        for (int k = 0; k < kDim; ++k) {  // fmaxf / fminf drop NaNs; they surface in s / maxsq
+            mx = fmaxf(mx, x[k]);
+            mn = fminf(mn, x[k]);
+        }
         // (a plain look first: after the first few rows hardly any thread still improves on the running extremes, and
         // thousands of same-address atomics are what such a kernel's time goes into; a stale look only costs an atomic)
-        const unsigned mb = __float_as_uint(m), sb = ~__float_as_uint(fabsf(s));
-        if (mb > reinterpret_cast<const volatile unsigned*>(qstat)[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), mb);
-        if (sb > reinterpret_cast<const volatile unsigned*>(qstat)[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+        const unsigned xb = ord_f32(mx), nb = ~ord_f32(mn), sb = ~__float_as_uint(fabsf(s));
+        volatile const unsigned* look = reinterpret_cast<const volatile unsigned*>(qstat);
+        if (xb > look[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), xb);
+        if (nb > look[3]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 3, nb);
+        if (sb > look[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
     }
 }
 
-// int8 copy of a prepared set for the screening pre-pass (match_screen_i8_kernel): q = round(x S) with S = 127 / max|x|
-// of the set, in P's (permuted) k order - a dot product does not care as long as both sides agree.  The value q stands
-// for is q * invS with invS = max|x| / 127 AS AN F32 NUMBER, so x = q invS + e holds exactly with e the real residual; dnq =
-// ||e|| rounded up (the fma delivers each e_k correctly rounded).  Eight lanes per row, 16 elements each.
-// qstat[1] = max dnq of the set.
-__device__ __forceinline__ float q8_inv_scale(float absmax) { return __fdiv_rn(absmax, 127.f); }
+// int8 copies of a prepared set for the screening pre-pass (match_screen_i8_kernel), in P's (permuted) k order - a dot
+// product does not care as long as both sides agree.  A set is the row side (A) of some pairs and the column side (B) of
+// others, and the two sides can afford different codes, because anything that is constant along a row of the distance
+// matrix leaves the row's ranking alone and is put back in the kernel's tail:
+//   row side   : qa = round(x SA_i), SA_i = 127 / max_k |x_ik| - a scale per ROW (finer steps for rows with small entries)
+//   column side: qb = round(x SB) - cB, SB = 255 / (max x - min x) over the SET, cB = round(SB min x) + 128 - the full
+//                eight bits whatever the data's sign; a.b = invSA_i invSB (qa.qb + cB sum_k qa_k) + error terms.
+// The value a code stands for is defined through the F32 numbers invSA_i = max|x_i| / 127 and invSB = (max - min) / 255:
+// x = q inv + e holds exactly with e the real residual, and the stored norms ||e|| are rounded up (each e_k comes out of
+// an fma correctly rounded).  Eight lanes per row, 16 elements each.
+struct Q8Set {
+    float inv_sb, sb;  // column-side step and its reciprocal (0 / 0 for a degenerate range)
+    float cb;          // column-side offset (an integer)
+};
 
-__global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ Q,
-                                                      float* __restrict__ dnq, float* __restrict__ qstat) {
+__device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
+    const float mx = unord_f32(__float_as_uint(qstat[0])), mn = unord_f32(~__float_as_uint(qstat[3]));
+    Q8Set q;
+    const float range = mx - mn;
+    const bool ok = range > 0.f && range < 1e30f;
+    q.inv_sb = ok ? __fdiv_rn(range, 255.f) : 0.f;
+    q.sb = ok ? __fdiv_rn(255.f, range) : 0.f;
+    q.cb = ok ? rintf(mn * q.sb) + 128.f : 0.f;
+    if (!(fabsf(q.cb) < 1e9f)) {  // a range far from zero relative to its width: the offset no longer fits the tail's arithmetic
+        q.inv_sb = q.sb = q.cb = 0.f;
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
+                                                      signed char* __restrict__ QB, float* __restrict__ dnqa,
+                                                      float* __restrict__ invsa, int* __restrict__ sumqa,
+                                                      float* __restrict__ qstat) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t i = g >> 3;
     const int part = (int)(g & 7);
-    const float amax = qstat[0];
-    const float inv_s = q8_inv_scale(amax);
-    const float sc = amax > 0.f ? __fdiv_rn(127.f, amax) : 0.f;
-    float ds = 0.f;
+    const Q8Set qs = q8_set(qstat);
+    float xs[16];
+    float rmax = 0.f;
     if (i < n) {
         const f32x4* src = reinterpret_cast<const f32x4*>(P + i * kDim + 16 * part);
-        uint32_t w[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const f32x4 v = src[q4];
-            const float xs[4] = {v.x, v.y, v.z, v.w};
-            uint32_t pk = 0;
+            xs[4 * q4] = v.x;
+            xs[4 * q4 + 1] = v.y;
+            xs[4 * q4 + 2] = v.z;
+            xs[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, fabsf(xs[e]));
+    }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 1));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 2));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 4));
+    const bool rok = rmax > 0.f && rmax < 1e30f;
+    const float inv_sa = rok ? __fdiv_rn(rmax, 127.f) : 0.f;
+    const float sa = rok ? __fdiv_rn(127.f, rmax) : 0.f;
+    float dsa = 0.f, dsb = 0.f;
+    int sq = 0;
+    if (i < n) {
+        uint32_t wa[4], wb[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            uint32_t pa = 0, pb = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float qf = rintf(xs[e] * sc);
-                qf = fminf(fmaxf(qf, -127.f), 127.f);  // (a NaN becomes -127; such sets are never screened)
-                const float r = fmaf(-qf, inv_s, xs[e]);
-                ds = fmaf(r, r, ds);
-                pk |= ((uint32_t)(int)qf & 0xffu) << (8 * e);
+                const float x = xs[4 * q4 + e];
+                float qa = rintf(x * sa);
+                qa = fminf(fmaxf(qa, -127.f), 127.f);  // (a NaN becomes -127; such sets are never screened)
+                const float ra = fmaf(-qa, inv_sa, x);
+                dsa = fmaf(ra, ra, dsa);
+                sq += (int)qa;
+                pa |= ((uint32_t)(int)qa & 0xffu) << (8 * e);
+                float qb = rintf(x * qs.sb) - qs.cb;
+                qb = fminf(fmaxf(qb, -128.f), 127.f);
+                const float rb = fmaf(-(qb + qs.cb), qs.inv_sb, x);
+                dsb = fmaf(rb, rb, dsb);
+                pb |= ((uint32_t)(int)qb & 0xffu) << (8 * e);
             }
-            w[q4] = pk;
+            wa[q4] = pa;
+            wb[q4] = pb;
         }
-        *reinterpret_cast<uint4*>(Q + i * kDim + 16 * part) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(QA + i * kDim + 16 * part) = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+        *reinterpret_cast<uint4*>(QB + i * kDim + 16 * part) = make_uint4(wb[0], wb[1], wb[2], wb[3]);
     }
-    ds += __shfl_xor(ds, 1);
-    ds += __shfl_xor(ds, 2);
-    ds += __shfl_xor(ds, 4);
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        dsa += __shfl_xor(dsa, off);
+        dsb += __shfl_xor(dsb, off);
+        sq += __shfl_xor(sq, off);
+    }
     if (i < n && part == 0) {
-        const float d = sqrtf(ds) * 1.001f;  // 130 roundings of 2^-24 in ds, one in the root
-        dnq[i] = d;
-        if (__float_as_uint(d) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
-            atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(d));
+        dnqa[i] = sqrtf(dsa) * 1.001f;  // 130 roundings of 2^-24 in the sum, one in the root
+        invsa[i] = inv_sa;
+        sumqa[i] = sq;
+        const float db = sqrtf(dsb) * 1.001f;  // [1]: the largest column-side residual norm of the set
+        if (__float_as_uint(db) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
+            atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(db));
     }
 }
 
@@ -297,12 +365,13 @@ struct MatchJob {
     const float* augresB;  // [0] largest b2/2 residual, [1] largest dn saturation loss of the B set
     const float* maxsqB;
     const float* maxdnB;
-    // int8 screening operands (q8_desc_kernel): quantised copies, the A rows' residual norms, the sets' statistics
-    // ([0] max |x|, [1] max residual norm, [2] ~bits of min ||x||^2)
+    // int8 screening operands (q8_desc_kernel): the row-side code of A with its per-row step, residual norm and code sum,
+    // the column-side code of B with the set's statistics ([0] max x, [1] max residual norm, [2] ~min ||x||^2, [3] ~min x)
     const signed char* AQ;
     const signed char* BQ;
     const float* dnqA;
-    const float* qstatA;
+    const float* invsA;
+    const int* sumqA;
     const float* qstatB;
 };
 
@@ -1237,9 +1306,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
 // next to none of a non-overlapping one, and a row it drops needs no exact 2-NN at all - only a PROOF that it will be
 // dropped.  v_mfma_i32_32x32x32_i8 runs at twice the f16 rate and accumulates exactly, so this pass streams every
 // (A row, B column) product once on int8 copies (q8_desc_kernel) and keeps, per row, nothing but the two largest integer
-// dot products D0 >= D1.  With x = q invS + e on both sides,
-//     a.b_j = invSA invSB D_j + (invSA qa).eb_j + ea.b_j,   |a.b_j - invSA invSB D_j| <= E = dnA NB + (||a|| + dnA) DNB
-// (NB >= every ||b_j||, DNB >= every ||eb_j||), hence for the distances the filter will see
+// dot products D0 >= D1.  With a = qa invSA + ea and b_j = (qb_j + cB) invSB + eb_j (q8_desc_kernel),
+//     a.b_j = invSA invSB (D_j + cB sum_k qa_k) + (invSA qa).eb_j + ea.b_j,   |error| <= E = dnA NB + (||a|| + dnA) DNB
+// (NB >= every ||b_j||, DNB >= every ||eb_j||; sc D below stands for the bracketed main term), hence for the distances the
+// filter will see
 //     d1 >= a2 + min b2 - 2 (sc D0 + E) - delta =: L1        (every column lies below D0)
 //     d2 <= a2 + max b2 - 2 (sc D1 - E) + delta =: H2        (two distinct columns lie at or above D1)
 // and a row with L1 > r^2 H2 or L1 > MatchThreshold is dismissed here (idx 0, the filter's "no match").  The survivors
@@ -1258,23 +1328,23 @@ constexpr int kQTN = 256;                 // B columns per LDS tile (8 column bl
 constexpr int kQBlk = kQTN / 32;
 constexpr int kQTileBytes = kQTN * kDim;  // 32 KiB
 
-struct ScreenSet {  // what the tail needs of a job's two sets
-    float inv_sa, inv_sb, nb, dnb, b2min, b2max, msb;
+struct ScreenSet {  // what the tail needs of a job's column set
+    float inv_sb, cb, nb, dnb, b2min, b2max, msb;
     bool ok;
 };
 
 __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
     ScreenSet q;
-    const float ama = jb.qstatA[0], amb = jb.qstatB[0];
-    q.inv_sa = q8_inv_scale(ama);
-    q.inv_sb = q8_inv_scale(amb);
+    const Q8Set qs = q8_set(jb.qstatB);
+    q.inv_sb = qs.inv_sb;
+    q.cb = qs.cb;
     q.msb = *jb.maxsqB;
     q.nb = sqrtf(q.msb) * 1.00001f;
     q.dnb = jb.qstatB[1];
     q.b2min = __uint_as_float(~__float_as_uint(jb.qstatB[2]));  // stored complemented (prep_desc_kernel)
     q.b2max = q.msb;
     // finite, non-degenerate data only (a NaN or an infinity anywhere in a set shows in its max ||x||^2)
-    q.ok = ama > 0.f && amb > 0.f && ama < 1e18f && amb < 1e18f && q.msb < 1e37f && q.b2min >= 0.f;
+    q.ok = qs.inv_sb > 0.f && q.msb < 1e37f && q.b2min >= 0.f;
     return q;
 }
 
@@ -1469,14 +1539,16 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
     if (row < nA) {
         const ScreenSet q = screen_set(jb);
         bool pruned = false;
-        if (q.ok && nB >= 2 && e1 != kNone) {
+        const float inv_sa = jb.invsA[row];
+        if (q.ok && inv_sa > 0.f && nB >= 2 && e1 != kNone) {
             const double a2 = (double)jb.sqA[row];
             const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
             const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
-            const double sc = (double)q.inv_sa * (double)q.inv_sb;
+            const double sc = (double)inv_sa * (double)q.inv_sb;
+            const double off = (double)q.cb * (double)jb.sumqA[row];  // the column code's offset, put back per row
             const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
-            const double L1 = a2 + (double)q.b2min - 2.0 * (sc * (double)e0 + E) - delta;
-            const double H2 = a2 + (double)q.b2max - 2.0 * (sc * (double)e1 - E) + delta;
+            const double L1 = a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta;
+            const double H2 = a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta;
             const double lo = L1 * (1.0 - 1e-5) - 1e-30;
             pruned = H2 >= 0.0 && (lo > (double)prune_r2 * H2 * (1.0 + 1e-5) || lo > (double)prune_thr * (1.0 + 1e-5));
         }
@@ -1633,8 +1705,9 @@ struct Prepared {
     Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals
     Ws<unsigned short> H;
     Ws<uint4> aug;
-    Ws<signed char> Q;   // int8 screening copy, its residual norms, and the set statistics (see MatchJob)
-    Ws<float> dnq, qstat;
+    Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
+    Ws<float> dnq, invs, qstat;
+    Ws<int> sumq;
     int64_t n = 0;
 };
 
@@ -1650,8 +1723,11 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     APS_HIP(hipMemsetAsync(out.maxsq, 0, 4 * sizeof(float), stream()));
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
     out.aug.alloc((size_t)n_pad);
-    out.Q.alloc(rows * kDim);
+    out.QA.alloc(rows * kDim);
+    out.QB.alloc(rows * kDim);
     out.dnq.alloc(rows);
+    out.invs.alloc(rows);
+    out.sumq.alloc(rows);
     out.qstat.alloc(4);
     APS_HIP(hipMemsetAsync(out.qstat, 0, 4 * sizeof(float), stream()));
     if (n == 0) return;
@@ -1660,7 +1736,7 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
                                                         out.P, out.sq, out.H, out.dn, out.maxsq,
                                                         (float*)out.maxsq + 1, out.qstat);
     aug_desc_kernel<<<cdiv(n_pad, 256), 256, 0, stream()>>>(out.sq, out.dn, n, n_pad, out.maxsq, out.aug, (float*)out.maxsq + 2);
-    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.Q, out.dnq, out.qstat);
+    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, out.qstat);
     check_launch("prep_desc_kernel");
 }
 
@@ -1680,10 +1756,11 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.augresB = (const float*)b.maxsq + 2;
     j.maxsqB = b.maxsq;
     j.maxdnB = (const float*)b.maxsq + 1;
-    j.AQ = a.Q;
-    j.BQ = b.Q;
+    j.AQ = a.QA;
+    j.BQ = b.QB;
     j.dnqA = a.dnq;
-    j.qstatA = a.qstat;
+    j.invsA = a.invs;
+    j.sumqA = a.sumq;
     j.qstatB = b.qstat;
     return j;
 }
@@ -1743,6 +1820,8 @@ __global__ void fb_compact_kernel(const MatchJob* __restrict__ jobs, const uint3
     for (unsigned int e = threadIdx.x; e < cnt; e += blockDim.x) out[e] = src[e];
 }
 
+static thread_local int64_t g_screen_rows = 0, g_screen_surv = 0;  // aps_match_screen_stats
+
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 // prune_r2 > 0: the caller will apply the ratio / threshold filter with these constants, so rows that cannot pass it
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
@@ -1751,6 +1830,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     std::vector<WgJob> wgs;
     for (int j = 0; j < (int)jobs.size(); ++j)
         for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r, 0});
+    g_screen_rows = g_screen_surv = 0;
     if (wgs.empty()) return;
     Ws<MatchJob> djobs(jobs.size());
     Ws<WgJob> dwgs(wgs.size());
@@ -1806,6 +1886,8 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
             n_surv += h_surv[j];
             for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
         }
+        g_screen_rows = total_rows;
+        g_screen_surv = (int64_t)n_surv;
         if (std::getenv("APS_TRACE")) {
             int hist[5] = {0, 0, 0, 0, 0};  // jobs by surviving share: 0, <1 %, <10 %, <50 %, >= 50 %
             for (int j = 0; j < (int)jobs.size(); ++j) {
@@ -2219,6 +2301,12 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
 }
 
 extern "C" {
+
+int aps_match_screen_stats(int64_t* rows, int64_t* survivors) {
+    if (rows) *rows = g_screen_rows;
+    if (survivors) *survivors = g_screen_surv;
+    return APS_OK;
+}
 
 int aps_match_pairwise(const float* const* desc, const int64_t* counts, const int64_t* ld,
                        int n_img, int dim, int layout, const aps_match_opts* opts,

@@ -34,6 +34,7 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" dense
+MFMA_I8_PEAK_TOPS = 5000.0      # same guide, matrix-core table: I8 32x32x32 = 2x the BF16 rate per clock (dense)
 HBM_PEAK_GBS = 8000.0           # same table, HBM3E peak (6.29 TB/s is the measured copy rate)
 NX, NY, W, H, FOCAL, OVERLAP, FINEST_PX = 8, 8, 3840, 2160, 8000.0, 0.4, 16.0
 
@@ -283,7 +284,7 @@ def main():
                 return None
             return round(sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows) / launches)
 
-        TRAFFIC_KEYS = {"match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
+        TRAFFIC_KEYS = {"match_screen_i8": ["match_screen_i8_kernel"], "match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
                         "sift_blur": ["aps::blur_kernel<"], "render_warp": ["rw_warp_kernel"],
                         "render_pyr_down": ["rw_down_kernel", "rw_up_kernel"]}
 
@@ -311,11 +312,22 @@ def main():
                 r["note"] = note
             return r
 
+        import ctypes
+        scr_rows, scr_surv = ctypes.c_int64(0), ctypes.c_int64(0)
+        capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(scr_rows), ctypes.byref(scr_surv)))
+        surv_share = scr_surv.value / scr_rows.value if scr_rows.value else 1.0
         cands = [
-            roof("match_cand_f16", "match_cand_f16_kernel (v_mfma_f32_32x32x16_f16 screening product + exact f32 rescoring)", "mfma",
-                 flops_rank0, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
-                 "achieved counts the ALGORITHMIC 2*128*Ni*Nj flops; the kernel executes 9/8 of that on the f16 pipe (one "
-                 "extra 16-wide k-step carries -b2/2 and the column's rounding-loss bound); the exact f32 rescoring of "
+            roof("match_screen_i8", "match_screen_i8_kernel (v_mfma_i32_32x32x32_i8: every descriptor pair once on int8 copies, "
+                 "exact integer accumulation, per-row top-2, proof that a row fails the ratio/threshold filter)", "mfma",
+                 flops_rank0, MFMA_I8_PEAK_TOPS, "TFLOP/s",
+                 "achieved counts the ALGORITHMIC 2*128*Ni*Nj multiply-adds (integer here, so TOP/s) against the dense int8 MFMA "
+                 f"peak; {100 * surv_share:.1f} % of the rows survive the screen and go through match_cand_f16_kernel in row-list "
+                 "mode; the match lists are bit-identical to the all-f32 path"),
+            roof("match_cand_f16", "match_cand_f16_kernel (v_mfma_f32_32x32x16_f16 screening product + exact f32 rescoring" +
+                 (", row-list mode on the int8 screen's survivors)" if scr_rows.value else ")"), "mfma",
+                 flops_rank0 * surv_share, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                 "achieved counts the ALGORITHMIC 2*128*(rows it is given)*Nj flops; the kernel executes 9/8 of that on the f16 "
+                 "pipe (one extra 16-wide k-step carries -b2/2 and the column's rounding-loss bound); the exact f32 rescoring of "
                  "three candidates per row runs in the kernel's tail; results are certified bit-identical to the f32 path"),
             roof("match2nn", "match2nn_kernel (v_mfma_f32_32x32x2_f32, exact f32)", "mfma", flops_rank0,
                  MFMA_F32_PEAK_TFLOPS, "TFLOP/s"),
@@ -352,6 +364,7 @@ def main():
                             f"the host-to-device upload of the images (overlapped with SIFT) and the download of the panorama",
                 "input_mpix": round(mpix_in, 1), "features_per_view": int(np.mean(counts)),
                 "pairs_matched": len(order), "pairs_verified": info["n_pairs_verified"],
+                "int8_screen_survivor_share": round(surv_share, 4) if scr_rows.value else None,
                 "panorama": [int(pano.shape[1]), int(pano.shape[0])], "parallelism": f"{world} rank(s), images/pairs/tiles sharded",
             },
             "roofline": dominant, "rooflines_all": cands,

@@ -123,6 +123,13 @@ int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2
                        int64_t ld2, int dim, int layout, const aps_match_opts* opts,
                        uint32_t* idx1, uint32_t* idx2, float* metric, int64_t cap, int64_t* count);
 
+/* Diagnostics of the calling thread's most recent filtered matching call (aps_match_features / _pairwise / _pairs):
+ * rows = (A row, pair) combinations the int8 screening pre-pass looked at (0 when it did not run: APS_MATCH_NO_SCREEN,
+ * APS_MATCH_MODE=f32), survivors = those it could NOT prove to fail the ratio / threshold filter and handed to the exact
+ * path.  The screen never changes a result (matchFeaturesScratch.m:170-178 is evaluated on exact distances for every
+ * row that can pass it); the counters exist for benchmarks and for tests that guard against a silently disabled screen. */
+int aps_match_screen_stats(int64_t* rows, int64_t* survivors);
+
 /* a3: featureMatchingPairwise (featureMatchingPairwise.m:48-63): all upper-triangular image pairs
  * in the reference's order (column-major linear index of triu(.,1): (1,2),(1,3),(2,3),(1,4),...),
  * each through aps_match_features' rule, in ONE batched launch sequence.

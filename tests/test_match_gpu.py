@@ -526,3 +526,22 @@ def test_int8_screen_is_off_for_non_finite_sets(fm, monkeypatch):
         pp, ii, jj, met = fm.match_pairwise_csr([aa, b], 0.6, 3.5, True, normalize=0)
         om, omet = oracle.match_features(aa, b, 0.6, 3.5, True, 0)
         assert np.array_equal(np.stack([ii, jj], 1), om) and np.array_equal(bits(met), bits(omet))
+
+
+def test_int8_screen_dismisses_most_rows_and_reports_it(fm, gpu, monkeypatch):
+    """Guard against a silently disabled screen: on unit SIFT-like sets with 30 % planted matches it must dismiss well
+    over half of the rows (aps_match_screen_stats), and report zero rows when it is switched off."""
+    import ctypes
+
+    capi = gpu._capi
+    rng = np.random.default_rng(5)
+    a, b, _, _ = planted_pair(rng, 4000, 5000, 1200, noise=0.02)
+    rows, surv = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    m, _ = fm.matchFeaturesScratch(a, b, MatchThreshold=3.5, MaxRatio=0.6, Unique=True)
+    capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    assert rows.value == 4000 and len(m) <= surv.value < 0.45 * rows.value, (rows.value, surv.value, len(m))
+    monkeypatch.setenv("APS_MATCH_NO_SCREEN", "1")
+    fm.matchFeaturesScratch(a, b, MatchThreshold=3.5, MaxRatio=0.6, Unique=True)
+    capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    assert rows.value == 0 and surv.value == 0
