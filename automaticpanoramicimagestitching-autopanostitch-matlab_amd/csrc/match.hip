@@ -212,8 +212,14 @@ struct Q8Set {
     float cb;          // column-side offset (an integer)
 };
 
+__device__ int g_q8_symmetric = 0;  // experiment switch (APS_Q8_SYMMETRIC=1): column code without the offset
+
 __device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
-    const float mx = unord_f32(__float_as_uint(qstat[0])), mn = unord_f32(~__float_as_uint(qstat[3]));
+    float mx = unord_f32(__float_as_uint(qstat[0])), mn = unord_f32(~__float_as_uint(qstat[3]));
+    if (g_q8_symmetric) {
+        mx = fmaxf(fabsf(mx), fabsf(mn));
+        mn = -mx;
+    }
     Q8Set q;
     const float range = mx - mn;
     const bool ok = range > 0.f && range < 1e30f;
@@ -1360,6 +1366,13 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
         const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
     }
+    // The kernel claims the whole vector register file of its SIMDs (2 waves x 256 registers) although it needs 169:
+    // waves of OTHER kernels that shared a SIMD with v_mfma_i32_32x32x32_i8 waves came back with different results
+    // (SIFT's refine / orientation / descriptor kernels, from another stream, when feature extraction and matching
+    // overlap; f16 MFMA, VALU, LDS or LDS-DMA neighbours leave them alone) - measured with scripts/probe_overlap_race3.py,
+    // DESIGN.md section 5.  With nothing co-resident the extraction is bit-identical again; this kernel's own results were
+    // never affected.
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
     const WgJob w = wgs[wg];
     const MatchJob jb = jobs[w.job];
     const int tid = threadIdx.x;
@@ -1702,11 +1715,11 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 struct Prepared {
-    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals
+    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals, [4..7] int8 screen
     Ws<unsigned short> H;
     Ws<uint4> aug;
     Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
-    Ws<float> dnq, invs, qstat;
+    Ws<float> dnq, invs;
     Ws<int> sumq;
     int64_t n = 0;
 };
@@ -1719,8 +1732,9 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.sq.alloc(rows);
     out.H.alloc(rows * kDim);
     out.dn.alloc(rows);
-    out.maxsq.alloc(4);
-    APS_HIP(hipMemsetAsync(out.maxsq, 0, 4 * sizeof(float), stream()));
+    out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
+    APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), stream()));
+    float* const qstat = (float*)out.maxsq + 4;
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
     out.aug.alloc((size_t)n_pad);
     out.QA.alloc(rows * kDim);
@@ -1728,15 +1742,17 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.dnq.alloc(rows);
     out.invs.alloc(rows);
     out.sumq.alloc(rows);
-    out.qstat.alloc(4);
-    APS_HIP(hipMemsetAsync(out.qstat, 0, 4 * sizeof(float), stream()));
+    if (std::getenv("APS_Q8_SYMMETRIC")) {  // A/B switch: column code without the offset
+        const int sym = 1;
+        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, stream()));
+    }
     if (n == 0) return;
     Prof prof("match_prep");
     prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
                                                         out.P, out.sq, out.H, out.dn, out.maxsq,
-                                                        (float*)out.maxsq + 1, out.qstat);
+                                                        (float*)out.maxsq + 1, qstat);
     aug_desc_kernel<<<cdiv(n_pad, 256), 256, 0, stream()>>>(out.sq, out.dn, n, n_pad, out.maxsq, out.aug, (float*)out.maxsq + 2);
-    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, out.qstat);
+    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat);
     check_launch("prep_desc_kernel");
 }
 
@@ -1761,7 +1777,7 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.dnqA = a.dnq;
     j.invsA = a.invs;
     j.sumqA = a.sumq;
-    j.qstatB = b.qstat;
+    j.qstatB = (const float*)b.maxsq + 4;
     return j;
 }
 
@@ -2338,3 +2354,64 @@ int aps_match_pairs(const float* const* desc, const int64_t* counts, const int64
 }
 
 }  // extern "C"
+
+#ifdef APS_DBG
+// co-run experiment (scripts/probe_overlap_race3.py): a workgroup that only occupies a CU's resources for a while
+namespace aps {
+__global__ __launch_bounds__(512) void dbg_corun_kernel(int mode, int spin, const signed char* __restrict__ src, int* __restrict__ sink) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[96 * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int acc = 0;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    i32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 cf = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float vf = (float)lane;
+    const i32x4 a = {lane, 1, 2, 3};
+    for (int it = 0; it < spin; ++it) {
+        if (mode & 1) {  // LDS-DMA into the own allocation
+            const signed char* s = src + ((size_t)(it & 255) * 8 + wave) * 1024 + lane * 16;
+            const uint32_t dst = lds_base + wave * 1024 + (it & 7) * 8192;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(s), "s"(dst)
+                         : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (mode & 2) {  // int8 MFMA
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
+        }
+        if (mode & 8) {  // f16 MFMA
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const h8 ah = {(_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f, (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f};
+            cf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, cf, 0, 0, 0);
+            cf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, cf, 0, 0, 0);
+        }
+        if (mode & 32) {  // plain VALU pressure
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vf = fmaf(vf, 1.0001f, 0.5f);
+        }
+        if (mode & 4) {  // plain LDS traffic
+            reinterpret_cast<volatile int*>(lds)[threadIdx.x + 512 * (it & 31)] = it;
+            acc += reinterpret_cast<volatile int*>(lds)[(threadIdx.x * 7 + it) & 16383];
+        }
+        if (!(mode & 7)) __builtin_amdgcn_s_sleep(20);
+    }
+    if (acc + c[0] + (int)cf[0] + (int)vf == 0x7fffffff) sink[0] = acc;
+}
+}  // namespace aps
+
+extern "C" int aps_dbg_corun(int mode, int n_wg, int spin) {
+    using namespace aps;
+    return guarded([&] {
+        ctx();
+        Ws<signed char> src((size_t)256 * 8 * 1024 + 65536);
+        Ws<int> sink(4);
+        dbg_corun_kernel<<<n_wg, 512, 0, stream()>>>(mode, spin, src, sink);
+        check_launch("dbg_corun_kernel");
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+#endif

@@ -256,6 +256,7 @@ def match_pairwise_csr(allDescriptors, MaxRatio, MatchThreshold, Unique=True, no
             i_i = torch.empty(cap, dtype=torch.int32, device="cuda")
             i_j = torch.empty(cap, dtype=torch.int32, device="cuda")
             met = torch.empty(cap, dtype=torch.float32, device="cuda")
+            _fence_fresh_blocks()
         else:
             i_i = np.zeros(cap, np.uint32)
             i_j = np.zeros(cap, np.uint32)
@@ -298,6 +299,7 @@ def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True
             i_a = torch.empty(cap, dtype=torch.int32, device="cuda")
             i_b = torch.empty(cap, dtype=torch.int32, device="cuda")
             met = torch.empty(cap, dtype=torch.float32, device="cuda")
+            _fence_fresh_blocks()
         else:
             i_a = np.zeros(cap, np.uint32)
             i_b = np.zeros(cap, np.uint32)
@@ -347,6 +349,16 @@ def _sift_params(input):
     return p
 
 
+def _fence_fresh_blocks():
+    """torch's caching allocator recycles a freed block for the next torch.empty at once, which is safe for consumers on
+    torch's own stream only: kernels that were queued there before the block was freed (by ANY thread) may still be
+    running.  The library writes on its private per-thread streams, so a freshly allocated output buffer is fenced
+    against torch's stream before it is handed over (the stream is nearly idle in this pipeline: the wait is short)."""
+    import torch
+
+    torch.cuda.current_stream().synchronize()
+
+
 def sift_extract(input, image, device_out=False, want_aux=False):
     """aps_sift_extract with automatic capacity: returns (features, validPts[, aux]).
 
@@ -370,6 +382,7 @@ def sift_extract(input, image, device_out=False, want_aux=False):
             import torch
 
             desc = torch.empty((cap, DIM), dtype=torch.float32, device="cuda")
+            _fence_fresh_blocks()
         else:
             desc = np.zeros((cap, DIM), np.float32)
         loc = np.zeros((2, cap), np.float64)  # column-major cap x 2

@@ -268,46 +268,82 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
     ws, rank = world()
     owner = lambda i: i % ws  # noqa: E731
 
-    # 1) SIFT on the local shard
-    t0 = time.perf_counter()
-    ldesc, lkps = {}, {}
-    mine_img = sorted(local_images)
-    if mine_img:
-        ready = [image_events[i] for i in mine_img] if image_events is not None else None
-        for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
-            ldesc[i] = d
-            lkps[i] = torch.from_numpy(p).to(dev)
-    times.add("features", t0)
-
-    # 2) the exchange: descriptors (one all-gather), keypoints (small)
-    t0 = time.perf_counter()
-    if ws > 1:
-        descs = gather_by_owner(ldesc, owner, n, torch.empty((0, 128), dtype=torch.float32, device=dev), None)
-        kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
-        descs = [d.contiguous() for d in descs]
-        torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
-    else:
-        descs = [ldesc[i] for i in range(n)]
-        kps_t = [lkps[i] for i in range(n)]
-    counts = [int(d.shape[0]) for d in descs]
-    times.add("exchange", t0)
-
-    # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
-    t0 = time.perf_counter()
-    order = fm.pair_order(n)
-    w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
-    host_lists = bool(os.environ.get("APS_PARALLEL_HOST_LISTS"))  # A/B switch: lists through the host (round-1 path)
-    pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
-    my = [p for p in range(len(order)) if pown[p] == rank]
     use_global = not int(input.get("matchFeaturesPairwise", 1))  # main.m:95-99
-    if use_global:
-        # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank
-        # holds all descriptors after the exchange and computes the (deterministic) result itself: no further exchange.
-        pp, ia_d, ib_d = fm.match_global_csr(descs, input["Ratiothreshold"], int(input.get("k", 4)), device_out=True)
+    host_lists = bool(os.environ.get("APS_PARALLEL_HOST_LISTS"))  # A/B switch: lists through the host (round-1 path)
+    order = fm.pair_order(n)
+    mine_img = sorted(local_images)
+    ready = [image_events[i] for i in mine_img] if image_events is not None else None
+    # One rank, optional (APS_MATCH_OVERLAP_CHUNK=<images per chunk>, default off): feature extraction and matching overlap.
+    # The pair order is j-major (featureMatchingPairwise.m:48), so the pairs whose later image lies in a chunk of images form
+    # one contiguous run of it: as soon as a chunk is extracted, that run is matched on this thread's stream while the
+    # worker streams go on with the next images.  The match lists are the same, only earlier.  Measured on the 64 x 4K
+    # scene it buys nothing (236.5 ms against 236.8; chunks of 8: 263): the screening kernel has to keep its SIMDs to
+    # itself (see match_screen_i8_kernel), so the overlap is time slicing at CU granularity, paid for with repeated
+    # descriptor preparation.  Kept as a switch for scenes with fewer, larger images.
+    chunk = int(os.environ.get("APS_MATCH_OVERLAP_CHUNK", "0"))
+    if ws == 1 and not use_global and not host_lists and chunk > 0 and n > chunk and len(mine_img) == n:
+        t0 = time.perf_counter()
+        futs = pl.sift_submit(input, [local_images[i] for i in range(n)], ready=ready)
+        descs, kps_t, pps, ias, ibs = [], [], [np.zeros(1, np.int64)], [], []
+        t_match = 0.0
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            for i in range(lo, hi):
+                d, p = futs[i].result()
+                descs.append(d)
+                kps_t.append(torch.from_numpy(p).to(dev))
+            if hi == n:
+                times.add("features", t0)  # wall time until the last image is extracted (part of the matching ran under it)
+                t0 = time.perf_counter()
+            p0, p1 = lo * (lo - 1) // 2 if lo else 0, hi * (hi - 1) // 2
+            if p1 > p0:
+                pp_k, ia_k, ib_k, _ = fm.match_pairs_csr(descs, order[p0:p1], input["Ratiothreshold"], input["Matchingthreshold"],
+                                                         True, device_out=True)
+                pps.append(pp_k[1:] + pps[-1][-1])
+                ias.append(ia_k)
+                ibs.append(ib_k)
+        counts = [int(d.shape[0]) for d in descs]
+        pp = np.concatenate(pps).astype(np.int64)
+        ia_d, ib_d = torch.cat(ias), torch.cat(ibs)
         my = list(range(len(order)))
+        pown = np.zeros(len(order), np.int64)
+        times.add("exchange", time.perf_counter())
     else:
-        pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
-                                               input["Matchingthreshold"], True, device_out=not host_lists)
+        # 1) SIFT on the local shard
+        t0 = time.perf_counter()
+        ldesc, lkps = {}, {}
+        if mine_img:
+            for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
+                ldesc[i] = d
+                lkps[i] = torch.from_numpy(p).to(dev)
+        times.add("features", t0)
+
+        # 2) the exchange: descriptors (one all-gather), keypoints (small)
+        t0 = time.perf_counter()
+        if ws > 1:
+            descs = gather_by_owner(ldesc, owner, n, torch.empty((0, 128), dtype=torch.float32, device=dev), None)
+            kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
+            descs = [d.contiguous() for d in descs]
+            torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
+        else:
+            descs = [ldesc[i] for i in range(n)]
+            kps_t = [lkps[i] for i in range(n)]
+        counts = [int(d.shape[0]) for d in descs]
+        times.add("exchange", t0)
+
+        # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
+        t0 = time.perf_counter()
+        w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
+        pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
+        my = [p for p in range(len(order)) if pown[p] == rank]
+        if use_global:
+            # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank
+            # holds all descriptors after the exchange and computes the (deterministic) result itself: no further exchange.
+            pp, ia_d, ib_d = fm.match_global_csr(descs, input["Ratiothreshold"], int(input.get("k", 4)), device_out=True)
+            my = list(range(len(order)))
+        else:
+            pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
+                                                   input["Matchingthreshold"], True, device_out=not host_lists)
     if host_lists and not use_global:
         ia_d = torch.from_numpy(ia_d.astype(np.int32)).to(dev)
         ib_d = torch.from_numpy(ib_d.astype(np.int32)).to(dev)

@@ -79,6 +79,20 @@ def sift_many(input, images, workers=8, ready=None):
         out = [fm.sift_extract(input, img, device_out=dev) for img in images]
         _sync()
         return out
+    return [f.result() for f in sift_submit(input, images, workers, ready)]
+
+
+def sift_submit(input, images, workers=8, ready=None):
+    """The asynchronous form of sift_many: one future per image, submitted in input order to the worker pool, so that
+    a caller can start matching the first images while the later ones are still being extracted (parallel._match_pass).
+    Each future resolves to (descriptors, keypoints) once that worker's stream has finished the image."""
+    global _SIFT_POOL
+    import os
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    workers = max(1, int(os.environ.get("APS_SIFT_WORKERS", workers)))
+    dev = _capi.is_torch(images[0]) and images[0].is_cuda
     if dev and ready is None:
         torch.cuda.synchronize()  # the images were produced on torch's stream; worker streams must see them
     if _SIFT_POOL is None:
@@ -91,7 +105,7 @@ def sift_many(input, images, workers=8, ready=None):
         _sync()  # this thread's stream
         return r
 
-    return list(_SIFT_POOL.map(work, range(len(images))))
+    return [_SIFT_POOL.submit(work, k) for k in range(len(images))]
 
 
 def extract_features(input, images, times=None):
