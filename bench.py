@@ -273,7 +273,7 @@ def main():
         # HBM-side bytes per launch from the committed PMC pass of THIS workload (scripts/hbm_traffic.sh ->
         # profiles/*_hbm_traffic.json: L2 memory-side requests x 64 B, one bench step); null for other configs
         traffic_db = {}
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02z_hbm_traffic.json")
         if world == 1 and (nx, ny, w, h, args.bands) == (8, 8, W, H, 5) and os.path.exists(tpath):
             traffic_db = json.load(open(tpath))
 
@@ -307,7 +307,7 @@ def main():
                  "timed": "live over the timed steps" if kernel in live else "during the last warm-up step"}
             if r["traffic"] is not None:
                 r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
-                                     "pass of this workload (profiles/r01m_hbm_traffic.txt)")
+                                     "pass of this workload (profiles/r02z_hbm_traffic.txt)")
             if note:
                 r["note"] = note
             return r

@@ -7,9 +7,9 @@ TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
-python3 bench.py > gpurun_out/${TAG}_bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
+python3 bench.py --steps 6 --warmup 2 > gpurun_out/${TAG}_bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
 rm -rf /tmp/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python3 bench.py --cpu-baseline off \
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python3 bench.py --cpu-baseline off --steps 6 --warmup 2 \
     > gpurun_out/${TAG}_bench_under_rocprofv3.json 2> /tmp/prof_stats.err
 cp /tmp/prof_stats/p_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
 # HBM traffic (FETCH_SIZE / WRITE_SIZE): NOT collected here.  Round 1 tried twice (on bench.py and on the small matching
