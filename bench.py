@@ -227,8 +227,12 @@ def main():
         step_e2e()  # warm-up: pinned output buffer, side stream
         barrier()
         t0 = time.perf_counter()
+        infos_h = []
         for _ in range(args.steps):
+            t_s = time.perf_counter()
             pano_h, info_h = step_e2e()
+            info_h["times"]["download"] = time.perf_counter() - t_s - sum(info_h["times"].values())
+            infos_h.append(info_h)
         barrier()
         dt_e2e = time.perf_counter() - t0
         if rank == 0 and (info_h["n_pairs_verified"], tuple(pano_h.shape)) != (infos[-1]["n_pairs_verified"], tuple(infos[-1]["panorama_shape"])):
@@ -368,7 +372,12 @@ def main():
                 "panorama": [int(pano.shape[1]), int(pano.shape[0])], "parallelism": f"{world} rank(s), images/pairs/tiles sharded",
             },
             "roofline": dominant, "rooflines_all": cands,
-            "stages_ms_per_step": stages, "kernels": kernels,
+            "stages_ms_per_step": stages,
+            # the same stages in the end-to-end steps; "download" = everything outside stitch_distributed (queueing the
+            # uploads, the device-to-host copy of the cropped panorama and the final synchronisation)
+            "stages_ms_per_step_end_to_end": ({k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos_h) / len(infos_h), 2)
+                                               for k in infos_h[-1]["times"]} if dt_e2e else None),
+            "kernels": kernels,
         }
         if world == 1 and args.cpu_baseline == "auto":
             try:
