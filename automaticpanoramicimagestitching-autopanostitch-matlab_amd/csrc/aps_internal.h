@@ -1,6 +1,7 @@
 // aps_internal.h — shared plumbing of libaps_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdarg>
 #include <cstdint>
@@ -195,5 +196,16 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
                             std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b);
 
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
+
+// compile-time loop: the body receives std::integral_constant<int, I>, so register arrays are indexed by constants
+// by construction (an index the optimiser fails to fold sends the whole array to scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 
 }  // namespace aps

@@ -626,16 +626,6 @@ __device__ __forceinline__ void top4_insert_sel(float t, int j, float& u0, float
     i2 = n2;
 }
 
-// compile-time loop: the body receives std::integral_constant<int, I>, so register arrays are indexed by constants
-// by construction (an index the optimiser fails to fold sends the whole array to scratch memory)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 __device__ __forceinline__ float max4_raw(float a, float b, float c, float d) {
     float m;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));

@@ -184,6 +184,19 @@ struct GaussK {
 
 constexpr int kTW = 64, kTH = 32;  // output tile per 256-thread workgroup
 
+// v_pk_fma_f32 with the tap in an SGPR pair (k[t & ~1], k[(t & ~1) + 1]): op_sel / op_sel_hi pick its low or high half
+// for BOTH result lanes.  One instruction = the next tap of two independent k-ascending fma chains.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int T>
+__device__ __forceinline__ void pk_tap(f32x2& acc, const GaussK& gk, f32x2 v) {
+    unsigned long long kk;  // the aligned tap pair holding k[T]
+    __builtin_memcpy(&kk, &gk.k[T & ~1], sizeof kk);
+    if (T & 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(kk), "v"(v));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(kk), "v"(v));
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
                                                    float* __restrict__ out) {
@@ -192,14 +205,18 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
     constexpr int RP = (R + 3) & ~3, OFF = RP - R;
     constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
-    // LDS pitches.  In the row pass the lanes of a wave take CONSECUTIVE ROWS of one 8-output segment, so a read
-    // instruction touches addresses P*ly + const: the pitch is chosen so that those land on distinct banks for the
-    // read width the segment start allows (OFF % 4 == 0: 16-byte reads, P = 4 mod 8; OFF even: 8-byte reads,
-    // P = 2 mod 4; OFF odd: 4-byte reads, P odd).  With eight threads side by side on one row (the previous mapping)
-    // every read was an 8-way bank conflict (SQ_LDS_BANK_CONFLICT was 3.5x the LDS-active cycles).
-    constexpr int IP = IW + (OFF % 4 == 0 ? 4 : (OFF % 2 == 0 ? 2 : 1));
-    constexpr int RPITCH = kTW + 4;  // s_row: 16-byte writes from consecutive rows, column reads by consecutive lanes
-    __shared__ __attribute__((aligned(16))) float s_in[IH * IP];
+    static_assert(IH % 2 == 0 && kTH % 4 == 0, "row pairs");
+    // Both passes run two fma chains per v_pk_fma_f32, and a packed operand must be an aligned register pair.  A pair
+    // of horizontally adjacent inputs is aligned for every other tap only, so the passes pair the OTHER direction:
+    //   row pass   : one lane = 8 outputs of TWO consecutive rows; the tile is stored row-interleaved
+    //                (s_in[(y >> 1)][x][y & 1]), so the window of both rows is one contiguous run of aligned pairs;
+    //   column pass: one lane = 4 outputs of TWO adjacent columns of the (plainly stored) row-pass result.
+    // Every accumulator still sees its taps in ascending order: the scalar form's chain, bit for bit.
+    // Pitches (floats): 4 * odd, so that consecutive row pairs land on distinct 16-byte bank groups.
+    constexpr int IP2 = 2 * IW + 4;
+    constexpr int RPITCH = kTW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
+    static_assert((IP2 / 4) % 2 == 1, "pitch");
+    __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
     __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
@@ -217,51 +234,63 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
             val.z = row[reflect101(gx + 2, w)];
             val.w = row[reflect101(gx + 3, w)];
         }
-        float* dst = &s_in[ly * IP + 4 * v];
+        float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
         dst[0] = val.x;
-        dst[1] = val.y;
-        dst[2] = val.z;
-        dst[3] = val.w;
+        dst[2] = val.y;
+        dst[4] = val.z;
+        dst[6] = val.w;
     }
     __syncthreads();
-    // row pass: IH rows x 64 cols, 8 consecutive outputs per thread; consecutive lanes = consecutive rows
-    for (int u = tid; u < IH * (kTW / 8); u += 256) {
-        const int seg = u / IH, ly = u - seg * IH, xb = seg * 8;
-        float v[8 + 2 * R], acc[8];
+    // row pass: IH/2 row pairs x 8 segments of 8 outputs; consecutive lanes = consecutive row pairs
+    for (int u = tid; u < (IH / 2) * (kTW / 8); u += 256) {
+        const int seg = u / (IH / 2), p = u - seg * (IH / 2), xb = seg * 8;
+        const f32x2* src = reinterpret_cast<const f32x2*>(&s_in[p * IP2 + 2 * (OFF + xb)]);
+        f32x2 v[8 + 2 * R], acc[8];
 #pragma unroll
-        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_in[ly * IP + OFF + xb + j];
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = src[j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.f, 0.f};
+        static_for<0, 2 * R + 1>([&](auto T) {
+            constexpr int t = decltype(T)::value;
 #pragma unroll
-        for (int t = 0; t < 2 * R + 1; ++t) {
-            const float kt = gk.k[t];
+            for (int j = 0; j < 8; ++j) pk_tap<t>(acc[j], gk, v[j + t]);
+        });
+        float* d0 = &s_row[(2 * p) * RPITCH + xb];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
+        for (int j = 0; j < 8; ++j) {
+            d0[j] = acc[j].x;
+            d0[RPITCH + j] = acc[j].y;
         }
-        *reinterpret_cast<float4*>(&s_row[ly * RPITCH + xb]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(&s_row[ly * RPITCH + xb + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
-    // column pass: 64 cols x kTH/8 groups of 8 rows
-    for (int u = tid; u < kTW * (kTH / 8); u += 256) {
-        const int lx = u & (kTW - 1), yb = (u / kTW) * 8;
-        float v[8 + 2 * R], acc[8];
+    // column pass: 32 column pairs x kTH/4 groups of 4 rows
+    for (int u = tid; u < (kTW / 2) * (kTH / 4); u += 256) {
+        const int lx = 2 * (u & (kTW / 2 - 1)), yb = (u / (kTW / 2)) * 4;
+        f32x2 v[4 + 2 * R], acc[4];
 #pragma unroll
-        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = s_row[(yb + j) * RPITCH + lx];
+        for (int j = 0; j < 4 + 2 * R; ++j) v[j] = *reinterpret_cast<const f32x2*>(&s_row[(yb + j) * RPITCH + lx]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
+        static_for<0, 2 * R + 1>([&](auto T) {
+            constexpr int t = decltype(T)::value;
 #pragma unroll
-        for (int t = 0; t < 2 * R + 1; ++t) {
-            const float kt = gk.k[t];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(kt, v[j + t], acc[j]);
-        }
+            for (int j = 0; j < 4; ++j) pk_tap<t>(acc[j], gk, v[j + t]);
+        });
         const int gx = x0 + lx;
-        if (gx < w) {
+        if (gx + 1 < w && (w & 1) == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int gy = y0 + yb + j;
-                if (gy < h) out[(size_t)gy * w + gx] = acc[j];
+                if (gy < h) *reinterpret_cast<f32x2*>(&out[(size_t)gy * w + gx]) = acc[j];
+            }
+        } else if (gx < w) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = y0 + yb + j;
+                if (gy < h) {
+                    out[(size_t)gy * w + gx] = acc[j].x;
+                    if (gx + 1 < w) out[(size_t)gy * w + gx + 1] = acc[j].y;
+                }
             }
         }
     }
