@@ -17,7 +17,7 @@ import csv, collections, json, sys
 tag = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
 for r in csv.DictReader(open("/tmp/pt/p_counter_collection.csv")):
-    k = r["Kernel_Name"].split("(")[0]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "TCC_EA0_RDREQ_sum": n[k] += 1
 rows = sorted(acc.items(), key=lambda kv: -(kv[1]["TCC_EA0_RDREQ_sum"] + kv[1]["TCC_EA0_WRREQ_sum"]))
