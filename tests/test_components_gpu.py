@@ -160,3 +160,36 @@ def test_two_ranks_equal_one_rank(gpu, mode):
     assert len(one["panos"]) == len(two["panos"]) == (3 if mode == "worlds" else 1)
     for a, b in zip(one["panos"], two["panos"]):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_overlapped_extraction_and_matching_changes_nothing(gpu, monkeypatch):
+    """APS_MATCH_OVERLAP_CHUNK: the pairs of every finished chunk of images are matched while the worker streams extract
+    the next chunk (parallel._match_pass).  Verified pairs, models and every panorama byte must equal the sequential
+    run's, and two overlapped runs must equal each other (the extraction must not be disturbed by the concurrent
+    matching kernels: the int8 screening kernel keeps its SIMDs to itself for that reason)."""
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    views, cams, _ = _worlds(synth)
+    torch.cuda.synchronize()
+    n = len(views)
+    inp = pl.default_input(bands=3)
+    Ks = [c["K"] for c in cams]
+
+    def run():
+        pano, info = par.stitch_distributed(inp, dict(enumerate(views)), n, Ks, (512, 512), 0, None, pano_root=0)
+        return info
+
+    monkeypatch.delenv("APS_MATCH_OVERLAP_CHUNK", raising=False)
+    ref = run()
+    for chunk in ("4", "5", "4"):
+        monkeypatch.setenv("APS_MATCH_OVERLAP_CHUNK", chunk)
+        got = run()
+        assert got["n_features"] == ref["n_features"]
+        assert got["n_pairs_verified"] == ref["n_pairs_verified"] and got["n_components"] == ref["n_components"]
+        assert len(got["panoramas"]) == len(ref["panoramas"])
+        for a, b in zip(got["panoramas"], ref["panoramas"]):
+            assert tuple(a.shape) == tuple(b.shape) and bool(torch.equal(a, b))
+    monkeypatch.delenv("APS_MATCH_OVERLAP_CHUNK", raising=False)
