@@ -105,3 +105,37 @@ def test_crop_rectangle_on_a_large_canvas(mods):
     want_rect, want_ok, _ = oracle.crop_rect(img)
     got_rect, got_ok = ip.cropRectangle(img)
     assert got_rect == want_rect and got_ok == want_ok and want_ok
+
+
+def test_bench_scale_matching_screen_on_equals_screen_off(gpu, mods, monkeypatch):
+    """BASELINE configs[2]'s matching workload in full: the 64 x 4K bench scene's descriptors (~19.8 k per view), all 2016
+    pairs.  The int8 screening pre-pass + row-list f16 pass must return exactly the lists of the f16 path on every row
+    (APS_MATCH_NO_SCREEN=1) - pair offsets, both index lists and the metric's bits - and the lists must be one-to-one per
+    pair.  (The oracle needs ~20 minutes for this; the small-size tests pin both paths to it.)"""
+    import ctypes
+    import torch
+
+    fm, synth = mods["featureMatching"], mods["synth"]
+    pl = import_module(gpu.__name__ + ".pipeline")
+    imgs, _ = synth.make_scene(8, 8, 3840, 2160, 8000.0, 0.4, device="cuda", finest_px=16.0)
+    torch.cuda.synchronize()
+    inp = pl.default_input(bands=5)
+    descs = [d for d, _ in pl.sift_many(inp, imgs)]
+    del imgs
+    torch.cuda.synchronize()
+    assert 15000 < np.mean([d.shape[0] for d in descs]) < 25000
+    order = fm.pair_order(len(descs))
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    pp, ia, ib, met = fm.match_pairs_csr(descs, order, 0.6, 1.5, True, device_out=True)
+    rows, surv = ctypes.c_int64(0), ctypes.c_int64(0)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    assert rows.value == sum(descs[i].shape[0] for i, _ in order) and int(pp[-1]) <= surv.value < 0.25 * rows.value
+    monkeypatch.setenv("APS_MATCH_NO_SCREEN", "1")
+    pp0, ia0, ib0, met0 = fm.match_pairs_csr(descs, order, 0.6, 1.5, True, device_out=True)
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    assert np.array_equal(pp, pp0) and int(pp[-1]) > 100000
+    assert bool(torch.equal(ia, ia0)) and bool(torch.equal(ib, ib0)) and bool(torch.equal(met.view(torch.int32), met0.view(torch.int32)))
+    # one-to-one per pair: within a pair's segment no column index repeats
+    seg = torch.repeat_interleave(torch.arange(len(order), device="cuda"), torch.from_numpy(np.diff(pp)).to("cuda"))
+    key = seg.to(torch.int64) * (1 << 32) + ib.to(torch.int64)
+    assert int(torch.unique(key).numel()) == int(key.numel())
