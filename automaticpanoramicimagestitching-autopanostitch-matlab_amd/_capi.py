@@ -118,6 +118,7 @@ _SIGNATURES = {
     "aps_crop_rect": [_vp, _i64, _i64, _i, _i, _d, _vp, _vp],
     "aps_crop_nonzero_bbox": [_vp, _i64, _i64, _i, _i, _vp, _vp],
     "aps_ransac_draws_exhausted": [],
+    "aps_gather_match_points": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64],
     "aps_match_screen_stats": [_vp, _vp],
     "aps_global_normalize": [_vp, _i64, _i64, _i, _i, _vp],
     "aps_knn_hamming": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64],

@@ -696,6 +696,37 @@ __global__ void draw_samples_kernel(const int64_t* __restrict__ counts, const un
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// imageMatching.m:121-135 on the device: one thread per match of the work list
+__global__ void gather_match_points_kernel(const unsigned long long* __restrict__ tab, int n_img, int n_work,
+                                           const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_b,
+                                           int64_t total, double* __restrict__ pa, double* __restrict__ pb, int64_t ldp) {
+    const int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (m >= total) return;
+    const unsigned long long* kp = tab;
+    const unsigned long long* cnt = tab + n_img;
+    const unsigned long long* lst = cnt + n_img;
+    const unsigned long long* wp = lst + n_work;
+    const unsigned long long* im = wp + n_work + 1;
+    int lo = 0, hi = n_work - 1;  // the work pair whose slice holds match m
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)wp[mid] <= m)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int64_t pos = (int64_t)lst[lo] + (m - (int64_t)wp[lo]);
+    const int ia = (int)(im[lo] & 0xffffffffull), ib = (int)(im[lo] >> 32);
+    const int64_t ra = (int64_t)idx_a[pos] - 1, rb = (int64_t)idx_b[pos] - 1;
+    const double* ka = reinterpret_cast<const double*>((uintptr_t)kp[ia]);
+    const double* kb = reinterpret_cast<const double*>((uintptr_t)kp[ib]);
+    const bool oka = ra >= 0 && ra < (int64_t)cnt[ia], okb = rb >= 0 && rb < (int64_t)cnt[ib];
+    pa[m] = oka ? ka[2 * ra] : NAN;
+    pa[ldp + m] = oka ? ka[2 * ra + 1] : NAN;
+    pb[m] = okb ? kb[2 * rb] : NAN;
+    pb[ldp + m] = okb ? kb[2 * rb + 1] : NAN;
+}
+
 static void check_opts(const aps_ransac_opts& o) {
     APS_REQUIRE(o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
                 "only transformationType 'projective' is built (inputs.m:74)");
@@ -913,6 +944,40 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
 }
 
 int aps_ransac_draws_exhausted(void) { return g_draws_exhausted; }
+
+int aps_gather_match_points(const double* const* kp, const int64_t* kp_count, int n_img, const int32_t* idx_a,
+                            const int32_t* idx_b, const int64_t* list_start, const int64_t* work_ptr,
+                            const int32_t* img_a, const int32_t* img_b, int n_work, double* pts_a, double* pts_b,
+                            int64_t ldp) {
+    return guarded([&] {
+        APS_REQUIRE(n_img >= 0 && n_work >= 0, APS_E_ARG, "negative count");
+        if (n_work == 0) return;
+        APS_REQUIRE(kp && kp_count && list_start && work_ptr && img_a && img_b, APS_E_ARG, "NULL table");
+        const int64_t total = work_ptr[n_work];
+        APS_REQUIRE(total >= 0 && ldp >= total, APS_E_DIM, "ldp < total");
+        if (total == 0) return;
+        APS_REQUIRE(idx_a && idx_b && pts_a && pts_b, APS_E_ARG, "NULL list / output");
+        APS_REQUIRE(is_device_ptr(idx_a) && is_device_ptr(idx_b) && is_device_ptr(pts_a) && is_device_ptr(pts_b), APS_E_ARG,
+                    "the match lists and the point arrays must be device memory");
+        for (int q = 0; q < n_work; ++q)
+            APS_REQUIRE(img_a[q] >= 0 && img_a[q] < n_img && img_b[q] >= 0 && img_b[q] < n_img && work_ptr[q + 1] >= work_ptr[q],
+                        APS_E_ARG, "bad work pair %d", q);
+        ctx();
+        // one table upload: [kp pointers | kp counts | list_start | work_ptr | img_a, img_b]
+        std::vector<unsigned long long> tab((size_t)2 * n_img + (size_t)2 * n_work + 1 + (size_t)n_work);
+        size_t o = 0;
+        for (int i = 0; i < n_img; ++i) tab[o++] = (unsigned long long)(uintptr_t)kp[i];
+        for (int i = 0; i < n_img; ++i) tab[o++] = (unsigned long long)kp_count[i];
+        for (int q = 0; q < n_work; ++q) tab[o++] = (unsigned long long)list_start[q];
+        for (int q = 0; q <= n_work; ++q) tab[o++] = (unsigned long long)work_ptr[q];
+        for (int q = 0; q < n_work; ++q) tab[o++] = ((unsigned long long)(uint32_t)img_b[q] << 32) | (uint32_t)img_a[q];
+        Ws<unsigned long long> dtab(tab.size());
+        APS_HIP(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream()));
+        gather_match_points_kernel<<<cdiv(total, 256), 256, 0, stream()>>>(dtab, n_img, n_work, idx_a, idx_b, total, pts_a, pts_b, ldp);
+        check_launch("gather_match_points_kernel");
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
 
 int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
                             uint64_t seed, uint32_t* sample_idx) {

@@ -195,6 +195,34 @@ def ransac_batch(pts_src, pts_dst, pair_ptr, samples, input):
     return models.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mask[:total], found, ninl
 
 
+def gather_match_points(keypoints, idx_a, idx_b, list_start, work_ptr, img_a, img_b):
+    """The matched keypoints of a list of candidate pairs (imageMatching.m:121-135) gathered on the device: work pair q
+    is images (img_a[q], img_b[q]) and owns entries list_start[q] .. + (work_ptr[q+1] - work_ptr[q]) of the resident
+    1-based match lists idx_a / idx_b (torch int32, CUDA).  keypoints: per image a CUDA float64 tensor [n_i, 2] = [x y].
+    Returns (pts_a, pts_b): CUDA float64 [2, total], row 0 = x, row 1 = y - the layout ransac_batch takes."""
+    import torch
+
+    n_img, n_work = len(keypoints), len(img_a)
+    kps = [k.contiguous() if k.dtype == torch.float64 else k.to(torch.float64).contiguous() for k in keypoints]
+    work_ptr = np.ascontiguousarray(work_ptr, np.int64)
+    total = int(work_ptr[-1])
+    dev = idx_a.device
+    pa = torch.empty((2, total), dtype=torch.float64, device=dev)
+    pb = torch.empty((2, total), dtype=torch.float64, device=dev)
+    if total == 0:
+        return pa, pb
+    tab = (C.c_void_p * n_img)(*[k.data_ptr() if k.numel() else None for k in kps])
+    cnt = np.ascontiguousarray([int(k.shape[0]) for k in kps], np.int64)
+    ls = np.ascontiguousarray(list_start, np.int64)
+    ia = np.ascontiguousarray(img_a, np.int32)
+    ib = np.ascontiguousarray(img_b, np.int32)
+    la, lb = idx_a.contiguous(), idx_b.contiguous()  # (named: the copies must outlive the call)
+    torch.cuda.current_stream().synchronize()  # the tables / lists / fresh blocks may still be in use on torch's stream
+    check(lib.aps_gather_match_points(tab, ptr(cnt), n_img, ptr(la), ptr(lb), ptr(ls), ptr(work_ptr),
+                                      ptr(ia), ptr(ib), n_work, ptr(pa), ptr(pb), total))
+    return pa, pb
+
+
 def ransac_batch_drawn(pts_src, pts_dst, pair_ptr, counts, input, seed=0, keys=None):
     """ransac_batch with the draws made here: maxIter + 64 subsets per pair from the counter-based stream, and - when a
     pair burns through them on invalid / degenerate subsets before the loop's own stopping rule (the reference keeps

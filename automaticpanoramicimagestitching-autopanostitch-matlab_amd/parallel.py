@@ -389,22 +389,10 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
     if mine:
         cnts = [int(n_match[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
-        # one device gather over the concatenated keypoint table (the keypoints are resident already; a host
-        # fancy-index of ~1e6 rows costs tens of milliseconds)
-        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        kp_all = torch.cat([k.to(dev) for k in kps_t]).to(torch.float64)
-        # segment p of the match lists -> rows of the concatenated keypoint table, all on the device
-        cnt_t = torch.tensor(cnts, dtype=torch.int64, device=dev)
-        seg0 = torch.from_numpy(gpos[mine]).to(dev)
-        pos = torch.arange(int(wptr[-1]), dtype=torch.int64, device=dev) + \
-            torch.repeat_interleave(seg0 - torch.from_numpy(wptr[:-1]).to(dev), cnt_t)
-        off_i = torch.repeat_interleave(torch.from_numpy(offs[[order[p][0] for p in mine]]).to(dev), cnt_t)
-        off_j = torch.repeat_interleave(torch.from_numpy(offs[[order[p][1] for p in mine]]).to(dev), cnt_t)
-        row_i = off_i + ia_d.index_select(0, pos).to(torch.int64) - 1
-        row_j = off_j + ib_d.index_select(0, pos).to(torch.int64) - 1
-        dst = kp_all.index_select(0, row_i).t().contiguous()
-        src = kp_all.index_select(0, row_j).t().contiguous()
-        torch.cuda.current_stream().synchronize()  # torch's stream produced dst/src; the library runs on its own
+        # imageMatching.m:121-135 (keypoints{i}(matches(:,1),:), keypoints{j}(matches(:,2),:)) as one library launch over
+        # the resident keypoint tables and match lists (a host fancy-index of ~1e6 rows costs tens of milliseconds)
+        dst, src = im.gather_match_points(kps_t, ia_d, ib_d, gpos[mine], wptr, [order[p][0] for p in mine],
+                                          [order[p][1] for p in mine])
         times.add("im_gather", t0)
         t0 = time.perf_counter()
         models, mask, found, ninl = im.ransac_batch_drawn(src, dst, wptr, cnts, input, seed, keys=mine)

@@ -242,6 +242,19 @@ int aps_ransac_draws_exhausted(void);
 int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
                             uint64_t seed, uint32_t* sample_idx);
 
+/* The input of that batch, gathered on the device (imageMatching.m:121-135: keypoints{i}(matches(:,1),:) and
+ * keypoints{j}(matches(:,2),:) per candidate pair): work pair q is images (img_a[q], img_b[q]); its matches are the
+ * work_ptr[q+1]-work_ptr[q] entries of the resident 1-based lists idx_a / idx_b starting at list_start[q].
+ *   kp       : host array of n_img DEVICE pointers, image i's keypoints as kp_count[i] x 2 f64 row-major [x y]
+ *   idx_a/b  : device int32 lists (what aps_match_pairs leaves on the device)
+ *   list_start, work_ptr (n_work+1), img_a, img_b: host arrays
+ *   pts_a/b  : device f64, (total x 2) column-major with leading dimension ldp >= total = work_ptr[n_work];
+ *              an index outside its image's table yields NaN coordinates (such a pair then fails RANSAC). */
+int aps_gather_match_points(const double* const* kp, const int64_t* kp_count, int n_img, const int32_t* idx_a,
+                            const int32_t* idx_b, const int64_t* list_start, const int64_t* work_ptr,
+                            const int32_t* img_a, const int32_t* img_b, int n_work, double* pts_a, double* pts_b,
+                            int64_t ldp);
+
 /* Batched a10/a11/a12: every candidate pair of imageMatching.m:121-156 in one device batch.
  *   pts1/pts2 : f64, pair p's matched points are rows pair_ptr[p]..pair_ptr[p+1]-1 of two
  *               (total x 2) column-major arrays with leading dimension ldp

@@ -223,3 +223,42 @@ def test_draw_exhaustion_is_reported_and_the_drawn_form_retries(gpu, im):
     assert capi.lib.aps_ransac_draws_exhausted() == 1
     _, _, found, ninl = im.ransac_batch_drawn(p1, p2, np.array([0, 80]), [80], inp5)
     assert found[0] == 1 and ninl[0] >= 10 and capi.lib.aps_ransac_draws_exhausted() == 0
+
+
+def test_gather_match_points_equals_host_indexing(gpu):
+    """aps_gather_match_points (imageMatching.m:121-135 on the device): keypoints{i}(matches(:,1),:) / keypoints{j}(matches(:,2),:)
+    for a work list of pairs, from per-image tables and the resident CSR match lists; out-of-table indices give NaN."""
+    import torch
+    from importlib import import_module
+
+    im = import_module(gpu.__name__ + ".imageMatching")
+    rng = np.random.default_rng(3)
+    counts = [50, 0, 77, 31]
+    kps = [rng.uniform(1, 500, (c, 2)) for c in counts]
+    # three work pairs with slices scattered in longer lists
+    work = [(0, 2, 40), (3, 0, 25), (2, 3, 0)]
+    ia = rng.integers(1, 20, 200).astype(np.int32)
+    ib = rng.integers(1, 20, 200).astype(np.int32)
+    starts, wptr = [], [0]
+    pos = 7
+    for a, b, m in work:
+        starts.append(pos)
+        ia[pos:pos + m] = rng.integers(1, counts[a] + 1, m)
+        ib[pos:pos + m] = rng.integers(1, counts[b] + 1, m)
+        pos += m + 11
+        wptr.append(wptr[-1] + m)
+    ia[starts[0] + 3] = counts[0] + 5  # outside image 0's table
+    kt = [torch.from_numpy(k).cuda() for k in kps]
+    pa, pb = im.gather_match_points(kt, torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda(), starts, wptr,
+                                    [w[0] for w in work], [w[1] for w in work])
+    pa, pb = pa.cpu().numpy(), pb.cpu().numpy()
+    assert pa.shape == (2, 65) and pb.shape == (2, 65)
+    for q, (a, b, m) in enumerate(work):
+        for e in range(m):
+            ra, rb = ia[starts[q] + e] - 1, ib[starts[q] + e] - 1
+            col = wptr[q] + e
+            if ra >= counts[a]:
+                assert np.isnan(pa[:, col]).all()
+            else:
+                assert np.array_equal(pa[:, col], kps[a][ra])
+            assert np.array_equal(pb[:, col], kps[b][rb])
