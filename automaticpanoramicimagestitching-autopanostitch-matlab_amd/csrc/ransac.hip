@@ -179,6 +179,98 @@ __device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, cons
     return true;
 }
 
+// The finalize kernel's form of jacobi9 / gram_to_h: ONE 9x9 problem per 64-lane workgroup (column 0 of the S = 2
+// layout).  A rotation (p, q) touches rows/columns k = 0..8 independently, so lane k < 9 updates "its" k while every lane
+// evaluates the (uniform) rotation parameters: the same operations on the same operands as the serial routine - bit
+// for bit - in a ninth of the dependent LDS round trips (the serial form by lane 0 was most of the kernel's 3.5 ms).
+__device__ void jacobi9_wave(double* sG, double* sV, int lane) {
+#define G2(p, q) sG[((p) * 9 + (q)) * 2]
+#define V2(p, q) sV[((p) * 9 + (q)) * 2]
+    const int k = lane;
+    if (k < 9)
+        for (int q = 0; q < 9; ++q) V2(k, q) = (k == q) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double gpq = G2(p, q);
+                const double gpp = G2(p, p), gqq = G2(q, q);
+                if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;  // uniform
+                rotated = true;
+                const double theta = (gqq - gpp) / (2.0 * gpq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                double gkp = 0, gkq = 0, vkp = 0, vkq = 0;
+                if (k < 9) {
+                    gkp = G2(k, p);
+                    gkq = G2(k, q);
+                    vkp = V2(k, p);
+                    vkq = V2(k, q);
+                }
+                __syncthreads();  // every read of this rotation before any of its writes
+                if (k < 9) {
+                    if (k != p && k != q) {
+                        const double np_ = c * gkp - s * gkq;
+                        const double nq_ = s * gkp + c * gkq;
+                        G2(k, p) = np_;
+                        G2(p, k) = np_;
+                        G2(k, q) = nq_;
+                        G2(q, k) = nq_;
+                    }
+                    V2(k, p) = c * vkp - s * vkq;
+                    V2(k, q) = s * vkp + c * vkq;
+                }
+                if (lane == 0) {
+                    G2(p, p) = gpp - t * gpq;
+                    G2(q, q) = gqq + t * gpq;
+                    G2(p, q) = 0.0;
+                    G2(q, p) = 0.0;
+                }
+                __syncthreads();
+            }
+        if (!rotated) break;
+    }
+}
+
+// gram_to_h for that layout; every lane returns the same H and verdict.
+__device__ bool gram_to_h_wave(double* sG, double* sV, int lane, const Norm& n1, const Norm& n2, Mat3& H, int mlesac) {
+    if (lane == 0)
+        for (int p = 0; p < 9; ++p)
+            for (int q = 0; q < p; ++q) G2(p, q) = G2(q, p);
+    __syncthreads();
+    jacobi9_wave(sG, sV, lane);
+    int kmin = 0;
+    for (int k = 1; k < 9; ++k)
+        if (G2(k, k) < G2(kmin, kmin)) kmin = k;
+    double h[9];
+    for (int k = 0; k < 9; ++k) h[k] = V2(k, kmin);
+#undef G2
+#undef V2
+    Mat3 Hn, M;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M3(Hn, r, c) = h[3 * r + c] / h[8];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = M3(Hn, 2, c);
+        M3(M, 2, c) = m2;
+        M3(M, 1, c) = (M3(Hn, 1, c) - n2.ty * m2) / n2.s;
+        M3(M, 0, c) = (M3(Hn, 0, c) - n2.tx * m2) / n2.s;
+    }
+    for (int r = 0; r < 3; ++r) {
+        M3(H, r, 0) = M3(M, r, 0) * n1.s;
+        M3(H, r, 1) = M3(M, r, 1) * n1.s;
+        M3(H, r, 2) = (M3(M, r, 0) * n1.tx + M3(M, r, 1) * n1.ty) + M3(M, r, 2);
+    }
+    if (mlesac) {  // denormalizeTform: tform ./ tform(end) (estimateTransformationMLESAC.m:713-714)
+        const double d = H.m[8];
+        for (int e = 0; e < 9; ++e) H.m[e] = H.m[e] / d;
+    }
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    return true;
+}
+
 // normalisation scale from the mean distance to the centroid: RANSAC 1/md (:592), MLESAC sqrt(2)/md guarded
 // against md == 0 (normalizePointsHartleyZisserman, estimateTransformationMLESAC.m:653-657)
 __device__ __forceinline__ double norm_scale(double md, int mlesac) {
@@ -550,6 +642,27 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
             __syncthreads();
         }
     };
+    __shared__ double s_val[18][64];
+    auto for_each_staged = [&](int nv, auto&& prep, auto&& body) {
+        (void)nv;
+        for (int64_t base = 0; base < m; base += 64) {
+            const int64_t i = base + lane;
+            const bool have = i < m;
+            const uint8_t in_me = have ? out_mask[i] : (uint8_t)0;
+            s_in[lane] = in_me;
+            if (in_me) prep(x1[i], y1[i], x2[i], y2[i], lane);
+            __syncthreads();
+            for (int e0 = 0; e0 < 64; e0 += 8) {
+                uint8_t in[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) in[k] = s_in[e0 + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (in[k]) body(e0 + k);
+            }
+            __syncthreads();
+        }
+    };
     Norm n1, n2;
     {
         double sx = 0, sy = 0, ux = 0, uy = 0;
@@ -561,12 +674,18 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         });
         const double dn = (double)nb;
         const double cx = sx / dn, cy = sy / dn, dx2 = ux / dn, dy2 = uy / dn;
+        // The per-inlier terms of the remaining sums are the same for every lane, so they are evaluated ONCE per inlier
+        // (lane j takes the chunk's j-th point) into s_val, and the lanes then only walk the staged terms - the same
+        // terms in the same order as when every lane recomputed them (3.4 ms -> see DESIGN.md section 4).
         double sd = 0, ud = 0;
-        for_each_inlier([&](double a, double b, double c2, double d) {
+        for_each_staged(2, [&](double a, double b, double c2, double d, int j) {
             const double ax = a - cx, ay = b - cy;
-            sd = sd + sqrt(ax * ax + ay * ay);
+            s_val[0][j] = sqrt(ax * ax + ay * ay);
             const double bx = c2 - dx2, by = d - dy2;
-            ud = ud + sqrt(bx * bx + by * by);
+            s_val[1][j] = sqrt(bx * bx + by * by);
+        }, [&](int e) {
+            sd = sd + s_val[0][e];
+            ud = ud + s_val[1][e];
         });
         n1.s = norm_scale(sd / dn, mlesac);
         n1.tx = -n1.s * cx;
@@ -588,32 +707,31 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     }
     double g = 0;
     if (mlesac) {  // per inlier: its "v" row, then its "u" row
-        for_each_inlier([&](double a, double b, double c2, double d) {
+        for_each_staged(18, [&](double a, double b, double c2, double d, int j) {
             const double x = n1.s * a + n1.tx, y = n1.s * b + n1.ty;
             const double u = n2.s * c2 + n2.tx, v = n2.s * d + n2.ty;
-            g = g + dlt_entry(pp, 1, x, y, u, v) * dlt_entry(qq, 1, x, y, u, v);
-            g = g + dlt_entry(pp, 0, x, y, u, v) * dlt_entry(qq, 0, x, y, u, v);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                s_val[k][j] = dlt_entry(k, 1, x, y, u, v);
+                s_val[9 + k][j] = dlt_entry(k, 0, x, y, u, v);
+            }
+        }, [&](int e) {
+            g = g + s_val[pp][e] * s_val[qq][e];
+            g = g + s_val[9 + pp][e] * s_val[9 + qq][e];
         });
     } else {
         for (int half = 0; half < 2; ++half)
-            for_each_inlier([&](double a, double b, double c2, double d) {
+            for_each_staged(9, [&](double a, double b, double c2, double d, int j) {
                 const double x = n1.s * a + n1.tx, y = n1.s * b + n1.ty;
                 const double u = n2.s * c2 + n2.tx, v = n2.s * d + n2.ty;
-                g = g + dlt_entry(pp, half, x, y, u, v) * dlt_entry(qq, half, x, y, u, v);
-            });
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s_val[k][j] = dlt_entry(k, half, x, y, u, v);
+            }, [&](int e) { g = g + s_val[pp][e] * s_val[qq][e]; });
     }
     if (lane < 45) sG[(pp * 9 + qq) * 2 + 0] = g;  // column 0 of the work matrix
     __syncthreads();
     Mat3 Hr;
-    int ok = 0;
-    if (lane == 0) {
-        ok = gram_to_h<2>(sG, sV, 0, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr)) ? 1 : 0;
-        for (int e = 0; e < 9; ++e) sV[e * 2 + 1] = Hr.m[e];  // broadcast through the free LDS column
-        sV[9 * 2 + 1] = (double)ok;
-    }
-    __syncthreads();
-    for (int e = 0; e < 9; ++e) Hr.m[e] = sV[e * 2 + 1];
-    ok = sV[9 * 2 + 1] != 0.0;
+    const bool ok = gram_to_h_wave(sG, sV, lane, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr));
     bool use_refit = false;
     int nr = 0;
     if (mlesac) {  // :216-236: the refit is the answer; invalid or no inlier left -> not found
