@@ -115,6 +115,10 @@ def cpu_baseline(synth, input_, f, bands):
 
 
 def main():
+    if os.environ.get("APS_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["APS_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
