@@ -61,6 +61,9 @@ def _grid_points(H, W, nx, ny, border):
     return xy1
 
 
+_RAYC_CACHE = {}
+
+
 def _solve_K(Ks, B):
     """K \\ B for a stack of intrinsic matrices (n x 3 x 3) and right-hand sides (n x 3 x m).  MATLAB's mldivide takes the
     triangular solver for an upper-triangular K (every pinhole K is): back substitution, which is also what the oracle
@@ -93,7 +96,15 @@ def _all_grid_rays(cams, imgSize, border=0):
         xy1 = _grid_points(H, W, 48, 32, border)
         Ks = np.stack([np.asarray(cams[i]["K"], np.float64) for i in ids])
         Rt = np.stack([np.asarray(cams[i]["R"], np.float64).T for i in ids])
-        rays = Rt @ _solve_K(Ks, np.broadcast_to(xy1, (len(ids),) + xy1.shape))
+        # the camera-frame rays depend on the intrinsics and the image size only: kept from call to call (a video or a
+        # re-render with refined rotations solves nothing again)
+        key = (Ks.tobytes(), H, W, border)
+        rayC = _RAYC_CACHE.get(key)
+        if rayC is None:
+            if len(_RAYC_CACHE) >= 8:
+                _RAYC_CACHE.clear()
+            rayC = _RAYC_CACHE[key] = _solve_K(Ks, np.broadcast_to(xy1, (len(ids),) + xy1.shape))
+        rays = Rt @ rayC
         for q, i in enumerate(ids):
             out[i] = rays[q]
     return out
