@@ -545,3 +545,29 @@ def test_int8_screen_dismisses_most_rows_and_reports_it(fm, gpu, monkeypatch):
     fm.matchFeaturesScratch(a, b, MatchThreshold=3.5, MaxRatio=0.6, Unique=True)
     capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
     assert rows.value == 0 and surv.value == 0
+
+
+def test_pairwise_more_than_65535_pairs(fm):
+    """BASELINE configs[4] has 500 images = 124750 pairs: more pairs than one grid dimension holds (65535).  370 small
+    descriptor sets (68265 pairs) go through the batched matcher - screen, list pass, filter, chunked emit - and a
+    sample of pairs, spread over the whole list including both sides of the 65535 boundary, is compared with the oracle."""
+    rng = np.random.default_rng(17)
+    n_img = 370
+    base = sift_like(rng, 400)
+    descs = []
+    for i in range(n_img):
+        k = int(rng.integers(20, 60))
+        d = base[rng.permutation(400)[:k]] + 0.01 * rng.standard_normal((k, 128)).astype(np.float32)
+        d = np.maximum(d, 0)
+        descs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
+    pp, ii, jj, met = fm.match_pairwise_csr(descs, 0.8, 1.0, True)
+    order = fm.pair_order(n_img)
+    assert len(order) == n_img * (n_img - 1) // 2 > 65535 and len(pp) == len(order) + 1
+    picks = sorted(set(rng.integers(0, len(order), 60).tolist()) | {0, 65534, 65535, 65536, len(order) - 1})
+    for p in picks:
+        i, j = order[p]
+        om, omet = oracle.match_features(descs[i], descs[j], 0.8, 1.0, True, 2)
+        s, e = int(pp[p]), int(pp[p + 1])
+        got = np.stack([np.asarray(ii[s:e]), np.asarray(jj[s:e])], 1)
+        assert np.array_equal(got, om), (p, i, j)
+        assert np.array_equal(bits(np.asarray(met[s:e])), bits(omet))
