@@ -695,6 +695,7 @@ __global__ void expand_oriented_kernel(const unsigned int* __restrict__ ori_coun
 
 // ---- descriptor: one wave per oriented keypoint -------------------------------------------------------
 constexpr int kD = 4, kN = 8, kHistLen = (kD + 2) * (kD + 2) * (kN + 2);  // 360
+constexpr int kDescQueue = 512;  // queued samples per wave between two strided passes over the queue
 
 __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__ pt,
                                                     const KpRec* __restrict__ kps,
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
                                                     float* __restrict__ aux) {
     __shared__ unsigned long long s_hist[4][kHistLen];
     __shared__ float s_raw[4][128];
+    __shared__ int s_queue[4][kDescQueue];  // per wave: samples that passed the window test, (i << 16) | (j & 0xffff)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned int oi = blockIdx.x * 4 + wv;
     const bool active = oi < n_out;
@@ -744,49 +746,88 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
     cos_t = cos_t / hist_width;
     sin_t = sin_t / hist_width;
     const int side = 2 * radius + 1;
-    if (active) {
-        for (int s = lane; s < side * side; s += 64) {
-            const int i = s / side - radius, j = s % side - radius;
-            const float c_rot = (float)j * cos_t - (float)i * sin_t;
-            const float r_rot = (float)j * sin_t + (float)i * cos_t;
-            float rbin = r_rot + (float)(kD / 2) - 0.5f;
-            float cbin = c_rot + (float)(kD / 2) - 0.5f;
-            const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
-            const int ctr = r * w + c;  // a plane holds < 2^31 floats: 32-bit offsets from the (scalar) plane base
-            const float dx = g[ctr + 1] - g[ctr - 1];
-            const float dy = g[ctr - w] - g[ctr + w];
-            const float wgt = my_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            const float o_deg = fast_atan2_deg(dy, dx);
-            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-            float obin = (o_deg - ori) * bins_per_deg;
-            const int rr0 = (int)floorf(rbin), cc0 = (int)floorf(cbin);
-            int o0 = (int)floorf(obin);
-            rbin -= (float)rr0;
-            cbin -= (float)cc0;
-            obin -= (float)o0;
-            if (o0 < 0) o0 += kN;
-            if (o0 >= kN) o0 -= kN;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
-            const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
-            const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
-            const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
-            const int idx = ((rr0 + 1) * (kD + 2) + cc0 + 1) * (kN + 2) + o0;
-            unsigned long long* hb = &s_hist[wv][idx];
+    (void)side;
+    // The samples that contribute lie in a rotated 5 x 5-bin window inside the (2 radius + 1)^2 square - about half of
+    // it.  The square is swept row by row with the cheap window test only; passing samples are queued (per wave, in LDS),
+    // and the expensive part (atan2, exp, sqrt, trilinear split, eight LDS atomics) runs on full wavefronts of queued
+    // samples.  The queue is consumed with a STRIDE: lane l takes entries l * rounds .. + rounds - 1, so that at any
+    // moment the lanes of a wave sit ~rounds samples apart along the sweep, i.e. in different histogram cells - 64
+    // NEIGHBOURING samples share a handful of bins, and their same-address LDS atomics serialise (the kernel was bound by
+    // exactly that: SQ_LDS_BANK_CONFLICT 1.3x the LDS-active cycles).  The histogram is int64 fixed point, so the order
+    // of the samples does not matter.
+    auto accumulate = [&](int i, int j) __attribute__((always_inline)) {
+        const float c_rot = (float)j * cos_t - (float)i * sin_t;
+        const float r_rot = (float)j * sin_t + (float)i * cos_t;
+        float rbin = r_rot + (float)(kD / 2) - 0.5f;
+        float cbin = c_rot + (float)(kD / 2) - 0.5f;
+        const int r = py + i, c = px + j;
+        const int ctr = r * w + c;  // a plane holds < 2^31 floats: 32-bit offsets from the (scalar) plane base
+        const float dx = g[ctr + 1] - g[ctr - 1];
+        const float dy = g[ctr - w] - g[ctr + w];
+        const float wgt = my_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+        const float o_deg = fast_atan2_deg(dy, dx);
+        const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+        float obin = (o_deg - ori) * bins_per_deg;
+        const int rr0 = (int)floorf(rbin), cc0 = (int)floorf(cbin);
+        int o0 = (int)floorf(obin);
+        rbin -= (float)rr0;
+        cbin -= (float)cc0;
+        obin -= (float)o0;
+        if (o0 < 0) o0 += kN;
+        if (o0 >= kN) o0 -= kN;
+        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+        const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+        const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
+        const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
+        const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
+        const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
+        const int idx = ((rr0 + 1) * (kD + 2) + cc0 + 1) * (kN + 2) + o0;
+        unsigned long long* hb = &s_hist[wv][idx];
 #define ADDQ(off, v) atomicAdd(hb + (off), (unsigned long long)to_fix(v))
-            ADDQ(0, v000);
-            ADDQ(1, v001);
-            ADDQ(kN + 2, v010);
-            ADDQ(kN + 3, v011);
-            ADDQ((kD + 2) * (kN + 2), v100);
-            ADDQ((kD + 2) * (kN + 2) + 1, v101);
-            ADDQ((kD + 3) * (kN + 2), v110);
-            ADDQ((kD + 3) * (kN + 2) + 1, v111);
+        ADDQ(0, v000);
+        ADDQ(1, v001);
+        ADDQ(kN + 2, v010);
+        ADDQ(kN + 3, v011);
+        ADDQ((kD + 2) * (kN + 2), v100);
+        ADDQ((kD + 2) * (kN + 2) + 1, v101);
+        ADDQ((kD + 3) * (kN + 2), v110);
+        ADDQ((kD + 3) * (kN + 2) + 1, v111);
 #undef ADDQ
+    };
+    if (active) {
+        int* q = s_queue[wv];
+        int qn = 0;  // wave-uniform
+        auto flush = [&]() __attribute__((always_inline)) {
+            const int rounds = (qn + 63) >> 6;
+            __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: the queue writes land before its reads)
+            for (int r = 0; r < rounds; ++r) {
+                const int e = lane * rounds + r;
+                if (e < qn) {
+                    const int pk = q[e];
+                    accumulate(pk >> 16, (int)(short)(pk & 0xffff));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            qn = 0;
+        };
+        for (int i = -radius; i <= radius; ++i) {
+            for (int j0 = -radius; j0 <= radius; j0 += 64) {
+                const int j = j0 + lane;
+                const float c_rot = (float)j * cos_t - (float)i * sin_t;
+                const float r_rot = (float)j * sin_t + (float)i * cos_t;
+                const float rbin = r_rot + (float)(kD / 2) - 0.5f;
+                const float cbin = c_rot + (float)(kD / 2) - 0.5f;
+                const int r = py + i, c = px + j;
+                const bool pass = j <= radius && rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+                const unsigned long long m = __ballot(pass);
+                if (m == 0ull) continue;
+                if (pass) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (i << 16) | (j & 0xffff);
+                qn += __popcll(m);
+                if (qn > kDescQueue - 64) flush();
+            }
         }
+        if (qn > 0) flush();
     }
     __syncthreads();
     // finalize: 128 outputs, two per lane
