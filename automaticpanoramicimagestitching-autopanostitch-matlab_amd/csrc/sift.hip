@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         if (vec_ok && gx >= 0 && gx + 3 < w) {
             float4 g[8];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) g[p] = *reinterpret_cast<const float4*>(od.G[p < nl + 3 ? p : 0] + rowoff + gx);
+            for (int p = 0; p < 7; ++p) g[p] = *reinterpret_cast<const float4*>(od.G[p < nl + 3 ? p : 0] + rowoff + gx);
+            g[7] = g[0];
+            if (nl + 3 > 7) g[7] = *reinterpret_cast<const float4*>(od.G[7] + rowoff + gx);  // (uniform; only nl = 5 has an 8th plane)
 #pragma unroll
             for (int p = 0; p < 7; ++p)
                 if (p < nl + 2)
