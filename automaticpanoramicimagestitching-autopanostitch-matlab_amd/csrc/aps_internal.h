@@ -75,7 +75,17 @@ struct Ctx {
     };
     std::vector<Block> blocks;
     hipStream_t stream() const { return use_user_stream ? user_stream : own_stream; }
+    // auxiliary streams of this thread for fork/join sections (many small independent launch chains, e.g. the
+    // per-image descriptor preparation of a pair batch), with one event each; created on first use
+    std::vector<hipStream_t> aux;
+    std::vector<hipEvent_t> aux_ev;
+    hipEvent_t fork_ev = nullptr;
 };
+
+// Fork/join on the calling thread's auxiliary streams: fork(n) makes streams 0..n-1 wait for everything queued on stream()
+// so far and returns them; join() makes stream() wait for everything queued on them since.
+std::vector<hipStream_t>& aux_fork(int n);
+void aux_join(int n);
 
 // Makes sure a gfx950 device is selected for this thread and returns the context.
 Ctx& ctx();

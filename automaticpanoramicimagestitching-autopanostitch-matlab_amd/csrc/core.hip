@@ -82,6 +82,30 @@ Ctx& ctx() {
     return c;
 }
 
+std::vector<hipStream_t>& aux_fork(int n) {
+    Ctx& c = ctx();
+    while ((int)c.aux.size() < n) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        APS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        APS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c.aux.push_back(st);
+        c.aux_ev.push_back(ev);
+    }
+    if (!c.fork_ev) APS_HIP(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
+    APS_HIP(hipEventRecord(c.fork_ev, c.stream()));
+    for (int i = 0; i < n; ++i) APS_HIP(hipStreamWaitEvent(c.aux[i], c.fork_ev, 0));
+    return c.aux;
+}
+
+void aux_join(int n) {
+    Ctx& c = ctx();
+    for (int i = 0; i < n && i < (int)c.aux.size(); ++i) {
+        APS_HIP(hipEventRecord(c.aux_ev[i], c.aux[i]));
+        APS_HIP(hipStreamWaitEvent(c.stream(), c.aux_ev[i], 0));
+    }
+}
+
 void* ws_alloc(size_t bytes) {
     Ctx& c = ctx();
     bytes = (bytes + 255) & ~size_t(255);

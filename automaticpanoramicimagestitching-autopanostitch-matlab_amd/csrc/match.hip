@@ -197,6 +197,52 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
     }
 }
 
+// Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
+// [e-11i-11, e-11i) and is stored as p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16
+// and p_i is one whenever the set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows
+// up in the residual).  The candidate kernel derives the same c_i for the A-side constants.
+__device__ __forceinline__ void aug_scales(float maxsq, float* ca, float* cinv) {
+    int e;
+    (void)frexpf(0.5f * maxsq, &e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ea = min(max(e - 11 * i, -14), 15);
+        ca[i] = ldexpf(1.0f, ea);
+        cinv[i] = ldexpf(1.0f, -ea);
+    }
+}
+
+// The extra k-step's B-side operand of every column, ready to be DMA'd into LDS: 16 bytes per descriptor =
+// [p0 p1 p2 dn^ 0 0 0 0] (f16): b2/2 in three pieces and the rounding-loss norm rounded up.  Rows n .. n_pad-1 (the
+// ragged end of the last 128-column tile) hold 65504 in p0: -65504 c0 loses against every real column.  Runs after
+// prep_desc_kernel of the same set on the same stream (it needs the set's max ||x||^2).  res[0] / res[1] = the largest
+// |b2/2 - pieces| and the largest saturation loss dn - dn^ over the set (both 0 for ordinary data).
+__device__ __forceinline__ void aug_desc_row(int64_t j, const float* __restrict__ sq, const float* __restrict__ dn, int64_t n,
+                                             int64_t n_pad, const float* __restrict__ maxsq, uint4* __restrict__ aug,
+                                             float* __restrict__ res) {
+    if (j >= n_pad) return;
+    if (j >= n) {
+        aug[j] = make_uint4(0x7bffu, 0u, 0u, 0u);
+        return;
+    }
+    float ca[3], cinv[3];
+    aug_scales(*maxsq, ca, cinv);
+    float r = 0.5f * sq[j];
+    unsigned short pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float back;
+        pc[i] = f32_to_f16_flush(r * cinv[i], back);
+        r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
+    }
+    float dn_back;
+    const unsigned short pd = f16_round_up(dn[j], dn_back);
+    const float rd = fmaxf(dn[j] - dn_back, 0.f);
+    aug[j] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2] | ((uint32_t)pd << 16), 0u, 0u);
+    if (r != 0.f) atomicMax(reinterpret_cast<unsigned*>(res), __float_as_uint(fabsf(r)));
+    if (rd > 0.f) atomicMax(reinterpret_cast<unsigned*>(res) + 1, __float_as_uint(rd));
+}
+
 // int8 copies of a prepared set for the screening pre-pass (match_screen_i8_kernel), in P's (permuted) k order - a dot
 // product does not care as long as both sides agree.  A set is the row side (A) of some pairs and the column side (B) of
 // others, and the two sides can afford different codes, because anything that is constant along a row of the distance
@@ -232,13 +278,19 @@ __device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
     return q;
 }
 
+// (The launch also carries aug_desc_row - same dependency on the finished prep_desc_kernel, one launch fewer per set: the
+// preparation of a pair batch is bound by its launch count.  Lane part 0 of row i, i < n_pad, writes that row's operand.)
 __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
                                                       signed char* __restrict__ QB, float* __restrict__ dnqa,
                                                       float* __restrict__ invsa, int* __restrict__ sumqa,
-                                                      float* __restrict__ qstat) {
+                                                      float* __restrict__ qstat, const float* __restrict__ row_sq,
+                                                      const float* __restrict__ row_dn, int64_t n_pad,
+                                                      const float* __restrict__ maxsq, uint4* __restrict__ aug,
+                                                      float* __restrict__ aug_res) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t i = g >> 3;
     const int part = (int)(g & 7);
+    if (part == 0) aug_desc_row(i, row_sq, row_dn, n, n_pad, maxsq, aug, aug_res);
     const Q8Set qs = q8_set(qstat);
     float xs[16];
     float rmax = 0.f;
@@ -303,52 +355,6 @@ __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ 
         if (__float_as_uint(db) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
             atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(db));
     }
-}
-
-// Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
-// [e-11i-11, e-11i) and is stored as p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16
-// and p_i is one whenever the set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows
-// up in the residual).  The candidate kernel derives the same c_i for the A-side constants.
-__device__ __forceinline__ void aug_scales(float maxsq, float* ca, float* cinv) {
-    int e;
-    (void)frexpf(0.5f * maxsq, &e);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int ea = min(max(e - 11 * i, -14), 15);
-        ca[i] = ldexpf(1.0f, ea);
-        cinv[i] = ldexpf(1.0f, -ea);
-    }
-}
-
-// The extra k-step's B-side operand of every column, ready to be DMA'd into LDS: 16 bytes per descriptor =
-// [p0 p1 p2 dn^ 0 0 0 0] (f16): b2/2 in three pieces and the rounding-loss norm rounded up.  Rows n .. n_pad-1 (the
-// ragged end of the last 128-column tile) hold 65504 in p0: -65504 c0 loses against every real column.  Runs after
-// prep_desc_kernel of the same set on the same stream (it needs the set's max ||x||^2).  res[0] / res[1] = the largest
-// |b2/2 - pieces| and the largest saturation loss dn - dn^ over the set (both 0 for ordinary data).
-__global__ void aug_desc_kernel(const float* __restrict__ sq, const float* __restrict__ dn, int64_t n, int64_t n_pad,
-                                const float* __restrict__ maxsq, uint4* __restrict__ aug, float* __restrict__ res) {
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= n_pad) return;
-    if (j >= n) {
-        aug[j] = make_uint4(0x7bffu, 0u, 0u, 0u);
-        return;
-    }
-    float ca[3], cinv[3];
-    aug_scales(*maxsq, ca, cinv);
-    float r = 0.5f * sq[j];
-    unsigned short pc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float back;
-        pc[i] = f32_to_f16_flush(r * cinv[i], back);
-        r -= back * ca[i];  // exact (Sterbenz) unless the piece saturated
-    }
-    float dn_back;
-    const unsigned short pd = f16_round_up(dn[j], dn_back);
-    const float rd = fmaxf(dn[j] - dn_back, 0.f);
-    aug[j] = make_uint4(pc[0] | ((uint32_t)pc[1] << 16), pc[2] | ((uint32_t)pd << 16), 0u, 0u);
-    if (r != 0.f) atomicMax(reinterpret_cast<unsigned*>(res), __float_as_uint(fabsf(r)));
-    if (rd > 0.f) atomicMax(reinterpret_cast<unsigned*>(res) + 1, __float_as_uint(rd));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1711,20 +1717,29 @@ struct Prepared {
     Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
     Ws<float> dnq, invs;
     Ws<int> sumq;
+    float* stat = nullptr;  // the eight statistics words: own (maxsq) or a slice of the caller's block (one fill for many sets)
     int64_t n = 0;
 };
 
+// `st`: the stream the set's launches go to (the caller's own stream, or one of its auxiliary streams when many sets are
+// prepared side by side - each set is a chain of small launches that leaves most of the chip idle)
 static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
-                    Prepared& out) {
+                    Prepared& out, hipStream_t st = nullptr, bool bracket = true, float* stat_ext = nullptr) {
+    if (!st) st = stream();
     out.n = n;
     const size_t rows = (size_t)std::max<int64_t>(n, 1);
     out.P.alloc(rows * kDim);
     out.sq.alloc(rows);
     out.H.alloc(rows * kDim);
     out.dn.alloc(rows);
-    out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
-    APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), stream()));
-    float* const qstat = (float*)out.maxsq + 4;
+    if (stat_ext) {  // zeroed by the caller
+        out.stat = stat_ext;
+    } else {
+        out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
+        APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), st));
+        out.stat = out.maxsq;
+    }
+    float* const qstat = out.stat + 4;
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
     out.aug.alloc((size_t)n_pad);
     out.QA.alloc(rows * kDim);
@@ -1734,15 +1749,19 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     out.sumq.alloc(rows);
     if (std::getenv("APS_Q8_SYMMETRIC")) {  // A/B switch: column code without the offset
         const int sym = 1;
-        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, st));
     }
     if (n == 0) return;
-    Prof prof("match_prep");
-    prep_desc_kernel<<<cdiv(n, 64), 64, 0, stream()>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
-                                                        out.P, out.sq, out.H, out.dn, out.maxsq,
-                                                        (float*)out.maxsq + 1, qstat);
-    aug_desc_kernel<<<cdiv(n_pad, 256), 256, 0, stream()>>>(out.sq, out.dn, n, n_pad, out.maxsq, out.aug, (float*)out.maxsq + 2);
-    q8_desc_kernel<<<cdiv(n * 8, 256), 256, 0, stream()>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat);
+    struct MaybeProf {  // (event brackets live on the caller's own stream: a forked section is bracketed as a whole)
+        Prof* p = nullptr;
+        explicit MaybeProf(bool on) { if (on) p = new Prof("match_prep"); }
+        ~MaybeProf() { delete p; }
+    } prof(bracket);
+    prep_desc_kernel<<<cdiv(n, 64), 64, 0, st>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
+                                                        out.P, out.sq, out.H, out.dn, out.stat,
+                                                        out.stat + 1, qstat);
+    q8_desc_kernel<<<cdiv(n_pad * 8, 256), 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn,
+                                                         n_pad, out.stat, out.aug, out.stat + 2);
     check_launch("prep_desc_kernel");
 }
 
@@ -1759,15 +1778,15 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.BF = b.H;
     j.dnA = a.dn;
     j.augB = b.aug;
-    j.augresB = (const float*)b.maxsq + 2;
-    j.maxsqB = b.maxsq;
-    j.maxdnB = (const float*)b.maxsq + 1;
+    j.augresB = b.stat + 2;
+    j.maxsqB = b.stat;
+    j.maxdnB = b.stat + 1;
     j.AQ = a.QA;
     j.BQ = b.QB;
     j.dnqA = a.dnq;
     j.invsA = a.invs;
     j.sumqA = a.sumq;
-    j.qstatB = (const float*)b.maxsq + 4;
+    j.qstatB = b.stat + 4;
     return j;
 }
 
@@ -2243,15 +2262,24 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
     auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
     std::vector<Prepared> raw(n_img), nrm(n_img);
+    Ws<float> prep_stats((size_t)16 * std::max(n_img, 1));
     std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
     for (int64_t p = 0; p < n_pairs; ++p) {
         const bool norm = big(pa[p]) || big(pb[p]);
         (norm ? need_nrm : need_raw)[pa[p]] = 1;
         (norm ? need_nrm : need_raw)[pb[p]] = 1;
     }
-    for (int i = 0; i < n_img; ++i) {
-        if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i]);
-        if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i]);
+    {  // the sets are independent chains of small launches: eight of them side by side
+        constexpr int kPrepStreams = 8;
+        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)16 * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
+        std::vector<hipStream_t>& aux = aux_fork(kPrepStreams);
+        Prof prof("match_prep");
+        int k = 0;
+        for (int i = 0; i < n_img; ++i) {
+            if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i);
+            if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i + 8);
+        }
+        aux_join(kPrepStreams);
     }
     const auto T1 = t_now();
     std::vector<MatchJob> jobs;
