@@ -62,7 +62,17 @@ static void bind_device(Ctx& c, int dev) {
         c.ev0 = c.ev1 = nullptr;
         c.device = dev;
     }
-    if (!c.own_stream) APS_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    if (!c.own_stream) {
+        // The library's streams run at the highest priority the device offers: the kernels of the path then win wave
+        // slots against copy (blit) kernels and collectives that run beside them on default-priority streams - host
+        // uploads next to the feature extraction cost it 17 ms per 64 x 4K step otherwise (APS_STREAM_PRIORITY=0: default).
+        int least = 0, greatest = 0;
+        const char* e = std::getenv("APS_STREAM_PRIORITY");
+        if ((!e || std::atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            APS_HIP(hipStreamCreateWithPriority(&c.own_stream, hipStreamNonBlocking, greatest));
+        else
+            APS_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    }
     if (!c.ev0) APS_HIP(hipEventCreate(&c.ev0));
     if (!c.ev1) APS_HIP(hipEventCreate(&c.ev1));
 }
