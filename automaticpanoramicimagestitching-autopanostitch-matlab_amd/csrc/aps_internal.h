@@ -67,6 +67,7 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t user_stream = nullptr;
     bool use_user_stream = false;
+    int own_priority = 0;  // 1: own_stream was created at the device's highest priority
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct Block {
         void* p;

@@ -63,14 +63,17 @@ static void bind_device(Ctx& c, int dev) {
         c.device = dev;
     }
     if (!c.own_stream) {
-        // The library's streams run at the highest priority the device offers: the kernels of the path then win wave
-        // slots against copy (blit) kernels and collectives that run beside them on default-priority streams - host
-        // uploads next to the feature extraction cost it 17 ms per 64 x 4K step otherwise (APS_STREAM_PRIORITY=0: default).
+        // APS_STREAM_PRIORITY=1: this thread's stream at the highest priority the device offers (an experiment switch: on
+        // the 64 x 4K step it costs the resident extraction 2-3 ms and helps only where other streams' copies share the
+        // runtime's hardware queues with the library's streams - GPU_MAX_HW_QUEUES=8, set by the Python package, is the
+        // cure for that).
         int least = 0, greatest = 0;
         const char* e = std::getenv("APS_STREAM_PRIORITY");
-        if ((!e || std::atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        const bool want_high = e && std::atoi(e) != 0;
+        if (want_high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
             APS_HIP(hipStreamCreateWithPriority(&c.own_stream, hipStreamNonBlocking, greatest));
-        else
+            c.own_priority = 1;
+        } else
             APS_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     }
     if (!c.ev0) APS_HIP(hipEventCreate(&c.ev0));

@@ -97,6 +97,7 @@ def sift_submit(input, images, workers=8, ready=None):
         torch.cuda.synchronize()  # the images were produced on torch's stream; worker streams must see them
     if _SIFT_POOL is None:
         _SIFT_POOL = ThreadPoolExecutor(max_workers=workers)
+    pool = _SIFT_POOL
 
     def work(k):
         if ready is not None:
@@ -105,7 +106,7 @@ def sift_submit(input, images, workers=8, ready=None):
         _sync()  # this thread's stream
         return r
 
-    return [_SIFT_POOL.submit(work, k) for k in range(len(images))]
+    return [pool.submit(work, k) for k in range(len(images))]
 
 
 def extract_features(input, images, times=None):

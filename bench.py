@@ -12,8 +12,9 @@ Images are generated on the GPU (seeded, procedural) and are resident in HBM bef
 With N > 1 the SAME 64-image job is sharded over the ranks (strong scaling, see parallel.py).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline"     : the dominant kernel (the f32-MFMA descriptor-distance GEMM) against its MFMA roofline,
-                   timed with HIP events on the stream the kernel runs on (aps_profile_*);
+  "roofline"     : the dominant kernel (the int8-MFMA screening pass of the descriptor matcher) against its MFMA
+                   roofline, timed with HIP events on the stream the kernel runs on (aps_profile_*);
+  "value_end_to_end": the same steps from pinned host images to the cropped panorama in pinned host memory;
   "cpu_baseline" : the CPU oracle (oracle/, kind "port") timed on a bounded 2x2-view sample of the same
                    workload on this box's host cores (rank 0, N = 1 only).
 """
@@ -28,6 +29,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# (the package sets this too on import; here it is certain to precede the process's first HIP call - see <pkg>/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
