@@ -128,3 +128,21 @@ def test_crop_nonzero_bbox_known_answers():
     assert oracle.crop_nonzero_bbox(np.zeros((8, 9, 3), np.uint8)) == ((1, 8, 1, 9), False)
     full = np.full((8, 9, 3), 9, np.uint8)
     assert oracle.crop_nonzero_bbox(full) == ((1, 8, 1, 9), True)
+
+
+def test_solve_K_back_substitution_equals_general_solver(rp):
+    """renderPanorama._solve_K: back substitution for the upper-triangular intrinsics (mldivide's triangular branch, what
+    oracle/bounds_oracle.c::solve_K does) against LAPACK's general solver; a K with a lower entry takes the general path."""
+    rng = np.random.default_rng(4)
+    Ks = np.zeros((5, 3, 3))
+    for k in range(5):
+        f = rng.uniform(500, 9000)
+        Ks[k] = [[f, rng.uniform(-2, 2), rng.uniform(100, 2000)], [0, f * rng.uniform(0.9, 1.1), rng.uniform(100, 1500)], [0, 0, 1]]
+    B = rng.uniform(-1, 4000, (5, 3, 200))
+    B[:, 2] = 1.0
+    got = rp._solve_K(Ks, B)
+    ref = np.linalg.solve(Ks, B)
+    assert np.allclose(got, ref, rtol=1e-13, atol=1e-13)
+    Kg = Ks.copy()
+    Kg[:, 2, 0] = 1e-4  # not triangular any more
+    assert np.array_equal(rp._solve_K(Kg, B), np.linalg.solve(Kg, B))
