@@ -844,32 +844,43 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
     }
     __syncthreads();
     if (!active) return;
-    // the norms are k-ascending fma chains: every lane walks the same chain (LDS broadcast reads)
+    // the norms are k-ascending fma chains: every lane walks the same chain (LDS broadcast reads).  The clipped and the
+    // quantised values are computed once per element (two per lane) and parked in s_raw, so that each chain step is one
+    // read and one fma instead of re-deriving the element in every lane.
     float nrm2 = 0;
     for (int k = 0; k < 128; ++k) nrm2 = fmaf(s_raw[wv][k], s_raw[wv][k], nrm2);
     const float thr = sqrtf(nrm2) * 0.2f;
-    nrm2 = 0;
-    for (int k = 0; k < 128; ++k) {
-        const float v = s_raw[wv][k] < thr ? s_raw[wv][k] : thr;
-        nrm2 = fmaf(v, v, nrm2);
+    float clip[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float v0 = s_raw[wv][lane + 64 * half];
+        clip[half] = v0 < thr ? v0 : thr;
     }
+    __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: all reads above before the writes below)
+    s_raw[wv][lane] = clip[0];
+    s_raw[wv][lane + 64] = clip[1];
+    __builtin_amdgcn_wave_barrier();
+    nrm2 = 0;
+    for (int k = 0; k < 128; ++k) nrm2 = fmaf(s_raw[wv][k], s_raw[wv][k], nrm2);
     const float sn = sqrtf(nrm2);
     const float scale = 512.0f / (sn > kFltEps ? sn : kFltEps);
-    float qq = 0;
-    for (int k = 0; k < 128; ++k) {
-        const float v0 = s_raw[wv][k] < thr ? s_raw[wv][k] : thr;
-        float v = rintf(v0 * scale);
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        qq = fmaf(v, v, qq);
+    float qv[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float v = rintf(clip[half] * scale);
+        qv[half] = v < 0 ? 0 : (v > 255 ? 255 : v);
     }
+    __builtin_amdgcn_wave_barrier();
+    s_raw[wv][lane] = qv[0];
+    s_raw[wv][lane + 64] = qv[1];
+    __builtin_amdgcn_wave_barrier();
+    float qq = 0;
+    for (int k = 0; k < 128; ++k) qq = fmaf(s_raw[wv][k], s_raw[wv][k], qq);
     const float inv = sqrtf(qq);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int e = lane + 64 * half;
-        const float v0 = s_raw[wv][e] < thr ? s_raw[wv][e] : thr;
-        float v = rintf(v0 * scale);
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        const float outv = inv > 0 ? v / inv : 0.0f;
+        const float outv = inv > 0 ? qv[half] / inv : 0.0f;
         if (desc_layout == APS_ROWMAJOR)
             desc[(size_t)oi * ldd + e] = outv;
         else
