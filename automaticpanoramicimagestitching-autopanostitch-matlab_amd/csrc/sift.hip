@@ -654,26 +654,34 @@ __global__ __launch_bounds__(256) void orient_kernel(const PyrTable* __restrict_
     __syncthreads();
     if (lane < kOriBins) s_h[wv][lane] = hv;
     __syncthreads();
-    if (active && lane == 0) {
-        float omax = s_h[wv][0];
-        for (int b = 1; b < kOriBins; ++b)
-            if (s_h[wv][b] > omax) omax = s_h[wv][b];
+    // peaks (>= 0.8 max, local maxima) in ascending bin order: lane j judges bin j, a ballot prefix orders the survivors
+    // (the same tests on the same values as a serial walk over the bins)
+    if (active) {
+        float omax = lane < kOriBins ? s_h[wv][lane] : -INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
         const float thr = omax * 0.8f;
-        unsigned int cnt = 0;
-        for (int j = 0; j < kOriBins; ++j) {
+        bool peak = false;
+        float angle = 0.f;
+        if (lane < kOriBins) {
+            const int j = lane;
             const int l = j > 0 ? j - 1 : kOriBins - 1, r2 = j < kOriBins - 1 ? j + 1 : 0;
             const float hj = s_h[wv][j], hl = s_h[wv][l], hr = s_h[wv][r2];
             if (hj > hl && hj > hr && hj >= thr) {
+                peak = true;
                 float bin = (float)j + 0.5f * (hl - hr) / (hl - 2.0f * hj + hr);
                 bin = bin < 0 ? (float)kOriBins + bin : (bin >= (float)kOriBins ? bin - (float)kOriBins : bin);
-                float angle = 360.0f - (360.0f / (float)kOriBins) * bin;
+                angle = 360.0f - (360.0f / (float)kOriBins) * bin;
                 if (fabsf(angle - 360.0f) < kFltEps) angle = 0.0f;
-                ori_angle[(size_t)ki * kOriBins + cnt] = angle;
-                ori_bin[(size_t)ki * kOriBins + cnt] = (unsigned char)j;
-                ++cnt;
             }
         }
-        ori_count[ki] = cnt;
+        const unsigned long long pm = __ballot(peak);
+        if (peak) {
+            const unsigned int cnt = (unsigned int)__popcll(pm & ((1ull << lane) - 1ull));
+            ori_angle[(size_t)ki * kOriBins + cnt] = angle;
+            ori_bin[(size_t)ki * kOriBins + cnt] = (unsigned char)lane;
+        }
+        if (lane == 0) ori_count[ki] = (unsigned int)__popcll(pm);
     }
 }
 
