@@ -221,24 +221,37 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
     const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    for (int e = tid; e < IH * NV; e += 256) {
-        const int ly = e / NV, v = e - ly * NV;
+    // All of a thread's pieces are requested before the first one is parked in LDS: as a plain loop (request, wait, store,
+    // next) every workgroup paid the memory latency NPF times in series before its first barrier.
+    constexpr int NPF = (IH * NV + 255) / 256;
+    float4 pf[NPF];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int e = tid + 256 * q;
+        const int ec = e < IH * NV ? e : IH * NV - 1;  // (threads past the end re-read the last piece and drop it)
+        const int ly = ec / NV, v = ec - ly * NV;
         const int gy = reflect101(y0 + ly - R, h), gx = x0 - RP + 4 * v;
         const float* row = in + (size_t)gy * w;
-        float4 val;
         if (vec_ok && gx >= 0 && gx + 3 < w) {
-            val = *reinterpret_cast<const float4*>(row + gx);
+            pf[q] = *reinterpret_cast<const float4*>(row + gx);
         } else {
-            val.x = row[reflect101(gx, w)];
-            val.y = row[reflect101(gx + 1, w)];
-            val.z = row[reflect101(gx + 2, w)];
-            val.w = row[reflect101(gx + 3, w)];
+            pf[q].x = row[reflect101(gx, w)];
+            pf[q].y = row[reflect101(gx + 1, w)];
+            pf[q].z = row[reflect101(gx + 2, w)];
+            pf[q].w = row[reflect101(gx + 3, w)];
         }
-        float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
-        dst[0] = val.x;
-        dst[2] = val.y;
-        dst[4] = val.z;
-        dst[6] = val.w;
+    }
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int e = tid + 256 * q;
+        if (e < IH * NV) {
+            const int ly = e / NV, v = e - ly * NV;
+            float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
+            dst[0] = pf[q].x;
+            dst[2] = pf[q].y;
+            dst[4] = pf[q].z;
+            dst[6] = pf[q].w;
+        }
     }
     __syncthreads();
     // row pass: IH/2 row pairs x 8 segments of 8 outputs; consecutive lanes = consecutive row pairs
