@@ -7,11 +7,10 @@
 // agree bit for bit.
 //
 // Kernels
-//   gray_kernel / upsample2_kernel : uint8 (HWC or MATLAB planar) -> f32 gray -> 2x bilinear base.
+//   gray_up_kernel                 : uint8 (HWC or MATLAB planar) -> f32 gray (LDS only) -> 2x bilinear base.
 //   blur_kernel<R>                 : separable Gaussian, row pass then column pass fused through an LDS
-//                                    tile (reflect-101 border), register-blocked 8 outputs per thread;
-//                                    optionally writes the DoG (out - in) in the same pass, so every
-//                                    pyramid plane is read once and written once.
+//                                    tile (reflect-101 border), both passes on v_pk_fma_f32; the blur of plane
+//                                    nl also writes the next octave's base (every second pixel) from registers.
 //   extrema_kernel                 : 26-neighbour test + Newton refinement + contrast/edge tests.
 //   orient_kernel / descr_kernel   : one 64-lane wave per keypoint, histograms in LDS (int64 atomics).
 #include <algorithm>
@@ -117,28 +116,35 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 
 // ---- gray + base upsample -------------------------------------------------------------------------
-__global__ void gray_kernel(const uint8_t* __restrict__ img, int h, int w, int c, int layout,
-                            float* __restrict__ g) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    float v;
-    if (c == 1) {
-        v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * w + x] : img[(size_t)x * h + y]);
-    } else {
-        uint8_t ch[3];
+// Gray conversion and 2x bilinear base in one pass: the gray values of a tile's footprint are computed into LDS and the
+// doubled tile is interpolated from there (same expressions, so the same bits); the gray plane is never stored.
+constexpr int kGUW = 128, kGUH = 16;  // output tile per 256-thread workgroup
+__global__ __launch_bounds__(256) void gray_up_kernel(const uint8_t* __restrict__ img, int h, int w, int c, int layout,
+                                                      float* __restrict__ out) {
+    constexpr int GW = kGUW / 2 + 2, GH = kGUH / 2 + 2;
+    __shared__ float s_g[GH][GW + 1];
+    const int x0 = blockIdx.x * kGUW, y0 = blockIdx.y * kGUH;
+    const int cx0 = x0 / 2 - 1, cy0 = y0 / 2 - 1;
+    for (int e = threadIdx.x; e < GH * GW; e += 256) {
+        const int ly = e / GW, lx = e - ly * GW;
+        const int y = min(max(cy0 + ly, 0), h - 1), x = min(max(cx0 + lx, 0), w - 1);
+        float v;
+        if (c == 1) {
+            v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * w + x] : img[(size_t)x * h + y]);
+        } else {
+            uint8_t ch[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            ch[k] = layout == APS_IMG_U8_HWC ? img[((size_t)y * w + x) * 3 + k]
-                                             : img[(size_t)k * h * w + (size_t)x * h + y];
-        const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
-        v = (float)floor(d + 0.5);
+            for (int k = 0; k < 3; ++k)
+                ch[k] = layout == APS_IMG_U8_HWC ? img[((size_t)y * w + x) * 3 + k]
+                                                 : img[(size_t)k * h * w + (size_t)x * h + y];
+            const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
+            v = (float)floor(d + 0.5);
+        }
+        s_g[ly][lx] = v;
     }
-    g[(size_t)y * w + x] = v;
-}
-
-__global__ void upsample2_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= 2 * w) return;
+    __syncthreads();
+    const int y = y0 + threadIdx.x / 16, xb = x0 + (threadIdx.x & 15) * 8;
+    if (y >= 2 * h || xb >= 2 * w) return;
     float fy = ((float)y + 0.5f) * 0.5f - 0.5f;
     int sy = (int)floorf(fy);
     fy -= (float)sy;
@@ -151,22 +157,39 @@ __global__ void upsample2_kernel(const float* __restrict__ in, int h, int w, flo
         fy = 0;
     }
     const int sy1 = sy + 1 < h ? sy + 1 : h - 1;
-    float fx = ((float)x + 0.5f) * 0.5f - 0.5f;
-    int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (sx < 0) {
-        sx = 0;
-        fx = 0;
+    const float b0 = 1.0f - fy, b1 = fy;
+    const float* r0 = s_g[sy - cy0];
+    const float* r1 = s_g[sy1 - cy0];
+    float res[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int x = xb + j;
+        float fx = ((float)x + 0.5f) * 0.5f - 0.5f;
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) {
+            sx = 0;
+            fx = 0;
+        }
+        if (sx >= w - 1) {
+            sx = w - 1;
+            fx = 0;
+        }
+        const int sx1 = sx + 1 < w ? sx + 1 : w - 1;
+        const float a0 = 1.0f - fx, a1 = fx;
+        const float h0 = r0[sx - cx0] * a0 + r0[sx1 - cx0] * a1;
+        const float h1 = r1[sx - cx0] * a0 + r1[sx1 - cx0] * a1;
+        res[j] = h0 * b0 + h1 * b1;
     }
-    if (sx >= w - 1) {
-        sx = w - 1;
-        fx = 0;
+    float* dst = out + (size_t)y * (2 * w) + xb;
+    if (xb + 8 <= 2 * w && (w & 1) == 0) {
+        reinterpret_cast<float4*>(dst)[0] = make_float4(res[0], res[1], res[2], res[3]);
+        reinterpret_cast<float4*>(dst)[1] = make_float4(res[4], res[5], res[6], res[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (xb + j < 2 * w) dst[j] = res[j];
     }
-    const int sx1 = sx + 1 < w ? sx + 1 : w - 1;
-    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
-    const float h0 = in[(size_t)sy * w + sx] * a0 + in[(size_t)sy * w + sx1] * a1;
-    const float h1 = in[(size_t)sy1 * w + sx] * a0 + in[(size_t)sy1 * w + sx1] * a1;
-    out[(size_t)y * (2 * w) + x] = h0 * b0 + h1 * b1;
 }
 
 __global__ void decimate_kernel(const float* __restrict__ in, int h, int w, int oh, int ow,
@@ -199,7 +222,9 @@ __device__ __forceinline__ void pk_tap(f32x2& acc, const GaussK& gk, f32x2 v) {
 
 template <int R>
 __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
+    // dec (optional): the next octave's base plane, out(2y, 2x) for y < dh, x < dw - written from the registers that
+    // hold the result instead of by a decimation pass that re-reads the plane.
     // The haloed input tile is fetched in 16-byte pieces: the horizontal halo is rounded up to a multiple of four
     // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
     // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
@@ -304,6 +329,13 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
                     out[(size_t)gy * w + gx] = acc[j].x;
                     if (gx + 1 < w) out[(size_t)gy * w + gx + 1] = acc[j].y;
                 }
+            }
+        }
+        if (dec && (gx >> 1) < dw) {  // gx, y0 + yb are even
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int dy = (y0 + yb + j) >> 1;
+                if (dy < dh) dec[(size_t)dy * dw + (gx >> 1)] = acc[j].x;
             }
         }
     }
@@ -938,7 +970,10 @@ static GaussK make_gauss(double sigma) {
     return g;
 }
 
-static void launch_blur(const float* in, int h, int w, double sigma, float* out, Ws<float>& scratch) {
+// dec/dh/dw: optional half-resolution copy of the result (the next octave's base); returns false when the radius took the
+// generic path, which does not write it.
+static bool launch_blur(const float* in, int h, int w, double sigma, float* out, Ws<float>& scratch, float* dec = nullptr,
+                        int dh = 0, int dw = 0) {
     const GaussK gk = make_gauss(sigma);
     const int r = gk.n / 2;
     Prof prof("sift_blur");
@@ -946,7 +981,7 @@ static void launch_blur(const float* in, int h, int w, double sigma, float* out,
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
-        blur_kernel<R><<<grid, 256, 0, stream()>>>(in, h, w, gk, out); \
+        blur_kernel<R><<<grid, 256, 0, stream()>>>(in, h, w, gk, out, dec, dh, dw); \
         break;
         APS_BLUR_CASE(1)
         APS_BLUR_CASE(2)
@@ -965,9 +1000,11 @@ static void launch_blur(const float* in, int h, int w, double sigma, float* out,
             if (scratch.n < (size_t)h * w) scratch.alloc((size_t)h * w);
             blur_row_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(in, h, w, gk, scratch);
             blur_col_generic<<<dim3(cdiv(w, 256), h), 256, 0, stream()>>>(scratch, h, w, gk, out);
+            dec = nullptr;
         }
     }
     check_launch("blur_kernel");
+    return dec != nullptr;
 }
 
 static int num_octaves(int H, int W) {
@@ -1000,10 +1037,9 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         const int nl = params->n_layers;
         const int H = height, W = width;
         In<uint8_t> dimg(img, (size_t)H * W * channels);
-        Ws<float> gray((size_t)H * W), up((size_t)4 * H * W), scratch;
-        gray_kernel<<<dim3(cdiv(W, 256), H), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, gray);
-        upsample2_kernel<<<dim3(cdiv(2 * W, 256), 2 * H), 256, 0, stream()>>>(gray, H, W, up);
-        check_launch("upsample2_kernel");
+        Ws<float> up((size_t)4 * H * W), scratch;
+        gray_up_kernel<<<dim3(cdiv(2 * W, kGUW), cdiv(2 * H, kGUH)), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, up);
+        check_launch("gray_up_kernel");
         const int n_oct = std::min(num_octaves(H, W), 16);
         if (n_oct <= 0) return;
         // pyramid storage
@@ -1021,6 +1057,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             sig[i] = std::sqrt(st * st - sp * sp);
         }
         int ow = 2 * W, oh = 2 * H;
+        bool base_written = false;  // the previous octave's blur of plane nl wrote this octave's base
         for (int o = 0; o < n_oct; ++o) {
             if (o > 0) {
                 ow = std::max(1, ow / 2);
@@ -1030,19 +1067,29 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             od.w = ow;
             od.h = oh;
             const size_t px = (size_t)ow * oh;
-            for (int i = 0; i < nl + 3; ++i) G[o * (nl + 3) + i].alloc(px);
+            for (int i = 0; i < nl + 3; ++i)
+                if (!(i == 0 && base_written)) G[o * (nl + 3) + i].alloc(px);
             if (o == 0) {
                 double sd = params->sigma * params->sigma - 4.0 * 0.5 * 0.5;
                 if (sd < 0.01) sd = 0.01;
                 launch_blur(up, oh, ow, std::sqrt(sd), G[0], scratch);
-            } else {
+            } else if (!base_written) {
                 const OctaveDesc& pd = table.oct[o - 1];
                 decimate_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(G[(o - 1) * (nl + 3) + nl], pd.h, pd.w,
                                                                             oh, ow, G[o * (nl + 3)]);
                 check_launch("decimate_kernel");
             }
-            for (int i = 1; i < nl + 3; ++i)
-                launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], scratch);
+            base_written = false;
+            for (int i = 1; i < nl + 3; ++i) {
+                if (i == nl && o + 1 < n_oct) {
+                    const int nw = std::max(1, ow / 2), nh = std::max(1, oh / 2);
+                    G[(o + 1) * (nl + 3)].alloc((size_t)nw * nh);
+                    base_written = launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], scratch,
+                                               G[(o + 1) * (nl + 3)], nh, nw);
+                } else {
+                    launch_blur(G[o * (nl + 3) + i - 1], oh, ow, sig[i], G[o * (nl + 3) + i], scratch);
+                }
+            }
             for (int i = 0; i < nl + 3; ++i) od.G[i] = G[o * (nl + 3) + i];
         }
         // extrema: detection sweep per octave -> packed cells; then one dense refinement launch
