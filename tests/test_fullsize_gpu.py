@@ -139,3 +139,39 @@ def test_bench_scale_matching_screen_on_equals_screen_off(gpu, mods, monkeypatch
     seg = torch.repeat_interleave(torch.arange(len(order), device="cuda"), torch.from_numpy(np.diff(pp)).to("cuda"))
     key = seg.to(torch.int64) * (1 << 32) + ib.to(torch.int64)
     assert int(torch.unique(key).numel()) == int(key.numel())
+
+
+def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
+    """BASELINE configs[4] on one GPU: 500 mixed 2K views (25 independent worlds x 20 views, shuffled) -> all 124 750
+    pairs matched -> connected components -> 25 spherical panoramas.  Properties only (the oracle would need hours):
+    every component is exactly one world, every panorama is rendered, covered and of a plausible size."""
+    import time
+    import torch
+
+    synth = mods["synth"]
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    W, H, f, nx, ny, n_worlds = 2048, 1536, 2400.0, 5, 4, 25
+    views, Ks, world_of = [], [], []
+    for wi in range(n_worlds):
+        imgs, cams = synth.make_scene(nx, ny, W, H, f, 0.4, seed=1000 + 17 * wi, device="cuda", finest_px=10.0)
+        views += imgs
+        Ks += [c["K"] for c in cams]
+        world_of += [wi] * len(imgs)
+    perm = np.random.default_rng(9).permutation(len(views))
+    views, Ks, world_of = [views[k] for k in perm], [Ks[k] for k in perm], [world_of[k] for k in perm]
+    torch.cuda.synchronize()
+    n = len(views)
+    assert n == 500
+    inp = pl.default_input(bands=5)
+    t0 = time.perf_counter()
+    pano, info = par.stitch_distributed(inp, dict(enumerate(views)), n, Ks, (2048, 2048), 0, None, pano_root=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"configs[4] scale on one GPU: {dt:.2f} s, stages {info['times']}")
+    assert info["n_components"] == n_worlds and len(info["panoramas"]) == n_worlds
+    for c, p in zip(info["components"], info["panoramas"]):
+        assert len(c["members"]) == nx * ny and len({world_of[k] for k in c["members"]}) == 1
+        assert p.dtype == torch.uint8 and p.shape[2] == 3 and p.shape[1] > 2 * W and p.shape[0] > 2 * H
+        assert (p.amax(dim=2) > 0).float().mean().item() > 0.5
+    assert any(pano is p for p in info["panoramas"])
