@@ -175,3 +175,31 @@ def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
         assert p.dtype == torch.uint8 and p.shape[2] == 3 and p.shape[1] > 2 * W and p.shape[0] > 2 * H
         assert (p.amax(dim=2) > 0).float().mean().item() > 0.5
     assert any(pano is p for p in info["panoramas"])
+
+
+def test_256_views_4k_at_configs3_image_count(gpu, mods):
+    """BASELINE configs[3]'s image set on one GPU (the 8-GPU sharding itself needs the node): 256 4K views of one world
+    (16 x 16 grid), all 32 640 pairs matched, one component, one spherical panorama.  Properties only."""
+    import time
+    import torch
+
+    synth = mods["synth"]
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    W, H, f, nx, ny = 3840, 2160, 8000.0, 16, 16
+    views, cams = synth.make_scene(nx, ny, W, H, f, 0.4, device="cuda", finest_px=16.0)
+    torch.cuda.synchronize()
+    n = len(views)
+    assert n == 256
+    inp = pl.default_input(bands=5)
+    t0 = time.perf_counter()
+    pano, info = par.stitch_distributed(inp, dict(enumerate(views)), n, [c["K"] for c in cams], (2048, 2048), 0, None, pano_root=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"configs[3] image set on one GPU: {dt:.2f} s, panorama {tuple(pano.shape)}, verified pairs {info['n_pairs_verified']}, "
+          f"stages {info['times']}")
+    assert info["n_components"] == 1 and len(info["panoramas"]) == 1 and sorted(info["members"]) == list(range(n))
+    # 4-neighbour pairs of the grid all verify (2 * 16 * 15), diagonal ones mostly
+    assert info["n_pairs_verified"] >= 2 * nx * (ny - 1)
+    assert pano.dtype == torch.uint8 and pano.shape[2] == 3 and pano.shape[0] > 4 * H and pano.shape[1] > 4 * W
+    assert (pano[::4, ::4].amax(dim=2) > 0).float().mean().item() > 0.5
