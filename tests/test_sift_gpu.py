@@ -29,13 +29,15 @@ def textured(rng, h, w, c=3):
 INPUT = {"detector": "SIFT", "Sigma": 1.6, "NumLayersInOctave": 4, "ContrastThreshold": 0.00133, "EdgeThreshold": 6}
 
 
-@pytest.mark.parametrize("h,w", [(120, 160), (97, 131), (240, 320), (64, 200)])
+@pytest.mark.parametrize("h,w", [(120, 160), (97, 131), (240, 320), (64, 200), (35, 47), (18, 515), (129, 66)])
 def test_sift_bit_exact_rgb(fm, h, w):
+    """(Odd sizes, sizes one past a tile of the fused gray / 2x-base kernel (128 x 16 outputs) and of the blur (64 x 32),
+    and planes whose halved octaves have odd sides: the blur of plane nl writes the next octave's base itself.)"""
     rng = np.random.default_rng(h * 7 + w)
     img = textured(rng, h, w)
     f, pts, aux = fm.sift_extract(INPUT, img, want_aux=True)
     od, ol, oa = oracle.sift(img)
-    assert len(od) > 50
+    assert len(od) > (50 if h * w > 5000 else 5)
     assert f.shape == od.shape
     assert np.array_equal(pts, ol)
     assert np.array_equal(aux.view(np.uint32), oa.view(np.uint32))
