@@ -466,16 +466,24 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
     return true;
 }
 
-// 64 x 16 pixel tile per 256-thread workgroup; all nl+2 DoG planes of the tile (plus a 1-pixel halo) are staged
-// in LDS once, so every plane is read from HBM ~1.16x instead of 27x per layer through the caches.
-constexpr int kEW = 64, kEH = 16;
+// 64 x 12 pixel tile per 256-thread workgroup; all nl+2 DoG planes of the tile (plus a 1-pixel halo) are staged
+// in LDS once, so every plane is read from HBM ~1.3x instead of 27x per layer through the caches.  12 rows: the
+// haloed tile is 14 x 18 = 252 sixteen-byte pieces, ONE per thread - every thread issues its seven plane loads once
+// and the workgroup pays one memory round trip (16 rows needed a second, quarter-filled round).
+#ifndef APS_EH
+#define APS_EH 12
+#endif
+constexpr int kEW = 64, kEH = APS_EH, kERows = kEH / 4;  // rows of a column owned by one thread
+static_assert(kEH % 4 == 0, "four row groups");
 
-__global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int o, float thr,
+template <int nl>  // NumLayersInOctave: nl + 3 Gaussian planes, nl + 2 DoG planes (sizes the LDS tile and the loops)
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int o, float thr,
                                                       unsigned long long* __restrict__ cells,
                                                       unsigned int* __restrict__ count, unsigned int cap) {
     // LDS rows hold pixels x0-4 .. x0+kEW+3 (the 1-pixel halo rounded out to 16-byte pieces; pitch TW)
     constexpr int TW = kEW + 8, TH = kEH + 2, NV = TW / 4, HX = 3;  // HX: LDS column of pixel x0-1
-    __shared__ __attribute__((aligned(16))) float s_d[7][TH * TW];
+    constexpr int NG = nl + 3, ND = nl + 2;
+    __shared__ __attribute__((aligned(16))) float s_d[ND][TH * TW];
     const int w = od.w, h = od.h;
     const int x0 = blockIdx.x * kEW, y0 = blockIdx.y * kEH;
     const int tid = threadIdx.x;
@@ -489,53 +497,32 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
         // early exit between the loads the compiler waits for each one before testing the next, and the seven
         // round trips in series made this kernel latency-bound (83 % of its wave cycles sat in s_waitcnt).
         if (vec_ok && gx >= 0 && gx + 3 < w) {
-            float4 g[8];
+            float4 g[NG];
 #pragma unroll
-            for (int p = 0; p < 7; ++p) g[p] = *reinterpret_cast<const float4*>(od.G[p < nl + 3 ? p : 0] + rowoff + gx);
-            g[7] = g[0];
-            if (nl + 3 > 7) g[7] = *reinterpret_cast<const float4*>(od.G[7] + rowoff + gx);  // (uniform; only nl = 5 has an 8th plane)
+            for (int p = 0; p < NG; ++p) g[p] = *reinterpret_cast<const float4*>(od.G[p] + rowoff + gx);
 #pragma unroll
-            for (int p = 0; p < 7; ++p)
-                if (p < nl + 2)
-                    *reinterpret_cast<float4*>(&s_d[p][ly * TW + 4 * v]) =
-                        make_float4(g[p + 1].x - g[p].x, g[p + 1].y - g[p].y, g[p + 1].z - g[p].z, g[p + 1].w - g[p].w);
+            for (int p = 0; p < ND; ++p)
+                *reinterpret_cast<float4*>(&s_d[p][ly * TW + 4 * v]) =
+                    make_float4(g[p + 1].x - g[p].x, g[p + 1].y - g[p].y, g[p + 1].z - g[p].z, g[p + 1].w - g[p].w);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const size_t off = rowoff + min(max(gx + q, 0), w - 1);
-                float g[8];
+                float g[NG];
 #pragma unroll
-                for (int p = 0; p < 8; ++p) g[p] = od.G[p < nl + 3 ? p : 0][off];
+                for (int p = 0; p < NG; ++p) g[p] = od.G[p][off];
 #pragma unroll
-                for (int p = 0; p < 7; ++p)
-                    if (p < nl + 2) s_d[p][ly * TW + 4 * v + q] = g[p + 1] - g[p];
+                for (int p = 0; p < ND; ++p) s_d[p][ly * TW + 4 * v + q] = g[p + 1] - g[p];
             }
         }
     }
     __syncthreads();
-    // thread (lx, g) owns column lx and the four consecutive rows 4g .. 4g+3 of the tile.  Per plane: the
-    // horizontal 3-max/3-min of the six rows it touches, then the vertical 3-max/3-min per owned pixel = the
+    // thread (lx, g) owns column lx and the kERows consecutive rows kERows g .. of the tile.  Per plane: the
+    // horizontal 3-max/3-min of the kERows + 2 rows it touches, then the vertical 3-max/3-min per owned pixel = the
     // 3x3 window extrema (centre included).  A pixel is a 26-neighbour maximum iff val >= the max of the three
     // planes' window maxima (val itself is inside its own window, which changes nothing).
     const int lx = tid & 63, g = tid >> 6;
     const int c = x0 + lx;
-    float wmax[7][4], wmin[7][4];
-#pragma unroll
-    for (int p = 0; p < 7; ++p) {
-        if (p >= nl + 2) break;
-        float hmx[6], hmn[6];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) {
-            const float* row = &s_d[p][(4 * g + rr) * TW + lx + HX];
-            hmx[rr] = fmaxf(fmaxf(row[0], row[1]), row[2]);
-            hmn[rr] = fminf(fminf(row[0], row[1]), row[2]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wmax[p][k] = fmaxf(fmaxf(hmx[k], hmx[k + 1]), hmx[k + 2]);
-            wmin[p][k] = fminf(fminf(hmn[k], hmn[k + 1]), hmn[k + 2]);
-        }
-    }
     // Candidates are collected per workgroup in LDS and appended with ONE global atomic: at the octaves where the
     // texture lives, tens of thousands of single-address atomics serialised in L2 (the 2 MPix octave took 110 us against
     // 24 us without candidates, longer than the 8 MPix octave).  The order of the cells is irrelevant: they are sorted
@@ -546,19 +533,34 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int nl, int
     if (tid == 0) s_n = 0u;
     __syncthreads();
     const bool col_ok = c >= kBorder && c < w - kBorder;
+    // The window extrema of three consecutive planes are live at a time (plane p in slot p % 3): layer p - 1 is tested
+    // as soon as plane p's are known.
+    float wmax[3][kERows], wmin[3][kERows];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ry = 4 * g + k;
-        const int r = y0 + ry;
-        if (!col_ok || r < kBorder || r >= h - kBorder) continue;
-        const int ctr = (ry + 1) * TW + lx + HX + 1;
+    for (int p = 0; p < ND; ++p) {
+        float hmx[kERows + 2], hmn[kERows + 2];
 #pragma unroll
-        for (int layer = 1; layer <= 5; ++layer) {
-            if (layer > nl) break;
-            const float val = s_d[layer][ctr];
+        for (int rr = 0; rr < kERows + 2; ++rr) {
+            const float* row = &s_d[p][(kERows * g + rr) * TW + lx + HX];
+            hmx[rr] = fmaxf(fmaxf(row[0], row[1]), row[2]);
+            hmn[rr] = fminf(fminf(row[0], row[1]), row[2]);
+        }
+#pragma unroll
+        for (int k = 0; k < kERows; ++k) {
+            wmax[p % 3][k] = fmaxf(fmaxf(hmx[k], hmx[k + 1]), hmx[k + 2]);
+            wmin[p % 3][k] = fminf(fminf(hmn[k], hmn[k + 1]), hmn[k + 2]);
+        }
+        if (p < 2) continue;
+        const int layer = p - 1;
+#pragma unroll
+        for (int k = 0; k < kERows; ++k) {
+            const int ry = kERows * g + k;
+            const int r = y0 + ry;
+            if (!col_ok || r < kBorder || r >= h - kBorder) continue;
+            const float val = s_d[layer][(ry + 1) * TW + lx + HX + 1];
             if (!(fabsf(val) > thr)) continue;
-            const float mx = fmaxf(fmaxf(wmax[layer - 1][k], wmax[layer][k]), wmax[layer + 1][k]);
-            const float mn = fminf(fminf(wmin[layer - 1][k], wmin[layer][k]), wmin[layer + 1][k]);
+            const float mx = fmaxf(fmaxf(wmax[0][k], wmax[1][k]), wmax[2][k]);
+            const float mn = fminf(fminf(wmin[0][k], wmin[1][k]), wmin[2][k]);
             const bool is_max = val > 0 && val >= mx, is_min = val < 0 && val <= mn;
             if (!(is_max || is_min)) continue;
             const unsigned long long cell = ((unsigned long long)o << 40) | ((unsigned long long)layer << 32) |
@@ -1109,8 +1111,14 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                 const OctaveDesc& od = table.oct[o];
                 if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
                 Prof prof("sift_extrema");
-                extrema_kernel<<<dim3(cdiv(od.w, kEW), cdiv(od.h, kEH)), 256, 0, stream()>>>(od, nl, o, thr, cells,
-                                                                                      d_count, cells_cap);
+                const dim3 eg(cdiv(od.w, kEW), cdiv(od.h, kEH));
+                switch (nl) {
+                    case 1: extrema_kernel<1><<<eg, 256, 0, stream()>>>(od, o, thr, cells, d_count, cells_cap); break;
+                    case 2: extrema_kernel<2><<<eg, 256, 0, stream()>>>(od, o, thr, cells, d_count, cells_cap); break;
+                    case 3: extrema_kernel<3><<<eg, 256, 0, stream()>>>(od, o, thr, cells, d_count, cells_cap); break;
+                    case 4: extrema_kernel<4><<<eg, 256, 0, stream()>>>(od, o, thr, cells, d_count, cells_cap); break;
+                    default: extrema_kernel<5><<<eg, 256, 0, stream()>>>(od, o, thr, cells, d_count, cells_cap); break;
+                }
                 check_launch("extrema_kernel");
             }
             APS_HIP(hipMemcpyAsync(h_counts, d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
