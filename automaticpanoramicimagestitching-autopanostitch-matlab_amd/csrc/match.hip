@@ -113,15 +113,43 @@ __device__ __forceinline__ unsigned ord_f32(float f) {
 }
 __device__ __forceinline__ float unord_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-__global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
+// One 64-thread workgroup = 64 rows, one row per lane (the norms are sequential k-ascending chains).  A row-major set
+// is read and the copies are written through an LDS tile (64 rows x 132 floats): every global instruction then moves
+// whole rows (two per 16-byte-per-lane instruction) instead of 64 scattered 16-byte pieces 512 bytes apart - the kernel
+// ran at 0.8 TB/s of its ~35 MB per set on that access pattern alone.
+constexpr int kPrepPitch = kDim + 4;  // floats; 132 = 4 (mod 64): ds_read/write_b128 of 16 consecutive lanes hit 16 slots
+__global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
                                  float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
+    const int lane = threadIdx.x;
+    const int64_t r0 = blockIdx.x * (int64_t)64, i = r0 + lane;
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : n - 1;  // (lanes past the end work on the last row and store nothing)
     float x[kDim];
+    const bool tiled = layout == APS_ROWMAJOR && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (tiled) {
+#pragma unroll 8
+        for (int it = 0; it < 32; ++it) {
+            const int row = 2 * it + (lane >> 5), c4 = lane & 31;
+            const int64_t gr = r0 + row < n ? r0 + row : n - 1;
+            *reinterpret_cast<f32x4*>(&s_t[row * kPrepPitch + 4 * c4]) = *reinterpret_cast<const f32x4*>(X + gr * ld + 4 * c4);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[i * ld + k] : X[i + k * ld];
+        for (int j = 0; j < kDim / 4; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&s_t[lane * kPrepPitch + 4 * j]);
+            x[4 * j + 0] = v.x;
+            x[4 * j + 1] = v.y;
+            x[4 * j + 2] = v.z;
+            x[4 * j + 3] = v.w;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[ic * ld + k] : X[ic + k * ld];
+    }
     if (normalize) {
         float s = 0.f;
 #pragma unroll
@@ -135,8 +163,8 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
-    sq[i] = s;
-    float* p = P + i * kDim;
+    if (valid) sq[i] = s;
+    // the permuted f32 copy (even k, then odd k), staged per lane and stored as whole rows
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) {
         f32x4 e, o;
@@ -148,13 +176,21 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
         o.z = x[8 * s4 + 5];
         e.w = x[8 * s4 + 6];
         o.w = x[8 * s4 + 7];
-        *reinterpret_cast<f32x4*>(p + 4 * s4) = e;
-        *reinterpret_cast<f32x4*>(p + 64 + 4 * s4) = o;
+        *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 4 * s4]) = e;
+        *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 64 + 4 * s4]) = o;
     }
+    __syncthreads();
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+        const int row = 2 * it + (lane >> 5), c4 = lane & 31;
+        if (r0 + row < n)
+            *reinterpret_cast<f32x4*>(P + (r0 + row) * kDim + 4 * c4) = *reinterpret_cast<const f32x4*>(&s_t[row * kPrepPitch + 4 * c4]);
+    }
+    __syncthreads();
     // screening copy in natural k order: xf = f16(x), and the norm of what the rounding dropped, ||x - xf||
     // (rounded up): the candidate kernel's error bound is built from these norms, not from a worst case
-    if (Hf) {
-        unsigned short* ph = Hf + i * kDim;
+    if (Hf) {  // (uniform)
+        uint4* ph = reinterpret_cast<uint4*>(&s_t[lane * kPrepPitch]);
         float ds = 0.f;
 #pragma unroll
         for (int k8 = 0; k8 < kDim / 8; ++k8) {
@@ -172,14 +208,24 @@ __global__ void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t
             a.y = hv[2] | ((uint32_t)hv[3] << 16);
             a.z = hv[4] | ((uint32_t)hv[5] << 16);
             a.w = hv[6] | ((uint32_t)hv[7] << 16);
-            *reinterpret_cast<uint4*>(ph + 8 * k8) = a;
+            ph[k8] = a;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int it = 0; it < 16; ++it) {  // four 256-byte rows per instruction
+            const int row = 4 * it + (lane >> 4), c = lane & 15;
+            if (r0 + row < n)
+                *reinterpret_cast<uint4*>(Hf + (r0 + row) * kDim + 8 * c) =
+                    reinterpret_cast<const uint4*>(&s_t[row * kPrepPitch])[c];
         }
         const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 roundings of 2^-24 in ds, one in the root: 2^-10 covers
-        dn[i] = dnv;
-        atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
-        atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
+        if (valid) {
+            dn[i] = dnv;
+            atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
+            atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
+        }
     }
-    if (qstat) {  // the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
+    if (qstat && valid) {  // the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
                   // [0] max x, [3] complement of min x (the column-side copy's range), [2] complement of min ||x||^2
         float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
