@@ -437,6 +437,9 @@ struct WgJob {
     int job;
     int row0;      // first A row of the tile (dense mode) / first entry of the row list (list mode)
     int list_cnt;  // list mode: number of listed rows in this tile (<= kTM)
+    // match2nn_kernel's list mode with n_pool > 0 only: the B tiles [t0, t1) of a column-split tile and the index of
+    // this part; parts write (idx, d1, d2) to part * n_pool + list position (merged by match2nn_merge_parts_kernel)
+    int t0, t1, part;
 };
 
 __device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob, int oi, float os) {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
                                                            const uint32_t* __restrict__ row_list, int n_jobs,
                                                            uint32_t* __restrict__ out_idx,
                                                            float* __restrict__ out_d1,
-                                                           float* __restrict__ out_d2) {
+                                                           float* __restrict__ out_d2, int64_t n_pool = 0) {
     __shared__ __attribute__((aligned(16))) float lds[2 * kTN * kLdsRow];
     // list mode: a tile's rows may come from different jobs that share the B set (w.job names one of them); per row
     // the output slot, its A row (pointer into that job's permuted copy) and ||a||^2
@@ -526,7 +529,9 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     }
 
     // B tile staging: 64 rows x 512 B = 2048 float4; 256 threads x 8
-    const int ntiles = (nB + kTN - 1) / kTN;
+    const int ntiles_all = (nB + kTN - 1) / kTN;
+    const bool part = LIST && n_pool > 0;  // a column range [t0, t1) of a split tile (possibly empty)
+    const int tfirst = part ? w.t0 : 0, ntiles = part ? min(w.t1, ntiles_all) : ntiles_all;  // (empty when t0 >= t1)
     f32x4 stage[8];
     auto load_tile = [&](int t) {
 #pragma unroll
@@ -545,11 +550,11 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
         }
     };
 
-    load_tile(0);
-    store_tile(0);
+    load_tile(min(tfirst, max(ntiles_all - 1, 0)));  // (an empty part still stages a valid tile and skips the loop)
+    store_tile(tfirst & 1);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tfirst; t < ntiles; ++t) {
         if (t + 1 < ntiles) load_tile(t + 1);
         const float* tile = lds + (t & 1) * (kTN * kLdsRow);
 #pragma unroll
@@ -597,15 +602,33 @@ __global__ __launch_bounds__(256, 2) void match2nn_kernel(const MatchJob* __rest
     if (c == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = a_row(rowbase + (r & 3) + 8 * (r >> 2) + 4 * h);
+            const int lr = rowbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = a_row(lr);
             if (row >= 0) {
-                const int64_t o = LIST ? (int64_t)row : jb.out_off + row;
+                const int64_t o = part ? (int64_t)w.part * n_pool + w.row0 + lr : LIST ? (int64_t)row : jb.out_off + row;
                 out_idx[o] = nB > 0 ? (uint32_t)bidx[r] + 1u : 0u;
                 out_d1[o] = best[r];
                 out_d2[o] = second[r];
             }
         }
     }
+}
+
+// The parts of column-split list tiles, merged per row in part order (top2_merge: the smaller index wins equal
+// distances, as in the kernel's own lane merge) and written to the row's output slot.
+__global__ void match2nn_merge_parts_kernel(const uint32_t* __restrict__ row_list, int64_t n_pool, int n_parts,
+                                            const uint32_t* __restrict__ p_idx, const float* __restrict__ p_d1,
+                                            const float* __restrict__ p_d2, uint32_t* __restrict__ out_idx,
+                                            float* __restrict__ out_d1, float* __restrict__ out_d2) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n_pool) return;
+    float b = p_d1[e], s2 = p_d2[e];
+    int i = (int)p_idx[e];  // 1-based (0: an empty column set - then every part says 0)
+    for (int p = 1; p < n_parts; ++p) top2_merge(b, i, s2, p_d1[p * n_pool + e], (int)p_idx[p * n_pool + e], p_d2[p * n_pool + e]);
+    const uint32_t slot = row_list[e];
+    out_idx[slot] = (uint32_t)i;
+    out_d1[slot] = b;
+    out_d2[slot] = s2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2012,10 +2035,29 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
             n_fb += h_cnt[order[b]];
             ++b;
         }
-        for (size_t r = g0; r < n_fb; r += kTM) fwgs.push_back({order[a], (int)r, (int)std::min<size_t>(kTM, n_fb - r)});
+        for (size_t r = g0; r < n_fb; r += kTM) fwgs.push_back({order[a], (int)r, (int)std::min<size_t>(kTM, n_fb - r), 0, 0, 0});
         a = b;
     }
     if (fwgs.empty()) return;
+    // A handful of tiles, each streaming a whole B set through f32 MFMAs, leaves most of the chip idle (63 tiles of ~32
+    // rows on the 64 x 4K scene: 1.5 ms): split the columns of every tile into parts and merge the parts' top-2.
+    int n_parts = 1;
+    if (!std::getenv("APS_MATCH_NO_FB_SPLIT")) n_parts = (int)std::min<size_t>(8, std::max<size_t>(1, 512 / fwgs.size()));
+    if (n_parts > 1) {
+        std::vector<WgJob> split;
+        for (const WgJob& f : fwgs) {
+            const int nt = (jobs[f.job].nB + kTN - 1) / kTN;
+            const int np = std::min(n_parts, std::max(nt, 1));
+            for (int p = 0; p < n_parts; ++p) {  // (every part index exists for every row: parts beyond np cover no tile)
+                WgJob g = f;
+                g.t0 = p < np ? (int)((long long)nt * p / np) : nt;
+                g.t1 = p < np ? (int)((long long)nt * (p + 1) / np) : nt;
+                g.part = p;
+                split.push_back(g);
+            }
+        }
+        fwgs.swap(split);
+    }
     Ws<long long> d_dst(jobs.size());
     Ws<uint32_t> fb_pool(n_fb);
     Ws<WgJob> dfw(fwgs.size());
@@ -2024,7 +2066,15 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     {
         Prof prof("match2nn_fallback");
         fb_compact_kernel<<<(unsigned)jobs.size(), 64, 0, stream()>>>(djobs, fb_list, fb_count, d_dst, fb_pool);
-        match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_pool, (int)jobs.size(), idx, d1, d2);
+        if (n_parts > 1) {
+            Ws<uint32_t> p_idx(n_fb * n_parts);
+            Ws<float> p_d1(n_fb * n_parts), p_d2(n_fb * n_parts);
+            match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_pool, (int)jobs.size(), p_idx, p_d1, p_d2,
+                                                                              (int64_t)n_fb);
+            match2nn_merge_parts_kernel<<<cdiv(n_fb, 256), 256, 0, stream()>>>(fb_pool, (int64_t)n_fb, n_parts, p_idx, p_d1, p_d2, idx, d1, d2);
+        } else {
+            match2nn_kernel<true><<<(unsigned)fwgs.size(), 256, 0, stream()>>>(djobs, dfw, fb_pool, (int)jobs.size(), idx, d1, d2);
+        }
     }
     check_launch("match2nn_kernel<list>");
     const auto R2 = std::chrono::steady_clock::now();
