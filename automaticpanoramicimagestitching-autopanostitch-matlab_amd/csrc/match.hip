@@ -1710,15 +1710,32 @@ __global__ void filter_select_kernel(const FilterJob* __restrict__ fj, int njobs
                                      unsigned long long* __restrict__ packed,  // kept keys, dense per job
                                      unsigned long long* __restrict__ job_count) {
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (slot >= total_rows) return;
-    const unsigned long long key = keys[slot];
-    if (key == ~0ull) return;
-    const int j = find_job(fj, njobs, slot);
-    if (unique && winner[fj[j].col_off + (idx[slot] - 1)] != key) return;
+    unsigned long long key = ~0ull;
+    if (slot < total_rows) key = keys[slot];
+    bool kept = key != ~0ull;
+    int j = 0;
+    if (kept) {
+        j = find_job(fj, njobs, slot);
+        if (unique && winner[fj[j].col_off + (idx[slot] - 1)] != key) kept = false;
+    }
     // the kept keys of a job form the head of its own row segment (any order: the sort that follows
-    // works on distinct keys), so the sort touches the survivors only
-    const unsigned long long pos = atomicAdd(&job_count[j], 1ull);
-    packed[fj[j].row_off + pos] = unique ? key : (key & 0xffffffffull);  // non-unique lists are in row order
+    // works on distinct keys), so the sort touches the survivors only.  One counter update per wave when its kept rows
+    // belong to one job (a wave spans 64 consecutive rows): an overlapping pair keeps thousands of rows, and that many
+    // same-address atomics serialised in L2 were most of this kernel's time.
+    const unsigned long long m = __ballot(kept);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    const int jl = __shfl(j, leader);
+    unsigned long long pos;
+    if (__ballot(kept && j != jl) == 0ull) {
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(&job_count[jl], (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    } else if (kept) {
+        pos = atomicAdd(&job_count[j], 1ull);
+    }
+    if (kept) packed[fj[j].row_off + pos] = unique ? key : (key & 0xffffffffull);  // non-unique lists are in row order
 }
 
 __global__ void filter_seg_end_kernel(const FilterJob* __restrict__ fj, int njobs,
