@@ -1689,14 +1689,13 @@ __global__ void filter_mark_kernel(const FilterJob* __restrict__ fj, int njobs, 
                                    unsigned long long* __restrict__ winner) {
     const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (slot >= total_rows) return;
-    const int j = find_job(fj, njobs, slot);
-    const FilterJob f = fj[j];
-    const uint32_t row = (uint32_t)(slot - f.row_off);
     const double b = (double)d1[slot], s = (double)d2[slot];
     // ratioOK = dBest <= r2*dSecond; threshOK = dBest <= MatchThreshold; both finite (:173-178)
     const bool keep = idx[slot] != 0 && (b <= r2 * s) && (b <= thr) && isfinite(b) && isfinite(s);
     unsigned long long key = ~0ull;
-    if (keep) {
+    if (keep) {  // (the row -> job search, eleven dependent loads, only for the few rows that pass)
+        const FilterJob f = fj[find_job(fj, njobs, slot)];
+        const uint32_t row = (uint32_t)(slot - f.row_off);
         key = ((unsigned long long)order_f32(d1[slot]) << 32) | row;
         if (unique) atomicMin(&winner[f.col_off + (idx[slot] - 1)], key);
     }
