@@ -371,21 +371,23 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
 
     # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
     t0 = time.perf_counter()
+    oi, oj = _pair_index_arrays(n)
     put = np.zeros((n, n), np.int64)
-    for p, (i, j) in enumerate(order):
-        put[i, j] = n_match[p]
+    put[oi, oj] = n_match
     sym = put + put.T
     srt = np.argsort(-sym, axis=1, kind="stable")[:, : min(int(input["mBrownLowe"]), n - 1)]
     cand = np.zeros((n, n), bool)
     cand[np.repeat(np.arange(n), srt.shape[1]), srt.reshape(-1)] = True
     cand = np.triu(cand | cand.T, 1)
-    pidx = {ij: p for p, ij in enumerate(order)}
-    cj, ci = np.nonzero(cand.T)
-    work = [pidx[(i, j)] for (i, j) in zip(ci.tolist(), cj.tolist()) if n_match[pidx[(i, j)]] >= 4]
+    cj, ci = np.nonzero(cand.T)  # column-major walk of the candidate matrix, like the reference's find
+    pw = cj * (cj - 1) // 2 + ci  # position of pair (i, j), i < j, in the j-major pair order
+    work = pw[n_match[pw] >= 4].tolist()
     mine = [p for k, p in enumerate(work) if k % ws == rank]
     times.add("im_select", t0)
     t0 = time.perf_counter()
-    rec = torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev)  # model (9), found, inliers
+    # model (9), found, inliers per candidate pair: a device tensor only when it has to be all-reduced
+    rec = (torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev) if ws > 1
+           else np.zeros((max(len(work), 1), 11), np.float64))
     if mine:
         cnts = [int(n_match[p]) for p in mine]
         wptr = np.concatenate([[0], np.cumsum(cnts)]).astype(np.int64)
@@ -399,25 +401,41 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
         times.add("im_ransac", t0)
         t0 = time.perf_counter()
         wk = {p: k for k, p in enumerate(work)}
-        rows = torch.tensor([wk[p] for p in mine], dtype=torch.int64, device=dev)
         vals = np.concatenate([models.reshape(len(mine), 9), found.reshape(-1, 1).astype(np.float64),
                                ninl.reshape(-1, 1).astype(np.float64)], axis=1)
-        rec[rows] = torch.from_numpy(vals).to(dev)
+        if ws > 1:
+            rows = torch.tensor([wk[p] for p in mine], dtype=torch.int64, device=dev)
+            rec[rows] = torch.from_numpy(vals).to(dev)
+        else:
+            rec[[wk[p] for p in mine]] = vals
     if ws > 1:
         _all_reduce(rec)  # every row is written by exactly one rank, zero elsewhere
-    rec = rec.cpu().numpy()
+        rec = rec.cpu().numpy()
     pairs, models_l, num_matches = [], [], np.zeros((n, n))
-    for k, p in enumerate(work):
-        nf = int(n_match[p])
-        ni = int(rec[k, 10]) if rec[k, 9] else 0
-        if ni > 8 + 0.3 * nf:  # imageMatching.m:150
-            i, j = order[p]
+    if work:
+        wk_ = np.asarray(work, np.int64)
+        nf = n_match[wk_]
+        ni = np.where(rec[: len(work), 9] != 0, rec[: len(work), 10].astype(np.int64), 0)
+        for k in np.nonzero(ni > 8 + 0.3 * nf)[0].tolist():  # imageMatching.m:150
+            i, j = order[work[k]]
             pairs.append((i, j))
             models_l.append(rec[k, :9].reshape(3, 3).copy())
-            num_matches[i, j] = ni
+            num_matches[i, j] = ni[k]
     times.add("im_merge", t0)
     return {"counts": counts, "kps_t": kps_t, "pairs": pairs, "models": models_l, "num_matches": num_matches,
             "n_match": n_match, "order": order}
+
+
+_PAIR_INDEX = {}
+
+
+def _pair_index_arrays(n):
+    """(i, j) of every pair of fm.pair_order(n) as two index arrays (pair (i, j), i < j, sits at j (j - 1) / 2 + i)."""
+    if n not in _PAIR_INDEX:
+        jj = np.repeat(np.arange(1, n), np.arange(1, n))
+        ii = np.concatenate([np.arange(j) for j in range(1, n)]) if n > 1 else np.zeros(0, np.int64)
+        _PAIR_INDEX[n] = (ii.astype(np.int64), jj.astype(np.int64))
+    return _PAIR_INDEX[n]
 
 
 def _sync_lib():
