@@ -53,7 +53,14 @@ def _sync():
 _SIFT_POOL = None
 
 
-def sift_many(input, images, workers=8, ready=None):
+# Host threads / HIP streams of the per-image feature extraction.  Measured on the 64 x 4K scene on several boxes:
+# 4, 5, 10, 11, 12, 14 threads give 88-93 ms, 10 the best or tied everywhere; 7-9 threads read 100 ms on some boxes and
+# 92 on others (reproducibly per box; the HIP runtime maps streams onto 8 hardware queues), 12 costs the end-to-end
+# step's uploads 14 ms.
+SIFT_WORKERS_DEFAULT = 10
+
+
+def sift_many(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
     """getFeaturePoints for many images — the reference runs this loop as a parfor (loadImages.m:82-99).
     Here a few host threads each drive their own HIP stream (the C ABI is thread-safe with per-thread streams
     and workspaces), so the small-octave launches and the count read-backs of one image overlap with the
@@ -82,7 +89,7 @@ def sift_many(input, images, workers=8, ready=None):
     return [f.result() for f in sift_submit(input, images, workers, ready)]
 
 
-def sift_submit(input, images, workers=8, ready=None):
+def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
     """The asynchronous form of sift_many: one future per image, submitted in input order to the worker pool, so that
     a caller can start matching the first images while the later ones are still being extracted (parallel._match_pass).
     Each future resolves to (descriptors, keypoints) once that worker's stream has finished the image."""

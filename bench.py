@@ -350,7 +350,7 @@ def main():
             roof("sift_blur", "blur_kernel<R> (separable Gaussian through LDS)", "hbm", 574.0 * npix_rank0,
                  HBM_PEAK_GBS, "GB/s", "574 B per input pixel is SURVEY 8(d)'s materialised-pyramid model (G and DoG "
                  "written and re-read); the build no longer stores DoG planes, so its real traffic is lower",
-                 streams=int(os.environ.get("APS_SIFT_WORKERS", "8"))),
+                 streams=int(os.environ.get("APS_SIFT_WORKERS", str(pl.SIFT_WORKERS_DEFAULT)))),
             roof(("render_pyr_down", "render_collapse"),
                  "multiband chain, all tiles level-major (rw_down_kernel x levels, rw_up_kernel x levels incl. paint)", "hbm",
                  64.0 * a_cov + 32.0 * a_pano, HBM_PEAK_GBS, "GB/s"),
