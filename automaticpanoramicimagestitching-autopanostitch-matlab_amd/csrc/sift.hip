@@ -466,15 +466,19 @@ __device__ bool adjust_extremum(const OctaveDesc& od, int nl, int o, int layer, 
     return true;
 }
 
-// 64 x 12 pixel tile per 256-thread workgroup; all nl+2 DoG planes of the tile (plus a 1-pixel halo) are staged
-// in LDS once, so every plane is read from HBM ~1.3x instead of 27x per layer through the caches.  12 rows: the
-// haloed tile is 14 x 18 = 252 sixteen-byte pieces, ONE per thread - every thread issues its seven plane loads once
-// and the workgroup pays one memory round trip (16 rows needed a second, quarter-filled round).
+// 128 x 8 pixel tile per 256-thread workgroup; all nl+2 DoG planes of the tile (plus a 1-pixel halo) are staged
+// in LDS once, so every plane is read from HBM ~1.3x instead of 27x per layer through the caches.  Tile shapes
+// measured on one 4K view (us per view, all octaves): 32x24 573, 64x16 437, 64x12 420, 128x4 454, 128x8 405, 256x4 403,
+// 128x12 416, 128x16 523, 256x8 535 - the rows a workgroup reads should be long, the LDS tile small enough for several
+// workgroups per CU.
 #ifndef APS_EH
-#define APS_EH 12
+#define APS_EH 8
 #endif
-constexpr int kEW = 64, kEH = APS_EH, kERows = kEH / 4;  // rows of a column owned by one thread
-static_assert(kEH % 4 == 0, "four row groups");
+#ifndef APS_EW
+#define APS_EW 128
+#endif
+constexpr int kEW = APS_EW, kEH = APS_EH, kEGroups = 256 / kEW, kERows = kEH / kEGroups;  // rows of a column owned by one thread
+static_assert(kEH % kEGroups == 0 && 256 % kEW == 0, "row groups");
 
 template <int nl>  // NumLayersInOctave: nl + 3 Gaussian planes, nl + 2 DoG planes (sizes the LDS tile and the loops)
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int o, float thr,
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDesc od, int o, floa
     // horizontal 3-max/3-min of the kERows + 2 rows it touches, then the vertical 3-max/3-min per owned pixel = the
     // 3x3 window extrema (centre included).  A pixel is a 26-neighbour maximum iff val >= the max of the three
     // planes' window maxima (val itself is inside its own window, which changes nothing).
-    const int lx = tid & 63, g = tid >> 6;
+    const int lx = tid % kEW, g = tid / kEW;
     const int c = x0 + lx;
     // Candidates are collected per workgroup in LDS and appended with ONE global atomic: at the octaves where the
     // texture lives, tens of thousands of single-address atomics serialised in L2 (the 2 MPix octave took 110 us against
