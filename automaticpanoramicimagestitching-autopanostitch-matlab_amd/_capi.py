@@ -20,6 +20,7 @@ APS_OK, APS_E_ARG, APS_E_DIM, APS_E_TYPE, APS_E_OOM, APS_E_DEVICE, APS_E_INTERNA
 APS_COLMAJOR, APS_ROWMAJOR = 0, 1
 APS_ROBUST_RANSAC, APS_ROBUST_MLESAC = 0, 1
 APS_RESIZE_BILINEAR, APS_RESIZE_BICUBIC = 0, 1
+APS_WARP_NEAREST, APS_WARP_BILINEAR, APS_WARP_BICUBIC = 0, 1, 2
 APS_TFORM_PROJECTIVE = 0
 APS_PROJ_CYLINDRICAL, APS_PROJ_SPHERICAL, APS_PROJ_PLANAR, APS_PROJ_STEREOGRAPHIC = 0, 1, 2, 3
 APS_BLEND_NONE, APS_BLEND_LINEAR, APS_BLEND_MULTIBAND = 0, 1, 2
@@ -81,6 +82,8 @@ _SIGNATURES = {
     "aps_last_error": [],
     "aps_device_count": [],
     "aps_set_device": [_i],
+    "aps_set_thread_device": [_i],
+    "aps_get_device": [],
     "aps_set_stream": [_vp],
     "aps_synchronize": [],
     "aps_release_workspace": [],
@@ -127,6 +130,8 @@ _SIGNATURES = {
     "aps_linear_blend": [_vp, _vp, _i, _i, _i, _vp],
     "aps_image_warp_h_u8": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, C.c_uint8, _vp],
     "aps_image_warp_h_f32": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _vp],
+    "aps_image_warp_u8": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, C.c_uint8, _i, _vp],
+    "aps_image_warp_f32": [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _i, _vp],
     "aps_synth_view": [_vp, _vp, _i, _i, C.c_uint, _f, _f, _vp],
     "aps_sift_extract": [_vp, _i, _i, _i, _i, C.POINTER(aps_sift_params), _vp, _i, _i64, _vp, _i64,
                          _vp, _i64, C.POINTER(_i64)],

@@ -87,6 +87,25 @@ struct Ctx {
 // so far and returns them; join() makes stream() wait for everything queued on them since.
 std::vector<hipStream_t>& aux_fork(int n);
 void aux_join(int n);
+// Scope of a fork/join section.  join() is the normal exit; when the scope is left by an exception instead, the
+// auxiliary streams are drained on the host before the caller's workspace blocks (which their kernels still use) go
+// back to the pool.
+struct AuxScope {
+    int n;
+    bool joined = false;
+    std::vector<hipStream_t>& streams;
+    explicit AuxScope(int n_) : n(n_), streams(aux_fork(n_)) {}
+    AuxScope(const AuxScope&) = delete;
+    AuxScope& operator=(const AuxScope&) = delete;
+    void join() {
+        joined = true;
+        aux_join(n);
+    }
+    ~AuxScope() {
+        if (!joined)
+            for (int i = 0; i < n && i < (int)streams.size(); ++i) (void)hipStreamSynchronize(streams[i]);
+    }
+};
 
 // Makes sure a gfx950 device is selected for this thread and returns the context.
 Ctx& ctx();

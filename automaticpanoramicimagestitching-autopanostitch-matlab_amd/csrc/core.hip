@@ -58,6 +58,13 @@ static void bind_device(Ctx& c, int dev) {
         if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
+        // the auxiliary streams of aux_fork() and their events belong to the old device as well
+        for (auto st : c.aux) (void)hipStreamDestroy(st);
+        for (auto ev : c.aux_ev) (void)hipEventDestroy(ev);
+        if (c.fork_ev) (void)hipEventDestroy(c.fork_ev);
+        c.aux.clear();
+        c.aux_ev.clear();
+        c.fork_ev = nullptr;
         c.own_stream = nullptr;
         c.ev0 = c.ev1 = nullptr;
         c.device = dev;
@@ -236,6 +243,16 @@ int aps_set_device(int device) {
         bind_device(g_ctx, device);
         g_default_device.store(device, std::memory_order_release);
     });
+}
+
+int aps_set_thread_device(int device) {
+    return guarded([&] { bind_device(g_ctx, device); });
+}
+
+int aps_get_device(void) {
+    int dev = -1;
+    const int rc = guarded([&] { dev = ctx().device; });
+    return rc == APS_OK ? dev : -1;
 }
 
 int aps_set_stream(void* hip_stream) {

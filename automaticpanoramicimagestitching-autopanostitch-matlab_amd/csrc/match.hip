@@ -2427,14 +2427,15 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     {  // the sets are independent chains of small launches: eight of them side by side
         constexpr int kPrepStreams = 8;
         APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)16 * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
-        std::vector<hipStream_t>& aux = aux_fork(kPrepStreams);
+        AuxScope fork(kPrepStreams);
+        std::vector<hipStream_t>& aux = fork.streams;
         Prof prof("match_prep");
         int k = 0;
         for (int i = 0; i < n_img; ++i) {
             if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i);
             if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i + 8);
         }
-        aux_join(kPrepStreams);
+        fork.join();
     }
     const auto T1 = t_now();
     std::vector<MatchJob> jobs;

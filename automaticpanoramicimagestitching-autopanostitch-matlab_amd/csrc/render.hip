@@ -481,7 +481,16 @@ struct HWarp {
     double det;
 };
 
-template <class T>
+// bicubicKernel of imageWarp.m:275-301 (Keys, a = -0.5), |x|^2 and |x|^3 as products, terms left to right
+__device__ __forceinline__ double warp_cubic(double x) {
+    const double a = fabs(x), a2 = a * a, a3 = a2 * a;
+    if (a <= 1.0) return (1.5 * a3 - 2.5 * a2) + 1.0;
+    if (a <= 2.0) return ((-0.5 * a3 + 2.5 * a2) - 4.0 * a) + 2.0;
+    return 0.0;
+}
+
+// METHOD: APS_WARP_NEAREST (imageWarp.m:109-123), APS_WARP_BILINEAR (:125-168), APS_WARP_BICUBIC (:170-264)
+template <class T, int METHOD>
 __global__ void image_warp_h_kernel(const T* __restrict__ in, int in_h, int in_w, int C, HWarp hw,
                                     int out_h, int out_w, double x0, double y0, double sx, double sy,
                                     T fill, T* __restrict__ out) {
@@ -495,7 +504,51 @@ __global__ void image_warp_h_kernel(const T* __restrict__ in, int in_h, int in_w
     double wv = fabs(s2) > 1e-12 ? fabs(s2) : 1e-12;
     wv = s2 < 0 ? -wv : (s2 > 0 ? wv : 0.0);
     const double srcx = s0 / wv, srcy = s1 / wv;
+    if (METHOD == APS_WARP_NEAREST) {
+        const double rx = round(srcx), ry = round(srcy);  // MATLAB round: half away from zero
+        const bool valid = rx >= 1 && rx <= in_w && ry >= 1 && ry <= in_h;
+        for (int c = 0; c < C; ++c)
+            out[((size_t)y * out_w + x) * C + c] = valid ? in[((size_t)((int)ry - 1) * in_w + ((int)rx - 1)) * C + c] : fill;
+        return;
+    }
     const double fx1 = floor(srcx), fy1 = floor(srcy);
+    if (METHOD == APS_WARP_BICUBIC) {
+        const bool valid = fx1 >= 2 && fx1 <= in_w - 2 && fy1 >= 2 && fy1 <= in_h - 2;  // :177
+        double wxk[4], wyk[4];
+        if (valid) {
+            const double dx = srcx - fx1, dy = srcy - fy1;
+#pragma unroll
+            for (int ii = -1; ii <= 2; ++ii) {
+                wxk[ii + 1] = warp_cubic((double)ii - dx);
+                wyk[ii + 1] = warp_cubic((double)ii - dy);
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            T o = fill;
+            if (valid) {
+                const int xb = (int)fx1, yb = (int)fy1;
+                double v = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {  // x direction first, taps in ascending order from 0 (:236-243), then y (:246)
+                    double xi = 0.0;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        xi = xi + (double)in[((size_t)(yb + jj - 2) * in_w + (xb + ii - 2)) * C + c] * wxk[ii];
+                    v = v + xi * wyk[jj];
+                }
+                if (sizeof(T) == 1) {
+                    double rr = round(v);
+                    rr = rr < 0 ? 0 : (rr > 255 ? 255 : rr);
+                    o = (T)rr;
+                } else {
+                    v = v < 0 ? 0 : (v > 1.0 ? 1.0 : v);  // max(0, min(maxVal, .)) with maxVal = 1 for float images (:216,:254)
+                    o = (T)v;
+                }
+            }
+            out[((size_t)y * out_w + x) * C + c] = o;
+        }
+        return;
+    }
     const bool valid = fx1 >= 1 && fx1 + 1 <= in_w && fy1 >= 1 && fy1 + 1 <= in_h;
     for (int c = 0; c < C; ++c) {
         T o = fill;
@@ -1652,17 +1705,24 @@ static void make_hwarp(const double* H, HWarp& hw) {
 
 template <class T>
 static int image_warp_impl(const T* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w,
-                           double x0, double y0, double sx, double sy, T fill, T* out) {
+                           double x0, double y0, double sx, double sy, T fill, int method, T* out) {
     return guarded([&] {
         APS_REQUIRE(in && H && out, APS_E_ARG, "NULL argument");
         APS_REQUIRE(in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0 && c >= 1 && c <= 4, APS_E_DIM, "bad dimensions");
+        APS_REQUIRE(method == APS_WARP_NEAREST || method == APS_WARP_BILINEAR || method == APS_WARP_BICUBIC, APS_E_ARG,
+                    "unknown interpolation method");
         ctx();
         HWarp hw;
         make_hwarp(H, hw);
         In<T> di(in, (size_t)in_h * in_w * c);
         Out<T> oo(out, (size_t)out_h * out_w * c);
-        image_warp_h_kernel<T><<<dim3(cdiv(out_w, 256), out_h), 256, 0, stream()>>>(
-            di, in_h, in_w, c, hw, out_h, out_w, x0, y0, sx, sy, fill, oo);
+        const dim3 grid(cdiv(out_w, 256), out_h);
+        if (method == APS_WARP_NEAREST)
+            image_warp_h_kernel<T, APS_WARP_NEAREST><<<grid, 256, 0, stream()>>>(di, in_h, in_w, c, hw, out_h, out_w, x0, y0, sx, sy, fill, oo);
+        else if (method == APS_WARP_BICUBIC)
+            image_warp_h_kernel<T, APS_WARP_BICUBIC><<<grid, 256, 0, stream()>>>(di, in_h, in_w, c, hw, out_h, out_w, x0, y0, sx, sy, fill, oo);
+        else
+            image_warp_h_kernel<T, APS_WARP_BILINEAR><<<grid, 256, 0, stream()>>>(di, in_h, in_w, c, hw, out_h, out_w, x0, y0, sx, sy, fill, oo);
         check_launch("image_warp_h_kernel");
         oo.commit();
         APS_HIP(hipStreamSynchronize(stream()));
@@ -1674,12 +1734,22 @@ extern "C" {
 int aps_image_warp_h_u8(const uint8_t* in, int in_h, int in_w, int c, const double* H, int out_h,
                         int out_w, double x0, double y0, double sx, double sy, uint8_t fill,
                         uint8_t* out) {
-    return image_warp_impl<uint8_t>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, out);
+    return image_warp_impl<uint8_t>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, APS_WARP_BILINEAR, out);
+}
+
+int aps_image_warp_u8(const uint8_t* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w, double x0,
+                      double y0, double sx, double sy, uint8_t fill, int method, uint8_t* out) {
+    return image_warp_impl<uint8_t>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, method, out);
+}
+
+int aps_image_warp_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w, double x0,
+                       double y0, double sx, double sy, float fill, int method, float* out) {
+    return image_warp_impl<float>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, method, out);
 }
 
 int aps_image_warp_h_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h,
                          int out_w, double x0, double y0, double sx, double sy, float fill, float* out) {
-    return image_warp_impl<float>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, out);
+    return image_warp_impl<float>(in, in_h, in_w, c, H, out_h, out_w, x0, y0, sx, sy, fill, APS_WARP_BILINEAR, out);
 }
 
 }  // extern "C"

@@ -37,9 +37,12 @@ def outputLimitsScratch(tform, xLimitsIn, yLimitsIn):
 
 
 def imageWarp(image, tform, outputView, method="bilinear", fillValue=0):
-    """warped = imageWarp(image, tform, outputView, options) (imageWarp.m:1-273), 'bilinear' on the device."""
-    if str(method).lower() != "bilinear":
-        raise NotImplementedError("only the reference's default 'bilinear' method is built on the device")
+    """warped = imageWarp(image, tform, outputView, options) (imageWarp.m:1-273) on the device: options.method
+    'nearest' (:109-123), 'bilinear' (:125-168, the default) or 'bicubic' (:170-264); uint8 images stay uint8, every
+    other class is interpolated as single."""
+    m = {"nearest": _capi.APS_WARP_NEAREST, "bilinear": _capi.APS_WARP_BILINEAR, "bicubic": _capi.APS_WARP_BICUBIC}.get(str(method).lower())
+    if m is None:
+        raise ValueError(f"unknown interpolation method '{method}'")  # (the reference's switch silently leaves the fill value)
     img = np.asarray(image)
     squeeze = img.ndim == 2
     if squeeze:
@@ -52,29 +55,42 @@ def imageWarp(image, tform, outputView, method="bilinear", fillValue=0):
     if img.dtype == np.uint8:
         src = np.ascontiguousarray(img)
         out = np.zeros((oh, ow, c), np.uint8)
-        check(lib.aps_image_warp_h_u8(ptr(src), img.shape[0], img.shape[1], c, ptr(H), oh, ow, x0, y0, sx, sy,
-                                      int(fillValue), ptr(out)))
+        check(lib.aps_image_warp_u8(ptr(src), img.shape[0], img.shape[1], c, ptr(H), oh, ow, x0, y0, sx, sy,
+                                    int(fillValue), m, ptr(out)))
     else:
         src = np.ascontiguousarray(img, np.float32)
         out = np.zeros((oh, ow, c), np.float32)
-        check(lib.aps_image_warp_h_f32(ptr(src), img.shape[0], img.shape[1], c, ptr(H), oh, ow, x0, y0, sx, sy,
-                                       float(fillValue), ptr(out)))
+        check(lib.aps_image_warp_f32(ptr(src), img.shape[0], img.shape[1], c, ptr(H), oh, ow, x0, y0, sx, sy,
+                                     float(fillValue), m, ptr(out)))
         out = out.astype(img.dtype) if img.dtype != np.float32 else out
     return out[..., 0] if squeeze else out
 
 
 def imresize(I, scale_or_size, method="bicubic"):
     """J = imresize(I, s, method) / imresize(I, [oh ow], method) for uint8 images on the device (toolbox semantics
-    as restated in oracle/render_oracle.c).  The scalar form gives ceil(s * size) with scale s in both dimensions."""
+    as restated in oracle/render_oracle.c).  The scalar form gives ceil(s * size) with scale s in both dimensions.
+    A torch CUDA tensor stays resident: the result is a CUDA tensor and nothing visits the host."""
     import math
 
-    a = np.ascontiguousarray(I)
-    if a.dtype != np.uint8:
-        raise TypeError("uint8 images only")
-    sq = a.ndim == 2
-    if sq:
-        a = a[..., None]
-    h, w, c = a.shape
+    dev = _capi.is_torch(I) and I.is_cuda
+    if dev:
+        import torch
+
+        a = I.contiguous()
+        if a.dtype != torch.uint8:
+            raise TypeError("uint8 images only")
+        sq = a.dim() == 2
+        if sq:
+            a = a[..., None]
+        h, w, c = (int(v) for v in a.shape)
+    else:
+        a = np.ascontiguousarray(I)
+        if a.dtype != np.uint8:
+            raise TypeError("uint8 images only")
+        sq = a.ndim == 2
+        if sq:
+            a = a[..., None]
+        h, w, c = a.shape
     if np.isscalar(scale_or_size):
         s = float(scale_or_size)
         oh, ow, sr, sc = int(math.ceil(h * s)), int(math.ceil(w * s)), s, s
@@ -82,7 +98,11 @@ def imresize(I, scale_or_size, method="bicubic"):
         oh, ow = int(scale_or_size[0]), int(scale_or_size[1])
         sr, sc = oh / h, ow / w
     m = {"bicubic": _capi.APS_RESIZE_BICUBIC, "bilinear": _capi.APS_RESIZE_BILINEAR}[str(method).lower()]
-    out = np.zeros((oh, ow, c), np.uint8)
+    if dev:
+        out = torch.empty((oh, ow, c), dtype=torch.uint8, device=a.device)
+        torch.cuda.current_stream().synchronize()  # the input came from torch's stream; the library runs on its own
+    else:
+        out = np.zeros((oh, ow, c), np.uint8)
     check(lib.aps_imresize_u8(ptr(a), h, w, c, _capi.APS_IMG_U8_HWC, oh, ow, sr, sc, m, ptr(out)))
     return out[..., 0] if sq else out
 

@@ -490,11 +490,26 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
             szs[k, 0], szs[k, 1] = int(im_.shape[0]), int(im_.shape[1])
         if ws > 1:
             _all_reduce(szs)
-        local_images = pl.resize_per_component(input, local_originals, labels, szs.cpu().tolist())
+        first_hw = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+        for k, im_ in local_images.items():
+            first_hw[k, 0], first_hw[k, 1] = int(im_.shape[0]), int(im_.shape[1])
+        local_images = pl.resize_per_component(input, local_originals, labels, szs.cpu().tolist())  # resident: no host hop
+        new_hw = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+        for k, im_ in local_images.items():
+            new_hw[k, 0], new_hw[k, 1] = int(im_.shape[0]), int(im_.shape[1])
+        if ws > 1:
+            both_hw = torch.cat([first_hw, new_hw], 1)
+            _all_reduce(both_hw)
+            first_hw, new_hw = both_hw[:, :2], both_hw[:, 2:]
+        if Ks is not None:  # the intrinsics follow the per-component resize (pipeline.rescale_K)
+            fh, nh = first_hw.cpu().tolist(), new_hw.cpu().tolist()
+            Ks = [pl.rescale_K(K, fh[k], nh[k]) for k, K in enumerate(Ks)]
         img_gather.wait()
         img_gather = ImageGather(local_images, n, dev)
         times.add("exchange", t0)
+        first_counts = res["counts"]
         res = _match_pass(input, local_images, n, seed, times, dev)
+        res["second_pass"], res["counts_first_pass"] = True, first_counts
     t0 = time.perf_counter()
     comps = pl.recognize_panoramas(n, res["pairs"], res["models"], res["num_matches"], Ks, labels, cameras)
     times.add("host_cameras", t0)
@@ -566,7 +581,8 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     info = {"times": dict(times), "n_features": res["counts"], "n_pairs_verified": len(res["pairs"]),
             "n_components": int(ncomp), "panorama_shape": tuple(int(v) for v in pano.shape) if pano is not None else None,
             "members": comps[main]["members"] if comps else [], "cameras": _scatter_cameras(comps, n),
-            "pairs": res["pairs"], "models": res["models"], "components": comps, "panoramas": panos, "labels": labels}
+            "pairs": res["pairs"], "models": res["models"], "components": comps, "panoramas": panos, "labels": labels,
+            "second_pass": bool(res.get("second_pass", False)), "n_features_first_pass": res.get("counts_first_pass")}
     return pano, info
 
 

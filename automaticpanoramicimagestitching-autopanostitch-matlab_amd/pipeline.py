@@ -10,6 +10,7 @@ host-side graph logic exactly as in the reference).
 """
 from __future__ import annotations
 
+import threading
 import time
 
 import numpy as np
@@ -89,6 +90,18 @@ def sift_many(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
     return [f.result() for f in sift_submit(input, images, workers, ready)]
 
 
+_INIT_LOCK = threading.Lock()
+
+
+def _init_worker(device):
+    """Pool initializer: each worker creates its library context (device binding, stream, events) on its own, one
+    worker after the other - ten threads racing through their first HIP calls at once is what rocprofv3 was seen to
+    crash under."""
+    with _INIT_LOCK:
+        _capi.check(_capi.lib.aps_set_thread_device(int(device)))
+        _capi.check(_capi.lib.aps_synchronize())
+
+
 def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
     """The asynchronous form of sift_many: one future per image, submitted in input order to the worker pool, so that
     a caller can start matching the first images while the later ones are still being extracted (parallel._match_pass).
@@ -103,10 +116,15 @@ def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
     if dev and ready is None:
         torch.cuda.synchronize()  # the images were produced on torch's stream; worker streams must see them
     if _SIFT_POOL is None:
-        _SIFT_POOL = ThreadPoolExecutor(max_workers=workers)
+        _SIFT_POOL = ThreadPoolExecutor(max_workers=workers, initializer=_init_worker, initargs=(_capi.lib.aps_get_device(),))
     pool = _SIFT_POOL
 
+    # every worker binds the device of the image it is handed (or the submitting thread's device for host images)
+    # instead of inheriting the process-wide default, which is whatever device ANY thread selected last
+    here = _capi.lib.aps_get_device()
+
     def work(k):
+        _capi.check(_capi.lib.aps_set_thread_device(images[k].device.index if dev else here))
         if ready is not None:
             ready[k].synchronize()
         r = fm.sift_extract(input, images[k], device_out=dev)
@@ -337,19 +355,24 @@ def resize_per_component(input, local_originals, labels, all_sizes):
         for k, (h1, w1, sc) in zip(idxs, st1):
             if k not in local_originals:
                 continue
-            img = local_originals[k]
-            is_t = _capi.is_torch(img)
-            a = img.cpu().numpy() if is_t else np.asarray(img)
+            a = local_originals[k]  # numpy stays numpy, a CUDA tensor stays resident (aps_imresize_u8 takes either)
             if sc < 1:
                 a = ip.imresize(a, sc, "bicubic")
-            if common is not None:
+            if common is not None:  # every image of the set, also those already at that size (resizeImagesToLimits.m:100-104)
                 a = ip.imresize(a, common, "bicubic")
-            if is_t:
-                import torch
-
-                a = torch.from_numpy(np.ascontiguousarray(a)).to(img.device)
             out[k] = a
     return out
+
+
+def rescale_K(K, old_hw, new_hw):
+    """Intrinsics of an image after imresize from old_hw to new_hw = (rows, cols): pixel x scales with the column count,
+    y with the row count (imresize may be anisotropic when a set is brought to a common size).  The reference has no
+    such step - its cameras come out of the bundle adjustment on the resized images; this serves the host stand-in,
+    which takes the intrinsics as an input."""
+    sy, sx = new_hw[0] / old_hw[0], new_hw[1] / old_hw[1]
+    if sx == 1.0 and sy == 1.0:
+        return np.asarray(K, np.float64)
+    return np.diag([sx, sy, 1.0]) @ np.asarray(K, np.float64)
 
 
 def imageMatchingPanoramaConComps(input, images_original, images_processed, descs, kps, seed=0, times=None):
@@ -357,16 +380,17 @@ def imageMatchingPanoramaConComps(input, images_original, images_processed, desc
     imageMatchingPanoramaConComps(...) (imageMatchingPanoramaConComps.m:39-91) in CSR form: first-pass matching and
     verification, connected components, and - with input.resizeImage and input.resizeImagePanoramaCluster set and
     more than one component - the second pass on images resized per component.
-    Returns (result dict of match_and_verify, images_processed, descs, kps, ncomp, labels)."""
+    Returns (result dict of match_and_verify, images_processed, descs, kps, ncomp, labels, second_pass: bool)."""
     res = match_and_verify(input, descs, kps, seed, times)
     ncomp, labels = connected_components(res["numMatches"])
-    if int(input.get("resizeImage", 0)) == 1 and int(input.get("resizeImagePanoramaCluster", 0)) == 1 and ncomp > 1:
+    second = int(input.get("resizeImage", 0)) == 1 and int(input.get("resizeImagePanoramaCluster", 0)) == 1 and ncomp > 1
+    if second:
         sizes = [(int(im_.shape[0]), int(im_.shape[1])) for im_ in images_original]
         resized = resize_per_component(input, dict(enumerate(images_original)), labels, sizes)
         images_processed = [resized[k] for k in range(len(images_original))]
         descs, kps = extract_features(input, images_processed, times)
         res = match_and_verify(input, descs, kps, seed, times)
-    return res, images_processed, descs, kps, ncomp, labels
+    return res, images_processed, descs, kps, ncomp, labels, second
 
 
 def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, device_out=True, profile=False,
@@ -379,9 +403,13 @@ def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, devi
     times = StageTimes()
     n = len(images)
     descs, kps = extract_features(input, images, times)
-    res, images, descs, kps, ncomp, labels = imageMatchingPanoramaConComps(
+    first_hw = [(int(im_.shape[0]), int(im_.shape[1])) for im_ in images]
+    first_counts = [len(k) for k in kps]
+    res, images, descs, kps, ncomp, labels, second = imageMatchingPanoramaConComps(
         input, images if images_original is None else images_original, images, descs, kps, seed, times)
     sizes = [(int(im_.shape[0]), int(im_.shape[1]), 3) for im_ in images]
+    if second and Ks is not None:  # the intrinsics follow the per-component resize
+        Ks = [rescale_K(K, first_hw[k], sizes[k][:2]) for k, K in enumerate(Ks)]
     t0 = time.perf_counter()
     comps = recognize_panoramas(n, res["pairs"], res["models"], res["numMatches"], Ks, labels, cameras)
     times.add("host_cameras", t0)
@@ -403,5 +431,6 @@ def stitch(input, images, Ks=None, cameras=None, tile=(2048, 2048), seed=0, devi
             cams[k] = cam
     info = {"times": dict(times), "n_features": [len(k) for k in kps], "n_pairs_verified": len(res["pairs"]),
             "n_components": int(ncomp), "putative": res["putative"], "result": res, "cameras": cams,
-            "components": comps, "labels": labels}
+            "components": comps, "labels": labels, "second_pass": bool(second), "n_features_first_pass": first_counts,
+            "images_processed": images}
     return panos, info

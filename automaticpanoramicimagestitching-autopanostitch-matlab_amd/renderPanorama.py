@@ -485,7 +485,10 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
             # disjoint canvas rectangles.  A few host threads each drive their own stream over an interleaved
             # share of this rank's tiles (t % (step*workers) == first + step*k), so the many small pyramid
             # launches of one tile overlap with another tile's; every tile's arithmetic is unchanged.
+            here = lib.aps_get_device()
+
             def work(k):
+                check(lib.aps_set_thread_device(here))  # not the process-wide default another thread may have changed
                 check(lib.aps_render_tiles(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
                                            first + step * k, step * workers, ptr(pano), ptr(cov)))
                 check(lib.aps_synchronize())  # this thread's stream

@@ -63,6 +63,12 @@ int aps_device_count(void);
  * never called aps_set_device start on (worker pools, parpool('Threads') workers); before any call the default is env
  * APS_DEVICE, else 0. */
 int aps_set_device(int device);
+/* Select the device for the calling thread ONLY (the process-wide default is left alone): what a worker thread of a
+ * process that drives several GPUs calls before its first entry point, so that it does not inherit whichever device
+ * another thread selected last. */
+int aps_set_thread_device(int device);
+/* The device the calling thread is bound to (binding it to the default first if it has none); < 0 on error. */
+int aps_get_device(void);
 /* Run the calling thread's work on an existing HIP stream (e.g. torch's current stream);
  * NULL restores the library's own per-thread stream. */
 int aps_set_stream(void* hip_stream);
@@ -397,6 +403,14 @@ int aps_image_warp_h_u8(const uint8_t* in, int in_h, int in_w, int c, const doub
 int aps_image_warp_h_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h,
                          int out_w, double x0, double y0, double sx, double sy, float fill,
                          float* out);
+/* The same with options.method: 'nearest' (imageWarp.m:109-123: round(src), valid inside [1,w] x [1,h]), 'bilinear'
+ * (:125-168) or 'bicubic' (:170-264: Keys kernel bicubicKernel :275-301 on the 4 x 4 taps around floor(src), valid for
+ * 2 <= floor(src) <= size - 2, x direction first, result clamped to [0, 255] and rounded for uint8, to [0, 1] for f32). */
+enum { APS_WARP_NEAREST = 0, APS_WARP_BILINEAR = 1, APS_WARP_BICUBIC = 2 };
+int aps_image_warp_u8(const uint8_t* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w, double x0,
+                      double y0, double sx, double sy, uint8_t fill, int method, uint8_t* out);
+int aps_image_warp_f32(const float* in, int in_h, int in_w, int c, const double* H, int out_h, int out_w, double x0,
+                       double y0, double sx, double sy, float fill, int method, float* out);
 
 /* ============================================================================================
  * (4) SIFT — PP/featureMatching/getFeaturePoints.m:36-40,71-74

@@ -366,11 +366,12 @@ static void cmd_ba(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                              mxGetScalar(prhs[6]) != 0, mxGetPr(plhs[0])));
 }
 
-// warped = aps_mex('image_warp', image (uint8 or single, h x w x c), H (3x3 double), [oh ow], x0, y0, sx, sy, fillValue)
-// imageWarp.m:39-168 'bilinear'.  MATLAB arrays are planar column-major; the C ABI wants row-major interleaved.
+// warped = aps_mex('image_warp', image (uint8 or single, h x w x c), H (3x3 double), [oh ow], x0, y0, sx, sy, fillValue
+//                  [, method: 0 nearest | 1 bilinear (default) | 2 bicubic])
+// imageWarp.m:39-264.  MATLAB arrays are planar column-major; the C ABI wants row-major interleaved.
 template <class T>
 static mxArray* warp_typed(const mxArray* img, const double* H, int oh, int ow, double x0, double y0, double sx, double sy,
-                           double fill, mxClassID cls) {
+                           double fill, int method, mxClassID cls) {
     const mwSize* d = mxGetDimensions(img);
     const int h = (int)d[0], w = (int)d[1], c = mxGetNumberOfDimensions(img) > 2 ? (int)d[2] : 1;
     const T* src = (const T*)mxGetData(img);
@@ -379,9 +380,9 @@ static mxArray* warp_typed(const mxArray* img, const double* H, int oh, int ow, 
         for (int x = 0; x < w; ++x)
             for (int y = 0; y < h; ++y) in[((size_t)y * w + x) * c + q] = src[(size_t)q * h * w + (size_t)x * h + y];
     if (sizeof(T) == 1)
-        check(aps_image_warp_h_u8((const uint8_t*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (uint8_t)fill, (uint8_t*)out.data()));
+        check(aps_image_warp_u8((const uint8_t*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (uint8_t)fill, method, (uint8_t*)out.data()));
     else
-        check(aps_image_warp_h_f32((const float*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (float)fill, (float*)out.data()));
+        check(aps_image_warp_f32((const float*)in.data(), h, w, c, H, oh, ow, x0, y0, sx, sy, (float)fill, method, (float*)out.data()));
     const mwSize dims[3] = {(mwSize)oh, (mwSize)ow, (mwSize)c};
     mxArray* o = mxCreateNumericArray(c > 1 ? 3 : 2, dims, cls, mxREAL);
     T* dst = (T*)mxGetData(o);
@@ -392,16 +393,17 @@ static mxArray* warp_typed(const mxArray* img, const double* H, int oh, int ow, 
 }
 static void cmd_image_warp(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     (void)nlhs;
-    need(nrhs == 9 && (mxIsUint8(prhs[1]) || mxIsSingle(prhs[1])) && mxIsDouble(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 9,
-         "aps:type", "usage: image (uint8|single), H 3x3 double, [oh ow], x0, y0, sx, sy, fillValue");
+    need((nrhs == 9 || nrhs == 10) && (mxIsUint8(prhs[1]) || mxIsSingle(prhs[1])) && mxIsDouble(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 9,
+         "aps:type", "usage: image (uint8|single), H 3x3 double, [oh ow], x0, y0, sx, sy, fillValue[, method]");
     const double* sz = mxGetPr(prhs[3]);
     const int oh = (int)sz[0], ow = (int)sz[1];
     const double x0 = mxGetScalar(prhs[4]), y0 = mxGetScalar(prhs[5]), sx = mxGetScalar(prhs[6]), sy = mxGetScalar(prhs[7]);
     const double fill = mxGetScalar(prhs[8]);
+    const int method = nrhs == 10 ? (int)mxGetScalar(prhs[9]) : APS_WARP_BILINEAR;
     if (mxIsUint8(prhs[1]))
-        plhs[0] = warp_typed<uint8_t>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, mxUINT8_CLASS);
+        plhs[0] = warp_typed<uint8_t>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, method, mxUINT8_CLASS);
     else
-        plhs[0] = warp_typed<float>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, mxSINGLE_CLASS);
+        plhs[0] = warp_typed<float>(prhs[1], mxGetPr(prhs[2]), oh, ow, x0, y0, sx, sy, fill, method, mxSINGLE_CLASS);
 }
 
 // [rect, didCrop] = aps_mex('crop_nonzero_bbox', panorama uint8 h x w x 3, canvasWhite)   rect = [r1 r2 c1 c2]

@@ -5,7 +5,10 @@ function [tform, inlierIdx, isFound] = estimateTransformationMLESAC(points1, poi
     %   inliers run in aps_mex.
     if nargin < 4, input = struct(); end
     if ~strcmpi(transformationType, 'projective')
-        error('aps:type', 'only ''projective'' is built on the device');
+        % the other model classes run the reference's own host code (only the projective estimator is built on the device)
+        [tform, inlierIdx, isFound] = aps_call_shadowed('estimateTransformationMLESAC', mfilename('fullpath'), ...
+            points1, points2, transformationType, input);
+        return;
     end
     if size(points1, 1) ~= size(points2, 1)
         error('estimateTransformationMLESAC:PointCountMismatch', 'points1 and points2 must have the same number of rows.');

@@ -4,7 +4,11 @@ function [model, inliers, isFound] = estimateTransformationRANSAC(matchedPoints1
     %   the device as an explicit input; fitting, scoring, the adaptive stop and the refit run in aps_mex.
     if nargin < 4, input = struct('maxDistance', 2.0, 'inliersConfidence', 99.9, 'maxIter', 500); end
     if ~strcmpi(transformType, 'projective')
-        error('aps:type', 'only ''projective'' is built on the device');
+        % 'affine' | 'similarity' | 'rigid' | 'translation' (estimateTransformationRANSAC.m:227-439): the reference's own
+        % host code runs (inputs.m:74 defaults to 'projective'; only that estimator is built on the device)
+        [model, inliers, isFound] = aps_call_shadowed('estimateTransformationRANSAC', mfilename('fullpath'), ...
+            matchedPoints1, matchedPoints2, transformType, input);
+        return;
     end
     M = size(matchedPoints1, 1);
     if M < 4

@@ -279,6 +279,7 @@ _orc_linear_blend = _sig("orc_linear_blend", [_vp, _vp, _i, _i, _i, _vp])
 _orc_render = _sig("orc_render", [C.POINTER(orc_image), _i, C.POINTER(orc_canvas),
                                   C.POINTER(orc_render_opts), _vp, _vp])
 _orc_image_warp_h = _sig("orc_image_warp_h", [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _i, _vp])
+_orc_image_warp_h_m = _sig("orc_image_warp_h_m", [_vp, _i, _i, _i, _vp, _i, _i, _d, _d, _d, _d, _f, _i, _i, _vp])
 
 _MODE_IDS = {"cylindrical": 0, "spherical": 1, "equirectangular": 1, "planar": 2, "perspective": 2,
              "stereographic": 3}
@@ -458,14 +459,15 @@ def crop_inside(img, canvas_white=False, rng=0.0):
     return out.astype(bool)
 
 
-def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0):
+def image_warp_h(img, H, out_h, out_w, x0, y0, sx, sy, fill=0.0, method="bilinear"):
     a = np.asarray(img)
     is_u8 = a.dtype == np.uint8
     src = _f32(a if a.ndim == 3 else a[..., None])
     Hc = np.ascontiguousarray(np.asarray(H, np.float64).T)
     out = np.zeros((out_h, out_w, src.shape[2]), np.float32)
-    _orc_image_warp_h(src.ctypes.data, src.shape[0], src.shape[1], src.shape[2], Hc.ctypes.data, out_h, out_w,
-                      float(x0), float(y0), float(sx), float(sy), float(fill), int(is_u8), out.ctypes.data)
+    m = {"nearest": 0, "bilinear": 1, "bicubic": 2}[method]
+    _orc_image_warp_h_m(src.ctypes.data, src.shape[0], src.shape[1], src.shape[2], Hc.ctypes.data, out_h, out_w,
+                        float(x0), float(y0), float(sx), float(sy), float(fill), int(is_u8), m, out.ctypes.data)
     out = out.astype(np.uint8) if is_u8 else out
     return out if a.ndim == 3 else out[..., 0]
 

@@ -571,6 +571,81 @@ ORC_API void orc_image_warp_h(const float* in, int in_h, int in_w, int C, const 
         }
 }
 
+/* ---- imageWarp 'nearest' (:109-123) and 'bicubic' (:170-264); method 0 / 2 (1 = bilinear, above) ---- */
+static double orc_warp_cubic(double x) { /* bicubicKernel, imageWarp.m:275-301; |x|^2, |x|^3 as products */
+    const double a = fabs(x), a2 = a * a, a3 = a2 * a;
+    if (a <= 1.0) return (1.5 * a3 - 2.5 * a2) + 1.0;
+    if (a <= 2.0) return ((-0.5 * a3 + 2.5 * a2) - 4.0 * a) + 2.0;
+    return 0.0;
+}
+
+ORC_API void orc_image_warp_h_m(const float* in, int in_h, int in_w, int C, const double* Hcm, int out_h,
+                                int out_w, double x0, double y0, double sx, double sy, float fill,
+                                int round_to_u8, int method, float* out) {
+    if (method == 1) {
+        orc_image_warp_h(in, in_h, in_w, C, Hcm, out_h, out_w, x0, y0, sx, sy, fill, round_to_u8, out);
+        return;
+    }
+    double H[9];
+    for (int e = 0; e < 9; ++e) H[e] = Hcm[e];
+    if (H[8] != 0) for (int e = 0; e < 9; ++e) H[e] = Hcm[e] / Hcm[8];
+#define HH(r, c) H[(r) + 3 * (c)]
+    double A[9];
+    A[0] = HH(1, 1) * HH(2, 2) - HH(1, 2) * HH(2, 1); A[3] = HH(0, 2) * HH(2, 1) - HH(0, 1) * HH(2, 2); A[6] = HH(0, 1) * HH(1, 2) - HH(0, 2) * HH(1, 1);
+    A[1] = HH(1, 2) * HH(2, 0) - HH(1, 0) * HH(2, 2); A[4] = HH(0, 0) * HH(2, 2) - HH(0, 2) * HH(2, 0); A[7] = HH(0, 2) * HH(1, 0) - HH(0, 0) * HH(1, 2);
+    A[2] = HH(1, 0) * HH(2, 1) - HH(1, 1) * HH(2, 0); A[5] = HH(0, 1) * HH(2, 0) - HH(0, 0) * HH(2, 1); A[8] = HH(0, 0) * HH(1, 1) - HH(0, 1) * HH(1, 0);
+    const double det = (HH(0, 0) * A[0] + HH(0, 1) * A[1]) + HH(0, 2) * A[2];
+#undef HH
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < out_h; ++y)
+        for (int x = 0; x < out_w; ++x) {
+            const double X = x0 + (double)x * sx, Y = y0 + (double)y * sy;
+            double s0 = ((A[0] * X + A[3] * Y) + A[6]) / det;
+            double s1 = ((A[1] * X + A[4] * Y) + A[7]) / det;
+            double s2 = ((A[2] * X + A[5] * Y) + A[8]) / det;
+            double wv = fabs(s2) > 1e-12 ? fabs(s2) : 1e-12;
+            wv = s2 < 0 ? -wv : (s2 > 0 ? wv : 0.0);
+            const double srcx = s0 / wv, srcy = s1 / wv;
+            if (method == 0) { /* x = round(srcX) (half away from zero), valid inside the image (:111-113) */
+                const double rx = round(srcx), ry = round(srcy);
+                const int valid = rx >= 1 && rx <= in_w && ry >= 1 && ry <= in_h;
+                for (int c = 0; c < C; ++c)
+                    out[((size_t)y * out_w + x) * C + c] = valid ? in[((size_t)((int)ry - 1) * in_w + ((int)rx - 1)) * C + c] : fill;
+                continue;
+            }
+            const double fx = floor(srcx), fy = floor(srcy);
+            const int valid = fx >= 2 && fx <= in_w - 2 && fy >= 2 && fy <= in_h - 2; /* :177 */
+            double wxk[4] = {0, 0, 0, 0}, wyk[4] = {0, 0, 0, 0};
+            if (valid)
+                for (int ii = -1; ii <= 2; ++ii) { /* :191-194 */
+                    wxk[ii + 1] = orc_warp_cubic((double)ii - (srcx - fx));
+                    wyk[ii + 1] = orc_warp_cubic((double)ii - (srcy - fy));
+                }
+            for (int c = 0; c < C; ++c) {
+                float o = fill;
+                if (valid) {
+                    const int xb = (int)fx, yb = (int)fy;
+                    double v = 0.0;
+                    for (int jj = 0; jj < 4; ++jj) { /* xInterp(:,jj) over ii ascending from 0 (:236-243), then sum over jj (:246) */
+                        double xi = 0.0;
+                        for (int ii = 0; ii < 4; ++ii)
+                            xi = xi + (double)in[((size_t)(yb + jj - 2) * in_w + (xb + ii - 2)) * C + c] * wxk[ii];
+                        v = v + xi * wyk[jj];
+                    }
+                    if (round_to_u8) {
+                        double rr = round(v);
+                        rr = rr < 0 ? 0 : (rr > 255 ? 255 : rr);
+                        o = (float)rr;
+                    } else {
+                        v = v < 0 ? 0 : (v > 1.0 ? 1.0 : v); /* maxVal = 1 for float images (:216,:254) */
+                        o = (float)v;
+                    }
+                }
+                out[((size_t)y * out_w + x) * C + c] = o;
+            }
+        }
+}
+
 /* ================================================================================================
  * Gain-compensation overlap statistics (PP/gainCompensation/gainCompensationRKf.m:96-149, 239-367,
  * 369-579): for every stride-th canvas point (1-BASED coordinates, :106-107), every image pair (i < j)

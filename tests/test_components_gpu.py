@@ -193,3 +193,74 @@ def test_overlapped_extraction_and_matching_changes_nothing(gpu, monkeypatch):
         for a, b in zip(got["panoramas"], ref["panoramas"]):
             assert tuple(a.shape) == tuple(b.shape) and bool(torch.equal(a, b))
     monkeypatch.delenv("APS_MATCH_OVERLAP_CHUNK", raising=False)
+
+
+# ---- the second matching pass (imageMatchingPanoramaConComps.m:48-91) ----------------------------------------------------
+def _worlds_of_three_sizes(synth):
+    """Three worlds whose ORIGINALS differ in size and aspect: a global 'fit' brings all of them to one common size
+    (anisotropically), the per-component 'fit' of the second pass keeps each world's own aspect."""
+    spec = [(2, 2, 11, 800, 600, 1125.0), (3, 2, 23, 640, 400, 900.0), (2, 2, 37, 720, 720, 1010.0)]
+    views, Ks, world_of = [], [], []
+    for wi, (nx, ny, seed, w, h, f) in enumerate(spec):
+        cs = synth.grid_cameras(nx, ny, w, h, f, 2 * np.arctan(w / (2 * f)) * 0.6, 2 * np.arctan(h / (2 * f)) * 0.6, 1.0, seed)
+        for c in cs:
+            views.append(synth.render_view(c, h, w, seed, "cuda", finest_px=6.0))
+            Ks.append(c["K"])
+            world_of.append(wi)
+    perm = np.random.default_rng(9).permutation(len(views))
+    return [views[k] for k in perm], [Ks[k] for k in perm], [world_of[k] for k in perm]
+
+
+@pytest.mark.parametrize("driver", ["single", "sharded"])
+def test_second_pass_on_images_resized_per_component(gpu, driver):
+    """resizeImage = 1 and resizeImagePanoramaCluster = 1 with more than one component: the images are resized per
+    component from the ORIGINALS, features are re-extracted and everything is re-matched and re-verified.  The run
+    must (a) take the branch, (b) see different feature counts than the first pass, (c) keep every resized image on the
+    device, and (d) produce exactly the panoramas of a plain run on images resized that way beforehand."""
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    ip = import_module(gpu.__name__ + ".imageProcessing")
+    originals, Ks_o, world_of = _worlds_of_three_sizes(synth)
+    torch.cuda.synchronize()
+    n = len(originals)
+    hw_o = [(int(v.shape[0]), int(v.shape[1])) for v in originals]
+    inp = pl.default_input(bands=3, resizeImage=1, resizeImagePanoramaCluster=1, heightLimit=480, widthLimit=480)
+    # loadImages.m:66-68: the first pass runs on resizeImagesToLimits(ALL images, 'fit') = one component holding everything
+    first = pl.resize_per_component(inp, dict(enumerate(originals)), np.zeros(n, np.int64), hw_o)
+    first = [first[k] for k in range(n)]
+    assert all(v.is_cuda for v in first) and len({tuple(v.shape) for v in first}) == 1
+    # the device resize is the host resize
+    assert np.array_equal(first[0].cpu().numpy(), ip.imresize(ip.imresize(originals[0].cpu().numpy(),
+                          pl.fit_size(*hw_o[0], 480, 480)[2], "bicubic"), tuple(first[0].shape[:2]), "bicubic"))
+    Ks_1 = [pl.rescale_K(K, hw_o[k], first[k].shape[:2]) for k, K in enumerate(Ks_o)]
+    if driver == "single":
+        panos, info = pl.stitch(inp, first, Ks=Ks_1, tile=(256, 256), images_original=originals)
+    else:
+        _, info = par.stitch_distributed(inp, dict(enumerate(first)), n, Ks_1, (256, 256), 0, None, pano_root=0,
+                                         local_originals=dict(enumerate(originals)))
+        panos = info["panoramas"]
+    assert info["second_pass"] is True and info["n_components"] == 3 and len(panos) == 3
+    assert list(info["n_features"]) != list(info["n_features_first_pass"])
+    for c in info["components"]:
+        assert len({world_of[k] for k in c["members"]}) == 1
+    # the same images prepared beforehand, plain run without the flags
+    labels = np.asarray(info["labels"])
+    pre = pl.resize_per_component(inp, dict(enumerate(originals)), labels, hw_o)
+    pre = [pre[k] for k in range(n)]
+    assert len({tuple(v.shape) for v in pre}) == 3  # every world kept its own aspect
+    Ks_2 = [pl.rescale_K(K, first[k].shape[:2], pre[k].shape[:2]) for k, K in enumerate(Ks_1)]
+    plain = pl.default_input(bands=3)
+    if driver == "single":
+        panos_b, info_b = pl.stitch(plain, pre, Ks=Ks_2, tile=(256, 256))
+    else:
+        _, info_b = par.stitch_distributed(plain, dict(enumerate(pre)), n, Ks_2, (256, 256), 0, None, pano_root=0)
+        panos_b = info_b["panoramas"]
+    assert info_b["second_pass"] is False and list(info_b["n_features"]) == list(info["n_features"])
+    assert [c["members"] for c in info_b["components"]] == [c["members"] for c in info["components"]]
+    assert len(panos_b) == 3
+    for a, b in zip(panos, panos_b):
+        assert tuple(a.shape) == tuple(b.shape) and bool(torch.equal(a, b))
+        assert (a.amax(dim=2) > 0).float().mean().item() > 0.4

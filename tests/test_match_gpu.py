@@ -409,6 +409,35 @@ def test_worker_threads_inherit_the_selected_device(gpu, monkeypatch):
     assert out["rc"] == 0, out
 
 
+def test_thread_device_binding_does_not_touch_the_process_default(gpu):
+    """aps_set_thread_device binds the calling thread only (pool workers must name their device instead of
+    inheriting whichever one another thread selected last); aps_get_device reports the binding; an out-of-range device
+    is refused and leaves the binding alone; re-binding after the auxiliary streams of a matching call exist works
+    (bind_device drops them with the old device's other resources)."""
+    import threading
+
+    capi = gpu._capi
+    capi.check(capi.lib.aps_set_device(0))
+    out = {}
+
+    def work():
+        out["bad"] = capi.lib.aps_set_thread_device(63)
+        out["ok"] = capi.lib.aps_set_thread_device(0)
+        out["dev"] = capi.lib.aps_get_device()
+        rng = np.random.default_rng(3)
+        a, b = sift_like(rng, 300), sift_like(rng, 280)
+        fmod = import_module(gpu.__name__ + ".featureMatching")
+        out["m1"] = fmod.match_pairs_csr([a, b], [(0, 1)], 0.9, 1.5)[0][-1]  # creates this thread's auxiliary streams
+        out["again"] = capi.lib.aps_set_thread_device(0)
+        out["m2"] = fmod.match_pairs_csr([a, b], [(0, 1)], 0.9, 1.5)[0][-1]
+
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    assert out["bad"] != 0 and out["ok"] == 0 and out["dev"] == 0 and out["again"] == 0 and out["m1"] == out["m2"] > 0, out
+    assert capi.lib.aps_get_device() == 0
+
+
 def test_filter_aware_dismissal_changes_no_match(fm, monkeypatch):
     """The candidate kernel dismisses rows whose screened values already prove that the ratio / threshold filter drops
     them (no exact evaluation, no fallback).  The match lists must equal the oracle's and those of a run with the

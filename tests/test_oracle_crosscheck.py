@@ -106,6 +106,54 @@ def test_bilinear_warp_equals_scipy_map_coordinates():
     assert np.all(got[~valid] == -1.0)
 
 
+def _keys(x):
+    a = np.abs(x)
+    return np.where(a <= 1, 1.5 * a ** 3 - 2.5 * a ** 2 + 1, np.where(a <= 2, -0.5 * a ** 3 + 2.5 * a ** 2 - 4 * a + 2, 0.0))
+
+
+def test_nearest_and_bicubic_warp_against_a_vectorised_numpy_form_and_closed_forms():
+    """imageWarp 'nearest' (imageWarp.m:109-123) and 'bicubic' (:170-264, Keys a = -0.5 over the 4 x 4 taps around
+    floor(src)).  No third-party interpolator in this image uses that kernel for arbitrary maps (torch: a = -0.75, scipy:
+    B-splines), so the independent form is a vectorised numpy evaluation (einsum over the separable weights); closed
+    forms: an integer translation reproduces the image, a constant stays constant, nearest rounds half away from zero."""
+    rng = np.random.default_rng(14)
+    img = rng.random((50, 70)).astype(np.float32)
+    a, s = -0.15, 0.93
+    Hm = np.array([[s * np.cos(a), -s * np.sin(a), 5.25], [s * np.sin(a), s * np.cos(a), 2.5], [2e-4, 1e-4, 1.0]])
+    oh, ow = 64, 84
+    X, Y = np.meshgrid(1.0 + np.arange(ow, dtype=np.float64), 1.0 + np.arange(oh, dtype=np.float64))
+    q = np.linalg.inv(Hm) @ np.stack([X.ravel(), Y.ravel(), np.ones(X.size)])
+    sx, sy = (q[0] / q[2]).reshape(oh, ow), (q[1] / q[2]).reshape(oh, ow)
+    # bicubic
+    got = oracle.image_warp_h(img, Hm, oh, ow, 1.0, 1.0, 1.0, 1.0, fill=-1.0, method="bicubic")
+    fx, fy = np.floor(sx), np.floor(sy)
+    valid = (fx >= 2) & (fx <= 70 - 2) & (fy >= 2) & (fy <= 50 - 2)
+    assert valid.sum() > 1500 and np.all(got[~valid] == -1.0)
+    xi, yi = fx[valid].astype(int), fy[valid].astype(int)
+    offs = np.arange(-1, 3)
+    wx = _keys(offs[None, :] - (sx[valid] - fx[valid])[:, None])
+    wy = _keys(offs[None, :] - (sy[valid] - fy[valid])[:, None])
+    taps = img.astype(np.float64)[(yi[:, None, None] + offs[None, :, None] - 1), (xi[:, None, None] + offs[None, None, :] - 1)]
+    want = np.clip(np.einsum("nyx,ny,nx->n", taps, wy, wx), 0.0, 1.0)
+    assert np.abs(got[valid] - want).max() < 1e-6
+    assert np.abs(wx.sum(1) - 1).max() < 1e-12  # the Keys weights are a partition of unity
+    # integer translation: the interior is reproduced exactly, by both methods
+    T = np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1.0]])
+    for method in ("bicubic", "nearest"):
+        out = oracle.image_warp_h(img, T, 50, 70, 1.0, 1.0, 1.0, 1.0, fill=-1.0, method=method)
+        assert np.array_equal(out[4:40, 8:60], img[6:42, 5:57]), method
+    u8 = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    const = np.full((30, 30), 0.625, np.float32)
+    cw = oracle.image_warp_h(const, Hm, 20, 20, 8.0, 8.0, 1.0, 1.0, fill=-1.0, method="bicubic")
+    assert (cw != -1.0).sum() > 200 and np.abs(cw[cw != -1.0] - 0.625).max() < 1e-6
+    # nearest: source x = X - 0.5 -> round half away from zero picks the pixel to the right of the tie
+    half = np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1.0]])
+    out = oracle.image_warp_h(u8, half, 40, 40, 1.0, 1.0, 1.0, 1.0, fill=7, method="nearest")
+    assert np.array_equal(out[:, 1:], u8[:, 1:]) and np.array_equal(out[:, 0], u8[:, 0])  # src 0.5 rounds to 1
+    out2 = oracle.image_warp_h(u8, np.array([[1, 0, 1.5], [0, 1, 0.0], [0, 0, 1.0]]), 40, 40, 1.0, 1.0, 1.0, 1.0, fill=7, method="nearest")
+    assert np.all(out2[:, 0] == 7) and np.array_equal(out2[:, 1:], u8[:, :-1])  # src -0.5 rounds to -1 (outside), 0.5 -> 1
+
+
 # ---- DLT: Jacobi on the Gram matrix vs LAPACK svd ------------------------------------------------------------------------
 def _dlt_svd(p1, p2):
     """estimateHomography (estimateTransformationRANSAC.m:188-225) with numpy's LAPACK svd: Hartley normalisation,

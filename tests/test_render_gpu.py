@@ -302,6 +302,24 @@ def test_image_warp_bit_exact(ip):
     assert xl[0] < 10 and xl[1] > 120 and yl[0] < 0
 
 
+@pytest.mark.parametrize("method", ["nearest", "bilinear", "bicubic"])
+def test_image_warp_methods_bit_exact(ip, method):
+    """options.method of imageWarp.m: 'nearest' (:109-123), 'bilinear' (:125-168), 'bicubic' (:170-264), uint8 and single."""
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    H = np.array([[0.97, 0.05, 6.5], [-0.04, 1.02, -3.25], [2e-5, -1e-5, 1.0]])
+    view = ip.imref2dScratch((100, 140), (-5.5, 134.5), (-4.5, 95.5))
+    out = ip.imageWarp(img, H, view, method, 9)
+    ref = oracle.image_warp_h(img, H, 100, 140, -5.5, -4.5, 1.0, 1.0, 9, method=method)
+    assert out.dtype == np.uint8 and np.array_equal(out, ref) and (out != 9).mean() > 0.5
+    f32 = rng.random((90, 120), dtype=np.float32)
+    outf = ip.imageWarp(f32, H, view, method, 0.25)
+    reff = oracle.image_warp_h(f32, H, 100, 140, -5.5, -4.5, 1.0, 1.0, 0.25, method=method)
+    assert np.array_equal(bits(outf), bits(reff))
+    with pytest.raises(ValueError):
+        ip.imageWarp(img, H, view, "lanczos")
+
+
 # ---- gain-compensation overlap statistics (SURVEY 8(f) rank 1) ---------------------------------------------------
 @pytest.mark.parametrize("mode,stride", [("spherical", 3), ("cylindrical", 5), ("planar", 2), ("stereographic", 1)])
 def test_gain_overlap_stats_match_oracle(gpu, rp, mode, stride):
