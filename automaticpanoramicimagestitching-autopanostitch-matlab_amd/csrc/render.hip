@@ -1113,6 +1113,18 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
         d.cx = (float)im.K[6];
         d.cy = (float)im.K[7];
         for (int c = 0; c < 3; ++c) d.gain[c] = im.gain[c];
+        for (int c = 0; c < 3; ++c) d.g255[c] = (float)((double)im.gain[c] / 255.0);
+        {   // tent_value(n, k) = k / (a - 1) on the rising half, (n - 1 - k) / (nb - 1) on the falling one, a = ceil(n / 2),
+            // nb = n - floor(n / 2); both halves are straight lines through the table's samples and the table is their minimum
+            // capped at one, so between two samples the bilinear interpolation of the table IS this function
+            auto slopes = [](int n, float t[2]) {
+                const int a = (n + 1) / 2, nb = n - n / 2;
+                t[0] = a > 1 ? (float)(1.0 / (double)(a - 1)) : 0.f;
+                t[1] = nb > 1 ? (float)(1.0 / (double)(nb - 1)) : 0.f;
+            };
+            slopes(im.width, d.tx);
+            slopes(im.height, d.ty);
+        }
         {
             const double ax = std::max(std::fabs(1.0 - im.K[6]), std::fabs((double)im.width - im.K[6])) / std::fabs(im.K[0]);
             const double ay = std::max(std::fabs(1.0 - im.K[7]), std::fabs((double)im.height - im.K[7])) / std::fabs(im.K[4]);

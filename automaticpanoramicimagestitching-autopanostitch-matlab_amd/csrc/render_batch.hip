@@ -58,6 +58,13 @@ struct RwEntry {
     long long off[kML];  // float4 offset of the compact G_l store, pitch g[l].x1 - g[l].x0
 };
 
+struct ColTrig {
+    float s, c;  // sin/cos of theta (cylindrical, spherical)
+};
+struct RowTrig {
+    float s, c;  // spherical: sin/cos of phi; cylindrical: s = height
+};
+
 struct RwArgs {
     const RwTile* tiles;
     const RwEntry* entries;
@@ -77,6 +84,10 @@ struct RwArgs {
     uint8_t* pano;
     uint8_t* covered;
     int H, W, out_layout, white;
+    const int* cd_s0;     // fused shrink (rw_down_fused_kernel): first source index per output sample ...
+    const float* cd_w;    // ... and the weights of the consecutive source samples from there, [sample][NCP]
+    const ColTrig* ct;  // per canvas column: sin/cos of theta (cylindrical, spherical), rw_trig_kernel
+    const RowTrig* rt;  // per canvas row: sin/cos of phi (spherical) or the height (cylindrical)
 };
 
 // largest s with ptr[s] <= bid (ptr nondecreasing, ptr[0] = 0, n segments); every wave evaluates it for itself
@@ -172,15 +183,52 @@ __global__ void rw_taps_kernel(const TapJob* __restrict__ jobs, int* __restrict_
     }
 }
 
+// The shrink G_{l+1} = imresize(imgaussfilt(G_l)) as ONE separable filter per axis: per output sample the weights of the
+// consecutive source samples it depends on, sum over (resize tap t, Gaussian tap k) of w_t g_k at source index
+// clamp(clamp(left + t) + k - R) (the blur's replicate padding at the level border and the resize's clamped taps merge
+// into the border sample).  Products and sums in f64, stored as f32.  This is the blur and the resize of
+// multiBandBlending.m:112-135 in exact arithmetic; it differs from the two-step evaluation by the rounding of the
+// intermediate blurred plane only, which is what the render's stated tolerance is for (the per-tile path and
+// APS_RENDER_EXACT=1 keep the two-step form bit for bit).
+constexpr int kNCPMax = 16;  // kTD + 2 * 4 = 14 weights, padded to whole 16-byte groups
+__global__ void rw_ctaps_kernel(const TapJob* __restrict__ jobs, Taps tp, int ncp, int* __restrict__ c_s0,
+                                float* __restrict__ c_w, int* __restrict__ status) {
+    const TapJob j = jobs[blockIdx.y];
+    if (j.T != kTD) return;  // enlargements keep their two-tap tables
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= j.out_len) return;
+    int left;
+    float wts[12];
+    const int P = resize_taps(j.in_len, j.out_len, o, left, wts);
+    const int R = tp.r, nc = kTD + 2 * R;
+    int lo = j.in_len;
+    for (int t = 0; t < P; ++t) {
+        if (wts[t] == 0.f) continue;
+        const int c = min(max(left + t, 1), j.in_len) - 1;
+        lo = min(lo, max(c - R, 0));
+    }
+    double acc[kNCPMax];
+    for (int n = 0; n < kNCPMax; ++n) acc[n] = 0.0;
+    bool ok = true;
+    for (int t = 0; t < P; ++t) {
+        if (wts[t] == 0.f) continue;
+        const int c = min(max(left + t, 1), j.in_len) - 1;
+        for (int k = 0; k <= 2 * R; ++k) {
+            const int i = min(max(c + k - R, 0), j.in_len - 1) - lo;
+            if (i < 0 || i >= nc)
+                ok = false;
+            else
+                acc[i] += (double)wts[t] * (double)tp.k[k];
+        }
+    }
+    if (!ok) atomicOr(status, 4);
+    c_s0[j.off + o] = lo;
+    for (int n = 0; n < ncp; ++n) c_w[(size_t)(j.off + o) * ncp + n] = n < nc ? (float)acc[n] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sampling with per-block trig tables and a u8 -> [0,1] table (same values as canvas_ray / sample_one)
 // ------------------------------------------------------------------------------------------------
-struct ColTrig {
-    float s, c;  // sin/cos of theta (cylindrical, spherical)
-};
-struct RowTrig {
-    float s, c;  // spherical: sin/cos of phi; cylindrical: s = height
-};
 
 __device__ __forceinline__ ColTrig col_trig(const DevCanvas& cv, float xp) {
     ColTrig t;
@@ -200,6 +248,15 @@ __device__ __forceinline__ RowTrig row_trig(const DevCanvas& cv, float yp) {
         t.c = 1.0f;
     }
     return t;
+}
+
+// The transcendental parts of every canvas column / row, once per call (W + H entries): the warp's blocks used to
+// evaluate sinf / cosf for their 32 columns and 8 rows themselves, behind a barrier - ~60 VALU instructions per wave
+// averaged over the kernel, for values that depend on the canvas coordinate alone.  Same functions, same bits.
+__global__ void rw_trig_kernel(DevCanvas cv, ColTrig* __restrict__ ct, RowTrig* __restrict__ rt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cv.W) ct[i] = col_trig(cv, (float)i);
+    if (i < cv.H) rt[i] = row_trig(cv, (float)i);
 }
 
 // canvas_ray with the transcendental parts taken from the tables (cylindrical / spherical) or evaluated in
@@ -316,6 +373,136 @@ __device__ __forceinline__ float4 sample_finish(const DevImage& im, const Sample
     const float bot = (1.0f - s) * f01 + s * f11;
     const float wf = top * (1.0f - t) + bot * t;
     return L.m ? make_float4(o[0], o[1], o[2], L.wa * wf) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- the fast sampler of rw_warp_kernel ---------------------------------------------------------------------------
+// Same projection, mask, taps and weights as sample_lut (renderPanorama.m:1089-1131), evaluated for speed instead of
+// for bit-identity with the per-tile path: the contract for warped pixels is a stated tolerance against the oracle
+// (tests: <= 2 grey levels, >= 99.95 % within one, coverage flips <= 1e-4), and the exact IEEE divisions, the u8 -> float
+// table and the 4-tap tent products were two thirds of the kernel's 680 VALU instructions per pixel.
+//   * ONE reciprocal of cam_z (v_rcp_f32 + one Newton step, < 1 ulp) serves u and v;
+//   * the clamps make x1 = x0 + 1 and y1 = y0 + 1 always, so the taps of a row are two adjacent dwords;
+//   * the bilinear form runs on the raw bytes (v_cvt_f32_ubyteN) as three lerps per channel, scaled once by gain / 255;
+//   * the tent weight is separable: bilinear(wy (x) wx) = lerp(wy) * lerp(wx).
+__device__ __forceinline__ float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = fmaf(-x, r, 1.0f);
+    return fmaf(r, e, r);
+}
+__device__ __forceinline__ float lerp1(float a, float b, float s) { return fmaf(s, b - a, a); }
+
+// The image, its tent tables and its constants as the warp's layer loop wants them: buffer resources (uniform, 4 SGPRs
+// each), so that a tap pair is ONE 8-byte buffer load at a 32-bit offset instead of two flat loads behind 64-bit
+// address arithmetic.  Needs w, h >= 2 (then x1 = x0 + 1, y1 = y0 + 1 always); the caller sends smaller images through
+// sample_lut.
+struct FastImage {
+    __amdgpu_buffer_rsrc_t rgba, wx, wy;
+    int w, h, row_bytes;
+};
+__device__ __forceinline__ FastImage fast_image(const DevImage& im) {
+    FastImage f;
+    f.w = im.w;
+    f.h = im.h;
+    f.row_bytes = im.w * 4;
+    f.rgba = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(im.rgba), 0, im.w * im.h * 4, 0x00020000);
+    f.wx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.wx), 0, im.w * 4, 0x00020000);
+    f.wy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.wy), 0, im.h * 4, 0x00020000);
+    return f;
+}
+template <class T2>
+__device__ __forceinline__ T2 ld_pair(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    T2 r;  // (copied whole: member access on the builtin's vector type is narrowed by this compiler, see ld_foot)
+    static_assert(sizeof v == sizeof r, "b64");
+    __builtin_memcpy(&r, &v, sizeof r);
+    return r;
+}
+
+// exact_ray(de): fills de with the pixel's ray as ray_from_tables computes it (called on the rare path only).
+template <bool BAND, bool BUF, class ExactRay>
+__device__ __forceinline__ float4 sample_fast(const DevImage& im, const FastImage& fi, const float d[3], float angle_pow,
+                                              ExactRay exact_ray) {
+    const float cam0 = fmaf(d[2], im.R[6], fmaf(d[1], im.R[3], d[0] * im.R[0]));
+    const float cam1 = fmaf(d[2], im.R[7], fmaf(d[1], im.R[4], d[0] * im.R[1]));
+    float cam2 = fmaf(d[2], im.R[8], fmaf(d[1], im.R[5], d[0] * im.R[2]));
+    const int w = im.w, h = im.h;
+    // WHICH pixels an image covers must not depend on the fast arithmetic: a pixel that flips at the rim of the panorama
+    // carries a normalised weight of one (it is the only layer there) and shifts the blend of its neighbourhood by a few
+    // grey levels.  A ray that lands within `band` of the image border or of the cam_z threshold - a band a few times
+    // wider than the fast path's error - is therefore re-projected exactly as sample_lut / project() do it, so that the
+    // coverage of the batched path stays that of the per-tile path bit for bit.  (About one wave in a hundred goes there.)
+    const float band = 1.6e-5f * (float)max(w, h) + 4e-3f;
+    float u = 0.f, v = 0.f;
+    bool exact = BAND && fabsf(cam2 - 1e-6f) < 1e-6f;
+    if (!exact) {
+        if (!(cam2 > 1e-6f)) return make_float4(0.f, 0.f, 0.f, 0.f);  // behind the camera (renderPanorama.m:1112-1116)
+        const float rz = fast_rcp(cam2);
+        u = fmaf(im.fx * cam0, rz, im.cx);
+        v = fmaf(im.fy * cam1, rz, im.cy);
+        exact = BAND && fminf(fminf(fabsf(u - 1.0f), fabsf(u - (float)w)), fminf(fabsf(v - 1.0f), fabsf(v - (float)h))) < band;
+    }
+    if (BAND && exact) {
+        float de[3], wa_;
+        exact_ray(de);
+        if (!project(im, de, 2.0f, u, v, wa_)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        cam2 = fmaf(de[2], im.R[8], fmaf(de[1], im.R[5], de[0] * im.R[2]));
+    } else if (!((u >= 1.0f) && (u <= (float)w) && (v >= 1.0f) && (v <= (float)h))) {
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float wa = cam2;
+    if (angle_pow == 2.0f)
+        wa = wa * wa;
+    else if (angle_pow != 1.0f)
+        wa = __powf(wa, angle_pow);
+    const int xm = min((int)u, w - 1) - 1, ym = min((int)v, h - 1) - 1;  // 0-based x0, y0 (u, v >= 1: truncation is floor)
+    const float s = u - (float)(xm + 1), t = v - (float)(ym + 1);
+    const int off = (ym * w + xm) * 4;
+    uint2 pa, pb;  // (x0, y0), (x1, y0) and (x0, y1), (x1, y1)
+    if (BUF) {
+        pa = ld_pair<uint2>(fi.rgba, off, 0);
+        pb = ld_pair<uint2>(fi.rgba, off, fi.row_bytes);
+    } else {
+        const uint32_t* __restrict__ r0p = im.rgba + ((size_t)ym * w + xm);
+        pa = make_uint2(r0p[0], r0p[1]);
+        pb = make_uint2(r0p[w], r0p[w + 1]);
+    }
+    // the tent weight in closed form (DevImage::tx, ty) instead of two more table loads: lerp(wx) * lerp(wy)
+    const float px = u - 1.0f, py = v - 1.0f;
+    const float wf = fminf(fminf(px * im.tx[0], ((float)(w - 1) - px) * im.tx[1]), 1.0f) *
+                     fminf(fminf(py * im.ty[0], ((float)(h - 1) - py) * im.ty[1]), 1.0f);
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b00 = (float)((pa.x >> (8 * c)) & 255u), b10 = (float)((pa.y >> (8 * c)) & 255u);
+        const float b01 = (float)((pb.x >> (8 * c)) & 255u), b11 = (float)((pb.y >> (8 * c)) & 255u);
+        o[c] = lerp1(lerp1(b00, b10, s), lerp1(b01, b11, s), t) * im.g255[c];
+    }
+    return make_float4(o[0], o[1], o[2], wa * wf);
+}
+
+// the ray of ray_from_tables with the normalisation through v_rsq_f32 (the spherical / cylindrical rays are unit
+// vectors up to rounding already)
+__device__ __forceinline__ void ray_fast(const DevCanvas& cv, const ColTrig& ct, const RowTrig& rt, float xp, float yp,
+                                         float d[3]) {
+    if (cv.mode == APS_PROJ_CYLINDRICAL || cv.mode == APS_PROJ_SPHERICAL) {
+        float x, y, z;
+        if (cv.mode == APS_PROJ_CYLINDRICAL) {
+            x = ct.s;
+            y = rt.s;
+            z = ct.c;
+        } else {
+            x = rt.c * ct.s;
+            y = rt.s;
+            z = rt.c * ct.c;
+        }
+        const float n2 = fmaf(z, z, fmaf(y, y, x * x));
+        const float r = __builtin_amdgcn_rsqf(n2 > 1e-16f ? n2 : 1e-16f);
+        d[0] = x * r;
+        d[1] = y * r;
+        d[2] = z * r;
+    } else {
+        canvas_ray(cv, xp, yp, d);
+    }
 }
 
 // geometry + tent weight only (what the normalisation sums need): Wang * Wf, 0 outside the mask
@@ -468,11 +655,18 @@ __global__ void rw_footprint_kernel(const unsigned long long* __restrict__ rowma
 // renderPanorama.m:1009-1017, then multiBandBlending.m:72-85, both in layer order) and go to the compact G_0 store
 // with their final weight: the level-0 layer is written once and the weights are never re-read for normalising.
 constexpr int kWL = 6;  // layers of a block whose samples are parked in LDS; further ones are re-sampled
-__global__ __launch_bounds__(256) void rw_warp_kernel(RwArgs A, const int* __restrict__ blk_ptr, int n_blocks) {
-    __shared__ ColTrig s_ct[kUW];
-    __shared__ RowTrig s_rt[kUH];
-    __shared__ float s_u8[256];
+// FAST (default): sample_fast / ray_fast and reciprocal-multiplies in the two normalisations.  !FAST (APS_WARP_EXACT=1):
+// the arithmetic of the per-tile path bit for bit (IEEE divisions, u8 table, 4-tap tent products) - kept so that the
+// tests can still pin the REST of the batched pipeline (footprints, compact stores, pyramids, collapse) byte for byte
+// against render.hip's per-tile kernels.
+// V (experiment switches of the FAST form, APS_WARP_VARIANT, default 6): bit 0 = trig tables from global memory (else
+// evaluated per block into LDS), bit 1 = exact re-projection in the border band, bit 2 = buffer loads for the taps.
+template <bool FAST, int V = 7>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void rw_warp_kernel(RwArgs A, const int* __restrict__ blk_ptr, int n_blocks) {
+    __shared__ float s_u8[FAST ? 1 : 256];
     __shared__ float4 s_g[kWL][256];
+    __shared__ ColTrig s_ct[(V & 1) ? 1 : kUW];
+    __shared__ RowTrig s_rt[(V & 1) ? 1 : kUH];
     const int bid = xcd_contiguous_id(n_blocks);
     if (bid >= n_blocks) return;
     const int t = find_segment(blk_ptr, A.n_tiles, bid);
@@ -481,14 +675,40 @@ __global__ __launch_bounds__(256) void rw_warp_kernel(RwArgs A, const int* __res
     const int h = T.ht, w = T.wt;
     const int local = bid - blk_ptr[t], nbx = (w + kUW - 1) / kUW;
     const int x0 = (local % nbx) * kUW, y0 = (local / nbx) * kUH;
-    if (tid < kUW) s_ct[tid] = col_trig(A.cv, (float)(T.c0 + min(x0 + tid, w - 1)));
-    if (tid >= 64 && tid < 64 + kUH) s_rt[tid - 64] = row_trig(A.cv, (float)(T.r0 + min(y0 + tid - 64, h - 1)));
-    s_u8[tid] = (float)tid / 255.0f;
-    __syncthreads();
+    if (!(V & 1)) {
+        if (tid < kUW) s_ct[tid] = col_trig(A.cv, (float)(T.c0 + min(x0 + tid, w - 1)));
+        if (tid >= 64 && tid < 64 + kUH) s_rt[tid - 64] = row_trig(A.cv, (float)(T.r0 + min(y0 + tid - 64, h - 1)));
+    }
+    if (!FAST) s_u8[tid] = (float)tid / 255.0f;
+    if (!FAST || !(V & 1)) __syncthreads();
     const int x = x0 + (tid & (kUW - 1)), y = y0 + tid / kUW;
     const bool in_tile = x < w && y < h;
+    // the column's / row's transcendental parts from the canvas-wide tables (rw_trig_kernel)
+    const ColTrig ct = (V & 1) ? A.ct[T.c0 + min(x, w - 1)] : s_ct[tid & (kUW - 1)];
+    const RowTrig rt = (V & 1) ? A.rt[T.r0 + min(y, h - 1)] : s_rt[tid / kUW];
     float d[3] = {0.f, 0.f, 1.f};
-    if (in_tile) ray_from_tables(A.cv, s_ct[tid & (kUW - 1)], s_rt[tid / kUW], (float)(T.c0 + x), (float)(T.r0 + y), d);
+    if (in_tile) {
+        if (FAST)
+            ray_fast(A.cv, ct, rt, (float)(T.c0 + x), (float)(T.r0 + y), d);
+        else
+            ray_from_tables(A.cv, ct, rt, (float)(T.c0 + x), (float)(T.r0 + y), d);
+    }
+    // (always_inline: left to its cost model the compiler turned `sample` into a real function - every by-reference
+    // capture, the kernel arguments included, then lives in scratch memory: 400 bytes per lane and a 5x slower kernel)
+    auto exact_ray = [&](float de[3]) __attribute__((always_inline)) {
+        ray_from_tables(A.cv, ct, rt, (float)(T.c0 + x), (float)(T.r0 + y), de);
+    };
+    auto sample = [&](const DevImage& im) __attribute__((always_inline)) {
+        if (FAST && im.w > 3 && im.h > 3)
+            return sample_fast<(V & 2) != 0, (V & 4) != 0>(im, (V & 4) ? fast_image(im) : FastImage{}, d, A.angle_pow, exact_ray);
+        if (FAST) {  // (an image of fewer than four rows or columns: the exact sampler on the exact ray)
+            float de[3];
+            exact_ray(de);
+            const Sample sm = sample_one(im, de, A.angle_pow);
+            return make_float4(sm.s[0], sm.s[1], sm.s[2], sm.wang * sm.wf);
+        }
+        return sample_lut(im, d, A.angle_pow, s_u8);
+    };
     const int bx1 = min(x0 + kUW, w), by1 = min(y0 + kUH, h);
     const LayerSet ls = block_layers(A, T, 0, x0, y0, bx1, by1);
     // pass A: samples and the first sum
@@ -499,13 +719,13 @@ __global__ __launch_bounds__(256) void rw_warp_kernel(RwArgs A, const int* __res
         const RwEntry& E = A.entries[T.e0 + k];
         const Rect g = E.g[0];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_tile && in_rect(g, x, y)) v = sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8);
+        if (in_tile && in_rect(g, x, y)) v = sample(A.imgs[E.img]);
         ssum = ssum + v.w;
         any |= v.w > 0.f;
         if (kc < kWL) s_g[kc][tid] = v;
         ++kc;
     });
-    const float inv = ssum > 1e-8f ? 1.0f / ssum : 0.f;
+    const float inv = ssum > 1e-8f ? (FAST ? fast_rcp(ssum) : 1.0f / ssum) : 0.f;
     // pass B: the second sum over the rescaled weights
     float s2 = 0.f;
     kc = 0;
@@ -515,21 +735,27 @@ __global__ __launch_bounds__(256) void rw_warp_kernel(RwArgs A, const int* __res
             wv = s_g[kc][tid].w;
         } else {
             const RwEntry& E = A.entries[T.e0 + k];
-            wv = (in_tile && in_rect(E.g[0], x, y)) ? sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8).w : 0.f;
+            wv = (in_tile && in_rect(E.g[0], x, y)) ? sample(A.imgs[E.img]).w : 0.f;
         }
         const float w1 = wv * inv;
         s2 = s2 + (w1 > 0.f ? w1 : 0.f);
         ++kc;
     });
     const float2 nrm = make_float2(inv, s2);
+    const float inv2 = s2 > 1e-8f ? fast_rcp(s2) : 0.f;  // (FAST only)
     // pass C: store with the final weight
     kc = 0;
     for_block_layers(ls, A, T, 0, x0, y0, bx1, by1, [&](int k) {
         const RwEntry& E = A.entries[T.e0 + k];
         const Rect g = E.g[0];
         if (in_tile && in_rect(g, x, y)) {
-            float4 v = kc < kWL ? s_g[kc][tid] : sample_lut(A.imgs[E.img], d, A.angle_pow, s_u8);
-            v.w = norm_weight(v.w, nrm);
+            float4 v = kc < kWL ? s_g[kc][tid] : sample(A.imgs[E.img]);
+            if (FAST) {
+                const float w1 = v.w * inv;
+                v.w = (w1 > 0.f ? w1 : 0.f) * inv2;
+            } else {
+                v.w = norm_weight(v.w, nrm);
+            }
             A.G[E.off[0] + (size_t)(y - g.y0) * (g.x1 - g.x0) + (x - g.x0)] = v;
         }
         ++kc;
@@ -750,6 +976,97 @@ __device__ __forceinline__ float4 ld_foot(const FootBuf& b, int x, int y) {
     return f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 2, fused form (default): one kBW x kBH block of G_{l+1} per workgroup straight from the compact store of G_l
+// ------------------------------------------------------------------------------------------------
+// Vertical pass out of REGISTERS, horizontal pass out of LDS, one barrier: a thread owns one patch column and RS
+// consecutive output rows, whose source rows (stride two between output rows: r0 .. r0 + 2 (RS - 1) + NC - 1) it fetches
+// once into a register window (range-checked buffer loads: zero outside the layer's footprint) - every source sample is
+// requested ~1.4 times instead of five, nothing is staged, and the only LDS buffer is the kBH x VC half-height plane
+// (20 KB against the 69 KB of the two-step kernel: eight workgroups fit a CU instead of two).  Rows whose taps do not
+// advance by exactly two (one row in ~a thousand when a level's height is odd) take a plain per-tap loop.
+template <int R>
+__global__ __launch_bounds__(256) void rw_down_fused_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
+    constexpr int NC = kTD + 2 * R, NCP = (NC + 3) & ~3, VC = 2 * kBW + NC + 2, RS = 6, NSEG = (kBH + RS - 1) / RS;
+    constexpr int WIN = 2 * (RS - 1) + NC;
+    static_assert(NSEG * VC <= 256 && kBH <= 16 && kBW == 32, "thread mapping");
+    __shared__ float4 s_v[kBH * VC];
+    const int bid = xcd_contiguous_id(n_blocks);
+    if (bid >= n_blocks) return;
+    const int e = find_segment(blk_ptr, A.n_entries, bid);
+    const RwEntry& E = A.entries[e];
+    const RwTile& T = A.tiles[E.tile];
+    const int tid = threadIdx.x;
+    const Rect gi = E.g[l], go = E.g[l + 1];
+    const int gow = go.x1 - go.x0;
+    const int local = bid - blk_ptr[e], nbx = (gow + kBW - 1) / kBW;
+    const int ox0 = go.x0 + (local % nbx) * kBW, oy0 = go.y0 + (local / nbx) * kBH;
+    const int ox1 = min(ox0 + kBW, go.x1), oy1 = min(oy0 + kBH, go.y1);
+    const int now = ox1 - ox0, noh = oy1 - oy0;
+    const int* __restrict__ cs0 = A.cd_s0 + T.tdc[l];
+    const int* __restrict__ rs0 = A.cd_s0 + T.tdr[l];
+    const float* __restrict__ cw = A.cd_w + (size_t)T.tdc[l] * NCP;
+    const float* __restrict__ rw = A.cd_w + (size_t)T.tdr[l] * NCP;
+    const int bx0 = cs0[ox0], nbc = cs0[ox1 - 1] + NC - bx0;
+    if (nbc > VC) {
+        if (tid == 0) atomicOr(A.status, 8);
+        return;
+    }
+    const FootBuf fb = foot_buf(A.G + E.off[l], gi);
+    {  // vertical pass: (column x of the patch, segment of RS output rows)
+        const int x = tid % VC, seg = tid / VC, j0 = seg * RS;
+        if (seg < NSEG && x < nbc && j0 < noh) {
+            const int gx = bx0 + x, nj = min(RS, noh - j0);
+            const int r0 = rs0[oy0 + j0];
+            bool regular = true;
+#pragma unroll
+            for (int j = 1; j < RS; ++j) regular &= j >= nj || rs0[oy0 + j0 + min(j, nj - 1)] == r0 + 2 * j;
+            if (regular) {
+                float4 win[WIN];
+#pragma unroll
+                for (int i = 0; i < WIN; ++i) win[i] = ld_foot(fb, gx, r0 + i);
+#pragma unroll
+                for (int j = 0; j < RS; ++j) {
+                    if (j < nj) {
+                        float wr[NCP];
+#pragma unroll
+                        for (int q = 0; q < NCP / 4; ++q)
+                            *reinterpret_cast<float4*>(&wr[4 * q]) = *reinterpret_cast<const float4*>(&rw[(size_t)(oy0 + j0 + j) * NCP + 4 * q]);
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int n = 0; n < NC; ++n) a = fma4(wr[n], win[2 * j + n], a);
+                        s_v[(j0 + j) * VC + x] = a;
+                    }
+                }
+            } else {
+                for (int j = 0; j < nj; ++j) {
+                    const int rr = rs0[oy0 + j0 + j];
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) a = fma4(rw[(size_t)(oy0 + j0 + j) * NCP + n], ld_foot(fb, gx, rr + n), a);
+                    s_v[(j0 + j) * VC + x] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int xo = tid & (kBW - 1);
+    if (xo < now) {  // horizontal pass: one output column per lane, rows 8 apart
+        const int ox = ox0 + xo, c0 = cs0[ox] - bx0;
+        float wc[NCP];
+#pragma unroll
+        for (int q = 0; q < NCP / 4; ++q)
+            *reinterpret_cast<float4*>(&wc[4 * q]) = *reinterpret_cast<const float4*>(&cw[(size_t)ox * NCP + 4 * q]);
+        float4* __restrict__ out = A.G + E.off[l + 1];
+        for (int yo = tid / kBW; yo < noh; yo += 256 / kBW) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) a = fma4(wc[n], s_v[yo * VC + c0 + n], a);
+            out[(size_t)(oy0 + yo - go.y0) * gow + (ox - go.x0)] = a;
+        }
+    }
+}
+
 // One thread = kUP pixels of a column, kUH rows apart: the loads of a covering layer (its own value + four taps of the
 // coarser level, per pixel) are in flight together.  With one pixel per thread the kernel sat at ~1.6 TB/s on
 // back-to-back dependent waits (taps, then per covering layer, then F) of waves that had little else to do.
@@ -911,7 +1228,20 @@ void launch_down_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
     (void)once;
     rw_down_kernel<R><<<8u * (unsigned)((n_blocks + 7) / 8), kNT, down_lds_bytes<R>(), stream()>>>(A, l, blk_ptr, n_blocks);
 }
-void launch_down(int r, const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
+template <int R>
+void launch_down_fused_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
+    rw_down_fused_kernel<R><<<8u * (unsigned)((n_blocks + 7) / 8), 256, 0, stream()>>>(A, l, blk_ptr, n_blocks);
+}
+void launch_down(int r, const RwArgs& A, int l, const int* blk_ptr, int n_blocks, bool exact) {
+    if (!exact) {
+        switch (r) {
+            case 1: launch_down_fused_r<1>(A, l, blk_ptr, n_blocks); break;
+            case 2: launch_down_fused_r<2>(A, l, blk_ptr, n_blocks); break;
+            case 3: launch_down_fused_r<3>(A, l, blk_ptr, n_blocks); break;
+            default: launch_down_fused_r<4>(A, l, blk_ptr, n_blocks); break;
+        }
+        return;
+    }
     switch (r) {
         case 1: launch_down_r<1>(A, l, blk_ptr, n_blocks); break;
         case 2: launch_down_r<2>(A, l, blk_ptr, n_blocks); break;
@@ -1131,6 +1461,17 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
                                                                                               d_status);
         check_launch("rw_taps_kernel");
     }
+    // APS_RENDER_EXACT=1 (or its older name APS_WARP_EXACT): the warp and the shrink keep the per-tile path's arithmetic
+    const bool exact = std::getenv("APS_RENDER_EXACT") != nullptr || std::getenv("APS_WARP_EXACT") != nullptr;
+    const int ncp = (kTD + 2 * tp.r + 3) & ~3;
+    Ws<int> cd_s0((size_t)std::max(n_down, 1));
+    Ws<float> cd_w((size_t)std::max(n_down, 1) * ncp);
+    if (!jobs.empty() && !exact) {
+        int longest = 1;
+        for (const TapJob& j : jobs) longest = std::max(longest, j.out_len);
+        rw_ctaps_kernel<<<dim3(cdiv(longest, 256), (unsigned)jobs.size()), 256, 0, stream()>>>(d_jobs, tp, ncp, cd_s0, cd_w, d_status);
+        check_launch("rw_ctaps_kernel");
+    }
     Ws<RwTile> d_tiles(nt);
     APS_HIP(hipMemcpyAsync(d_tiles, ht_.data(), nt * sizeof(RwTile), hipMemcpyHostToDevice, stream()));
     Ws<uint8_t> d_cov((size_t)plane_px);
@@ -1148,6 +1489,8 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     A.td_w = td_w;
     A.tu_idx = tu_idx;
     A.tu_w = tu_w;
+    A.cd_s0 = cd_s0;
+    A.cd_w = cd_w;
     A.cov = d_cov;
     A.status = d_status;
     A.pano = pano;
@@ -1156,6 +1499,12 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     A.W = cv.W;
     A.out_layout = out_layout;
     A.white = o.canvas_white;
+    Ws<ColTrig> d_ct((size_t)std::max(cv.W, 1));
+    Ws<RowTrig> d_rt((size_t)std::max(cv.H, 1));
+    rw_trig_kernel<<<cdiv(std::max(cv.W, cv.H), 256), 256, 0, stream()>>>(cv, d_ct, d_rt);
+    check_launch("rw_trig_kernel");
+    A.ct = d_ct;
+    A.rt = d_rt;
 
     // ---- pass 1: the footprint rectangle of every image in every tile ----------------------------------------------
     // on the host where the projection allows it (no kernel, no read-back), else by the exact coverage kernel
@@ -1294,14 +1643,28 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     // ---- pass 2: pyramids, fine to coarse ------------------------------------------------------------------------
     if (warp_blocks) {
         Prof prof("render_warp");
-        rw_warp_kernel<<<8u * (unsigned)((warp_blocks + 7) / 8), 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        const unsigned wgrid = 8u * (unsigned)((warp_blocks + 7) / 8);
+        const char* wv = std::getenv("APS_WARP_VARIANT");  // experiment switch, see rw_warp_kernel
+        const int variant = wv ? std::atoi(wv) : 6;  // (measured: per-block LDS trig tables 6.97 ms, canvas-wide global ones 7.39)
+        if (exact)
+            rw_warp_kernel<false><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        else if (variant == 6)
+            rw_warp_kernel<true, 6><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        else if (variant == 5)
+            rw_warp_kernel<true, 5><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        else if (variant == 3)
+            rw_warp_kernel<true, 3><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        else if (variant == 0)
+            rw_warp_kernel<true, 0><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
+        else
+            rw_warp_kernel<true, 7><<<wgrid, 256, 0, stream()>>>(A, d_blk0, warp_blocks);
         check_launch("rw_warp_kernel");
     }
     {
         Prof prof("render_pyr_down");
         for (int l = 0; l + 1 < max_nl; ++l) {
             if (down_blocks[l] == 0) continue;
-            launch_down(tp.r, A, l, d_blk.get() + (size_t)l * (ne + 1), down_blocks[l]);
+            launch_down(tp.r, A, l, d_blk.get() + (size_t)l * (ne + 1), down_blocks[l], exact);
             check_launch("rw_down_kernel");
         }
     }

@@ -21,6 +21,8 @@ struct DevImage {
     float R[9];  // column-major, single(cam.R)
     float fx, fy, cx, cy;
     float gain[3];
+    float g255[3];  // gain / 255: byte -> [0,1] and the gain in one factor (the fast sampler of the batched path)
+    float tx[2], ty[2];  // the tent weight as min(p * t[0], (n - 1 - p) * t[1], 1), p = 0-based position (warpWeights in closed form)
     float cmin;  // cos of the largest angle between the optical axis and a ray that hits the pixel rectangle (minus a margin)
 };
 

@@ -341,6 +341,138 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     }
 }
 
+// ---- the same blur, marching (default for planes tall enough) ---------------------------------------------------------
+// The tile kernel above fetches (kTW + 2 RP) x (kTH + 2 R) inputs for kTW x kTH outputs - 1.4x (R = 4) to 2.2x (R = 10)
+// of the plane through L2 - and row-filters the vertical halo of every tile again.  Here a workgroup owns kSW columns and
+// `ch` rows of the plane and walks down them kRS input rows at a time: the next step's rows are requested before the
+// current ones are consumed, the row pass runs on the kRS new rows only, its results live in a ring of NR rows in LDS, and
+// the column pass produces the kRS output rows whose window the ring now holds.  A chunk re-reads the 2 R rows above it;
+// nothing else is read twice.  Same chains (pk_tap, taps ascending), so the same bits as blur_kernel.
+constexpr int kSW = 128, kRS = 16;
+template <int R>
+__global__ __launch_bounds__(256) void blur_march_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
+                                                         float* __restrict__ out, float* __restrict__ dec, int dh, int dw, int ch) {
+    constexpr int RP = (R + 3) & ~3, OFF = RP - R;
+    constexpr int IW = kSW + 2 * RP, NV = IW / 4;
+    constexpr int LAG = (2 * R + kRS - 1) / kRS;       // steps between a row's arrival and the output batch that ends at it
+    constexpr int NR = kRS * (LAG + 1) <= 32 ? 32 : 64;  // ring rows (a power of two >= kRS (LAG + 1))
+    static_assert(kRS * (LAG + 1) <= NR && kRS % 4 == 0, "ring");
+    constexpr int IP2 = 2 * IW + 4;   // floats per row PAIR of the interleaved input rows (see blur_kernel)
+    constexpr int RPITCH = kSW + 2;
+    static_assert((IP2 / 4) % 2 == 1, "pitch");
+    __shared__ __attribute__((aligned(16))) float s_in[(kRS / 2) * IP2];
+    __shared__ __attribute__((aligned(16))) float s_row[NR * RPITCH];
+    const int x0 = blockIdx.x * kSW, y0 = blockIdx.y * ch, y1 = min(y0 + ch, h);
+    const int tid = threadIdx.x;
+    const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    constexpr int NPF = (kRS * NV + 255) / 256;
+    float4 pf[NPF];
+    // input rows of step t: y0 - R + kRS t .. + kRS - 1 (reflected into the plane)
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int e = tid + 256 * q;
+            const int ec = e < kRS * NV ? e : kRS * NV - 1;
+            const int ly = ec / NV, v = ec - ly * NV;
+            const int gy = reflect101(y0 - R + kRS * t + ly, h), gx = x0 - RP + 4 * v;
+            const float* row = in + (size_t)gy * w;
+            if (vec_ok && gx >= 0 && gx + 3 < w) {
+                pf[q] = *reinterpret_cast<const float4*>(row + gx);
+            } else {
+                pf[q].x = row[reflect101(gx, w)];
+                pf[q].y = row[reflect101(gx + 1, w)];
+                pf[q].z = row[reflect101(gx + 2, w)];
+                pf[q].w = row[reflect101(gx + 3, w)];
+            }
+        }
+    };
+    const int n_batches = (y1 - y0 + kRS - 1) / kRS;  // output batches of kRS rows
+    const int n_steps = n_batches + LAG;
+    fetch(0);
+    for (int t = 0; t < n_steps; ++t) {
+        // a. park the rows of step t (row-interleaved pairs), request those of step t + 1
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int e = tid + 256 * q;
+            if (e < kRS * NV) {
+                const int ly = e / NV, v = e - ly * NV;
+                float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
+                dst[0] = pf[q].x;
+                dst[2] = pf[q].y;
+                dst[4] = pf[q].z;
+                dst[6] = pf[q].w;
+            }
+        }
+        if (t + 1 < n_steps) fetch(t + 1);
+        __syncthreads();
+        // b. row pass on the kRS new rows: kRS / 2 row pairs x kSW / 8 segments of 8 outputs -> ring rows kRS t ...
+        for (int u = tid; u < (kRS / 2) * (kSW / 8); u += 256) {
+            const int seg = u / (kRS / 2), p = u - seg * (kRS / 2), xb = seg * 8;
+            const f32x2* src = reinterpret_cast<const f32x2*>(&s_in[p * IP2 + 2 * (OFF + xb)]);
+            f32x2 v[8 + 2 * R], acc[8];
+#pragma unroll
+            for (int j = 0; j < 8 + 2 * R; ++j) v[j] = src[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.f, 0.f};
+            static_for<0, 2 * R + 1>([&](auto T) {
+                constexpr int tt = decltype(T)::value;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pk_tap<tt>(acc[j], gk, v[j + tt]);
+            });
+            const int rel = kRS * t + 2 * p;  // input row index relative to y0 - R
+            float* d0 = &s_row[(rel & (NR - 1)) * RPITCH + xb];
+            float* d1 = &s_row[((rel + 1) & (NR - 1)) * RPITCH + xb];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d0[j] = acc[j].x;
+                d1[j] = acc[j].y;
+            }
+        }
+        __syncthreads();
+        // c. column pass for output batch k = t - LAG: output row y0 + o reads ring rows o .. o + 2 R
+        const int k = t - LAG;
+        if (k >= 0) {
+            const int u = tid;  // 64 column pairs x kRS / 4 groups of 4 rows = 256 work items
+            const int lx = 2 * (u & (kSW / 2 - 1)), yb = kRS * k + (u / (kSW / 2)) * 4;
+            f32x2 v[4 + 2 * R], acc[4];
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * R; ++j) v[j] = *reinterpret_cast<const f32x2*>(&s_row[((yb + j) & (NR - 1)) * RPITCH + lx]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
+            static_for<0, 2 * R + 1>([&](auto T) {
+                constexpr int tt = decltype(T)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk_tap<tt>(acc[j], gk, v[j + tt]);
+            });
+            const int gx = x0 + lx;
+            if (gx + 1 < w && (w & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gy = y0 + yb + j;
+                    if (gy < y1) *reinterpret_cast<f32x2*>(&out[(size_t)gy * w + gx]) = acc[j];
+                }
+            } else if (gx < w) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gy = y0 + yb + j;
+                    if (gy < y1) {
+                        out[(size_t)gy * w + gx] = acc[j].x;
+                        if (gx + 1 < w) out[(size_t)gy * w + gx + 1] = acc[j].y;
+                    }
+                }
+            }
+            if (dec && (gx >> 1) < dw) {  // gx, y0 + yb are even (ch and kRS are)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int gy = y0 + yb + j, dy = gy >> 1;
+                    if (gy < y1 && dy < dh) dec[(size_t)dy * dw + (gx >> 1)] = acc[j].x;
+                }
+            }
+        }
+        __syncthreads();  // the next step parks into s_in and writes ring rows this one has read
+    }
+}
+
 // generic fallback for unusual radii: two plain passes through global memory (same arithmetic)
 __global__ void blur_row_generic(const float* __restrict__ in, int h, int w, GaussK gk, float* __restrict__ out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -618,6 +750,138 @@ struct PyrTable {
     int n_oct, nl;
     float sigma;
 };
+
+// ---- the same sweep, marching (default) -----------------------------------------------------------------------------
+// scripts/probe/mem_pattern.hip: the seven planes of octave 0 stream at 6.1 TB/s read linearly, at 4.0 TB/s (useful
+// bytes) through 128 x 8 tiles with their halo, at 6.2 TB/s through 512-wide strips marched top to bottom - the tiles
+// were not slow, they re-read a third of their pixels as halo, and the LDS that holds all DoG planes of a tile kept them
+// from growing.  Here a workgroup owns a strip of kMI columns and CH rows of one octave and walks down it four rows at
+// a time: the next step's seven float4 per thread are requested before the current step is consumed, the DoG rows live
+// in a six-row ring in LDS (the two rows carried over + the four new ones), and a pixel is read ~1.05 times.  Every
+// octave of the image is swept by ONE launch (block table in ExtremaPlan).  Same window logic as extrema_kernel, same
+// cells (their order is irrelevant: they are sorted into the canonical keypoint order later).
+constexpr int kMW = 256;      // columns a workgroup loads per row: 64 float4, the outer four on each side are halo
+constexpr int kMI = kMW - 8;  // columns it owns
+struct ExtremaPlan {
+    int blk_ptr[17];  // first workgroup of octave o
+    int nstrip[16];   // strips per row of chunks
+    int ch[16];       // rows per chunk (multiple of 4)
+};
+
+template <int nl>
+__global__ __launch_bounds__(256) void extrema_march_kernel(const PyrTable* __restrict__ pt, ExtremaPlan plan, float thr,
+                                                            unsigned long long* __restrict__ cells,
+                                                            unsigned int* __restrict__ count, unsigned int cap) {
+    constexpr int NG = nl + 3, ND = nl + 2, RING = 6, TW = kMW;
+    __shared__ __attribute__((aligned(16))) float s_d[ND][RING * TW];
+    constexpr int kLocalCap = 256;
+    __shared__ unsigned long long s_cells[kLocalCap];
+    __shared__ unsigned int s_n, s_base;
+    int o = 0;
+    while (o < 15 && (int)blockIdx.x >= plan.blk_ptr[o + 1]) ++o;
+    const OctaveDesc& od = pt->oct[o];
+    const int w = od.w, h = od.h;
+    const int local = (int)blockIdx.x - plan.blk_ptr[o];
+    const int strip = local % plan.nstrip[o], chunk = local / plan.nstrip[o];
+    const int x0 = strip * kMI - 4, y0 = chunk * plan.ch[o], y1 = min(y0 + plan.ch[o], h);
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0u;
+    const __attribute__((address_space(1))) float* G[NG];
+#pragma unroll
+    for (int p = 0; p < NG; ++p) G[p] = (const __attribute__((address_space(1))) float*)od.G[p];
+    const int lx4 = tid & 63, lr = tid >> 6;
+    const int gx = x0 + 4 * lx4;
+    const bool vec = (w & 3) == 0 && gx >= 0 && gx + 3 < w;
+    auto fetch = [&](int row, float4 g[NG]) __attribute__((always_inline)) {
+        const size_t rowoff = (size_t)min(max(row, 0), h - 1) * w;
+        if (vec) {
+#pragma unroll
+            for (int p = 0; p < NG; ++p) {
+                typedef float f32x4g __attribute__((ext_vector_type(4)));
+                const f32x4g v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4g*>(G[p] + rowoff + gx);
+                g[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+            const size_t o0 = rowoff + min(max(gx, 0), w - 1), o1 = rowoff + min(max(gx + 1, 0), w - 1);
+            const size_t o2 = rowoff + min(max(gx + 2, 0), w - 1), o3 = rowoff + min(max(gx + 3, 0), w - 1);
+#pragma unroll
+            for (int p = 0; p < NG; ++p) g[p] = make_float4(G[p][o0], G[p][o1], G[p][o2], G[p][o3]);
+        }
+    };
+    auto park = [&](int row, const float4 g[NG]) __attribute__((always_inline)) {
+        const int slot = (row - (y0 - 1)) % RING;
+#pragma unroll
+        for (int p = 0; p < ND; ++p)
+            *reinterpret_cast<float4*>(&s_d[p][slot * TW + 4 * lx4]) =
+                make_float4(g[p + 1].x - g[p].x, g[p + 1].y - g[p].y, g[p + 1].z - g[p].z, g[p + 1].w - g[p].w);
+    };
+    float4 g[NG];
+    if (lr < 2) {  // the two rows above the first step
+        fetch(y0 - 1 + lr, g);
+        park(y0 - 1 + lr, g);
+    }
+    fetch(y0 + 1 + lr, g);
+    const int lx = tid, c = x0 + lx;
+    const int lxc = min(max(lx, 1), kMW - 2);  // (the outermost halo lanes own nothing; keep their reads inside the row)
+    const bool col_ok = lx >= 4 && lx < kMW - 4 && c >= kBorder && c < w - kBorder;
+    for (int ys = y0; ys < y1; ys += 4) {
+        park(ys + 1 + lr, g);                    // rows ys+1 .. ys+4
+        if (ys + 4 < y1) fetch(ys + 5 + lr, g);  // the next step's rows: in flight while this step is consumed
+        __syncthreads();
+        const int base = (ys - y0) % RING;  // ring slot of row ys-1
+        float wmax[3][4], wmin[3][4];
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            float hmx[6], hmn[6];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) {
+                int slot = base + rr;
+                slot = slot >= RING ? slot - RING : slot;
+                const float* row = &s_d[p][slot * TW + lxc - 1];
+                hmx[rr] = fmaxf(fmaxf(row[0], row[1]), row[2]);
+                hmn[rr] = fminf(fminf(row[0], row[1]), row[2]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wmax[p % 3][k] = fmaxf(fmaxf(hmx[k], hmx[k + 1]), hmx[k + 2]);
+                wmin[p % 3][k] = fminf(fminf(hmn[k], hmn[k + 1]), hmn[k + 2]);
+            }
+            if (p < 2) continue;
+            const int layer = p - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = ys + k;
+                if (!col_ok || r >= y1 || r < kBorder || r >= h - kBorder) continue;
+                int slot = base + k + 1;
+                slot = slot >= RING ? slot - RING : slot;
+                const float val = s_d[layer][slot * TW + lx];
+                if (!(fabsf(val) > thr)) continue;
+                const float mx = fmaxf(fmaxf(wmax[0][k], wmax[1][k]), wmax[2][k]);
+                const float mn = fminf(fminf(wmin[0][k], wmin[1][k]), wmin[2][k]);
+                const bool is_max = val > 0 && val >= mx, is_min = val < 0 && val <= mn;
+                if (!(is_max || is_min)) continue;
+                const unsigned long long cell = ((unsigned long long)o << 40) | ((unsigned long long)layer << 32) |
+                                                ((unsigned long long)r << 16) | (unsigned long long)c;
+                const unsigned int loc = atomicAdd(&s_n, 1u);
+                if (loc < (unsigned)kLocalCap) {
+                    s_cells[loc] = cell;
+                } else {
+                    const unsigned int slot2 = atomicAdd(count, 1u);
+                    if (slot2 < cap) cells[slot2] = cell;
+                }
+            }
+        }
+        __syncthreads();  // the next step parks into the slots this one has read
+    }
+    const unsigned int n_loc = min(s_n, (unsigned)kLocalCap);
+    if (n_loc == 0u) return;
+    if (tid == 0) s_base = atomicAdd(count, n_loc);
+    __syncthreads();
+    for (unsigned int e = tid; e < n_loc; e += 256) {
+        const unsigned int slot = s_base + e;
+        if (slot < cap) cells[slot] = s_cells[e];
+    }
+}
 
 // one lane per detected extremum: Newton refinement + contrast/edge tests (dense, no divergence against
 // the detection sweep)
@@ -984,6 +1248,35 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
     const int r = gk.n / 2;
     Prof prof("sift_blur");
     const dim3 grid(cdiv(w, kTW), cdiv(h, kTH));
+    // the marching form for planes that give it enough rows to walk (APS_BLUR_TILES=1: the tile kernel everywhere)
+    static const bool tiles_only = std::getenv("APS_BLUR_TILES") != nullptr;
+    if (!tiles_only && r >= 1 && r <= 12 && h >= 64 && w >= kSW) {
+        const int strips = cdiv(w, kSW);
+        int ch = (int)(((long long)h * strips + 1023) / 1024);  // about a thousand workgroups on the large planes
+        ch = std::max(4 * kRS, (ch + kRS - 1) / kRS * kRS);
+        const dim3 mg(strips, cdiv(h, ch));
+        switch (r) {
+#define APS_BLUR_CASE(R) \
+    case R:              \
+        blur_march_kernel<R><<<mg, 256, 0, stream()>>>(in, h, w, gk, out, dec, dh, dw, ch); \
+        break;
+            APS_BLUR_CASE(1)
+            APS_BLUR_CASE(2)
+            APS_BLUR_CASE(3)
+            APS_BLUR_CASE(4)
+            APS_BLUR_CASE(5)
+            APS_BLUR_CASE(6)
+            APS_BLUR_CASE(7)
+            APS_BLUR_CASE(8)
+            APS_BLUR_CASE(9)
+            APS_BLUR_CASE(10)
+            APS_BLUR_CASE(11)
+            APS_BLUR_CASE(12)
+#undef APS_BLUR_CASE
+        }
+        check_launch("blur_march_kernel");
+        return dec != nullptr;
+    }
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
@@ -1111,6 +1404,38 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         unsigned int h_counts[2] = {0, 0};
         for (int attempt = 0; attempt < 2; ++attempt) {
             APS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned int), stream()));
+            if (!std::getenv("APS_EXTREMA_TILES")) {
+                // one marching launch over all octaves (extrema_march_kernel)
+                ExtremaPlan plan;
+                std::memset(&plan, 0, sizeof plan);
+                int run = 0;
+                for (int o = 0; o < 16; ++o) {
+                    plan.blk_ptr[o] = run;
+                    plan.nstrip[o] = plan.ch[o] = 1;
+                    if (o >= n_oct) continue;
+                    const OctaveDesc& od = table.oct[o];
+                    if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
+                    const int ns = cdiv(od.w, kMI);
+                    // rows per chunk: about a thousand workgroups for the large octaves, never fewer than 16 rows
+                    int ch = (int)(((long long)od.h * ns + 1023) / 1024);
+                    ch = std::max(16, (ch + 3) & ~3);
+                    plan.nstrip[o] = ns;
+                    plan.ch[o] = ch;
+                    run += ns * cdiv(od.h, ch);
+                }
+                plan.blk_ptr[16] = run;
+                if (run > 0) {
+                    Prof prof("sift_extrema");
+                    switch (nl) {
+                        case 1: extrema_march_kernel<1><<<run, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 2: extrema_march_kernel<2><<<run, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 3: extrema_march_kernel<3><<<run, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 4: extrema_march_kernel<4><<<run, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        default: extrema_march_kernel<5><<<run, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                    }
+                    check_launch("extrema_march_kernel");
+                }
+            } else
             for (int o = 0; o < n_oct; ++o) {
                 const OctaveDesc& od = table.oct[o];
                 if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;

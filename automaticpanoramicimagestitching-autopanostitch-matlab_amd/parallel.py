@@ -204,16 +204,93 @@ class ImageGather:
         self.per = per
         self.work = _all_gather_into(self.recv, self.send, async_op=True)
 
+    def finish(self):
+        """Blocks until the collective has completed (idempotent).  Called before the matching stage: the int8 screening
+        kernel claims whole CUs (match_screen_i8_kernel), so a collective left running beside it would only time-slice
+        against it - and nothing may share a SIMD with its waves."""
+        if self.ws > 1 and self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.recv.is_cuda:
+                torch.cuda.current_stream().synchronize()
+
     def wait(self):
         if self.ws == 1:
             return [self.local[i] for i in range(self.n)]
-        if self.work is not None:
-            self.work.wait()
+        self.finish()
         out = []
         for i in range(self.n):
             h, w, c = self.shapes[i]
             out.append(self.recv[(i % self.ws) * self.per + i // self.ws, : h * w * c].reshape(h, w, c))
         return out
+
+
+class FeatureExchange:
+    """The descriptor exchange in chunks that overlap the extraction: image i lives on rank
+    i % world in slot i // world; the slots are cut into `rounds` chunks, and as soon as a rank's images of a chunk are
+    extracted the chunk is all-gathered (descriptors: one padded collective, keypoints: a second, small one) while the
+    worker streams go on with the next chunk.  Per chunk the only host visit is the count exchange (one small
+    all-gather), which the main thread waits for while the GPU keeps extracting.  Every rank runs the same rounds, also
+    those in which it owns no image.
+    futures: dict image index -> future resolving to (descriptors [k,128] float32 tensor, keypoints [k,2] float64
+    numpy or tensor); dev: device of the exchanged tensors."""
+
+    def __init__(self, futures, n, dev, rounds=4):
+        self.ws, self.rank = world()
+        self.n, self.dev = n, dev
+        self.per = (n + self.ws - 1) // self.ws
+        rounds = max(1, min(int(os.environ.get("APS_EXCHANGE_ROUNDS", rounds)), self.per))
+        self.chunk = (self.per + rounds - 1) // rounds
+        self.rounds = (self.per + self.chunk - 1) // self.chunk
+        self.futures = futures
+        self.parts = []  # per round: (slot0, nslot, counts [ws, nslot], desc buffer, kps buffer, handles)
+
+    def run(self):
+        """Issues every round (blocking on the local futures of each in turn); returns self."""
+        ws, rank, C = self.ws, self.rank, self.chunk
+        for r in range(self.rounds):
+            s0 = r * C
+            ns = min(C, self.per - s0)
+            mine = [(s, s * ws + rank) for s in range(s0, s0 + ns) if s * ws + rank < self.n]
+            got = {s: self.futures[i].result() for (s, i) in mine}
+            cnt = torch.zeros(ns, dtype=torch.int64)
+            for s, (d, _) in got.items():
+                cnt[s - s0] = int(d.shape[0])
+            cnt = cnt.to(self.dev)
+            cnt_all = torch.empty(ws * ns, dtype=torch.int64, device=self.dev)
+            _all_gather_into(cnt_all, cnt)
+            counts = cnt_all.cpu().view(ws, ns)  # the one host visit of the round
+            m = max(int(counts.max()), 1)
+            send_d = torch.zeros((ns, m, 128), dtype=torch.float32, device=self.dev)
+            send_k = torch.zeros((ns, m, 2), dtype=torch.float64, device=self.dev)
+            for s, (d, p) in got.items():
+                k = int(d.shape[0])
+                send_d[s - s0, :k] = d
+                send_k[s - s0, :k] = p if torch.is_tensor(p) else torch.from_numpy(np.ascontiguousarray(p))
+            # (the futures resolve after their worker's stream has drained; the packing above and the collectives below are
+            # ordered by torch's current stream)
+            recv_d = torch.empty((ws, ns, m, 128), dtype=torch.float32, device=self.dev)
+            recv_k = torch.empty((ws, ns, m, 2), dtype=torch.float64, device=self.dev)
+            h1 = _all_gather_into(recv_d.view(ws * ns, m, 128), send_d, async_op=True)
+            h2 = _all_gather_into(recv_k.view(ws * ns, m, 2), send_k, async_op=True)
+            self.parts.append((s0, ns, counts, recv_d, recv_k, (h1, h2), (send_d, send_k)))
+        return self
+
+    def wait(self):
+        """(descriptors, keypoints) of all n images on every rank, as views into the gathered chunk buffers."""
+        descs, kps = [None] * self.n, [None] * self.n
+        for (s0, ns, counts, recv_d, recv_k, handles, _keep) in self.parts:
+            for hnd in handles:
+                if hnd is not None:
+                    hnd.wait()
+            for r in range(self.ws):
+                for q in range(ns):
+                    i = (s0 + q) * self.ws + r
+                    if i < self.n:
+                        k = int(counts[r, q])
+                        descs[i] = recv_d[r, q, :k]
+                        kps[i] = recv_k[r, q, :k]
+        return descs, kps
 
 
 def tile_rects(H, W, tile):
@@ -256,7 +333,7 @@ def gather_tiles_to_root(pano, tile, root=0):
     return pano
 
 
-def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
+def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None):
     """Steps 1-4 on the current images: SIFT on the local shard, the descriptor exchange, the sharded pair matching
     and the sharded RANSAC verification (main.m:88-107 up to imageMatching).  Everything that is exchanged stays on
     the device; the host sees counts, candidate lists and the 3 x 3 models.
@@ -309,23 +386,28 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None):
         pown = np.zeros(len(order), np.int64)
         times.add("exchange", time.perf_counter())
     else:
-        # 1) SIFT on the local shard
-        t0 = time.perf_counter()
-        ldesc, lkps = {}, {}
-        if mine_img:
-            for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
-                ldesc[i] = d
-                lkps[i] = torch.from_numpy(p).to(dev)
-        times.add("features", t0)
-
-        # 2) the exchange: descriptors (one all-gather), keypoints (small)
+        # 1) SIFT on the local shard; 2) the exchange of descriptors and keypoints.  With more than one rank the exchange
+        # runs in chunks BESIDE the extraction (FeatureExchange): a chunk is all-gathered while the worker streams
+        # extract the next one, so only the last chunk's collective is left on the critical path.
         t0 = time.perf_counter()
         if ws > 1:
-            descs = gather_by_owner(ldesc, owner, n, torch.empty((0, 128), dtype=torch.float32, device=dev), None)
-            kps_t = gather_by_owner(lkps, owner, n, torch.empty((0, 2), dtype=torch.float64, device=dev), None)
-            descs = [d.contiguous() for d in descs]
-            torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
+            futs = dict(zip(mine_img, pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready))) if mine_img else {}
+            ex = FeatureExchange(futs, n, dev).run()
+            times.add("features", t0)  # (the last local image is extracted; all but the last chunk have been sent)
+            t0 = time.perf_counter()
+            descs, kps_t = ex.wait()
+            if before_match is not None:
+                before_match()  # e.g. the early image all-gather: no collective may run beside the matching kernels
+            if dev.type == "cuda":
+                torch.cuda.synchronize()  # gathered blocks are produced on RCCL's / torch's streams, consumed on the library's
         else:
+            ldesc, lkps = {}, {}
+            if mine_img:
+                for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
+                    ldesc[i] = d
+                    lkps[i] = torch.from_numpy(p).to(dev)
+            times.add("features", t0)
+            t0 = time.perf_counter()
             descs = [ldesc[i] for i in range(n)]
             kps_t = [lkps[i] for i in range(n)]
         counts = [int(d.shape[0]) for d in descs]
@@ -473,7 +555,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     img_gather = ImageGather(local_images, n, dev)
     times.add("exchange", t0)
 
-    res = _match_pass(input, local_images, n, seed, times, dev, image_events)
+    res = _match_pass(input, local_images, n, seed, times, dev, image_events, before_match=img_gather.finish)
 
     # 5) host segment (redundant on every rank): components, second pass if asked for, cameras per component
     t0 = time.perf_counter()
@@ -508,7 +590,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         img_gather = ImageGather(local_images, n, dev)
         times.add("exchange", t0)
         first_counts = res["counts"]
-        res = _match_pass(input, local_images, n, seed, times, dev)
+        res = _match_pass(input, local_images, n, seed, times, dev, before_match=img_gather.finish)
         res["second_pass"], res["counts_first_pass"] = True, first_counts
     t0 = time.perf_counter()
     comps = pl.recognize_panoramas(n, res["pairs"], res["models"], res["num_matches"], Ks, labels, cameras)

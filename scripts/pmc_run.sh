@@ -3,6 +3,7 @@
 # Runs separate rocprofv3 --pmc passes (never combined with sys/hip traces) and prints per-kernel counter sums.
 KERN="$1"; OUT="$2"; shift 2; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT" ;; esac   # (the passes run from /tmp: a relative path is meant from the repo root)
 cd /tmp && export TMPDIR=/tmp
 : > "$OUT"
 i=0

@@ -61,8 +61,9 @@ def test_sift_4k_is_deterministic_and_well_formed(mods):
 
 
 def test_render_4k_multitile_batched_equals_per_tile_path(mods, monkeypatch):
-    """16 4K views (4 x 4 grid), 2048^2 tiles, 5 bands: the batched level-major path (render_batch.hip) against the
-    per-tile path with its footprint culls, block-level image cull and fused levels all off."""
+    """16 4K views (4 x 4 grid), 2048^2 tiles, 5 bands: the batched level-major path (render_batch.hip, warp in its
+    exact mode) against the per-tile path with its footprint culls, block-level image cull and fused levels all off,
+    byte for byte; then the default fast warp against those within the stated tolerance."""
     import torch
 
     synth, rp = mods["synth"], mods["renderPanorama"]
@@ -73,9 +74,9 @@ def test_render_4k_multitile_batched_equals_per_tile_path(mods, monkeypatch):
     opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
     sizes = [(H, W, 3)] * 16
     outs = []
-    keys = ("APS_RENDER_LEGACY", "APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE", "APS_RENDER_CHECK_RECTS")
-    for env in ({"APS_RENDER_CHECK_RECTS": "1"}, {"APS_RENDER_LEGACY": "1"},
-                {"APS_RENDER_LEGACY": "1", "APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}):
+    keys = ("APS_RENDER_LEGACY", "APS_RENDER_NO_CULL", "APS_RENDER_NO_FUSE", "APS_RENDER_CHECK_RECTS", "APS_WARP_EXACT")
+    for env in ({"APS_RENDER_CHECK_RECTS": "1", "APS_WARP_EXACT": "1"}, {"APS_RENDER_LEGACY": "1"},
+                {"APS_RENDER_LEGACY": "1", "APS_RENDER_NO_CULL": "1", "APS_RENDER_NO_FUSE": "1"}, {}):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -86,6 +87,10 @@ def test_render_4k_multitile_batched_equals_per_tile_path(mods, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert outs[0].shape[0] > 4096 and outs[0].shape[1] > 8192 and int((outs[0] > 0).sum()) > 5e7
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # the default (fast-warp) render against the exact one: within one grey level on >= 99.95 %, never more than two
+    dd = (outs[3].to(torch.int16) - outs[0].to(torch.int16)).abs()
+    assert int(dd.max()) <= 2 and float((dd <= 1).float().mean()) >= 0.9995
+    assert float((dd == 0).float().mean()) >= 0.97
 
 
 def test_crop_rectangle_on_a_large_canvas(mods):

@@ -66,6 +66,28 @@ def _worker(rank, world, port, q):
         gotm = par.ImageGather(mixed, 3, dev).wait()
         assert [tuple(g.shape) for g in gotm] == [(2, 3, 3), (3, 3, 3), (4, 3, 3)]
         assert all(bool((g == i + 1).all()) for i, g in enumerate(gotm))
+        # the chunked feature exchange: 7 images, image i on rank i % world with 3 + 2 i descriptors; the local futures
+        # resolve late and out of order (a worker pool), every rank runs the same rounds
+        from concurrent.futures import ThreadPoolExecutor
+        import time as _time
+
+        nimg = 7
+
+        def extract(i):
+            _time.sleep(0.01 * ((i * 5) % 3))
+            k = 3 + 2 * i
+            d = torch.full((k, 128), float(i), dtype=torch.float32) + torch.arange(k, dtype=torch.float32)[:, None]
+            return d, np.stack([np.arange(k, dtype=np.float64) + 0.25 * i, np.full(k, float(i))], axis=1)
+
+        with ThreadPoolExecutor(3) as pool:
+            futs = {i: pool.submit(extract, i) for i in par.shard_indices(nimg, world, rank)}
+            for rounds in (1, 2, 4):
+                ex = par.FeatureExchange(futs, nimg, dev, rounds=rounds).run()
+                assert ex.rounds == min(rounds, (nimg + world - 1) // world)
+                descs, kps = ex.wait()
+                for i in range(nimg):
+                    d, p = extract(i)
+                    assert torch.equal(descs[i], d) and np.array_equal(kps[i].numpy(), p), (rounds, i)
         # tiles to the root: canvas 7x10x3 with 3x4 tiles (ragged edge tiles), tile t painted with t+1 by rank t % world
         H, W = 7, 10
         rects = par.tile_rects(H, W, (3, 4))

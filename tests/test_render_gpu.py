@@ -412,6 +412,11 @@ def test_batched_multiband_equals_per_tile_path(rp, monkeypatch, mode, levels, t
     opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": levels, "pyrSigma": sigma, "tile": tile,
             "cropBorder": False, "canvasColor": "white" if white else "black", "margin": 0.08}
     monkeypatch.delenv("APS_RENDER_LEGACY", raising=False)
+    # the default batched warp samples with reciprocals instead of IEEE divisions (tolerance against the per-tile path
+    # below); APS_WARP_EXACT=1 keeps the per-tile arithmetic in the warp, so that everything ELSE in the batched pipeline
+    # is still pinned byte for byte
+    fast, _, fcov, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 2, opts, gains=gains, return_covered=True)
+    monkeypatch.setenv("APS_WARP_EXACT", "1")
     # APS_RENDER_CHECK_RECTS: the analytic (host) footprints of the cylindrical / spherical canvases are checked against the
     # exact coverage kernel inside the call - every exact footprint must lie inside its analytic rectangle
     monkeypatch.setenv("APS_RENDER_CHECK_RECTS", "1")
@@ -426,6 +431,13 @@ def test_batched_multiband_equals_per_tile_path(rp, monkeypatch, mode, levels, t
     assert cov.sum() > 20000 and (cov == 0).sum() > 100
     assert np.array_equal(cov, rcov)
     assert np.array_equal(pano, ref)
+    # the fast warp against the exact one: the SAME coverage (rays near an image border are re-projected exactly),
+    # colours within one grey level (two at most) - the tolerance the oracle comparison states
+    assert np.array_equal(fcov, cov)
+    both = (fcov == 1) & (cov == 1)
+    dd = np.abs(fast.astype(int) - pano.astype(int))[both]
+    assert dd.max() <= 2 and (dd <= 1).mean() >= 0.9995, (dd.max(), (dd <= 1).mean())
+    assert (dd == 0).mean() >= 0.97, (dd == 0).mean()
 
 
 def test_batched_multiband_tile_subsets_compose(rp, monkeypatch):
