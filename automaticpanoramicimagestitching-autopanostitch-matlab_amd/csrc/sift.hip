@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     }
 }
 
-// ---- the same blur, marching (default for planes tall enough) ---------------------------------------------------------
+// ---- the same blur, marching (experiment, APS_BLUR_MARCH=1; see launch_blur for the measurement) ------------------------
 // The tile kernel above fetches (kTW + 2 RP) x (kTH + 2 R) inputs for kTW x kTH outputs - 1.4x (R = 4) to 2.2x (R = 10)
 // of the plane through L2 - and row-filters the vertical halo of every tile again.  Here a workgroup owns kSW columns and
 // `ch` rows of the plane and walks down them kRS input rows at a time: the next step's rows are requested before the
@@ -1248,9 +1248,13 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
     const int r = gk.n / 2;
     Prof prof("sift_blur");
     const dim3 grid(cdiv(w, kTW), cdiv(h, kTH));
-    // the marching form for planes that give it enough rows to walk (APS_BLUR_TILES=1: the tile kernel everywhere)
-    static const bool tiles_only = std::getenv("APS_BLUR_TILES") != nullptr;
-    if (!tiles_only && r >= 1 && r <= 12 && h >= 64 && w >= kSW) {
+    // The marching form (APS_BLUR_MARCH=1) is an experiment that did NOT pay: bit-identical, but 66 / 75 / 109 us per
+    // 33 MPix plane at R = 4 / 5 / 10 against the tile kernel's 60 / 60 / 83 (profiles/r03f_sift_trace.txt).  Unlike the
+    // extrema sweep the blur is not a pure stream: at R = 10 its 42 fma per output and ~1.5 GB of LDS traffic per plane
+    // already cost what the memory system does, and the march adds three barriers per 16 rows with only 3-6 workgroups
+    // per CU to cover them.
+    static const bool march = std::getenv("APS_BLUR_MARCH") != nullptr;
+    if (march && r >= 1 && r <= 12 && h >= 64 && w >= kSW) {
         const int strips = cdiv(w, kSW);
         int ch = (int)(((long long)h * strips + 1023) / 1024);  // about a thousand workgroups on the large planes
         ch = std::max(4 * kRS, (ch + kRS - 1) / kRS * kRS);

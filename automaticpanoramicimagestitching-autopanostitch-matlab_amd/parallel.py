@@ -333,7 +333,7 @@ def gather_tiles_to_root(pano, tile, root=0):
     return pano
 
 
-def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None):
+def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None, after_features=None):
     """Steps 1-4 on the current images: SIFT on the local shard, the descriptor exchange, the sharded pair matching
     and the sharded RANSAC verification (main.m:88-107 up to imageMatching).  Everything that is exchanged stays on
     the device; the host sees counts, candidate lists and the 3 x 3 models.
@@ -412,6 +412,8 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
             kps_t = [lkps[i] for i in range(n)]
         counts = [int(d.shape[0]) for d in descs]
         times.add("exchange", t0)
+        if after_features is not None:
+            after_features()  # caller's hook: the worker streams are idle from here until the next extraction
 
         # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
         t0 = time.perf_counter()
@@ -527,7 +529,7 @@ def _sync_lib():
 
 
 def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None,
-                       local_originals=None, image_events=None):
+                       local_originals=None, image_events=None, after_features=None):
     """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
     local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
     pano_root: None = every panorama is combined on every rank; r = only rank r receives the tiles / panoramas of the
@@ -537,6 +539,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     extract -> match -> verify chain runs a second time (imageMatchingPanoramaConComps.m:48-91).
     image_events: dict image index -> torch CUDA event that marks the local image as uploaded (end-to-end runs issue
     the host-to-device copies on a side stream; SIFT of image k then waits for event k only).
+    after_features: optional callable run once the (first-pass) feature extraction has finished and before the matching
+    starts - the point from which the per-image worker streams are idle; a caller that streams the PREVIOUS result to
+    the host starts that copy here, where it cannot sit in front of a worker stream's kernels in a shared hardware queue.
     Returns (panorama of the component that holds the best-connected image, uint8 H x W x 3 CUDA tensor; info dict
     with info["panoramas"]: one entry per connected component of at least two images, in component order)."""
     from . import pipeline as pl
@@ -555,7 +560,8 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     img_gather = ImageGather(local_images, n, dev)
     times.add("exchange", t0)
 
-    res = _match_pass(input, local_images, n, seed, times, dev, image_events, before_match=img_gather.finish)
+    res = _match_pass(input, local_images, n, seed, times, dev, image_events, before_match=img_gather.finish,
+                      after_features=after_features)
 
     # 5) host segment (redundant on every rank): components, second pass if asked for, cameras per component
     t0 = time.perf_counter()

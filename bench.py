@@ -238,31 +238,32 @@ def main():
     host_imgs, copy_stream = {}, None
     if args.end_to_end == "auto":
         host_imgs = {i: torch.empty(local[i].shape, dtype=torch.uint8, pin_memory=True).copy_(local[i]) for i in mine}
-        copy_stream = torch.cuda.Stream()
+        copy_stream = torch.cuda.Stream(priority=-1)
 
-    # The device-to-host copy of step k's panorama runs on a side stream into one of two pinned buffers while step
-    # k + 1 extracts its features (the copy engines use no CU): what a production loop that stitches set after set does.
-    # Every panorama has landed before the closing barrier of the timed region (drain()), so `value` is the rate at
-    # which finished panoramas reach the host; the un-overlapped cost of one copy is reported as download_ms_alone and
-    # the latency of a single step as ms_per_step_latency.
-    out_stream = torch.cuda.Stream()
+    # The device-to-host copy of step k's panorama (737 MB, ~13 ms of PCIe) is started while step k + 1 is MATCHING and
+    # lands in one of two pinned buffers: what a production loop that stitches set after set does.  (Started at once it
+    # overlaps step k + 1's feature extraction instead and costs that stage more than it saves - measured +10-15 ms:
+    # the HIP runtime maps the copy stream onto a hardware queue it shares with per-image worker streams, whose kernels
+    # then wait behind the transfer; during the matching those streams are idle.)  Every panorama has landed before the
+    # closing barrier of the timed region (drain()), so `value` is the rate at which finished panoramas reach the host;
+    # the un-overlapped cost of one copy is reported as download_ms_alone, the latency of one isolated step as
+    # ms_per_step_latency.
+    # (a HIGH-priority stream: the runtime keeps separate hardware queues per priority level, so the transfer never sits
+    # in a queue in front of a normal-priority stream's kernels - with a normal-priority copy stream the descriptor
+    # preparation of the matching stage, forked over eight auxiliary streams, went from 1.8 to 10.6 ms)
+    out_stream = torch.cuda.Stream(priority=-1)
     host_out = [None, None]
-    pending = []
+    pending = []    # copies in flight: (done event, host view, device tensor kept alive)
+    deferred = []   # device panoramas whose copy has not been started yet
     out_slot = [0]
 
-    def drain():
-        while pending:
-            done, _dst, _keep = pending.pop()
-            done.synchronize()
-
-    def to_host(pano_, wait=False):
+    def start_copy(pano_):
         need = pano_.numel()
         k = out_slot[0]
         out_slot[0] ^= 1
         if host_out[k] is None or host_out[k].numel() < need:
             host_out[k] = torch.empty(int(need * 1.05) + 1, dtype=torch.uint8, pin_memory=True)
         dst = host_out[k][:need].view(pano_.shape)
-        drain()  # the previous step's copy (long finished) before its buffer pair is touched again
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(out_stream):
@@ -270,10 +271,28 @@ def main():
             dst.copy_(pano_, non_blocking=True)
             done = torch.cuda.Event()
             done.record(out_stream)
-        pending.append((done, dst, pano_))  # (pano_ stays alive until its copy has run)
+        pending.append((done, dst, pano_))
+        return dst
+
+    def flush_deferred():
+        while pending:  # (the copy before last: long finished)
+            pending.pop(0)[0].synchronize()
+        while deferred:
+            start_copy(deferred.pop(0))
+
+    def drain():
+        flush_deferred()
+        while pending:
+            pending.pop(0)[0].synchronize()
+
+    def to_host(pano_, wait=False):
         if wait:
             drain()
-        return dst
+            dst = start_copy(pano_)
+            drain()
+            return dst
+        deferred.append(pano_)  # copied while the NEXT step is matching (or by drain() at the end of the run)
+        return pano_
 
     dl_alone = []
 
@@ -286,15 +305,16 @@ def main():
                     up[i] = host_imgs[i].to("cuda", non_blocking=True)
                     evs[i] = torch.cuda.Event()
                     evs[i].record(copy_stream)
-            pano_, info_ = par.stitch_distributed(input_, up, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs)
+            pano_, info_ = par.stitch_distributed(input_, up, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs,
+                                                  after_features=flush_deferred)
         else:
-            pano_, info_ = par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0)
+            pano_, info_ = par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0,
+                                                  after_features=flush_deferred)
         t_d = time.perf_counter()
         if rank == 0 and pano_ is not None and pano_.numel():
             pano_ = to_host(pano_, wait=sync_download)
         info_["times"]["download"] = time.perf_counter() - t_d
-        if sync_download:
-            dl_alone.append(info_["times"]["download"])
+
         info_["t_stitch"] = t_d - t_s
         return pano_, info_
 
@@ -303,16 +323,27 @@ def main():
     # include the dominant kernel, whose `roofline` is therefore measured live over the timed steps - and the
     # per-image / per-tile chains (SIFT, warp, pyramid) are bracketed during the last warm-up step instead.
     warm_prof, warm_steps = {}, 0
+    pano_w = None
     for k in range(args.warmup):
         last = k == args.warmup - 1
         if last:
             capi.profile_enable(1)
             capi.profile_reset()
-        step(sync_download=True)  # (warm-up steps wait for their own copy: its un-overlapped cost is reported)
+        pano_w, _ = step(sync_download=True)
         if last:
             barrier()
             warm_prof, warm_steps = capi.profile_all(), 1
             capi.profile_enable(False)
+    # the un-overlapped cost of one panorama copy (both pinned buffers exist by now): three synchronous copies of a
+    # canvas-sized device buffer, the fastest counts
+    if rank == 0 and args.warmup > 0 and pano_w is not None and pano_w.numel():
+        probe = torch.empty(tuple(pano_w.shape), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            to_host(probe, wait=True)
+            dl_alone.append(time.perf_counter() - t_c)
+        del probe
     capi.profile_enable(2 if warm_steps else 1)
     capi.profile_reset()
     barrier()
@@ -384,7 +415,7 @@ def main():
         # HBM-side bytes per launch from the committed PMC pass of THIS workload (scripts/hbm_traffic.sh ->
         # profiles/*_hbm_traffic.json: L2 memory-side requests x 64 B, one bench step); null for other configs
         traffic_db = {}
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02z_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03z_hbm_traffic.json")
         if world == 1 and (nx, ny, w, h, args.bands) == (8, 8, W, H, 5) and os.path.exists(tpath):
             traffic_db = json.load(open(tpath))
 
@@ -396,8 +427,10 @@ def main():
             return round(sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows) / launches)
 
         TRAFFIC_KEYS = {"match_screen_i8": ["match_screen_i8_kernel"], "match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
-                        "sift_blur": ["aps::blur_kernel<"], "render_warp": ["rw_warp_kernel"],
-                        "render_pyr_down": ["rw_down_kernel", "rw_up_kernel"]}
+                        "sift_blur": ["aps::blur_kernel<"], "render_warp": ["rw_warp_staged_kernel", "rw_warp_kernel"],
+                        "render_pyr_down": ["rw_down_fused_kernel", "rw_down_kernel", "rw_up_kernel"]}
+        SIFT_KERNELS = ["blur_kernel", "blur_march_kernel", "extrema_march_kernel", "extrema_kernel", "gray_up_kernel", "descr_kernel",
+                        "orient_kernel", "refine_kernel", "decimate_kernel"]
 
         def roof(kernel, name, bound, work_per_step, peak, unit, note="", streams=1):
             keys = [kernel] if isinstance(kernel, str) else list(kernel)  # several launch sites of one chain are summed
@@ -418,7 +451,8 @@ def main():
                  "timed": "live over the timed steps" if kernel in live else "during the last warm-up step"}
             if r["traffic"] is not None:
                 r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
-                                     "pass of this workload (profiles/r02z_hbm_traffic.txt)")
+                                     "pass of this workload (profiles/r03z_hbm_traffic.txt); replayed from that committed file, "
+                                     "not observed in this run")
             if note:
                 r["note"] = note
             return r
@@ -455,6 +489,22 @@ def main():
         ]
         cands = [c for c in cands if c]
         dominant = max(cands, key=lambda c: c["wall_share_ms"]) if cands else None
+        # The feature-extraction STAGE as one roofline entry (its kernels run on ten streams side by side, so per-kernel
+        # event sums overlap): algorithmic bytes of SURVEY 8(d)'s materialised-pyramid model, and the bytes the stage
+        # really moves (PMC pass), over the stage's wall time.
+        t_feat = sum(i["times"].get("features", 0.0) for i in infos) / len(infos)
+        if t_feat > 0:
+            sift_rows = [v for k, v in traffic_db.items() if any(n_ in k for n_ in SIFT_KERNELS)]
+            sift_bytes = sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in sift_rows) if sift_rows else None
+            ach = 574.0 * npix_rank0 / t_feat / 1e9
+            cands.append({"bound": "hbm", "kernel": "SIFT stage: all kernels of this rank's views on their worker streams (wall time of the stage)",
+                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                          "traffic": round(sift_bytes) if sift_bytes else None,
+                          "achieved_measured_bytes": round(sift_bytes / t_feat / 1e9, 2) if sift_bytes else None,
+                          "algorithmic_work_per_step": 574.0 * npix_rank0, "ms_per_step": round(1e3 * t_feat, 3),
+                          "note": "574 B per input pixel is the survey's model (G and DoG planes written and re-read); DoG planes are "
+                                  "not stored here, so `traffic` (bytes per STEP for this entry, all SIFT kernels) is lower; "
+                                  "achieved_measured_bytes = traffic / stage wall time"})
         stages = {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in infos[-1]["times"]}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 3), "launches_per_step": v[1] // max(args.steps, 1)}
                    for k, v in prof.items()}

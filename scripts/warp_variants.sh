@@ -3,9 +3,9 @@
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export APS_RENDER_WORKERS=1
-for v in exact 7 6 5 3 0; do
+for v in exact staged 6; do
   rm -rf /tmp/prof_$v
-  if [ "$v" = "exact" ]; then export APS_RENDER_EXACT=1; unset APS_WARP_VARIANT; else unset APS_RENDER_EXACT; export APS_WARP_VARIANT=$v; fi
+  if [ "$v" = "exact" ]; then export APS_RENDER_EXACT=1; unset APS_WARP_VARIANT; elif [ "$v" = "staged" ]; then unset APS_RENDER_EXACT; unset APS_WARP_VARIANT; else unset APS_RENDER_EXACT; export APS_WARP_VARIANT=$v; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -o p -- python3 scripts/probe_render.py 3 > /dev/null 2>&1 || { echo "variant $v failed"; exit 1; }
   python3 - "$v" <<PY
 import csv, sys
