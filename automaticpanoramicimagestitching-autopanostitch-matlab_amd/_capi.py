@@ -101,6 +101,8 @@ _SIGNATURES = {
     "aps_match_pairs": [C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _i, _i, _i, _vp, _vp, _i64,
                         C.POINTER(aps_match_opts), _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)],
     "aps_knn_global": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64],
+    "aps_knn_global_screened": [_vp, _i64, _i64, _i, _i, _vp, _i, _f, _i, _vp, _vp, _i64],
+    "aps_knn_global_screen_stats": [C.POINTER(_i64), C.POINTER(_i64)],
     "aps_global_filter": [_vp, _vp, _i64, _i, _i64, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i64,
                           C.POINTER(_i64)],
     "aps_hamming_2nn": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp],

@@ -224,6 +224,12 @@ inline void check_launch(const char* what) {
 // match.hip: the screening half of the blocked global k-NN (see the definition)
 int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& block_off,
                             std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b);
+// The pooled matcher's search with featureMatchingGlobal's filter in view (match.hip): rows the filter provably drops
+// at `ratio` are flagged in dismissed[] and not searched; for the others t3_* hold, per (row, image) slot, the certified
+// prefix of the three nearest rows of that image and the bound of its unlisted rows.
+int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
+                             std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
+                             int64_t* n_survivors);
 
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 

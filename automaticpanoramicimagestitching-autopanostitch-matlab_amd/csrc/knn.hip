@@ -251,6 +251,73 @@ __global__ void knn_merge_kernel(const int64_t* __restrict__ block_off, int nb, 
     }
 }
 
+// The same merge for the pooled matcher's screened search (screened_global_top3): blocks = images, EVERY image
+// (the row's own too) comes as a certified prefix of three with a bound; rows the filter provably drops are written as
+// four copies of themselves (featureMatchingGlobal.m:129-141 removes the self matches, fewer than two candidates
+// remain, the query is skipped) and are never looked up.
+__global__ void knn_merge3_kernel(const int64_t* __restrict__ block_off, int nb, const int64_t* __restrict__ job_off,
+                                  const uint8_t* __restrict__ dismissed, const uint32_t* __restrict__ t3_idx,
+                                  const float* __restrict__ t3_d, const float* __restrict__ t3_b, int64_t f, int k_out,
+                                  uint32_t* __restrict__ idx, float* __restrict__ dist, int64_t ldo, int layout,
+                                  uint32_t* __restrict__ unc_list, unsigned int* __restrict__ unc_count) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= f) return;
+    const int kk = k_out < 4 ? k_out : 4;
+    if (dismissed[q]) {
+        for (int e = 0; e < kk; ++e) {
+            const int64_t o = layout == APS_ROWMAJOR ? q * ldo + e : (int64_t)e * ldo + q;
+            idx[o] = (uint32_t)(q + 1);
+            dist[o] = 0.f;
+        }
+        return;
+    }
+    int lo = 0, hi = nb - 1;  // image of q
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_off[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int bi = lo;
+    const int64_t r = q - block_off[bi];
+    float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    long long id[4] = {-1, -1, -1, -1};
+    auto put = [&](float d, long long g) {
+        bool lt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lt[e] = id[e] < 0 || d < v[e] || (d == v[e] && g < id[e]);
+        if (!lt[3]) return;
+#pragma unroll
+        for (int e = 3; e >= 1; --e) {
+            v[e] = lt[e - 1] ? v[e - 1] : d;
+            id[e] = lt[e - 1] ? id[e - 1] : g;
+            if (!lt[e - 1]) return;
+        }
+        v[0] = d;
+        id[0] = g;
+    };
+    float bound = INFINITY;
+    for (int j = 0; j < nb; ++j) {
+        if (block_off[j + 1] == block_off[j]) continue;
+        const int64_t slot = job_off[(size_t)bi * nb + j] + r;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const uint32_t li = t3_idx[slot * 3 + e];
+            if (li) put(t3_d[slot * 3 + e], block_off[j] + (long long)li - 1);
+        }
+        bound = fminf(bound, t3_b[slot]);
+    }
+    const float dk = id[kk - 1] >= 0 ? v[kk - 1] : INFINITY;
+    const bool certified = dk < bound || !(bound < INFINITY);
+    if (certified) {
+        for (int e = 0; e < kk; ++e) {
+            const int64_t o = layout == APS_ROWMAJOR ? q * ldo + e : (int64_t)e * ldo + q;
+            idx[o] = id[e] >= 0 ? (uint32_t)(id[e] + 1) : 0u;
+            dist[o] = id[e] >= 0 ? v[e] : INFINITY;
+        }
+    } else {
+        unc_list[atomicAdd(unc_count, 1u)] = (uint32_t)q;
+    }
+}
+
 // Exact top-4 of one uncertified query row inside ONE block of the pool (one wave per (row, block); lane j takes the
 // block's rows j, j+64, ...).  d = (q2 + t2) - 2 G with G the k-ascending f32 fma chain: the arithmetic of knn_f32_kernel
 // (the MFMA computes that chain) on the k-permuted copies.  Each lane keeps its four nearest - a row among the block's
@@ -540,6 +607,8 @@ __global__ void pack_bytes_kernel(const uint8_t* __restrict__ X, int64_t n, int6
 
 using namespace aps;
 
+static thread_local int64_t g_global_rows = 0, g_global_surv = 0;  // aps_knn_global_screen_stats
+
 extern "C" {
 
 int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* query, int64_t fq, int64_t ldq,
@@ -646,6 +715,85 @@ int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* que
         od.commit();
         APS_HIP(hipStreamSynchronize(stream()));
     });
+}
+
+int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, int layout, const int64_t* img_off, int n_img,
+                            float ratio, int k, uint32_t* idx, float* dist, int64_t ldo) {
+    return guarded([&] {
+        APS_REQUIRE(dim == kDim, APS_E_DIM, "descriptor length %d not supported (built for %d-D SIFT)", dim, kDim);
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(k >= 1 && k <= 4, APS_E_ARG, "k in 1..4 (featureMatchingGlobal uses k = 4)");
+        APS_REQUIRE(img_off && n_img >= 1 && img_off[0] == 0 && img_off[n_img] == f, APS_E_ARG, "img_off must span the pool");
+        APS_REQUIRE(f >= 0 && f < (1ll << 31) && (f == 0 || (pool && idx && dist)), APS_E_ARG, "bad sizes / NULL argument");
+        APS_REQUIRE(ratio > 0.f && std::isfinite(ratio), APS_E_ARG, "ratio must be positive");
+        APS_REQUIRE(layout == APS_ROWMAJOR ? (ld >= dim && ldo >= k) : (ld >= f && ldo >= f), APS_E_DIM, "leading dimension too small");
+        for (int i = 0; i < n_img; ++i) APS_REQUIRE(img_off[i + 1] >= img_off[i], APS_E_ARG, "img_off must not decrease");
+        ctx();
+        if (f == 0) return;
+        const std::vector<int64_t> ioff(img_off, img_off + n_img + 1);
+        std::vector<int64_t> job_off;
+        const int64_t slots = screened_global_top3(nullptr, ld, layout, ioff, ratio, job_off, nullptr, nullptr, nullptr, nullptr, nullptr);
+        const bool fits = slots < ((int64_t)1 << 31) - 1;
+        if (!fits || f < 8192 || (std::getenv("APS_KNN_MODE") && !std::strcmp(std::getenv("APS_KNN_MODE"), "f32"))) {
+            // too many (row, image) slots for one pass, a tiny pool, or the exact mode asked for: the plain search
+            const int rc = aps_knn_global(pool, f, ld, pool, f, ld, dim, layout, k, idx, dist, ldo);
+            if (rc != APS_OK) {
+                const std::string why = aps_last_error();
+                fail(rc, "%s", why.c_str());
+            }
+            return;
+        }
+        const size_t te = layout == APS_ROWMAJOR ? (size_t)(f - 1) * ld + dim : (size_t)(dim - 1) * ld + f;
+        const size_t oe = layout == APS_ROWMAJOR ? (size_t)(f - 1) * ldo + k : (size_t)(k - 1) * ldo + f;
+        In<float> dT(pool, te);
+        Out<uint32_t> oi(idx, oe);
+        Out<float> od(dist, oe);
+        Ws<uint32_t> t3i((size_t)slots * 3);
+        Ws<float> t3d((size_t)slots * 3), t3b((size_t)slots);
+        Ws<uint8_t> dismissed((size_t)f);
+        int64_t n_surv = 0;
+        screened_global_top3(dT, ld, layout, ioff, ratio, job_off, t3i, t3d, t3b, dismissed, &n_surv);
+        Ws<int64_t> d_boff(n_img + 1), d_joff((size_t)n_img * n_img);
+        Ws<uint32_t> unc((size_t)f);
+        Ws<unsigned int> unc_n(1);
+        APS_HIP(hipMemcpyAsync(d_boff, ioff.data(), (n_img + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)n_img * n_img * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemsetAsync(unc_n, 0, sizeof(unsigned int), stream()));
+        {
+            Prof prof("knn_merge");
+            knn_merge3_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(d_boff, n_img, d_joff, dismissed, t3i, t3d, t3b, f, k, oi, od, ldo, layout,
+                                                                  unc, unc_n);
+        }
+        check_launch("knn_merge3_kernel");
+        unsigned int n_unc = 0;
+        APS_HIP(hipMemcpyAsync(&n_unc, unc_n, sizeof n_unc, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (n_unc) {  // (as in aps_knn_global: the exact top-4 of those rows in every image, then the head of the lists)
+            Prof prof("knn_exact_rows");
+            Ws<float> PT((size_t)f * kDim), sT((size_t)f);
+            knn_prep_kernel<<<cdiv(f, 64), 64, 0, stream()>>>(dT, f, ld, layout, PT, sT);
+            Ws<long long> li((size_t)n_unc * n_img * 4);
+            Ws<float> ldv((size_t)n_unc * n_img * 4);
+            knn_rows_block_top4_kernel<<<(unsigned)((size_t)n_unc * n_img), 64, 0, stream()>>>(PT, sT, unc, (int)n_unc, d_boff, n_img, li, ldv);
+            knn_rows_merge_kernel<<<cdiv(n_unc, 64), 64, 0, stream()>>>(unc, (int)n_unc, n_img, li, ldv, k, oi, od, ldo, layout);
+            check_launch("knn exact rows");
+            APS_HIP(hipStreamSynchronize(stream()));
+        }
+        if (std::getenv("APS_TRACE"))
+            std::fprintf(stderr, "[aps] screened pooled k-NN: %d images, %lld of %lld rows searched, %u recomputed exactly\n", n_img,
+                         (long long)n_surv, (long long)f, n_unc);
+        g_global_rows = f;
+        g_global_surv = n_surv;
+        oi.commit();
+        od.commit();
+        APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+int aps_knn_global_screen_stats(int64_t* rows, int64_t* survivors) {
+    if (rows) *rows = g_global_rows;
+    if (survivors) *survivors = g_global_surv;
+    return APS_OK;
 }
 
 int aps_global_normalize(const float* X, int64_t n, int64_t ld, int dim, int layout, float* out) {

@@ -1447,7 +1447,10 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
                                                                  uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
                                                                  float* __restrict__ out_d2, uint32_t* __restrict__ surv_list,
                                                                  unsigned int* __restrict__ surv_count, float prune_r2,
-                                                                 float prune_thr) {
+                                                                 float prune_thr, float* __restrict__ bounds_out) {
+    // bounds_out != nullptr (the pooled matcher, screened_global_top3): nothing is decided here; per (row, job) slot the
+    // three bounds L1 <= d1, H1 >= d1, H2 >= d2 on the row's two smallest distances in this job's column set are written
+    // (rounded outwards; -inf / +inf where nothing can be said) and a later pass combines them over a row's jobs.
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes];  // [buf][256][128 B], tile t in buf t % 3
     int wg = blockIdx.x;
     {  // XCD-aware order, as in match_cand_f16_kernel
@@ -1637,7 +1640,26 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
     const int row = row0 + 32 * h;
     const int e0 = h ? D0[1] : D0[0], e1 = h ? D1[1] : D1[0];
     bool survive = false;
-    if (row < nA) {
+    if (row < nA && bounds_out) {
+        const ScreenSet q = screen_set(jb);
+        const float inv_sa = jb.invsA[row];
+        float L1f = -INFINITY, H1f = INFINITY, H2f = INFINITY;
+        if (q.ok && inv_sa > 0.f && nB >= 1 && e0 != kNone) {
+            const double a2 = (double)jb.sqA[row];
+            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
+            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
+            const double sc = (double)inv_sa * (double)q.inv_sb;
+            const double off = (double)q.cb * (double)jb.sumqA[row];
+            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
+            L1f = __double2float_rd(a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta);
+            H1f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e0 + off) - E) + delta);
+            if (nB >= 2 && e1 != kNone) H2f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta);
+        }
+        float* bo = bounds_out + (size_t)(jb.out_off + row) * 3;
+        bo[0] = L1f;
+        bo[1] = H1f;
+        bo[2] = H2f;
+    } else if (row < nA) {
         const ScreenSet q = screen_set(jb);
         bool pruned = false;
         const float inv_sa = jb.invsA[row];
@@ -2007,7 +2029,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         {
             Prof prof("match_screen_i8");
             match_screen_i8_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list, surv_count,
-                                                                               prune_r2, prune_thr);
+                                                                               prune_r2, prune_thr, nullptr);
         }
         check_launch("match_screen_i8_kernel");
         std::vector<unsigned int> h_surv(jobs.size());
@@ -2209,6 +2231,230 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
     if (std::getenv("APS_TRACE"))
         std::fprintf(stderr, "[aps] blocked k-NN screen: %d blocks, %zu jobs, %lld slots, %zu uncertified (%.3f %%)\n", nb, jobs.size(),
                      (long long)slots, n_fb, 100.0 * (double)n_fb / (double)slots);
+    return slots;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pooled matcher (featureMatchingGlobal.m) with its filter in view
+// ------------------------------------------------------------------------------------------------
+// featureMatchingGlobal keeps query q only if, among its k nearest rows of the pool with q itself and the rows of q's own
+// image taken out, at least two remain and dist(first) / max(dist(second), eps) <= ratio (:129-147).  Blocks = images.
+// For every OTHER image j the int8 screen gives, per row, L1(j) <= the smallest distance into image j and H1(j), H2(j) >=
+// its smallest / second smallest one.  Let c1 <= c2 be the two smallest cross-image distances of q: c1 >= min_j L1(j) and
+// c2 <= min(second smallest H1(j), min_j H2(j)).  Whatever the k nearest are, the two cross-image rows the ratio test
+// compares are no nearer than c1 and c2 - so  min_j L1(j) > ratio * max(that upper bound, eps)  proves that q is dropped,
+// and only the other rows need their exact neighbours.
+__global__ __launch_bounds__(256) void global_screen_reduce_kernel(const float* __restrict__ bounds, const int64_t* __restrict__ img_off,
+                                                                   int n_img, const int64_t* __restrict__ job_off, int64_t f, float ratio,
+                                                                   uint8_t* __restrict__ dismissed, uint32_t* __restrict__ row_list,
+                                                                   unsigned int* __restrict__ list_count) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = q < f;
+    const int64_t qc = live ? q : f - 1;
+    int lo = 0, hi = n_img - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (img_off[mid] <= qc) lo = mid; else hi = mid - 1;
+    }
+    const int i = lo;
+    const int64_t r = qc - img_off[i];
+    // pass 1: the smallest lower bound and the three smallest upper bounds over the other images' columns
+    float lmin = INFINITY, h1a = INFINITY, h1b = INFINITY, h2m = INFINITY;
+    float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY;  // three smallest of {H1(j), H2(j)}: distinct columns each
+    auto put3 = [&](float h) {
+        if (h < u2) {
+            if (h < u1) {
+                u2 = u1;
+                if (h < u0) {
+                    u1 = u0;
+                    u0 = h;
+                } else {
+                    u1 = h;
+                }
+            } else {
+                u2 = h;
+            }
+        }
+    };
+    for (int j = 0; j < n_img; ++j) {
+        if (j == i || img_off[j + 1] == img_off[j]) continue;
+        const float* b = bounds + (size_t)(job_off[(size_t)i * n_img + j] + r) * 3;
+        const float l1 = b[0], h1 = b[1], h2 = b[2];
+        lmin = fminf(lmin, l1);
+        if (h1 < h1a) {
+            h1b = h1a;
+            h1a = h1;
+        } else if (h1 < h1b) {
+            h1b = h1;
+        }
+        h2m = fminf(h2m, h2);
+        put3(h1);
+        put3(h2);
+    }
+    const float hsec = fmaxf(fminf(h1b, h2m), 1.1920929e-07f);  // (the reference divides by max(second, eps('single')))
+    const bool drop = live && hsec < INFINITY && lmin > -INFINITY && lmin * (1.0f - 1e-5f) - 1e-30f > ratio * hsec * (1.0f + 1e-5f);
+    if (live) dismissed[q] = drop ? 1 : 0;
+    // pass 2: the images a surviving row has to be searched in.  Its k <= 4 nearest are itself and three more rows; three
+    // distinct rows of other images lie within u2, so a row of image j can be among them only if L1(j) <= u2 - every
+    // other image is skipped for this row (its unlisted rows are provably farther than the row's fourth neighbour).  The
+    // row's own image is always searched.  One list per job, appended with one atomic per wave and image.
+    const float cut = u2 < INFINITY ? u2 * (1.0f + 1e-5f) + 1e-30f : INFINITY;
+    const int lane = threadIdx.x & 63;
+    const int i_first = __shfl(i, 0), i_last = __shfl(i, 63);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int iw = pass ? i_last : i_first;  // a wave of consecutive rows spans at most two images of >= 64 rows; any
+        if (pass && i_last == i_first) break;    // further image in between is handled by the slow path below
+        for (int j = 0; j < n_img; ++j) {
+            if (img_off[j + 1] == img_off[j]) continue;
+            bool keep = live && !drop && i == iw;
+            if (keep && j != i) {
+                const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
+                keep = !(l1 * (1.0f - 1e-5f) - 1e-30f > cut);  // (NaN / -inf bounds keep the image)
+            }
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                const int job = iw * n_img + j;
+                unsigned int base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) base = atomicAdd(&list_count[job], (unsigned int)__popcll(m));
+                base = __shfl(base, leader);
+                if (keep) row_list[job_off[job] + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            }
+        }
+    }
+    if (live && !drop && i != i_first && i != i_last) {  // (images of fewer than 64 rows inside one wave)
+        for (int j = 0; j < n_img; ++j) {
+            if (img_off[j + 1] == img_off[j]) continue;
+            bool keep = true;
+            if (j != i) {
+                const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
+                keep = !(l1 * (1.0f - 1e-5f) - 1e-30f > cut);
+            }
+            if (keep) {
+                const int job = i * n_img + j;
+                row_list[job_off[job] + atomicAdd(&list_count[job], 1u)] = (uint32_t)r;
+            }
+        }
+    }
+}
+
+// (row, image) slots that are not searched: no candidates, and nothing unlisted there can matter (bound = +inf)
+__global__ void global_t3_init_kernel(uint32_t* __restrict__ t3_idx, float* __restrict__ t3_d, float* __restrict__ t3_b, int64_t slots) {
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    t3_idx[s * 3] = t3_idx[s * 3 + 1] = t3_idx[s * 3 + 2] = 0u;
+    t3_d[s * 3] = t3_d[s * 3 + 1] = t3_d[s * 3 + 2] = INFINITY;
+    t3_b[s] = INFINITY;
+}
+
+// X_dev: the (normalised) pool; img_off: n + 1 row offsets of the images.  Slots: job (i, j), EVERY j (the diagonal too:
+// the rows of q's own image and q itself are candidates of the k nearest), slot = job_off[i n + j] + local row.
+// Outputs t3_* as screened_block_top3 for the rows with dismissed[q] == 0 (the other slots are not written).
+// Returns the slot count; call with t3_idx == nullptr to get it (and job_off) first.
+int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
+                             std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
+                             int64_t* n_survivors) {
+    const int n = (int)img_off.size() - 1;
+    const int64_t f = img_off[n];
+    job_off.assign((size_t)n * n, 0);
+    int64_t slots = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            job_off[(size_t)i * n + j] = slots;
+            slots += img_off[i + 1] - img_off[i];
+        }
+    if (!t3_idx || slots == 0) return slots;
+    APS_REQUIRE(slots < ((int64_t)1 << 31), APS_E_DIM, "too many (row, image) pairs for one pass (%lld)", (long long)slots);
+    std::vector<Prepared> prep(n);
+    {  // the images' operand forms, eight chains of small launches side by side (as in match_pairs_impl)
+        constexpr int kPrepStreams = 8;
+        AuxScope fork(kPrepStreams);
+        Prof prof("match_prep");
+        for (int b = 0; b < n; ++b) {
+            const float* xb = layout == APS_ROWMAJOR ? X_dev + (size_t)img_off[b] * ld : X_dev + img_off[b];
+            prepare(xb, img_off[b + 1] - img_off[b], ld, layout, false, prep[b], fork.streams[b % kPrepStreams], false);
+        }
+        fork.join();
+    }
+    // ---- the int8 screen over every ordered pair of different images: bounds per (row, image) ----
+    std::vector<MatchJob> jobs;
+    std::vector<WgJob> bw;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int nA = (int)(img_off[i + 1] - img_off[i]), nB = (int)(img_off[j + 1] - img_off[j]);
+            if (i == j || nA == 0 || nB == 0) continue;
+            for (int r = 0; r < nA; r += kTMB) bw.push_back({(int)jobs.size(), r, 0});
+            jobs.push_back(make_job(prep[i], prep[j], nA, nB, job_off[(size_t)i * n + j]));
+        }
+    Ws<float> bounds((size_t)slots * 3);
+    Ws<int64_t> d_ioff(n + 1), d_joff((size_t)n * n);
+    Ws<uint32_t> row_list((size_t)slots);
+    Ws<unsigned int> list_count((size_t)n * n);
+    APS_HIP(hipMemcpyAsync(d_ioff, img_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)n * n * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemsetAsync(list_count, 0, (size_t)n * n * sizeof(unsigned int), stream()));
+    const bool screen = !std::getenv("APS_MATCH_NO_SCREEN") && !jobs.empty();
+    if (screen) {
+        Ws<MatchJob> djobs(jobs.size());
+        Ws<WgJob> dbw(bw.size());
+        APS_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+        {
+            Prof prof("match_screen_i8");
+            match_screen_i8_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr, nullptr,
+                                                                               nullptr, 0.f, 0.f, bounds);
+        }
+        check_launch("match_screen_i8_kernel (bounds)");
+        APS_HIP(hipStreamSynchronize(stream()));  // djobs / dbw go out of scope
+    } else {
+        // no screen: NaN bounds - every comparison fails, every row survives and is searched in every image
+        APS_HIP(hipMemsetAsync(bounds, 0xff, (size_t)slots * 3 * sizeof(float), stream()));
+    }
+    {
+        Prof prof("global_screen_reduce");
+        global_screen_reduce_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, row_list, list_count);
+        global_t3_init_kernel<<<cdiv(slots, 256), 256, 0, stream()>>>(t3_idx, t3_d, t3_b, slots);
+    }
+    check_launch("global_screen_reduce_kernel");
+    std::vector<unsigned int> h_cnt((size_t)n * n);
+    APS_HIP(hipMemcpyAsync(h_cnt.data(), list_count, (size_t)n * n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    bounds.reset();
+    int64_t n_surv = 0, n_pairs_rows = 0;
+    for (int i = 0; i < n; ++i) {
+        n_surv += h_cnt[(size_t)i * n + i];  // (the diagonal job lists every surviving row of image i)
+        for (int j = 0; j < n; ++j) n_pairs_rows += h_cnt[(size_t)i * n + j];
+    }
+    if (n_survivors) *n_survivors = n_surv;
+    if (std::getenv("APS_TRACE"))
+        std::fprintf(stderr, "[aps] pooled matcher screen: %lld of %lld rows survive (%.2f %%); %lld of %lld (row, image) searches remain (%.2f %%)\n",
+                     (long long)n_surv, (long long)f, 100.0 * (double)n_surv / (double)std::max<int64_t>(f, 1), (long long)n_pairs_rows,
+                     (long long)slots, 100.0 * (double)n_pairs_rows / (double)slots);
+    if (n_surv == 0) return slots;
+    // ---- the exact three nearest rows (with a certified bound) of every remaining (row, image) pair ----
+    std::vector<MatchJob> cj;
+    std::vector<WgJob> lw;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int nA = (int)(img_off[i + 1] - img_off[i]), nB = (int)(img_off[j + 1] - img_off[j]);
+            cj.push_back(make_job(prep[i], prep[j], nA, nB, job_off[(size_t)i * n + j]));  // (job index == i n + j)
+            if (nA == 0 || nB == 0) continue;
+            const unsigned int cnt = h_cnt[(size_t)i * n + j];
+            for (unsigned int r = 0; r < cnt; r += kTMB) lw.push_back({i * n + j, (int)r, (int)std::min<unsigned int>(kTMB, cnt - r)});
+        }
+    Ws<MatchJob> dcj(cj.size());
+    Ws<WgJob> dlw(std::max<size_t>(lw.size(), 1));
+    Ws<uint32_t> fb_list(1);
+    Ws<unsigned int> fb_count(cj.size());
+    APS_HIP(hipMemcpyAsync(dcj, cj.data(), cj.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
+    if (!lw.empty()) APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+    if (!lw.empty()) {
+        Prof prof("match_cand_f16");
+        match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(dcj, dlw, (int)lw.size(), nullptr, nullptr, nullptr, fb_list,
+                                                                                fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, row_list);
+    }
+    check_launch("match_cand_f16_kernel (pooled, list mode)");
+    APS_HIP(hipStreamSynchronize(stream()));  // the host tables and the Prepared blocks must outlive the launches
     return slots;
 }
 

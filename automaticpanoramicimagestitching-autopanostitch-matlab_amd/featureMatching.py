@@ -515,7 +515,15 @@ def match_global_csr(allDescriptors, ratio=0.6, k=4, device_out=False):
         oi = np.zeros(F, np.uint32)
         oj = np.zeros(F, np.uint32)
     check(lib.aps_global_normalize(ptr(raw), F, DIM, DIM, _capi.APS_ROWMAJOR, ptr(pool)))
-    check(lib.aps_knn_global(ptr(pool), F, DIM, ptr(pool), F, DIM, DIM, _capi.APS_ROWMAJOR, k, ptr(nn_idx), ptr(nn_dist), k))
+    if k <= 4:
+        # the search with the filter in view: queries that featureMatchingGlobal.m:129-147 provably drops at this ratio are
+        # not searched (they come back as copies of themselves, which the filter removes as self matches); every other
+        # query gets its exact k nearest - the CSR lists equal those of the plain search
+        img_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        check(lib.aps_knn_global_screened(ptr(pool), F, DIM, DIM, _capi.APS_ROWMAJOR, ptr(img_off), numImg, float(ratio), k,
+                                          ptr(nn_idx), ptr(nn_dist), k))
+    else:
+        check(lib.aps_knn_global(ptr(pool), F, DIM, ptr(pool), F, DIM, DIM, _capi.APS_ROWMAJOR, k, ptr(nn_idx), ptr(nn_dist), k))
     cnt = C.c_int64(0)
     check(lib.aps_global_filter(ptr(nn_idx), ptr(nn_dist), F, k, k, _capi.APS_ROWMAJOR, ptr(img_idx), ptr(local_idx),
                                 numImg, float(ratio), ptr(pair_ptr), ptr(oi), ptr(oj), F, C.byref(cnt)))

@@ -164,6 +164,17 @@ int aps_match_pairs(const float* const* desc, const int64_t* counts, const int64
 int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* query, int64_t fq,
                    int64_t ldq, int dim, int layout, int k, uint32_t* idx, float* dist,
                    int64_t ldo);
+/* The same search for featureMatchingGlobal's own use (featureMatchingGlobal.m:106-147: the pool against itself, then the
+ * per-query filter at ratioThr).  pool: the normalised descriptors of all images back to back, img_off[n_img + 1] the row
+ * offsets of the images (img_off[0] = 0, img_off[n_img] = f).  A query that the filter PROVABLY drops at `ratio` - an
+ * int8 screening pass bounds its two smallest cross-image distances, :129-147 - may come back as k copies of itself
+ * (distance 0): the filter removes them as self matches, fewer than two candidates remain, the query is skipped exactly
+ * as the reference skips it.  Every other row gets its exact k nearest (k <= 4), bit-identical to aps_knn_global.  The
+ * output of aps_global_filter on this table therefore equals its output on aps_knn_global's. */
+int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, int layout, const int64_t* img_off, int n_img,
+                            float ratio, int k, uint32_t* idx, float* dist, int64_t ldo);
+/* Diagnostics of the calling thread's most recent aps_knn_global_screened call: rows of the pool, rows that were searched. */
+int aps_knn_global_screen_stats(int64_t* rows, int64_t* survivors);
 
 /* a8 kNN, binary descriptors: [idx, dist] = flann_knn_win(train_u8, query_u8, k, 'bf' | 'flann', ...) - the uint8 branches
  * of flann_knn.cpp: cv::BFMatcher(NORM_HAMMING).knnMatch (:199-223) and the LSH index (:235-240), both replaced by ONE exact

@@ -165,3 +165,67 @@ def test_blocked_screened_knn_equals_f32_path_and_oracle(gpu, monkeypatch):
         b_i, b_d = fm.flann_knn_win(y, y, k)
         assert np.array_equal(a_i, b_i) and np.array_equal(bits(a_d), bits(b_d))
     monkeypatch.delenv("APS_KNN_MODE")
+
+
+def test_screened_pooled_matcher_equals_plain_search_and_oracle(gpu, monkeypatch):
+    """featureMatchingGlobal through aps_knn_global_screened: the int8 screen dismisses the queries whose two nearest
+    cross-image rows provably fail the ratio test, the others get their exact four nearest.  The CSR lists must equal
+    those of the plain exact search (APS_KNN_MODE=f32) and of the oracle chain on a pool that has clear matches, matches
+    near the ratio boundary, near-duplicates INSIDE an image (they crowd the four nearest: fewer than two cross-image
+    neighbours remain), exact duplicates across images (ties by index) and an empty image."""
+    import ctypes
+
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    rng = np.random.default_rng(123)
+    base = sift_like(rng, 2600)
+    descs = []
+    for i in range(6):
+        keep = rng.permutation(2600)[: 1500 + 60 * i]
+        noise = rng.uniform(0.0, 0.12, len(keep))[:, None]   # ratios from clear matches to clear non-matches
+        d = np.maximum(base[keep] + noise * rng.standard_normal((len(keep), 128)).astype(np.float32), 0)
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        own = sift_like(rng, 300)                            # rows only this image has
+        descs.append(np.concatenate([d, own]).astype(np.float32))
+    descs[2][5] = descs[2][4] + np.float32(1e-3) * rng.standard_normal(128).astype(np.float32)   # crowding inside image 2
+    descs[2][6] = descs[2][4] + np.float32(2e-3) * rng.standard_normal(128).astype(np.float32)
+    descs[2][7] = descs[2][4] + np.float32(3e-3) * rng.standard_normal(128).astype(np.float32)
+    descs[3][9] = descs[1][11]                               # exact duplicates across images
+    descs[4][9] = descs[1][11]
+    descs.insert(3, np.zeros((0, 128), np.float32))          # an image without features
+    n_img = len(descs)
+    assert sum(len(d) for d in descs) > 8192                 # the screened path, not the small-pool shortcut
+    monkeypatch.delenv("APS_KNN_MODE", raising=False)
+    pp, oi, oj = fm.match_global_csr(descs, 0.6, 4)
+    rows, surv = ctypes.c_int64(0), ctypes.c_int64(0)
+    gpu._capi.check(gpu.lib.aps_knn_global_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    assert rows.value == sum(len(d) for d in descs) and 0 < surv.value < 0.7 * rows.value, (rows.value, surv.value)
+    monkeypatch.setenv("APS_KNN_MODE", "f32")
+    pp0, oi0, oj0 = fm.match_global_csr(descs, 0.6, 4)
+    monkeypatch.delenv("APS_KNN_MODE")
+    assert np.array_equal(pp, pp0) and np.array_equal(oi, oi0) and np.array_equal(oj, oj0) and pp[-1] > 1500
+    monkeypatch.setenv("APS_MATCH_NO_SCREEN", "1")           # the f16 path on every row: same lists again
+    pp1, oi1, oj1 = fm.match_global_csr(descs, 0.6, 4)
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN")
+    assert np.array_equal(pp, pp1) and np.array_equal(oi, oi1) and np.array_equal(oj, oj1)
+    # the oracle chain
+    pool = np.concatenate(descs)
+    sq = np.zeros(len(pool), np.float32)
+    for kk in range(128):
+        sq = sq + pool[:, kk] * pool[:, kk]
+    pool = (pool / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    counts = [len(d) for d in descs]
+    img = np.repeat(np.arange(1, n_img + 1, dtype=np.uint32), counts)
+    loc = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
+    ni, nd = oracle.knn(pool, pool, 4)
+    want = oracle.global_filter(ni, nd, img, loc, 0.6)
+    for p, (i, j) in enumerate(fm.pair_order(n_img)):
+        exp = want[(want[:, 0] == i + 1) & (want[:, 1] == j + 1)][:, 2:]
+        got = np.stack([oi[pp[p]:pp[p + 1]], oj[pp[p]:pp[p + 1]]], axis=1)
+        assert np.array_equal(got.astype(np.int64), exp.astype(np.int64)), (i, j)
+    # other ratios: a tight one (few queries pass) and one above 1 (nothing may be dismissed wrongly)
+    for ratio in (0.3, 0.95):
+        a = fm.match_global_csr(descs, ratio, 4)
+        monkeypatch.setenv("APS_KNN_MODE", "f32")
+        b = fm.match_global_csr(descs, ratio, 4)
+        monkeypatch.delenv("APS_KNN_MODE")
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), ratio
