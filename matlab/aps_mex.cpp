@@ -143,6 +143,59 @@ static void cmd_pairwise(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
         }
 }
 
+// matches = aps_mex('match_global', allDescriptors (1xN cell of single Ki x 128), ratioThr, k) -> N x N cell, upper triangle
+// featureMatchingGlobal.m:69-161 for float descriptors in one device pass: pooling, row normalisation (:80-86), the
+// screened exact k-NN of the pool against itself (aps_knn_global_screened: queries the filter provably drops are not
+// searched) and the per-query filter (:123-161, aps_global_filter).  Same lists as flann_knn_win + the reference's loop.
+static void cmd_match_global(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 4 && mxIsCell(prhs[1]), "aps:type", "usage: allDescriptors (cell of single K x 128), ratioThr, k");
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    const double ratio = mxGetScalar(prhs[2]);
+    const int k = (int)mxGetScalar(prhs[3]);
+    need(k >= 1 && k <= 4, "aps:args", "k in 1..4 is built on the device (inputs.m: input.k = 4)");
+    std::vector<int64_t> off(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const mxArray* d = mxGetCell(prhs[1], i);
+        need(d && (mxGetM(d) == 0 || (mxIsSingle(d) && mxGetN(d) == 128)), "aps:type", "descriptors must be single K x 128");
+        off[i + 1] = off[i] + (int64_t)mxGetM(d);
+    }
+    const int64_t f = off[n];
+    plhs[0] = mxCreateCellMatrix(n, n);
+    if (f == 0) return;
+    // the pool, row-major (MATLAB's matrices are column-major K x 128)
+    std::vector<float> raw((size_t)f * 128), pool((size_t)f * 128);
+    std::vector<uint32_t> img((size_t)f), loc((size_t)f);
+    for (int i = 0; i < n; ++i) {
+        const mxArray* d = mxGetCell(prhs[1], i);
+        const int64_t m = off[i + 1] - off[i];
+        const float* src = m ? (const float*)mxGetData(d) : nullptr;
+        for (int64_t r = 0; r < m; ++r) {
+            for (int c = 0; c < 128; ++c) raw[(size_t)(off[i] + r) * 128 + c] = src[(size_t)c * m + r];
+            img[(size_t)(off[i] + r)] = (uint32_t)(i + 1);
+            loc[(size_t)(off[i] + r)] = (uint32_t)(r + 1);
+        }
+    }
+    check(aps_global_normalize(raw.data(), f, 128, 128, APS_ROWMAJOR, pool.data()));
+    std::vector<uint32_t> nn((size_t)f * k), oi((size_t)f), oj((size_t)f);
+    std::vector<float> nd((size_t)f * k);
+    check(aps_knn_global_screened(pool.data(), f, 128, 128, APS_ROWMAJOR, off.data(), n, (float)ratio, k, nn.data(), nd.data(), k));
+    const int64_t np = (int64_t)n * (n - 1) / 2;
+    std::vector<int64_t> pp(np + 1);
+    int64_t cnt = 0;
+    check(aps_global_filter(nn.data(), nd.data(), f, k, k, APS_ROWMAJOR, img.data(), loc.data(), n, (float)ratio, pp.data(), oi.data(),
+                            oj.data(), f, &cnt));
+    int64_t p = 0;
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i, ++p) {
+            const int64_t s = pp[p], m = pp[p + 1] - pp[p];
+            if (m == 0) continue;  // (the reference leaves such cells empty)
+            mxArray* c = mxCreateDoubleMatrix(m, 2, mxREAL);
+            double* out = mxGetPr(c);
+            for (int64_t e = 0; e < m; ++e) { out[e] = oi[s + e]; out[e + m] = oj[s + e]; }
+            mxSetCell(plhs[0], i + (mwSize)j * n, c);
+        }
+}
+
 // [idx, dist] = aps_mex('knn_global', train, query, k)            (flann_knn_win contract)
 static void cmd_knn(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const bool flt = nrhs >= 4 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]);
@@ -428,6 +481,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "match_features") cmd_match(nlhs, plhs, nrhs, prhs);
     else if (cmd == "match_pairwise") cmd_pairwise(nlhs, plhs, nrhs, prhs);
     else if (cmd == "knn_global") cmd_knn(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "match_global") cmd_match_global(nlhs, plhs, nrhs, prhs);
     else if (cmd == "hamming_2nn") cmd_hamming(nlhs, plhs, nrhs, prhs);
     else if (cmd == "ransac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, false);
     else if (cmd == "mlesac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, true);

@@ -65,5 +65,6 @@ def test_shadows_cover_the_operator_table_of_survey_8b():
     have = {f[:-2] for f in os.listdir(MATLAB) if f.endswith(".m")}
     need = {"getFeaturePoints", "featureMatchingPairwise", "matchFeaturesScratch", "flann_knn_win",
             "nearest2HammingExhaustiveMEX", "nearest2HammingExhaustiveOMPMEX", "estimateTransformationRANSAC",
-            "estimateTransformationMLESAC", "renderPanorama", "multiBandBlending", "linearBlending", "imageWarp"}
+            "estimateTransformationMLESAC", "renderPanorama", "multiBandBlending", "linearBlending", "imageWarp",
+            "featureMatchingGlobal"}
     assert need <= have, need - have
