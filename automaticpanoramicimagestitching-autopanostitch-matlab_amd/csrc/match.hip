@@ -1442,6 +1442,9 @@ __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
     return q;
 }
 
+// BOUNDS: the pooled matcher's form (screened_global_top3) - a separate instantiation, so that profiles keep the two
+// apart.
+template <bool BOUNDS>
 __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __restrict__ jobs,
                                                                  const WgJob* __restrict__ wgs, int n_wg,
                                                                  uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
@@ -1640,7 +1643,8 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
     const int row = row0 + 32 * h;
     const int e0 = h ? D0[1] : D0[0], e1 = h ? D1[1] : D1[0];
     bool survive = false;
-    if (row < nA && bounds_out) {
+    if (BOUNDS) {
+        if (row < nA) {
         const ScreenSet q = screen_set(jb);
         const float inv_sa = jb.invsA[row];
         float L1f = -INFINITY, H1f = INFINITY, H2f = INFINITY;
@@ -1659,6 +1663,7 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
         bo[0] = L1f;
         bo[1] = H1f;
         bo[2] = H2f;
+        }
     } else if (row < nA) {
         const ScreenSet q = screen_set(jb);
         bool pruned = false;
@@ -2028,8 +2033,8 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
         {
             Prof prof("match_screen_i8");
-            match_screen_i8_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list, surv_count,
-                                                                               prune_r2, prune_thr, nullptr);
+            match_screen_i8_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
+                                                                                      surv_count, prune_r2, prune_thr, nullptr);
         }
         check_launch("match_screen_i8_kernel");
         std::vector<unsigned int> h_surv(jobs.size());
@@ -2400,9 +2405,9 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         APS_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
         APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
         {
-            Prof prof("match_screen_i8");
-            match_screen_i8_kernel<<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr, nullptr,
-                                                                               nullptr, 0.f, 0.f, bounds);
+            Prof prof("match_screen_i8_bounds");
+            match_screen_i8_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
+                                                                                     nullptr, nullptr, 0.f, 0.f, bounds);
         }
         check_launch("match_screen_i8_kernel (bounds)");
         APS_HIP(hipStreamSynchronize(stream()));  // djobs / dbw go out of scope

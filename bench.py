@@ -64,6 +64,9 @@ def parse():
                     help="after the timed steps (inputs resident in HBM -> cropped uint8 panorama in pinned host memory), time the "
                          "same steps with the images starting in pinned host memory (SURVEY 8(d): first byte uploaded -> "
                          "panorama on the host); reported as value_end_to_end next to `value`")
+    ap.add_argument("--global-probe", choices=["auto", "off"], default="auto",
+                    help="after the timed steps, one pass of the reference's default matcher (featureMatchingGlobal) on the same "
+                         "views, reported as global_matcher_probe (off: for profiling runs that want per-step launch counts)")
     ap.add_argument("--gain-compensation", action="store_true",
                     help="also run gainCompensationRKf (device overlap statistics + host solve) before the render; "
                          "off in the headline configuration, which follows BASELINE.json configs[2]")
@@ -198,7 +201,7 @@ def global_matcher_probe(pl, capi, input_, images):
     capi.check(capi.lib.aps_knn_global_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
     F = float(sum(int(d.shape[0]) for d in descs))
     dt, prof, n_match = best
-    ms_screen = prof.get("match_screen_i8", (0.0, 0))[0]
+    ms_screen = prof.get("match_screen_i8_bounds", (0.0, 0))[0]
     return {
         "ms": round(1e3 * dt, 2), "pool_rows": int(F), "matches": n_match,
         "rows_searched_share": round(surv.value / rows.value, 4) if rows.value else None,
@@ -585,7 +588,7 @@ def main():
                                                for k in infos_h[-1]["times"]} if dt_e2e else None),
             "kernels": kernels,
         }
-        if world == 1 and args.matcher == "pairwise" and (nx, ny) == (NX, NY):
+        if world == 1 and args.matcher == "pairwise" and (nx, ny) == (NX, NY) and args.global_probe == "auto":
             # The reference's DEFAULT matcher switch (inputs.m:46, featureMatchingGlobal) on the same 64 views, outside the
             # timed region: one pass of the pooled exact 4-NN + filter with its int8 proof pass, its stage time and kernels.
             try:

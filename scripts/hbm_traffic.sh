@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 rm -rf /tmp/pt
 timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d /tmp/pt -o p -- \
-    python3 bench.py --cpu-baseline off --end-to-end off --steps 1 --warmup 0 > /tmp/pt.json 2> /tmp/pt.err
+    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --steps 1 --warmup 0 > /tmp/pt.json 2> /tmp/pt.err
 python3 - "$TAG" <<'PY'
 import csv, collections, json, sys
 tag = sys.argv[1]
