@@ -1184,6 +1184,11 @@ __device__ __forceinline__ float4 ld_foot(const FootBuf& b, int x, int y) {
     return f;
 }
 
+#ifndef APS_DFRS
+#define APS_DFRS 6  // (measured: 4 rows per thread with 320 threads - 84 instead of 100 VGPRs, 1.45x instead of 1.36x re-reads - 4.35 -> 5.1 ms)
+#endif
+constexpr int kDFRS = APS_DFRS;                     // output rows per vertical-pass thread (register window 2 (RS - 1) + NC rows)
+constexpr int kDFT = kDFRS == 6 ? 256 : 320;        // threads: ceil(16 / RS) segments x <= 82 patch columns
 // ------------------------------------------------------------------------------------------------
 // pass 2, fused form (default): one kBW x kBH block of G_{l+1} per workgroup straight from the compact store of G_l
 // ------------------------------------------------------------------------------------------------
@@ -1194,10 +1199,10 @@ __device__ __forceinline__ float4 ld_foot(const FootBuf& b, int x, int y) {
 // (20 KB against the 69 KB of the two-step kernel: eight workgroups fit a CU instead of two).  Rows whose taps do not
 // advance by exactly two (one row in ~a thousand when a level's height is odd) take a plain per-tap loop.
 template <int R>
-__global__ __launch_bounds__(256) void rw_down_fused_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
-    constexpr int NC = kTD + 2 * R, NCP = (NC + 3) & ~3, VC = 2 * kBW + NC + 2, RS = 6, NSEG = (kBH + RS - 1) / RS;
+__global__ __launch_bounds__(kDFT) void rw_down_fused_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
+    constexpr int NC = kTD + 2 * R, NCP = (NC + 3) & ~3, VC = 2 * kBW + NC + 2, RS = kDFRS, NSEG = (kBH + RS - 1) / RS;
     constexpr int WIN = 2 * (RS - 1) + NC;
-    static_assert(NSEG * VC <= 256 && kBH <= 16 && kBW == 32, "thread mapping");
+    static_assert(NSEG * VC <= kDFT && kBH <= 16 && kBW == 32 && kDFT >= kBW * 8, "thread mapping");
     __shared__ float4 s_v[kBH * VC];
     const int bid = xcd_contiguous_id(n_blocks);
     if (bid >= n_blocks) return;
@@ -1259,7 +1264,7 @@ __global__ __launch_bounds__(256) void rw_down_fused_kernel(RwArgs A, int l, con
     }
     __syncthreads();
     const int xo = tid & (kBW - 1);
-    if (xo < now) {  // horizontal pass: one output column per lane, rows 8 apart
+    if (xo < now && tid < 256) {  // horizontal pass: one output column per lane, rows 8 apart (the first 256 threads)
         const int ox = ox0 + xo, c0 = cs0[ox] - bx0;
         float wc[NCP];
 #pragma unroll
@@ -1282,6 +1287,8 @@ __global__ __launch_bounds__(256) void rw_down_fused_kernel(RwArgs A, int l, con
 #define APS_KUP 2
 #endif
 constexpr int kUP = APS_KUP;
+// (Measured and dropped in round 3: 8 waves per SIMD through amdgpu_waves_per_eu(8, 8) - 64 VGPRs with ten dwords of
+// scratch: 4.2 -> 7.6 ms at level 0.)
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void rw_up_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
     const int bid = xcd_contiguous_id(n_blocks);
@@ -1440,7 +1447,7 @@ void launch_down_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
 }
 template <int R>
 void launch_down_fused_r(const RwArgs& A, int l, const int* blk_ptr, int n_blocks) {
-    rw_down_fused_kernel<R><<<8u * (unsigned)((n_blocks + 7) / 8), 256, 0, stream()>>>(A, l, blk_ptr, n_blocks);
+    rw_down_fused_kernel<R><<<8u * (unsigned)((n_blocks + 7) / 8), kDFT, 0, stream()>>>(A, l, blk_ptr, n_blocks);
 }
 void launch_down(int r, const RwArgs& A, int l, const int* blk_ptr, int n_blocks, bool exact) {
     if (!exact) {
