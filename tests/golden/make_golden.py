@@ -155,9 +155,64 @@ def main_v3():
     print("wrote golden_v3.npz:", {k: v.shape for k, v in out.items()})
 
 
+def main_v4():
+    """golden_v4.npz (round 3): imageWarp 'nearest' / 'bicubic' on uint8 and single images, the pooled matcher's CSR lists
+    on a pool large enough for the screened search, and the two-stage 'fit' resize of resizeImagesToLimits."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    img = textured(rng, 70, 96)
+    Hm = np.array([[0.96, 0.06, 5.5], [-0.05, 1.03, -2.25], [3e-5, -2e-5, 1.0]])
+    out["w_img"], out["w_H"] = img, Hm
+    out["w_view"] = np.array([80.0, 110.0, -4.5, -3.5, 1.0, 1.0])  # rows, cols, x0, y0, sx, sy
+    f32 = (img[..., 1].astype(np.float32) / 255.0)
+    for m in ("nearest", "bicubic"):
+        out[f"w_u8_{m}"] = oracle.image_warp_h(img, Hm, 80, 110, -4.5, -3.5, 1.0, 1.0, 9, method=m)
+        out[f"w_f32_{m}"] = oracle.image_warp_h(f32, Hm, 80, 110, -4.5, -3.5, 1.0, 1.0, 0.25, method=m)
+    # pooled matcher: 5 images of ~1800 descriptors sharing planted correspondences (pool > 8192 rows)
+    from util import sift_like
+
+    base = sift_like(rng, 2400)
+    counts = []
+    pool = []
+    for i in range(5):
+        keep = rng.permutation(2400)[: 1500 + 50 * i]
+        noise = rng.uniform(0.0, 0.1, len(keep))[:, None]
+        d = np.maximum(base[keep] + noise * rng.standard_normal((len(keep), 128)).astype(np.float32), 0)
+        d = np.concatenate([(d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32), sift_like(rng, 250)])
+        pool.append(d.astype(np.float32))
+        counts.append(len(d))
+    allp = np.concatenate(pool)
+    sq = np.zeros(len(allp), np.float32)
+    for kk in range(128):
+        sq = sq + allp[:, kk] * allp[:, kk]
+    normed = (allp / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    imgi = np.repeat(np.arange(1, 6, dtype=np.uint32), counts)
+    loc = np.concatenate([np.arange(1, c + 1, dtype=np.uint32) for c in counts])
+    ni, nd = oracle.knn(normed, normed, 4)
+    out["gm_pool"] = allp.astype(np.float16).astype(np.float32)  # (stored at half precision: the fixture stays small)
+    # recompute on the stored values so that the fixture is self-consistent
+    allp = out["gm_pool"]
+    sq = np.zeros(len(allp), np.float32)
+    for kk in range(128):
+        sq = sq + allp[:, kk] * allp[:, kk]
+    normed = (allp / np.sqrt(sq + np.float32(np.finfo(np.float32).eps))[:, None]).astype(np.float32)
+    ni, nd = oracle.knn(normed, normed, 4)
+    out["gm_counts"] = np.asarray(counts, np.int64)
+    out["gm_rows"] = oracle.global_filter(ni, nd, imgi, loc, 0.6)
+    # resizeImagesToLimits 'fit': shrink by the scalar form, then to the common largest size
+    big = textured(rng, 120, 200)
+    out["fit_img"] = big
+    s1 = oracle.imresize_u8(big, 0.4, "bicubic")
+    out["fit_stage1"] = s1
+    out["fit_stage2"] = oracle.imresize_u8(s1, (64, 80), "bicubic")
+    np.savez_compressed(os.path.join(HERE, "golden_v4.npz"), **out)
+    print("wrote golden_v4.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(HERE, "golden_v1.npz")) or "--v1" in sys.argv:
         main()
     if not os.path.exists(os.path.join(HERE, "golden_v2.npz")) or "--v2" in sys.argv:
         main_v2()
     main_v3()
+    main_v4()
