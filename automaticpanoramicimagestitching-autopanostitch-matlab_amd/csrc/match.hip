@@ -2249,9 +2249,28 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
 // c2 <= min(second smallest H1(j), min_j H2(j)).  Whatever the k nearest are, the two cross-image rows the ratio test
 // compares are no nearer than c1 and c2 - so  min_j L1(j) > ratio * max(that upper bound, eps)  proves that q is dropped,
 // and only the other rows need their exact neighbours.
+// A wave's rows lie in at most two images of >= 64 rows (rows are pooled image by image): the lanes of image `iw` append
+// to job (iw, j) with one atomic per wave.  `keep` must be false for lanes of another image.
+__device__ __forceinline__ void global_list_append(bool keep, int job, int64_t r, const int64_t* __restrict__ job_off,
+                                                   uint32_t* __restrict__ row_list, unsigned int* __restrict__ list_count) {
+    const unsigned long long m = __ballot(keep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    unsigned int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&list_count[job], (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    if (keep) row_list[job_off[job] + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+}
+
+// Phase 0 of the pooled search: per row the verdict of the proof (dismissed), the bound-based cut (three distinct rows of
+// other images lie within it), and the FIRST images to search: the row's own image and the (up to) three images with the
+// smallest upper bound H1 - where its nearest rows most likely are.  Their exact distances then replace the cut's upper
+// bounds (phase B, global_phase_b_kernel).
 __global__ __launch_bounds__(256) void global_screen_reduce_kernel(const float* __restrict__ bounds, const int64_t* __restrict__ img_off,
                                                                    int n_img, const int64_t* __restrict__ job_off, int64_t f, float ratio,
-                                                                   uint8_t* __restrict__ dismissed, uint32_t* __restrict__ row_list,
+                                                                   uint8_t* __restrict__ dismissed, float* __restrict__ cut_out,
+                                                                   int* __restrict__ first_imgs /* f x 3 */, uint32_t* __restrict__ row_list,
                                                                    unsigned int* __restrict__ list_count) {
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool live = q < f;
@@ -2263,9 +2282,10 @@ __global__ __launch_bounds__(256) void global_screen_reduce_kernel(const float* 
     }
     const int i = lo;
     const int64_t r = qc - img_off[i];
-    // pass 1: the smallest lower bound and the three smallest upper bounds over the other images' columns
-    float lmin = INFINITY, h1a = INFINITY, h1b = INFINITY, h2m = INFINITY;
+    float lmin = INFINITY, h2m = INFINITY;
     float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY;  // three smallest of {H1(j), H2(j)}: distinct columns each
+    float g0 = INFINITY, g1 = INFINITY, g2 = INFINITY;  // three smallest H1(j) ...
+    int a0 = -1, a1 = -1, a2 = -1;                      // ... and their images
     auto put3 = [&](float h) {
         if (h < u2) {
             if (h < u1) {
@@ -2286,59 +2306,146 @@ __global__ __launch_bounds__(256) void global_screen_reduce_kernel(const float* 
         const float* b = bounds + (size_t)(job_off[(size_t)i * n_img + j] + r) * 3;
         const float l1 = b[0], h1 = b[1], h2 = b[2];
         lmin = fminf(lmin, l1);
-        if (h1 < h1a) {
-            h1b = h1a;
-            h1a = h1;
-        } else if (h1 < h1b) {
-            h1b = h1;
-        }
         h2m = fminf(h2m, h2);
         put3(h1);
         put3(h2);
-    }
-    const float hsec = fmaxf(fminf(h1b, h2m), 1.1920929e-07f);  // (the reference divides by max(second, eps('single')))
-    const bool drop = live && hsec < INFINITY && lmin > -INFINITY && lmin * (1.0f - 1e-5f) - 1e-30f > ratio * hsec * (1.0f + 1e-5f);
-    if (live) dismissed[q] = drop ? 1 : 0;
-    // pass 2: the images a surviving row has to be searched in.  Its k <= 4 nearest are itself and three more rows; three
-    // distinct rows of other images lie within u2, so a row of image j can be among them only if L1(j) <= u2 - every
-    // other image is skipped for this row (its unlisted rows are provably farther than the row's fourth neighbour).  The
-    // row's own image is always searched.  One list per job, appended with one atomic per wave and image.
-    const float cut = u2 < INFINITY ? u2 * (1.0f + 1e-5f) + 1e-30f : INFINITY;
-    const int lane = threadIdx.x & 63;
-    const int i_first = __shfl(i, 0), i_last = __shfl(i, 63);
-    for (int pass = 0; pass < 2; ++pass) {
-        const int iw = pass ? i_last : i_first;  // a wave of consecutive rows spans at most two images of >= 64 rows; any
-        if (pass && i_last == i_first) break;    // further image in between is handled by the slow path below
-        for (int j = 0; j < n_img; ++j) {
-            if (img_off[j + 1] == img_off[j]) continue;
-            bool keep = live && !drop && i == iw;
-            if (keep && j != i) {
-                const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
-                keep = !(l1 * (1.0f - 1e-5f) - 1e-30f > cut);  // (NaN / -inf bounds keep the image)
-            }
-            const unsigned long long m = __ballot(keep);
-            if (m) {
-                const int job = iw * n_img + j;
-                unsigned int base = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if (lane == leader) base = atomicAdd(&list_count[job], (unsigned int)__popcll(m));
-                base = __shfl(base, leader);
-                if (keep) row_list[job_off[job] + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        if (h1 < g2) {
+            if (h1 < g1) {
+                g2 = g1, a2 = a1;
+                if (h1 < g0) {
+                    g1 = g0, a1 = a0;
+                    g0 = h1, a0 = j;
+                } else {
+                    g1 = h1, a1 = j;
+                }
+            } else {
+                g2 = h1, a2 = j;
             }
         }
     }
-    if (live && !drop && i != i_first && i != i_last) {  // (images of fewer than 64 rows inside one wave)
+    const float hsec = fmaxf(fminf(g1, h2m), 1.1920929e-07f);  // (the reference divides by max(second, eps('single')))
+    const bool drop = live && hsec < INFINITY && lmin > -INFINITY && lmin < INFINITY &&
+                      lmin * (1.0f - 1e-5f) - 1e-30f > ratio * hsec * (1.0f + 1e-5f);
+    if (live) {
+        dismissed[q] = drop ? 1 : 0;
+        cut_out[q] = u2 < INFINITY ? u2 * (1.0f + 1e-5f) + 1e-30f : INFINITY;
+        first_imgs[q * 3] = a0;
+        first_imgs[q * 3 + 1] = a1;
+        first_imgs[q * 3 + 2] = a2;
+    }
+    const int i_first = __shfl(i, 0), i_last = __shfl(i, 63);
+    const bool edge = i != i_first && i != i_last;  // (an image of fewer than 64 rows inside one wave: plain atomics)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int iw = pass ? i_last : i_first;
+        if (pass && i_last == i_first) break;
         for (int j = 0; j < n_img; ++j) {
             if (img_off[j + 1] == img_off[j]) continue;
-            bool keep = true;
-            if (j != i) {
-                const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
-                keep = !(l1 * (1.0f - 1e-5f) - 1e-30f > cut);
+            const bool keep = live && !drop && i == iw && (j == i || j == a0 || j == a1 || j == a2);
+            global_list_append(keep, iw * n_img + j, r, job_off, row_list, list_count);
+        }
+    }
+    if (live && !drop && edge) {
+        const int js[4] = {i, a0, a1, a2};
+        for (int e = 0; e < 4; ++e)
+            if (js[e] >= 0) row_list[job_off[i * n_img + js[e]] + atomicAdd(&list_count[i * n_img + js[e]], 1u)] = (uint32_t)r;
+    }
+}
+
+// Phase B: with the exact distances of phase A's candidates the third nearest non-self row found so far replaces the
+// bound-based cut where it is smaller, and every image not searched yet is listed for the row only if its lower bound
+// does not exceed that cut - a row of such an image could still be among the row's four nearest.
+__global__ __launch_bounds__(256) void global_phase_b_kernel(const float* __restrict__ bounds, const int64_t* __restrict__ img_off, int n_img,
+                                                             const int64_t* __restrict__ job_off, int64_t f, float ratio,
+                                                             uint8_t* __restrict__ dismissed, const float* __restrict__ cut_in,
+                                                             const int* __restrict__ first_imgs, const uint32_t* __restrict__ t3_idx,
+                                                             const float* __restrict__ t3_d, uint32_t* __restrict__ row_list,
+                                                             unsigned int* __restrict__ list_count) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = q < f;
+    const int64_t qc = live ? q : f - 1;
+    int lo = 0, hi = n_img - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (img_off[mid] <= qc) lo = mid; else hi = mid - 1;
+    }
+    const int i = lo;
+    const int64_t r = qc - img_off[i];
+    bool act = live && !dismissed[qc];
+    const int a0 = first_imgs[qc * 3], a1 = first_imgs[qc * 3 + 1], a2 = first_imgs[qc * 3 + 2];
+    float cut = cut_in[qc];
+    if (act) {
+        // the three smallest exact distances to rows other than q itself among phase A's (certified) candidates, and the
+        // two smallest among those of OTHER images
+        float x0 = INFINITY, x1 = INFINITY, x2 = INFINITY, c0 = INFINITY, c1 = INFINITY;
+        const int js[4] = {i, a0, a1, a2};
+        for (int e = 0; e < 4; ++e) {
+            const int j = js[e];
+            if (j < 0) continue;
+            const int64_t slot = job_off[(size_t)i * n_img + j] + r;
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t li = t3_idx[slot * 3 + c];
+                if (!li || (j == i && (int64_t)li - 1 == r)) continue;  // none / the row itself
+                const float d = t3_d[slot * 3 + c];
+                if (j != i) {
+                    if (d < c0) {
+                        c1 = c0;
+                        c0 = d;
+                    } else if (d < c1) {
+                        c1 = d;
+                    }
+                }
+                if (d < x2) {
+                    if (d < x1) {
+                        x2 = x1;
+                        if (d < x0) {
+                            x1 = x0;
+                            x0 = d;
+                        } else {
+                            x1 = d;
+                        }
+                    } else {
+                        x2 = d;
+                    }
+                }
             }
+        }
+        if (x2 < INFINITY) cut = fminf(cut, x2 * (1.0f + 1e-6f) + 1e-30f);
+        // the proof of global_screen_reduce_kernel once more, with the EXACT second cross-image distance found so far in
+        // place of its upper bound: c2 <= c1 (found), c1 (true) >= min_j L1(j)
+        if (c1 < INFINITY) {
+            float lmin = INFINITY;
+            for (int j = 0; j < n_img; ++j) {
+                if (j == i || img_off[j + 1] == img_off[j]) continue;
+                lmin = fminf(lmin, bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3]);
+            }
+            const float hsec = fmaxf(c1, 1.1920929e-07f);
+            // (lmin == +inf: no bound at all - the unscreened mode writes NaN bounds, which fminf skips)
+            if (lmin > -INFINITY && lmin < INFINITY && lmin * (1.0f - 1e-5f) - 1e-30f > ratio * hsec * (1.0f + 1e-5f)) {
+                dismissed[qc] = 1;
+                act = false;
+            }
+        }
+    }
+    const int i_first = __shfl(i, 0), i_last = __shfl(i, 63);
+    const bool edge = i != i_first && i != i_last;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int iw = pass ? i_last : i_first;
+        if (pass && i_last == i_first) break;
+        for (int j = 0; j < n_img; ++j) {
+            if (img_off[j + 1] == img_off[j]) continue;
+            bool keep = act && i == iw && j != i && j != a0 && j != a1 && j != a2;
             if (keep) {
-                const int job = i * n_img + j;
-                row_list[job_off[job] + atomicAdd(&list_count[job], 1u)] = (uint32_t)r;
+                const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
+                keep = !(l1 * (1.0f - 1e-5f) - 1e-30f > cut);  // (NaN / -inf bounds keep the image)
             }
+            global_list_append(keep, iw * n_img + j, r, job_off, row_list, list_count);
+        }
+    }
+    if (act && edge) {
+        for (int j = 0; j < n_img; ++j) {
+            if (img_off[j + 1] == img_off[j] || j == i || j == a0 || j == a1 || j == a2) continue;
+            const float l1 = bounds[(size_t)(job_off[(size_t)i * n_img + j] + r) * 3];
+            if (!(l1 * (1.0f - 1e-5f) - 1e-30f > cut)) row_list[job_off[i * n_img + j] + atomicAdd(&list_count[i * n_img + j], 1u)] = (uint32_t)r;
         }
     }
 }
@@ -2415,51 +2522,72 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         // no screen: NaN bounds - every comparison fails, every row survives and is searched in every image
         APS_HIP(hipMemsetAsync(bounds, 0xff, (size_t)slots * 3 * sizeof(float), stream()));
     }
+    Ws<float> cut((size_t)f);
+    Ws<int> first_imgs((size_t)f * 3);
     {
         Prof prof("global_screen_reduce");
-        global_screen_reduce_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, row_list, list_count);
+        global_screen_reduce_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs, row_list,
+                                                                        list_count);
         global_t3_init_kernel<<<cdiv(slots, 256), 256, 0, stream()>>>(t3_idx, t3_d, t3_b, slots);
     }
     check_launch("global_screen_reduce_kernel");
-    std::vector<unsigned int> h_cnt((size_t)n * n);
-    APS_HIP(hipMemcpyAsync(h_cnt.data(), list_count, (size_t)n * n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    std::vector<unsigned int> h_a((size_t)n * n), h_b((size_t)n * n);
+    APS_HIP(hipMemcpyAsync(h_a.data(), list_count, (size_t)n * n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));
-    bounds.reset();
-    int64_t n_surv = 0, n_pairs_rows = 0;
-    for (int i = 0; i < n; ++i) {
-        n_surv += h_cnt[(size_t)i * n + i];  // (the diagonal job lists every surviving row of image i)
-        for (int j = 0; j < n; ++j) n_pairs_rows += h_cnt[(size_t)i * n + j];
-    }
+    int64_t n_surv = 0;
+    for (int i = 0; i < n; ++i) n_surv += h_a[(size_t)i * n + i];  // (the diagonal job lists every surviving row of image i)
     if (n_survivors) *n_survivors = n_surv;
-    if (std::getenv("APS_TRACE"))
-        std::fprintf(stderr, "[aps] pooled matcher screen: %lld of %lld rows survive (%.2f %%); %lld of %lld (row, image) searches remain (%.2f %%)\n",
-                     (long long)n_surv, (long long)f, 100.0 * (double)n_surv / (double)std::max<int64_t>(f, 1), (long long)n_pairs_rows,
-                     (long long)slots, 100.0 * (double)n_pairs_rows / (double)slots);
     if (n_surv == 0) return slots;
-    // ---- the exact three nearest rows (with a certified bound) of every remaining (row, image) pair ----
+    // ---- the exact three nearest rows (with a certified bound) of the listed (row, image) pairs, in two phases ----
     std::vector<MatchJob> cj;
-    std::vector<WgJob> lw;
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const int nA = (int)(img_off[i + 1] - img_off[i]), nB = (int)(img_off[j + 1] - img_off[j]);
-            cj.push_back(make_job(prep[i], prep[j], nA, nB, job_off[(size_t)i * n + j]));  // (job index == i n + j)
-            if (nA == 0 || nB == 0) continue;
-            const unsigned int cnt = h_cnt[(size_t)i * n + j];
-            for (unsigned int r = 0; r < cnt; r += kTMB) lw.push_back({i * n + j, (int)r, (int)std::min<unsigned int>(kTMB, cnt - r)});
-        }
+        for (int j = 0; j < n; ++j)
+            cj.push_back(make_job(prep[i], prep[j], (int)(img_off[i + 1] - img_off[i]), (int)(img_off[j + 1] - img_off[j]),
+                                  job_off[(size_t)i * n + j]));  // (job index == i n + j)
     Ws<MatchJob> dcj(cj.size());
-    Ws<WgJob> dlw(std::max<size_t>(lw.size(), 1));
     Ws<uint32_t> fb_list(1);
     Ws<unsigned int> fb_count(cj.size());
     APS_HIP(hipMemcpyAsync(dcj, cj.data(), cj.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
-    if (!lw.empty()) APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
-    if (!lw.empty()) {
-        Prof prof("match_cand_f16");
-        match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(dcj, dlw, (int)lw.size(), nullptr, nullptr, nullptr, fb_list,
-                                                                                fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, row_list);
+    auto search = [&](const std::vector<unsigned int>& from, const std::vector<unsigned int>& to) {  // list entries [from, to) of every job
+        std::vector<WgJob> lw;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                if (img_off[i + 1] == img_off[i] || img_off[j + 1] == img_off[j]) continue;
+                const size_t job = (size_t)i * n + j;
+                for (unsigned int r = from[job]; r < to[job]; r += kTMB) lw.push_back({(int)job, (int)r, (int)std::min<unsigned int>(kTMB, to[job] - r)});
+            }
+        if (lw.empty()) return;
+        Ws<WgJob> dlw(lw.size());
+        APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+        {
+            Prof prof("match_cand_f16");
+            match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(dcj, dlw, (int)lw.size(), nullptr, nullptr, nullptr, fb_list,
+                                                                                    fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, row_list);
+        }
+        check_launch("match_cand_f16_kernel (pooled, list mode)");
+        APS_HIP(hipStreamSynchronize(stream()));  // lw / dlw go out of scope
+    };
+    const std::vector<unsigned int> zero((size_t)n * n, 0u);
+    search(zero, h_a);  // phase A: the own image and the three most promising ones
+    {
+        Prof prof("global_screen_reduce");
+        global_phase_b_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs, t3_idx, t3_d,
+                                                                  row_list, list_count);
     }
-    check_launch("match_cand_f16_kernel (pooled, list mode)");
-    APS_HIP(hipStreamSynchronize(stream()));  // the host tables and the Prepared blocks must outlive the launches
+    check_launch("global_phase_b_kernel");
+    APS_HIP(hipMemcpyAsync(h_b.data(), list_count, (size_t)n * n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    bounds.reset();
+    int64_t n_a = 0, n_b = 0;
+    for (size_t job = 0; job < (size_t)n * n; ++job) {
+        n_a += h_a[job];
+        n_b += h_b[job] - h_a[job];
+    }
+    if (std::getenv("APS_TRACE"))
+        std::fprintf(stderr, "[aps] pooled matcher screen: %lld of %lld rows survive (%.2f %%); (row, image) searches: %lld first + %lld more of %lld (%.2f %%)\n",
+                     (long long)n_surv, (long long)f, 100.0 * (double)n_surv / (double)std::max<int64_t>(f, 1), (long long)n_a, (long long)n_b,
+                     (long long)slots, 100.0 * (double)(n_a + n_b) / (double)slots);
+    search(h_a, h_b);  // phase B: every other image that can still hold one of the four nearest
     return slots;
 }
 
