@@ -210,6 +210,58 @@ def ransac_homography(p1, p2, sample_idx, max_distance=5.5, confidence=99.9, max
     return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value
 
 
+TFORM_TYPES = {"projective": 0, "affine": 1, "similarity": 2, "rigid": 3, "translation": 4}
+_orc_tform_min_points = _sig("orc_tform_min_points", [_i], _i)
+_orc_fit_tform = _sig("orc_fit_tform", [_i, _vp, _vp, _i64, _vp, _i64, _vp], _i)
+_orc_ransac_score_tform = _sig("orc_ransac_score_tform", [_i, _vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp])
+_orc_ransac_tform = _sig("orc_ransac_tform", [_i, _vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
+
+
+def tform_min_points(tform):
+    return _orc_tform_min_points(TFORM_TYPES[tform])
+
+
+def fit_tform(tform, p1, p2, sel):
+    """estimateTransform for any transformType on the points listed in sel (0-based).  Returns (H 3x3, finite)."""
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    sel = np.ascontiguousarray(sel, np.int64)
+    H = np.zeros(9, np.float64)
+    ok = _orc_fit_tform(TFORM_TYPES[tform], a.ctypes.data, b.ctypes.data, m, sel.ctypes.data, len(sel), H.ctypes.data)
+    return H.reshape(3, 3).T.copy(), bool(ok)
+
+
+def ransac_score_tform(tform, Hs, p1, p2, thr, want_mask=True):
+    """findInliers for any transformType; Hs: T x 3 x 3.  Returns (n_inl[T], mean_err[T], mask[T, M])."""
+    Hs = np.asarray(Hs, np.float64)
+    T = Hs.shape[0]
+    Hc = np.ascontiguousarray(np.transpose(Hs, (0, 2, 1)))
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    n = np.zeros(T, np.int32)
+    e = np.zeros(T, np.float64)
+    mask = np.zeros((T, max(m, 1)), np.uint8) if want_mask else None
+    _orc_ransac_score_tform(TFORM_TYPES[tform], Hc.ctypes.data, T, a.ctypes.data, b.ctypes.data, m, m, float(thr),
+                            n.ctypes.data, e.ctypes.data, mask.ctypes.data if want_mask else None)
+    return n, e, (mask[:, :m] if want_mask else None)
+
+
+def ransac_tform(tform, p1, p2, sample_idx, max_distance=5.5, confidence=99.9, max_iter=500):
+    """estimateTransformationRANSAC for any transformType.  sample_idx: n_samples x 4, 1-based (the first minPoints
+    entries of a row are the sample).  Returns (model 3x3, mask bool[M], found, draws consumed)."""
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    s = np.ascontiguousarray(sample_idx, np.uint32)
+    model = np.zeros(9, np.float64)
+    mask = np.zeros(max(m, 1), np.uint8)
+    found = C.c_int(0)
+    trials = C.c_int(0)
+    _orc_ransac_tform(TFORM_TYPES[tform], a.ctypes.data, b.ctypes.data, m, m, s.ctypes.data, s.shape[0],
+                      float(max_distance), float(confidence), int(max_iter), model.ctypes.data, mask.ctypes.data,
+                      C.byref(found), C.byref(trials))
+    return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value
+
+
 _orc_mlesac_homography = _sig("orc_mlesac_homography",
                               [_vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
 _orc_mlesac_eval = _sig("orc_mlesac_eval", [_vp, _vp, _vp, _i64, _i64, _d, _vp, _vp], _d)

@@ -542,3 +542,388 @@ ORC_API void orc_mlesac_homography(const double* p1, const double* p2, int64_t m
     free(cur);
     free(best_mask);
 }
+
+/* ================================================================================================
+ * The other transformTypes of estimateTransformationRANSAC.m: 'affine' (:227-288), 'similarity'
+ * (:290-356), 'rigid' (:358-421), 'translation' (:423-452); findInliers' one-way error for them
+ * (:483-497); minimal samples 3 / 2 / 2 / 1 (getTransformParams :612-660).  PARITY UNPINNED like the
+ * projective path.  Fixed here and mirrored by the HIP path:
+ *   - draws: the FIRST minPoints entries of every 4-column draw are the sample;
+ *   - estimateAffine's svd-based pseudo-inverse of the block matrix [P 0; 0 P] (P = [x y 1]) is evaluated on
+ *     the 3x3 Gram matrix P'P by cyclic Jacobi: h = sum_k v_k (v_k' P' b) / lambda_k over the kept k.  A
+ *     singular value is kept when sqrt(lambda_k) >= 1e-10 sqrt(lambda_max) (:263-267); a lambda_k at the
+ *     rounding level of the Gram sums (<= 64 eps lambda_max) stands for a singular value the reference's
+ *     svd reports below that threshold (exactly collinear samples) and is dropped;
+ *   - [U,S,V] = svd(M) of the 2x2 cross-covariance M = pts2c' * pts1c and R = V*diag(1,det(V*U'))*U'
+ *     (:322-323, :391-403) in closed form: with E = M11 + M22, A = M21 - M12, r = hypot(E, A):
+ *     R = [E A; -A E] / r (the transpose of the least-squares rotation: the reference's V and U are swapped
+ *     with respect to Kabsch's formula, and that is what is restated); singular values Q + T and |Q - T|,
+ *     Q = hypot(E, A)/2, T = hypot(M11 - M22, M21 + M12)/2;  rigid's second svd (:406-407, re-orthogonalising
+ *     an orthogonal matrix) is a rounding-level no-op and is dropped;
+ *   - median (:335,:339,:445-446): exact order statistic; even counts a + (b - a)/2 (MATLAB's meanof), or
+ *     (a + b)/2 when the signs differ or one is infinite; NaN if any element is NaN;
+ *   - sums of a fit run over the selected points in ascending order; the Frobenius norms (:328) add all x
+ *     squares, then all y squares.
+ * ================================================================================================ */
+enum { TF_PROJECTIVE = 0, TF_AFFINE = 1, TF_SIMILARITY = 2, TF_RIGID = 3, TF_TRANSLATION = 4 };
+
+static int tf_min_points(int type) {
+    switch (type) {
+        case TF_AFFINE: return 3;
+        case TF_SIMILARITY: case TF_RIGID: return 2;
+        case TF_TRANSLATION: return 1;
+        default: return 4;
+    }
+}
+
+static int cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+/* MATLAB median of n >= 1 values (v is sorted in place) */
+static double median_inplace(double* v, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        if (isnan(v[i])) return NAN;
+    qsort(v, (size_t)n, sizeof(double), cmp_double);
+    if (n & 1) return v[(n - 1) / 2];
+    const double a = v[n / 2 - 1], b = v[n / 2];
+    const int sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+    if (sa != sb || isinf(a) || isinf(b)) return (a + b) / 2;
+    return a + (b - a) / 2;
+}
+
+/* H = T2 \ Hn * T1 (left to right), Hn row-major here; then the exact affine last row (:284-287 etc.) */
+static void denormalize_affine(const double Hn[9], double s1, double t1x, double t1y, double s2, double t2x,
+                               double t2y, double* H) {
+    double M[9];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Hn[3 * 2 + c];
+        M[2 + 3 * c] = m2;
+        M[1 + 3 * c] = (Hn[3 * 1 + c] - t2y * m2) / s2;
+        M[0 + 3 * c] = (Hn[3 * 0 + c] - t2x * m2) / s2;
+    }
+    for (int r = 0; r < 3; ++r) {
+        H[r + 3 * 0] = M[r + 3 * 0] * s1;
+        H[r + 3 * 1] = M[r + 3 * 1] * s1;
+        H[r + 3 * 2] = (M[r + 3 * 0] * t1x + M[r + 3 * 1] * t1y) + M[r + 3 * 2];
+    }
+    H[2 + 3 * 0] = 0.0;
+    H[2 + 3 * 1] = 0.0;
+    H[2 + 3 * 2] = 1.0;
+}
+
+/* cyclic Jacobi on a symmetric 3x3 (row-major), same rotation rule as jacobi9 */
+static void jacobi3(double* G, double* V) {
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) V[3 * p + q] = (p == q) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double gpq = G[3 * p + q];
+                const double gpp = G[3 * p + p], gqq = G[3 * q + q];
+                if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;
+                rotated = 1;
+                const double theta = (gqq - gpp) / (2.0 * gpq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                const int k = 3 - p - q; /* the one index that is neither p nor q */
+                const double gkp = G[3 * k + p], gkq = G[3 * k + q];
+                const double np_ = c * gkp - s * gkq;
+                const double nq_ = s * gkp + c * gkq;
+                G[3 * k + p] = np_; G[3 * p + k] = np_;
+                G[3 * k + q] = nq_; G[3 * q + k] = nq_;
+                G[3 * p + p] = gpp - t * gpq;
+                G[3 * q + q] = gqq + t * gpq;
+                G[3 * p + q] = 0.0;
+                G[3 * q + p] = 0.0;
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double vkp = V[3 * kk + p], vkq = V[3 * kk + q];
+                    V[3 * kk + p] = c * vkp - s * vkq;
+                    V[3 * kk + q] = s * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+/* estimateAffine (:227-288) */
+static int fit_affine(const double* x1, const double* y1, const double* x2, const double* y2, const int64_t* sel,
+                      int64_t n, double* H) {
+    double s1, t1x, t1y, s2, t2x, t2y;
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    double gxx = 0, gxy = 0, gx = 0, gyy = 0, gy = 0, g1 = 0, bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
+    for (int64_t e = 0; e < n; ++e) {
+        const double x = s1 * x1[sel[e]] + t1x, y = s1 * y1[sel[e]] + t1y;
+        const double u = s2 * x2[sel[e]] + t2x, v = s2 * y2[sel[e]] + t2y;
+        gxx = gxx + x * x; gxy = gxy + x * y; gx = gx + x;
+        gyy = gyy + y * y; gy = gy + y; g1 = g1 + 1.0;
+        bu[0] = bu[0] + x * u; bu[1] = bu[1] + y * u; bu[2] = bu[2] + u;
+        bv[0] = bv[0] + x * v; bv[1] = bv[1] + y * v; bv[2] = bv[2] + v;
+    }
+    double G[9] = {gxx, gxy, gx, gxy, gyy, gy, gx, gy, g1}, V[9];
+    jacobi3(G, V);
+    double lmax = G[0];
+    if (G[4] > lmax) lmax = G[4];
+    if (G[8] > lmax) lmax = G[8];
+    const double smax = sqrt(lmax > 0 ? lmax : 0.0);
+    double cu[3], cv[3];
+    for (int k = 0; k < 3; ++k) {
+        const double lam = G[3 * k + k];
+        const double sg = sqrt(lam > 0 ? lam : 0.0);
+        const int keep = sg > 0 && !(sg < 1e-10 * smax) && lam > 64.0 * DBL_EPS * lmax;
+        const double du = (V[3 * 0 + k] * bu[0] + V[3 * 1 + k] * bu[1]) + V[3 * 2 + k] * bu[2];
+        const double dv = (V[3 * 0 + k] * bv[0] + V[3 * 1 + k] * bv[1]) + V[3 * 2 + k] * bv[2];
+        cu[k] = keep ? du / lam : 0.0;
+        cv[k] = keep ? dv / lam : 0.0;
+    }
+    double Hn[9];
+    for (int j = 0; j < 3; ++j) {
+        Hn[3 * 0 + j] = (V[3 * j + 0] * cu[0] + V[3 * j + 1] * cu[1]) + V[3 * j + 2] * cu[2];
+        Hn[3 * 1 + j] = (V[3 * j + 0] * cv[0] + V[3 * j + 1] * cv[1]) + V[3 * j + 2] * cv[2];
+    }
+    Hn[6] = 0; Hn[7] = 0; Hn[8] = 1;
+    denormalize_affine(Hn, s1, t1x, t1y, s2, t2x, t2y, H);
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0;
+    return 1;
+}
+
+/* estimateSimilarity (:290-356) and estimateRigid (:358-421) */
+static int fit_sim_rigid(const double* x1, const double* y1, const double* x2, const double* y2, const int64_t* sel,
+                         int64_t n, int rigid, double* H) {
+    double s1, t1x, t1y, s2, t2x, t2y;
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    double sx = 0, sy = 0, su = 0, sv = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        sx = sx + (s1 * x1[sel[e]] + t1x); sy = sy + (s1 * y1[sel[e]] + t1y);
+        su = su + (s2 * x2[sel[e]] + t2x); sv = sv + (s2 * y2[sel[e]] + t2y);
+    }
+    const double dn = (double)n;
+    const double c1x = sx / dn, c1y = sy / dn, c2x = su / dn, c2y = sv / dn;
+    double m11 = 0, m12 = 0, m21 = 0, m22 = 0, fax = 0, fay = 0, fbx = 0, fby = 0;
+    double* q = rigid ? NULL : (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int64_t nq = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        const double ax = (s1 * x1[sel[e]] + t1x) - c1x, ay = (s1 * y1[sel[e]] + t1y) - c1y;
+        const double bx = (s2 * x2[sel[e]] + t2x) - c2x, by = (s2 * y2[sel[e]] + t2y) - c2y;
+        m11 = m11 + bx * ax; m12 = m12 + bx * ay; m21 = m21 + by * ax; m22 = m22 + by * ay;
+        if (!rigid) {
+            fax = fax + ax * ax; fay = fay + ay * ay; fbx = fbx + bx * bx; fby = fby + by * by;
+            const double ra = sqrt(ax * ax + ay * ay), rb = sqrt(bx * bx + by * by);
+            if (ra > 1e-10) q[nq++] = rb / ra;
+        }
+    }
+    const double E = m11 + m22, A = m21 - m12;
+    const double r = sqrt(E * E + A * A);
+    double c = E / r, sn = A / r;
+    double scale = 1.0;
+    if (rigid) {
+        const double F = m11 - m22, Gs = m21 + m12;
+        const double Q = 0.5 * r, T = 0.5 * sqrt(F * F + Gs * Gs);
+        const double sv1 = Q + T, sv2 = fabs(Q - T);
+        const double cond = sv1 / (sv2 > DBL_EPS ? sv2 : DBL_EPS);
+        if (cond > 1e6) { c = 1.0; sn = 0.0; } /* :397-399 */
+    } else {
+        const double sa = sqrt(fbx + fby) / sqrt(fax + fay);
+        if (nq > 0) {
+            double two[2] = {sa, median_inplace(q, nq)};
+            scale = median_inplace(two, 2);
+        } else {
+            scale = sa;
+        }
+        free(q);
+    }
+    /* R = [c sn; -sn c];  t = centroid2' - s*R*centroid1' with (s*R) formed first */
+    const double r11 = scale * c, r12 = scale * sn, r21 = scale * (-sn), r22 = scale * c;
+    const double tx = c2x - (r11 * c1x + r12 * c1y), ty = c2y - (r21 * c1x + r22 * c1y);
+    const double Hn[9] = {r11, r12, tx, r21, r22, ty, 0, 0, 1};
+    denormalize_affine(Hn, s1, t1x, t1y, s2, t2x, t2y, H);
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0;
+    return 1;
+}
+
+/* estimateTranslation (:423-452) */
+static int fit_translation(const double* x1, const double* y1, const double* x2, const double* y2, const int64_t* sel,
+                           int64_t n, double* H) {
+    double* d = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int64_t e = 0; e < n; ++e) d[e] = x2[sel[e]] - x1[sel[e]];
+    const double tx = median_inplace(d, n);
+    for (int64_t e = 0; e < n; ++e) d[e] = y2[sel[e]] - y1[sel[e]];
+    const double ty = median_inplace(d, n);
+    free(d);
+    const double Hc[9] = {1, 0, 0, 0, 1, 0, tx, ty, 1};
+    memcpy(H, Hc, sizeof Hc);
+    return isfinite(tx) && isfinite(ty);
+}
+
+static int fit_tform(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                     const int64_t* sel, int64_t n, double* H) {
+    switch (type) {
+        case TF_AFFINE: return fit_affine(x1, y1, x2, y2, sel, n, H);
+        case TF_SIMILARITY: return fit_sim_rigid(x1, y1, x2, y2, sel, n, 0, H);
+        case TF_RIGID: return fit_sim_rigid(x1, y1, x2, y2, sel, n, 1, H);
+        case TF_TRANSLATION: return fit_translation(x1, y1, x2, y2, sel, n, H);
+        default: return fit_homography(x1, y1, x2, y2, sel, n, H);
+    }
+}
+
+/* findInliers (:444-516) for the affine family and translation; projective goes to find_inliers above */
+static int find_inliers_tform(int type, const double* H, const double* x1, const double* y1, const double* x2,
+                              const double* y2, int64_t m, double thr, uint8_t* mask, double* mean_err) {
+    if (type == TF_PROJECTIVE) return find_inliers(H, x1, y1, x2, y2, m, thr, mask, mean_err);
+    double scale = 1.0; /* max(abs([pts1_homog(:); pts2_homog(:)])): the homogeneous ones are part of it (:487) */
+    if (type == TF_TRANSLATION) {
+        for (int64_t i = 0; i < m; ++i) {
+            if (fabs(x1[i]) > scale) scale = fabs(x1[i]);
+            if (fabs(y1[i]) > scale) scale = fabs(y1[i]);
+            if (fabs(x2[i]) > scale) scale = fabs(x2[i]);
+            if (fabs(y2[i]) > scale) scale = fabs(y2[i]);
+        }
+        thr = thr / scale;
+    }
+    double pc[64], pe[64], px[64], py[64];
+    for (int l = 0; l < 64; ++l) pc[l] = pe[l] = px[l] = py[l] = 0;
+    uint8_t* in_all = (uint8_t*)malloc((size_t)(m > 0 ? m : 1));
+    for (int64_t i = 0; i < m; ++i) {
+        const double X = (H_(0, 0) * x1[i] + H_(0, 1) * y1[i]) + H_(0, 2);
+        const double Y = (H_(1, 0) * x1[i] + H_(1, 1) * y1[i]) + H_(1, 2);
+        const double W = (H_(2, 0) * x1[i] + H_(2, 1) * y1[i]) + H_(2, 2);
+        const double ex = x2[i] - X / W, ey = y2[i] - Y / W;
+        double e = sqrt(ex * ex + ey * ey);
+        if (type == TF_TRANSLATION) e = e / scale;
+        if (!isfinite(e)) e = INFINITY;
+        if (fabs(W) < DBL_EPS) e = INFINITY;
+        const int in = e < thr;
+        in_all[i] = (uint8_t)in;
+        if (mask) mask[i] = (uint8_t)in;
+        if (in) {
+            const int l = (int)(i & 63);
+            pc[l] += 1.0;
+            pe[l] = pe[l] + e;
+            px[l] = px[l] + x1[i];
+            py[l] = py[l] + y1[i];
+        }
+    }
+    const double cnt = wave_reduce(pc);
+    const double se = wave_reduce(pe), sx = wave_reduce(px), sy = wave_reduce(py);
+    const int n = (int)cnt;
+    if (type == TF_AFFINE && n >= 3) { /* isDegenerate (:506-513, :537-574) */
+        const double mx = sx / cnt, my = sy / cnt;
+        double pxx[64], pxy[64], pyy[64];
+        for (int l = 0; l < 64; ++l) pxx[l] = pxy[l] = pyy[l] = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (in_all[i]) {
+                const int l = (int)(i & 63);
+                const double dx = x1[i] - mx, dy = y1[i] - my;
+                pxx[l] = pxx[l] + dx * dx;
+                pxy[l] = pxy[l] + dx * dy;
+                pyy[l] = pyy[l] + dy * dy;
+            }
+        const double sxx = wave_reduce(pxx), sxy = wave_reduce(pxy), syy = wave_reduce(pyy);
+        const double hs = 0.5 * (sxx + syy), hd = 0.5 * (sxx - syy);
+        const double r = sqrt(hd * hd + sxy * sxy);
+        const double l1 = hs + r;
+        double l2 = hs - r;
+        if (l2 < 0) l2 = 0;
+        if (sqrt(l2) / sqrt(l1) < 1e-3) {
+            if (mask) memset(mask, 0, (size_t)m);
+            free(in_all);
+            *mean_err = NAN;
+            return 0;
+        }
+    }
+    free(in_all);
+    *mean_err = n > 0 ? se / cnt : NAN;
+    return n;
+}
+
+ORC_API int orc_tform_min_points(int type) { return tf_min_points(type); }
+
+ORC_API int orc_fit_tform(int type, const double* p1, const double* p2, int64_t ldp, const int64_t* sel, int64_t n,
+                          double* H) {
+    return fit_tform(type, p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+}
+
+ORC_API void orc_ransac_score_tform(int type, const double* Hs, int n_hyp, const double* p1, const double* p2,
+                                    int64_t m, int64_t ldp, double thr, int32_t* n_inl, double* mean_err,
+                                    uint8_t* mask) {
+    for (int t = 0; t < n_hyp; ++t)
+        n_inl[t] = find_inliers_tform(type, Hs + 9 * t, p1, p1 + ldp, p2, p2 + ldp, m, thr,
+                                      mask ? mask + (size_t)t * m : NULL, mean_err + t);
+}
+
+/* The whole loop (:54-183) for any transformType.  sample_idx: 4 x n_samples, 1-based, column-major; the first
+ * minPoints entries of a column are the sample. */
+ORC_API void orc_ransac_tform(int type, const double* p1, const double* p2, int64_t m, int64_t ldp,
+                              const uint32_t* sample_idx, int n_samples, double max_distance, double confidence,
+                              int max_iter, double* model, uint8_t* inlier_mask, int* is_found, int* trials_used) {
+    const double *x1 = p1, *y1 = p1 + ldp, *x2 = p2, *y2 = p2 + ldp;
+    const int min_pts = tf_min_points(type);
+    memset(inlier_mask, 0, (size_t)m);
+    for (int e = 0; e < 9; ++e) model[e] = NAN;
+    *is_found = 0;
+    if (trials_used) *trials_used = 0;
+    if (m < min_pts) return;
+    int max_trials = max_iter;
+    const int max_skip = max_iter * 10;
+    int trial = 1, skip = 0, it = 0, best_n = 0, have_best = 0;
+    double best_err = INFINITY, bestH[9];
+    uint8_t* cur = (uint8_t*)malloc((size_t)m);
+    uint8_t* best_mask = (uint8_t*)calloc((size_t)m, 1);
+    while (trial <= max_trials && skip < max_skip && it < n_samples) {
+        int64_t sel[4];
+        int in_range = 1;
+        for (int k = 0; k < min_pts; ++k) {
+            sel[k] = (int64_t)sample_idx[4 * it + k] - 1;
+            if (sel[k] < 0 || sel[k] >= m) in_range = 0;
+        }
+        ++it;
+        double H[9];
+        if (!in_range || !fit_tform(type, x1, y1, x2, y2, sel, min_pts, H) || !check_model(H)) {
+            ++skip;
+            continue;
+        }
+        double me;
+        const int n = find_inliers_tform(type, H, x1, y1, x2, y2, m, max_distance, cur, &me);
+        if (n >= min_pts) {
+            if (n > best_n || (n == best_n && me < best_err)) {
+                best_n = n;
+                best_err = me;
+                have_best = 1;
+                memcpy(bestH, H, sizeof bestH);
+                memcpy(best_mask, cur, (size_t)m);
+                const double ratio = (double)n / (double)m;
+                if (ratio > 0) {
+                    const double need = ceil(log(1 - confidence / 100) / log(1 - pow(ratio, min_pts)));
+                    if (need < (double)max_trials) max_trials = (int)need;
+                }
+            }
+        }
+        ++trial;
+    }
+    if (trials_used) *trials_used = it;
+    if (have_best && best_n >= min_pts) {
+        int64_t* sel = (int64_t*)malloc(sizeof(int64_t) * (size_t)best_n);
+        int64_t c = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (best_mask[i]) sel[c++] = i;
+        double R[9];
+        const int ok = fit_tform(type, x1, y1, x2, y2, sel, c, R) && check_model(R);
+        free(sel);
+        int use_refit = 0;
+        if (ok) {
+            double me;
+            use_refit = find_inliers_tform(type, R, x1, y1, x2, y2, m, max_distance, cur, &me) >= min_pts;
+        }
+        memcpy(model, use_refit ? R : bestH, sizeof bestH);
+        memcpy(inlier_mask, use_refit ? cur : best_mask, (size_t)m);
+        *is_found = 1;
+    }
+    free(cur);
+    free(best_mask);
+}
