@@ -21,7 +21,7 @@ APS_COLMAJOR, APS_ROWMAJOR = 0, 1
 APS_ROBUST_RANSAC, APS_ROBUST_MLESAC = 0, 1
 APS_RESIZE_BILINEAR, APS_RESIZE_BICUBIC = 0, 1
 APS_WARP_NEAREST, APS_WARP_BILINEAR, APS_WARP_BICUBIC = 0, 1, 2
-APS_TFORM_PROJECTIVE = 0
+APS_TFORM_PROJECTIVE, APS_TFORM_AFFINE, APS_TFORM_SIMILARITY, APS_TFORM_RIGID, APS_TFORM_TRANSLATION = 0, 1, 2, 3, 4
 APS_PROJ_CYLINDRICAL, APS_PROJ_SPHERICAL, APS_PROJ_PLANAR, APS_PROJ_STEREOGRAPHIC = 0, 1, 2, 3
 APS_BLEND_NONE, APS_BLEND_LINEAR, APS_BLEND_MULTIBAND = 0, 1, 2
 APS_NONE_LAST, APS_NONE_FIRST, APS_NONE_MAXANGLE = 0, 1, 2

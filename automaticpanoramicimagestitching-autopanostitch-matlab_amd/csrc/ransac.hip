@@ -1,9 +1,9 @@
-// ransac.hip — batched projective RANSAC on gfx950 (f64).
+// ransac.hip — batched RANSAC / MLESAC on gfx950 (f64).
 //
 // Restates PP/imageMatching/estimateTransformationRANSAC.m:54-183 (loop), :188-225 (normalised DLT),
 // :444-516 (findInliers), :518-535 (checkModel), :537-574 (isDegenerate), :579-610 (normalizePoints)
-// for transformType 'projective', batched over the candidate image pairs of
-// PP/imageMatching/imageMatching.m:121-156.
+// for transformType 'projective', and :227-452, :483-497 for 'affine' / 'similarity' / 'rigid' / 'translation' (the section
+// "The other transformTypes" below), batched over the candidate image pairs of PP/imageMatching/imageMatching.m:121-156.
 //
 // Shape of the computation (why it is batched this way):
 //   fit kernel    : one lane per (pair, draw): 4-point normalised DLT.  The right null vector of the
@@ -504,8 +504,12 @@ __global__ __launch_bounds__(256) void mlesac_score_kernel(
     }
 }
 
+__device__ __forceinline__ int wave_find_inliers_any(int type, const Mat3& H, const double* x1, const double* y1,
+                                                     const double* x2, const double* y2, int64_t m, double thr,
+                                                     uint8_t* mask, double* mean_err);  // (defined with the other transformTypes)
+
 // one wave per (pair, draw); 4 waves per block
-__global__ __launch_bounds__(256) void ransac_score_kernel(
+__global__ __launch_bounds__(256) void ransac_score_kernel(int type,
     const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
     const int64_t* __restrict__ pair_ptr, const int* __restrict__ act, int n_act, int c0, int nc,
     int n_samples, const double* __restrict__ Hs,
@@ -529,8 +533,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(
 #pragma unroll
     for (int e = 0; e < 9; ++e) H.m[e] = Hs[gid * 9 + e];
     double me;
-    const int n = wave_find_inliers(H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr,
-                                    nullptr, &me);
+    const int n = wave_find_inliers_any(type, H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr,
+                                        nullptr, &me);
     if (lane == 0) {
         n_inl[wid] = n;
         mean_err[wid] = me;
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(
 }
 
 // explicit-hypothesis scoring for aps_ransac_score: one wave per hypothesis, optional masks
-__global__ __launch_bounds__(256) void ransac_score_explicit_kernel(
+__global__ __launch_bounds__(256) void ransac_score_explicit_kernel(int type,
     const double* __restrict__ p1, const double* __restrict__ p2, int64_t ldp, int64_t m,
     const double* __restrict__ Hs, int n_hyp, double thr, int32_t* __restrict__ n_inl,
     double* __restrict__ mean_err, uint8_t* __restrict__ mask) {
@@ -548,8 +552,8 @@ __global__ __launch_bounds__(256) void ransac_score_explicit_kernel(
 #pragma unroll
     for (int e = 0; e < 9; ++e) H.m[e] = Hs[(int64_t)t * 9 + e];
     double me;
-    const int n = wave_find_inliers(H, p1, p1 + ldp, p2, p2 + ldp, m, thr,
-                                    mask ? mask + (int64_t)t * m : nullptr, &me);
+    const int n = wave_find_inliers_any(type, H, p1, p1 + ldp, p2, p2 + ldp, m, thr,
+                                        mask ? mask + (int64_t)t * m : nullptr, &me);
     if ((threadIdx.x & 63) == 0) {
         n_inl[t] = n;
         mean_err[t] = me;
@@ -763,6 +767,540 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The other transformTypes: 'affine' (:227-288), 'similarity' (:290-356), 'rigid' (:358-421), 'translation'
+// (:423-452), findInliers' one-way error for them (:483-497).  svd / pinv / median are the closed forms of the
+// oracle's second header (oracle/ransac_oracle.c), evaluated here in the same order.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int tf_min_points(int type) {
+    return type == APS_TFORM_AFFINE ? 3 : (type == APS_TFORM_SIMILARITY || type == APS_TFORM_RIGID) ? 2 : type == APS_TFORM_TRANSLATION ? 1 : 4;
+}
+
+// H = T2 \ Hn * T1 (left to right; Hn row-major), then the exact affine last row
+__device__ __forceinline__ void denormalize_affine(const double* Hn, const Norm& n1, const Norm& n2, Mat3& H) {
+    Mat3 M;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Hn[6 + c];
+        M3(M, 2, c) = m2;
+        M3(M, 1, c) = (Hn[3 + c] - n2.ty * m2) / n2.s;
+        M3(M, 0, c) = (Hn[c] - n2.tx * m2) / n2.s;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        M3(H, r, 0) = M3(M, r, 0) * n1.s;
+        M3(H, r, 1) = M3(M, r, 1) * n1.s;
+        M3(H, r, 2) = (M3(M, r, 0) * n1.tx + M3(M, r, 1) * n1.ty) + M3(M, r, 2);
+    }
+    M3(H, 2, 0) = 0.0;
+    M3(H, 2, 1) = 0.0;
+    M3(H, 2, 2) = 1.0;
+}
+
+// cyclic Jacobi on a symmetric 3x3 (row-major), the rotation rule of jacobi9
+__device__ __forceinline__ void jacobi3(double* G, double* V) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) V[e] = (e % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double gpq = G[3 * p + q];
+                const double gpp = G[3 * p + p], gqq = G[3 * q + q];
+                if (!(fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq)))) {
+                    rotated = true;
+                    const double theta = (gqq - gpp) / (2.0 * gpq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0);
+                    const double s = t * c;
+                    const int k = 3 - p - q;
+                    const double gkp = G[3 * k + p], gkq = G[3 * k + q];
+                    const double np_ = c * gkp - s * gkq;
+                    const double nq_ = s * gkp + c * gkq;
+                    G[3 * k + p] = np_;
+                    G[3 * p + k] = np_;
+                    G[3 * k + q] = nq_;
+                    G[3 * q + k] = nq_;
+                    G[3 * p + p] = gpp - t * gpq;
+                    G[3 * q + q] = gqq + t * gpq;
+                    G[3 * p + q] = 0.0;
+                    G[3 * q + p] = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const double vkp = V[3 * kk + p], vkq = V[3 * kk + q];
+                        V[3 * kk + p] = c * vkp - s * vkq;
+                        V[3 * kk + q] = s * vkp + c * vkq;
+                    }
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+// MATLAB's median of two values
+__device__ __forceinline__ double median2(double a, double b) {
+    if (isnan(a) || isnan(b)) return NAN;
+    if (b < a) {
+        const double t = a;
+        a = b;
+        b = t;
+    }
+    const int sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+    if (sa != sb || isinf(a) || isinf(b)) return (a + b) / 2;
+    return a + (b - a) / 2;
+}
+
+// what a median callback may need to form its per-point values
+struct FitCtx {
+    Norm n1, n2;
+    double c1x, c1y, c2x, c2y;
+};
+enum { MED_DX = 0, MED_DY = 1, MED_RATIO = 2 };
+
+// The estimators over an ordered point selection.  each(body) calls body(x1, y1, x2, y2) for every selected point in
+// ascending order; med(which, ctx, &n_valid) returns the MATLAB median of the per-point quantity `which` over the selection
+// (MED_RATIO: |pts2c| / |pts1c| over the points with |pts1c| > 1e-10; n_valid = how many there were).  Every caller of
+// one fit evaluates the same expressions in the same order, so a wave may run it redundantly in all lanes.
+template <class Each, class Med>
+__device__ __forceinline__ bool fit_tform(int type, int n, Each&& each, Med&& med, Mat3& H) {
+    FitCtx cx{};
+    if (type == APS_TFORM_TRANSLATION) {
+        int nv;
+        const double tx = med(MED_DX, cx, &nv);
+        const double ty = med(MED_DY, cx, &nv);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) H.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+        M3(H, 0, 2) = tx;
+        M3(H, 1, 2) = ty;
+        return isfinite(tx) && isfinite(ty);
+    }
+    const double dn = (double)n;
+    {  // normalizePoints (:579-610) of both sets
+        double sx = 0, sy = 0, ux = 0, uy = 0;
+        each([&](double a, double b, double c, double d) {
+            sx = sx + a;
+            sy = sy + b;
+            ux = ux + c;
+            uy = uy + d;
+        });
+        const double ax = sx / dn, ay = sy / dn, bx = ux / dn, by = uy / dn;
+        double sd = 0, ud = 0;
+        each([&](double a, double b, double c, double d) {
+            const double dx = a - ax, dy = b - ay;
+            sd = sd + sqrt(dx * dx + dy * dy);
+            const double ex = c - bx, ey = d - by;
+            ud = ud + sqrt(ex * ex + ey * ey);
+        });
+        cx.n1.s = 1.0 / (sd / dn);
+        cx.n1.tx = -cx.n1.s * ax;
+        cx.n1.ty = -cx.n1.s * ay;
+        cx.n2.s = 1.0 / (ud / dn);
+        cx.n2.tx = -cx.n2.s * bx;
+        cx.n2.ty = -cx.n2.s * by;
+    }
+    const Norm n1 = cx.n1, n2 = cx.n2;
+    double Hn[9];
+    if (type == APS_TFORM_AFFINE) {
+        double gxx = 0, gxy = 0, gx = 0, gyy = 0, gy = 0, g1 = 0, bu0 = 0, bu1 = 0, bu2 = 0, bv0 = 0, bv1 = 0, bv2 = 0;
+        each([&](double a, double b, double c, double d) {
+            const double x = n1.s * a + n1.tx, y = n1.s * b + n1.ty;
+            const double u = n2.s * c + n2.tx, v = n2.s * d + n2.ty;
+            gxx = gxx + x * x;
+            gxy = gxy + x * y;
+            gx = gx + x;
+            gyy = gyy + y * y;
+            gy = gy + y;
+            g1 = g1 + 1.0;
+            bu0 = bu0 + x * u;
+            bu1 = bu1 + y * u;
+            bu2 = bu2 + u;
+            bv0 = bv0 + x * v;
+            bv1 = bv1 + y * v;
+            bv2 = bv2 + v;
+        });
+        double G[9] = {gxx, gxy, gx, gxy, gyy, gy, gx, gy, g1}, V[9];
+        jacobi3(G, V);
+        double lmax = G[0];
+        if (G[4] > lmax) lmax = G[4];
+        if (G[8] > lmax) lmax = G[8];
+        const double smax = sqrt(lmax > 0 ? lmax : 0.0);
+        double cu[3], cv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double lam = G[3 * k + k];
+            const double sg = sqrt(lam > 0 ? lam : 0.0);
+            const bool keep = sg > 0 && !(sg < 1e-10 * smax) && lam > 64.0 * kDblEps * lmax;
+            const double du = (V[k] * bu0 + V[3 + k] * bu1) + V[6 + k] * bu2;
+            const double dv = (V[k] * bv0 + V[3 + k] * bv1) + V[6 + k] * bv2;
+            cu[k] = keep ? du / lam : 0.0;
+            cv[k] = keep ? dv / lam : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Hn[j] = (V[3 * j] * cu[0] + V[3 * j + 1] * cu[1]) + V[3 * j + 2] * cu[2];
+            Hn[3 + j] = (V[3 * j] * cv[0] + V[3 * j + 1] * cv[1]) + V[3 * j + 2] * cv[2];
+        }
+    } else {  // similarity / rigid
+        const bool rigid = type == APS_TFORM_RIGID;
+        double sx = 0, sy = 0, su = 0, sv = 0;
+        each([&](double a, double b, double c, double d) {
+            sx = sx + (n1.s * a + n1.tx);
+            sy = sy + (n1.s * b + n1.ty);
+            su = su + (n2.s * c + n2.tx);
+            sv = sv + (n2.s * d + n2.ty);
+        });
+        cx.c1x = sx / dn;
+        cx.c1y = sy / dn;
+        cx.c2x = su / dn;
+        cx.c2y = sv / dn;
+        const double c1x = cx.c1x, c1y = cx.c1y, c2x = cx.c2x, c2y = cx.c2y;
+        double m11 = 0, m12 = 0, m21 = 0, m22 = 0, fax = 0, fay = 0, fbx = 0, fby = 0;
+        each([&](double a, double b, double c, double d) {
+            const double ax = (n1.s * a + n1.tx) - c1x, ay = (n1.s * b + n1.ty) - c1y;
+            const double bx = (n2.s * c + n2.tx) - c2x, by = (n2.s * d + n2.ty) - c2y;
+            m11 = m11 + bx * ax;
+            m12 = m12 + bx * ay;
+            m21 = m21 + by * ax;
+            m22 = m22 + by * ay;
+            fax = fax + ax * ax;
+            fay = fay + ay * ay;
+            fbx = fbx + bx * bx;
+            fby = fby + by * by;
+        });
+        const double E = m11 + m22, A = m21 - m12;
+        const double r = sqrt(E * E + A * A);
+        double c = E / r, sn = A / r;
+        double scale = 1.0;
+        if (rigid) {
+            const double F = m11 - m22, Gs = m21 + m12;
+            const double Q = 0.5 * r, T = 0.5 * sqrt(F * F + Gs * Gs);
+            const double sv1 = Q + T, sv2 = fabs(Q - T);
+            const double cond = sv1 / (sv2 > kDblEps ? sv2 : kDblEps);
+            if (cond > 1e6) {
+                c = 1.0;
+                sn = 0.0;
+            }
+        } else {
+            const double sa = sqrt(fbx + fby) / sqrt(fax + fay);
+            int nq = 0;
+            const double mq = med(MED_RATIO, cx, &nq);
+            scale = nq > 0 ? median2(sa, mq) : sa;
+        }
+        const double r11 = scale * c, r12 = scale * sn, r21 = scale * (-sn), r22 = scale * c;
+        Hn[0] = r11;
+        Hn[1] = r12;
+        Hn[2] = c2x - (r11 * c1x + r12 * c1y);
+        Hn[3] = r21;
+        Hn[4] = r22;
+        Hn[5] = c2y - (r21 * c1x + r22 * c1y);
+    }
+    Hn[6] = 0;
+    Hn[7] = 0;
+    Hn[8] = 1;
+    denormalize_affine(Hn, n1, n2, H);
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    return true;
+}
+
+// the per-point quantity a median runs over (valid = it takes part)
+__device__ __forceinline__ double med_value(int which, const FitCtx& cx, double a, double b, double c, double d, bool* valid) {
+    *valid = true;
+    if (which == MED_DX) return (c - a) + 0.0;  // (+ 0.0: no negative zero among the sort keys)
+    if (which == MED_DY) return (d - b) + 0.0;
+    const double ax = (cx.n1.s * a + cx.n1.tx) - cx.c1x, ay = (cx.n1.s * b + cx.n1.ty) - cx.c1y;
+    const double bx = (cx.n2.s * c + cx.n2.tx) - cx.c2x, by = (cx.n2.s * d + cx.n2.ty) - cx.c2y;
+    const double ra = sqrt(ax * ax + ay * ay), rb = sqrt(bx * bx + by * by);
+    *valid = ra > 1e-10;
+    return rb / ra;
+}
+
+// minimal-sample fit of one lane: K points in registers
+template <int K>
+__device__ __forceinline__ bool fit_sample(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                                           Mat3& H) {
+    auto each = [&](auto&& body) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) body(x1[k], y1[k], x2[k], y2[k]);
+    };
+    auto med = [&](int which, const FitCtx& cx, int* nv) -> double {
+        double v[K];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            bool valid;
+            const double q = med_value(which, cx, x1[k], y1[k], x2[k], y2[k], &valid);
+            if (valid) {
+                if (n == 0) v[0] = q;
+                if (K > 1 && n == 1) v[K > 1 ? 1 : 0] = q;
+                ++n;
+            }
+        }
+        *nv = n;
+        if (n == 0) return NAN;
+        if (n == 1) return v[0];
+        return median2(v[0], v[K > 1 ? 1 : 0]);  // K <= 2 wherever a median is taken (similarity 2, translation 1)
+    };
+    return fit_tform(type, K, each, med, H);
+}
+
+__global__ __launch_bounds__(64) void tform_fit_kernel(int type, const double* __restrict__ pts1, const double* __restrict__ pts2,
+                                                        int64_t ldp, const int64_t* __restrict__ pair_ptr,
+                                                        const int* __restrict__ act, int n_act, int c0, int nc,
+                                                        const uint32_t* __restrict__ sample_idx, int n_samples,
+                                                        double* __restrict__ Hs, uint8_t* __restrict__ valid) {
+    const int64_t wid = blockIdx.x * (int64_t)64 + threadIdx.x;
+    if (wid >= (int64_t)n_act * nc) return;
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    const int K = tf_min_points(type);
+    double x1[3], y1[3], x2[3], y2[3];
+    bool ok = m >= K;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t id = k < K ? sample_idx[gid * 4 + k] : 1u;
+        if (k < K && (id < 1 || (int64_t)id > m)) ok = false;
+        const int64_t row = r0 + (ok ? (int64_t)id - 1 : 0);
+        const bool ld = ok && k < K;
+        x1[k] = ld ? pts1[row] : 0.0;
+        y1[k] = ld ? pts1[ldp + row] : 0.0;
+        x2[k] = ld ? pts2[row] : 0.0;
+        y2[k] = ld ? pts2[ldp + row] : 0.0;
+    }
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = 0.0;
+    if (ok) {
+        bool fin;
+        if (K == 3)
+            fin = fit_sample<3>(type, x1, y1, x2, y2, H);
+        else if (K == 2)
+            fin = fit_sample<2>(type, x1, y1, x2, y2, H);
+        else
+            fin = fit_sample<1>(type, x1, y1, x2, y2, H);
+        ok = fin && check_model(H);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
+    valid[wid] = ok ? 1 : 0;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off);
+        if (o > v) v = o;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// findInliers (:444-516) for the affine family and translation: all 64 lanes of a wave, same arguments
+__device__ int wave_find_inliers_t(int type, const Mat3& H, const double* __restrict__ x1, const double* __restrict__ y1,
+                                   const double* __restrict__ x2, const double* __restrict__ y2, int64_t m, double thr,
+                                   uint8_t* __restrict__ mask, double* mean_err) {
+    const int lane = threadIdx.x & 63;
+    double scale = 1.0;  // max(abs([pts1_homog(:); pts2_homog(:)])): the homogeneous ones take part (:487)
+    if (type == APS_TFORM_TRANSLATION) {
+        for (int64_t i = lane; i < m; i += 64) {
+            if (fabs(x1[i]) > scale) scale = fabs(x1[i]);
+            if (fabs(y1[i]) > scale) scale = fabs(y1[i]);
+            if (fabs(x2[i]) > scale) scale = fabs(x2[i]);
+            if (fabs(y2[i]) > scale) scale = fabs(y2[i]);
+        }
+        scale = wave_max(scale);
+        thr = thr / scale;
+    }
+    auto error_of = [&](int64_t i) -> double {
+        const double X = (M3(H, 0, 0) * x1[i] + M3(H, 0, 1) * y1[i]) + M3(H, 0, 2);
+        const double Y = (M3(H, 1, 0) * x1[i] + M3(H, 1, 1) * y1[i]) + M3(H, 1, 2);
+        const double W = (M3(H, 2, 0) * x1[i] + M3(H, 2, 1) * y1[i]) + M3(H, 2, 2);
+        const double ex = x2[i] - X / W, ey = y2[i] - Y / W;
+        double e = sqrt(ex * ex + ey * ey);
+        if (type == APS_TFORM_TRANSLATION) e = e / scale;
+        if (!isfinite(e)) e = INFINITY;
+        if (fabs(W) < kDblEps) e = INFINITY;
+        return e;
+    };
+    double pc = 0, pe = 0, px = 0, py = 0;
+    for (int64_t i = lane; i < m; i += 64) {
+        const double e = error_of(i);
+        const bool in = e < thr;
+        if (mask) mask[i] = in ? 1 : 0;
+        if (in) {
+            pc += 1.0;
+            pe = pe + e;
+            px = px + x1[i];
+            py = py + y1[i];
+        }
+    }
+    const double cnt = wave_sum(pc);
+    const double se = wave_sum(pe), sx = wave_sum(px), sy = wave_sum(py);
+    const int n = (int)cnt;
+    if (type == APS_TFORM_AFFINE && n >= 3) {  // isDegenerate (:506-513, :537-574)
+        const double mx = sx / cnt, my = sy / cnt;
+        double pxx = 0, pxy = 0, pyy = 0;
+        for (int64_t i = lane; i < m; i += 64)
+            if (error_of(i) < thr) {
+                const double dx = x1[i] - mx, dy = y1[i] - my;
+                pxx = pxx + dx * dx;
+                pxy = pxy + dx * dy;
+                pyy = pyy + dy * dy;
+            }
+        const double sxx = wave_sum(pxx), sxy = wave_sum(pxy), syy = wave_sum(pyy);
+        const double hs = 0.5 * (sxx + syy), hd = 0.5 * (sxx - syy);
+        const double r = sqrt(hd * hd + sxy * sxy);
+        const double l1 = hs + r;
+        double l2 = hs - r;
+        if (l2 < 0) l2 = 0;
+        if (sqrt(l2) / sqrt(l1) < 1e-3) {
+            if (mask)
+                for (int64_t i = lane; i < m; i += 64) mask[i] = 0;
+            *mean_err = NAN;
+            return 0;
+        }
+    }
+    *mean_err = n > 0 ? se / cnt : NAN;
+    return n;
+}
+
+__device__ __forceinline__ int wave_find_inliers_any(int type, const Mat3& H, const double* x1, const double* y1,
+                                                     const double* x2, const double* y2, int64_t m, double thr,
+                                                     uint8_t* mask, double* mean_err) {
+    return type == APS_TFORM_PROJECTIVE ? wave_find_inliers(H, x1, y1, x2, y2, m, thr, mask, mean_err)
+                                        : wave_find_inliers_t(type, H, x1, y1, x2, y2, m, thr, mask, mean_err);
+}
+
+// k-th smallest (0-based) of the m sortable keys in `keys` (slots that do not take part hold ~0ull and k < #valid): an
+// MSB-first radix select, one counting pass per bit, all 64 lanes.  Exact and independent of the order of the slots.
+__device__ unsigned long long wave_kth_key(const unsigned long long* __restrict__ keys, int64_t m, int64_t k) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long prefix = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        int c = 0;
+        for (int64_t i = lane; i < m; i += 64) c += ((keys[i] >> bit) == (prefix >> bit)) ? 1 : 0;
+        const int64_t zeros = wave_sum_i(c);  // keys that agree with the prefix above `bit` and have a 0 there
+        if (k >= zeros) {
+            k -= zeros;
+            prefix |= 1ull << bit;
+        }
+    }
+    return prefix;
+}
+__device__ __forceinline__ unsigned long long sort_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// finalize for these types: one wave per pair (:146-181)
+__global__ __launch_bounds__(64) void tform_finalize_kernel(int type, const double* __restrict__ pts1,
+                                                             const double* __restrict__ pts2, int64_t ldp,
+                                                             const int64_t* __restrict__ pair_ptr, int n_samples,
+                                                             const double* __restrict__ Hs, const int32_t* __restrict__ best_it,
+                                                             double thr, double* __restrict__ models, uint8_t* __restrict__ mask,
+                                                             uint8_t* __restrict__ scratch_mask,
+                                                             unsigned long long* __restrict__ scratch_keys,
+                                                             int32_t* __restrict__ found, int32_t* __restrict__ n_final) {
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    const int min_pts = tf_min_points(type);
+    const double *x1 = pts1 + r0, *y1 = pts1 + ldp + r0, *x2 = pts2 + r0, *y2 = pts2 + ldp + r0;
+    uint8_t* out_mask = mask + r0;
+    uint8_t* tmp_mask = scratch_mask + r0;
+    unsigned long long* keys = scratch_keys + r0;
+    const int bi = best_it[p];
+    if (bi < 0) {
+        for (int64_t i = lane; i < m; i += 64) out_mask[i] = 0;
+        if (lane < 9) models[(int64_t)p * 9 + lane] = NAN;
+        if (lane == 0) {
+            found[p] = 0;
+            n_final[p] = 0;
+        }
+        return;
+    }
+    Mat3 Hb;
+    for (int e = 0; e < 9; ++e) Hb.m[e] = Hs[((int64_t)p * n_samples + bi) * 9 + e];
+    double me;
+    const int nb = wave_find_inliers_t(type, Hb, x1, y1, x2, y2, m, thr, out_mask, &me);
+    __threadfence_block();
+    __syncthreads();
+    // the refit walks the inliers in ascending order, staged through LDS 64 at a time; every lane evaluates the same sums
+    __shared__ double s_pt[4][64];
+    __shared__ uint8_t s_in[64];
+    auto each = [&](auto&& body) {
+        for (int64_t base = 0; base < m; base += 64) {
+            const int64_t i = base + lane;
+            const bool have = i < m;
+            s_pt[0][lane] = have ? x1[i] : 0.0;
+            s_pt[1][lane] = have ? y1[i] : 0.0;
+            s_pt[2][lane] = have ? x2[i] : 0.0;
+            s_pt[3][lane] = have ? y2[i] : 0.0;
+            s_in[lane] = have ? out_mask[i] : (uint8_t)0;
+            __syncthreads();
+            for (int e = 0; e < 64; ++e)
+                if (s_in[e]) body(s_pt[0][e], s_pt[1][e], s_pt[2][e], s_pt[3][e]);
+            __syncthreads();
+        }
+    };
+    auto med = [&](int which, const FitCtx& cx, int* nv) -> double {
+        int c_valid = 0, c_nan = 0;
+        for (int64_t i = lane; i < m; i += 64) {
+            unsigned long long key = ~0ull;
+            if (out_mask[i]) {
+                bool valid;
+                const double q = med_value(which, cx, x1[i], y1[i], x2[i], y2[i], &valid);
+                if (valid) {
+                    ++c_valid;
+                    if (isnan(q)) ++c_nan;
+                    key = sort_key(q);
+                }
+            }
+            keys[i] = key;
+        }
+        const int n = wave_sum_i(c_valid), n_nan = wave_sum_i(c_nan);
+        __threadfence_block();
+        __syncthreads();
+        *nv = n;
+        if (n == 0 || n_nan > 0) return NAN;
+        if (n & 1) return key_value(wave_kth_key(keys, m, (n - 1) / 2));
+        const double a = key_value(wave_kth_key(keys, m, n / 2 - 1)), b = key_value(wave_kth_key(keys, m, n / 2));
+        return median2(a, b);
+    };
+    Mat3 Hr;
+    const bool ok = fit_tform(type, nb, each, med, Hr) && check_model(Hr);
+    bool use_refit = false;
+    int nr = 0;
+    if (ok) {
+        nr = wave_find_inliers_t(type, Hr, x1, y1, x2, y2, m, thr, tmp_mask, &me);
+        use_refit = nr >= min_pts;
+    }
+    if (use_refit) {
+        __threadfence_block();
+        __syncthreads();
+        for (int64_t i = lane; i < m; i += 64) out_mask[i] = tmp_mask[i];
+    }
+    if (lane < 9) models[(int64_t)p * 9 + lane] = use_refit ? Hr.m[lane] : Hb.m[lane];
+    if (lane == 0) {
+        found[p] = 1;
+        n_final[p] = use_refit ? nr : nb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // seeded 4-subsets (stand-in for randperm(numPoints, 4), :96)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double mix_uniform(unsigned long long seed, unsigned long long key, unsigned long long ctr) {
@@ -784,31 +1322,26 @@ __global__ void draw_samples_kernel(const int64_t* __restrict__ counts, const un
     const int p = (int)(gid / n_samples), it = (int)(gid % n_samples);
     const long long n = counts[p];
     uint32_t* o = out + gid * 4;
-    if (n < 4) {
-        o[0] = o[1] = o[2] = o[3] = 1u;
-        return;
-    }
     const unsigned long long key = keys ? keys[p] : (unsigned long long)p;
-    auto draw = [&](int k) -> long long {
-        const long long v = (long long)(mix_uniform(seed, key, 4ull * it + k) * (double)(n - k));
-        return v < n - k - 1 ? v : n - k - 1;
-    };
-    const long long c0 = draw(0);
-    long long v = draw(1);
-    const long long c1 = v + (v >= c0);
-    const long long lo = c0 < c1 ? c0 : c1, hi = c0 < c1 ? c1 : c0;
-    v = draw(2);
-    v = v + (v >= lo);
-    const long long c2 = v + (v >= hi);
-    const long long l3 = lo < c2 ? lo : c2, h3 = hi > c2 ? hi : c2, m3 = c0 + c1 + c2 - l3 - h3;
-    v = draw(3);
-    v = v + (v >= l3);
-    v = v + (v >= m3);
-    const long long c3 = v + (v >= h3);
-    o[0] = (uint32_t)(c0 + 1);
-    o[1] = (uint32_t)(c1 + 1);
-    o[2] = (uint32_t)(c2 + 1);
-    o[3] = (uint32_t)(c3 + 1);
+    // partial Fisher-Yates without a table: the k-th draw picks among the n-k values not chosen yet, so it skips over
+    // the earlier picks in ascending order.  A pair with fewer than 4 matches gets n distinct entries, then ones.
+    long long srt[4];  // the picks so far, ascending
+    for (int k = 0; k < 4; ++k) {
+        if (k >= n) {
+            o[k] = 1u;
+            continue;
+        }
+        long long v = (long long)(mix_uniform(seed, key, 4ull * it + k) * (double)(n - k));
+        v = v < n - k - 1 ? v : n - k - 1;
+        for (int j = 0; j < k; ++j) v = v + (v >= srt[j]);
+        o[k] = (uint32_t)(v + 1);
+        int j = k;
+        while (j > 0 && srt[j - 1] > v) {
+            srt[j] = srt[j - 1];
+            --j;
+        }
+        srt[j] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,9 +1379,11 @@ __global__ void gather_match_points_kernel(const unsigned long long* __restrict_
 }
 
 static void check_opts(const aps_ransac_opts& o) {
-    APS_REQUIRE(o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
-                "only transformationType 'projective' is built (inputs.m:74)");
+    APS_REQUIRE(o.tform_type >= APS_TFORM_PROJECTIVE && o.tform_type <= APS_TFORM_TRANSLATION, APS_E_TYPE,
+                "unknown transformationType %d", o.tform_type);
     APS_REQUIRE(o.method == APS_ROBUST_RANSAC || o.method == APS_ROBUST_MLESAC, APS_E_ARG, "unknown robust estimator %d", o.method);
+    APS_REQUIRE(o.method == APS_ROBUST_RANSAC || o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
+                "estimateTransformationMLESAC is built for transformationType 'projective' only");
     APS_REQUIRE(o.max_iter > 0, APS_E_ARG, "maxIter must be positive");
     APS_REQUIRE(o.max_distance > 0, APS_E_ARG, "maxDistance must be positive");
     APS_REQUIRE(o.confidence > 0 && o.confidence < 100, APS_E_ARG, "inliersConfidence must be in (0,100)");
@@ -867,7 +1402,7 @@ struct Replay {
 // valid/n_inl/mean_err hold draws [st.it, upto) of this pair
 static void replay_loop(Replay& st, const uint8_t* valid, const int32_t* n_inl, const double* mean_err, int upto,
                         int64_t m, const aps_ransac_opts& o) {
-    const int min_pts = 4;
+    const int min_pts = tf_min_points(o.tform_type);
     const int max_skip = o.max_iter * 10;
     const int base = st.it;
     while (st.trial <= st.limit && st.skip < max_skip && st.it < upto) {
@@ -933,6 +1468,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     const int n_pairs = (int)h_ptr.size() - 1;
     if (n_pairs <= 0) return;
     const int mlesac = o.method == APS_ROBUST_MLESAC ? 1 : 0;
+    const int type = o.tform_type, min_pts = tf_min_points(type);
     const int64_t total_rows = h_ptr.back();
     const int64_t nh = (int64_t)n_pairs * n_samples;
     Ws<int64_t> d_ptr(n_pairs + 1);
@@ -941,6 +1477,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     Ws<double> Hs(nh * 9), merr(nh);
     Ws<uint8_t> valid(nh), scratch(std::max<int64_t>(total_rows, 1));
     Ws<int32_t> ninl(nh), best(n_pairs), d_act(n_pairs);
+    Ws<unsigned long long> med_keys(type == APS_TFORM_PROJECTIVE ? 1 : std::max<int64_t>(total_rows, 1));
     const size_t lds_bytes = 2 * 81 * 64 * sizeof(double);
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -960,7 +1497,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         const int64_t m = h_ptr[p + 1] - h_ptr[p];
         st[p].limit = o.max_iter;
         if (mlesac) st[p].best = o.max_distance * (double)m;
-        if (m < 4)
+        if (m < min_pts)
             st[p].done = true;
         else
             act.push_back(p);
@@ -978,8 +1515,12 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         APS_HIP(hipMemcpyAsync(d_act, act.data(), n_act * sizeof(int), hipMemcpyHostToDevice, stream()));
         {
             Prof prof("ransac_fit");
-            ransac_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                          d_samples, n_samples, Hs, valid, mlesac);
+            if (type == APS_TFORM_PROJECTIVE)
+                ransac_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                              d_samples, n_samples, Hs, valid, mlesac);
+            else
+                tform_fit_kernel<<<cdiv(nw, 64), 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                     d_samples, n_samples, Hs, valid);
         }
         check_launch("ransac_fit_kernel");
         {
@@ -988,7 +1529,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                 mlesac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
                                                                         n_samples, Hs, valid, o.max_distance, ninl, merr);
             else
-                ransac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                ransac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
                                                                         n_samples, Hs, valid, o.max_distance, ninl, merr);
         }
         check_launch("ransac_score_kernel");
@@ -1022,9 +1563,13 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
                            stream()));
     {
         Prof prof("ransac_finalize");
-    ransac_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs,
-                                                                  best, o.max_distance, d_models,
-                                                                  d_mask, scratch, d_found, d_ninl, mlesac);
+        if (type == APS_TFORM_PROJECTIVE)
+            ransac_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs, best, o.max_distance,
+                                                                  d_models, d_mask, scratch, d_found, d_ninl, mlesac);
+        else
+            tform_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, n_samples, Hs, best,
+                                                                 o.max_distance, d_models, d_mask, scratch, med_keys, d_found,
+                                                                 d_ninl);
     }
     check_launch("ransac_finalize_kernel");
     APS_HIP(hipStreamSynchronize(stream()));
@@ -1040,7 +1585,8 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
                      int64_t ldp, double thr, int tform_type, int32_t* n_inl, double* mean_err,
                      uint8_t* mask) {
     return guarded([&] {
-        APS_REQUIRE(tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE, "only 'projective' is built");
+        APS_REQUIRE(tform_type >= APS_TFORM_PROJECTIVE && tform_type <= APS_TFORM_TRANSLATION, APS_E_TYPE,
+                    "unknown transformationType %d", tform_type);
         APS_REQUIRE(n_hyp >= 0 && m >= 0, APS_E_ARG, "negative size");
         APS_REQUIRE(ldp >= m, APS_E_DIM, "ldp < m");
         APS_REQUIRE(n_hyp == 0 || (Hs && n_inl && mean_err), APS_E_ARG, "NULL argument");
@@ -1052,7 +1598,7 @@ int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double
         Out<double> oe(mean_err, n_hyp);
         Out<uint8_t> om(mask, (size_t)n_hyp * m);
         ransac_score_explicit_kernel<<<cdiv(n_hyp, 4), 256, 0, stream()>>>(
-            d1, d2, ldp, m, dH, n_hyp, thr, on, oe, om.present() ? om.get() : nullptr);
+            tform_type, d1, d2, ldp, m, dH, n_hyp, thr, on, oe, om.present() ? om.get() : nullptr);
         check_launch("ransac_score_explicit_kernel");
         on.commit();
         oe.commit();

@@ -19,7 +19,7 @@ def draw_samples(counts, n_samples, seed=0, keys=None):
     """randperm(numPoints, 4) for every loop iteration of every pair (estimateTransformationRANSAC.m:96).
 
     counts: matches per pair.  Returns uint32 [n_pairs, n_samples, 4], 1-based, distinct within a draw
-    (pairs with fewer than 4 matches get ones; they are never fitted).  Counter-based hash stream keyed
+    (a pair with fewer than 4 matches gets that many distinct entries, then ones).  Counter-based hash stream keyed
     by (`seed`, keys[p] or p): pass the GLOBAL pair index as key and the draws do not depend on how the
     pairs are sharded over GPUs."""
     counts = np.asarray(counts, np.int64).reshape(-1)
@@ -40,29 +40,22 @@ def draw_samples(counts, n_samples, seed=0, keys=None):
         x *= np.uint64(0x94D049BB133111EB)
         x ^= x >> np.uint64(31)
     u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
-    n = np.maximum(counts, 4)[:, None]
-    c = np.empty((P, n_samples, 4), np.int64)
-    def draw(k):
-        return np.minimum((u[..., k] * (n - k)).astype(np.int64), n - k - 1)
-
-    # partial Fisher-Yates without a table: the k-th draw picks among the n-k values not chosen yet, so it
-    # skips over the earlier picks in ascending order (sorting networks instead of np.sort: k <= 3)
-    c0 = draw(0)
-    v = draw(1)
-    c1 = v + (v >= c0)
-    lo, hi = np.minimum(c0, c1), np.maximum(c0, c1)
-    v = draw(2)
-    v = v + (v >= lo)
-    c2 = v + (v >= hi)
-    l3, h3 = np.minimum(lo, c2), np.maximum(hi, c2)
-    m3 = c0 + c1 + c2 - l3 - h3
-    v = draw(3)
-    v = v + (v >= l3)
-    v = v + (v >= m3)
-    c3 = v + (v >= h3)
-    c[..., 0], c[..., 1], c[..., 2], c[..., 3] = c0, c1, c2, c3
-    ok = counts >= 4
-    out[ok] = (c[ok] + 1).astype(np.uint32)
+    n = counts[:, None]
+    # partial Fisher-Yates without a table: the k-th draw picks among the n-k values not chosen yet, so it skips over
+    # the earlier picks in ascending order.  A pair with fewer than 4 matches gets n distinct entries, then ones.
+    srt = []  # the picks so far, ascending (element-wise)
+    for k in range(4):
+        left = np.maximum(n - k, 1)
+        v = np.minimum((u[..., k] * left).astype(np.int64), left - 1)
+        for s_j in srt:
+            v = v + (v >= s_j)
+        have = np.broadcast_to(k < n, v.shape)
+        out[..., k] = np.where(have, v + 1, 1).astype(np.uint32)
+        ins = v
+        for j in range(len(srt)):  # insert into the ascending list
+            lo, hi = np.minimum(srt[j], ins), np.maximum(srt[j], ins)
+            srt[j], ins = lo, hi
+        srt.append(ins)
     return out
 
 
@@ -79,9 +72,16 @@ def draw_samples_device(counts, n_samples, seed=0, keys=None):
     return out
 
 
-def _ransac_opts(input, method=None):
+TFORM_TYPES = {"projective": _capi.APS_TFORM_PROJECTIVE, "affine": _capi.APS_TFORM_AFFINE,
+               "similarity": _capi.APS_TFORM_SIMILARITY, "rigid": _capi.APS_TFORM_RIGID,
+               "translation": _capi.APS_TFORM_TRANSLATION}
+MIN_POINTS = {"projective": 4, "affine": 3, "similarity": 2, "rigid": 2, "translation": 1}  # getTransformParams :612-660
+
+
+def _ransac_opts(input, method=None, transformType=None):
     """aps_ransac_opts from the reference's `input` struct.  method: 'ransac' | 'mlesac' (default:
-    input.imageMatchingMethod, inputs.m:66); MLESAC's own defaults are maxDistance 2, 1000 trials (:740-765)."""
+    input.imageMatchingMethod, inputs.m:66); MLESAC's own defaults are maxDistance 2, 1000 trials (:740-765).
+    transformType defaults to input.transformationType (inputs.m:74)."""
     method = str(method if method is not None else input.get("imageMatchingMethod", "ransac")).lower()
     if method not in ("ransac", "mlesac"):
         raise ValueError(f"unknown imageMatchingMethod '{method}'")
@@ -89,20 +89,26 @@ def _ransac_opts(input, method=None):
     o.max_distance = float(input.get("maxDistance", 2.0))
     o.confidence = float(input.get("inliersConfidence", 99.9))
     o.max_iter = int(input.get("maxIter", 1000 if method == "mlesac" else 500))
-    o.tform_type = _capi.APS_TFORM_PROJECTIVE
+    tform = _check_type(transformType if transformType is not None else input.get("transformationType", "projective"), method)
+    o.tform_type = TFORM_TYPES[tform]
     o.method = _capi.APS_ROBUST_MLESAC if method == "mlesac" else _capi.APS_ROBUST_RANSAC
     return o
 
 
-def _check_type(transformType):
-    if str(transformType).lower() != "projective":
-        raise ValueError("Unknown transform type" if str(transformType).lower() not in
-                         ("translation", "rigid", "similarity", "affine") else
-                         "only transformationType 'projective' runs on the device path (inputs.m:74)")
+def _check_type(transformType, method="ransac"):
+    """The lower-cased transform type (getTransformParams :648-660 lower-cases too).  All five run through RANSAC; the
+    MLESAC estimators of the other four (estimateTransformationMLESAC.m:389-640) are not built."""
+    tform = str(transformType).lower()
+    if tform not in TFORM_TYPES:
+        raise ValueError("Unknown transform type")  # estimateTransformationRANSAC.m:658-659
+    if method == "mlesac" and tform != "projective":
+        raise NotImplementedError("estimateTransformationMLESAC runs on the device for transformationType 'projective' "
+                                  "only; use imageMatchingMethod 'ransac' for '%s'" % tform)
+    return tform
 
 
 def _estimate_robust(matchedPoints1, matchedPoints2, transformType, input, sample_idx, seed, method):
-    _check_type(transformType)
+    tform = _check_type(transformType, method)
     input = {} if input is None else input
     p1 = np.asfortranarray(np.asarray(matchedPoints1, np.float64))
     p2 = np.asfortranarray(np.asarray(matchedPoints2, np.float64))
@@ -111,9 +117,9 @@ def _estimate_robust(matchedPoints1, matchedPoints2, transformType, input, sampl
     if p1.shape[0] != p2.shape[0]:
         raise ValueError("matchedPoints1 and matchedPoints2 must have the same number of rows.")
     m = p1.shape[0]
-    if m < 4:  # :71-76
+    if m < MIN_POINTS[tform]:  # :71-76
         return None, np.zeros(m, bool), False
-    o = _ransac_opts(input, method)
+    o = _ransac_opts(input, method, tform)
     if sample_idx is None:
         sample_idx = draw_samples([m], o.max_iter + 64, seed)[0]
     s = np.ascontiguousarray(sample_idx, np.uint32)
@@ -147,7 +153,7 @@ def estimateTransformationMLESAC(points1, points2, transformationType, input=Non
     return _estimate_robust(points1, points2, transformationType, input, sample_idx, seed, "mlesac")
 
 
-def ransac_score(Hs, p1, p2, thr):
+def ransac_score(Hs, p1, p2, thr, transformType="projective"):
     """findInliers for T hypotheses (estimateTransformationRANSAC.m:444-516): (n_inl, mean_err, mask[T,M])."""
     Hs = np.asarray(Hs, np.float64)
     T = Hs.shape[0]
@@ -158,7 +164,7 @@ def ransac_score(Hs, p1, p2, thr):
     n = np.zeros(T, np.int32)
     e = np.zeros(T, np.float64)
     mask = np.zeros((T, max(m, 1)), np.uint8)
-    check(lib.aps_ransac_score(ptr(Hc), T, ptr(a), ptr(b), m, m, float(thr), _capi.APS_TFORM_PROJECTIVE,
+    check(lib.aps_ransac_score(ptr(Hc), T, ptr(a), ptr(b), m, m, float(thr), TFORM_TYPES[_check_type(transformType)],
                                ptr(n), ptr(e), ptr(mask)))
     return n, e, mask[:, :m]
 
@@ -268,7 +274,7 @@ def imageMatching(input, n, keypoints, matchesAll, imagesProcessed=None, seed=0)
         raise ValueError("keypoints must contain n elements (one per image).")
     if imagesProcessed is not None and len(imagesProcessed) != n:
         raise ValueError("images must contain n elements (one per image).")
-    _check_type(input.get("transformationType", "projective"))
+    _check_type(input.get("transformationType", "projective"), str(input.get("imageMatchingMethod", "ransac")).lower())
     allMatches = [[None] * n for _ in range(n)]
     numMatches = np.zeros((n, n))
     tforms = [[None] * n for _ in range(n)]

@@ -208,7 +208,15 @@ int aps_hamming_2nn(const uint8_t* A, int64_t n1, int64_t lda, const uint8_t* B,
  * (2) Geometric verification — PP/imageMatching/estimateTransformationRANSAC.m
  * ============================================================================================ */
 
-enum { APS_TFORM_PROJECTIVE = 0 };
+/* input.transformationType (inputs.m:74) = transformType of estimateTransformationRANSAC.m:612-660; minimal samples
+ * 4 / 3 / 2 / 2 / 1.  All five run through APS_ROBUST_RANSAC; APS_ROBUST_MLESAC is built for 'projective' only. */
+enum {
+    APS_TFORM_PROJECTIVE = 0,
+    APS_TFORM_AFFINE = 1,      /* estimateAffine :227-288: pseudo-inverse of the normalised design matrix        */
+    APS_TFORM_SIMILARITY = 2,  /* estimateSimilarity :290-356: rotation from the 2x2 cross-covariance, median scale */
+    APS_TFORM_RIGID = 3,       /* estimateRigid :358-421 (identity rotation when the cross-covariance is ill-conditioned) */
+    APS_TFORM_TRANSLATION = 4  /* estimateTranslation :423-452: per-axis median displacement                      */
+};
 
 /* a12 findInliers (estimateTransformationRANSAC.m:444-516) for T hypotheses at once.
  *   Hs    : f64 3x3xT, each 3x3 column-major (MATLAB page layout)
@@ -216,7 +224,9 @@ enum { APS_TFORM_PROJECTIVE = 0 };
  *   n_inl : int32[T]; mean_err: f64[T] (mean error over inliers, NaN if none);
  *   mask  : uint8 MxT column-major (may be NULL).
  * Projective: e = sqrt(|x2-Hx1|^2 + |x1-H^-1 x2|^2) < thr (:474-481); non-finite or |w|<eps -> inf
- * (:499-503); >=4 inliers whose centred x1 have s2/s1 < 1e-3 -> all false (:506-513,:567). */
+ * (:499-503); >=4 inliers whose centred x1 have s2/s1 < 1e-3 -> all false (:506-513,:567).
+ * Affine / similarity / rigid: e = |x2 - Hx1| (:483-484); translation: the same error and the threshold both divided by
+ * max(|coordinates|, 1) of the whole point set (:486-494); the collinearity test applies to affine (>= 3 inliers) only. */
 int aps_ransac_score(const double* Hs, int n_hyp, const double* p1, const double* p2, int64_t m,
                      int64_t ldp, double thr, int tform_type, int32_t* n_inl, double* mean_err,
                      uint8_t* mask);
@@ -227,14 +237,16 @@ typedef struct aps_ransac_opts {
     double max_distance; /* input.maxDistance        (inputs.m:69: 5.5)  */
     double confidence;   /* input.inliersConfidence  (inputs.m:72: 99.9) */
     int max_iter;        /* input.maxIter            (inputs.m:68: 500)  */
-    int tform_type;      /* APS_TFORM_PROJECTIVE                          */
+    int tform_type;      /* APS_TFORM_* (input.transformationType, inputs.m:74: 'projective')  */
     int method;          /* APS_ROBUST_RANSAC: estimateTransformationRANSAC.m (input.imageMatchingMethod 'ransac');
                             APS_ROBUST_MLESAC: estimateTransformationMLESAC.m:94-254 ('mlesac'): one-way distance,
                             truncated-loss score, refit on the inliers is the answer                */
 } aps_ransac_opts;
 
-/* a12 whole loop: [model, inliers, isFound] = estimateTransformationRANSAC(p1, p2, 'projective', input)
- * (estimateTransformationRANSAC.m:54-183).  The random 4-subsets are an INPUT: sample_idx is
+/* a12 whole loop: [model, inliers, isFound] = estimateTransformationRANSAC(p1, p2, transformType, input)
+ * (estimateTransformationRANSAC.m:54-183; the name dates from the projective-only rounds, opts->tform_type selects the
+ * model).  The random subsets are an INPUT for every type: the first minPoints entries of a 4-column draw are the
+ * sample.  sample_idx is
  * uint32 4 x n_samples column-major, 1-based, one column per loop iteration (each iteration of
  * :94-143 consumes one randperm draw, skipped ones included).  All hypotheses are fitted and scored
  * on the device in one batch; the data-dependent best/early-exit logic (:115-130) is replayed on the
@@ -255,7 +267,8 @@ int aps_ransac_draws_exhausted(void);
 /* The seeded stand-in for randperm(numPoints, 4) (estimateTransformationRANSAC.m:96): fills sample_idx
  * (uint32 4 x n_samples x n_pairs, 1-based) with distinct 4-subsets of 1..counts[p] from the counter-based
  * stream u = mix64(seed, keys[p] (or p if keys is NULL), 4*iteration + k) — identical to
- * imageMatching.draw_samples on the host.  Pairs with counts[p] < 4 get ones. */
+ * imageMatching.draw_samples on the host.  A pair with counts[p] < 4 gets counts[p] distinct entries followed by ones
+ * (enough for the transformTypes whose minimal sample it can still serve). */
 int aps_ransac_draw_samples(const int64_t* counts, const uint64_t* keys, int n_pairs, int n_samples,
                             uint64_t seed, uint32_t* sample_idx);
 

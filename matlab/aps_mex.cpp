@@ -233,21 +233,33 @@ static void cmd_hamming(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs
     if (nlhs > 2) plhs[2] = d2; else mxDestroyArray(d2);
 }
 
-// [model, inliers, isFound] = aps_mex('ransac_homography' | 'mlesac_homography', p1 Mx2, p2 Mx2, input, sampleIdx uint32 4xS)
+// [model, inliers, isFound] = aps_mex('ransac_homography' | 'mlesac_homography', p1 Mx2, p2 Mx2, input, sampleIdx uint32 4xS
+//                                      [, transformType = 'projective'])
 static void cmd_ransac(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[], bool mlesac) {
-    need(nrhs == 5 && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsUint32(prhs[4]), "aps:type", "usage: p1, p2 double Mx2; sampleIdx uint32 4xS");
+    need((nrhs == 5 || nrhs == 6) && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsUint32(prhs[4]), "aps:type", "usage: p1, p2 double Mx2; sampleIdx uint32 4xS");
+    need(mxGetM(prhs[4]) == 4, "aps:dim", "sampleIdx must have 4 rows");
+    int tform = APS_TFORM_PROJECTIVE, min_pts = 4;
+    if (nrhs == 6) {
+        const std::string t = str(prhs[5]);
+        if (t == "projective") tform = APS_TFORM_PROJECTIVE, min_pts = 4;
+        else if (t == "affine") tform = APS_TFORM_AFFINE, min_pts = 3;
+        else if (t == "similarity") tform = APS_TFORM_SIMILARITY, min_pts = 2;
+        else if (t == "rigid") tform = APS_TFORM_RIGID, min_pts = 2;
+        else if (t == "translation") tform = APS_TFORM_TRANSLATION, min_pts = 1;
+        else mexErrMsgIdAndTxt("aps:type", "Unknown transform type");
+    }
     const int64_t m = mxGetM(prhs[1]);
     need(mxGetM(prhs[2]) == (mwSize)m, "aps:dim", "matchedPoints1 and matchedPoints2 must have the same number of rows.");
     aps_ransac_opts o;
     o.max_distance = field(prhs[3], "maxDistance", 2.0);
     o.confidence = field(prhs[3], "inliersConfidence", 99.9);
     o.max_iter = (int)field(prhs[3], "maxIter", mlesac ? 1000 : 500);
-    o.tform_type = APS_TFORM_PROJECTIVE;
+    o.tform_type = tform;
     o.method = mlesac ? APS_ROBUST_MLESAC : APS_ROBUST_RANSAC;
     plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
     std::vector<uint8_t> mask(m ? m : 1);
     int found = 0;
-    if (m >= 4)
+    if (m >= min_pts)
         check(aps_ransac_homography(mxGetPr(prhs[1]), mxGetPr(prhs[2]), m, m, (const uint32_t*)mxGetData(prhs[4]), (int)mxGetN(prhs[4]), &o,
                                     mxGetPr(plhs[0]), mask.data(), &found, nullptr));
     if (nlhs > 1) {
