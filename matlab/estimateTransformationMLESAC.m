@@ -5,7 +5,8 @@ function [tform, inlierIdx, isFound] = estimateTransformationMLESAC(points1, poi
     %   inliers run in aps_mex.
     if nargin < 4, input = struct(); end
     if ~strcmpi(transformationType, 'projective')
-        % the other model classes run the reference's own host code (only the projective estimator is built on the device)
+        % MLESAC's estimators of the other model classes (:389-640) run the reference's own host code; with
+        % imageMatchingMethod 'ransac' all five types run on the device
         [tform, inlierIdx, isFound] = aps_call_shadowed('estimateTransformationMLESAC', mfilename('fullpath'), ...
             points1, points2, transformationType, input);
         return;
