@@ -220,64 +220,15 @@ __device__ __forceinline__ void pk_tap(f32x2& acc, const GaussK& gk, f32x2 v) {
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(kk), "v"(v));
 }
 
+// The two passes of blur_kernel / blur_base_kernel on a filled tile (s_in row-interleaved, see blur_kernel).
 template <int R>
-__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
-                                                   float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
-    // dec (optional): the next octave's base plane, out(2y, 2x) for y < dh, x < dw - written from the registers that
-    // hold the result instead of by a decimation pass that re-reads the plane.
-    // The haloed input tile is fetched in 16-byte pieces: the horizontal halo is rounded up to a multiple of four
-    // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
-    // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
+__device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row, const GaussK& gk, int x0, int y0, int h, int w,
+                                                 float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
     constexpr int RP = (R + 3) & ~3, OFF = RP - R;
-    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
-    static_assert(IH % 2 == 0 && kTH % 4 == 0, "row pairs");
-    // Both passes run two fma chains per v_pk_fma_f32, and a packed operand must be an aligned register pair.  A pair
-    // of horizontally adjacent inputs is aligned for every other tap only, so the passes pair the OTHER direction:
-    //   row pass   : one lane = 8 outputs of TWO consecutive rows; the tile is stored row-interleaved
-    //                (s_in[(y >> 1)][x][y & 1]), so the window of both rows is one contiguous run of aligned pairs;
-    //   column pass: one lane = 4 outputs of TWO adjacent columns of the (plainly stored) row-pass result.
-    // Every accumulator still sees its taps in ascending order: the scalar form's chain, bit for bit.
-    // Pitches (floats): 4 * odd, so that consecutive row pairs land on distinct 16-byte bank groups.
+    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R;
     constexpr int IP2 = 2 * IW + 4;
-    constexpr int RPITCH = kTW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
-    static_assert((IP2 / 4) % 2 == 1, "pitch");
-    __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
-    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    constexpr int RPITCH = kTW + 2;
     const int tid = threadIdx.x;
-    const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    // All of a thread's pieces are requested before the first one is parked in LDS: as a plain loop (request, wait, store,
-    // next) every workgroup paid the memory latency NPF times in series before its first barrier.
-    constexpr int NPF = (IH * NV + 255) / 256;
-    float4 pf[NPF];
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) {
-        const int e = tid + 256 * q;
-        const int ec = e < IH * NV ? e : IH * NV - 1;  // (threads past the end re-read the last piece and drop it)
-        const int ly = ec / NV, v = ec - ly * NV;
-        const int gy = reflect101(y0 + ly - R, h), gx = x0 - RP + 4 * v;
-        const float* row = in + (size_t)gy * w;
-        if (vec_ok && gx >= 0 && gx + 3 < w) {
-            pf[q] = *reinterpret_cast<const float4*>(row + gx);
-        } else {
-            pf[q].x = row[reflect101(gx, w)];
-            pf[q].y = row[reflect101(gx + 1, w)];
-            pf[q].z = row[reflect101(gx + 2, w)];
-            pf[q].w = row[reflect101(gx + 3, w)];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) {
-        const int e = tid + 256 * q;
-        if (e < IH * NV) {
-            const int ly = e / NV, v = e - ly * NV;
-            float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
-            dst[0] = pf[q].x;
-            dst[2] = pf[q].y;
-            dst[4] = pf[q].z;
-            dst[6] = pf[q].w;
-        }
-    }
     __syncthreads();
     // row pass: IH/2 row pairs x 8 segments of 8 outputs; consecutive lanes = consecutive row pairs
     for (int u = tid; u < (IH / 2) * (kTW / 8); u += 256) {
@@ -339,6 +290,156 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
             }
         }
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
+                                                   float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
+    // dec (optional): the next octave's base plane, out(2y, 2x) for y < dh, x < dw - written from the registers that
+    // hold the result instead of by a decimation pass that re-reads the plane.
+    // The haloed input tile is fetched in 16-byte pieces: the horizontal halo is rounded up to a multiple of four
+    // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
+    // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
+    constexpr int RP = (R + 3) & ~3, OFF = RP - R;
+    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
+    static_assert(IH % 2 == 0 && kTH % 4 == 0, "row pairs");
+    // Both passes run two fma chains per v_pk_fma_f32, and a packed operand must be an aligned register pair.  A pair
+    // of horizontally adjacent inputs is aligned for every other tap only, so the passes pair the OTHER direction:
+    //   row pass   : one lane = 8 outputs of TWO consecutive rows; the tile is stored row-interleaved
+    //                (s_in[(y >> 1)][x][y & 1]), so the window of both rows is one contiguous run of aligned pairs;
+    //   column pass: one lane = 4 outputs of TWO adjacent columns of the (plainly stored) row-pass result.
+    // Every accumulator still sees its taps in ascending order: the scalar form's chain, bit for bit.
+    // Pitches (floats): 4 * odd, so that consecutive row pairs land on distinct 16-byte bank groups.
+    constexpr int IP2 = 2 * IW + 4;
+    constexpr int RPITCH = kTW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
+    static_assert((IP2 / 4) % 2 == 1, "pitch");
+    __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
+    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int tid = threadIdx.x;
+    const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    // All of a thread's pieces are requested before the first one is parked in LDS: as a plain loop (request, wait, store,
+    // next) every workgroup paid the memory latency NPF times in series before its first barrier.
+    constexpr int NPF = (IH * NV + 255) / 256;
+    float4 pf[NPF];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int e = tid + 256 * q;
+        const int ec = e < IH * NV ? e : IH * NV - 1;  // (threads past the end re-read the last piece and drop it)
+        const int ly = ec / NV, v = ec - ly * NV;
+        const int gy = reflect101(y0 + ly - R, h), gx = x0 - RP + 4 * v;
+        const float* row = in + (size_t)gy * w;
+        if (vec_ok && gx >= 0 && gx + 3 < w) {
+            pf[q] = *reinterpret_cast<const float4*>(row + gx);
+        } else {
+            pf[q].x = row[reflect101(gx, w)];
+            pf[q].y = row[reflect101(gx + 1, w)];
+            pf[q].z = row[reflect101(gx + 2, w)];
+            pf[q].w = row[reflect101(gx + 3, w)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int e = tid + 256 * q;
+        if (e < IH * NV) {
+            const int ly = e / NV, v = e - ly * NV;
+            float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
+            dst[0] = pf[q].x;
+            dst[2] = pf[q].y;
+            dst[4] = pf[q].z;
+            dst[6] = pf[q].w;
+        }
+    }
+    blur_tile_passes<R>(s_in, s_row, gk, x0, y0, h, w, out, dec, dh, dw);
+}
+
+// The base plane of octave 0 in one pass: gray conversion, 2x bilinear upsample (gray_up_kernel's expressions, so the same
+// bits) and the first blur.  The tile's inputs are interpolated straight into the blur's LDS tile from the gray values of
+// the tile's footprint (computed into LDS first); neither the gray plane nor the doubled plane is ever stored - a 4K view
+// saves the 133 MB write of gray_up_kernel and the 133 MB read of the blur.  img is sh x sw; the output plane 2sh x 2sw.
+template <int R>
+__global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restrict__ img, int sh, int sw, int c, int layout,
+                                                        GaussK gk, float* __restrict__ out) {
+    constexpr int RP = (R + 3) & ~3;
+    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
+    constexpr int IP2 = 2 * IW + 4;
+    constexpr int RPITCH = kTW + 2;
+    constexpr int GW = IW / 2 + 3, GH = IH / 2 + 3;  // gray footprint of the haloed tile (+ the interpolation's neighbours)
+    __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
+    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
+    __shared__ float s_g[GH][GW + 1];
+    const int h = 2 * sh, w = 2 * sw;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int tid = threadIdx.x;
+    // source rows / columns of the doubled pixels [lo, hi] that exist (reflected halo pixels of outputs inside the plane fall
+    // into the same range): doubled pixel p reads sources floor(p/2 - 1/4) and the next one
+    const int lo_x = max(x0 - RP, 0), lo_y = max(y0 - R, 0);
+    const int cx0 = max((lo_x + 1) / 2 - 1, 0), cy0 = max((lo_y + 1) / 2 - 1, 0);
+    for (int e = tid; e < GH * GW; e += 256) {
+        const int ly = e / GW, lx = e - ly * GW;
+        const int y = min(cy0 + ly, sh - 1), x = min(cx0 + lx, sw - 1);
+        float v;
+        if (c == 1) {
+            v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * sw + x] : img[(size_t)x * sh + y]);
+        } else {
+            uint8_t ch[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                ch[k] = layout == APS_IMG_U8_HWC ? img[((size_t)y * sw + x) * 3 + k]
+                                                 : img[(size_t)k * sh * sw + (size_t)x * sh + y];
+            const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
+            v = (float)floor(d + 0.5);
+        }
+        s_g[ly][lx] = v;
+    }
+    // the interpolation's row and column terms (index of the first source in s_g, index of the second, second weight), once
+    // per tile row / column instead of once per pixel; same expressions as gray_up_kernel.  (The clamps only act on halo
+    // pixels of outputs beyond the plane's edge, whose results are never stored.)
+    __shared__ int s_ci[IW + IH][2];
+    __shared__ float s_cf[IW + IH];
+    if (tid < IW + IH) {
+        const bool col = tid < IW;
+        const int n = col ? sw : sh, c0 = col ? cx0 : cy0, lim = col ? GW : GH;
+        const int p = col ? reflect101(x0 - RP + tid, w) : reflect101(y0 + (tid - IW) - R, h);
+        float f = ((float)p + 0.5f) * 0.5f - 0.5f;
+        int s0 = (int)floorf(f);
+        f -= (float)s0;
+        if (s0 < 0) {
+            s0 = 0;
+            f = 0;
+        }
+        if (s0 >= n - 1) {
+            s0 = n - 1;
+            f = 0;
+        }
+        const int s1 = s0 + 1 < n ? s0 + 1 : n - 1;
+        s_ci[tid][0] = min(max(s0 - c0, 0), lim - 1);
+        s_ci[tid][1] = min(max(s1 - c0, 0), lim - 1);
+        s_cf[tid] = f;
+    }
+    __syncthreads();
+    for (int e = tid; e < IH * NV; e += 256) {
+        const int ly = e / NV, v = e - ly * NV;
+        const float b1 = s_cf[IW + ly], b0 = 1.0f - b1;
+        const float* r0 = s_g[s_ci[IW + ly][0]];
+        const float* r1 = s_g[s_ci[IW + ly][1]];
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cx = 4 * v + j;
+            const float a1 = s_cf[cx], a0 = 1.0f - a1;
+            const int i0 = s_ci[cx][0], i1 = s_ci[cx][1];
+            const float h0 = r0[i0] * a0 + r0[i1] * a1;
+            const float h1 = r1[i0] * a0 + r1[i1] * a1;
+            res[j] = h0 * b0 + h1 * b1;
+        }
+        float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
+        dst[0] = res[0];
+        dst[2] = res[1];
+        dst[4] = res[2];
+        dst[6] = res[3];
+    }
+    blur_tile_passes<R>(s_in, s_row, gk, x0, y0, h, w, out, nullptr, 0, 0);
 }
 
 // ---- the same blur, marching (experiment, APS_BLUR_MARCH=1; see launch_blur for the measurement) ------------------------
@@ -1310,6 +1411,36 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
     return dec != nullptr;
 }
 
+// gray + 2x upsample + first blur in one kernel (blur_base_kernel); false when the radius has no tile instantiation (the
+// caller then takes gray_up_kernel + launch_blur).  APS_SIFT_NO_BASE_FUSE=1 forces that two-kernel path (same bits).
+static bool launch_base_blur(const uint8_t* img, int sh, int sw, int c, int layout, double sigma, float* out) {
+    static const bool off = [] {
+        const char* e = std::getenv("APS_SIFT_NO_BASE_FUSE");
+        return e && e[0] == '1';
+    }();
+    if (off) return false;
+    const GaussK gk = make_gauss(sigma);
+    const int r = (gk.n - 1) / 2;
+    const dim3 grid(cdiv(2 * sw, kTW), cdiv(2 * sh, kTH));
+    Prof prof("sift_blur");
+    switch (r) {
+#define APS_BLUR_CASE(R) \
+    case R:              \
+        blur_base_kernel<R><<<grid, 256, 0, stream()>>>(img, sh, sw, c, layout, gk, out); \
+        break;
+        APS_BLUR_CASE(3)
+        APS_BLUR_CASE(4)
+        APS_BLUR_CASE(5)
+        APS_BLUR_CASE(6)
+        APS_BLUR_CASE(7)
+        APS_BLUR_CASE(8)
+#undef APS_BLUR_CASE
+        default: return false;
+    }
+    check_launch("blur_base_kernel");
+    return true;
+}
+
 static int num_octaves(int H, int W) {
     const int mn = std::min(2 * W, 2 * H);
     return (int)std::lrint(std::log((double)mn) / std::log(2.0) - 2.0) + 1;
@@ -1340,9 +1471,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         const int nl = params->n_layers;
         const int H = height, W = width;
         In<uint8_t> dimg(img, (size_t)H * W * channels);
-        Ws<float> up((size_t)4 * H * W), scratch;
-        gray_up_kernel<<<dim3(cdiv(2 * W, kGUW), cdiv(2 * H, kGUH)), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, up);
-        check_launch("gray_up_kernel");
+        Ws<float> up, scratch;  // (up: the doubled gray plane, only when the fused base kernel does not apply)
         const int n_oct = std::min(num_octaves(H, W), 16);
         if (n_oct <= 0) return;
         // pyramid storage
@@ -1375,7 +1504,12 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             if (o == 0) {
                 double sd = params->sigma * params->sigma - 4.0 * 0.5 * 0.5;
                 if (sd < 0.01) sd = 0.01;
-                launch_blur(up, oh, ow, std::sqrt(sd), G[0], scratch);
+                if (!launch_base_blur(dimg, H, W, channels, img_layout, std::sqrt(sd), G[0])) {
+                    up.alloc((size_t)4 * H * W);
+                    gray_up_kernel<<<dim3(cdiv(2 * W, kGUW), cdiv(2 * H, kGUH)), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, up);
+                    check_launch("gray_up_kernel");
+                    launch_blur(up, oh, ow, std::sqrt(sd), G[0], scratch);
+                }
             } else if (!base_written) {
                 const OctaveDesc& pd = table.oct[o - 1];
                 decimate_kernel<<<dim3(cdiv(ow, 256), oh), 256, 0, stream()>>>(G[(o - 1) * (nl + 3) + nl], pd.h, pd.w,
