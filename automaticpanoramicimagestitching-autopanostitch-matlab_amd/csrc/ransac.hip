@@ -91,14 +91,15 @@ __device__ __forceinline__ bool check_model(const Mat3& H) {
 #define VE(p, q) sV[((p) * 9 + (q)) * S + lane]
 
 // Cyclic Jacobi on the symmetric 9x9 in GE; eigenvectors in the columns of VE.
-template <int S>
+// (N x N problem in the 9-stride layout; N = 9 is the homography, 7 / 5 MLESAC's affine / similarity systems)
+template <int S, int N = 9>
 __device__ void jacobi9(double* sG, double* sV, int lane) {
-    for (int p = 0; p < 9; ++p)
-        for (int q = 0; q < 9; ++q) VE(p, q) = (p == q) ? 1.0 : 0.0;
+    for (int p = 0; p < N; ++p)
+        for (int q = 0; q < N; ++q) VE(p, q) = (p == q) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < 8; ++p)
-            for (int q = p + 1; q < 9; ++q) {
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
                 const double gpq = GE(p, q);
                 const double gpp = GE(p, p), gqq = GE(q, q);
                 if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;
@@ -108,7 +109,7 @@ __device__ void jacobi9(double* sG, double* sV, int lane) {
                     (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0);
                 const double s = t * c;
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < N; ++k) {
                     if (k == p || k == q) continue;
                     const double gkp = GE(k, p), gkq = GE(k, q);
                     const double np_ = c * gkp - s * gkq;
@@ -122,7 +123,7 @@ __device__ void jacobi9(double* sG, double* sV, int lane) {
                 GE(q, q) = gqq + t * gpq;
                 GE(p, q) = 0.0;
                 GE(q, p) = 0.0;
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < N; ++k) {
                     const double vkp = VE(k, p), vkq = VE(k, q);
                     VE(k, p) = c * vkp - s * vkq;
                     VE(k, q) = s * vkp + c * vkq;
@@ -134,7 +135,12 @@ __device__ void jacobi9(double* sG, double* sV, int lane) {
 
 struct Norm {
     double s, tx, ty;
+    double cx, cy;  // the centroid: MLESAC's normalised points are (p - centroid) * s (normalizePointsHartleyZisserman
+                    // :667-671), RANSAC's are T * [p; 1] = s * p + t (normalizePoints :604-606)
 };
+__device__ __forceinline__ double norm_coord(const Norm& n, double p, double c, double t, int mlesac) {
+    return mlesac ? (p - c) * n.s : n.s * p + t;
+}
 
 // Row `half` (0: x-row, 1: y-row) of the DLT matrix for one normalised correspondence (:209-212)
 __device__ __forceinline__ double dlt_entry(int k, int half, double x, double y, double u, double v) {
@@ -183,17 +189,18 @@ __device__ bool gram_to_h(double* sG, double* sV, int lane, const Norm& n1, cons
 // layout).  A rotation (p, q) touches rows/columns k = 0..8 independently, so lane k < 9 updates "its" k while every lane
 // evaluates the (uniform) rotation parameters: the same operations on the same operands as the serial routine - bit
 // for bit - in a ninth of the dependent LDS round trips (the serial form by lane 0 was most of the kernel's 3.5 ms).
+template <int N = 9>
 __device__ void jacobi9_wave(double* sG, double* sV, int lane) {
 #define G2(p, q) sG[((p) * 9 + (q)) * 2]
 #define V2(p, q) sV[((p) * 9 + (q)) * 2]
     const int k = lane;
-    if (k < 9)
-        for (int q = 0; q < 9; ++q) V2(k, q) = (k == q) ? 1.0 : 0.0;
+    if (k < N)
+        for (int q = 0; q < N; ++q) V2(k, q) = (k == q) ? 1.0 : 0.0;
     __syncthreads();
     for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < 8; ++p)
-            for (int q = p + 1; q < 9; ++q) {
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
                 const double gpq = G2(p, q);
                 const double gpp = G2(p, p), gqq = G2(q, q);
                 if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;  // uniform
@@ -203,14 +210,14 @@ __device__ void jacobi9_wave(double* sG, double* sV, int lane) {
                 const double c = 1.0 / sqrt(t * t + 1.0);
                 const double s = t * c;
                 double gkp = 0, gkq = 0, vkp = 0, vkq = 0;
-                if (k < 9) {
+                if (k < N) {
                     gkp = G2(k, p);
                     gkq = G2(k, q);
                     vkp = V2(k, p);
                     vkq = V2(k, q);
                 }
                 __syncthreads();  // every read of this rotation before any of its writes
-                if (k < 9) {
+                if (k < N) {
                     if (k != p && k != q) {
                         const double np_ = c * gkp - s * gkq;
                         const double nq_ = s * gkp + c * gkq;
@@ -335,6 +342,8 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
             n1.s = norm_scale(sd / 4.0, mlesac);
             n1.tx = -n1.s * cx;
             n1.ty = -n1.s * cy;
+            n1.cx = cx;
+            n1.cy = cy;
         }
         {
             double sx = 0, sy = 0;
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
             n2.s = norm_scale(sd / 4.0, mlesac);
             n2.tx = -n2.s * cx;
             n2.ty = -n2.s * cy;
+            n2.cx = cx;
+            n2.cy = cy;
         }
         for (int a = 0; a < 9; ++a)
             for (int b = a; b < 9; ++b) GE(a, b) = 0.0;
@@ -359,8 +370,8 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
         for (int step = 0; step < 8; ++step) {
             const int half = mlesac ? 1 - (step & 1) : step >> 2;
             const int k = mlesac ? step >> 1 : step & 3;
-            const double x = n1.s * x1[k] + n1.tx, y = n1.s * y1[k] + n1.ty;
-            const double u = n2.s * x2[k] + n2.tx, v = n2.s * y2[k] + n2.ty;
+            const double x = norm_coord(n1, x1[k], n1.cx, n1.tx, mlesac), y = norm_coord(n1, y1[k], n1.cy, n1.ty, mlesac);
+            const double u = norm_coord(n2, x2[k], n2.cx, n2.tx, mlesac), v = norm_coord(n2, y2[k], n2.cy, n2.ty, mlesac);
             double a[9];
             for (int e = 0; e < 9; ++e) a[e] = dlt_entry(e, half, x, y, u, v);
             for (int pp = 0; pp < 9; ++pp)
@@ -694,9 +705,13 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         n1.s = norm_scale(sd / dn, mlesac);
         n1.tx = -n1.s * cx;
         n1.ty = -n1.s * cy;
+        n1.cx = cx;
+        n1.cy = cy;
         n2.s = norm_scale(ud / dn, mlesac);
         n2.tx = -n2.s * dx2;
         n2.ty = -n2.s * dy2;
+        n2.cx = dx2;
+        n2.cy = dy2;
     }
     // Gram matrix: lane e < 45 owns the upper-triangular entry (pp,qq); rows in the reference's order
     int pp = 0, qq = 0;
@@ -712,8 +727,8 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
     double g = 0;
     if (mlesac) {  // per inlier: its "v" row, then its "u" row
         for_each_staged(18, [&](double a, double b, double c2, double d, int j) {
-            const double x = n1.s * a + n1.tx, y = n1.s * b + n1.ty;
-            const double u = n2.s * c2 + n2.tx, v = n2.s * d + n2.ty;
+            const double x = (a - n1.cx) * n1.s, y = (b - n1.cy) * n1.s;
+            const double u = (c2 - n2.cx) * n2.s, v = (d - n2.cy) * n2.s;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 s_val[k][j] = dlt_entry(k, 1, x, y, u, v);
@@ -895,9 +910,13 @@ __device__ __forceinline__ bool fit_tform(int type, int n, Each&& each, Med&& me
         cx.n1.s = 1.0 / (sd / dn);
         cx.n1.tx = -cx.n1.s * ax;
         cx.n1.ty = -cx.n1.s * ay;
+        cx.n1.cx = ax;
+        cx.n1.cy = ay;
         cx.n2.s = 1.0 / (ud / dn);
         cx.n2.tx = -cx.n2.s * bx;
         cx.n2.ty = -cx.n2.s * by;
+        cx.n2.cx = bx;
+        cx.n2.cy = by;
     }
     const Norm n1 = cx.n1, n2 = cx.n2;
     double Hn[9];
@@ -1301,6 +1320,393 @@ __global__ __launch_bounds__(64) void tform_finalize_kernel(int type, const doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// MLESAC for the other transformationTypes (estimateTransformationMLESAC.m): estimateAffine (:389-424, null vector of
+// the 2n x 7 system), estimateSimilarity (:426-458, 2n x 5), estimateRigid (:460-490, Kabsch on the raw points, closed
+// form), estimateTranslation (:492-510, the mean displacement), evaluateTranslation2d (:578-598).
+// ------------------------------------------------------------------------------------------------
+// entry k of a constraint row: half 1 = the point's "v" row (odd rows of :404-407 / :441-444), half 0 its "u" row
+__device__ __forceinline__ double mlesac_entry(int type, int k, int half, double x, double y, double u, double v) {
+    if (type == APS_TFORM_AFFINE) {
+        if (half) return k == 3 ? -x : k == 4 ? -y : k == 5 ? -1.0 : k == 6 ? v : 0.0;
+        return k == 0 ? x : k == 1 ? y : k == 2 ? 1.0 : k == 6 ? -u : 0.0;
+    }
+    if (half) return k == 0 ? -y : k == 1 ? x : k == 3 ? -1.0 : k == 4 ? v : 0.0;
+    return k == 0 ? x : k == 1 ? y : k == 2 ? 1.0 : k == 4 ? -u : 0.0;
+}
+
+// T from the null vector h of the affine (N = 7) / similarity (N = 5) system, denormalised: (N2 \ T) * N1, ./ T(end)
+__device__ __forceinline__ bool mlesac_h_to_model(int type, const double* h, const Norm& n1, const Norm& n2, Mat3& H) {
+    double Tn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
+    if (type == APS_TFORM_AFFINE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Tn[k] = h[k] / h[6];
+    } else {
+        Tn[0] = h[0] / h[4];
+        Tn[1] = h[1] / h[4];
+        Tn[2] = h[2] / h[4];
+        Tn[3] = -h[1] / h[4];
+        Tn[4] = h[0] / h[4];
+        Tn[5] = h[3] / h[4];
+    }
+    Mat3 M;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Tn[6 + c];
+        M3(M, 2, c) = m2;
+        M3(M, 1, c) = (Tn[3 + c] - n2.ty * m2) / n2.s;
+        M3(M, 0, c) = (Tn[c] - n2.tx * m2) / n2.s;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        M3(H, r, 0) = M3(M, r, 0) * n1.s;
+        M3(H, r, 1) = M3(M, r, 1) * n1.s;
+        M3(H, r, 2) = (M3(M, r, 0) * n1.tx + M3(M, r, 1) * n1.ty) + M3(M, r, 2);
+    }
+    const double d = H.m[8];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = H.m[e] / d;
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    return true;
+}
+
+// rigid / translation over an ordered selection (`each` as in fit_tform); every caller evaluates the same expressions
+template <class Each>
+__device__ __forceinline__ bool mlesac_fit_closed(int type, int n, Each&& each, Mat3& H) {
+    const double dn = (double)n;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+    if (type == APS_TFORM_TRANSLATION) {
+        double sx = 0, sy = 0;
+        each([&](double a, double b, double c, double d) {
+            sx = sx + (c - a);
+            sy = sy + (d - b);
+        });
+        M3(H, 0, 2) = sx / dn;
+        M3(H, 1, 2) = sy / dn;
+        return isfinite(M3(H, 0, 2)) && isfinite(M3(H, 1, 2));
+    }
+    double sx = 0, sy = 0, su = 0, sv = 0;
+    each([&](double a, double b, double c, double d) {
+        sx = sx + a;
+        sy = sy + b;
+        su = su + c;
+        sv = sv + d;
+    });
+    const double c1x = sx / dn, c1y = sy / dn, c2x = su / dn, c2y = sv / dn;
+    double c11 = 0, c12 = 0, c21 = 0, c22 = 0;
+    each([&](double a, double b, double c, double d) {
+        const double ax = a - c1x, ay = b - c1y, bx = c - c2x, by = d - c2y;
+        c11 = c11 + ax * bx;
+        c12 = c12 + ax * by;
+        c21 = c21 + ay * bx;
+        c22 = c22 + ay * by;
+    });
+    const double E = c11 + c22, A = c12 - c21;
+    const double r = sqrt(E * E + A * A);
+    const double c = E / r, sn = A / r;  // R = [c -sn; sn c]
+    M3(H, 0, 0) = c;
+    M3(H, 0, 1) = -sn;
+    M3(H, 1, 0) = sn;
+    M3(H, 1, 1) = c;
+    M3(H, 0, 2) = c2x - (c * c1x + (-sn) * c1y);
+    M3(H, 1, 2) = c2y - (sn * c1x + c * c1y);
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H.m[e])) return false;
+    return true;
+}
+
+// Hartley-Zisserman normalisation of an ordered selection (sums in order)
+template <class Each>
+__device__ __forceinline__ void mlesac_normalize(int n, Each&& each, Norm& n1, Norm& n2) {
+    const double dn = (double)n;
+    double sx = 0, sy = 0, ux = 0, uy = 0;
+    each([&](double a, double b, double c, double d) {
+        sx = sx + a;
+        sy = sy + b;
+        ux = ux + c;
+        uy = uy + d;
+    });
+    n1.cx = sx / dn;
+    n1.cy = sy / dn;
+    n2.cx = ux / dn;
+    n2.cy = uy / dn;
+    double sd = 0, ud = 0;
+    each([&](double a, double b, double c, double d) {
+        const double dx = a - n1.cx, dy = b - n1.cy;
+        sd = sd + sqrt(dx * dx + dy * dy);
+        const double ex = c - n2.cx, ey = d - n2.cy;
+        ud = ud + sqrt(ex * ex + ey * ey);
+    });
+    n1.s = norm_scale(sd / dn, 1);
+    n1.tx = -n1.s * n1.cx;
+    n1.ty = -n1.s * n1.cy;
+    n2.s = norm_scale(ud / dn, 1);
+    n2.tx = -n2.s * n2.cx;
+    n2.ty = -n2.s * n2.cy;
+}
+
+// one lane per (pair, draw): K = 3 / 2 / 2 / 1 sample points; the N x N Gram problem of a lane in its LDS column
+template <int N>
+__device__ __forceinline__ bool mlesac_fit_sample_null(int type, int K, const double* x1, const double* y1, const double* x2,
+                                                       const double* y2, double* sG, double* sV, int lane, Mat3& H) {
+    constexpr int S = 64;
+    auto each = [&](auto&& body) {
+        for (int k = 0; k < K; ++k) body(x1[k], y1[k], x2[k], y2[k]);
+    };
+    Norm n1, n2;
+    mlesac_normalize(K, each, n1, n2);
+    for (int a = 0; a < N; ++a)
+        for (int b = a; b < N; ++b) GE(a, b) = 0.0;
+    for (int k = 0; k < K; ++k)
+        for (int half = 1; half >= 0; --half) {
+            const double x = (x1[k] - n1.cx) * n1.s, y = (y1[k] - n1.cy) * n1.s;
+            const double u = (x2[k] - n2.cx) * n2.s, v = (y2[k] - n2.cy) * n2.s;
+            double a[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) a[e] = mlesac_entry(type, e, half, x, y, u, v);
+#pragma unroll
+            for (int pp = 0; pp < N; ++pp)
+#pragma unroll
+                for (int qq = pp; qq < N; ++qq) GE(pp, qq) = GE(pp, qq) + a[pp] * a[qq];
+        }
+    for (int p = 0; p < N; ++p)
+        for (int q = 0; q < p; ++q) GE(p, q) = GE(q, p);
+    jacobi9<S, N>(sG, sV, lane);
+    int kmin = 0;
+    for (int k = 1; k < N; ++k)
+        if (GE(k, k) < GE(kmin, kmin)) kmin = k;
+    double h[N];
+    for (int k = 0; k < N; ++k) h[k] = VE(k, kmin);
+    return mlesac_h_to_model(type, h, n1, n2, H);
+}
+
+__global__ __launch_bounds__(64) void mlesac_tform_fit_kernel(int type, const double* __restrict__ pts1,
+                                                               const double* __restrict__ pts2, int64_t ldp,
+                                                               const int64_t* __restrict__ pair_ptr,
+                                                               const int* __restrict__ act, int n_act, int c0, int nc,
+                                                               const uint32_t* __restrict__ sample_idx, int n_samples,
+                                                               double* __restrict__ Hs, uint8_t* __restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) double lds_fit[];
+    double* sG = lds_fit;
+    double* sV = lds_fit + 81 * 64;
+    const int lane = threadIdx.x;
+    const int64_t wid = blockIdx.x * (int64_t)64 + lane;
+    if (wid >= (int64_t)n_act * nc) return;  // no barriers below
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    const int K = tf_min_points(type);
+    double x1[3], y1[3], x2[3], y2[3];
+    bool ok = m >= K;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t id = k < K ? sample_idx[gid * 4 + k] : 1u;
+        if (k < K && (id < 1 || (int64_t)id > m)) ok = false;
+        const int64_t row = r0 + (ok ? (int64_t)id - 1 : 0);
+        const bool ld = ok && k < K;
+        x1[k] = ld ? pts1[row] : 0.0;
+        y1[k] = ld ? pts1[ldp + row] : 0.0;
+        x2[k] = ld ? pts2[row] : 0.0;
+        y2[k] = ld ? pts2[ldp + row] : 0.0;
+    }
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = 0.0;
+    if (ok) {
+        if (type == APS_TFORM_AFFINE)
+            ok = mlesac_fit_sample_null<7>(type, K, x1, y1, x2, y2, sG, sV, lane, H);
+        else if (type == APS_TFORM_SIMILARITY)
+            ok = mlesac_fit_sample_null<5>(type, K, x1, y1, x2, y2, sG, sV, lane, H);
+        else
+            ok = mlesac_fit_closed(type, K, [&](auto&& body) {
+                for (int k = 0; k < K; ++k) body(x1[k], y1[k], x2[k], y2[k]);
+            }, H);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
+    valid[wid] = ok ? 1 : 0;
+}
+
+// evaluateModel over evaluateTransform2d, or evaluateTranslation2d for 'translation' (no division, no |w| test)
+__device__ double wave_mlesac_eval_any(int type, const Mat3& H, const double* __restrict__ x1, const double* __restrict__ y1,
+                                       const double* __restrict__ x2, const double* __restrict__ y2, int64_t m, double thr,
+                                       uint8_t* __restrict__ mask, int* n_inl) {
+    if (type != APS_TFORM_TRANSLATION) return wave_mlesac_eval(H, x1, y1, x2, y2, m, thr, mask, n_inl);
+    const int lane = threadIdx.x & 63;
+    double ps = 0, pc = 0;
+    for (int64_t i = lane; i < m; i += 64) {
+        const double dx = (x1[i] + M3(H, 0, 2)) - x2[i], dy = (y1[i] + M3(H, 1, 2)) - y2[i];
+        double d = sqrt(dx * dx + dy * dy);
+        if (d > thr) d = thr;
+        const bool in = d < thr;
+        if (mask) mask[i] = in ? 1 : 0;
+        ps = ps + d;
+        if (in) pc += 1.0;
+    }
+    *n_inl = (int)wave_sum(pc);
+    return wave_sum(ps);
+}
+
+__global__ __launch_bounds__(256) void mlesac_tform_score_kernel(
+    int type, const double* __restrict__ pts1, const double* __restrict__ pts2, int64_t ldp,
+    const int64_t* __restrict__ pair_ptr, const int* __restrict__ act, int n_act, int c0, int nc, int n_samples,
+    const double* __restrict__ Hs, const uint8_t* __restrict__ valid, double thr, int32_t* __restrict__ n_inl,
+    double* __restrict__ acc_dis) {
+    const int64_t wid = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+    if (wid >= (int64_t)n_act * nc) return;
+    const int lane = threadIdx.x & 63;
+    if (!valid[wid]) {
+        if (lane == 0) {
+            n_inl[wid] = 0;
+            acc_dis[wid] = NAN;
+        }
+        return;
+    }
+    const int p = act[wid / nc];
+    const int64_t gid = (int64_t)p * n_samples + c0 + (int)(wid % nc);
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    Mat3 H;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H.m[e] = Hs[gid * 9 + e];
+    int n;
+    const double acc = wave_mlesac_eval_any(type, H, pts1 + r0, pts1 + ldp + r0, pts2 + r0, pts2 + ldp + r0, m, thr, nullptr, &n);
+    if (lane == 0) {
+        n_inl[wid] = n;
+        acc_dis[wid] = acc;
+    }
+}
+
+// finalize: one wave per pair (:213-241): the best draw's inliers, refit on them, re-evaluate; the refit is the answer
+__global__ __launch_bounds__(64) void mlesac_tform_finalize_kernel(int type, const double* __restrict__ pts1,
+                                                                    const double* __restrict__ pts2, int64_t ldp,
+                                                                    const int64_t* __restrict__ pair_ptr, int n_samples,
+                                                                    const double* __restrict__ Hs,
+                                                                    const int32_t* __restrict__ best_it, double thr,
+                                                                    double* __restrict__ models, uint8_t* __restrict__ mask,
+                                                                    uint8_t* __restrict__ scratch_mask,
+                                                                    int32_t* __restrict__ found, int32_t* __restrict__ n_final) {
+    __shared__ __attribute__((aligned(16))) double lds_fin[2 * 81 * 2];
+    double* sG = lds_fin;
+    double* sV = lds_fin + 81 * 2;
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r0 = pair_ptr[p];
+    const int64_t m = pair_ptr[p + 1] - r0;
+    const int min_pts = tf_min_points(type);
+    const double *x1 = pts1 + r0, *y1 = pts1 + ldp + r0, *x2 = pts2 + r0, *y2 = pts2 + ldp + r0;
+    uint8_t* out_mask = mask + r0;
+    uint8_t* tmp_mask = scratch_mask + r0;
+    auto not_found = [&]() {
+        __threadfence_block();
+        __syncthreads();
+        for (int64_t i = lane; i < m; i += 64) out_mask[i] = 0;
+        if (lane < 9) models[(int64_t)p * 9 + lane] = NAN;
+        if (lane == 0) {
+            found[p] = 0;
+            n_final[p] = 0;
+        }
+    };
+    const int bi = best_it[p];
+    if (bi < 0) {
+        not_found();
+        return;
+    }
+    Mat3 Hb;
+    for (int e = 0; e < 9; ++e) Hb.m[e] = Hs[((int64_t)p * n_samples + bi) * 9 + e];
+    int nb;
+    (void)wave_mlesac_eval_any(type, Hb, x1, y1, x2, y2, m, thr, out_mask, &nb);
+    if (nb < min_pts) {
+        not_found();
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    __shared__ double s_pt[4][64];
+    __shared__ uint8_t s_in[64];
+    auto each = [&](auto&& body) {
+        for (int64_t base = 0; base < m; base += 64) {
+            const int64_t i = base + lane;
+            const bool have = i < m;
+            s_pt[0][lane] = have ? x1[i] : 0.0;
+            s_pt[1][lane] = have ? y1[i] : 0.0;
+            s_pt[2][lane] = have ? x2[i] : 0.0;
+            s_pt[3][lane] = have ? y2[i] : 0.0;
+            s_in[lane] = have ? out_mask[i] : (uint8_t)0;
+            __syncthreads();
+            for (int e = 0; e < 64; ++e)
+                if (s_in[e]) body(s_pt[0][e], s_pt[1][e], s_pt[2][e], s_pt[3][e]);
+            __syncthreads();
+        }
+    };
+    Mat3 Hr;
+    bool ok;
+    if (type == APS_TFORM_RIGID || type == APS_TFORM_TRANSLATION) {
+        ok = mlesac_fit_closed(type, nb, each, Hr);
+    } else {
+        const int N = type == APS_TFORM_AFFINE ? 7 : 5;
+        Norm n1, n2;
+        mlesac_normalize(nb, each, n1, n2);
+        // lane e owns the upper-triangular Gram entry (pp, qq) of the N x N system; rows per inlier: "v" then "u"
+        int pp = 0, qq = 0;
+        {
+            int e = lane < N * (N + 1) / 2 ? lane : 0, row = 0;
+            while (e >= N - row) {
+                e -= N - row;
+                ++row;
+            }
+            pp = row;
+            qq = row + e;
+        }
+        double g = 0;
+        each([&](double a, double b, double c, double d) {
+            const double x = (a - n1.cx) * n1.s, y = (b - n1.cy) * n1.s;
+            const double u = (c - n2.cx) * n2.s, v = (d - n2.cy) * n2.s;
+            g = g + mlesac_entry(type, pp, 1, x, y, u, v) * mlesac_entry(type, qq, 1, x, y, u, v);
+            g = g + mlesac_entry(type, pp, 0, x, y, u, v) * mlesac_entry(type, qq, 0, x, y, u, v);
+        });
+#define G2(p, q) sG[((p) * 9 + (q)) * 2]
+#define V2(p, q) sV[((p) * 9 + (q)) * 2]
+        if (lane < N * (N + 1) / 2) G2(pp, qq) = g;
+        __syncthreads();
+        if (lane == 0)
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < a; ++b) G2(a, b) = G2(b, a);
+        __syncthreads();
+        if (N == 7)
+            jacobi9_wave<7>(sG, sV, lane);
+        else
+            jacobi9_wave<5>(sG, sV, lane);
+        int kmin = 0;
+        for (int k = 1; k < N; ++k)
+            if (G2(k, k) < G2(kmin, kmin)) kmin = k;
+        double h[7];
+        for (int k = 0; k < 7; ++k) h[k] = k < N ? V2(k, kmin) : 0.0;
+#undef G2
+#undef V2
+        ok = mlesac_h_to_model(type, h, n1, n2, Hr);
+    }
+    int nr = 0;
+    if (ok) (void)wave_mlesac_eval_any(type, Hr, x1, y1, x2, y2, m, thr, tmp_mask, &nr);
+    if (!ok || nr < 1) {
+        not_found();
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t i = lane; i < m; i += 64) out_mask[i] = tmp_mask[i];
+    if (lane < 9) models[(int64_t)p * 9 + lane] = Hr.m[lane];
+    if (lane == 0) {
+        found[p] = 1;
+        n_final[p] = nr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // seeded 4-subsets (stand-in for randperm(numPoints, 4), :96)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double mix_uniform(unsigned long long seed, unsigned long long key, unsigned long long ctr) {
@@ -1382,8 +1788,6 @@ static void check_opts(const aps_ransac_opts& o) {
     APS_REQUIRE(o.tform_type >= APS_TFORM_PROJECTIVE && o.tform_type <= APS_TFORM_TRANSLATION, APS_E_TYPE,
                 "unknown transformationType %d", o.tform_type);
     APS_REQUIRE(o.method == APS_ROBUST_RANSAC || o.method == APS_ROBUST_MLESAC, APS_E_ARG, "unknown robust estimator %d", o.method);
-    APS_REQUIRE(o.method == APS_ROBUST_RANSAC || o.tform_type == APS_TFORM_PROJECTIVE, APS_E_TYPE,
-                "estimateTransformationMLESAC is built for transformationType 'projective' only");
     APS_REQUIRE(o.max_iter > 0, APS_E_ARG, "maxIter must be positive");
     APS_REQUIRE(o.max_distance > 0, APS_E_ARG, "maxDistance must be positive");
     APS_REQUIRE(o.confidence > 0 && o.confidence < 100, APS_E_ARG, "inliersConfidence must be in (0,100)");
@@ -1431,9 +1835,9 @@ static void replay_loop(Replay& st, const uint8_t* valid, const int32_t* n_inl, 
     st.done = !(st.trial <= st.limit && st.skip < max_skip);
 }
 
-// vision.internal.ransac.computeLoopNumber restated (toolbox-internal, unpinned): sample size 4
-static int mlesac_loop_number(double confidence, int64_t num_pts, int inlier_num) {
-    const double pr = std::pow((double)inlier_num / (double)num_pts, 4.0);
+// vision.internal.ransac.computeLoopNumber restated (toolbox-internal, unpinned)
+static int mlesac_loop_number(int sample_size, double confidence, int64_t num_pts, int inlier_num) {
+    const double pr = std::pow((double)inlier_num / (double)num_pts, (double)sample_size);
     if (pr < 2.220446049250313e-16) return 2147483647;
     const double n = std::ceil(std::log10(1.0 - 0.01 * confidence) / std::log10(1.0 - pr));
     if (!(n < 2147483647.0)) return 2147483647;
@@ -1454,7 +1858,7 @@ static void replay_mlesac(Replay& st, const uint8_t* valid, const int32_t* n_inl
         if (acc_dis[cur] < st.best) {
             st.best = acc_dis[cur];
             st.best_it = base + cur;
-            st.limit = std::min(st.limit, mlesac_loop_number(o.confidence, m, n_inl[cur]));
+            st.limit = std::min(st.limit, mlesac_loop_number(tf_min_points(o.tform_type), o.confidence, m, n_inl[cur]));
         }
         ++st.trial;
     }
@@ -1484,6 +1888,8 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         APS_HIP(hipFuncSetAttribute((const void*)ransac_fit_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         APS_HIP(hipFuncSetAttribute((const void*)ransac_finalize_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        APS_HIP(hipFuncSetAttribute((const void*)mlesac_tform_fit_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
@@ -1518,6 +1924,9 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
             if (type == APS_TFORM_PROJECTIVE)
                 ransac_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
                                                                               d_samples, n_samples, Hs, valid, mlesac);
+            else if (mlesac)
+                mlesac_tform_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act,
+                                                                                    c0, nc, d_samples, n_samples, Hs, valid);
             else
                 tform_fit_kernel<<<cdiv(nw, 64), 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
                                                                      d_samples, n_samples, Hs, valid);
@@ -1525,7 +1934,10 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         check_launch("ransac_fit_kernel");
         {
             Prof prof("ransac_score");
-            if (mlesac)
+            if (mlesac && type != APS_TFORM_PROJECTIVE)
+                mlesac_tform_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
+                                                                              n_samples, Hs, valid, o.max_distance, ninl, merr);
+            else if (mlesac)
                 mlesac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
                                                                         n_samples, Hs, valid, o.max_distance, ninl, merr);
             else
@@ -1566,6 +1978,10 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
         if (type == APS_TFORM_PROJECTIVE)
             ransac_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, n_samples, Hs, best, o.max_distance,
                                                                   d_models, d_mask, scratch, d_found, d_ninl, mlesac);
+        else if (mlesac)
+            mlesac_tform_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, n_samples, Hs, best,
+                                                                        o.max_distance, d_models, d_mask, scratch, d_found,
+                                                                        d_ninl);
         else
             tform_finalize_kernel<<<n_pairs, 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, n_samples, Hs, best,
                                                                  o.max_distance, d_models, d_mask, scratch, med_keys, d_found,

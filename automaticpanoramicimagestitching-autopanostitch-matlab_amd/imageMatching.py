@@ -96,14 +96,11 @@ def _ransac_opts(input, method=None, transformType=None):
 
 
 def _check_type(transformType, method="ransac"):
-    """The lower-cased transform type (getTransformParams :648-660 lower-cases too).  All five run through RANSAC; the
-    MLESAC estimators of the other four (estimateTransformationMLESAC.m:389-640) are not built."""
+    """The lower-cased transform type (getTransformParams :648-660 lower-cases too).  All five run on the device through
+    both estimateTransformationRANSAC (:227-452) and estimateTransformationMLESAC (:345-510)."""
     tform = str(transformType).lower()
     if tform not in TFORM_TYPES:
         raise ValueError("Unknown transform type")  # estimateTransformationRANSAC.m:658-659
-    if method == "mlesac" and tform != "projective":
-        raise NotImplementedError("estimateTransformationMLESAC runs on the device for transformationType 'projective' "
-                                  "only; use imageMatchingMethod 'ransac' for '%s'" % tform)
     return tform
 
 
@@ -148,7 +145,7 @@ def estimateTransformationRANSAC(matchedPoints1, matchedPoints2, transformType, 
 def estimateTransformationMLESAC(points1, points2, transformationType, input=None, sample_idx=None, seed=0):
     """[tform, inlierIdx, isFound] = estimateTransformationMLESAC(points1, points2, transformationType, input)
     (estimateTransformationMLESAC.m:1-254): truncated-loss consensus on the one-way reprojection distance,
-    the refit on the best model's inliers is the answer.  'projective' on the device; draws are explicit
+    the refit on the best model's inliers is the answer.  All five transformationTypes; draws are explicit
     (sample_idx, uint32 n x 4, 1-based) or seeded.  Returns (3x3 float64 or None, bool[M], bool)."""
     return _estimate_robust(points1, points2, transformationType, input, sample_idx, seed, "mlesac")
 

@@ -209,7 +209,9 @@ int aps_hamming_2nn(const uint8_t* A, int64_t n1, int64_t lda, const uint8_t* B,
  * ============================================================================================ */
 
 /* input.transformationType (inputs.m:74) = transformType of estimateTransformationRANSAC.m:612-660; minimal samples
- * 4 / 3 / 2 / 2 / 1.  All five run through APS_ROBUST_RANSAC; APS_ROBUST_MLESAC is built for 'projective' only. */
+ * 4 / 3 / 2 / 2 / 1.  All five run through APS_ROBUST_RANSAC and through APS_ROBUST_MLESAC (whose estimators differ:
+ * estimateTransformationMLESAC.m:345-510 - null vectors of the 2n x 9 / 7 / 5 systems, Kabsch for 'rigid', the mean
+ * displacement for 'translation'). */
 enum {
     APS_TFORM_PROJECTIVE = 0,
     APS_TFORM_AFFINE = 1,      /* estimateAffine :227-288: pseudo-inverse of the normalised design matrix        */

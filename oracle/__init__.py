@@ -262,6 +262,48 @@ def ransac_tform(tform, p1, p2, sample_idx, max_distance=5.5, confidence=99.9, m
     return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value
 
 
+_orc_fit_tform_mlesac = _sig("orc_fit_tform_mlesac", [_i, _vp, _vp, _i64, _vp, _i64, _vp], _i)
+_orc_mlesac_eval_tform = _sig("orc_mlesac_eval_tform", [_i, _vp, _vp, _vp, _i64, _i64, _d, _vp, _vp], _d)
+_orc_mlesac_tform = _sig("orc_mlesac_tform", [_i, _vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
+
+
+def fit_tform_mlesac(tform, p1, p2, sel):
+    """MLESAC's estimator of a transformType (estimateTransformationMLESAC.m:345-510) on the points in sel (0-based)."""
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    sel = np.ascontiguousarray(sel, np.int64)
+    H = np.zeros(9, np.float64)
+    ok = _orc_fit_tform_mlesac(TFORM_TYPES[tform], a.ctypes.data, b.ctypes.data, m, sel.ctypes.data, len(sel), H.ctypes.data)
+    return H.reshape(3, 3).T.copy(), bool(ok)
+
+
+def mlesac_eval_tform(tform, H, p1, p2, thr):
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    Hc = np.ascontiguousarray(np.asarray(H, np.float64).T)
+    mask = np.zeros(max(m, 1), np.uint8)
+    n = C.c_int(0)
+    acc = _orc_mlesac_eval_tform(TFORM_TYPES[tform], Hc.ctypes.data, a.ctypes.data, b.ctypes.data, m, m, float(thr),
+                                 mask.ctypes.data, C.byref(n))
+    return float(acc), n.value, mask[:m].astype(bool)
+
+
+def mlesac_tform(tform, p1, p2, sample_idx, max_distance=2.0, confidence=99.9, max_num_trials=1000):
+    """estimateTransformationMLESAC for any transformationType.  sample_idx: n_samples x 4, 1-based (the first
+    sampleSize entries of a row are the sample).  Returns (model 3x3, mask bool[M], found, draws consumed)."""
+    a, m = _pts(p1)
+    b, _ = _pts(p2)
+    s = np.ascontiguousarray(sample_idx, np.uint32)
+    model = np.zeros(9, np.float64)
+    mask = np.zeros(max(m, 1), np.uint8)
+    found = C.c_int(0)
+    trials = C.c_int(0)
+    _orc_mlesac_tform(TFORM_TYPES[tform], a.ctypes.data, b.ctypes.data, m, m, s.ctypes.data, s.shape[0],
+                      float(max_distance), float(confidence), int(max_num_trials), model.ctypes.data, mask.ctypes.data,
+                      C.byref(found), C.byref(trials))
+    return model.reshape(3, 3).T.copy(), mask[:m].astype(bool), bool(found.value), trials.value
+
+
 _orc_mlesac_homography = _sig("orc_mlesac_homography",
                               [_vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
 _orc_mlesac_eval = _sig("orc_mlesac_eval", [_vp, _vp, _vp, _i64, _i64, _d, _vp, _vp], _d)

@@ -367,7 +367,7 @@ ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m
  *   - sum(dis) after truncation (:283-285) in wave order.
  * ================================================================================================ */
 static void normalize_sel_hz(const double* x, const double* y, const int64_t* sel, int64_t n,
-                             double* scale, double* tx, double* ty) {
+                             double* scale, double* tx, double* ty, double* cxo, double* cyo) {
     double sx = 0, sy = 0;
     for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
     const double cx = sx / (double)n, cy = sy / (double)n;
@@ -381,19 +381,21 @@ static void normalize_sel_hz(const double* x, const double* y, const int64_t* se
     *scale = s;
     *tx = -s * cx;
     *ty = -s * cy;
+    *cxo = cx; /* the normalised points are (p - centroid) * scale (:667-671: p has no homogeneous row), */
+    *cyo = cy; /* the matrix [s 0 -s*cx; ...] only enters the denormalisation                           */
 }
 
 static int fit_homography_mlesac(const double* x1, const double* y1, const double* x2, const double* y2,
                                  const int64_t* sel, int64_t n, double* H) {
-    double s1, t1x, t1y, s2, t2x, t2y;
-    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y);
-    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y);
+    double s1, t1x, t1y, s2, t2x, t2y, c1x, c1y, c2x, c2y;
+    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y);
+    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y);
     double G[81];
     for (int e = 0; e < 81; ++e) G[e] = 0;
     for (int64_t e = 0; e < n; ++e)
         for (int half = 1; half >= 0; --half) { /* rows 2i-1 (v) and 2i (u) of :368-373; a a' is sign-blind */
-            const double x = s1 * x1[sel[e]] + t1x, y = s1 * y1[sel[e]] + t1y;
-            const double u = s2 * x2[sel[e]] + t2x, v = s2 * y2[sel[e]] + t2y;
+            const double x = (x1[sel[e]] - c1x) * s1, y = (y1[sel[e]] - c1y) * s1;
+            const double u = (x2[sel[e]] - c2x) * s2, v = (y2[sel[e]] - c2y) * s2;
             double a[9];
             if (half == 0) {
                 a[0] = -x; a[1] = -y; a[2] = -1; a[3] = 0; a[4] = 0; a[5] = 0;
@@ -923,6 +925,255 @@ ORC_API void orc_ransac_tform(int type, const double* p1, const double* p2, int6
         memcpy(model, use_refit ? R : bestH, sizeof bestH);
         memcpy(inlier_mask, use_refit ? cur : best_mask, (size_t)m);
         *is_found = 1;
+    }
+    free(cur);
+    free(best_mask);
+}
+
+/* ================================================================================================
+ * MLESAC for the other transformTypes (estimateTransformationMLESAC.m): estimateAffine (:389-424, the null vector
+ * of the 2n x 7 system), estimateSimilarity (:426-458, 2n x 5), estimateRigid (:460-490, Kabsch on the raw
+ * points), estimateTranslation (:492-510, the MEAN displacement), evaluateTransform2d / evaluateTranslation2d
+ * (:534-598), sampleSize 3 / 2 / 2 / 1 (:83-92).  Fixed here as in the projective MLESAC path, plus:
+ *   - the null vectors by cyclic Jacobi on the 7x7 / 5x5 Gram matrices (rows in the reference's order: per point
+ *     its "v" row, then its "u" row);
+ *   - estimateRigid's svd(C), C = P1c' * P2c, R = V*diag(1, sign(det(U*V')))*U' in closed form:
+ *     R = [E -A; A E] / hypot(E, A), E = C11 + C22, A = C12 - C21 (here the reference has Kabsch's order: this is
+ *     the least-squares rotation);
+ *   - computeLoopNumber with the sample size as the exponent.
+ * ================================================================================================ */
+static void jacobi_n(double* G, double* V, int N) { /* row stride N; the rotation rule of jacobi9 */
+    for (int p = 0; p < N; ++p)
+        for (int q = 0; q < N; ++q) V[N * p + q] = (p == q) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                const double gpq = G[N * p + q];
+                const double gpp = G[N * p + p], gqq = G[N * q + q];
+                if (fabs(gpq) <= 1e-300 || fabs(gpq) <= 1e-18 * sqrt(fabs(gpp * gqq))) continue;
+                rotated = 1;
+                const double theta = (gqq - gpp) / (2.0 * gpq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < N; ++k) {
+                    if (k == p || k == q) continue;
+                    const double gkp = G[N * k + p], gkq = G[N * k + q];
+                    const double np_ = c * gkp - s * gkq;
+                    const double nq_ = s * gkp + c * gkq;
+                    G[N * k + p] = np_; G[N * p + k] = np_;
+                    G[N * k + q] = nq_; G[N * q + k] = nq_;
+                }
+                G[N * p + p] = gpp - t * gpq;
+                G[N * q + q] = gqq + t * gpq;
+                G[N * p + q] = 0.0;
+                G[N * q + p] = 0.0;
+                for (int k = 0; k < N; ++k) {
+                    const double vkp = V[N * k + p], vkq = V[N * k + q];
+                    V[N * k + p] = c * vkp - s * vkq;
+                    V[N * k + q] = s * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+/* denormalizeTform (:705-716): (N2 \ T) * N1, then ./ T(end); Tn row-major */
+static int denormalize_mlesac(const double Tn[9], double s1, double t1x, double t1y, double s2, double t2x, double t2y,
+                              double* H) {
+    double M[9], T[9];
+    for (int c = 0; c < 3; ++c) {
+        const double m2 = Tn[6 + c];
+        M[2 + 3 * c] = m2;
+        M[1 + 3 * c] = (Tn[3 + c] - t2y * m2) / s2;
+        M[0 + 3 * c] = (Tn[c] - t2x * m2) / s2;
+    }
+    for (int r = 0; r < 3; ++r) {
+        T[r + 3 * 0] = M[r + 3 * 0] * s1;
+        T[r + 3 * 1] = M[r + 3 * 1] * s1;
+        T[r + 3 * 2] = (M[r + 3 * 0] * t1x + M[r + 3 * 1] * t1y) + M[r + 3 * 2];
+    }
+    for (int e = 0; e < 9; ++e) H[e] = T[e] / T[8];
+    for (int e = 0; e < 9; ++e)
+        if (!isfinite(H[e])) return 0;
+    return 1;
+}
+
+static int fit_tform_mlesac(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                            const int64_t* sel, int64_t n, double* H) {
+    if (type == TF_PROJECTIVE) return fit_homography_mlesac(x1, y1, x2, y2, sel, n, H);
+    const double dn = (double)n;
+    if (type == TF_TRANSLATION) { /* mean(points2 - points1) */
+        double sx = 0, sy = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            sx = sx + (x2[sel[e]] - x1[sel[e]]);
+            sy = sy + (y2[sel[e]] - y1[sel[e]]);
+        }
+        const double Hc[9] = {1, 0, 0, 0, 1, 0, sx / dn, sy / dn, 1};
+        memcpy(H, Hc, sizeof Hc);
+        return isfinite(H[6]) && isfinite(H[7]);
+    }
+    if (type == TF_RIGID) {
+        double sx = 0, sy = 0, su = 0, sv = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            sx = sx + x1[sel[e]]; sy = sy + y1[sel[e]];
+            su = su + x2[sel[e]]; sv = sv + y2[sel[e]];
+        }
+        const double c1x = sx / dn, c1y = sy / dn, c2x = su / dn, c2y = sv / dn;
+        double c11 = 0, c12 = 0, c21 = 0, c22 = 0; /* C = normPoints1' * normPoints2 */
+        for (int64_t e = 0; e < n; ++e) {
+            const double ax = x1[sel[e]] - c1x, ay = y1[sel[e]] - c1y;
+            const double bx = x2[sel[e]] - c2x, by = y2[sel[e]] - c2y;
+            c11 = c11 + ax * bx; c12 = c12 + ax * by; c21 = c21 + ay * bx; c22 = c22 + ay * by;
+        }
+        const double E = c11 + c22, A = c12 - c21;
+        const double r = sqrt(E * E + A * A);
+        const double c = E / r, sn = A / r; /* R = [c -sn; sn c] */
+        const double tx = c2x - (c * c1x + (-sn) * c1y), ty = c2y - (sn * c1x + c * c1y);
+        const double Hc[9] = {c, sn, 0, -sn, c, 0, tx, ty, 1};
+        memcpy(H, Hc, sizeof Hc);
+        for (int e = 0; e < 9; ++e)
+            if (!isfinite(H[e])) return 0;
+        return 1;
+    }
+    double s1, t1x, t1y, s2, t2x, t2y, c1x, c1y, c2x, c2y;
+    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y);
+    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y);
+    const int N = type == TF_AFFINE ? 7 : 5;
+    double G[49], V[49];
+    for (int e = 0; e < 49; ++e) G[e] = 0;
+    for (int64_t e = 0; e < n; ++e)
+        for (int half = 1; half >= 0; --half) { /* the "v" row (odd rows of the constraints), then the "u" row */
+            const double x = (x1[sel[e]] - c1x) * s1, y = (y1[sel[e]] - c1y) * s1;
+            const double u = (x2[sel[e]] - c2x) * s2, v = (y2[sel[e]] - c2y) * s2;
+            double a[7];
+            if (type == TF_AFFINE) {
+                if (half) { a[0] = 0; a[1] = 0; a[2] = 0; a[3] = -x; a[4] = -y; a[5] = -1; a[6] = v; }
+                else { a[0] = x; a[1] = y; a[2] = 1; a[3] = 0; a[4] = 0; a[5] = 0; a[6] = -u; }
+            } else {
+                if (half) { a[0] = -y; a[1] = x; a[2] = 0; a[3] = -1; a[4] = v; }
+                else { a[0] = x; a[1] = y; a[2] = 1; a[3] = 0; a[4] = -u; }
+            }
+            for (int p = 0; p < N; ++p)
+                for (int q = p; q < N; ++q) G[N * p + q] = G[N * p + q] + a[p] * a[q];
+        }
+    for (int p = 0; p < N; ++p)
+        for (int q = 0; q < p; ++q) G[N * p + q] = G[N * q + p];
+    jacobi_n(G, V, N);
+    int kmin = 0;
+    for (int k = 1; k < N; ++k)
+        if (G[N * k + k] < G[N * kmin + kmin]) kmin = k;
+    double h[7];
+    for (int k = 0; k < N; ++k) h[k] = V[N * k + kmin];
+    double Tn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
+    if (type == TF_AFFINE) {
+        for (int k = 0; k < 6; ++k) Tn[k] = h[k] / h[6];
+    } else {
+        Tn[0] = h[0] / h[4]; Tn[1] = h[1] / h[4]; Tn[2] = h[2] / h[4];
+        Tn[3] = -h[1] / h[4]; Tn[4] = h[0] / h[4]; Tn[5] = h[3] / h[4];
+    }
+    return denormalize_mlesac(Tn, s1, t1x, t1y, s2, t2x, t2y, H);
+}
+
+static double mlesac_eval_tform(int type, const double* H, const double* x1, const double* y1, const double* x2,
+                                const double* y2, int64_t m, double thr, uint8_t* mask, int* n_inl) {
+    if (type != TF_TRANSLATION) return mlesac_eval(H, x1, y1, x2, y2, m, thr, mask, n_inl);
+    double ps[64], pc[64];
+    for (int l = 0; l < 64; ++l) ps[l] = pc[l] = 0;
+    for (int64_t i = 0; i < m; ++i) { /* evaluateTranslation2d (:578-598) */
+        const double dx = (x1[i] + H_(0, 2)) - x2[i], dy = (y1[i] + H_(1, 2)) - y2[i];
+        double d = sqrt(dx * dx + dy * dy);
+        if (d > thr) d = thr;
+        const int in = d < thr;
+        if (mask) mask[i] = (uint8_t)in;
+        const int l = (int)(i & 63);
+        ps[l] = ps[l] + d;
+        if (in) pc[l] += 1.0;
+    }
+    *n_inl = (int)wave_reduce(pc);
+    return wave_reduce(ps);
+}
+
+static int mlesac_loop_number_k(int k, double confidence, int64_t num_pts, int inlier_num) {
+    const double pr = pow((double)inlier_num / (double)num_pts, (double)k);
+    if (pr < DBL_EPS) return 2147483647;
+    const double num = log10(1.0 - 0.01 * confidence), den = log10(1.0 - pr);
+    const double n = ceil(num / den);
+    if (!(n < 2147483647.0)) return 2147483647;
+    return n < 0 ? 0 : (int)n;
+}
+
+ORC_API int orc_fit_tform_mlesac(int type, const double* p1, const double* p2, int64_t ldp, const int64_t* sel, int64_t n,
+                                 double* H) {
+    return fit_tform_mlesac(type, p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+}
+
+ORC_API double orc_mlesac_eval_tform(int type, const double* H, const double* p1, const double* p2, int64_t m, int64_t ldp,
+                                     double thr, uint8_t* mask, int* n_inl) {
+    return mlesac_eval_tform(type, H, p1, p1 + ldp, p2, p2 + ldp, m, thr, mask, n_inl);
+}
+
+/* mlesac() (:94-254) for any transformationType; the first sampleSize entries of a 4-column draw are the sample */
+ORC_API void orc_mlesac_tform(int type, const double* p1, const double* p2, int64_t m, int64_t ldp,
+                              const uint32_t* sample_idx, int n_samples, double max_distance, double confidence,
+                              int max_num_trials, double* model, uint8_t* inlier_mask, int* is_found, int* trials_used) {
+    const double *x1 = p1, *y1 = p1 + ldp, *x2 = p2, *y2 = p2 + ldp;
+    const int k = tf_min_points(type);
+    memset(inlier_mask, 0, (size_t)m);
+    for (int e = 0; e < 9; ++e) model[e] = NAN;
+    *is_found = 0;
+    if (trials_used) *trials_used = 0;
+    if (m < k) return;
+    int num_trials = max_num_trials;
+    const int max_skip = 10000;
+    int idx = 1, skip = 0, it = 0, have_best = 0;
+    double best_dis = max_distance * (double)m, bestH[9];
+    uint8_t* cur = (uint8_t*)malloc((size_t)m);
+    uint8_t* best_mask = (uint8_t*)calloc((size_t)m, 1);
+    while (idx <= num_trials && skip < max_skip && it < n_samples) {
+        int64_t sel[4];
+        int in_range = 1;
+        for (int j = 0; j < k; ++j) {
+            sel[j] = (int64_t)sample_idx[4 * it + j] - 1;
+            if (sel[j] < 0 || sel[j] >= m) in_range = 0;
+        }
+        ++it;
+        double H[9];
+        if (!in_range || !fit_tform_mlesac(type, x1, y1, x2, y2, sel, k, H)) {
+            ++skip;
+            continue;
+        }
+        int n;
+        const double acc = mlesac_eval_tform(type, H, x1, y1, x2, y2, m, max_distance, cur, &n);
+        if (acc < best_dis) {
+            best_dis = acc;
+            have_best = 1;
+            memcpy(bestH, H, sizeof bestH);
+            memcpy(best_mask, cur, (size_t)m);
+            const int num = mlesac_loop_number_k(k, confidence, m, n);
+            if (num < num_trials) num_trials = num;
+        }
+        ++idx;
+    }
+    if (trials_used) *trials_used = it;
+    int64_t c = 0;
+    for (int64_t i = 0; i < m; ++i) c += best_mask[i];
+    if (have_best && c >= k) {
+        int64_t* sel = (int64_t*)malloc(sizeof(int64_t) * (size_t)c);
+        int64_t kk = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (best_mask[i]) sel[kk++] = i;
+        double R[9];
+        const int ok = fit_tform_mlesac(type, x1, y1, x2, y2, sel, c, R);
+        free(sel);
+        int n = 0;
+        if (ok) mlesac_eval_tform(type, R, x1, y1, x2, y2, m, max_distance, cur, &n);
+        if (ok && n > 0) {
+            memcpy(model, R, sizeof R);
+            memcpy(inlier_mask, cur, (size_t)m);
+            *is_found = 1;
+        }
     }
     free(cur);
     free(best_mask);

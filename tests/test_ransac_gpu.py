@@ -157,8 +157,8 @@ def test_mlesac_degenerate_draws_and_method_switch(gpu):
     oH, omask, ofound, _ = oracle.mlesac_homography(p1, p2, samples, 2.0, 99.9, 1000)
     assert bool(bfound[0]) == ofound and np.array_equal(bmask.astype(bool), omask) and ninl[0] == omask.sum()
     assert np.array_equal(models[0].view(np.uint64), oH.view(np.uint64))
-    with pytest.raises(NotImplementedError):  # MLESAC's own affine / similarity / rigid / translation estimators are not built
-        im.estimateTransformationMLESAC(p1, p2, "affine", {})
+    with pytest.raises(ValueError):  # "Unknown transform type"
+        im.estimateTransformationMLESAC(p1, p2, "homography", {})
 
 
 def test_ransac_shards_do_not_depend_on_the_partition(gpu):

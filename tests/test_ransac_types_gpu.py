@@ -157,7 +157,52 @@ def test_image_matching_with_an_affine_model(im):
     # tforms{1,2} maps image-2 points to image-1 points: the inverse of A
     np.testing.assert_allclose(tf[0][1][:2, :2], np.linalg.inv(A), atol=2e-3)
     assert np.array_equal(tf[0][1][2], [0, 0, 1])
-    with pytest.raises(NotImplementedError):
-        im.imageMatching(dict(inp, imageMatchingMethod="mlesac"), n, kp, matches, seed=3)
+    allM2, num2, tf2 = im.imageMatching(dict(inp, imageMatchingMethod="mlesac", maxDistance=2.0, maxIter=1000), n, kp, matches, seed=3)
+    assert num2[0, 1] >= 295
+    np.testing.assert_allclose(tf2[0][1][:2, :2], np.linalg.inv(A), atol=2e-3)
     with pytest.raises(ValueError):
         im.estimateTransformationRANSAC(kp[0], kp[1], "perspective", INP)
+
+
+# ---- estimateTransformationMLESAC for every transformationType ----------------------------------------------------------
+from test_mlesac_types_oracle import TYPES as ML_TYPES, scene as ml_scene  # noqa: E402
+
+ML_INP = {"maxDistance": 2.0, "inliersConfidence": 99.9, "maxIter": 1000, "imageMatchingMethod": "mlesac"}
+
+
+@pytest.mark.parametrize("tform", ML_TYPES)
+@pytest.mark.parametrize("m,outliers,noise", [(4, 0.0, 0.0), (6, 0.0, 0.2), (40, 0.3, 0.2), (500, 0.35, 0.3),
+                                              (3001, 0.6, 0.4), (257, 0.0, 0.0)])
+def test_mlesac_whole_loop_bit_exact(im, tform, m, outliers, noise):
+    rng = np.random.default_rng(90 + m)
+    p1, p2 = ml_scene(tform, rng, n=m, outliers=outliers, noise=noise)
+    s = im.draw_samples([m], 1064, seed=m)[0]
+    H, mask, found = im.estimateTransformationMLESAC(p1, p2, tform, ML_INP, sample_idx=s)
+    oH, omask, ofound, _ = oracle.mlesac_tform(tform, p1, p2, s, 2.0, 99.9, 1000)
+    assert found == ofound
+    assert np.array_equal(mask, omask)
+    if found:
+        assert np.array_equal(bits(H), bits(oH))
+        if m >= 40:
+            assert mask.sum() >= 0.8 * (1 - outliers) * m
+
+
+@pytest.mark.parametrize("tform", ML_TYPES)
+def test_mlesac_tiny_inputs_and_batch(im, tform):
+    rng = np.random.default_rng(95)
+    sizes = [0, 1, 2, 3, 4, 5, 64, 65, 900]
+    worlds = [ml_scene(tform, rng, n=m, outliers=0.25 if m > 10 else 0.0) for m in sizes]
+    src = np.concatenate([w[0] for w in worlds])
+    dst = np.concatenate([w[1] for w in worlds])
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    samples = im.draw_samples(sizes, 1064, seed=6)
+    models, mask, found, ninl = im.ransac_batch(src, dst, ptr, samples, dict(ML_INP, transformationType=tform))
+    for p, (p1, p2) in enumerate(worlds):
+        oH, omask, ofound, _ = oracle.mlesac_tform(tform, p1, p2, samples[p], 2.0, 99.9, 1000)
+        assert bool(found[p]) == ofound, (tform, sizes[p])
+        assert np.array_equal(mask[ptr[p]:ptr[p + 1]].astype(bool), omask), (tform, sizes[p])
+        if ofound:
+            assert np.array_equal(bits(models[p]), bits(oH)) and ninl[p] == omask.sum()
+        if sizes[p] >= 1:  # the single-pair entry agrees with the batch
+            H1, mask1, found1 = im.estimateTransformationMLESAC(p1, p2, tform, ML_INP, sample_idx=samples[p])
+            assert found1 == ofound and np.array_equal(mask1, omask)
