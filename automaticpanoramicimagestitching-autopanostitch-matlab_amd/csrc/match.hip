@@ -136,6 +136,12 @@ __device__ __forceinline__ unsigned ord_f32(float f) {
 }
 __device__ __forceinline__ float unord_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+    return v;
+}
+
 // One 64-thread workgroup = 64 rows, one row per lane (the norms are sequential k-ascending chains).  A row-major set
 // is read and the copies are written through an LDS tile (64 rows x 132 floats): every global instruction then moves
 // whole rows (two per 16-byte-per-lane instruction) instead of 64 scattered 16-byte pieces 512 bytes apart - the kernel
@@ -242,13 +248,17 @@ __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__
                     reinterpret_cast<const uint4*>(&s_t[row * kPrepPitch])[c];
         }
         const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 roundings of 2^-24 in ds, one in the root: 2^-10 covers
-        if (valid) {
-            dn[i] = dnv;
-            atomicMax(reinterpret_cast<unsigned*>(maxsq), __float_as_uint(s));  // s >= 0
-            atomicMax(reinterpret_cast<unsigned*>(maxdn), __float_as_uint(dnv));
+        if (valid) dn[i] = dnv;
+        // one atomic per workgroup, not per row: 64 lanes x 310 workgroups of same-address atomics per statistic WERE this
+        // kernel's time (60-170 us per set; the bit patterns are compared as unsigned either way, so the result is the same)
+        const unsigned ms = wave_umax(valid ? __float_as_uint(s) : 0u);  // s >= 0
+        const unsigned md = wave_umax(valid ? __float_as_uint(dnv) : 0u);
+        if (lane == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(maxsq), ms);
+            atomicMax(reinterpret_cast<unsigned*>(maxdn), md);
         }
     }
-    if (qstat && valid) {  // the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
+    if (qstat) {  // (uniform) the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
                   // [0] max x, [3] complement of min x (the column-side copy's range), [2] complement of min ||x||^2
         float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
@@ -256,13 +266,16 @@ __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__
             mx = fmaxf(mx, x[k]);
             mn = fminf(mn, x[k]);
         }
-        // (a plain look first: after the first few rows hardly any thread still improves on the running extremes, and
-        // thousands of same-address atomics are what such a kernel's time goes into; a stale look only costs an atomic)
-        const unsigned xb = ord_f32(mx), nb = ~ord_f32(mn), sb = ~__float_as_uint(fabsf(s));
-        volatile const unsigned* look = reinterpret_cast<const volatile unsigned*>(qstat);
-        if (xb > look[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), xb);
-        if (nb > look[3]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 3, nb);
-        if (sb > look[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+        // reduced over the workgroup's rows first (rows past the end contribute the zero fill), then a plain look: hardly
+        // any workgroup still improves on the running extremes, and a stale look only costs an atomic
+        const unsigned xb = wave_umax(valid ? ord_f32(mx) : 0u), nb = wave_umax(valid ? ~ord_f32(mn) : 0u),
+                       sb = wave_umax(valid ? ~__float_as_uint(fabsf(s)) : 0u);
+        if (lane == 0) {
+            volatile const unsigned* look = reinterpret_cast<const volatile unsigned*>(qstat);
+            if (xb > look[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), xb);
+            if (nb > look[3]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 3, nb);
+            if (sb > look[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+        }
     }
 }
 
