@@ -206,3 +206,46 @@ def test_mlesac_tiny_inputs_and_batch(im, tform):
         if sizes[p] >= 1:  # the single-pair entry agrees with the batch
             H1, mask1, found1 = im.estimateTransformationMLESAC(p1, p2, tform, ML_INP, sample_idx=samples[p])
             assert found1 == ofound and np.array_equal(mask1, omask)
+
+
+# ---- adversarial inputs: both estimators, every type, device == oracle ------------------------------------------------------
+def _adversarial_sets():
+    rng = np.random.default_rng(123)
+    base = rng.uniform(0, 1000, (120, 2))
+    out = {}
+    p2 = base + [7.0, -3.0]
+    nan1 = base.copy()
+    nan1[::5] = np.nan  # a fifth of the source points missing
+    out["nan_points"] = (nan1, p2)
+    inf2 = p2.copy()
+    inf2[3] = [np.inf, 1.0]
+    out["inf_point"] = (base, inf2)
+    out["all_identical"] = (np.full((50, 2), 5.0), np.full((50, 2), 9.0))
+    t = np.linspace(0, 900, 80)
+    line = np.stack([t, 0.5 * t + 20], 1)
+    out["collinear"] = (line, line + [4.0, 4.0])
+    out["huge_coordinates"] = (base * 1e7, base * 1e7 + 3e7)
+    dup = np.repeat(base[:30], 4, axis=0)
+    out["duplicates"] = (dup, dup * 1.01 + [2, 2])
+    out["pure_noise"] = (rng.uniform(0, 1e3, (90, 2)), rng.uniform(0, 1e3, (90, 2)))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_adversarial_sets()))
+@pytest.mark.parametrize("tform", ML_TYPES)
+def test_adversarial_inputs_agree_with_the_oracle(im, tform, name):
+    p1, p2 = _adversarial_sets()[name]
+    m = len(p1)
+    s = im.draw_samples([m], 1064, seed=17)[0]
+    with np.errstate(all="ignore"):
+        H, mask, found = im.estimateTransformationRANSAC(p1, p2, tform, dict(INP, maxIter=300), sample_idx=s[:364])
+        oH, omask, ofound, _ = oracle.ransac_tform(tform, p1, p2, s[:364], 3.0, 99.9, 300)
+    assert found == ofound and np.array_equal(mask, omask), ("ransac", tform, name)
+    if found:
+        assert np.array_equal(bits(H), bits(oH)), ("ransac", tform, name)
+    with np.errstate(all="ignore"):
+        H, mask, found = im.estimateTransformationMLESAC(p1, p2, tform, ML_INP, sample_idx=s)
+        oH, omask, ofound, _ = oracle.mlesac_tform(tform, p1, p2, s, 2.0, 99.9, 1000)
+    assert found == ofound and np.array_equal(mask, omask), ("mlesac", tform, name)
+    if found:
+        assert np.array_equal(bits(H), bits(oH)), ("mlesac", tform, name)
