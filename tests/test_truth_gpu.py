@@ -1,0 +1,83 @@
+"""End-to-end check against PHYSICAL truth instead of the oracle: the synthetic world is a known function of the viewing
+direction (synth.world_color), so a correct chain - SIFT, matching, RANSAC, camera chaining, inverse warp, multiband
+blend - must (1) recover the cameras up to one global rotation and (2) paint every panorama pixel with the world's
+colour along that pixel's ray.  Nothing here depends on oracle/: a wrong convention anywhere (a transposed rotation, a
+0/1-based pixel offset, theta/phi swapped, a mis-registered pair) shows up as degrees of camera error or as a panorama
+that disagrees with the world."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+W, H, F, SEED, FINEST = 1024, 768, 1100.0, 321, 5.0
+
+
+def _so3(M):
+    U, _, Vt = np.linalg.svd(M)
+    R = U @ Vt
+    return R if np.linalg.det(R) > 0 else U @ np.diag([1, 1, -1.0]) @ Vt
+
+
+def _angle_deg(R):
+    return float(np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))))
+
+
+@pytest.fixture(scope="module")
+def world(gpu):
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    rp = import_module(gpu.__name__ + ".renderPanorama")
+    imgs, cams = synth.make_scene(3, 2, W, H, F, overlap=0.45, seed=SEED, device="cuda", finest_px=FINEST)
+    inp = pl.default_input(bands=3)
+    panos, info = pl.stitch(inp, imgs, Ks=[c["K"] for c in cams], tile=(1024, 1024), seed=1)
+    return synth, pl, rp, imgs, cams, inp, panos, info
+
+
+def test_cameras_are_recovered_up_to_one_rotation(world):
+    synth, pl, rp, imgs, cams, inp, panos, info = world
+    assert info["n_components"] == 1 and all(c is not None for c in info["cameras"])
+    # x_cam = R_gt x_world = R_est x_est  =>  x_world = (R_gt' R_est) x_est: the same matrix for every camera
+    A_k = [np.asarray(g["R"]).T @ np.asarray(e["R"]) for g, e in zip(cams, info["cameras"])]
+    A = _so3(np.mean(A_k, axis=0))
+    err = [_angle_deg(a @ A.T) for a in A_k]
+    assert max(err) < 0.02, err  # degrees; measured 0.003-0.005 (a tenth of a pixel at f = 1100)
+
+
+@pytest.mark.parametrize("mode", ["spherical", "cylindrical", "planar"])
+def test_panorama_pixels_show_the_world_along_their_rays(world, mode):
+    synth, pl, rp, imgs, cams, inp, panos, info = world
+    comp = info["components"][0]
+    members, est = comp["members"], comp["cameras"]
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 3, "pyrSigma": inp["MBBsigma"],
+            "canvasColor": "black", "tile": (1024, 1024), "cropBorder": False}
+    pano, _, cov, geo = rp.renderPanorama(inp, [imgs[k] for k in members], [(H, W, 3)] * len(members), est, mode,
+                                          comp["ref"], opts, return_covered=True, device_out=True)
+    pano, cov = pano.cpu().numpy().astype(np.float64), cov.cpu().numpy() > 0
+    A = _so3(np.mean([np.asarray(cams[k]["R"]).T @ np.asarray(e["R"]) for k, e in zip(members, est)], axis=0))
+    # the canvas ray of pixel (row y, column x), 0-based (renderPanorama.m:1282-1345 / csrc/render_dev.h canvas_ray)
+    ys, xs = np.mgrid[0:geo["H"], 0:geo["W"]]
+    a, b = geo["o0"] + xs / geo["fPan"], geo["o1"] + ys / geo["fPan"]
+    if mode == "spherical":
+        d = np.stack([np.cos(b) * np.sin(a), np.sin(b), np.cos(b) * np.cos(a)], -1)
+    elif mode == "cylindrical":
+        d = np.stack([np.sin(a), b, np.cos(a)], -1)
+    else:
+        d = np.stack([a, b, np.ones_like(a)], -1) @ np.asarray(geo["Rref"], np.float64)  # Rref' * [u v 1]'
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    d_world = d @ A.T
+    truth = synth.world_color(torch.tensor(d_world, dtype=torch.float32, device="cuda"), F, SEED, finest_px=FINEST)
+    truth = (truth * 255.0).cpu().numpy().astype(np.float64)
+    from scipy import ndimage
+
+    inside = ndimage.binary_erosion(cov, structure=np.ones((15, 15), bool))  # away from the rim's blend fall-off
+    assert inside.sum() > 0.5 * cov.sum() > 0
+    diff = np.abs(pano - truth)[inside]
+    mse = float((diff ** 2).mean())
+    psnr = 10 * np.log10(255.0 ** 2 / mse)
+    # measured (all three projections): PSNR 55.6 dB, median error 0.29 grey levels, 99th percentile 1.08 - what u8 sources,
+    # bilinear taps of a 5-pixel texture and a tenth of a pixel of registration error leave
+    assert psnr > 50.0, psnr
+    assert np.median(diff) <= 0.5 and np.quantile(diff, 0.99) < 2.5, (np.median(diff), np.quantile(diff, 0.99))
