@@ -34,6 +34,13 @@ def world():
     return 1, 0
 
 
+def _multi(ws):
+    """True when the multi-rank code path has to run.  APS_PARALLEL_FORCE_COLLECTIVES=1 (a test hook) takes that path with a
+    ONE-rank process group too: every collective, hand-over and stream wait of the N > 1 driver then runs on the real
+    backend (RCCL refuses two ranks on one GPU, so this is how a one-GPU box exercises the nccl calls)."""
+    return ws > 1 or (os.environ.get("APS_PARALLEL_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def _staged(t=None):
     """gloo moves host memory: collectives on device tensors are staged through the host (used by the 2-rank
     equality test, which runs both ranks on one GPU; production is "nccl" = RCCL, device to device)."""
@@ -102,7 +109,7 @@ def allgather_ragged(local, group=None):
     """All-gather of per-rank tensors whose first dimension differs: one count exchange + ONE padded
     all-gather.  Returns the list of per-rank tensors (on the same device as `local`)."""
     ws, _ = world()
-    if ws == 1:
+    if not _multi(ws):
         return [local]
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     cnt_all = torch.zeros(ws, dtype=torch.int64, device=local.device)
@@ -128,7 +135,7 @@ def gather_by_owner(local_items, owner_of, n, make_tensor, split_sizes_local):
         lens[i] = local_items[i].shape[0]
     dev = make_tensor.device
     lens = lens.to(dev)
-    if ws > 1:
+    if _multi(ws):
         _all_reduce(lens)
     lens = lens.cpu().tolist()
     cat = torch.cat([local_items[i] for i in mine]) if mine else make_tensor[:0]
@@ -148,7 +155,7 @@ def exchange_items(local_ids, local_arrays, n_items, owner_of, width, dtype, dev
     arrays on every rank.  One all-reduce of the lengths + ONE padded all-gather of the concatenated payload
     (no per-item tensors)."""
     ws, rank = world()
-    if ws == 1:
+    if not _multi(ws):
         out = [None] * n_items
         for i, a in zip(local_ids, local_arrays):
             out[i] = a
@@ -184,7 +191,7 @@ class ImageGather:
         self.n = n
         self.local = local_images
         self.work = None
-        if self.ws == 1:
+        if not _multi(self.ws):
             return
         if dev is None:
             dev = next(iter(local_images.values())).device if local_images else torch.device("cuda")
@@ -208,14 +215,14 @@ class ImageGather:
         """Blocks until the collective has completed (idempotent).  Called before the matching stage: the int8 screening
         kernel claims whole CUs (match_screen_i8_kernel), so a collective left running beside it would only time-slice
         against it - and nothing may share a SIMD with its waves."""
-        if self.ws > 1 and self.work is not None:
+        if _multi(self.ws) and self.work is not None:
             self.work.wait()
             self.work = None
             if self.recv.is_cuda:
                 torch.cuda.current_stream().synchronize()
 
     def wait(self):
-        if self.ws == 1:
+        if not _multi(self.ws):
             return [self.local[i] for i in range(self.n)]
         self.finish()
         out = []
@@ -304,7 +311,7 @@ def gather_tiles_to_root(pano, tile, root=0):
     the whole canvas, every rank sends exactly its tiles to `root` (xGMI is point to point: the transfers of
     the other ranks run side by side), which copies them into place.  Returns pano (complete on root only)."""
     ws, rank = world()
-    if ws == 1:
+    if not _multi(ws):
         return pano
     H, W = int(pano.shape[0]), int(pano.shape[1])
     rects = tile_rects(H, W, tile)
@@ -358,7 +365,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
     # itself (see match_screen_i8_kernel), so the overlap is time slicing at CU granularity, paid for with repeated
     # descriptor preparation.  Kept as a switch for scenes with fewer, larger images.
     chunk = int(os.environ.get("APS_MATCH_OVERLAP_CHUNK", "0"))
-    if ws == 1 and not use_global and not host_lists and chunk > 0 and n > chunk and len(mine_img) == n:
+    if not _multi(ws) and not use_global and not host_lists and chunk > 0 and n > chunk and len(mine_img) == n:
         t0 = time.perf_counter()
         futs = pl.sift_submit(input, [local_images[i] for i in range(n)], ready=ready)
         descs, kps_t, pps, ias, ibs = [], [], [np.zeros(1, np.int64)], [], []
@@ -390,7 +397,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         # runs in chunks BESIDE the extraction (FeatureExchange): a chunk is all-gathered while the worker streams
         # extract the next one, so only the last chunk's collective is left on the critical path.
         t0 = time.perf_counter()
-        if ws > 1:
+        if _multi(ws):
             futs = dict(zip(mine_img, pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready))) if mine_img else {}
             ex = FeatureExchange(futs, n, dev).run()
             times.add("features", t0)  # (the last local image is extracted; all but the last chunk have been sent)
@@ -418,7 +425,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
         t0 = time.perf_counter()
         w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
-        pown = partition_weighted(w, ws) if ws > 1 else np.zeros(len(order), np.int64)
+        pown = partition_weighted(w, ws) if _multi(ws) else np.zeros(len(order), np.int64)
         my = [p for p in range(len(order)) if pown[p] == rank]
         if use_global:
             # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank
@@ -433,7 +440,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         ib_d = torch.from_numpy(ib_d.astype(np.int32)).to(dev)
     n_match = np.zeros(len(order), np.int64)
     n_match[my] = np.diff(pp)
-    if ws > 1 and not use_global:
+    if _multi(ws) and not use_global:
         nm = torch.from_numpy(n_match).to(dev)
         _all_reduce(nm)
         n_match = nm.cpu().numpy()
@@ -470,7 +477,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
     times.add("im_select", t0)
     t0 = time.perf_counter()
     # model (9), found, inliers per candidate pair: a device tensor only when it has to be all-reduced
-    rec = (torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev) if ws > 1
+    rec = (torch.zeros((max(len(work), 1), 11), dtype=torch.float64, device=dev) if _multi(ws)
            else np.zeros((max(len(work), 1), 11), np.float64))
     if mine:
         cnts = [int(n_match[p]) for p in mine]
@@ -487,12 +494,12 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         wk = {p: k for k, p in enumerate(work)}
         vals = np.concatenate([models.reshape(len(mine), 9), found.reshape(-1, 1).astype(np.float64),
                                ninl.reshape(-1, 1).astype(np.float64)], axis=1)
-        if ws > 1:
+        if _multi(ws):
             rows = torch.tensor([wk[p] for p in mine], dtype=torch.int64, device=dev)
             rec[rows] = torch.from_numpy(vals).to(dev)
         else:
             rec[[wk[p] for p in mine]] = vals
-    if ws > 1:
+    if _multi(ws):
         _all_reduce(rec)  # every row is written by exactly one rank, zero elsewhere
         rec = rec.cpu().numpy()
     pairs, models_l, num_matches = [], [], np.zeros((n, n))
@@ -553,7 +560,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
 
     # 0) the render will need every source image everywhere: start that all-gather now, collect it at step 6
     t0 = time.perf_counter()
-    if ws > 1 and image_events is not None:
+    if _multi(ws) and image_events is not None:
         for ev in image_events.values():
             ev.synchronize()  # the early image all-gather reads every local image
         image_events = None
@@ -576,7 +583,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         szs = torch.zeros((n, 2), dtype=torch.int64, device=dev)
         for k, im_ in local_originals.items():
             szs[k, 0], szs[k, 1] = int(im_.shape[0]), int(im_.shape[1])
-        if ws > 1:
+        if _multi(ws):
             _all_reduce(szs)
         first_hw = torch.zeros((n, 2), dtype=torch.int64, device=dev)
         for k, im_ in local_images.items():
@@ -585,7 +592,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         new_hw = torch.zeros((n, 2), dtype=torch.int64, device=dev)
         for k, im_ in local_images.items():
             new_hw[k, 0], new_hw[k, 1] = int(im_.shape[0]), int(im_.shape[1])
-        if ws > 1:
+        if _multi(ws):
             both_hw = torch.cat([first_hw, new_hw], 1)
             _all_reduce(both_hw)
             first_hw, new_hw = both_hw[:, :2], both_hw[:, 2:]
@@ -605,7 +612,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     # 6) render every component
     t0 = time.perf_counter()
     images = img_gather.wait()
-    if ws > 1:
+    if _multi(ws):
         torch.cuda.synchronize()  # the collective ran on RCCL's stream; the library reads the images on its own
     times.add("exchange", t0)
     t0 = time.perf_counter()
@@ -618,7 +625,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
         sizes = [(int(images[k].shape[0]), int(images[k].shape[1]), 3) for k in c["members"]]
         o_ = rp.default_opts(opts, c["cameras"], c["ref"])
         geos.append((sizes, rp.canvas_geometry(c["cameras"], sizes, mode, c["ref"], o_)))
-    by_component = ws > 1 and len(comps) >= ws
+    by_component = _multi(ws) and len(comps) >= ws
     comp_owner = partition_weighted([float(g["H"]) * float(g["W"]) for (_, g) in geos], ws) if by_component else None
     panos = []
     for ci, c in enumerate(comps):
@@ -632,7 +639,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
 
             tg = time.perf_counter()
             gains = gc.gainCompensationRKf([images[k] for k in members], c["cameras"], mode, c["ref"], input, geo)
-            if ws > 1:
+            if _multi(ws):
                 gt_ = torch.from_numpy(np.ascontiguousarray(gains)).to(dev)
                 _broadcast(gt_, 0)
                 gains = gt_.cpu().numpy()
@@ -647,9 +654,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
             pano = _deliver_panorama(pano, int(comp_owner[ci]), root, dev)
         else:
             pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
-                                        gains=gains, device_out=True, tile_subset=(rank, ws) if ws > 1 else None, geo=geo)
+                                        gains=gains, device_out=True, tile_subset=(rank, ws) if _multi(ws) else None, geo=geo)
             pl._sync()
-            if ws > 1:
+            if _multi(ws):
                 torch.cuda.synchronize()
                 if pano_root is None:
                     _all_reduce(pano, dist.ReduceOp.MAX)  # disjoint tiles, zero elsewhere
