@@ -222,12 +222,23 @@ def main():
 
         faulthandler.dump_traceback_later(int(os.environ["APS_BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout
+    # when a communicator comes up): everything but the result line is sent to stderr by pointing fd 1 at fd 2 for the
+    # run; the result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # APS_PARALLEL_FORCE_COLLECTIVES=1 (test hook, see parallel._multi): the N > 1 launch path - process group on "nccl",
+    # barriers, the max-over-ranks reduction, every collective of the sharded driver - with a single rank, which is as far
+    # as a one-GPU box can rehearse what `torchrun --nproc-per-node N bench.py --gpus N` does
+    multi = world > 1 or os.environ.get("APS_PARALLEL_FORCE_COLLECTIVES") == "1"
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29551")
         os.environ["APS_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
 
@@ -236,10 +247,10 @@ def main():
 
     capi = apsamd._capi
     capi.check(capi.lib.aps_set_device(local_rank))
-    if world > 1:
+    if multi:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     synth = import_module(apsamd.__name__ + ".synth")
     pl = import_module(apsamd.__name__ + ".pipeline")
     par = import_module(apsamd.__name__ + ".parallel")
@@ -268,7 +279,7 @@ def main():
         drain()  # (defined below: the last panorama's copy to the host)
         capi.check(capi.lib.aps_synchronize())
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -422,7 +433,7 @@ def main():
     for k, v in warm_prof.items():
         if k not in prof:
             prof[k] = (v[0] * args.steps / warm_steps, v[1] * args.steps // warm_steps)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt, dt_e2e or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
@@ -600,14 +611,15 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(synth, input_, f, args.bands, float(pano.shape[0] * pano.shape[1]))
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
         if args.save_pano:
             from PIL import Image
 
             small = pano[:: max(1, pano.shape[0] // 1200), :: max(1, pano.shape[0] // 1200)].cpu().numpy()
             os.makedirs(os.path.dirname(os.path.abspath(args.save_pano)), exist_ok=True)
             Image.fromarray(small).save(args.save_pano)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
