@@ -203,7 +203,7 @@ class ImageGather:
         self.shapes = [tuple(int(v) for v in row) for row in shp.cpu().tolist()]
         per = (n + self.ws - 1) // self.ws  # slots per rank (the last ones may stay empty)
         flat = max(max(h * w * c for (h, w, c) in self.shapes), 1)
-        self.send = torch.zeros((per, flat), dtype=torch.uint8, device=dev)
+        self.send = torch.empty((per, flat), dtype=torch.uint8, device=dev)  # (padding is never read: the shapes are known)
         for slot, i in enumerate(sorted(local_images)):
             v = local_images[i].reshape(-1)
             self.send[slot, : v.numel()] = v
@@ -268,8 +268,8 @@ class FeatureExchange:
             _all_gather_into(cnt_all, cnt)
             counts = cnt_all.cpu().view(ws, ns)  # the one host visit of the round
             m = max(int(counts.max()), 1)
-            send_d = torch.zeros((ns, m, 128), dtype=torch.float32, device=self.dev)
-            send_k = torch.zeros((ns, m, 2), dtype=torch.float64, device=self.dev)
+            send_d = torch.empty((ns, m, 128), dtype=torch.float32, device=self.dev)  # (rows past a slot's count are never read)
+            send_k = torch.empty((ns, m, 2), dtype=torch.float64, device=self.dev)
             for s, (d, p) in got.items():
                 k = int(d.shape[0])
                 send_d[s - s0, :k] = d
