@@ -242,10 +242,16 @@ class FeatureExchange:
     futures: dict image index -> future resolving to (descriptors [k,128] float32 tensor, keypoints [k,2] float64
     numpy or tensor); dev: device of the exchanged tensors."""
 
-    def __init__(self, futures, n, dev, rounds=4):
+    def __init__(self, futures, n, dev, rounds=None):
         self.ws, self.rank = world()
         self.n, self.dev = n, dev
         self.per = (n + self.ws - 1) // self.ws
+        if rounds is None:
+            # a rank's images are extracted APS_SIFT_WORKERS at a time: with no more images than workers they all finish
+            # together and chunks have nothing to hide behind - one exchange then (8 ranks x 8 views), else one chunk per
+            # batch of workers, four at most (2 ranks x 32 views)
+            workers = max(1, int(os.environ.get("APS_SIFT_WORKERS", 10)))
+            rounds = min(4, (self.per + workers - 1) // workers)
         rounds = max(1, min(int(os.environ.get("APS_EXCHANGE_ROUNDS", rounds)), self.per))
         self.chunk = (self.per + rounds - 1) // rounds
         self.rounds = (self.per + self.chunk - 1) // self.chunk
