@@ -457,11 +457,10 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         ia_d, ib_d = allidx[:, 0], allidx[:, 1]
         # start of pair p in the concatenated lists: rank base + the lengths of that rank's earlier pairs
         gpos = np.zeros(len(order), np.int64)
-        run = base[:-1].astype(np.int64).copy()
-        for p in range(len(order)):
-            r = int(pown[p])
-            gpos[p] = run[r]
-            run[r] += n_match[p]
+        for r in range(ws):
+            sel = np.nonzero(pown == r)[0]
+            if sel.size:
+                gpos[sel] = int(base[r]) + np.concatenate([[0], np.cumsum(n_match[sel])[:-1]])
     else:
         gpos = pp[:-1].astype(np.int64)
     times.add("matching", t0)
