@@ -247,8 +247,10 @@ def match_pairwise_csr(allDescriptors, MaxRatio, MatchThreshold, Unique=True, no
     pair_ptr = np.zeros(npairs + 1, np.int64)
     o = _opts(MaxRatio, MatchThreshold, Unique, normalize)
     cnt = C.c_int64(0)
-    # first call with a modest capacity; APS_E_CAP reports the exact need
-    cap = max(1, sum(p[1] for p in prepared) // 4)
+    # resident outputs: room for every row of every pair (see match_pairs_csr); host outputs: a modest first capacity,
+    # APS_E_CAP reports the exact need
+    rows = sum(prepared[i][1] * (n - 1 - i) for i in range(n))  # pair (i, j), i < j, has image i's rows
+    cap = max(1, rows if device_out else sum(p[1] for p in prepared) // 4)
     while True:
         if device_out:
             import torch
@@ -291,7 +293,11 @@ def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True
     pair_ptr = np.zeros(P + 1, np.int64)
     o = _opts(MaxRatio, MatchThreshold, Unique, normalize)
     cnt = C.c_int64(0)
-    cap = max(1, sum(prepared[a][1] for a in pa.tolist()) // 16)
+    rows = sum(prepared[a][1] for a in pa.tolist())
+    # resident outputs: room for every row (uninitialised device memory from torch's cache costs nothing, and a second
+    # pass over all pairs after APS_E_CAP costs the whole matcher again - well-overlapping small sets keep more than a
+    # sixteenth of their rows); host outputs: a sixteenth, grown on demand
+    cap = max(1, rows if device_out else rows // 16)
     while True:
         if device_out:
             import torch
