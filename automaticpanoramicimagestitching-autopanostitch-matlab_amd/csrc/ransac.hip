@@ -657,7 +657,10 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
             __syncthreads();
         }
     };
-    __shared__ double s_val[18][64];
+    // (pitch 65: lane e of the Gram pass reads row pp(e) of the staged terms at the SAME column - with a pitch of 64 doubles
+    // all 45 rows fell into one bank pair and every step paid a 45-way conflict twice, which was most of this kernel:
+    // SQ_LDS_BANK_CONFLICT 3.1e7 cycles against 7.7e6 active LDS cycles, profiles/r03z_pmc_ransac_finalize.txt)
+    __shared__ double s_val[18][65];
     auto for_each_staged = [&](int nv, auto&& prep, auto&& body) {
         (void)nv;
         for (int64_t base = 0; base < m; base += 64) {
