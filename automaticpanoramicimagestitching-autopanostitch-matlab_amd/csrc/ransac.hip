@@ -658,8 +658,9 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         }
     };
     // (pitch 65: lane e of the Gram pass reads row pp(e) of the staged terms at the SAME column - with a pitch of 64 doubles
-    // all 45 rows fell into one bank pair and every step paid a 45-way conflict twice, which was most of this kernel:
-    // SQ_LDS_BANK_CONFLICT 3.1e7 cycles against 7.7e6 active LDS cycles, profiles/r03z_pmc_ransac_finalize.txt)
+    // all 45 rows fell into one bank pair, a 45-way conflict twice per step: SQ_LDS_BANK_CONFLICT 3.1e7 cycles against 7.7e6
+    // active LDS cycles, profiles/r03z_pmc_ransac_finalize.txt.  Worth 2 % only (1.56 -> 1.53 ms): the kernel's time is the
+    // ~134 k vector instructions every lane of a pair's wave executes for the serial, order-fixed sums.)
     __shared__ double s_val[18][65];
     auto for_each_staged = [&](int nv, auto&& prep, auto&& body) {
         (void)nv;
