@@ -199,3 +199,67 @@ def panoramaCropper(input, stitchedImage):
         warnings.warn("Cannot crop the image. Image has background holes.")
         return stitchedImage
     return stitchedImage[oy - 1:oy + ch, ox - 1:ox + cw]
+
+
+# ---- loadImages.m:57-68,103-215: the two per-image steps in front of the resize ----------------------------------------
+def applyOrientation(img, orientation):
+    """The EXIF orientation switch of imreadAutoRotate (loadImages.m:194-212) on an H x W [x C] array: numpy, or a torch
+    tensor (host or resident: pure data movement, the result stays where the input is).  rot90(A, k) turns
+    counter-clockwise like MATLAB's; unknown codes leave the image unchanged, like the reference's switch."""
+    is_t = _capi.is_torch(img)
+    if is_t:
+        import torch
+
+        flip = lambda a, ax: torch.flip(a, (ax,))  # noqa: E731
+        rot = lambda a, k: torch.rot90(a, k, (0, 1))  # noqa: E731
+    else:
+        flip = lambda a, ax: np.flip(a, ax)  # noqa: E731
+        rot = lambda a, k: np.rot90(a, k, (0, 1))  # noqa: E731
+    o = int(orientation) if orientation is not None else 1
+    if o == 2:
+        out = flip(img, 1)
+    elif o == 3:
+        out = rot(img, 2)
+    elif o == 4:
+        out = flip(img, 0)
+    elif o == 5:
+        out = rot(flip(img, 1), -1)
+    elif o == 6:
+        out = rot(img, -1)
+    elif o == 7:
+        out = rot(flip(img, 1), 1)
+    elif o == 8:
+        out = rot(img, 1)
+    else:
+        return img
+    return out.contiguous() if is_t else np.ascontiguousarray(out)
+
+
+def convertToRGB(img):
+    """loadImages.m:103-125: a single-channel image replicated to H x W x 3, a three-channel one unchanged."""
+    if img.ndim == 2:
+        img = img[:, :, None]
+    if img.shape[2] == 1:
+        return img.repeat(1, 1, 3).contiguous() if _capi.is_torch(img) else np.ascontiguousarray(np.repeat(img, 3, axis=2))
+    return img
+
+
+def imreadAutoRotate(filename, device=None):
+    """img = imreadAutoRotate(filename) (loadImages.m:127-215): imread + the EXIF orientation (tag 274) undone.  Returns a
+    uint8 numpy array, or with device='cuda' a resident torch tensor (the turn is then done on the device)."""
+    from PIL import Image
+
+    with Image.open(filename) as im_:
+        orientation = None
+        try:
+            orientation = im_.getexif().get(274)
+        except Exception:  # noqa: BLE001 - like the reference's try/catch around imfinfo: unreadable metadata = no turn
+            orientation = None
+        if im_.mode not in ("L", "RGB", "RGBA"):
+            im_ = im_.convert("RGB")
+        arr = np.asarray(im_)
+    if device is not None:
+        import torch
+
+        arr = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    return applyOrientation(arr, orientation)
