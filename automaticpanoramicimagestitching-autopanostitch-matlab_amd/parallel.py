@@ -105,6 +105,32 @@ def partition_weighted(weights, world_size):
     return owner
 
 
+def partition_pairs_blocked(pairs, weights, n, world_size):
+    """Owner of every image pair for the matching stage.  The matcher prepares every descriptor set a rank's pairs touch
+    (a fixed cost per image and rank), so the pairs are dealt in BLOCKS of the pair matrix instead of one by one: images
+    are cut into ceil(sqrt(2 * world)) groups, the pairs are walked group-pair by group-pair (stable inside one), and the
+    walk is cut into `world` contiguous segments of equal total weight.  A rank then touches the images of one or two
+    group pairs (at 8 ranks and 64 views: ~32-48 of them instead of all 64); the balance is that of a prefix-sum cut: within
+    one pair's weight of even.  The result depends on (pairs, weights, n, world) only - every rank computes the same."""
+    P = len(pairs)
+    owner = np.zeros(P, np.int64)
+    if world_size <= 1 or P == 0:
+        return owner
+    nb = int(np.ceil(np.sqrt(2.0 * world_size)))
+    B = max(1, -(-n // nb))
+    arr = np.asarray(pairs, np.int64).reshape(P, 2)
+    key = (np.minimum(arr[:, 0], arr[:, 1]) // B) * (nb + 1) + (np.maximum(arr[:, 0], arr[:, 1]) // B)
+    walk = np.argsort(key, kind="stable")
+    w = np.asarray(weights, np.float64)[walk]
+    total = float(w.sum())
+    if total <= 0:
+        owner[walk] = np.arange(P) * world_size // P
+        return owner
+    mid = np.cumsum(w) - 0.5 * w  # a pair belongs to the segment its midpoint falls into
+    owner[walk] = np.minimum((mid * world_size / total).astype(np.int64), world_size - 1)
+    return owner
+
+
 def allgather_ragged(local, group=None):
     """All-gather of per-rank tensors whose first dimension differs: one count exchange + ONE padded
     all-gather.  Returns the list of per-rank tensors (on the same device as `local`)."""
@@ -431,7 +457,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
         t0 = time.perf_counter()
         w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
-        pown = partition_weighted(w, ws) if _multi(ws) else np.zeros(len(order), np.int64)
+        pown = partition_pairs_blocked(order, w, n, ws) if _multi(ws) else np.zeros(len(order), np.int64)
         my = [p for p in range(len(order)) if pown[p] == rank]
         if use_global:
             # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank

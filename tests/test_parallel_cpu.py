@@ -140,3 +140,29 @@ def test_sharding_collectives_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_blocked_pair_partition_is_balanced_and_touches_fewer_images():
+    import importlib
+
+    import apsamd
+
+    par = importlib.import_module(apsamd.__name__ + ".parallel")
+    fm = importlib.import_module(apsamd.__name__ + ".featureMatching")
+    rng = np.random.default_rng(0)
+    for n in (9, 64, 130):
+        order = fm.pair_order(n)
+        cnt = rng.integers(15000, 21000, n)
+        w = [float(cnt[i]) * float(cnt[j]) for (i, j) in order]
+        for ws in (1, 2, 3, 4, 8):
+            own = par.partition_pairs_blocked(order, w, n, ws)
+            assert own.shape == (len(order),) and own.min() >= 0 and own.max() < ws
+            assert np.array_equal(own, par.partition_pairs_blocked(order, w, n, ws))  # deterministic: every rank agrees
+            loads = np.bincount(own, weights=w, minlength=ws)
+            if ws > 1 and len(order) >= 20 * ws:
+                assert loads.max() <= 1.02 * loads.sum() / ws, (n, ws, loads)
+            if n == 64 and ws == 8:
+                touched = [len({x for p in np.nonzero(own == r)[0] for x in order[p]}) for r in range(ws)]
+                assert max(touched) <= 44 and sum(touched) / ws <= 36, touched  # all 64 with a pair-by-pair deal
+    assert par.partition_pairs_blocked([], [], 4, 8).size == 0
+    assert np.array_equal(par.partition_pairs_blocked([(0, 1)], [0.0], 2, 4), [0])
