@@ -1455,6 +1455,75 @@ __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
     return q;
 }
 
+// The decision for one row from its two largest integer dots e0 >= e1 (kScreenNone = "no such column"): shared by the two
+// MFMA shapes of the screening kernel.
+constexpr int kScreenNone = -2147483647 - 1;
+
+template <bool BOUNDS>
+__device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row, int e0, int e1, int lane,
+                                            uint32_t* __restrict__ out_idx, float* __restrict__ out_d1, float* __restrict__ out_d2,
+                                            uint32_t* __restrict__ surv_list, unsigned int* __restrict__ surv_count, float prune_r2,
+                                            float prune_thr, float* __restrict__ bounds_out) {
+    constexpr int kNone = kScreenNone;
+    const int nA = jb.nA, nB = jb.nB;
+    bool survive = false;
+    if (BOUNDS) {
+        if (row < nA) {
+        const ScreenSet q = screen_set(jb);
+        const float inv_sa = jb.invsA[row];
+        float L1f = -INFINITY, H1f = INFINITY, H2f = INFINITY;
+        if (q.ok && inv_sa > 0.f && nB >= 1 && e0 != kNone) {
+            const double a2 = (double)jb.sqA[row];
+            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
+            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
+            const double sc = (double)inv_sa * (double)q.inv_sb;
+            const double off = (double)q.cb * (double)jb.sumqA[row];
+            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
+            L1f = __double2float_rd(a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta);
+            H1f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e0 + off) - E) + delta);
+            if (nB >= 2 && e1 != kNone) H2f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta);
+        }
+        float* bo = bounds_out + (size_t)(jb.out_off + row) * 3;
+        bo[0] = L1f;
+        bo[1] = H1f;
+        bo[2] = H2f;
+        }
+    } else if (row < nA) {
+        const ScreenSet q = screen_set(jb);
+        bool pruned = false;
+        const float inv_sa = jb.invsA[row];
+        if (q.ok && inv_sa > 0.f && nB >= 2 && e1 != kNone) {
+            const double a2 = (double)jb.sqA[row];
+            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
+            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
+            const double sc = (double)inv_sa * (double)q.inv_sb;
+            const double off = (double)q.cb * (double)jb.sumqA[row];  // the column code's offset, put back per row
+            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
+            const double L1 = a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta;
+            const double H2 = a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta;
+            const double lo = L1 * (1.0 - 1e-5) - 1e-30;
+            pruned = H2 >= 0.0 && (lo > (double)prune_r2 * H2 * (1.0 + 1e-5) || lo > (double)prune_thr * (1.0 + 1e-5));
+        }
+        if (pruned) {
+            const int64_t slot = jb.out_off + row;
+            out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter drops too)
+            out_d1[slot] = INFINITY;
+            out_d2[slot] = INFINITY;
+        } else {
+            survive = true;
+        }
+    }
+    // survivors: one list segment per job (at the job's first output slot), one counter update per wave
+    const unsigned long long sm = __ballot(survive);
+    if (sm) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long)sm) - 1;
+        if (lane == leader) base = atomicAdd(&surv_count[job], (unsigned int)__popcll(sm));
+        base = __shfl(base, leader);
+        if (survive) surv_list[jb.out_off + base + __popcll(sm & ((1ull << lane) - 1ull))] = (uint32_t)row;
+    }
+}
+
 // BOUNDS: the pooled matcher's form (screened_global_top3) - a separate instantiation, so that profiles keep the two
 // apart.
 template <bool BOUNDS>
@@ -1655,62 +1724,224 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
     // the h == 0 half decides row block 0, the h == 1 half row block 1
     const int row = row0 + 32 * h;
     const int e0 = h ? D0[1] : D0[0], e1 = h ? D1[1] : D1[0];
-    bool survive = false;
-    if (BOUNDS) {
-        if (row < nA) {
-        const ScreenSet q = screen_set(jb);
-        const float inv_sa = jb.invsA[row];
-        float L1f = -INFINITY, H1f = INFINITY, H2f = INFINITY;
-        if (q.ok && inv_sa > 0.f && nB >= 1 && e0 != kNone) {
-            const double a2 = (double)jb.sqA[row];
-            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
-            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
-            const double sc = (double)inv_sa * (double)q.inv_sb;
-            const double off = (double)q.cb * (double)jb.sumqA[row];
-            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
-            L1f = __double2float_rd(a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta);
-            H1f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e0 + off) - E) + delta);
-            if (nB >= 2 && e1 != kNone) H2f = __double2float_ru(a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta);
+    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out);
+}
+
+// The same pass on v_mfma_i32_16x16x64_i8 (round 4, the default).  Both shapes do the same multiply-adds per cycle on
+// paper, but the chip is power-limited under a dense int8 stream and the clock it holds depends on the shape:
+// scripts/probe/mfma_i8_shapes.hip on random operands reads 3.44 POP/s at 1.71 GHz for 32x32x32 and 3.99 POP/s at
+// 1.98 GHz for 16x16x64 (4.96 POP/s at 2.39 GHz for both on all-zero operands) - the 32x32x32 kernel above, at 3.1 POP/s
+// on real codes, already sat at 0.9 of what its shape can be fed.
+// Mapping: a wave owns 64 rows as four groups of 16; operand 2 of the MFMA is a row group (lane l: row l & 15 of the group,
+// k bytes 16 (l >> 4) .. + 15 of the 64-byte k-step), operand 1 a 16-column sub-block of the B tile (lane l: column l & 15,
+// the same k bytes), the result D[column 4 (l >> 4) + r][row l & 15] in four registers.  A 32-column block = two
+// sub-blocks x two k-steps = four ds_read_b128 per lane (the LDS image and its XOR swizzle are unchanged and stay
+// conflict-free for this read pattern: row c, chunk (4 ks + kq) ^ ((c >> 1) & 7)), each feeding four MFMAs of 16 cycles
+// - the cadence of the 32x32x32 loop, so DMA, hand-over and read-ahead carry over.  Selection: see fold_group; the four
+// lane quarters of a row are merged at the end.
+template <bool BOUNDS>
+__global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob* __restrict__ jobs,
+                                                                    const WgJob* __restrict__ wgs, int n_wg,
+                                                                    uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
+                                                                    float* __restrict__ out_d2, uint32_t* __restrict__ surv_list,
+                                                                    unsigned int* __restrict__ surv_count, float prune_r2,
+                                                                    float prune_thr, float* __restrict__ bounds_out) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes];  // [buf][256][128 B], tile t in buf t % 3
+    int wg = blockIdx.x;
+    {  // XCD-aware order, as in match_cand_f16_kernel
+        const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    // (the whole register file of the SIMD is claimed: see match_screen_i8_kernel and DESIGN.md section 5)
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    const WgJob w = wgs[wg];
+    const MatchJob jb = jobs[w.job];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int kq = lane >> 4;
+    const int nA = jb.nA, nB = jb.nB;
+    const int rowb = w.row0 + wave * 64;  // this wave's rows: rowb + 16 g + c, every lane quarter kq sees them
+
+    i32x4 aq[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int arow = min(rowb + 16 * g + c, nA - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            aq[g][ks] = *reinterpret_cast<const i32x4*>(jb.AQ + (size_t)arow * kDim + 64 * ks + 16 * kq);
+    }
+    constexpr int kNone = kScreenNone;
+    int d0[4] = {kNone, kNone, kNone, kNone}, d1[4] = {kNone, kNone, kNone, kNone};
+
+    const int ntiles = (nB + kQTN - 1) / kQTN;
+    // DMA pieces: as in match_screen_i8_kernel
+    const int dma_sub = lane >> 3, dma_pos = lane & 7;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto issue_piece = [&](int t, int buf, int u) {
+        const int piece = wave * 4 + u;
+        const int lrow = 8 * piece + dma_sub;
+        const int brow = min(t * kQTN + lrow, nB - 1);
+        const signed char* src = jb.BQ + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
+        const uint32_t dst = lds_base + buf * kQTileBytes + piece * 1024;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    };
+    i32x4 acc[2][2][4];  // [block parity][sub-block][row group]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[p][u][g][e] = kNone;
+
+    // The search of a finished block for row group g: the lane's 8 columns, 16 u + 4 kq + r of the block, are folded into the
+    // running maximum of the lane's columns of the TILE (4 v_max3); the tile's last block (LAST) then updates the two best:
+    // D1 = med3(D0, D1, m), D0 = max(D0, m).  A group is thus the 64 columns a lane holds of a 256-column tile: D1 is the
+    // second largest GROUP maximum, which can only be lower than the second largest dot (when a row's two best columns fall
+    // into one group of one lane: 64 of ~20 000 columns) - still a bound, and 17 instead of 24 VALU per block, which matters
+    // here: a 16x16x64 MFMA holds the SIMD's vector issue for half of its 16 cycles, twice the share of the 32x32x32 form.
+    // `limit` (ragged last tile only) = number of valid columns counted from the block's first.
+    int m_run[4] = {kNone, kNone, kNone, kNone};
+    auto fold_group = [&](auto PAR, auto G, auto MASK, int limit, auto FIRST, auto LAST) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value, g = decltype(G)::value;
+        constexpr bool mask = decltype(MASK)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
+        int v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = acc[par][e >> 2][g][e & 3];
+            if (mask) v[e] = (16 * (e >> 2) + 4 * kq + (e & 3)) < limit ? v[e] : kNone;
         }
-        float* bo = bounds_out + (size_t)(jb.out_off + row) * 3;
-        bo[0] = L1f;
-        bo[1] = H1f;
-        bo[2] = H2f;
+        // (volatile asm: see match_screen_i8_kernel)
+        int m = m_run[g];
+        if (first)
+            asm volatile("v_max3_i32 %0, %1, %2, %3\n\tv_max3_i32 %0, %0, %4, %5\n\tv_max3_i32 %0, %0, %6, %7\n\tv_max_i32 %0, %0, %8"
+                         : "=&v"(m)
+                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        else
+            asm volatile("v_max3_i32 %0, %0, %1, %2\n\tv_max3_i32 %0, %0, %3, %4\n\tv_max3_i32 %0, %0, %5, %6\n\tv_max3_i32 %0, %0, %7, %8"
+                         : "+v"(m)
+                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        m_run[g] = m;
+        if (last) {
+            int t0 = d0[g], t1 = d1[g];
+            asm volatile("v_med3_i32 %0, %1, %0, %2\n\tv_max_i32 %1, %1, %2" : "+v"(t1), "+v"(t0) : "v"(m));
+            d0[g] = t0;
+            d1[g] = t1;
         }
-    } else if (row < nA) {
-        const ScreenSet q = screen_set(jb);
-        bool pruned = false;
-        const float inv_sa = jb.invsA[row];
-        if (q.ok && inv_sa > 0.f && nB >= 2 && e1 != kNone) {
-            const double a2 = (double)jb.sqA[row];
-            const double na = sqrt(a2) * 1.00001, dna = (double)jb.dnqA[row];
-            const double E = (dna * (double)q.nb + (na + dna) * (double)q.dnb) * 1.0001 + 1e-7 * (na * (double)q.nb);
-            const double sc = (double)inv_sa * (double)q.inv_sb;
-            const double off = (double)q.cb * (double)jb.sumqA[row];  // the column code's offset, put back per row
-            const double delta = 1.52587890625e-05 * (a2 + (double)q.msb + 2.0 * na * (double)q.nb) + 1e-37;
-            const double L1 = a2 + (double)q.b2min - 2.0 * (sc * ((double)e0 + off) + E) - delta;
-            const double H2 = a2 + (double)q.b2max - 2.0 * (sc * ((double)e1 + off) - E) + delta;
-            const double lo = L1 * (1.0 - 1e-5) - 1e-30;
-            pruned = H2 >= 0.0 && (lo > (double)prune_r2 * H2 * (1.0 + 1e-5) || lo > (double)prune_thr * (1.0 + 1e-5));
+    };
+
+    if (ntiles > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(aq[g][0]), "v"(aq[g][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-lane read offsets: slot s of a block = sub-block s >> 1, k-step s & 1: row 16 (s >> 1) + c, chunk (4 (s & 1) + kq)
+    // ^ ((c >> 1) & 7)  (the sub-block's 16 rows leave (row >> 1) & 7 alone)
+    const int hx = (16 * kq) ^ (16 * ((c >> 1) & 7));
+    const i32x4 zero4 = {0, 0, 0, 0};
+    constexpr int kAhead = 3;
+    auto slot_off = [&](int s) __attribute__((always_inline)) { return (s >> 1) * 16 * kDim + ((64 * (s & 1)) ^ hx); };
+    i32x4 bq[4];
+    if (ntiles > 0) {
+        if (ntiles > 1) issue_piece(1, 1, 0);
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) bq[s] = *reinterpret_cast<const i32x4*>(lds + c * kDim + slot_off(s));
+    }
+    int b_cur = 0;  // t % 3
+    auto run_tile = [&](int t, auto MASK) __attribute__((always_inline)) {
+        constexpr bool mask = decltype(MASK)::value;
+        const bool more = t + 1 < ntiles;
+        const bool more2 = t + 2 < ntiles;
+        const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
+        const unsigned char* tile = lds + b_cur * kQTileBytes + c * kDim;
+        const unsigned char* tile_n = lds + b_nxt * kQTileBytes + c * kDim;
+        b_cur = b_nxt;
+        static_for<0, kQBlk>([&](auto CB) {
+            constexpr int cb = decltype(CB)::value;
+            constexpr int kLast = kQBlk - 1;
+            constexpr int par = cb & 1;
+            if (cb == 0 || cb == 2 || cb == 4) {
+                if (more) issue_piece(t + 1, b_nxt, cb / 2 + 1);
+            } else if (cb == kLast) {
+                if (more2) issue_piece(t + 2, b_nxt2, 0);
+            }
+            const unsigned char* blk = tile + cb * 32 * kDim;
+            const unsigned char* nblk = cb < kLast ? blk + 32 * kDim : tile_n;
+            const bool fetch = cb < kLast || more;
+            const int limit = mask ? nB - (t * kQTN + (cb - 1) * 32) : 0;
+            static_for<0, 4>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                constexpr int u = s >> 1, ks = s & 1;
+                const i32x4 xq = bq[s & 3];
+                if (s + kAhead < 4) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(blk + slot_off(s + kAhead));
+                } else if (fetch) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(nblk + slot_off(s + kAhead - 4));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[par][u][g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xq, aq[g][ks], ks == 0 ? zero4 : acc[par][u][g], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // the block being searched is the previous one: (t, cb - 1), or the last block of tile t - 1 (never ragged)
+                constexpr bool first = cb == 1, last = cb == 0;
+                if (mask && cb > 0)
+                    fold_group(std::integral_constant<int, par ^ 1>{}, S, std::true_type{}, limit, std::integral_constant<bool, first>{},
+                               std::integral_constant<bool, last>{});
+                else
+                    fold_group(std::integral_constant<int, par ^ 1>{}, S, std::false_type{}, 0, std::integral_constant<bool, first>{},
+                               std::integral_constant<bool, last>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (cb == kLast - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        });
+    };
+    const int nfull = nB / kQTN;
+    for (int t = 0; t < nfull; ++t) run_tile(t, std::false_type{});
+    if (nfull < ntiles) {
+        run_tile(nfull, std::true_type{});
+        const int limit = nB - (nfull * kQTN + (kQBlk - 1) * 32);
+        static_for<0, 4>([&](auto S) {
+            fold_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::true_type{}, limit, std::false_type{}, std::true_type{});
+        });
+    } else if (ntiles > 0) {
+        static_for<0, 4>([&](auto S) {
+            fold_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::false_type{}, 0, std::false_type{}, std::true_type{});
+        });
+    }
+    // the four lane quarters of a wave saw disjoint columns of the same rows; quarter kq then decides row group kq
+    int e0 = kNone, e1 = kNone;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int a0 = d0[g], a1 = d1[g];
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const int p0 = __shfl_xor(a0, off), p1 = __shfl_xor(a1, off);
+            const int n0 = max(a0, p0);
+            a1 = max(min(a0, p0), max(a1, p1));
+            a0 = n0;
         }
-        if (pruned) {
-            const int64_t slot = jb.out_off + row;
-            out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter drops too)
-            out_d1[slot] = INFINITY;
-            out_d2[slot] = INFINITY;
-        } else {
-            survive = true;
+        if (g == kq) {
+            e0 = a0;
+            e1 = a1;
         }
     }
-    // survivors: one list segment per job (at the job's first output slot), one counter update per wave
-    const unsigned long long sm = __ballot(survive);
-    if (sm) {
-        unsigned int base = 0;
-        const int leader = __ffsll((long long)sm) - 1;
-        if (lane == leader) base = atomicAdd(&surv_count[w.job], (unsigned int)__popcll(sm));
-        base = __shfl(base, leader);
-        if (survive) surv_list[jb.out_off + base + __popcll(sm & ((1ull << lane) - 1ull))] = (uint32_t)row;
-    }
+    const int row = rowb + lane;  // = rowb + 16 kq + c
+    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1995,6 +2226,12 @@ __global__ void fb_compact_kernel(const MatchJob* __restrict__ jobs, const uint3
 
 static thread_local int64_t g_screen_rows = 0, g_screen_surv = 0;  // aps_match_screen_stats
 
+// A/B switch: APS_SCREEN_SHAPE=32 runs the screening pass on v_mfma_i32_32x32x32_i8 (rounds 2-3) instead of 16x16x64
+static bool screen_shape_32() {
+    const char* e = std::getenv("APS_SCREEN_SHAPE");
+    return e && std::atoi(e) == 32;
+}
+
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 // prune_r2 > 0: the caller will apply the ratio / threshold filter with these constants, so rows that cannot pass it
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
@@ -2046,8 +2283,12 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
         {
             Prof prof("match_screen_i8");
-            match_screen_i8_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
-                                                                                      surv_count, prune_r2, prune_thr, nullptr);
+            if (screen_shape_32())
+                match_screen_i8_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
+                                                                                          surv_count, prune_r2, prune_thr, nullptr);
+            else
+                match_screen_i8x16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
+                                                                                             surv_count, prune_r2, prune_thr, nullptr);
         }
         check_launch("match_screen_i8_kernel");
         std::vector<unsigned int> h_surv(jobs.size());
@@ -2526,8 +2767,12 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
         {
             Prof prof("match_screen_i8_bounds");
-            match_screen_i8_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
-                                                                                     nullptr, nullptr, 0.f, 0.f, bounds);
+            if (screen_shape_32())
+                match_screen_i8_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
+                                                                                         nullptr, nullptr, 0.f, 0.f, bounds);
+            else
+                match_screen_i8x16_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
+                                                                                            nullptr, nullptr, 0.f, 0.f, bounds);
         }
         check_launch("match_screen_i8_kernel (bounds)");
         APS_HIP(hipStreamSynchronize(stream()));  // djobs / dbw go out of scope
