@@ -22,6 +22,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -41,6 +43,17 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" dense
 MFMA_I8_PEAK_TOPS = 5000.0      # same guide, matrix-core table: I8 32x32x32 = 2x the BF16 rate per clock (dense)
 HBM_PEAK_GBS = 8000.0           # same table, HBM3E peak (6.29 TB/s is the measured copy rate)
 NX, NY, W, H, FOCAL, OVERLAP, FINEST_PX = 8, 8, 3840, 2160, 8000.0, 0.4, 16.0
+
+
+def csrc_sha256():
+    """Hash of the kernel sources (what scripts/hbm_traffic.sh stamps into the PMC pass it writes)."""
+    d = glob.glob(os.path.join(ROOT, "automaticpanoramicimagestitching-autopanostitch-matlab_amd", "csrc", "*.hip")) + \
+        glob.glob(os.path.join(ROOT, "automaticpanoramicimagestitching-autopanostitch-matlab_amd", "csrc", "*.h"))
+    hsh = hashlib.sha256()
+    for f in sorted(d):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()
 
 
 def parse():
@@ -467,19 +480,29 @@ def main():
 
         # HBM-side bytes per launch from the committed PMC pass of THIS workload (scripts/hbm_traffic.sh ->
         # profiles/*_hbm_traffic.json: L2 memory-side requests x 64 B, one bench step); null for other configs
-        traffic_db = {}
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03z_hbm_traffic.json")
-        if world == 1 and (nx, ny, w, h, args.bands) == (8, 8, W, H, 5) and os.path.exists(tpath):
-            traffic_db = json.load(open(tpath))
+        traffic_db, traffic_file, traffic_stale = {}, None, None
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+        if world == 1 and (nx, ny, w, h, args.bands) == (8, 8, W, H, 5) and args.matcher == "pairwise" and tfiles:
+            traffic_file = os.path.relpath(tfiles[-1], ROOT)
+            db = json.load(open(tfiles[-1]))
+            meta = db.pop("_meta", {})
+            # The file is a REPLAY of a separate rocprofv3 --pmc pass (scripts/hbm_traffic.sh records the hash of the kernel
+            # sources it ran): a pass taken before the last kernel change describes other kernels - then nothing is reported.
+            if meta.get("csrc_sha256") == csrc_sha256():
+                traffic_db = db
+            else:
+                traffic_stale = (f"{traffic_file} was taken from other kernel sources (csrc hash {str(meta.get('csrc_sha256'))[:12]} "
+                                 f"!= {csrc_sha256()[:12]} now): traffic not reported; re-run scripts/hbm_traffic.sh")
 
-        def traffic_of(prefixes):
+        def traffic_of(prefixes, per_step=False):
             rows = [v for k, v in traffic_db.items() if any(p in k for p in prefixes)]
             launches = sum(r["launches_per_step"] for r in rows)
             if not rows or launches == 0:
                 return None
-            return round(sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows) / launches)
+            total = sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in rows)
+            return round(total if per_step else total / launches)
 
-        TRAFFIC_KEYS = {"match_screen_i8": ["match_screen_i8_kernel"], "match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
+        TRAFFIC_KEYS = {"match_screen_i8": ["match_screen_i8"], "match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
                         "sift_blur": ["aps::blur_kernel<"], "render_warp": ["rw_warp_staged_kernel", "rw_warp_kernel"],
                         "render_pyr_down": ["rw_down_fused_kernel", "rw_down_kernel", "rw_up_kernel"]}
         SIFT_KERNELS = ["blur_kernel", "blur_march_kernel", "extrema_march_kernel", "extrema_kernel", "gray_up_kernel", "descr_kernel",
@@ -492,7 +515,7 @@ def main():
             launches = sum(prof.get(k, (0.0, 0))[1] for k in keys)
             if ms <= 0:
                 return None
-            scale = 1e12 if unit == "TFLOP/s" else 1e9
+            scale = 1e12 if unit in ("TFLOP/s", "TOP/s") else 1e9
             ach = work_per_step * args.steps / (ms * 1e-3) / scale
             r = {"bound": bound, "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                  "frac": round(ach / peak, 4), "traffic": traffic_of(TRAFFIC_KEYS.get(kernel, ["\0"])),
@@ -504,8 +527,14 @@ def main():
                  "timed": "live over the timed steps" if kernel in live else "during the last warm-up step"}
             if r["traffic"] is not None:
                 r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
-                                     "pass of this workload (profiles/r03z_hbm_traffic.txt); replayed from that committed file, "
-                                     "not observed in this run")
+                                     f"pass of this workload ({traffic_file}, taken from these kernel sources); replayed from "
+                                     "that committed file, not observed in this run")
+                if bound == "hbm":  # what the memory system really moved per step for this chain, over the chain's time
+                    per_step = traffic_of(TRAFFIC_KEYS.get(kernel, ["\0"]), per_step=True)
+                    r["traffic_bytes_per_step"] = per_step
+                    r["achieved_measured_bytes"] = round(per_step * args.steps / (ms * 1e-3) / 1e9, 2)
+            elif traffic_stale:
+                r["traffic_note"] = traffic_stale
             if note:
                 r["note"] = note
             return r
@@ -515,12 +544,13 @@ def main():
         capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(scr_rows), ctypes.byref(scr_surv)))
         surv_share = scr_surv.value / scr_rows.value if scr_rows.value else 1.0
         cands = [
-            roof("match_screen_i8", "match_screen_i8_kernel (v_mfma_i32_32x32x32_i8: every descriptor pair once on int8 copies, "
+            roof("match_screen_i8", "match_screen_i8x16_kernel (v_mfma_i32_16x16x64_i8: every descriptor pair once on int8 copies, "
                  "exact integer accumulation, per-row top-2, proof that a row fails the ratio/threshold filter)", "mfma",
-                 flops_rank0, MFMA_I8_PEAK_TOPS, "TFLOP/s",
-                 "UNIT: the contract's unit string is TFLOP/s; the operations counted here are INTEGER multiply-adds, i.e. the "
-                 "figure is TOP/s.  achieved counts the ALGORITHMIC 2*128*Ni*Nj multiply-adds against the dense int8 MFMA "
-                 f"peak; {100 * surv_share:.1f} % of the rows survive the screen and go through match_cand_f16_kernel in row-list "
+                 flops_rank0, MFMA_I8_PEAK_TOPS, "TOP/s",
+                 "achieved counts the ALGORITHMIC 2*128*Ni*Nj INTEGER multiply-adds against the dense int8 MFMA peak (5 POP/s = "
+                 "twice the bf16 rate per clock at 2.4 GHz; under a dense int8 stream on random operands the chip holds 1.98 GHz "
+                 "with this MFMA shape, 1.71 GHz with 32x32x32: profiles/r04a_mfma_i8_shapes.txt); "
+                 f"{100 * surv_share:.1f} % of the rows survive the screen and go through match_cand_f16_kernel in row-list "
                  "mode; the match lists are bit-identical to the all-f32 path"),
             roof("match_cand_f16", "match_cand_f16_kernel (v_mfma_f32_32x32x16_f16 screening product + exact f32 rescoring" +
                  (", row-list mode on the int8 screen's survivors)" if scr_rows.value else ")"), "mfma",
@@ -553,6 +583,7 @@ def main():
             cands.append({"bound": "hbm", "kernel": "SIFT stage: all kernels of this rank's views on their worker streams (wall time of the stage)",
                           "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                           "traffic": round(sift_bytes) if sift_bytes else None,
+                          **({"traffic_note": traffic_stale} if traffic_stale and not sift_bytes else {}),
                           "achieved_measured_bytes": round(sift_bytes / t_feat / 1e9, 2) if sift_bytes else None,
                           "algorithmic_work_per_step": 574.0 * npix_rank0, "ms_per_step": round(1e3 * t_feat, 3),
                           "note": "574 B per input pixel is the survey's model (G and DoG planes written and re-read); DoG planes are "
@@ -578,7 +609,9 @@ def main():
             "ms_per_step_latency": round(1e3 * (dt_resident / args.steps + (min(dl_alone) if dl_alone else 0.0)), 2),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
+                "workload": f"[`value` starts with the inputs RESIDENT IN HBM and ends with the cropped uint8 panorama in pinned host "
+                            f"memory - it is not SURVEY 8(d)'s first-byte-uploaded number, which is value_end_to_end in this line] "
+                            f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
                             f"{int(OVERLAP * 100)}% overlap): SIFT -> " + ("all-pairs exhaustive 2-NN + Lowe ratio" if args.matcher == "pairwise" else "pooled exact 4-NN of all descriptors + per-query filter (featureMatchingGlobal)") + " -> batched RANSAC -> "
                             f"host match graph/cameras ({args.cameras}) -> spherical inverse warp + {args.bands}-band multiband blend, "
                             f"tile 2048 -> cropNonzeroBbox -> panorama copied to pinned host memory; BASELINE.json configs[2].  "

@@ -24,7 +24,9 @@ rows = sorted(acc.items(), key=lambda kv: -(kv[1]["TCC_EA0_RDREQ_sum"] + kv[1]["
 out = ["# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum (own pass), bench.py --steps 1 --warmup 0: ONE step of 64 x 4K",
        "# bytes = requests x 64 B (calibrated on blur_kernel/extrema_kernel, see scripts/hbm_traffic.sh)",
        "%-72s %8s %10s %10s %14s" % ("kernel", "launches", "read GB", "write GB", "GB per launch")]
-js = {}
+sys.path.insert(0, ".")
+import bench
+js = {"_meta": {"csrc_sha256": bench.csrc_sha256(), "how": "scripts/hbm_traffic.sh: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum, one bench step"}}
 for k, v in rows:
     rd, wr = v["TCC_EA0_RDREQ_sum"] * 64 / 1e9, v["TCC_EA0_WRREQ_sum"] * 64 / 1e9
     js[k] = {"launches_per_step": n[k], "read_bytes_per_step": rd * 1e9, "write_bytes_per_step": wr * 1e9}

@@ -140,18 +140,27 @@ def test_bench_scale_matching_screen_on_equals_screen_off(gpu, mods, monkeypatch
     monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
     assert np.array_equal(pp, pp0) and int(pp[-1]) > 100000
     assert bool(torch.equal(ia, ia0)) and bool(torch.equal(ib, ib0)) and bool(torch.equal(met.view(torch.int32), met0.view(torch.int32)))
+    # the screening pass on the other MFMA shape (v_mfma_i32_32x32x32_i8, rounds 2-3; the default is 16x16x64): its groups of
+    # columns differ, so its survivor set may differ by a few rows - the lists may not
+    monkeypatch.setenv("APS_SCREEN_SHAPE", "32")
+    pp2, ia2, ib2, met2 = fm.match_pairs_csr(descs, order, 0.6, 1.5, True, device_out=True)
+    monkeypatch.delenv("APS_SCREEN_SHAPE", raising=False)
+    rows2, surv2 = ctypes.c_int64(0), ctypes.c_int64(0)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_stats(ctypes.byref(rows2), ctypes.byref(surv2)))
+    assert rows2.value == rows.value and abs(surv2.value - surv.value) < 0.01 * surv.value
+    assert np.array_equal(pp, pp2) and bool(torch.equal(ia, ia2)) and bool(torch.equal(ib, ib2))
+    assert bool(torch.equal(met.view(torch.int32), met2.view(torch.int32)))
     # one-to-one per pair: within a pair's segment no column index repeats
     seg = torch.repeat_interleave(torch.arange(len(order), device="cuda"), torch.from_numpy(np.diff(pp)).to("cuda"))
     key = seg.to(torch.int64) * (1 << 32) + ib.to(torch.int64)
     assert int(torch.unique(key).numel()) == int(key.numel())
 
 
-def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
+def _configs4(gpu, mods, **switches):
     """BASELINE configs[4] as SURVEY 8(d) cfg5 specifies it, on one GPU: 500 mixed 2048 x 1080 views drawn from SIX
     independent worlds of 60 - 110 views each (different seeds, grids and overlaps, one of them a full 360 degree ring),
-    shuffled -> all 124 750 pairs matched -> connected components -> six equirectangular panoramas.  Properties only
-    (the oracle would need hours): every component is exactly one world, every panorama is rendered, covered and of a
-    plausible size."""
+    shuffled -> matched -> connected components -> six equirectangular panoramas.  Properties only (the oracle would need
+    hours): every component is exactly one world, every panorama is rendered, covered and of a plausible size."""
     import time
     import torch
 
@@ -173,12 +182,12 @@ def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
     torch.cuda.synchronize()
     n = len(views)
     assert n == 500
-    inp = pl.default_input(bands=5, panorama2DisplaynSave="equirectangular")
+    inp = pl.default_input(bands=5, panorama2DisplaynSave="equirectangular", **switches)
     t0 = time.perf_counter()
     pano, info = par.stitch_distributed(inp, dict(enumerate(views)), n, Ks, (2048, 2048), 0, None, pano_root=0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"configs[4] (6 worlds, 500 views of 2048 x 1080) on one GPU: {dt:.2f} s, stages {info['times']}")
+    print(f"configs[4] (6 worlds, 500 views of 2048 x 1080, {switches or 'pairwise matcher'}) on one GPU: {dt:.2f} s, stages {info['times']}")
     assert info["n_components"] == len(worlds) and len(info["panoramas"]) == len(worlds)
     sizes = sorted(nx * ny for nx, ny, _ in worlds)
     assert sorted(len(c["members"]) for c in info["components"]) == sizes
@@ -190,6 +199,24 @@ def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
     ring = next(p for c, p in zip(info["components"], info["panoramas"]) if len(c["members"]) == 95)
     assert ring.shape[1] > 0.9 * 2 * np.pi * f
     assert any(pano is p for p in info["panoramas"])
+    return info
+
+
+def test_multi_panorama_recognition_at_configs4_image_count(gpu, mods):
+    """configs[4] with every pair matched exhaustively (matchFeaturesPairwise = 1, 124 750 pairs)."""
+    _configs4(gpu, mods)
+
+
+def test_configs4_with_the_reference_default_pooled_matcher(gpu, mods):
+    """configs[4] with the reference's DEFAULT matcher switch (inputs.m:46 matchFeaturesPairwise = 0: featureMatchingGlobal.m:69-161,
+    the "global matcher" of BASELINE.md row 5): one pool of ~2.7 M descriptors, exact 4-NN of the pool against itself
+    through the int8 proof pass, per-query filter.  Same properties: six components, each exactly one world."""
+    import ctypes
+
+    info = _configs4(gpu, mods, matchFeaturesPairwise=0, k=4)
+    rows, searched = ctypes.c_int64(0), ctypes.c_int64(0)
+    gpu._capi.check(gpu._capi.lib.aps_knn_global_screen_stats(ctypes.byref(rows), ctypes.byref(searched)))
+    print(f"pooled matcher at configs[4] size: {sum(info['n_features'])} pool rows, (row, image) slots {rows.value}, searched {searched.value}")
 
 
 def test_256_views_4k_at_configs3_image_count(gpu, mods):
