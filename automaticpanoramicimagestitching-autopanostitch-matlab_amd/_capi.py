@@ -119,6 +119,7 @@ _SIGNATURES = {
     "aps_warp_tile": [C.POINTER(aps_image), C.POINTER(aps_canvas), _i, _i, _i, _i, _f, _vp, _vp, _vp,
                       _vp],
     "aps_gain_overlap_stats": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), _i, _vp, _vp, _vp],
+    "aps_gain_overlap_stats_warped": [_vp, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp],
     "aps_imresize_u8": [_vp, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp],
     "aps_crop_rect": [_vp, _i64, _i64, _i, _i, _d, _vp, _vp],
     "aps_crop_nonzero_bbox": [_vp, _i64, _i64, _i, _i, _vp, _vp],

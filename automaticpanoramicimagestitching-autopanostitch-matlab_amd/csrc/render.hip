@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <memory>
 #include <vector>
 
 #include "render_dev.h"
@@ -1606,6 +1607,169 @@ extern "C" int aps_gain_overlap_stats(const aps_image* images, int n_img, const 
         oI.commit();
         oJ.commit();
         APS_HIP(hipStreamSynchronize(stream()));
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// gainCompensationH's overlap statistics (PP/gainCompensation/gainCompensationH.m:45-52,78-149): the planar-scan path has
+// every image ALREADY warped to one canvas (Iw{k} H x W x 3 single, Ww{k} H x W single, renderPanorama.m:579-588), so the
+// statistics are plain strided sums over those canvases: every ds-th row and column (1:ds:end), a point is valid for
+// image k when Ww{k} > 0 and all three channels are finite, and every pair i < j that is valid there adds one count and
+// the two colours (accumulated in double, as the reference's sum(..., 'double')).
+// ------------------------------------------------------------------------------------------------
+namespace aps {
+struct WarpedSet {
+    const float* const* iw;  // device array of N device pointers
+    const float* const* ww;
+    int n, h, w, ch, layout;  // layout APS_ROWMAJOR: h x w x ch interleaved rows (C / numpy); APS_COLMAJOR: MATLAB h x w x ch
+};
+
+__device__ __forceinline__ size_t warped_at(const WarpedSet& S, int y, int x, int c, int nch) {
+    return S.layout == APS_ROWMAJOR ? ((size_t)y * S.w + x) * nch + c : (size_t)y + (size_t)S.h * ((size_t)x + (size_t)S.w * c);
+}
+
+// One thread per sampled canvas point; the pair table of gain_stats_kernel (an LDS hash per workgroup, one double
+// atomicAdd per touched pair at the end).
+__global__ __launch_bounds__(256) void gain_stats_warped_kernel(WarpedSet S, int ds, int ws, int hs, double* __restrict__ Nij,
+                                                                double* __restrict__ sCi, double* __restrict__ sCj) {
+    __shared__ unsigned int s_key[kGainSlots];
+    __shared__ unsigned int s_cnt[kGainSlots];
+    __shared__ double s_sum[kGainSlots][6];
+    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
+        s_key[e] = 0u;
+        s_cnt[e] = 0u;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_sum[e][c] = 0.0;
+    }
+    __syncthreads();
+    const int n_img = S.n;
+    const size_t nn = (size_t)n_img * n_img;
+    auto add_pair = [&](int i, int j, const float* ci, const float* cj) {
+        const unsigned int key = (unsigned int)(i * n_img + j) + 1u;
+        unsigned int slot = (key * 2654435761u) >> 25;
+        for (int probe = 0; probe < kGainSlots; ++probe) {
+            const unsigned int old = atomicCAS(&s_key[slot], 0u, key);
+            if (old == 0u || old == key) {
+                atomicAdd(&s_cnt[slot], 1u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    atomicAdd(&s_sum[slot][c], (double)ci[c]);
+                    atomicAdd(&s_sum[slot][3 + c], (double)cj[c]);
+                }
+                return;
+            }
+            slot = (slot + 1) & (kGainSlots - 1);
+        }
+        const size_t e = (size_t)i + (size_t)n_img * j;  // table full: straight to memory
+        atomicAdd(&Nij[e], 1.0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(&sCi[e + nn * c], (double)ci[c]);
+            atomicAdd(&sCj[e + nn * c], (double)cj[c]);
+        }
+    };
+    const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (ix < ws && iy < hs) {
+        const int x = ix * ds, y = iy * ds;
+        auto sample = [&](int k, float* c3) {
+            if (!(S.ww[k][warped_at(S, y, x, 0, 1)] > 0.f)) return false;
+            bool fin = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                c3[c] = S.iw[k][warped_at(S, y, x, c < S.ch ? c : S.ch - 1, S.ch)];
+                fin = fin && isfinite(c3[c]);
+            }
+            return fin;
+        };
+        int cov[kGainMaxCover];
+        float col[kGainMaxCover][3];
+        int k = 0;
+        bool overflow = false;
+        for (int i = 0; i < n_img; ++i) {
+            float c3[3];
+            if (!sample(i, c3)) continue;
+            if (k < kGainMaxCover) {
+                cov[k] = i;
+                col[k][0] = c3[0];
+                col[k][1] = c3[1];
+                col[k][2] = c3[2];
+                ++k;
+            } else {
+                overflow = true;
+            }
+        }
+        if (!overflow) {
+            for (int a = 0; a < k; ++a)
+                for (int b = a + 1; b < k; ++b) add_pair(cov[a], cov[b], col[a], col[b]);
+        } else {
+            for (int i = 0; i < n_img; ++i) {
+                float ci[3];
+                if (!sample(i, ci)) continue;
+                for (int j = i + 1; j < n_img; ++j) {
+                    float cj[3];
+                    if (sample(j, cj)) add_pair(i, j, ci, cj);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
+        const unsigned int key = s_key[e];
+        if (!key) continue;
+        const int i = (int)((key - 1u) / (unsigned int)n_img), j = (int)((key - 1u) % (unsigned int)n_img);
+        const size_t o = (size_t)i + (size_t)n_img * j;
+        atomicAdd(&Nij[o], (double)s_cnt[e]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(&sCi[o + nn * c], s_sum[e][c]);
+            atomicAdd(&sCj[o + nn * c], s_sum[e][3 + c]);
+        }
+    }
+}
+}  // namespace aps
+
+extern "C" int aps_gain_overlap_stats_warped(const float* const* iw, const float* const* ww, int n_img, int64_t height, int64_t width,
+                                             int channels, int layout, int downsample, double* n_ij, double* sum_ci,
+                                             double* sum_cj) {
+    using namespace aps;
+    return guarded([&] {
+        APS_REQUIRE(iw && ww && n_ij && sum_ci && sum_cj, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(n_img >= 1 && n_img <= 46340, APS_E_ARG, "bad image count");
+        APS_REQUIRE(height >= 1 && width >= 1 && height * width < ((int64_t)1 << 31), APS_E_DIM, "bad canvas size");
+        APS_REQUIRE(channels == 1 || channels == 3, APS_E_DIM, "channels must be 1 or 3");
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_TYPE, "unknown layout");
+        APS_REQUIRE(downsample >= 1, APS_E_ARG, "overlapDownsample must be >= 1");
+        ctx();
+        const size_t px = (size_t)height * width;
+        std::vector<std::unique_ptr<In<float>>> keep;
+        std::vector<const float*> hi(n_img), hw(n_img);
+        for (int k = 0; k < n_img; ++k) {
+            APS_REQUIRE(iw[k] && ww[k], APS_E_ARG, "NULL canvas %d", k);
+            keep.emplace_back(new In<float>(iw[k], px * channels));
+            hi[k] = keep.back()->get();
+            keep.emplace_back(new In<float>(ww[k], px));
+            hw[k] = keep.back()->get();
+        }
+        Ws<const float*> di(n_img), dw(n_img);
+        APS_HIP(hipMemcpyAsync(di, hi.data(), n_img * sizeof(const float*), hipMemcpyHostToDevice, stream()));
+        APS_HIP(hipMemcpyAsync(dw, hw.data(), n_img * sizeof(const float*), hipMemcpyHostToDevice, stream()));
+        const size_t nn = (size_t)n_img * n_img;
+        Out<double> oN(n_ij, nn), oI(sum_ci, 3 * nn), oJ(sum_cj, 3 * nn);
+        APS_HIP(hipMemsetAsync(oN.get(), 0, nn * sizeof(double), stream()));
+        APS_HIP(hipMemsetAsync(oI.get(), 0, 3 * nn * sizeof(double), stream()));
+        APS_HIP(hipMemsetAsync(oJ.get(), 0, 3 * nn * sizeof(double), stream()));
+        const int ws = (int)((width - 1) / downsample + 1), hs = (int)((height - 1) / downsample + 1);  // numel(1:ds:end)
+        WarpedSet S{di, dw, n_img, (int)height, (int)width, channels, layout};
+        {
+            Prof prof("gain_stats_warped");
+            gain_stats_warped_kernel<<<dim3(cdiv(ws, 16), cdiv(hs, 16)), 256, 0, stream()>>>(S, downsample, ws, hs, oN.get(), oI.get(),
+                                                                                          oJ.get());
+        }
+        check_launch("gain_stats_warped_kernel");
+        oN.commit();
+        oI.commit();
+        oJ.commit();
+        APS_HIP(hipStreamSynchronize(stream()));  // the host pointer arrays and the staged inputs must outlive the launch
     });
 }
 

@@ -387,11 +387,13 @@ def pureNonRotationalPanoramas(images, cameras, numImages, opts, gains=None):
     (renderPanorama.m:519-699): planar-scan compositing.  Canvas = bounding box of all H2refined corner
     maps with MATLAB-rounded size (:547-575); every image warped to the FULL canvas; then whole-canvas
     'none' (winner-take-all by weight, first maximum) / 'linear' / 'multiband'; void pixels painted; uint8.
-    Gain compensation (gainCompensationH) stays on the host: pass `gains` (N x 3) or ones are used."""
+    Gains: pass `gains` (N x 3), or set opts['gainCompensation'] to have gainCompensationH run on the warped canvases
+    (:584-591: overlap statistics on the device, solve on the host); otherwise ones."""
     from .blending import linearBlending, multiBandBlending
     from .imageProcessing import imref2dScratch, outputLimitsScratch
 
-    o = {"blending": "multiband", "pyrLevels": 3, "pyrSigma": 1.0, "canvasColor": "black"}
+    o = {"blending": "multiband", "pyrLevels": 3, "pyrSigma": 1.0, "canvasColor": "black",
+         "sigmaN": 10.0, "sigmag": 0.1}  # (renderPanorama.m:56-58: the defaults opts carries into gainCompensationH)
     o.update(opts or {})
     tforms = [np.asarray(cam["H2refined"], np.float64) for cam in cameras[:numImages]]
     lims = [outputLimitsScratch(T, (1, np.asarray(im).shape[1]), (1, np.asarray(im).shape[0]))
@@ -403,6 +405,12 @@ def pureNonRotationalPanoramas(images, cameras, numImages, opts, gains=None):
         raise ValueError("degenerate planar canvas")
     view = imref2dScratch((height, width), (xMin, xMax), (yMin, yMax))
     Iw, Ww, _, _, _ = pureNonRotationalImagesToCanvas(images, tforms, view, warpWeights(images), o)
+    if gains is None and o.get("gainCompensation"):
+        # renderPanorama.m:584-591: gains from the warped canvases (statistics on the device, N x N solve on the host).  As
+        # in the ray renderer below only when the caller asks for it explicitly; otherwise ones (or the caller's own).
+        from .gainCompensation import gainCompensationH
+
+        gains = gainCompensationH(Iw, Ww, o)
     if gains is not None:
         Iw = [I * np.asarray(g, np.float32).reshape(1, 1, -1) for I, g in zip(Iw, gains)]
     mode = str(o["blending"]).lower()

@@ -404,6 +404,18 @@ int aps_crop_nonzero_bbox(const uint8_t* img, int64_t h, int64_t w, int layout, 
 int aps_gain_overlap_stats(const aps_image* images, int n_img, const aps_canvas* canvas, int stride,
                            double* n_ij, double* sum_ci, double* sum_cj);
 
+/* SURVEY 8(f) rank 1, planar scans -- the overlap statistics of gainCompensationH
+ * (PP/gainCompensation/gainCompensationH.m:45-52,78-149; caller renderPanorama.m:584-588).  iw[k]: the k-th image warped to
+ * the common canvas, f32 height x width x channels; ww[k]: its weight map, f32 height x width (host or device memory, like
+ * every other buffer of this library; layout APS_ROWMAJOR = interleaved rows as C / numpy hold them, APS_COLMAJOR = MATLAB's
+ * planar column-major arrays).  Every `downsample`-th row and column of the canvas is sampled (1:ds:end, :45-52); a sample
+ * is valid for image k when ww[k] > 0 and all channels are finite (:117); each pair i < j valid there adds 1 to n_ij(i,j)
+ * and its two colours to sum_ci(i,j,:) / sum_cj(i,j,:), accumulated in double (:126-146).  Outputs as aps_gain_overlap_stats:
+ * f64 N x N and N x N x 3, column-major, upper triangle.  Sums are added in an unspecified order (compare with a relative
+ * tolerance); counts are exact.  The edge selection and the N x N solve (:152-223) stay on the host. */
+int aps_gain_overlap_stats_warped(const float* const* iw, const float* const* ww, int n_img, int64_t height, int64_t width,
+                                  int channels, int layout, int downsample, double* n_ij, double* sum_ci, double* sum_cj);
+
 /* a15/a16 for ONE tile, layers out (for tests): rows r0..r0+ht-1, cols c0..c0+wt-1 (0-based) of
  * the canvas sampled from ONE image.  S: f32 ht x wt x 3 row-major interleaved, Wang/Wf: f32 ht x wt,
  * M: uint8 ht x wt (sampleOneTile, renderPanorama.m:1063-1146). */

@@ -385,6 +385,36 @@ static void cmd_gain(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     if (nlhs > 2) plhs[2] = sj; else mxDestroyArray(sj);
 }
 
+// [Nij, sumCi, sumCj] = aps_mex('gain_overlap_stats_warped', Iw (1xN cell single HxWx3), Ww (1xN cell single HxW), ds)
+// (the accumulation of gainCompensationH.m:45-52,78-149)
+static void cmd_gain_warped(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 4 && mxIsCell(prhs[1]) && mxIsCell(prhs[2]), "aps:type", "usage: Iw cell, Ww cell, overlapDownsample");
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    need(n >= 1 && (int)mxGetNumberOfElements(prhs[2]) == n, "aps:type", "Iw and Ww must have the same length");
+    std::vector<const float*> iw(n), ww(n);
+    const mwSize* d0 = mxGetDimensions(mxGetCell(prhs[1], 0));
+    const int64_t h = (int64_t)d0[0], w = (int64_t)d0[1];
+    const int ch = mxGetNumberOfDimensions(mxGetCell(prhs[1], 0)) > 2 ? (int)d0[2] : 1;
+    for (int i = 0; i < n; ++i) {
+        const mxArray* a = mxGetCell(prhs[1], i);
+        const mxArray* b = mxGetCell(prhs[2], i);
+        need(mxIsSingle(a) && mxIsSingle(b), "aps:type", "Iw / Ww must be single");
+        const mwSize* da = mxGetDimensions(a);
+        const mwSize* db = mxGetDimensions(b);
+        need((int64_t)da[0] == h && (int64_t)da[1] == w && (int64_t)db[0] == h && (int64_t)db[1] == w, "aps:type", "canvas sizes differ");
+        iw[i] = (const float*)mxGetData(a);
+        ww[i] = (const float*)mxGetData(b);
+    }
+    const mwSize d3[3] = {(mwSize)n, (mwSize)n, 3};
+    plhs[0] = mxCreateDoubleMatrix(n, n, mxREAL);
+    mxArray* si = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+    mxArray* sj = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+    check(aps_gain_overlap_stats_warped(iw.data(), ww.data(), n, h, w, ch, APS_COLMAJOR, (int)mxGetScalar(prhs[3]), mxGetPr(plhs[0]),
+                                        mxGetPr(si), mxGetPr(sj)));
+    if (nlhs > 1) plhs[1] = si; else mxDestroyArray(si);
+    if (nlhs > 2) plhs[2] = sj; else mxDestroyArray(sj);
+}
+
 // J = aps_mex('imresize_u8', I uint8 HxWxC, [oh ow], [scale_r scale_c], bicubic(0/1))
 static void cmd_imresize(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs == 5 && mxIsUint8(prhs[1]), "aps:type", "usage: I uint8, [oh ow], [scale_r scale_c], bicubic");
@@ -501,6 +531,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);
     else if (cmd == "gain_overlap_stats") cmd_gain(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "gain_overlap_stats_warped") cmd_gain_warped(nlhs, plhs, nrhs, prhs);
     else if (cmd == "imresize_u8") cmd_imresize(nlhs, plhs, nrhs, prhs);
     else if (cmd == "crop_rect") cmd_crop(nlhs, plhs, nrhs, prhs);
     else if (cmd == "ba_pair_blocks") cmd_ba(nlhs, plhs, nrhs, prhs);

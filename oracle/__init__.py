@@ -496,6 +496,27 @@ def gain_overlap_stats(images, cameras, geo, stride=5):
     return np.ascontiguousarray(Nij), np.ascontiguousarray(sCi), np.ascontiguousarray(sCj)
 
 
+_orc_gain_overlap_stats_warped = _sig("orc_gain_overlap_stats_warped", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+
+
+def gain_overlap_stats_warped(Iw, Ww, ds=4):
+    """gainCompensationH's overlap statistics of images already warped to one canvas (Iw[k]: H x W x C float32, Ww[k]: H x W
+    float32): (Nij [N,N], sumCi [N,N,3], sumCj [N,N,3]), upper triangle."""
+    n = len(Iw)
+    Iw = [np.ascontiguousarray(np.asarray(a, np.float32)) for a in Iw]
+    Ww = [np.ascontiguousarray(np.asarray(a, np.float32)) for a in Ww]
+    Iw = [a if a.ndim == 3 else a[..., None] for a in Iw]
+    h, w, ch = Iw[0].shape
+    pi = (C.c_void_p * n)(*[a.ctypes.data for a in Iw])
+    pw = (C.c_void_p * n)(*[a.ctypes.data for a in Ww])
+    Nij = np.zeros((n, n), np.float64, order="F")
+    sCi = np.zeros((n, n, 3), np.float64, order="F")
+    sCj = np.zeros((n, n, 3), np.float64, order="F")
+    _orc_gain_overlap_stats_warped(C.addressof(pi), C.addressof(pw), n, h, w, ch, int(ds), Nij.ctypes.data, sCi.ctypes.data,
+                                   sCj.ctypes.data)
+    return np.ascontiguousarray(Nij), np.ascontiguousarray(sCi), np.ascontiguousarray(sCj)
+
+
 _orc_imresize_u8 = _sig("orc_imresize_u8", [_vp, _i, _i, _i, _i, _i, _d, _d, _i, _vp])
 
 

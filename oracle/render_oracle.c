@@ -760,6 +760,44 @@ ORC_API void orc_gain_overlap_stats(const orc_image* imgs, int n, const orc_canv
 }
 
 /* ================================================================================================
+ * gainCompensationH's overlap statistics (PP/gainCompensation/gainCompensationH.m:45-52, 78-149): the images are
+ * already warped to one canvas (Iw{k}: H x W x C float, Ww{k}: H x W float, row-major interleaved here).  Every ds-th
+ * row and column (MATLAB 1:ds:end = 0-based 0, ds, 2 ds, ...) is sampled; valid(k) = Ww{k} > 0 & all channels finite
+ * (:117); every pair i < j valid at a sample adds one count and its two colours, summed in double (:126-146).
+ * Outputs N x N (x 3), column-major, upper triangle - the layout of orc_gain_overlap_stats.
+ * ================================================================================================ */
+ORC_API void orc_gain_overlap_stats_warped(const float* const* iw, const float* const* ww, int n, int h, int w, int C, int ds,
+                                           double* Nij, double* sumCi, double* sumCj) {
+    const size_t nn = (size_t)n * n;
+    memset(Nij, 0, nn * sizeof(double));
+    memset(sumCi, 0, 3 * nn * sizeof(double));
+    memset(sumCj, 0, 3 * nn * sizeof(double));
+    if (ds < 1) ds = 1;
+    int* cov = (int*)malloc(sizeof(int) * n);
+    for (int y = 0; y < h; y += ds)
+        for (int x = 0; x < w; x += ds) {
+            int k = 0;
+            for (int i = 0; i < n; ++i) {
+                if (!(ww[i][(size_t)y * w + x] > 0.0f)) continue;
+                int fin = 1;
+                for (int c = 0; c < C; ++c) fin = fin && isfinite(iw[i][((size_t)y * w + x) * C + c]);
+                if (fin) cov[k++] = i;
+            }
+            for (int a = 0; a < k; ++a)
+                for (int b = a + 1; b < k; ++b) {
+                    const size_t e = (size_t)cov[a] + (size_t)n * cov[b];
+                    Nij[e] += 1.0;
+                    for (int c = 0; c < 3; ++c) {
+                        const int cc = c < C ? c : C - 1;
+                        sumCi[e + nn * c] += (double)iw[cov[a]][((size_t)y * w + x) * C + cc];
+                        sumCj[e + nn * c] += (double)iw[cov[b]][((size_t)y * w + x) * C + cc];
+                    }
+                }
+        }
+    free(cov);
+}
+
+/* ================================================================================================
  * imresize(I, s | [oh ow], 'bicubic' | 'bilinear') on uint8 images -- the preprocessing step in front of SIFT
  * (PP/imageProcessing/resizeImagesToLimits.m:49-106).  imresize is toolbox code: PARITY
  * UNPINNED.  Fixed here and mirrored by the HIP path (public documentation of imresize/contributions):

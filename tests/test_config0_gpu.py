@@ -88,3 +88,48 @@ def test_two_view_homography_stitch_matches_the_oracle_stage_by_stage(gpu, pair,
     both = (W_[0] > 0.2) & (W_[1] > 0.2)
     assert both.sum() > 50000
     assert np.abs(pano.astype(np.float32)[both] - 255.0 * C_[0][both]).mean() < 10.0
+
+
+def test_planar_scan_gain_compensation_recovers_a_planted_gain(gpu, pair):
+    """gainCompensationH on the configs[0] pair (renderPanorama.m:584-591 -> gainCompensationH.m): view 2 is darkened by a
+    known factor, both views are warped to the planar canvas with the scene's homography, the overlap statistics come from
+    the device (against the oracle: counts equal, sums to 1e-12) and the solved gains undo the factor to 1 %; the
+    planar-scan renderer with opts.gainCompensation set applies exactly those gains."""
+    rp = import_module(gpu.__name__ + ".renderPanorama")
+    ip = import_module(gpu.__name__ + ".imageProcessing")
+    gc = import_module(gpu.__name__ + ".gainCompensation")
+    imgs, cams = pair
+    planted = 0.8
+    dark = np.clip(np.floor(imgs[1].astype(np.float32) * planted + 0.5), 0, 255).astype(np.uint8)
+    views = [imgs[0], dark]
+    K = cams[0]["K"]
+    Ht = K @ cams[0]["R"] @ cams[1]["R"].T @ np.linalg.inv(K)
+    Hn = Ht / Ht[2, 2]
+    tforms = [np.eye(3), Hn]
+    lims = [ip.outputLimitsScratch(T, (1, W), (1, H)) for T in tforms]
+    xMin, xMax = min(l[0][0] for l in lims), max(l[0][1] for l in lims)
+    yMin, yMax = min(l[1][0] for l in lims), max(l[1][1] for l in lims)
+    width, height = int(np.floor(xMax - xMin + 0.5)), int(np.floor(yMax - yMin + 0.5))
+    view = ip.imref2dScratch((height, width), (xMin, xMax), (yMin, yMax))
+    Iw, Ww, _, _, _ = rp.pureNonRotationalImagesToCanvas(views, tforms, view, rp.warpWeights(views), {})
+    for ds in (4, 3):
+        N, sI, sJ = gc.gain_overlap_stats_warped(Iw, Ww, ds)
+        oN, oI, oJ = oracle.gain_overlap_stats_warped(Iw, Ww, ds)
+        assert np.array_equal(N, oN) and N[0, 1] > 10000 and N.sum() == N[0, 1]
+        assert np.allclose(sI, oI, rtol=1e-12, atol=0) and np.allclose(sJ, oJ, rtol=1e-12, atol=0)
+    g = gc.gainCompensationH(Iw, Ww, {"sigmag": 10.0})  # (gainCompensationH.m:30: its own default prior, loose)
+    assert g.shape == (2, 3) and np.all((g >= 0.25) & (g <= 4.0))
+    assert np.allclose(g[1] / g[0], 1.0 / planted, rtol=0.01)
+    assert np.allclose(np.sqrt(g[0] * g[1] * planted), 1.0, atol=0.15)  # the pair's common scale stays near one
+    # the renderer: opts.gainCompensation -> the same gains, applied before the blend
+    pcams = [{"H2refined": T, "noRotation": 1} for T in tforms]
+    opts = {"blending": "linear", "canvasColor": "black", "gainCompensation": 1, "sigmag": 10.0}
+    pano_auto, _ = rp.renderPanorama({}, views, [(H, W, 3)] * 2, pcams, "planar", 0, opts)
+    opts_off = {"blending": "linear", "canvasColor": "black"}
+    pano_given, _ = rp.renderPanorama({}, views, [(H, W, 3)] * 2, pcams, "planar", 0, opts_off, gains=g)
+    pano_none, _ = rp.renderPanorama({}, views, [(H, W, 3)] * 2, pcams, "planar", 0, opts_off)
+    assert np.array_equal(pano_auto, pano_given) and not np.array_equal(pano_auto, pano_none)
+    # and the compensated composite is more uniform across the seam than the raw one
+    both = (Ww[0] > 0.3) & (Ww[1] > 0.3)
+    a, b = Iw[0][both].mean(0), Iw[1][both].mean(0)
+    assert np.abs(a * g[0] - b * g[1]).max() < 0.2 * np.abs(a - b).max()

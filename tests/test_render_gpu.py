@@ -489,3 +489,31 @@ def test_analytic_footprints_contain_the_exact_ones_for_tilted_wide_and_near_pol
     ref, _, rcov, _ = rp.renderPanorama({}, imgs, sizes, cams, mode, 0, opts, return_covered=True)
     monkeypatch.delenv("APS_RENDER_DEVICE_COVER")
     assert cov.sum() > 20000 and np.array_equal(cov, rcov) and np.array_equal(pano, ref)
+
+
+@pytest.mark.parametrize("ds", [1, 4, 7])
+@pytest.mark.parametrize("resident", [False, True])
+def test_gain_overlap_stats_of_warped_canvases_match_oracle(gpu, ds, resident):
+    """aps_gain_overlap_stats_warped (gainCompensationH.m:45-52,78-149) against the oracle on random canvases with holes,
+    non-finite colours, a single-channel set and > 16 images covering one point (the kernel's overflow path); host arrays
+    and resident tensors."""
+    import torch
+
+    gc = import_module(gpu.__name__ + ".gainCompensation")
+    rng = np.random.default_rng(100 + ds)
+    for n, ch in ((5, 3), (19, 3), (3, 1)):
+        Hc, Wc = 83, 121
+        Iw = [rng.random((Hc, Wc, ch)).astype(np.float32) for _ in range(n)]
+        Ww = [((rng.random((Hc, Wc)) > 0.3) * rng.random((Hc, Wc))).astype(np.float32) for _ in range(n)]
+        Iw[1][::5, ::3, ch - 1] = np.nan
+        Iw[2][3::7, 1::4, 0] = np.inf
+        if resident:
+            a = [torch.from_numpy(x).cuda() for x in Iw]
+            b = [torch.from_numpy(x).cuda() for x in Ww]
+            torch.cuda.synchronize()
+        else:
+            a, b = Iw, Ww
+        N, sI, sJ = gc.gain_overlap_stats_warped(a, b, ds)
+        oN, oI, oJ = oracle.gain_overlap_stats_warped(Iw, Ww, ds)
+        assert np.array_equal(N, oN) and oN.sum() > 50 and np.all(np.tril(N) == 0)
+        assert np.allclose(sI, oI, rtol=1e-12, atol=1e-9) and np.allclose(sJ, oJ, rtol=1e-12, atol=1e-9)

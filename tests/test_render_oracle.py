@@ -227,3 +227,57 @@ def test_imresize_u8_analytic_cases():
     sat[:, 8:] = 255  # a step: the cubic overshoot must saturate, not wrap
     o = oracle.imresize_u8(sat, 3.0, "bicubic")
     assert o.min() == 0 and o.max() == 255
+
+
+def test_gain_overlap_statistics_of_warped_canvases_analytic_cases():
+    """gainCompensationH.m:45-52,78-149 on cases with a known answer: constant canvases with rectangular weight supports
+    count the ds-strided samples of the supports' intersection (1:ds:end = 0-based 0, ds, ...), the sums are count x the
+    constants per channel; a non-finite colour or a zero weight removes the sample for that image only; and a literal
+    numpy transcription of the reference's vectorised accumulation agrees on random data."""
+    Hc, Wc = 37, 53
+    Iw = [np.zeros((Hc, Wc, 3), np.float32) for _ in range(3)]
+    Ww = [np.zeros((Hc, Wc), np.float32) for _ in range(3)]
+    vals = [(0.2, 0.4, 0.6), (0.5, 0.25, 0.125), (0.9, 0.8, 0.7)]
+    boxes = [(0, 30, 0, 40), (5, 37, 10, 53), (20, 37, 0, 20)]  # r0, r1, c0, c1
+    for k in range(3):
+        Iw[k][...] = vals[k]
+        r0, r1, c0, c1 = boxes[k]
+        Ww[k][r0:r1, c0:c1] = 0.5
+    for ds in (1, 4, 5):
+        N, sI, sJ = oracle.gain_overlap_stats_warped(Iw, Ww, ds)
+        ys, xs = np.arange(0, Hc, ds), np.arange(0, Wc, ds)
+
+        def cnt(a, b):
+            r0, r1 = max(boxes[a][0], boxes[b][0]), min(boxes[a][1], boxes[b][1])
+            c0, c1 = max(boxes[a][2], boxes[b][2]), min(boxes[a][3], boxes[b][3])
+            return int(((ys >= r0) & (ys < r1)).sum() * ((xs >= c0) & (xs < c1)).sum())
+
+        for a, b in ((0, 1), (0, 2), (1, 2)):
+            assert N[a, b] == cnt(a, b)
+            assert np.allclose(sI[a, b], np.array(vals[a], np.float32).astype(np.float64) * cnt(a, b), rtol=1e-12)
+            assert np.allclose(sJ[a, b], np.array(vals[b], np.float32).astype(np.float64) * cnt(a, b), rtol=1e-12)
+        assert np.all(np.tril(N) == 0)
+    # invalid samples: a NaN in one channel of image 1 and a zero weight of image 0 at sampled points inside the overlap
+    Iw[1][8, 12, 2] = np.nan
+    Ww[0][12, 16] = 0.0
+    N2, _, _ = oracle.gain_overlap_stats_warped(Iw, Ww, 4)
+    N0, _, _ = oracle.gain_overlap_stats_warped([np.nan_to_num(a) for a in Iw], [np.where(w == 0, w, w) for w in Ww], 4)
+    assert N2[0, 1] == N0[0, 1] - 1  # (8, 12): image 1 invalid there; (12, 16) is counted in N0 only if Ww[0] > 0 - it is not
+    # the reference's vectorised form, transcribed: valid = (W > 0) & all(isfinite(I), channel); overlap = vi & vj; sums in double
+    rng = np.random.default_rng(5)
+    n = 4
+    Iw = [rng.random((29, 41, 3)).astype(np.float32) for _ in range(n)]
+    Ww = [(rng.random((29, 41)) > 0.4).astype(np.float32) * rng.random((29, 41)).astype(np.float32) for _ in range(n)]
+    Iw[2][::3, ::5, 1] = np.inf
+    ds = 3
+    N, sI, sJ = oracle.gain_overlap_stats_warped(Iw, Ww, ds)
+    I4 = np.stack([a[::ds, ::ds] for a in Iw], 3).reshape(-1, 3, n)
+    W3 = np.stack([w[::ds, ::ds] for w in Ww], 2).reshape(-1, n)
+    valid = (W3 > 0) & np.isfinite(I4).all(1)
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            ov = valid[:, i] & valid[:, j]
+            assert N[i, j] == ov.sum()
+            for ch in range(3):
+                assert np.isclose(sI[i, j, ch], np.where(ov, I4[:, ch, i], 0).astype(np.float64).sum(), rtol=1e-12)
+                assert np.isclose(sJ[i, j, ch], np.where(ov, I4[:, ch, j], 0).astype(np.float64).sum(), rtol=1e-12)
