@@ -270,6 +270,83 @@ static void cmd_ransac(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
     if (nlhs > 2) plhs[2] = mxCreateLogicalScalar(found != 0);
 }
 
+static void tform_of(const mxArray* a, int* tform, int* min_pts) {
+    const std::string t = str(a);
+    if (t == "projective") *tform = APS_TFORM_PROJECTIVE, *min_pts = 4;
+    else if (t == "affine") *tform = APS_TFORM_AFFINE, *min_pts = 3;
+    else if (t == "similarity") *tform = APS_TFORM_SIMILARITY, *min_pts = 2;
+    else if (t == "rigid") *tform = APS_TFORM_RIGID, *min_pts = 2;
+    else if (t == "translation") *tform = APS_TFORM_TRANSLATION, *min_pts = 1;
+    else mexErrMsgIdAndTxt("aps:type", "Unknown transform type");
+}
+
+// sampleIdx = aps_mex('ransac_draw_samples', counts (P x 1 double: matches per pair), S, seed)
+//   uint32 4 x S x P, column s of page p = one minimal-sample draw of pair p (1-based, local to the pair); the seeded
+//   counter-based generator of aps_ransac_draw_samples, keyed by the pair's position (imageMatching.m:121 draws inside
+//   parfor workers, whose streams the reference does not pin)
+static void cmd_draw(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 4 && mxIsDouble(prhs[1]), "aps:type", "usage: counts double, S, seed");
+    const int P = (int)mxGetNumberOfElements(prhs[1]);
+    const int S = (int)mxGetScalar(prhs[2]);
+    need(S >= 1, "aps:args", "S must be positive");
+    std::vector<int64_t> counts(P ? P : 1);
+    std::vector<uint64_t> keys(P ? P : 1);
+    for (int p = 0; p < P; ++p) {
+        counts[p] = (int64_t)mxGetPr(prhs[1])[p];
+        keys[p] = (uint64_t)p;
+    }
+    const mwSize d3[3] = {4, (mwSize)S, (mwSize)P};
+    plhs[0] = mxCreateNumericArray(3, d3, mxUINT32_CLASS, mxREAL);
+    if (P > 0)
+        check(aps_ransac_draw_samples(counts.data(), keys.data(), P, S, (uint64_t)mxGetScalar(prhs[3]), (uint32_t*)mxGetData(plhs[0])));
+}
+
+// [models, mask, found, nInl] = aps_mex('ransac_homography_batch', pts1, pts2 (total x 2 double: the pairs' matched points one
+//   after the other), pairPtr (P+1 double, 0-based row offsets), input struct, sampleIdx (uint32 4 x S x P), transformType,
+//   method ('ransac' | 'mlesac'))  - every candidate pair of imageMatching.m:121-156 in one device batch
+static void cmd_ransac_batch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 8 && mxIsDouble(prhs[1]) && mxIsDouble(prhs[2]) && mxIsDouble(prhs[3]) && mxIsUint32(prhs[5]), "aps:type",
+         "usage: pts1, pts2 double total x 2; pairPtr double; input; sampleIdx uint32 4 x S x P; transformType; method");
+    const int64_t total = (int64_t)mxGetM(prhs[1]);
+    need(mxGetN(prhs[1]) == 2 && mxGetM(prhs[2]) == (mwSize)total && mxGetN(prhs[2]) == 2, "aps:dim", "pts1 and pts2 must both be total x 2");
+    const int P = (int)mxGetNumberOfElements(prhs[3]) - 1;
+    need(P >= 0, "aps:dim", "pairPtr needs P + 1 entries");
+    std::vector<int64_t> pp(P + 1);
+    for (int p = 0; p <= P; ++p) pp[p] = (int64_t)mxGetPr(prhs[3])[p];
+    need(pp[0] == 0 && pp[P] == total, "aps:dim", "pairPtr must run from 0 to the number of rows");
+    const mwSize* sd = mxGetDimensions(prhs[5]);
+    const int nsd = (int)mxGetNumberOfDimensions(prhs[5]);
+    need(sd[0] == 4 && (nsd > 2 ? (int)sd[2] : 1) == std::max(P, 1), "aps:dim", "sampleIdx must be 4 x S x P");
+    aps_ransac_opts o;
+    int min_pts = 4;
+    tform_of(prhs[6], &o.tform_type, &min_pts);
+    const bool mlesac = str(prhs[7]) == "mlesac";
+    o.max_distance = field(prhs[4], "maxDistance", 2.0);
+    o.confidence = field(prhs[4], "inliersConfidence", 99.9);
+    o.max_iter = (int)field(prhs[4], "maxIter", mlesac ? 1000 : 500);
+    o.method = mlesac ? APS_ROBUST_MLESAC : APS_ROBUST_RANSAC;
+    const mwSize d3[3] = {3, 3, (mwSize)P};
+    plhs[0] = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+    std::vector<uint8_t> mask(total ? total : 1);
+    std::vector<int32_t> found(P ? P : 1), ninl(P ? P : 1);
+    if (P > 0 && total > 0)
+        check(aps_ransac_homography_batch(mxGetPr(prhs[1]), mxGetPr(prhs[2]), total, pp.data(), P, (const uint32_t*)mxGetData(prhs[5]),
+                                          (int)sd[1], &o, mxGetPr(plhs[0]), mask.data(), found.data(), ninl.data()));
+    if (nlhs > 1) {
+        plhs[1] = mxCreateLogicalMatrix(total, 1);
+        mxLogical* l = mxGetLogicals(plhs[1]);
+        for (int64_t e = 0; e < total; ++e) l[e] = mask[e] != 0;
+    }
+    if (nlhs > 2) {
+        plhs[2] = mxCreateLogicalMatrix(P, 1);
+        for (int p = 0; p < P; ++p) mxGetLogicals(plhs[2])[p] = found[p] != 0;
+    }
+    if (nlhs > 3) {
+        plhs[3] = mxCreateDoubleMatrix(P, 1, mxREAL);
+        for (int p = 0; p < P; ++p) mxGetPr(plhs[3])[p] = (double)ninl[p];
+    }
+}
+
 // F = aps_mex('multiband_blend', Ci (1xK cell of single h x w x 3), Wi (1xK cell of single h x w), levels, sigma)
 // F = aps_mex('linear_blend', Ci, Wi)
 static void cmd_blend(bool multiband, int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -527,6 +604,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "hamming_2nn") cmd_hamming(nlhs, plhs, nrhs, prhs);
     else if (cmd == "ransac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, false);
     else if (cmd == "mlesac_homography") cmd_ransac(nlhs, plhs, nrhs, prhs, true);
+    else if (cmd == "ransac_homography_batch") cmd_ransac_batch(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "ransac_draw_samples") cmd_draw(nlhs, plhs, nrhs, prhs);
     else if (cmd == "multiband_blend") cmd_blend(true, nlhs, plhs, nrhs, prhs);
     else if (cmd == "linear_blend") cmd_blend(false, nlhs, plhs, nrhs, prhs);
     else if (cmd == "render") cmd_render(nlhs, plhs, nrhs, prhs);

@@ -66,5 +66,5 @@ def test_shadows_cover_the_operator_table_of_survey_8b():
     need = {"getFeaturePoints", "featureMatchingPairwise", "matchFeaturesScratch", "flann_knn_win",
             "nearest2HammingExhaustiveMEX", "nearest2HammingExhaustiveOMPMEX", "estimateTransformationRANSAC",
             "estimateTransformationMLESAC", "renderPanorama", "multiBandBlending", "linearBlending", "imageWarp",
-            "featureMatchingGlobal"}
+            "featureMatchingGlobal", "imageMatching"}
     assert need <= have, need - have
