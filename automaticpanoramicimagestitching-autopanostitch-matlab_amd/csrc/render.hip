@@ -1302,6 +1302,15 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
             APS_HIP(hipStreamSynchronize(stream()));
             return;
         }
+        // 'linear' / 'none': one fused launch over all tiles (render_batch.hip, rw_fuse_kernel); APS_RENDER_LEGACY=1 keeps the
+        // per-tile kernels below, whose bytes it reproduces
+        if (opts->blending != APS_BLEND_MULTIBAND && !std::getenv("APS_RENDER_LEGACY") &&
+            render_fuse_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr)) {
+            oP.commit();
+            oC.commit();
+            APS_HIP(hipStreamSynchronize(stream()));
+            return;
+        }
         // phase 1: footprint of every image in every tile (the reference skips images with ~any(Mi), :989;
         // here the bounding box of Mi also bounds all later work on that layer); one read-back
         std::vector<int> hbox((size_t)nt * n_img * 4, 0);

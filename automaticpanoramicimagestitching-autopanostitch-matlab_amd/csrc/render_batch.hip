@@ -1434,6 +1434,117 @@ __global__ __launch_bounds__(256) void rw_up_kernel(RwArgs A, int l, const int* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 'linear' and 'none' blending, every tile in ONE launch (round 4; renderPanorama.m:864-978)
+// ------------------------------------------------------------------------------------------------
+// The per-tile path (render.hip) materialises one full-tile float4 layer per contributing image (warp_layer_kernel), folds
+// the layers (linear_fuse_kernel) or visits every image of the set once per tile (none_fuse_kernel, n_img launches per tile)
+// and paints: ~4 500 launches and 54 ms for the 64 x 4K scene.  Neither blend needs the layers afterwards, so here a
+// thread owns one canvas pixel, computes its ray once, walks the layers that meet its 32 x 8 block in ascending image order
+// (footprint rectangles, block masks as in the warp) and folds each sample straight into the pixel's accumulators - the
+// per-tile kernels' expressions on the same values in the same order (sample_one, the 'linear' floor Wf >= 1e-4 and
+// best-weight fallback of :931-975, the three 'none' policies of :876-911), then paints.  Nothing is stored but the
+// panorama: the bytes equal the per-tile path's (tests/test_render_gpu.py).
+template <int MODE>
+__global__ __launch_bounds__(256) void rw_fuse_kernel(RwArgs A, const int* __restrict__ blk_ptr, int n_blocks, int none_policy) {
+    __shared__ ColTrig s_ct[kUW];
+    __shared__ RowTrig s_rt[kUH];
+    const int bid = xcd_contiguous_id(n_blocks);
+    if (bid >= n_blocks) return;
+    const int t = find_segment(blk_ptr, A.n_tiles, bid);
+    const RwTile& T = A.tiles[t];
+    const int tid = threadIdx.x;
+    const int h = T.ht, w = T.wt;
+    const int local = bid - blk_ptr[t], nbx = (w + kUW - 1) / kUW;
+    const int x0 = (local % nbx) * kUW, y0 = (local / nbx) * kUH;
+    if (tid < kUW) s_ct[tid] = col_trig(A.cv, (float)(T.c0 + min(x0 + tid, w - 1)));
+    if (tid >= 64 && tid < 64 + kUH) s_rt[tid - 64] = row_trig(A.cv, (float)(T.r0 + min(y0 + tid - 64, h - 1)));
+    __syncthreads();
+    const ColTrig ct = s_ct[tid & (kUW - 1)];
+    const RowTrig rt = s_rt[tid / kUW];
+    const int x = x0 + (tid & (kUW - 1)), y = y0 + tid / kUW;
+    const bool in_tile = x < w && y < h;
+    float d[3] = {0.f, 0.f, 1.f};
+    if (in_tile) ray_from_tables(A.cv, ct, rt, (float)(T.c0 + x), (float)(T.r0 + y), d);  // (= canvas_ray, bit for bit)
+    const int bx1 = min(x0 + kUW, w), by1 = min(y0 + kUH, h);
+    const LayerSet ls = block_layers(A, T, 0, x0, y0, bx1, by1);
+    float acc[3] = {0.f, 0.f, 0.f}, ws = 0.f, bestw = 0.f, best[3] = {0.f, 0.f, 0.f};  // 'linear' (linear_fuse_kernel)
+    bool anyv = false;
+    float f[3] = {0.f, 0.f, 0.f}, fw = 0.f;  // 'none' (none_fuse_kernel): F and, for 'maxangle', the best Wang so far
+    bool cov = false;
+    for_block_layers(ls, A, T, 0, x0, y0, bx1, by1, [&](int k) __attribute__((always_inline)) {
+        const RwEntry& E = A.entries[T.e0 + k];
+        if (!(in_tile && in_rect(E.g[0], x, y))) return;  // outside the footprint the sample is (0, 0, 0, mask false)
+        const Sample sm = sample_one(A.imgs[E.img], d, A.angle_pow);
+        if (MODE == APS_BLEND_LINEAR) {
+            float wf = sm.wf;  // warp_layer_kernel with wf_floor = 1e-4 (:933)
+            if (!isfinite(wf)) wf = 0.f;
+            wf = wf > 1e-4f ? wf : 1e-4f;
+            const float gw = sm.m ? sm.wang * wf : 0.0f;
+            acc[0] = acc[0] + sm.s[0] * gw;
+            acc[1] = acc[1] + sm.s[1] * gw;
+            acc[2] = acc[2] + sm.s[2] * gw;
+            ws = ws + gw;
+            const bool m = gw > 0.f;
+            anyv |= m;
+            if (m && gw > bestw) {
+                bestw = gw;
+                best[0] = sm.s[0];
+                best[1] = sm.s[1];
+                best[2] = sm.s[2];
+            }
+        } else {
+            bool upd;
+            if (none_policy == APS_NONE_LAST)
+                upd = sm.m;
+            else if (none_policy == APS_NONE_FIRST)
+                upd = sm.m && !cov;
+            else
+                upd = sm.m && (sm.wang > fw);
+            if (upd) {
+                f[0] = sm.s[0];
+                f[1] = sm.s[1];
+                f[2] = sm.s[2];
+                if (none_policy == APS_NONE_MAXANGLE) fw = sm.wang;
+                cov = true;
+            }
+        }
+    });
+    if (!in_tile) return;
+    float v[3];
+    bool c;
+    if (MODE == APS_BLEND_LINEAR) {
+        const bool z = ws > 1e-12f;
+        v[0] = z ? acc[0] / ws : (anyv ? best[0] : 0.f);
+        v[1] = z ? acc[1] / ws : (anyv ? best[1] : 0.f);
+        v[2] = z ? acc[2] / ws : (anyv ? best[2] : 0.f);
+        c = ws > 0.f;
+    } else {
+        v[0] = f[0];
+        v[1] = f[1];
+        v[2] = f[2];
+        c = cov;
+    }
+    const int gy = T.r0 + y, gx = T.c0 + x;  // paint_kernel (:408-425)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float tt = roundf(255.0f * v[k]);  // MATLAB round: half away from zero
+        if (!(tt > 0.f)) tt = 0.f;
+        if (tt > 255.f) tt = 255.f;
+        const uint8_t b = c ? (uint8_t)tt : (A.white ? 255 : 0);
+        if (A.out_layout == APS_IMG_U8_HWC)
+            A.pano[((size_t)gy * A.W + gx) * 3 + k] = b;
+        else
+            A.pano[(size_t)k * A.H * A.W + (size_t)gx * A.H + gy] = b;
+    }
+    if (A.covered) {
+        if (A.out_layout == APS_IMG_U8_HWC)
+            A.covered[(size_t)gy * A.W + gx] = c ? 1 : 0;
+        else
+            A.covered[(size_t)gx * A.H + gy] = c ? 1 : 0;
+    }
+}
+
 template <int R>
 constexpr size_t down_lds_bytes() {
     return (size_t)(kBR * DownShape<R>::IC + DownShape<R>::T1) * sizeof(float4);
@@ -1601,6 +1712,50 @@ bool host_footprints(const DevImage* himgs, int n_img, const DevCanvas& cv, cons
     return true;
 }
 
+// pass 1 of both batched renderers: the footprint rectangle of every image in every tile, on the host where the
+// projection allows it (no kernel, no read-back), else by the exact coverage kernel.  hbox: [tile][image][x0 y0 x1 y1].
+static void tile_footprints(const RwArgs& A, const DevImage* himgs, int n_img, const std::vector<RwTile>& ht_, const std::vector<int>& xshift,
+                            const int* d_xshift, const RwTile* d_tiles, int max_ht, int max_wt, std::vector<int>& hbox) {
+    const int nt = (int)ht_.size();
+    const DevCanvas& cv = A.cv;
+    hbox.assign((size_t)nt * n_img * 4, 0);
+    const bool check_rects = std::getenv("APS_RENDER_CHECK_RECTS") != nullptr;
+    const bool analytic = !std::getenv("APS_RENDER_DEVICE_COVER") && host_footprints(himgs, n_img, cv, ht_, hbox);
+    if (!analytic || check_rects) {
+        const int nby_max = cdiv(max_ht, 8);
+        Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
+        Ws<int> d_bbox((size_t)nt * n_img * 4);
+        std::vector<int> dbox((size_t)nt * n_img * 4);
+        APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
+        {
+            Prof prof("render_cover");
+            rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
+            rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
+                                                                                    nt * n_img, d_bbox);
+        }
+        check_launch("rw_cover_kernel");
+        APS_HIP(hipMemcpyAsync(dbox.data(), d_bbox, dbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        if (analytic) {  // test hook: every exact footprint must lie inside its analytic rectangle
+            for (size_t e = 0; e < dbox.size() / 4; ++e) {
+                const int* d = &dbox[4 * e];
+                const int* hb = &hbox[4 * e];
+                if (!(d[2] > d[0] && d[3] > d[1])) continue;
+                // the coverage kernel reports whole 32 x 8 blocks (32 << xshift wide): compare on that grid
+                const int t_ = (int)(e / n_img), gx = 32 << xshift[t_];
+                const bool inside = hb[2] > hb[0] && hb[0] / gx * gx <= d[0] && hb[1] / 8 * 8 <= d[1] &&
+                                    std::min((hb[2] + gx - 1) / gx * gx, ht_[t_].wt) >= d[2] && std::min((hb[3] + 7) / 8 * 8, ht_[t_].ht) >= d[3];
+                APS_REQUIRE(inside, APS_E_INTERNAL,
+                            "analytic footprint [%d %d %d %d] does not contain the exact one [%d %d %d %d] (tile %zu, image %zu)",
+                            hb[0], hb[1], hb[2], hb[3], d[0], d[1], d[2], d[3], e / n_img, e % n_img);
+            }
+        } else {
+            hbox = dbox;
+        }
+    }
+
+}
+
 }  // namespace
 
 bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
@@ -1727,42 +1882,8 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     A.rt = d_rt;
 
     // ---- pass 1: the footprint rectangle of every image in every tile ----------------------------------------------
-    // on the host where the projection allows it (no kernel, no read-back), else by the exact coverage kernel
-    std::vector<int> hbox((size_t)nt * n_img * 4);
-    const bool check_rects = std::getenv("APS_RENDER_CHECK_RECTS") != nullptr;
-    const bool analytic = !std::getenv("APS_RENDER_DEVICE_COVER") && host_footprints(himgs, n_img, cv, ht_, hbox);
-    if (!analytic || check_rects) {
-        const int nby_max = cdiv(max_ht, 8);
-        Ws<unsigned long long> rowmask((size_t)nt * n_img * nby_max);
-        Ws<int> d_bbox((size_t)nt * n_img * 4);
-        std::vector<int> dbox((size_t)nt * n_img * 4);
-        APS_HIP(hipMemsetAsync(rowmask, 0, (size_t)nt * n_img * nby_max * sizeof(unsigned long long), stream()));
-        {
-            Prof prof("render_cover");
-            rw_cover_kernel<<<dim3(cdiv(max_wt, 32), cdiv(max_ht, 8), nt), 256, 0, stream()>>>(A, n_img, nby_max, d_xshift, rowmask);
-            rw_footprint_kernel<<<cdiv((size_t)nt * n_img, 256), 256, 0, stream()>>>(rowmask, d_tiles, d_xshift, n_img, nby_max,
-                                                                                    nt * n_img, d_bbox);
-        }
-        check_launch("rw_cover_kernel");
-        APS_HIP(hipMemcpyAsync(dbox.data(), d_bbox, dbox.size() * sizeof(int), hipMemcpyDeviceToHost, stream()));
-        APS_HIP(hipStreamSynchronize(stream()));
-        if (analytic) {  // test hook: every exact footprint must lie inside its analytic rectangle
-            for (size_t e = 0; e < dbox.size() / 4; ++e) {
-                const int* d = &dbox[4 * e];
-                const int* hb = &hbox[4 * e];
-                if (!(d[2] > d[0] && d[3] > d[1])) continue;
-                // the coverage kernel reports whole 32 x 8 blocks (32 << xshift wide): compare on that grid
-                const int t_ = (int)(e / n_img), gx = 32 << xshift[t_];
-                const bool inside = hb[2] > hb[0] && hb[0] / gx * gx <= d[0] && hb[1] / 8 * 8 <= d[1] &&
-                                    std::min((hb[2] + gx - 1) / gx * gx, ht_[t_].wt) >= d[2] && std::min((hb[3] + 7) / 8 * 8, ht_[t_].ht) >= d[3];
-                APS_REQUIRE(inside, APS_E_INTERNAL,
-                            "analytic footprint [%d %d %d %d] does not contain the exact one [%d %d %d %d] (tile %zu, image %zu)",
-                            hb[0], hb[1], hb[2], hb[3], d[0], d[1], d[2], d[3], e / n_img, e % n_img);
-            }
-        } else {
-            hbox = dbox;
-        }
-    }
+    std::vector<int> hbox;
+    tile_footprints(A, himgs, n_img, ht_, xshift, d_xshift, d_tiles, max_ht, max_wt, hbox);
 
     // ---- entries, compact stores, block tables ----------------------------------------------------------------
     std::vector<RwEntry> ents;
@@ -1908,6 +2029,96 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     APS_HIP(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));  // also keeps the host tables alive until their uploads have run
     APS_REQUIRE(status == 0, APS_E_INTERNAL, "batched render: tap table assumption violated (status %d)", status);
+    return true;
+}
+
+// 'linear' / 'none': all tiles in one launch (rw_fuse_kernel).  Same tile list and footprints as the multiband form.
+bool render_fuse_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
+                         const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered) {
+    const int nt = (int)tiles.size();
+    if (nt == 0) return true;
+    if (o.blending != APS_BLEND_LINEAR && o.blending != APS_BLEND_NONE) return false;
+    std::vector<RwTile> ht_(nt);
+    std::vector<int> xshift(nt);
+    int max_ht = 0, max_wt = 0;
+    for (int t = 0; t < nt; ++t) {
+        RwTile& T = ht_[t];
+        std::memset(&T, 0, sizeof T);
+        T.r0 = tiles[t].r0;
+        T.c0 = tiles[t].c0;
+        T.ht = tiles[t].ht;
+        T.wt = tiles[t].wt;
+        T.nl = 1;
+        T.lh[0] = T.ht;
+        T.lw[0] = T.wt;
+        max_ht = std::max(max_ht, T.ht);
+        max_wt = std::max(max_wt, T.wt);
+        int xs = 0;
+        while ((cdiv(T.wt, 32) >> xs) > 64 || (((cdiv(T.wt, 32) - 1) >> xs) > 63)) ++xs;
+        xshift[t] = xs;
+    }
+    Ws<int> d_xshift(nt);
+    Ws<RwTile> d_tiles(nt);
+    APS_HIP(hipMemcpyAsync(d_xshift, xshift.data(), nt * sizeof(int), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_tiles, ht_.data(), nt * sizeof(RwTile), hipMemcpyHostToDevice, stream()));
+    RwArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.tiles = d_tiles;
+    A.n_tiles = nt;
+    A.imgs = dimgs;
+    A.cv = cv;
+    A.angle_pow = o.angle_power;
+    A.pano = pano;
+    A.covered = covered;
+    A.H = cv.H;
+    A.W = cv.W;
+    A.out_layout = out_layout;
+    A.white = o.canvas_white;
+    std::vector<int> hbox;
+    tile_footprints(A, himgs, n_img, ht_, xshift, d_xshift, d_tiles, max_ht, max_wt, hbox);
+    std::vector<RwEntry> ents;
+    for (int t = 0; t < nt; ++t) {
+        RwTile& T = ht_[t];
+        T.e0 = (int)ents.size();
+        for (int i = 0; i < n_img; ++i) {
+            const int* b = &hbox[((size_t)t * n_img + i) * 4];
+            if (!(b[2] > b[0] && b[3] > b[1])) continue;
+            RwEntry E;
+            std::memset(&E, 0, sizeof E);
+            E.tile = t;
+            E.img = i;
+            E.g[0] = clip_rect(Rect{b[0], b[1], b[2], b[3]}, T.wt, T.ht);
+            ents.push_back(E);
+        }
+        T.ne = (int)ents.size() - T.e0;
+    }
+    // every tile is painted (a tile without layers gets the canvas colour): blocks over the level-0 grid of all tiles
+    std::vector<int> blk0(nt + 1, 0);
+    long long run = 0;
+    for (int t = 0; t < nt; ++t) {
+        blk0[t] = (int)run;
+        run += (long long)cdiv(ht_[t].wt, kUW) * cdiv(ht_[t].ht, kUH);
+    }
+    APS_REQUIRE(run < (1ll << 30), APS_E_DIM, "too many canvas blocks in one render call (%lld)", run);
+    blk0[nt] = (int)run;
+    const int ne = (int)ents.size();
+    Ws<RwEntry> d_ents(std::max(ne, 1));
+    Ws<int> d_blk0(blk0.size());
+    if (ne) APS_HIP(hipMemcpyAsync(d_ents, ents.data(), ne * sizeof(RwEntry), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_tiles, ht_.data(), nt * sizeof(RwTile), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    A.entries = d_ents;
+    A.n_entries = ne;
+    {
+        Prof prof("render_fuse");
+        const unsigned grid = 8u * (unsigned)((run + 7) / 8);
+        if (o.blending == APS_BLEND_LINEAR)
+            rw_fuse_kernel<APS_BLEND_LINEAR><<<grid, 256, 0, stream()>>>(A, d_blk0, (int)run, o.none_policy);
+        else
+            rw_fuse_kernel<APS_BLEND_NONE><<<grid, 256, 0, stream()>>>(A, d_blk0, (int)run, o.none_policy);
+    }
+    check_launch("rw_fuse_kernel");
+    APS_HIP(hipStreamSynchronize(stream()));  // keeps the host tables alive until their uploads have run
     return true;
 }
 

@@ -257,5 +257,7 @@ struct TileRect {
 // what the batched kernels are built for (the caller then takes the per-tile path).
 bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
                               const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered);
+bool render_fuse_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
+                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered);
 
 }  // namespace aps

@@ -469,11 +469,11 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
     else:
         pano = np.zeros((H, W, 3), np.uint8)
         cov = np.zeros((H, W), np.uint8)
-    # multiband: ONE call renders all tiles level-major (render_batch.hip); the per-tile paths ('none', 'linear', or
-    # APS_RENDER_LEGACY=1) still gain from a few host threads driving interleaved tile subsets
+    # ONE call renders all tiles (render_batch.hip: multiband level-major, 'linear' / 'none' as one fused launch); the
+    # per-tile path (APS_RENDER_LEGACY=1) still gains from a few host threads driving interleaved tile subsets
     import os as _os
 
-    batched = o["blending"] == "multiband" and not _os.environ.get("APS_RENDER_LEGACY")
+    batched = not _os.environ.get("APS_RENDER_LEGACY")  # (since round 4 'linear' and 'none' are one fused launch as well)
     workers = _render_workers() if (device_out and not batched) else 1
     if tile_subset is None and workers <= 1:
         check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))

@@ -1,5 +1,5 @@
 """Render stage alone on the bench scene (64 x 4K views, ground-truth cameras): wall time per render and, under
-rocprofv3 --kernel-trace --stats, the per-kernel breakdown.  usage: probe_render.py [reps] [NXxNY]"""
+rocprofv3 --kernel-trace --stats, the per-kernel breakdown.  usage: probe_render.py [reps] [NXxNY] [blending]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -14,9 +14,10 @@ W, H, f = 3840, 2160, 8000.0
 imgs, cams = synth.make_scene(nx, ny, W, H, f, 0.4, device="cuda", finest_px=16.0)
 inp = pl.default_input(bands=5)
 sizes = [(H, W, 3)] * len(imgs)
-opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
+blending = sys.argv[3] if len(sys.argv) > 3 else "multiband"
+opts = {"anglePower": 2, "blending": blending, "pyrLevels": 5, "pyrSigma": 1.0, "tile": (2048, 2048), "cropBorder": False}
 for r in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pano, _ = rp.renderPanorama(inp, imgs, sizes, cams, "spherical", len(imgs) // 2, opts, device_out=True)
     apsamd._capi.check(apsamd.lib.aps_synchronize()); torch.cuda.synchronize()
-    print(f"render {r}: {(time.perf_counter()-t0)*1e3:.1f} ms, pano {tuple(pano.shape)}, mean {pano.float().mean().item():.3f}", flush=True)
+    print(f"render {r} ({blending}): {(time.perf_counter()-t0)*1e3:.1f} ms, pano {tuple(pano.shape)}, mean {pano.float().mean().item():.3f}", flush=True)
