@@ -621,91 +621,38 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         nb = wave_find_inliers(Hb, x1, y1, x2, y2, m, thr, out_mask, &me);
     }
     __threadfence_block();
-    // refit on the inliers: sums in ascending index order, identical in every lane (uniform branches).  The points are
-    // staged through LDS 64 at a time (one coalesced load per lane), and every lane then walks the staged chunk: read
-    // straight from global memory, each of the ~15 k serial iterations paid a full memory round trip behind the mask
-    // test (3.3 ms per pair, the whole launch 6.6 ms); the additions and their order are unchanged.
-    __shared__ double s_pt[4][64];
-    __shared__ uint8_t s_in[64];
-    auto for_each_inlier = [&](auto&& body) {
-        for (int64_t base = 0; base < m; base += 64) {
-            const int64_t i = base + lane;
-            const bool have = i < m;
-            s_pt[0][lane] = have ? x1[i] : 0.0;
-            s_pt[1][lane] = have ? y1[i] : 0.0;
-            s_pt[2][lane] = have ? x2[i] : 0.0;
-            s_pt[3][lane] = have ? y2[i] : 0.0;
-            s_in[lane] = have ? out_mask[i] : (uint8_t)0;
-            __syncthreads();
-            // eight entries are fetched from LDS before the (uniform) mask tests, so the reads do not queue up behind
-            // the branches; entries past the end of the list were staged with a zero mask
-            for (int e0 = 0; e0 < 64; e0 += 8) {
-                double a[8], b[8], c2[8], d[8];
-                uint8_t in[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    in[k] = s_in[e0 + k];
-                    a[k] = s_pt[0][e0 + k];
-                    b[k] = s_pt[1][e0 + k];
-                    c2[k] = s_pt[2][e0 + k];
-                    d[k] = s_pt[3][e0 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (in[k]) body(a[k], b[k], c2[k], d[k]);
-            }
-            __syncthreads();
-        }
-    };
-    // (pitch 65: lane e of the Gram pass reads row pp(e) of the staged terms at the SAME column - with a pitch of 64 doubles
-    // all 45 rows fell into one bank pair, a 45-way conflict twice per step: SQ_LDS_BANK_CONFLICT 3.1e7 cycles against 7.7e6
-    // active LDS cycles, profiles/r03z_pmc_ransac_finalize.txt.  Worth 2 % only (1.56 -> 1.53 ms): the kernel's time is the
-    // ~134 k vector instructions every lane of a pair's wave executes for the serial, order-fixed sums.)
-    __shared__ double s_val[18][65];
-    auto for_each_staged = [&](int nv, auto&& prep, auto&& body) {
-        (void)nv;
-        for (int64_t base = 0; base < m; base += 64) {
-            const int64_t i = base + lane;
-            const bool have = i < m;
-            const uint8_t in_me = have ? out_mask[i] : (uint8_t)0;
-            s_in[lane] = in_me;
-            if (in_me) prep(x1[i], y1[i], x2[i], y2[i], lane);
-            __syncthreads();
-            for (int e0 = 0; e0 < 64; e0 += 8) {
-                uint8_t in[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) in[k] = s_in[e0 + k];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (in[k]) body(e0 + k);
-            }
-            __syncthreads();
-        }
-    };
+    // Refit on the inliers (:146-181 -> estimateHomography).  Its sums - centroids, mean distances, the Gram sums of the DLT
+    // rows - run in the WAVE ORDER over the point index (round 4; oracle/ransac_oracle.c header): lane l accumulates the
+    // inliers i = l, l + 64, ... in ascending order and the 64 partials meet in the xor butterfly, like the other inlier
+    // sums.  Rounds 1-3 summed sequentially in index order, which made every lane of the pair's wave walk all of its
+    // ~3 700 matches four times behind uniform mask tests: ~134 k serial vector instructions and 1.3 of the 3.4 ms of
+    // the whole RANSAC stage for ~200 pairs, no faster for the 28 pairs of one rank of eight.
     Norm n1, n2;
     {
         double sx = 0, sy = 0, ux = 0, uy = 0;
-        for_each_inlier([&](double a, double b, double c2, double d) {
-            sx = sx + a;
-            sy = sy + b;
-            ux = ux + c2;
-            uy = uy + d;
-        });
+        for (int64_t i = lane; i < m; i += 64)
+            if (out_mask[i]) {
+                sx = sx + x1[i];
+                sy = sy + y1[i];
+                ux = ux + x2[i];
+                uy = uy + y2[i];
+            }
+        sx = wave_sum(sx);
+        sy = wave_sum(sy);
+        ux = wave_sum(ux);
+        uy = wave_sum(uy);
         const double dn = (double)nb;
         const double cx = sx / dn, cy = sy / dn, dx2 = ux / dn, dy2 = uy / dn;
-        // The per-inlier terms of the remaining sums are the same for every lane, so they are evaluated ONCE per inlier
-        // (lane j takes the chunk's j-th point) into s_val, and the lanes then only walk the staged terms - the same
-        // terms in the same order as when every lane recomputed them (3.4 ms -> see DESIGN.md section 4).
         double sd = 0, ud = 0;
-        for_each_staged(2, [&](double a, double b, double c2, double d, int j) {
-            const double ax = a - cx, ay = b - cy;
-            s_val[0][j] = sqrt(ax * ax + ay * ay);
-            const double bx = c2 - dx2, by = d - dy2;
-            s_val[1][j] = sqrt(bx * bx + by * by);
-        }, [&](int e) {
-            sd = sd + s_val[0][e];
-            ud = ud + s_val[1][e];
-        });
+        for (int64_t i = lane; i < m; i += 64)
+            if (out_mask[i]) {
+                const double ax = x1[i] - cx, ay = y1[i] - cy;
+                sd = sd + sqrt(ax * ax + ay * ay);
+                const double bx = x2[i] - dx2, by = y2[i] - dy2;
+                ud = ud + sqrt(bx * bx + by * by);
+            }
+        sd = wave_sum(sd);
+        ud = wave_sum(ud);
         n1.s = norm_scale(sd / dn, mlesac);
         n1.tx = -n1.s * cx;
         n1.ty = -n1.s * cy;
@@ -717,41 +664,48 @@ __global__ __launch_bounds__(64) void ransac_finalize_kernel(
         n2.cx = dx2;
         n2.cy = dy2;
     }
-    // Gram matrix: lane e < 45 owns the upper-triangular entry (pp,qq); rows in the reference's order
-    int pp = 0, qq = 0;
-    {
-        int e = lane < 45 ? lane : 0, row = 0;
-        while (e >= 9 - row) {
-            e -= 9 - row;
-            ++row;
-        }
-        pp = row;
-        qq = row + e;
-    }
-    double g = 0;
-    if (mlesac) {  // per inlier: its "v" row, then its "u" row
-        for_each_staged(18, [&](double a, double b, double c2, double d, int j) {
-            const double x = (a - n1.cx) * n1.s, y = (b - n1.cy) * n1.s;
-            const double u = (c2 - n2.cx) * n2.s, v = (d - n2.cy) * n2.s;
+    // Gram matrix: every lane keeps the 45 upper-triangular partial sums of ITS inliers (rows in the reference's order:
+    // RANSAC all "x" rows, then all "y" rows; MLESAC per inlier its "v" row, then its "u" row), then the butterfly
+    double g[45];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                s_val[k][j] = dlt_entry(k, 1, x, y, u, v);
-                s_val[9 + k][j] = dlt_entry(k, 0, x, y, u, v);
+    for (int e = 0; e < 45; ++e) g[e] = 0;
+    auto add_row = [&](int half, double x, double y, double u, double v) __attribute__((always_inline)) {
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = dlt_entry(k, half, x, y, u, v);
+        int e = 0;
+#pragma unroll
+        for (int pp = 0; pp < 9; ++pp)
+#pragma unroll
+            for (int qq = pp; qq < 9; ++qq, ++e) g[e] = g[e] + a[pp] * a[qq];
+    };
+    if (mlesac) {
+        for (int64_t i = lane; i < m; i += 64)
+            if (out_mask[i]) {
+                const double x = (x1[i] - n1.cx) * n1.s, y = (y1[i] - n1.cy) * n1.s;
+                const double u = (x2[i] - n2.cx) * n2.s, v = (y2[i] - n2.cy) * n2.s;
+                add_row(1, x, y, u, v);
+                add_row(0, x, y, u, v);
             }
-        }, [&](int e) {
-            g = g + s_val[pp][e] * s_val[qq][e];
-            g = g + s_val[9 + pp][e] * s_val[9 + qq][e];
-        });
     } else {
         for (int half = 0; half < 2; ++half)
-            for_each_staged(9, [&](double a, double b, double c2, double d, int j) {
-                const double x = n1.s * a + n1.tx, y = n1.s * b + n1.ty;
-                const double u = n2.s * c2 + n2.tx, v = n2.s * d + n2.ty;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) s_val[k][j] = dlt_entry(k, half, x, y, u, v);
-            }, [&](int e) { g = g + s_val[pp][e] * s_val[qq][e]; });
+            for (int64_t i = lane; i < m; i += 64)
+                if (out_mask[i]) {
+                    const double x = n1.s * x1[i] + n1.tx, y = n1.s * y1[i] + n1.ty;
+                    const double u = n2.s * x2[i] + n2.tx, v = n2.s * y2[i] + n2.ty;
+                    add_row(half, x, y, u, v);
+                }
     }
-    if (lane < 45) sG[(pp * 9 + qq) * 2 + 0] = g;  // column 0 of the work matrix
+    {
+        int e = 0;
+#pragma unroll
+        for (int pp = 0; pp < 9; ++pp)
+#pragma unroll
+            for (int qq = pp; qq < 9; ++qq, ++e) {
+                const double t = wave_sum(g[e]);
+                if (lane == 0) sG[(pp * 9 + qq) * 2 + 0] = t;  // column 0 of the work matrix
+            }
+    }
     __syncthreads();
     Mat3 Hr;
     const bool ok = gram_to_h_wave(sG, sV, lane, n1, n2, Hr, mlesac) && (mlesac || check_model(Hr));

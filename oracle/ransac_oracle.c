@@ -12,6 +12,11 @@
  *   - sums over inliers (mean error :117, centroid and second moments of isDegenerate :559-567) use
  *     the "wave order": 64 lane-strided partial sums (element i -> lane i%64, ascending i), combined
  *     by the xor butterfly 32,16,8,4,2,1;
+ *   - (round 4) so do the sums of the projective REFIT on the inliers (:146-181 -> estimateHomography: centroids, mean
+ *     distances and the Gram sums of the DLT rows; point i adds to partial i % 64).  MATLAB's mean / sum and A'*A leave the
+ *     order open, a sequential order made the refit one wave's serial walk over every match of a pair (1.3 of the 3.4 ms
+ *     of the RANSAC stage), and the wave order is the one the other inlier sums already use.  The MINIMAL-sample fits
+ *     (four points) keep plain sequential sums;
  *   - svd of the centred n x 2 inlier matrix (:562) is the closed form from its 2x2 scatter matrix.
  * Everything is IEEE double with no contraction (-ffp-contract=off), so the device reproduces it.
  */
@@ -112,16 +117,40 @@ static void jacobi9(double* G, double* V) {
     }
 }
 
-/* normalizePoints (:579-610): sequential sums in index order over the SELECTED points */
+/* normalizePoints (:579-610): sums over the SELECTED points - sequential in index order, or (wave != 0: the refit on the
+ * inliers) in the wave order over the point index: point i adds to partial i % 64, the partials meet in wave_reduce */
 static void normalize_sel(const double* x, const double* y, const int64_t* sel, int64_t n,
-                          double* scale, double* tx, double* ty) {
+                          double* scale, double* tx, double* ty, int wave) {
     double sx = 0, sy = 0;
-    for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    if (wave) {
+        double px[64], py[64];
+        for (int l = 0; l < 64; ++l) px[l] = py[l] = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            const int l = (int)(sel[e] & 63);
+            px[l] = px[l] + x[sel[e]];
+            py[l] = py[l] + y[sel[e]];
+        }
+        sx = wave_reduce(px);
+        sy = wave_reduce(py);
+    } else {
+        for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    }
     const double cx = sx / (double)n, cy = sy / (double)n;
     double sd = 0;
-    for (int64_t e = 0; e < n; ++e) {
-        const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
-        sd = sd + sqrt(dx * dx + dy * dy);
+    if (wave) {
+        double pd[64];
+        for (int l = 0; l < 64; ++l) pd[l] = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+            const int l = (int)(sel[e] & 63);
+            pd[l] = pd[l] + sqrt(dx * dx + dy * dy);
+        }
+        sd = wave_reduce(pd);
+    } else {
+        for (int64_t e = 0; e < n; ++e) {
+            const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+            sd = sd + sqrt(dx * dx + dy * dy);
+        }
     }
     const double s = 1.0 / (sd / (double)n);
     *scale = s;
@@ -129,15 +158,29 @@ static void normalize_sel(const double* x, const double* y, const int64_t* sel, 
     *ty = -s * cy;
 }
 
+/* the upper triangle of a 9 x 9 Gram matrix accumulated in the wave order: PG[k][l], k = the (p, q >= p) entry */
+typedef struct { double v[45][64]; } gram_partials;
+static void gram_partials_add(gram_partials* P, int lane, const double* a) {
+    int k = 0;
+    for (int p = 0; p < 9; ++p)
+        for (int q = p; q < 9; ++q, ++k) P->v[k][lane] = P->v[k][lane] + a[p] * a[q];
+}
+static void gram_partials_reduce(gram_partials* P, double* G) {
+    int k = 0;
+    for (int p = 0; p < 9; ++p)
+        for (int q = p; q < 9; ++q, ++k) G[9 * p + q] = wave_reduce(P->v[k]);
+}
+
 /* estimateHomography (:188-225) on the points listed in sel (n >= 4).  H column-major.
  * Returns 0 if the result is not finite. */
 static int fit_homography(const double* x1, const double* y1, const double* x2, const double* y2,
-                          const int64_t* sel, int64_t n, double* H) {
+                          const int64_t* sel, int64_t n, double* H, int wave) {
     double s1, t1x, t1y, s2, t2x, t2y;
-    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
-    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y, wave);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y, wave);
     double G[81];
     for (int e = 0; e < 81; ++e) G[e] = 0;
+    gram_partials* PG = wave ? (gram_partials*)calloc(1, sizeof(gram_partials)) : NULL;
     /* rows of A in the reference's order: first all "x" rows, then all "y" rows (:209-212) */
     for (int half = 0; half < 2; ++half)
         for (int64_t e = 0; e < n; ++e) {
@@ -151,9 +194,17 @@ static int fit_homography(const double* x1, const double* y1, const double* x2, 
                 a[0] = 0; a[1] = 0; a[2] = 0; a[3] = -x; a[4] = -y; a[5] = -1;
                 a[6] = x * v; a[7] = y * v; a[8] = v;
             }
+            if (wave) {
+                gram_partials_add(PG, (int)(sel[e] & 63), a);
+                continue;
+            }
             for (int p = 0; p < 9; ++p)
                 for (int q = p; q < 9; ++q) G[9 * p + q] = G[9 * p + q] + a[p] * a[q];
         }
+    if (wave) {
+        gram_partials_reduce(PG, G);
+        free(PG);
+    }
     for (int p = 0; p < 9; ++p)
         for (int q = 0; q < p; ++q) G[9 * p + q] = G[9 * q + p];
     double V[81];
@@ -272,7 +323,7 @@ ORC_API void orc_ransac_score(const double* Hs, int n_hyp, const double* p1, con
 
 ORC_API int orc_fit_homography(const double* p1, const double* p2, int64_t ldp, const int64_t* sel,
                                int64_t n, double* H) {
-    return fit_homography(p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+    return fit_homography(p1, p1 + ldp, p2, p2 + ldp, sel, n, H, 0);
 }
 
 ORC_API int orc_check_model(const double* H) { return check_model(H); }
@@ -302,7 +353,7 @@ ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m
         for (int k = 0; k < 4; ++k) sel[k] = (int64_t)sample_idx[4 * it + k] - 1;
         ++it;
         double H[9];
-        if (!fit_homography(x1, y1, x2, y2, sel, 4, H) || !check_model(H)) { /* :101-108,:138-141 */
+        if (!fit_homography(x1, y1, x2, y2, sel, 4, H, 0) || !check_model(H)) { /* :101-108,:138-141 */
             ++skip;
             continue;
         }
@@ -332,7 +383,7 @@ ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m
         for (int64_t i = 0; i < m; ++i)
             if (best_mask[i]) sel[c++] = i;
         double R[9];
-        const int ok = fit_homography(x1, y1, x2, y2, sel, c, R) && check_model(R);
+        const int ok = fit_homography(x1, y1, x2, y2, sel, c, R, 1) && check_model(R); /* the refit: wave-order sums */
         free(sel);
         if (ok) {
             double me;
@@ -367,14 +418,37 @@ ORC_API void orc_ransac_homography(const double* p1, const double* p2, int64_t m
  *   - sum(dis) after truncation (:283-285) in wave order.
  * ================================================================================================ */
 static void normalize_sel_hz(const double* x, const double* y, const int64_t* sel, int64_t n,
-                             double* scale, double* tx, double* ty, double* cxo, double* cyo) {
+                             double* scale, double* tx, double* ty, double* cxo, double* cyo, int wave) {
     double sx = 0, sy = 0;
-    for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    if (wave) { /* the refit on the inliers: wave-order sums over the point index (see normalize_sel) */
+        double px[64], py[64];
+        for (int l = 0; l < 64; ++l) px[l] = py[l] = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            const int l = (int)(sel[e] & 63);
+            px[l] = px[l] + x[sel[e]];
+            py[l] = py[l] + y[sel[e]];
+        }
+        sx = wave_reduce(px);
+        sy = wave_reduce(py);
+    } else {
+        for (int64_t e = 0; e < n; ++e) { sx = sx + x[sel[e]]; sy = sy + y[sel[e]]; }
+    }
     const double cx = sx / (double)n, cy = sy / (double)n;
     double sd = 0;
-    for (int64_t e = 0; e < n; ++e) {
-        const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
-        sd = sd + sqrt(dx * dx + dy * dy);
+    if (wave) {
+        double pd[64];
+        for (int l = 0; l < 64; ++l) pd[l] = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+            const int l = (int)(sel[e] & 63);
+            pd[l] = pd[l] + sqrt(dx * dx + dy * dy);
+        }
+        sd = wave_reduce(pd);
+    } else {
+        for (int64_t e = 0; e < n; ++e) {
+            const double dx = x[sel[e]] - cx, dy = y[sel[e]] - cy;
+            sd = sd + sqrt(dx * dx + dy * dy);
+        }
     }
     const double md = sd / (double)n;
     const double s = md > 0 ? sqrt(2.0) / md : 1.0;
@@ -386,12 +460,13 @@ static void normalize_sel_hz(const double* x, const double* y, const int64_t* se
 }
 
 static int fit_homography_mlesac(const double* x1, const double* y1, const double* x2, const double* y2,
-                                 const int64_t* sel, int64_t n, double* H) {
+                                 const int64_t* sel, int64_t n, double* H, int wave) {
     double s1, t1x, t1y, s2, t2x, t2y, c1x, c1y, c2x, c2y;
-    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y);
-    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y);
+    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y, wave);
+    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y, wave);
     double G[81];
     for (int e = 0; e < 81; ++e) G[e] = 0;
+    gram_partials* PG = wave ? (gram_partials*)calloc(1, sizeof(gram_partials)) : NULL;
     for (int64_t e = 0; e < n; ++e)
         for (int half = 1; half >= 0; --half) { /* rows 2i-1 (v) and 2i (u) of :368-373; a a' is sign-blind */
             const double x = (x1[sel[e]] - c1x) * s1, y = (y1[sel[e]] - c1y) * s1;
@@ -404,9 +479,17 @@ static int fit_homography_mlesac(const double* x1, const double* y1, const doubl
                 a[0] = 0; a[1] = 0; a[2] = 0; a[3] = -x; a[4] = -y; a[5] = -1;
                 a[6] = x * v; a[7] = y * v; a[8] = v;
             }
+            if (wave) {
+                gram_partials_add(PG, (int)(sel[e] & 63), a);
+                continue;
+            }
             for (int p = 0; p < 9; ++p)
                 for (int q = p; q < 9; ++q) G[9 * p + q] = G[9 * p + q] + a[p] * a[q];
         }
+    if (wave) {
+        gram_partials_reduce(PG, G);
+        free(PG);
+    }
     for (int p = 0; p < 9; ++p)
         for (int q = 0; q < p; ++q) G[9 * p + q] = G[9 * q + p];
     double V[81];
@@ -482,7 +565,7 @@ ORC_API double orc_mlesac_eval(const double* H, const double* p1, const double* 
 
 ORC_API int orc_fit_homography_mlesac(const double* p1, const double* p2, int64_t ldp, const int64_t* sel,
                                       int64_t n, double* H) {
-    return fit_homography_mlesac(p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
+    return fit_homography_mlesac(p1, p1 + ldp, p2, p2 + ldp, sel, n, H, 0);
 }
 
 ORC_API void orc_mlesac_homography(const double* p1, const double* p2, int64_t m, int64_t ldp,
@@ -506,7 +589,7 @@ ORC_API void orc_mlesac_homography(const double* p1, const double* p2, int64_t m
         for (int k = 0; k < 4; ++k) sel[k] = (int64_t)sample_idx[4 * it + k] - 1;
         ++it;
         double H[9];
-        if (!fit_homography_mlesac(x1, y1, x2, y2, sel, 4, H)) {
+        if (!fit_homography_mlesac(x1, y1, x2, y2, sel, 4, H, 0)) {
             ++skip;
             continue;
         }
@@ -531,7 +614,7 @@ ORC_API void orc_mlesac_homography(const double* p1, const double* p2, int64_t m
         for (int64_t i = 0; i < m; ++i)
             if (best_mask[i]) sel[k++] = i;
         double R[9];
-        const int ok = fit_homography_mlesac(x1, y1, x2, y2, sel, c, R);
+        const int ok = fit_homography_mlesac(x1, y1, x2, y2, sel, c, R, 1); /* the refit: wave-order sums */
         free(sel);
         int n = 0;
         if (ok) mlesac_eval(R, x1, y1, x2, y2, m, max_distance, cur, &n);
@@ -654,8 +737,8 @@ static void jacobi3(double* G, double* V) {
 static int fit_affine(const double* x1, const double* y1, const double* x2, const double* y2, const int64_t* sel,
                       int64_t n, double* H) {
     double s1, t1x, t1y, s2, t2x, t2y;
-    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
-    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y, 0);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y, 0);
     double gxx = 0, gxy = 0, gx = 0, gyy = 0, gy = 0, g1 = 0, bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
     for (int64_t e = 0; e < n; ++e) {
         const double x = s1 * x1[sel[e]] + t1x, y = s1 * y1[sel[e]] + t1y;
@@ -697,8 +780,8 @@ static int fit_affine(const double* x1, const double* y1, const double* x2, cons
 static int fit_sim_rigid(const double* x1, const double* y1, const double* x2, const double* y2, const int64_t* sel,
                          int64_t n, int rigid, double* H) {
     double s1, t1x, t1y, s2, t2x, t2y;
-    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y);
-    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y);
+    normalize_sel(x1, y1, sel, n, &s1, &t1x, &t1y, 0);
+    normalize_sel(x2, y2, sel, n, &s2, &t2x, &t2y, 0);
     double sx = 0, sy = 0, su = 0, sv = 0;
     for (int64_t e = 0; e < n; ++e) {
         sx = sx + (s1 * x1[sel[e]] + t1x); sy = sy + (s1 * y1[sel[e]] + t1y);
@@ -763,15 +846,20 @@ static int fit_translation(const double* x1, const double* y1, const double* x2,
     return isfinite(tx) && isfinite(ty);
 }
 
-static int fit_tform(int type, const double* x1, const double* y1, const double* x2, const double* y2,
-                     const int64_t* sel, int64_t n, double* H) {
+/* refit != 0: the fit on the inliers after the loop (only the projective type distinguishes it: wave-order sums) */
+static int fit_tform_r(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                       const int64_t* sel, int64_t n, double* H, int refit) {
     switch (type) {
         case TF_AFFINE: return fit_affine(x1, y1, x2, y2, sel, n, H);
         case TF_SIMILARITY: return fit_sim_rigid(x1, y1, x2, y2, sel, n, 0, H);
         case TF_RIGID: return fit_sim_rigid(x1, y1, x2, y2, sel, n, 1, H);
         case TF_TRANSLATION: return fit_translation(x1, y1, x2, y2, sel, n, H);
-        default: return fit_homography(x1, y1, x2, y2, sel, n, H);
+        default: return fit_homography(x1, y1, x2, y2, sel, n, H, refit);
     }
+}
+static int fit_tform(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                     const int64_t* sel, int64_t n, double* H) {
+    return fit_tform_r(type, x1, y1, x2, y2, sel, n, H, 0);
 }
 
 /* findInliers (:444-516) for the affine family and translation; projective goes to find_inliers above */
@@ -915,7 +1003,7 @@ ORC_API void orc_ransac_tform(int type, const double* p1, const double* p2, int6
         for (int64_t i = 0; i < m; ++i)
             if (best_mask[i]) sel[c++] = i;
         double R[9];
-        const int ok = fit_tform(type, x1, y1, x2, y2, sel, c, R) && check_model(R);
+        const int ok = fit_tform_r(type, x1, y1, x2, y2, sel, c, R, 1) && check_model(R);
         free(sel);
         int use_refit = 0;
         if (ok) {
@@ -1000,9 +1088,9 @@ static int denormalize_mlesac(const double Tn[9], double s1, double t1x, double 
     return 1;
 }
 
-static int fit_tform_mlesac(int type, const double* x1, const double* y1, const double* x2, const double* y2,
-                            const int64_t* sel, int64_t n, double* H) {
-    if (type == TF_PROJECTIVE) return fit_homography_mlesac(x1, y1, x2, y2, sel, n, H);
+static int fit_tform_mlesac_r(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                              const int64_t* sel, int64_t n, double* H, int refit) {
+    if (type == TF_PROJECTIVE) return fit_homography_mlesac(x1, y1, x2, y2, sel, n, H, refit);
     const double dn = (double)n;
     if (type == TF_TRANSLATION) { /* mean(points2 - points1) */
         double sx = 0, sy = 0;
@@ -1038,8 +1126,8 @@ static int fit_tform_mlesac(int type, const double* x1, const double* y1, const 
         return 1;
     }
     double s1, t1x, t1y, s2, t2x, t2y, c1x, c1y, c2x, c2y;
-    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y);
-    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y);
+    normalize_sel_hz(x1, y1, sel, n, &s1, &t1x, &t1y, &c1x, &c1y, 0);
+    normalize_sel_hz(x2, y2, sel, n, &s2, &t2x, &t2y, &c2x, &c2y, 0);
     const int N = type == TF_AFFINE ? 7 : 5;
     double G[49], V[49];
     for (int e = 0; e < 49; ++e) G[e] = 0;
@@ -1104,6 +1192,11 @@ static int mlesac_loop_number_k(int k, double confidence, int64_t num_pts, int i
     return n < 0 ? 0 : (int)n;
 }
 
+static int fit_tform_mlesac(int type, const double* x1, const double* y1, const double* x2, const double* y2,
+                            const int64_t* sel, int64_t n, double* H) {
+    return fit_tform_mlesac_r(type, x1, y1, x2, y2, sel, n, H, 0);
+}
+
 ORC_API int orc_fit_tform_mlesac(int type, const double* p1, const double* p2, int64_t ldp, const int64_t* sel, int64_t n,
                                  double* H) {
     return fit_tform_mlesac(type, p1, p1 + ldp, p2, p2 + ldp, sel, n, H);
@@ -1165,7 +1258,7 @@ ORC_API void orc_mlesac_tform(int type, const double* p1, const double* p2, int6
         for (int64_t i = 0; i < m; ++i)
             if (best_mask[i]) sel[kk++] = i;
         double R[9];
-        const int ok = fit_tform_mlesac(type, x1, y1, x2, y2, sel, c, R);
+        const int ok = fit_tform_mlesac_r(type, x1, y1, x2, y2, sel, c, R, 1);
         free(sel);
         int n = 0;
         if (ok) mlesac_eval_tform(type, R, x1, y1, x2, y2, m, max_distance, cur, &n);
