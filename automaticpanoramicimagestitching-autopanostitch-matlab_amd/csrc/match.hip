@@ -143,10 +143,12 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 }
 
 // One 64-thread workgroup = 64 rows, one row per lane (the norms are sequential k-ascending chains).  A row-major set
-// is read and the copies are written through an LDS tile (64 rows x 132 floats): every global instruction then moves
-// whole rows (two per 16-byte-per-lane instruction) instead of 64 scattered 16-byte pieces 512 bytes apart - the kernel
-// ran at 0.8 TB/s of its ~35 MB per set on that access pattern alone.
-constexpr int kPrepPitch = kDim + 4;  // floats; 132 = 4 (mod 64): ds_read/write_b128 of 16 consecutive lanes hit 16 slots
+// is read and the copies are written through an LDS tile: every global instruction then moves whole half rows (four per
+// 16-byte-per-lane instruction) instead of 64 scattered 16-byte pieces 512 bytes apart - the kernel ran at 0.8 TB/s of
+// its ~35 MB per set on that access pattern alone.  The tile holds HALF a row per lane (64 rows x 68 floats, 17 KB; a
+// whole row was 34 KB until round 4): the kernel is one wave walking ~4000 dependent instructions, so its throughput is
+// the number of workgroups a CU holds, and LDS was what limited that to four (one wave per SIMD).
+constexpr int kPrepPitch = kDim / 2 + 4;  // floats; 68 = 4 (mod 64): ds_read/write_b128 of 16 consecutive lanes hit 16 slots
 __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
@@ -159,22 +161,26 @@ __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__
     float x[kDim];
     const bool tiled = layout == APS_ROWMAJOR && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (tiled) {
-#pragma unroll 8
-        for (int it = 0; it < 32; ++it) {
-            const int row = 2 * it + (lane >> 5), c4 = lane & 31;
-            const int64_t gr = r0 + row < n ? r0 + row : n - 1;
-            *reinterpret_cast<f32x4*>(&s_t[row * kPrepPitch + 4 * c4]) = *reinterpret_cast<const f32x4*>(X + gr * ld + 4 * c4);
-        }
-        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kDim / 4; ++j) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&s_t[lane * kPrepPitch + 4 * j]);
-            x[4 * j + 0] = v.x;
-            x[4 * j + 1] = v.y;
-            x[4 * j + 2] = v.z;
-            x[4 * j + 3] = v.w;
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll 8
+            for (int it = 0; it < 16; ++it) {  // four 256-byte half rows per instruction
+                const int row = 4 * it + (lane >> 4), c4 = lane & 15;
+                const int64_t gr = r0 + row < n ? r0 + row : n - 1;
+                *reinterpret_cast<f32x4*>(&s_t[row * kPrepPitch + 4 * c4]) =
+                    *reinterpret_cast<const f32x4*>(X + gr * ld + 64 * half + 4 * c4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kDim / 8; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&s_t[lane * kPrepPitch + 4 * j]);
+                x[64 * half + 4 * j + 0] = v.x;
+                x[64 * half + 4 * j + 1] = v.y;
+                x[64 * half + 4 * j + 2] = v.z;
+                x[64 * half + 4 * j + 3] = v.w;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     } else {
 #pragma unroll
         for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[ic * ld + k] : X[ic + k * ld];
@@ -193,29 +199,28 @@ __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
     if (valid) sq[i] = s;
-    // the permuted f32 copy (even k, then odd k), staged per lane and stored as whole rows
+    // the permuted f32 copy (even k, then odd k), staged per lane and stored as whole half rows: first the evens
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
-        f32x4 e, o;
-        e.x = x[8 * s4 + 0];
-        o.x = x[8 * s4 + 1];
-        e.y = x[8 * s4 + 2];
-        o.y = x[8 * s4 + 3];
-        e.z = x[8 * s4 + 4];
-        o.z = x[8 * s4 + 5];
-        e.w = x[8 * s4 + 6];
-        o.w = x[8 * s4 + 7];
-        *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 4 * s4]) = e;
-        *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 64 + 4 * s4]) = o;
-    }
-    __syncthreads();
+    for (int odd = 0; odd < 2; ++odd) {
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            f32x4 e;
+            e.x = x[8 * s4 + 0 + odd];
+            e.y = x[8 * s4 + 2 + odd];
+            e.z = x[8 * s4 + 4 + odd];
+            e.w = x[8 * s4 + 6 + odd];
+            *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 4 * s4]) = e;
+        }
+        __syncthreads();
 #pragma unroll 8
-    for (int it = 0; it < 32; ++it) {
-        const int row = 2 * it + (lane >> 5), c4 = lane & 31;
-        if (r0 + row < n)
-            *reinterpret_cast<f32x4*>(P + (r0 + row) * kDim + 4 * c4) = *reinterpret_cast<const f32x4*>(&s_t[row * kPrepPitch + 4 * c4]);
+        for (int it = 0; it < 16; ++it) {
+            const int row = 4 * it + (lane >> 4), c4 = lane & 15;
+            if (r0 + row < n)
+                *reinterpret_cast<f32x4*>(P + (r0 + row) * kDim + 64 * odd + 4 * c4) =
+                    *reinterpret_cast<const f32x4*>(&s_t[row * kPrepPitch + 4 * c4]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // screening copy in natural k order: xf = f16(x), and the norm of what the rounding dropped, ||x - xf||
     // (rounded up): the candidate kernel's error bound is built from these norms, not from a worst case
     if (Hf) {  // (uniform)
@@ -3179,6 +3184,7 @@ __global__ __launch_bounds__(512) void dbg_corun_kernel(int mode, int spin, cons
     int acc = 0;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     i32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    i32x4 c4 = {0, 0, 0, 0};
     f32x16 cf = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float vf = (float)lane;
     const i32x4 a = {lane, 1, 2, 3};
@@ -3197,6 +3203,12 @@ __global__ __launch_bounds__(512) void dbg_corun_kernel(int mode, int spin, cons
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
         }
+        if (mode & 64) {  // int8 MFMA, the 16x16x64 shape (the screening kernel's since round 4)
+            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
+        }
         if (mode & 8) {  // f16 MFMA
             typedef _Float16 h8 __attribute__((ext_vector_type(8)));
             const h8 ah = {(_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f, (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f};
@@ -3211,19 +3223,28 @@ __global__ __launch_bounds__(512) void dbg_corun_kernel(int mode, int spin, cons
             reinterpret_cast<volatile int*>(lds)[threadIdx.x + 512 * (it & 31)] = it;
             acc += reinterpret_cast<volatile int*>(lds)[(threadIdx.x * 7 + it) & 16383];
         }
-        if (!(mode & 7)) __builtin_amdgcn_s_sleep(20);
+        if (!(mode & (7 | 64))) __builtin_amdgcn_s_sleep(20);
     }
-    if (acc + c[0] + (int)cf[0] + (int)vf == 0x7fffffff) sink[0] = acc;
+    if (acc + c[0] + c4[0] + (int)cf[0] + (int)vf == 0x7fffffff) sink[0] = acc;
 }
 }  // namespace aps
 
+namespace aps { void dbg_corun_agpr_launch(int mode, int n_wg, int spin, int* sink, hipStream_t st); }
 extern "C" int aps_dbg_corun(int mode, int n_wg, int spin) {
     using namespace aps;
     return guarded([&] {
         ctx();
         Ws<signed char> src((size_t)256 * 8 * 1024 + 65536);
         Ws<int> sink(4);
-        dbg_corun_kernel<<<n_wg, 512, 0, stream()>>>(mode, spin, src, sink);
+        if (mode & (128 | 256)) {  // the same int8 MFMAs with their accumulators in AGPRs (dbg_agpr.hip)
+            // Round 4: with this co-runner beside the SIFT worker streams the process died with "Memory access fault by GPU"
+            // (mode 128, profiles/r04c_corun_probe.txt) - the co-runner itself touches no memory.  Not to be run again on a
+            // shared pool without a reason: the switch below keeps it from being started by accident.
+            APS_REQUIRE(std::getenv("APS_DBG_ALLOW_AGPR_CORUN") != nullptr, APS_E_ARG,
+                        "co-run modes 128 / 256 faulted the GPU in round 4; set APS_DBG_ALLOW_AGPR_CORUN=1 to run them anyway");
+            dbg_corun_agpr_launch(mode, n_wg, spin, sink, stream());
+        } else
+            dbg_corun_kernel<<<n_wg, 512, 0, stream()>>>(mode, spin, src, sink);
         check_launch("dbg_corun_kernel");
         APS_HIP(hipStreamSynchronize(stream()));
     });

@@ -1,4 +1,6 @@
-"""Which property of a co-running workgroup disturbs SIFT?  (debug build: make EXTRA=-DAPS_DBG)"""
+"""Which property of a co-running workgroup disturbs SIFT?  (debug build: make EXTRA=-DAPS_DBG)
+modes (bits): 1 LDS-DMA, 2 int8 MFMA 32x32x32 (VGPR accumulators), 4 LDS traffic, 8 f16 MFMA, 32 VALU, 64 int8 MFMA 16x16x64
+(VGPR accumulators), 128 / 256 = 2 / 64 with the accumulators in AGPRs (csrc/dbg_agpr.hip)"""
 import sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, ".")
