@@ -201,6 +201,62 @@ def panoramaCropper(input, stitchedImage):
     return stitchedImage[oy - 1:oy + ch, ox - 1:ox + cw]
 
 
+PANO_PROJECTIONS = ("planar", "cylindrical", "spherical", "equirectangular", "stereographic")
+
+
+def panorama_file_names(input, panoStore, myImg, datasetName):
+    """The file names cropNsavePanorama.m:136-208 writes, in its order: for every panorama ii (1-based) and every projection
+    field present and non-empty: '<proj>_<transformationType>_<myImg>_<ii>_<dataset>.png'; then, with input.cropPanorama,
+    '<proj>_cropped_...'; then, with showPanoramaImgsNums and showCropBoundingBox, '<proj>_annotated_...'.
+    Returns [(file name, panorama index (0-based), projection, slot)], slot 0 = base, 1 = annotated, 2 = cropped
+    (the cell slots {1}, {2}, {3} of the reference)."""
+    tt = str(input["transformationType"])
+    name = str(datasetName[myImg - 1])
+    out = []
+    for ii, rec in enumerate(panoStore):
+        have = [p for p in PANO_PROJECTIONS if rec.get(p)]
+        for tag, slot, on in (("", 0, True), ("_cropped", 2, int(input.get("cropPanorama", 0)) == 1),
+                              ("_annotated", 1, bool(input.get("showPanoramaImgsNums")) and bool(input.get("showCropBoundingBox")))):
+            if on:
+                out += [(f"{p}{tag}_{tt}_{myImg}_{ii + 1}_{name}.png", ii, p, slot) for p in have]
+    return out
+
+
+def cropNsavePanorama(input, panoStore, myImg, datasetName):
+    """panoStore = cropNsavePanorama(input, panoStore, myImg, datasetName) (cropNsavePanorama.m:1-215): panoStore is a list of
+    dicts, one per panorama, with a projection name -> [base RGB, annotated RGB or None, cropped RGB] (the reference's 1 x M
+    struct array of cells).  With input.cropPanorama every present projection's base panorama goes through panoramaCropper
+    (crop rectangle on the device) into slot 3; with input.imageWrite the PNG files are written to input.imageSaveFolder under
+    the reference's names (host I/O: PIL).  Same argument checks and messages as :51-66.  myImg is 1-based."""
+    import os
+
+    if not (isinstance(myImg, (int, np.integer)) and 1 <= myImg <= len(datasetName)):
+        raise ValueError(f"cropNsavePanorama:InvalidDatasetIndex: myImg ({myImg}) must index into datasetName (numel={len(datasetName)}).")
+    if not isinstance(datasetName[myImg - 1], str):
+        raise ValueError("cropNsavePanorama:InvalidDatasetNameType: datasetName{myImg} must be char or string.")
+    write = bool(input.get("imageWrite"))
+    if write and "transformationType" not in input:
+        raise ValueError("cropNsavePanorama:MissingTransformationType: input.transformationType is required when input.imageWrite is true.")
+    if write and not os.path.isdir(input["imageSaveFolder"]):
+        os.makedirs(input["imageSaveFolder"])
+    if int(input.get("cropPanorama", 0)) == 1:
+        for rec in panoStore:
+            for p in PANO_PROJECTIONS:
+                if rec.get(p):
+                    cell = list(rec[p]) + [None] * (3 - len(rec[p]))
+                    cell[2] = panoramaCropper(input, cell[0])
+                    rec[p] = cell
+    if write:
+        from PIL import Image
+
+        for fname, ii, p, slot in panorama_file_names(input, panoStore, myImg, datasetName):
+            img = panoStore[ii][p][slot]
+            if _capi.is_torch(img):
+                img = img.cpu().numpy()
+            Image.fromarray(np.ascontiguousarray(img)).save(os.path.join(input["imageSaveFolder"], fname))
+    return panoStore
+
+
 # ---- loadImages.m:57-68,103-215: the two per-image steps in front of the resize ----------------------------------------
 def applyOrientation(img, orientation):
     """The EXIF orientation switch of imreadAutoRotate (loadImages.m:194-212) on an H x W [x C] array: numpy, or a torch

@@ -177,3 +177,26 @@ def test_crop_nonzero_bbox_equals_oracle(gpu):
         t = torch.from_numpy(im_).cuda()
         out_t, rect_t, did_t = rp.cropNonzeroBbox(t, color)
         assert tuple(rect_t) == want_rect and did_t == want_did and torch.equal(out_t.cpu(), torch.from_numpy(out))
+
+
+def test_crop_and_save_panorama_writes_the_reference_files(ip, tmp_path):
+    """cropNsavePanorama.m:68-208: slot 3 = panoramaCropper's crop of the base panorama, PNG files under the reference's
+    names in input.imageSaveFolder; the files decode to the arrays that were handed in."""
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    m = np.zeros((90, 140), bool)
+    m[10:80, 15:120] = True
+    m[10:30, 15:40] = False  # a notch: the largest inscribed rectangle is not the bounding box
+    pano = _img(m, rng)
+    inp = {"canvasColor": "black", "blackRange": 0, "whiteRange": 250, "showCropBoundingBox": False, "displayPanoramas": False,
+           "cropPanorama": 1, "imageWrite": True, "imageSaveFolder": str(tmp_path / "out"), "transformationType": "projective",
+           "showPanoramaImgsNums": False}
+    store = ip.cropNsavePanorama(inp, [{"spherical": [pano, None, None]}], 1, ["set"])
+    crop = store[0]["spherical"][2]
+    want = oracle.crop_rect(pano)[0]  # (offsetx, offsety, cropW, cropH), 1-based
+    assert crop.shape == (want[3] + 1, want[2] + 1, 3) and (crop.sum(2) > 0).mean() > 0.9
+    base = np.asarray(Image.open(tmp_path / "out" / "spherical_projective_1_1_set.png"))
+    cut = np.asarray(Image.open(tmp_path / "out" / "spherical_cropped_projective_1_1_set.png"))
+    assert np.array_equal(base, pano) and np.array_equal(cut, crop)
+    assert sorted(p.name for p in (tmp_path / "out").iterdir()) == ["spherical_cropped_projective_1_1_set.png", "spherical_projective_1_1_set.png"]

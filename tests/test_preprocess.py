@@ -74,3 +74,27 @@ def test_orientation_on_the_device(gpu):
     for o in range(1, 9):
         out = ip.applyOrientation(d, o)
         assert out.is_cuda and np.array_equal(out.cpu().numpy(), _matlab(img, o))
+
+
+def test_crop_and_save_panorama_file_names_follow_the_reference():
+    """cropNsavePanorama.m:136-208: '<proj>[_cropped|_annotated]_<transformationType>_<myImg>_<ii>_<dataset>.png', base files
+    first, then the cropped ones (cropPanorama), then the annotated ones (both show flags); argument checks of :51-66."""
+    import pytest
+
+    ip = import_module(apsamd.__name__ + ".imageProcessing")
+    inp = {"transformationType": "projective", "cropPanorama": 1, "showPanoramaImgsNums": True, "showCropBoundingBox": True}
+    store = [{"spherical": [1, 2, 3]}, {"planar": [1, 2, 3], "stereographic": [1, 2, 3], "cylindrical": []}]
+    names = [n for n, _, _, _ in ip.panorama_file_names(inp, store, 2, ["a", "Grand Canyon"])]
+    assert names == ["spherical_projective_2_1_Grand Canyon.png", "spherical_cropped_projective_2_1_Grand Canyon.png",
+                     "spherical_annotated_projective_2_1_Grand Canyon.png", "planar_projective_2_2_Grand Canyon.png",
+                     "stereographic_projective_2_2_Grand Canyon.png", "planar_cropped_projective_2_2_Grand Canyon.png",
+                     "stereographic_cropped_projective_2_2_Grand Canyon.png", "planar_annotated_projective_2_2_Grand Canyon.png",
+                     "stereographic_annotated_projective_2_2_Grand Canyon.png"]
+    inp2 = dict(inp, cropPanorama=0, showCropBoundingBox=False)
+    assert [n for n, _, _, _ in ip.panorama_file_names(inp2, store[:1], 1, ["set"])] == ["spherical_projective_1_1_set.png"]
+    with pytest.raises(ValueError, match="InvalidDatasetIndex"):
+        ip.cropNsavePanorama(inp, store, 3, ["a", "b"])
+    with pytest.raises(ValueError, match="InvalidDatasetNameType"):
+        ip.cropNsavePanorama(inp, store, 1, [5])
+    with pytest.raises(ValueError, match="MissingTransformationType"):
+        ip.cropNsavePanorama({"imageWrite": True, "imageSaveFolder": "/tmp"}, store, 1, ["a"])
