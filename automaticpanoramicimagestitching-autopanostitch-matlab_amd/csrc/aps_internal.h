@@ -229,7 +229,7 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
 // prefix of the three nearest rows of that image and the bound of its unlisted rows.
 int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
                              std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
-                             int64_t* n_survivors);
+                             int64_t* n_survivors, int img_a = 0, int img_b = -1);  // [img_a, img_b): the query images of this call
 
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 

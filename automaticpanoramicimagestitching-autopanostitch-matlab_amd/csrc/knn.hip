@@ -259,8 +259,8 @@ __global__ void knn_merge3_kernel(const int64_t* __restrict__ block_off, int nb,
                                   const uint8_t* __restrict__ dismissed, const uint32_t* __restrict__ t3_idx,
                                   const float* __restrict__ t3_d, const float* __restrict__ t3_b, int64_t f, int k_out,
                                   uint32_t* __restrict__ idx, float* __restrict__ dist, int64_t ldo, int layout,
-                                  uint32_t* __restrict__ unc_list, unsigned int* __restrict__ unc_count) {
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+                                  uint32_t* __restrict__ unc_list, unsigned int* __restrict__ unc_count, int64_t q_lo) {
+    const int64_t q = q_lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // this call's rows: [q_lo, f)
     if (q >= f) return;
     const int kk = k_out < 4 ? k_out : 4;
     if (dismissed[q]) {
@@ -732,10 +732,8 @@ int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, i
         if (f == 0) return;
         const std::vector<int64_t> ioff(img_off, img_off + n_img + 1);
         std::vector<int64_t> job_off;
-        const int64_t slots = screened_global_top3(nullptr, ld, layout, ioff, ratio, job_off, nullptr, nullptr, nullptr, nullptr, nullptr);
-        const bool fits = slots < ((int64_t)1 << 31) - 1;
-        if (!fits || f < 8192 || (std::getenv("APS_KNN_MODE") && !std::strcmp(std::getenv("APS_KNN_MODE"), "f32"))) {
-            // too many (row, image) slots for one pass, a tiny pool, or the exact mode asked for: the plain search
+        if (f < 8192 || (std::getenv("APS_KNN_MODE") && !std::strcmp(std::getenv("APS_KNN_MODE"), "f32"))) {
+            // a tiny pool, or the exact mode asked for: the plain search
             const int rc = aps_knn_global(pool, f, ld, pool, f, ld, dim, layout, k, idx, dist, ldo);
             if (rc != APS_OK) {
                 const std::string why = aps_last_error();
@@ -743,28 +741,56 @@ int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, i
             }
             return;
         }
+        // The (row, image) tables are addressed with 32-bit slots: a pool with more than 2^31 of them (BASELINE configs[4]:
+        // 500 images, 5.4 M rows = 2.7e9 slots) is searched in several passes over ranges of QUERY images - every pass sees
+        // all images as columns, so every row still gets its exact neighbours in the whole pool.  APS_KNN_SLOT_CAP (test
+        // hook) lowers the budget so that small pools take the chunked path too.
+        int64_t slot_cap = ((int64_t)1 << 31) - 2;
+        if (const char* e = std::getenv("APS_KNN_SLOT_CAP")) slot_cap = std::max<int64_t>(1, std::atoll(e));
+        std::vector<int> cuts{0};  // query image ranges [cuts[c], cuts[c + 1])
+        {
+            int64_t run = 0;
+            for (int i = 0; i < n_img; ++i) {
+                const int64_t need = (ioff[i + 1] - ioff[i]) * (int64_t)n_img;
+                APS_REQUIRE(need <= ((int64_t)1 << 31) - 2, APS_E_DIM, "image %d alone needs %lld (row, image) slots", i, (long long)need);
+                if (run > 0 && run + need > slot_cap) {
+                    cuts.push_back(i);
+                    run = 0;
+                }
+                run += need;
+            }
+            cuts.push_back(n_img);
+        }
         const size_t te = layout == APS_ROWMAJOR ? (size_t)(f - 1) * ld + dim : (size_t)(dim - 1) * ld + f;
         const size_t oe = layout == APS_ROWMAJOR ? (size_t)(f - 1) * ldo + k : (size_t)(k - 1) * ldo + f;
         In<float> dT(pool, te);
         Out<uint32_t> oi(idx, oe);
         Out<float> od(dist, oe);
-        Ws<uint32_t> t3i((size_t)slots * 3);
-        Ws<float> t3d((size_t)slots * 3), t3b((size_t)slots);
         Ws<uint8_t> dismissed((size_t)f);
-        int64_t n_surv = 0;
-        screened_global_top3(dT, ld, layout, ioff, ratio, job_off, t3i, t3d, t3b, dismissed, &n_surv);
         Ws<int64_t> d_boff(n_img + 1), d_joff((size_t)n_img * n_img);
         Ws<uint32_t> unc((size_t)f);
         Ws<unsigned int> unc_n(1);
         APS_HIP(hipMemcpyAsync(d_boff, ioff.data(), (n_img + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
-        APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)n_img * n_img * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
         APS_HIP(hipMemsetAsync(unc_n, 0, sizeof(unsigned int), stream()));
-        {
-            Prof prof("knn_merge");
-            knn_merge3_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(d_boff, n_img, d_joff, dismissed, t3i, t3d, t3b, f, k, oi, od, ldo, layout,
-                                                                  unc, unc_n);
+        int64_t n_surv = 0;
+        for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+            const int ia = cuts[c], ib = cuts[c + 1];
+            const int64_t slots = screened_global_top3(nullptr, ld, layout, ioff, ratio, job_off, nullptr, nullptr, nullptr, nullptr, nullptr, ia, ib);
+            if (slots == 0) continue;
+            Ws<uint32_t> t3i((size_t)slots * 3);
+            Ws<float> t3d((size_t)slots * 3), t3b((size_t)slots);
+            int64_t n_surv_c = 0;
+            screened_global_top3(dT, ld, layout, ioff, ratio, job_off, t3i, t3d, t3b, dismissed, &n_surv_c, ia, ib);
+            n_surv += n_surv_c;
+            APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)n_img * n_img * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+            {
+                Prof prof("knn_merge");
+                knn_merge3_kernel<<<cdiv(ioff[ib] - ioff[ia], 256), 256, 0, stream()>>>(d_boff, n_img, d_joff, dismissed, t3i, t3d, t3b, ioff[ib], k, oi,
+                                                                                        od, ldo, layout, unc, unc_n, ioff[ia]);
+            }
+            check_launch("knn_merge3_kernel");
+            APS_HIP(hipStreamSynchronize(stream()));  // job_off is rebuilt by the next pass; the t3 tables go out of scope
         }
-        check_launch("knn_merge3_kernel");
         unsigned int n_unc = 0;
         APS_HIP(hipMemcpyAsync(&n_unc, unc_n, sizeof n_unc, hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));

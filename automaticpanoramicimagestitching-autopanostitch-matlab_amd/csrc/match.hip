@@ -2530,8 +2530,8 @@ __global__ __launch_bounds__(256) void global_screen_reduce_kernel(const float* 
                                                                    int n_img, const int64_t* __restrict__ job_off, int64_t f, float ratio,
                                                                    uint8_t* __restrict__ dismissed, float* __restrict__ cut_out,
                                                                    int* __restrict__ first_imgs /* f x 3 */, uint32_t* __restrict__ row_list,
-                                                                   unsigned int* __restrict__ list_count) {
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+                                                                   unsigned int* __restrict__ list_count, int64_t q_lo) {
+    const int64_t q = q_lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // this call's rows: [q_lo, f)
     const bool live = q < f;
     const int64_t qc = live ? q : f - 1;
     int lo = 0, hi = n_img - 1;
@@ -2618,8 +2618,8 @@ __global__ __launch_bounds__(256) void global_phase_b_kernel(const float* __rest
                                                              uint8_t* __restrict__ dismissed, const float* __restrict__ cut_in,
                                                              const int* __restrict__ first_imgs, const uint32_t* __restrict__ t3_idx,
                                                              const float* __restrict__ t3_d, uint32_t* __restrict__ row_list,
-                                                             unsigned int* __restrict__ list_count) {
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+                                                             unsigned int* __restrict__ list_count, int64_t q_lo) {
+    const int64_t q = q_lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // this call's rows: [q_lo, f)
     const bool live = q < f;
     const int64_t qc = live ? q : f - 1;
     int lo = 0, hi = n_img - 1;
@@ -2724,12 +2724,15 @@ __global__ void global_t3_init_kernel(uint32_t* __restrict__ t3_idx, float* __re
 // Returns the slot count; call with t3_idx == nullptr to get it (and job_off) first.
 int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
                              std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
-                             int64_t* n_survivors) {
+                             int64_t* n_survivors, int img_a, int img_b) {
+    // [img_a, img_b): the QUERY images of this call (every image is a column set); a pool whose (row, image) table exceeds
+    // 2^31 slots - BASELINE configs[4]: 500 images, 5.4 M rows - is searched in several calls over ranges of query images
     const int n = (int)img_off.size() - 1;
-    const int64_t f = img_off[n];
+    if (img_b < 0) img_b = n;
+    const int64_t q_lo = img_off[img_a], f = img_off[img_b];  // this call's rows (f: their end)
     job_off.assign((size_t)n * n, 0);
     int64_t slots = 0;
-    for (int i = 0; i < n; ++i)
+    for (int i = img_a; i < img_b; ++i)
         for (int j = 0; j < n; ++j) {
             job_off[(size_t)i * n + j] = slots;
             slots += img_off[i + 1] - img_off[i];
@@ -2750,7 +2753,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     // ---- the int8 screen over every ordered pair of different images: bounds per (row, image) ----
     std::vector<MatchJob> jobs;
     std::vector<WgJob> bw;
-    for (int i = 0; i < n; ++i)
+    for (int i = img_a; i < img_b; ++i)
         for (int j = 0; j < n; ++j) {
             const int nA = (int)(img_off[i + 1] - img_off[i]), nB = (int)(img_off[j + 1] - img_off[j]);
             if (i == j || nA == 0 || nB == 0) continue;
@@ -2789,8 +2792,8 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     Ws<int> first_imgs((size_t)f * 3);
     {
         Prof prof("global_screen_reduce");
-        global_screen_reduce_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs, row_list,
-                                                                        list_count);
+        global_screen_reduce_kernel<<<cdiv(f - q_lo, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs,
+                                                                               row_list, list_count, q_lo);
         global_t3_init_kernel<<<cdiv(slots, 256), 256, 0, stream()>>>(t3_idx, t3_d, t3_b, slots);
     }
     check_launch("global_screen_reduce_kernel");
@@ -2834,8 +2837,8 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     search(zero, h_a);  // phase A: the own image and the three most promising ones
     {
         Prof prof("global_screen_reduce");
-        global_phase_b_kernel<<<cdiv(f, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs, t3_idx, t3_d,
-                                                                  row_list, list_count);
+        global_phase_b_kernel<<<cdiv(f - q_lo, 256), 256, 0, stream()>>>(bounds, d_ioff, n, d_joff, f, ratio, dismissed, cut, first_imgs, t3_idx,
+                                                                         t3_d, row_list, list_count, q_lo);
     }
     check_launch("global_phase_b_kernel");
     APS_HIP(hipMemcpyAsync(h_b.data(), list_count, (size_t)n * n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
@@ -2848,7 +2851,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     }
     if (std::getenv("APS_TRACE"))
         std::fprintf(stderr, "[aps] pooled matcher screen: %lld of %lld rows survive (%.2f %%); (row, image) searches: %lld first + %lld more of %lld (%.2f %%)\n",
-                     (long long)n_surv, (long long)f, 100.0 * (double)n_surv / (double)std::max<int64_t>(f, 1), (long long)n_a, (long long)n_b,
+                     (long long)n_surv, (long long)(f - q_lo), 100.0 * (double)n_surv / (double)std::max<int64_t>(f - q_lo, 1), (long long)n_a, (long long)n_b,
                      (long long)slots, 100.0 * (double)(n_a + n_b) / (double)slots);
     search(h_a, h_b);  // phase B: every other image that can still hold one of the four nearest
     return slots;

@@ -222,6 +222,15 @@ def test_screened_pooled_matcher_equals_plain_search_and_oracle(gpu, monkeypatch
         exp = want[(want[:, 0] == i + 1) & (want[:, 1] == j + 1)][:, 2:]
         got = np.stack([oi[pp[p]:pp[p + 1]], oj[pp[p]:pp[p + 1]]], axis=1)
         assert np.array_equal(got.astype(np.int64), exp.astype(np.int64)), (i, j)
+    # a pool whose (row, image) table exceeds 2^31 slots (BASELINE configs[4]) is searched in passes over ranges of query
+    # images; APS_KNN_SLOT_CAP lowers the budget so that this pool takes that path too: three passes, two, one image per pass
+    for cap in (7 * 12000, 7 * 6000, 1):
+        monkeypatch.setenv("APS_KNN_SLOT_CAP", str(cap))
+        ppc, oic, ojc = fm.match_global_csr(descs, 0.6, 4)
+        gpu._capi.check(gpu.lib.aps_knn_global_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+        monkeypatch.delenv("APS_KNN_SLOT_CAP")
+        assert np.array_equal(pp, ppc) and np.array_equal(oi, oic) and np.array_equal(oj, ojc), cap
+        assert rows.value == sum(len(d) for d in descs) and 0 < surv.value < 0.7 * rows.value
     # other ratios: a tight one (few queries pass) and one above 1 (nothing may be dismissed wrongly)
     for ratio in (0.3, 0.95):
         a = fm.match_global_csr(descs, ratio, 4)
