@@ -149,13 +149,12 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
 // whole row was 34 KB until round 4): the kernel is one wave walking ~4000 dependent instructions, so its throughput is
 // the number of workgroups a CU holds, and LDS was what limited that to four (one wave per SIMD).
 constexpr int kPrepPitch = kDim / 2 + 4;  // floats; 68 = 4 (mod 64): ds_read/write_b128 of 16 consecutive lanes hit 16 slots
-__global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
-                                 int normalize, float* __restrict__ P, float* __restrict__ sq,
+__device__ __forceinline__ void prep_desc_rows(int64_t blk, float* __restrict__ s_t, const float* __restrict__ X, int64_t n, int64_t ld,
+                                 int layout, int normalize, float* __restrict__ P, float* __restrict__ sq,
                                  unsigned short* __restrict__ Hf, float* __restrict__ dn,
                                  float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
-    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
     const int lane = threadIdx.x;
-    const int64_t r0 = blockIdx.x * (int64_t)64, i = r0 + lane;
+    const int64_t r0 = blk * (int64_t)64, i = r0 + lane;
     const bool valid = i < n;
     const int64_t ic = valid ? i : n - 1;  // (lanes past the end work on the last row and store nothing)
     float x[kDim];
@@ -284,6 +283,45 @@ __global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
+                                 int normalize, float* __restrict__ P, float* __restrict__ sq,
+                                 unsigned short* __restrict__ Hf, float* __restrict__ dn,
+                                 float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
+    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
+    prep_desc_rows(blockIdx.x, s_t, X, n, ld, layout, normalize, P, sq, Hf, dn, maxsq, maxdn, qstat);
+}
+
+// Every set of a pair batch in ONE launch (round 4): block b belongs to job j with blk_ptr[j] <= b < blk_ptr[j + 1].
+// (Round 2 measured a batched launch at 7.3 ms against 2.1 for eight streams of per-set launches - with the whole-row tile,
+// four workgroups per CU.  With the half-row tile eight fit, and the per-set chains of ~128 small launches on streams that
+// share hardware queues had become the cost: 2.0 ms for 64 sets, 0.85 ms for the 25 sets of one rank of eight.)
+struct PrepJob {
+    const float* X;
+    int64_t n, ld, n_pad;
+    int layout, normalize;
+    float *P, *sq, *dn, *stat;  // stat: the set's eight statistics words ([0] max ||x||^2, [1] max dn, [2..3] aug residuals, [4..7] int8)
+    unsigned short* Hf;
+    signed char *QA, *QB;
+    float *dnq, *invs;
+    int* sumq;
+    uint4* aug;
+};
+__device__ __forceinline__ int prep_find_job(const int* __restrict__ blk_ptr, int n_jobs, int b) {
+    int lo = 0, hi = n_jobs - 1;  // largest j with blk_ptr[j] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk_ptr[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(64) void prep_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
+    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
+    const int j = prep_find_job(blk_ptr, n_jobs, (int)blockIdx.x);
+    const PrepJob J = jobs[j];
+    prep_desc_rows((int64_t)blockIdx.x - blk_ptr[j], s_t, J.X, J.n, J.ld, J.layout, J.normalize, J.P, J.sq, J.Hf, J.dn, J.stat, J.stat + 1,
+                   J.stat + 4);
+}
+
 // Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
 // [e-11i-11, e-11i) and is stored as p_i = r_i / c_i with c_i = 2^clamp(e-11i, -14, 15), so that c_i is a normal f16
 // and p_i is one whenever the set's norms are not wildly apart (a piece that would be subnormal is dropped: it shows
@@ -367,14 +405,13 @@ __device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
 
 // (The launch also carries aug_desc_row - same dependency on the finished prep_desc_kernel, one launch fewer per set: the
 // preparation of a pair batch is bound by its launch count.  Lane part 0 of row i, i < n_pad, writes that row's operand.)
-__global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
+__device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
                                                       signed char* __restrict__ QB, float* __restrict__ dnqa,
                                                       float* __restrict__ invsa, int* __restrict__ sumqa,
                                                       float* __restrict__ qstat, const float* __restrict__ row_sq,
                                                       const float* __restrict__ row_dn, int64_t n_pad,
                                                       const float* __restrict__ maxsq, uint4* __restrict__ aug,
                                                       float* __restrict__ aug_res) {
-    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t i = g >> 3;
     const int part = (int)(g & 7);
     if (part == 0) aug_desc_row(i, row_sq, row_dn, n, n_pad, maxsq, aug, aug_res);
@@ -442,6 +479,23 @@ __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ 
         if (__float_as_uint(db) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
             atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(db));
     }
+}
+
+__global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
+                                                      signed char* __restrict__ QB, float* __restrict__ dnqa,
+                                                      float* __restrict__ invsa, int* __restrict__ sumqa,
+                                                      float* __restrict__ qstat, const float* __restrict__ row_sq,
+                                                      const float* __restrict__ row_dn, int64_t n_pad,
+                                                      const float* __restrict__ maxsq, uint4* __restrict__ aug,
+                                                      float* __restrict__ aug_res) {
+    q8_desc_rows(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, P, n, QA, QB, dnqa, invsa, sumqa, qstat, row_sq, row_dn, n_pad, maxsq, aug,
+                 aug_res);
+}
+__global__ __launch_bounds__(256) void q8_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
+    const int j = prep_find_job(blk_ptr, n_jobs, (int)blockIdx.x);
+    const PrepJob J = jobs[j];
+    q8_desc_rows(((int64_t)blockIdx.x - blk_ptr[j]) * (int64_t)blockDim.x + threadIdx.x, J.P, J.n, J.QA, J.QB, J.dnq, J.invs, J.sumq, J.stat + 4,
+                 J.sq, J.dn, J.n_pad, J.stat, J.aug, J.stat + 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2107,30 +2161,15 @@ struct Prepared {
 
 // `st`: the stream the set's launches go to (the caller's own stream, or one of its auxiliary streams when many sets are
 // prepared side by side - each set is a chain of small launches that leaves most of the chip idle)
+// the buffers of a set (and, when the set owns its statistics words, their zero fill on `st`)
+static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext);
+
 static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
                     Prepared& out, hipStream_t st = nullptr, bool bracket = true, float* stat_ext = nullptr) {
     if (!st) st = stream();
-    out.n = n;
-    const size_t rows = (size_t)std::max<int64_t>(n, 1);
-    out.P.alloc(rows * kDim);
-    out.sq.alloc(rows);
-    out.H.alloc(rows * kDim);
-    out.dn.alloc(rows);
-    if (stat_ext) {  // zeroed by the caller
-        out.stat = stat_ext;
-    } else {
-        out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
-        APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), st));
-        out.stat = out.maxsq;
-    }
+    prepare_alloc(n, out, st, stat_ext);
     float* const qstat = out.stat + 4;
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
-    out.aug.alloc((size_t)n_pad);
-    out.QA.alloc(rows * kDim);
-    out.QB.alloc(rows * kDim);
-    out.dnq.alloc(rows);
-    out.invs.alloc(rows);
-    out.sumq.alloc(rows);
     if (std::getenv("APS_Q8_SYMMETRIC")) {  // A/B switch: column code without the offset
         const int sym = 1;
         APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, st));
@@ -2147,6 +2186,69 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     q8_desc_kernel<<<cdiv(n_pad * 8, 256), 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn,
                                                          n_pad, out.stat, out.aug, out.stat + 2);
     check_launch("prep_desc_kernel");
+}
+
+// Several sets in two launches on the caller's stream (prep_desc_batch_kernel, q8_desc_batch_kernel).  stat_ext[s]: the
+// set's eight zeroed statistics words (the caller's block).
+struct PrepRequest {
+    const float* X;
+    int64_t n, ld;
+    bool normalize;
+    Prepared* out;
+    float* stat_ext;
+};
+static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
+    std::vector<PrepJob> jobs;
+    std::vector<int> bp{0}, bq{0};
+    for (const PrepRequest& r : req) {
+        prepare_alloc(r.n, *r.out, stream(), r.stat_ext);
+        if (r.n == 0) continue;
+        const Prepared& o = *r.out;
+        const int64_t n_pad = (std::max<int64_t>(r.n, 1) + kTNB - 1) / kTNB * kTNB;
+        jobs.push_back(PrepJob{r.X, r.n, r.ld, n_pad, layout, r.normalize ? 1 : 0, o.P, o.sq, o.dn, o.stat, o.H, o.QA, o.QB, o.dnq, o.invs, o.sumq, o.aug});
+        bp.push_back(bp.back() + (int)cdiv(r.n, 64));
+        bq.push_back(bq.back() + (int)cdiv(n_pad * 8, 256));
+    }
+    if (std::getenv("APS_Q8_SYMMETRIC")) {
+        const int sym = 1;
+        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, stream()));
+    }
+    if (jobs.empty()) return;
+    Ws<PrepJob> dj(jobs.size());
+    Ws<int> dbp(bp.size()), dbq(bq.size());
+    APS_HIP(hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(dbp, bp.data(), bp.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(dbq, bq.data(), bq.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    {
+        Prof prof("match_prep");
+        prep_desc_batch_kernel<<<(unsigned)bp.back(), 64, 0, stream()>>>(dj, dbp, (int)jobs.size());
+        q8_desc_batch_kernel<<<(unsigned)bq.back(), 256, 0, stream()>>>(dj, dbq, (int)jobs.size());
+    }
+    check_launch("prep_desc_batch_kernel");
+    APS_HIP(hipStreamSynchronize(stream()));  // the host tables (and dj / dbp / dbq) must outlive the launches
+}
+
+static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext) {
+    out.n = n;
+    const size_t rows = (size_t)std::max<int64_t>(n, 1);
+    out.P.alloc(rows * kDim);
+    out.sq.alloc(rows);
+    out.H.alloc(rows * kDim);
+    out.dn.alloc(rows);
+    if (stat_ext) {  // zeroed by the caller
+        out.stat = stat_ext;
+    } else {
+        out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
+        APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), st));
+        out.stat = out.maxsq;
+    }
+    const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
+    out.aug.alloc((size_t)n_pad);
+    out.QA.alloc(rows * kDim);
+    out.QB.alloc(rows * kDim);
+    out.dnq.alloc(rows);
+    out.invs.alloc(rows);
+    out.sumq.alloc(rows);
 }
 
 static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, int64_t out_off) {
@@ -3075,15 +3177,24 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
        // faster than eight streams of 310; the lever would be the workgroup's own latency, not the launch count.)
         constexpr int kPrepStreams = 8;
         APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)16 * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
-        AuxScope fork(kPrepStreams);
-        std::vector<hipStream_t>& aux = fork.streams;
-        Prof prof("match_prep");
-        int k = 0;
-        for (int i = 0; i < n_img; ++i) {
-            if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i);
-            if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i + 8);
+        if (!std::getenv("APS_MATCH_PREP_STREAMS")) {  // round 4: every set in two launches (see prep_desc_batch_kernel)
+            std::vector<PrepRequest> req;
+            for (int i = 0; i < n_img; ++i) {
+                if (need_raw[i]) req.push_back({din[i], counts[i], ld[i], false, &raw[i], prep_stats.get() + 16 * i});
+                if (need_nrm[i]) req.push_back({din[i], counts[i], ld[i], true, &nrm[i], prep_stats.get() + 16 * i + 8});
+            }
+            prepare_batch(req, layout);
+        } else {
+            AuxScope fork(kPrepStreams);
+            std::vector<hipStream_t>& aux = fork.streams;
+            Prof prof("match_prep");
+            int k = 0;
+            for (int i = 0; i < n_img; ++i) {
+                if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i);
+                if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i + 8);
+            }
+            fork.join();
         }
-        fork.join();
     }
     const auto T1 = t_now();
     std::vector<MatchJob> jobs;
