@@ -321,9 +321,16 @@ def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True
     return pair_ptr, i_a[:k], i_b[:k], met[:k]
 
 
+_PAIR_ORDER = {}
+
+
 def pair_order(numImg):
-    """The reference's pair order: nonzeros(triu(reshape(1:n^2,n,n),1)) (featureMatchingPairwise.m:48)."""
-    return [(i, j) for j in range(1, numImg) for i in range(j)]
+    """The reference's pair order: nonzeros(triu(reshape(1:n^2,n,n),1)) (featureMatchingPairwise.m:48).  (Cached per image
+    count: a step asks for it several times; callers do not modify the list.)"""
+    numImg = int(numImg)
+    if numImg not in _PAIR_ORDER:
+        _PAIR_ORDER[numImg] = [(i, j) for j in range(1, numImg) for i in range(j)]
+    return _PAIR_ORDER[numImg]
 
 
 def featureMatchingPairwise(input, allDescriptors, numImg):

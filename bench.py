@@ -494,6 +494,18 @@ def main():
                 traffic_stale = (f"{traffic_file} was taken from other kernel sources (csrc hash {str(meta.get('csrc_sha256'))[:12]} "
                                  f"!= {csrc_sha256()[:12]} now): traffic not reported; re-run scripts/hbm_traffic.sh")
 
+        # vector instructions per kernel from the same kind of committed pass (scripts/hbm_traffic.sh, second pass), same guard
+        valu_db = {}
+        vfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")))
+        if traffic_file is not None and vfiles:
+            vdb = json.load(open(vfiles[-1]))
+            if vdb.pop("_meta", {}).get("csrc_sha256") == csrc_sha256():
+                valu_db = vdb
+
+        def valu_of(prefixes):
+            rows = [v for k, v in valu_db.items() if any(p in k for p in prefixes)]
+            return sum(r["insts_valu_per_step"] for r in rows) if rows else None
+
         def traffic_of(prefixes, per_step=False):
             rows = [v for k, v in traffic_db.items() if any(p in k for p in prefixes)]
             launches = sum(r["launches_per_step"] for r in rows)
@@ -535,6 +547,13 @@ def main():
                     r["achieved_measured_bytes"] = round(per_step * args.steps / (ms * 1e-3) / 1e9, 2)
             elif traffic_stale:
                 r["traffic_note"] = traffic_stale
+            if bound == "hbm" and streams == 1:  # (event sums of concurrent streams overlap: no rate from those)
+                iv = valu_of(TRAFFIC_KEYS.get(kernel, ["\0"]))
+                if iv:  # the fraction of the chip's vector issue rate the chain's instructions take: 4 cycles per wave
+                    # instruction on one of 1024 SIMDs at 2.4 GHz, over the chain's time
+                    r["valu_frac"] = round(iv * 4.0 / 1024.0 / 2.4e9 / (ms / args.steps * 1e-3), 4)
+                    r["valu_note"] = ("SQ_INSTS_VALU of a separate --pmc pass x 4 cycles / 1024 SIMDs / 2.4 GHz over the kernel time: "
+                                      "where this exceeds `frac`, vector issue and not HBM is what the chain is bound by")
             if note:
                 r["note"] = note
             return r

@@ -35,3 +35,30 @@ open(f"gpurun_out/{tag}_hbm_traffic.txt", "w").write("\n".join(out) + "\n")
 json.dump(js, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=0)
 print("\n".join(out[:14]))
 PY
+
+# Second pass (its own --pmc run): vector instructions per kernel, for the entries of the bench line that are bound by vector
+# issue rather than by bytes (bench.py: valu_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz / kernel time).
+rm -rf /tmp/pv
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d /tmp/pv -o p -- \
+    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --steps 1 --warmup 0 > /tmp/pv.json 2> /tmp/pv.err
+python3 - "$TAG" <<'PY'
+import csv, collections, json, sys
+sys.path.insert(0, ".")
+import bench
+tag = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+for r in csv.DictReader(open("/tmp/pv/p_counter_collection.csv")):
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
+js = {"_meta": {"csrc_sha256": bench.csrc_sha256(), "how": "scripts/hbm_traffic.sh, second pass: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES, one bench step"}}
+rows = sorted(acc.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"])
+out = ["%-72s %8s %14s %14s %12s" % ("kernel", "launches", "INSTS_VALU", "INSTS_SALU", "VALU/wave")]
+for k, v in rows:
+    js[k] = {"launches_per_step": n[k], "insts_valu_per_step": v["SQ_INSTS_VALU"], "insts_salu_per_step": v["SQ_INSTS_SALU"], "waves_per_step": v["SQ_WAVES"]}
+    if v["SQ_INSTS_VALU"] > 1e7:
+        out.append("%-72s %8d %14.4g %14.4g %12.1f" % (k[:72], n[k], v["SQ_INSTS_VALU"], v["SQ_INSTS_SALU"], v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)))
+open(f"gpurun_out/{tag}_pmc_valu.txt", "w").write("\n".join(out) + "\n")
+json.dump(js, open(f"gpurun_out/{tag}_pmc_valu.json", "w"), indent=0)
+print("\n".join(out[:12]))
+PY

@@ -3,7 +3,7 @@ import cProfile
 import pstats
 import sys
 
-sys.argv = ["bench.py", "--steps", "4", "--warmup", "1", "--cpu-baseline", "off"]
+sys.argv = ["bench.py", "--steps", "6", "--warmup", "2", "--cpu-baseline", "off", "--end-to-end", "off", "--global-probe", "off"]
 sys.path.insert(0, ".")
 import bench  # noqa: E402
 
