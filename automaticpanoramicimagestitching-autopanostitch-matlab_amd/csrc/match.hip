@@ -1089,7 +1089,12 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
                                                                 float prune_r2, float prune_thr,
                                                                 uint32_t* __restrict__ t3_idx, float* __restrict__ t3_d,
                                                                 float* __restrict__ t3_b,
-                                                                const uint32_t* __restrict__ row_list) {
+                                                                const uint32_t* __restrict__ row_list,
+                                                                const int* __restrict__ row_job) {
+    // row_job != nullptr (LIST only, round 4): a POOLED list - the tile's rows are row_list[w.row0 ...] of the jobs
+    // row_job[w.row0 ...], all of which share w.job's B set (the survivor lists of the jobs that share a B set, packed into
+    // common 512-row tiles: a pair of the 64 x 4K scene leaves ~600 survivors in a non-overlapping pair - one full tile and
+    // one that is 83 % padding; pooled, 1806 such lists fill their tiles).  Everything on the A side is then per row.
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kTileBytes];  // [buf][128][256 B], tile t in buf t % 3
     // b2/2 of each B row as three f16 pieces (p0 c0 + p1 c1 + p2 c2 == the f32 value, c_i powers of two chosen per
     // B set) + five zeros: one extra 16-wide k-step against the constant [-c0 -c1 -c2 0 ...] puts -b2/2 into the
@@ -1116,14 +1121,21 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     const int nA = jb.nA, nB = jb.nB;
     // this lane owns tile rows wave * 64 + c and + 32.  LIST = false: the tile is the 512 consecutive A rows from w.row0;
     // LIST = true: it is the w.list_cnt rows row_list[jb.out_off + w.row0 ...] of this job (the survivors of the int8 screen)
-    int rowid[2];
+    int rowid[2], rjob[2];
     bool rvalid[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int local = wave * 64 + c + 32 * rb;
+        rjob[rb] = w.job;
         if (LIST) {
             rvalid[rb] = local < w.list_cnt;
-            rowid[rb] = (int)row_list[jb.out_off + w.row0 + (rvalid[rb] ? local : 0)];
+            if (row_job) {
+                const int e = w.row0 + (rvalid[rb] ? local : 0);
+                rowid[rb] = (int)row_list[e];
+                rjob[rb] = row_job[e];
+            } else {
+                rowid[rb] = (int)row_list[jb.out_off + w.row0 + (rvalid[rb] ? local : 0)];
+            }
         } else {
             rvalid[rb] = w.row0 + local < nA;
             rowid[rb] = min(w.row0 + local, nA - 1);
@@ -1134,9 +1146,10 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int arow = rowid[rb];
+        const unsigned short* af = (LIST && row_job) ? jobs[rjob[rb]].AF : jb.AF;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
-            ah[rb][s] = *reinterpret_cast<const f16x8*>(jb.AF + (size_t)arow * kDim + 16 * s + 8 * h);
+            ah[rb][s] = *reinterpret_cast<const f16x8*>(af + (size_t)arow * kDim + 16 * s + 8 * h);
     }
     float u0[2], u1[2], u2[2], u3[2];  // a.b - b2/2, descending, per owned row
     int i0[2], i1[2], i2[2];
@@ -1295,8 +1308,11 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
     f16x8 aug_a2 = aug_a;
     if (h == 0) {
         float unused;
-        const unsigned short n0 = f16_round_up(sqrtf(jb.sqA[rowid[0]]) * 1.000001f, unused);
-        const unsigned short n1 = f16_round_up(sqrtf(jb.sqA[rowid[1]]) * 1.000001f, unused);
+        // (pooled list: the norms come from each row's own job - jb is only some job of the B group)
+        const float* sq0 = (LIST && row_job) ? jobs[rjob[0]].sqA : jb.sqA;
+        const float* sq1 = (LIST && row_job) ? jobs[rjob[1]].sqA : jb.sqA;
+        const unsigned short n0 = f16_round_up(sqrtf(sq0[rowid[0]]) * 1.000001f, unused);
+        const unsigned short n1 = f16_round_up(sqrtf(sq1[rowid[1]]) * 1.000001f, unused);
         aug_a[3] = __builtin_bit_cast(_Float16, n0);
         aug_a2[3] = __builtin_bit_cast(_Float16, n1);
     }
@@ -1431,6 +1447,9 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
         const int c0 = h ? s0 : i0[0], c1 = h ? s1 : i1[0], c2 = h ? s2 : i2[0];
         const float ub = h ? sb : u3[0], ub2 = h ? sb2 : u2[0], ub1 = h ? sb1 : u1[0], ub0 = h ? sb0 : u0[0];
         const int row = h ? rowid[1] : rowid[0];
+        const int myjob = h ? rjob[1] : rjob[0];
+        // (pooled list: the row's own job - same B set, its own A side and output slots)
+        const MatchJob& jr = (LIST && row_job) ? jobs[myjob] : jb;
         if ((h ? rvalid[1] : rvalid[0]) && !(ablate & 32)) {  // (bit 32: timing experiment without the rescoring tail)
             // Rows that cannot pass the caller's ratio / threshold filter (matchFeaturesScratch.m:170-178) are dismissed
             // on the screened values alone: d1 >= L1 and d2 <= H2 hold for the exact f32 distances (see prune_bounds), so
@@ -1439,22 +1458,22 @@ __global__ __launch_bounds__(512) void match_cand_f16_kernel(const MatchJob* __r
             bool pruned = false;
             if (prune_r2 > 0.f && nB >= 2 && c0 >= 0 && c0 < nB && c1 >= 0 && c1 < nB) {
                 float L1, H2;
-                prune_bounds(jb, row, ub0, ub1, jb.augresB[0], jb.augresB[1], L1, H2);
+                prune_bounds(jr, row, ub0, ub1, jb.augresB[0], jb.augresB[1], L1, H2);
                 const float lo = L1 * (1.0f - 1e-5f) - 1e-30f;
                 pruned = H2 >= 0.f && (lo > prune_r2 * H2 * (1.0f + 1e-5f) || lo > prune_thr * (1.0f + 1e-5f));
             }
             if (t3_idx) {  // top-3 mode (blocked global k-NN): three exact distances + the set's bound per row
-                const float bnd = jb.sqA[row] - 2.0f * ub;
-                rescore_row3(jb, w.job, row, c0, c1, c2, bnd, jb.augresB[0], jb.augresB[1], t3_idx, t3_d, t3_b, fb_list, fb_count);
+                const float bnd = jr.sqA[row] - 2.0f * ub;
+                rescore_row3(jr, myjob, row, c0, c1, c2, bnd, jb.augresB[0], jb.augresB[1], t3_idx, t3_d, t3_b, fb_list, fb_count);
             } else if (pruned) {
-                const int64_t slot = jb.out_off + row;
+                const int64_t slot = jr.out_off + row;
                 out_idx[slot] = 0u;  // "no match": the filter drops idx 0 (a row the reference's filter would drop too)
                 out_d1[slot] = INFINITY;
                 out_d2[slot] = INFINITY;
             } else {
-                const float bnd = jb.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
-                const float bnd3 = jb.sqA[row] - 2.0f * ub2;  // ... and the 3rd
-                rescore_row(jb, w.job, row, c0, c1, c2, bnd3, bnd, jb.augresB[0], jb.augresB[1], out_idx, out_d1, out_d2, fb_list,
+                const float bnd = jr.sqA[row] - 2.0f * ub;    // approximate 4th-smallest distance (inf if < 4 columns)
+                const float bnd3 = jr.sqA[row] - 2.0f * ub2;  // ... and the 3rd
+                rescore_row(jr, myjob, row, c0, c1, c2, bnd3, bnd, jb.augresB[0], jb.augresB[1], out_idx, out_d1, out_d2, fb_list,
                             fb_count);
             }
         }
@@ -2331,6 +2350,82 @@ __global__ void fb_compact_kernel(const MatchJob* __restrict__ jobs, const uint3
     for (unsigned int e = threadIdx.x; e < cnt; e += blockDim.x) out[e] = src[e];
 }
 
+// entries [from[j], to[j]) of job j's list segment (at seg_off[j]) -> the pooled list at dst[j] ..., with their job ids
+// (from == nullptr: from 0)
+__global__ void list_pool_kernel(const int64_t* __restrict__ seg_off, const uint32_t* __restrict__ list, const unsigned int* __restrict__ from,
+                                 const unsigned int* __restrict__ to, const long long* __restrict__ dst, uint32_t* __restrict__ pool,
+                                 int* __restrict__ pool_job) {
+    const int j = blockIdx.x;
+    const unsigned int f0 = from ? from[j] : 0u, cnt = to[j] - f0;
+    const uint32_t* src = list + seg_off[j] + f0;
+    for (unsigned int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        pool[dst[j] + e] = src[e];
+        pool_job[dst[j] + e] = j;
+    }
+}
+
+// Pools the list segments of jobs that share a B set (same operand pointer and column count) into common tiles of kTMB
+// rows: returns the tiles (WgJob{a job of the group, start in the pooled list, rows}); pool / pool_job are filled on the
+// stream.  from / to: host copies of the per-job entry ranges (from may be empty = zeros); d_from / d_to: device copies.
+static std::vector<WgJob> pool_lists(const std::vector<MatchJob>& jobs, const MatchJob* djobs_unused, const std::vector<int64_t>& seg_off,
+                                     const uint32_t* d_list, const std::vector<unsigned int>& from, const std::vector<unsigned int>& to,
+                                     const unsigned int* d_from, const unsigned int* d_to, Ws<uint32_t>& pool, Ws<int>& pool_job) {
+    (void)djobs_unused;
+    const size_t nj = jobs.size();
+    std::vector<int> order(nj);
+    for (size_t j = 0; j < nj; ++j) order[j] = (int)j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return std::less<const void*>()(jobs[a].BF, jobs[b].BF) || (jobs[a].BF == jobs[b].BF && jobs[a].nB < jobs[b].nB);
+    });
+    std::vector<long long> h_dst(nj, 0);
+    std::vector<WgJob> tiles;
+    size_t total = 0;
+    for (size_t a = 0; a < nj;) {
+        size_t b = a;
+        const size_t g0 = total;
+        while (b < nj && jobs[order[b]].BF == jobs[order[a]].BF && jobs[order[b]].nB == jobs[order[a]].nB) {
+            const int j = order[b];
+            h_dst[j] = (long long)total;
+            total += to[j] - (from.empty() ? 0u : from[j]);
+            ++b;
+        }
+        if (jobs[order[a]].nB > 0)
+            for (size_t r = g0; r < total; r += kTMB) tiles.push_back({order[a], (int)r, (int)std::min<size_t>(kTMB, total - r), 0, 0, 0});
+        a = b;
+    }
+    if (total == 0) return tiles;
+    APS_REQUIRE(total < ((size_t)1 << 31), APS_E_DIM, "pooled row list too long (%zu)", total);
+    pool.alloc(total);
+    pool_job.alloc(total);
+    Ws<long long> d_dst(nj);
+    Ws<int64_t> d_seg(nj);
+    APS_HIP(hipMemcpyAsync(d_dst, h_dst.data(), nj * sizeof(long long), hipMemcpyHostToDevice, stream()));
+    APS_HIP(hipMemcpyAsync(d_seg, seg_off.data(), nj * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
+    list_pool_kernel<<<(unsigned)nj, 128, 0, stream()>>>(d_seg, d_list, d_from, d_to, d_dst, pool, pool_job);
+    check_launch("list_pool_kernel");
+    APS_HIP(hipStreamSynchronize(stream()));  // h_dst / seg_off and their device copies go out of scope
+    if (std::getenv("APS_POOL_DEBUG")) {  // consistency of the pooled list with the host's view of it
+        std::vector<int> hj(total);
+        std::vector<uint32_t> hr(total);
+        std::vector<unsigned int> dto(nj);
+        APS_HIP(hipMemcpy(hj.data(), pool_job, total * sizeof(int), hipMemcpyDeviceToHost));
+        APS_HIP(hipMemcpy(hr.data(), pool, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        APS_HIP(hipMemcpy(dto.data(), d_to, nj * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < nj; ++j)
+            if (dto[j] != to[j]) std::fprintf(stderr, "[aps pool] job %zu: device count %u, host count %u\n", j, dto[j], to[j]);
+        size_t bad = 0;
+        for (const WgJob& t : tiles)
+            for (int e = 0; e < t.list_cnt; ++e) {
+                const int j = hj[t.row0 + e];
+                if (j < 0 || j >= (int)nj || jobs[j].BF != jobs[t.job].BF || hr[t.row0 + e] >= (uint32_t)jobs[j].nA) {
+                    if (bad++ < 5) std::fprintf(stderr, "[aps pool] tile at %d entry %d: job %d row %u (tile job %d)\n", t.row0, e, j, hr[t.row0 + e], t.job);
+                }
+            }
+        std::fprintf(stderr, "[aps pool] %zu entries in %zu tiles, %zu bad\n", total, tiles.size(), bad);
+    }
+    return tiles;
+}
+
 static thread_local int64_t g_screen_rows = 0, g_screen_surv = 0;  // aps_match_screen_stats
 
 // A/B switch: APS_SCREEN_SHAPE=32 runs the screening pass on v_mfma_i32_32x32x32_i8 (rounds 2-3) instead of 16x16x64
@@ -2401,11 +2496,21 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         std::vector<unsigned int> h_surv(jobs.size());
         APS_HIP(hipMemcpyAsync(h_surv.data(), surv_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));
+        // the survivors of the jobs that share a B set are pooled into common 512-row tiles (APS_MATCH_NO_POOL=1: one list per
+        // job, as in rounds 2-3 - 6599 tiles instead of ~5600 for the 64 x 4K scene)
+        const bool pooled = !std::getenv("APS_MATCH_NO_POOL");
         std::vector<WgJob> lw;
         size_t n_surv = 0;
-        for (int j = 0; j < (int)jobs.size(); ++j) {
-            n_surv += h_surv[j];
-            for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
+        Ws<uint32_t> pool;
+        Ws<int> pool_job;
+        for (int j = 0; j < (int)jobs.size(); ++j) n_surv += h_surv[j];
+        if (pooled) {
+            std::vector<int64_t> seg(jobs.size());
+            for (size_t j = 0; j < jobs.size(); ++j) seg[j] = jobs[j].out_off;
+            lw = pool_lists(jobs, djobs, seg, surv_list, {}, h_surv, nullptr, surv_count, pool, pool_job);
+        } else {
+            for (int j = 0; j < (int)jobs.size(); ++j)
+                for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
         }
         g_screen_rows = total_rows;
         g_screen_surv = (int64_t)n_surv;
@@ -2426,7 +2531,8 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                 Prof prof("match_cand_f16");
                 match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(djobs, dlw, (int)lw.size(), idx, d1, d2, fb_list, fb_count,
                                                                                         ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr,
-                                                                                        surv_list);
+                                                                                        pooled ? pool.get() : surv_list.get(),
+                                                                                        pooled ? pool_job.get() : nullptr);
             }
             check_launch("match_cand_f16_kernel<list>");
             APS_HIP(hipStreamSynchronize(stream()));  // lw must outlive its copy
@@ -2434,7 +2540,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     } else {
         Prof prof("match_cand_f16");
         match_cand_f16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, fb_list, fb_count,
-                                                                                 ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr, nullptr);
+                                                                                 ablate, prune_r2, prune_thr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
@@ -2570,7 +2676,7 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
     {
         Prof prof("match_cand_f16");
         match_cand_f16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr, fb_list,
-                                                                                 fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, nullptr);
+                                                                                 fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, nullptr, nullptr);
     }
     check_launch("match_cand_f16_kernel");
     std::vector<unsigned int> h_cnt(jobs.size());
@@ -2916,21 +3022,32 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     Ws<uint32_t> fb_list(1);
     Ws<unsigned int> fb_count(cj.size());
     APS_HIP(hipMemcpyAsync(dcj, cj.data(), cj.size() * sizeof(MatchJob), hipMemcpyHostToDevice, stream()));
+    const bool pooled = !std::getenv("APS_MATCH_NO_POOL");
+    Ws<unsigned int> d_from((size_t)n * n);
     auto search = [&](const std::vector<unsigned int>& from, const std::vector<unsigned int>& to) {  // list entries [from, to) of every job
         std::vector<WgJob> lw;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                if (img_off[i + 1] == img_off[i] || img_off[j + 1] == img_off[j]) continue;
-                const size_t job = (size_t)i * n + j;
-                for (unsigned int r = from[job]; r < to[job]; r += kTMB) lw.push_back({(int)job, (int)r, (int)std::min<unsigned int>(kTMB, to[job] - r)});
-            }
+        Ws<uint32_t> pool;
+        Ws<int> pool_job;
+        if (pooled) {  // the lists of the jobs (i, j) that share the column image j in common tiles (list_count holds `to`)
+            APS_HIP(hipMemcpyAsync(d_from, from.data(), (size_t)n * n * sizeof(unsigned int), hipMemcpyHostToDevice, stream()));
+            lw = pool_lists(cj, dcj, job_off, row_list, from, to, d_from, list_count, pool, pool_job);
+        } else {
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    if (img_off[i + 1] == img_off[i] || img_off[j + 1] == img_off[j]) continue;
+                    const size_t job = (size_t)i * n + j;
+                    for (unsigned int r = from[job]; r < to[job]; r += kTMB) lw.push_back({(int)job, (int)r, (int)std::min<unsigned int>(kTMB, to[job] - r)});
+                }
+        }
         if (lw.empty()) return;
         Ws<WgJob> dlw(lw.size());
         APS_HIP(hipMemcpyAsync(dlw, lw.data(), lw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
         {
             Prof prof("match_cand_f16");
             match_cand_f16_kernel<true><<<(unsigned)lw.size(), 512, 0, stream()>>>(dcj, dlw, (int)lw.size(), nullptr, nullptr, nullptr, fb_list,
-                                                                                    fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b, row_list);
+                                                                                    fb_count, 0, 0.f, 0.f, t3_idx, t3_d, t3_b,
+                                                                                    pooled ? pool.get() : row_list.get(),
+                                                                                    pooled ? pool_job.get() : nullptr);
         }
         check_launch("match_cand_f16_kernel (pooled, list mode)");
         APS_HIP(hipStreamSynchronize(stream()));  // lw / dlw go out of scope

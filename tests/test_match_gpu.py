@@ -600,3 +600,48 @@ def test_pairwise_more_than_65535_pairs(fm):
         got = np.stack([np.asarray(ii[s:e]), np.asarray(jj[s:e])], 1)
         assert np.array_equal(got, om), (p, i, j)
         assert np.array_equal(bits(np.asarray(met[s:e])), bits(omet))
+
+
+def test_pooled_survivor_tiles_of_unequal_sets_equal_per_job_lists_and_oracle(fm, gpu, monkeypatch):
+    """The f16 list pass packs the int8 screen's survivors of all jobs that share a B set into common 512-row tiles
+    (match_cand_f16_kernel's row_job form, round 4): every A-side quantity is then per ROW.  Sets of very different sizes
+    (a tile's anchor job is the group's first - here the 37-row set - while its rows come from sets of up to 2100 rows),
+    unit and unnormalised descriptors, near-ties: the lists must equal those of one list per job (APS_MATCH_NO_POOL=1), of
+    the all-f32 kernel and of the oracle, pair by pair."""
+    import ctypes
+
+    rng = np.random.default_rng(77)
+    base = sift_like(rng, 2600)
+    sizes = [37, 2100, 640, 1500, 5, 980]
+    for unit in (True, False):
+        descs = []
+        for n in sizes:
+            keep = rng.permutation(2600)[:n]
+            noise = rng.uniform(0.0, 0.08, n)[:, None]
+            d = np.maximum(base[keep] + noise * rng.standard_normal((n, 128)).astype(np.float32), 0)
+            d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+            descs.append(d if unit else np.round(d * 512).clip(0, 255).astype(np.float32))
+        descs[3][7] = descs[1][11]                     # an exact duplicate across sets
+        descs[1][13] = descs[1][12] + np.float32(1e-4)  # two near-identical columns: the rows near them need the exact path
+        order = fm.pair_order(len(descs))
+        monkeypatch.delenv("APS_MATCH_NO_POOL", raising=False)
+        monkeypatch.delenv("APS_MATCH_MODE", raising=False)
+        pp, ia, ib, met = fm.match_pairs_csr(descs, order, 0.8, 1.5, True)
+        rows, surv = ctypes.c_int64(0), ctypes.c_int64(0)
+        gpu._capi.check(gpu.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+        assert rows.value == sum(len(descs[i]) for i, _ in order) and surv.value > 2000  # the list pass has real work
+        monkeypatch.setenv("APS_MATCH_NO_POOL", "1")
+        qp, qa, qb, qm = fm.match_pairs_csr(descs, order, 0.8, 1.5, True)
+        monkeypatch.delenv("APS_MATCH_NO_POOL")
+        monkeypatch.setenv("APS_MATCH_MODE", "f32")
+        fp, fa, fb_, fmet = fm.match_pairs_csr(descs, order, 0.8, 1.5, True)
+        monkeypatch.delenv("APS_MATCH_MODE")
+        for other in ((qp, qa, qb, qm), (fp, fa, fb_, fmet)):
+            assert np.array_equal(pp, other[0]) and np.array_equal(ia, other[1]) and np.array_equal(ib, other[2])
+            assert np.array_equal(met.view(np.uint32), other[3].view(np.uint32))
+        assert pp[-1] > 1500
+        for p, (i, j) in enumerate(order):
+            om, omet = oracle.match_features(descs[i], descs[j], 0.8, 1.5, True, 2)
+            got = np.stack([ia[pp[p]:pp[p + 1]], ib[pp[p]:pp[p + 1]]], axis=1).astype(np.int64)
+            assert np.array_equal(got, om.astype(np.int64)), (unit, i, j)
+            assert np.array_equal(met[pp[p]:pp[p + 1]].view(np.uint32), np.asarray(omet, np.float32).view(np.uint32)), (unit, i, j)
