@@ -220,6 +220,10 @@ __device__ __forceinline__ void pk_tap(f32x2& acc, const GaussK& gk, f32x2 v) {
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(kk), "v"(v));
 }
 
+// radii whose tile kernel keeps ONE LDS buffer for both passes (see blur_tile_passes)
+template <int R>
+constexpr bool kBlurOneBuffer = R >= 7;
+
 // The two passes of blur_kernel / blur_base_kernel on a filled tile (s_in row-interleaved, see blur_kernel).
 template <int R>
 __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row, const GaussK& gk, int x0, int y0, int h, int w,
@@ -231,8 +235,17 @@ __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row
     const int tid = threadIdx.x;
     __syncthreads();
     // row pass: IH/2 row pairs x 8 segments of 8 outputs; consecutive lanes = consecutive row pairs
-    for (int u = tid; u < (IH / 2) * (kTW / 8); u += 256) {
-        const int seg = u / (IH / 2), p = u - seg * (IH / 2), xb = seg * 8;
+    // kBlurOneBuffer<R> (the large radii, round 4): s_row IS s_in - a thread's row-pass results (one work item per thread:
+    // IH / 2 * 8 <= 256 for every R <= 12) wait in registers until every thread has read its window, then overwrite the
+    // tile.  One barrier more, 19 instead of 32 KB of LDS at R = 10: eight workgroups per CU instead of five, which is what
+    // a kernel whose fill -> row pass -> column pass -> store chain is latency per workgroup needs; the small radii are
+    // memory-bound and lose a few per cent to the extra barrier (round 2's measurement), so they keep two buffers.
+    constexpr bool one_buf = kBlurOneBuffer<R>;
+    static_assert(!one_buf || (IH / 2) * (kTW / 8) <= 256, "one work item per thread");
+    for (int u = tid; u < (one_buf ? 256 : (IH / 2) * (kTW / 8)); u += 256) {
+        const bool live = u < (IH / 2) * (kTW / 8);
+        const int uc = live ? u : 0;
+        const int seg = uc / (IH / 2), p = uc - seg * (IH / 2), xb = seg * 8;
         const f32x2* src = reinterpret_cast<const f32x2*>(&s_in[p * IP2 + 2 * (OFF + xb)]);
         f32x2 v[8 + 2 * R], acc[8];
 #pragma unroll
@@ -244,11 +257,14 @@ __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row
 #pragma unroll
             for (int j = 0; j < 8; ++j) pk_tap<t>(acc[j], gk, v[j + t]);
         });
+        if (one_buf) __syncthreads();  // every window has been read: the tile may be overwritten
         float* d0 = &s_row[(2 * p) * RPITCH + xb];
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            d0[j] = acc[j].x;
-            d0[RPITCH + j] = acc[j].y;
+            for (int j = 0; j < 8; ++j) {
+                d0[j] = acc[j].x;
+                d0[RPITCH + j] = acc[j].y;
+            }
         }
     }
     __syncthreads();
@@ -313,8 +329,10 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     constexpr int IP2 = 2 * IW + 4;
     constexpr int RPITCH = kTW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
     static_assert((IP2 / 4) % 2 == 1, "pitch");
+    static_assert(IH * RPITCH <= (IH / 2) * IP2, "the row-pass result fits the tile's buffer");
     __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
-    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
+    __shared__ __attribute__((aligned(16))) float s_row_own[kBlurOneBuffer<R> ? 1 : IH * RPITCH];
+    float* const s_row = kBlurOneBuffer<R> ? s_in : s_row_own;
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
     const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
@@ -366,7 +384,8 @@ __global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restric
     constexpr int RPITCH = kTW + 2;
     constexpr int GW = IW / 2 + 3, GH = IH / 2 + 3;  // gray footprint of the haloed tile (+ the interpolation's neighbours)
     __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
-    __shared__ __attribute__((aligned(16))) float s_row[IH * RPITCH];
+    __shared__ __attribute__((aligned(16))) float s_row_own[kBlurOneBuffer<R> ? 1 : IH * RPITCH];
+    float* const s_row = kBlurOneBuffer<R> ? s_in : s_row_own;
     __shared__ float s_g[GH][GW + 1];
     const int h = 2 * sh, w = 2 * sw;
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
