@@ -191,15 +191,16 @@ def cpu_cfg1_single_thread(synth):
 
 
 def global_matcher_probe(pl, capi, input_, images):
-    """featureMatchingGlobal (the reference's default matcher) on the bench's views: SIFT once (untimed), then two passes of
-    the pooled matcher (normalise, screened exact 4-NN, per-query filter); the second is reported."""
+    """featureMatchingGlobal (the reference's default matcher) on the bench's views: SIFT once (untimed), then three passes of
+    the pooled matcher (normalise, screened exact 4-NN, per-query filter); the last is reported (the first two still grow the
+    calling thread's workspaces: 202 / 177 / 177 ms in a same-process series, scripts/ab_global.py)."""
     import ctypes
     from importlib import import_module
 
     fm = import_module(pl.__name__.rsplit(".", 1)[0] + ".featureMatching")
     descs = [d for d, _ in pl.sift_many(input_, images)]
     best = None
-    for _ in range(2):
+    for _ in range(3):
         capi.profile_enable(2)
         capi.profile_reset()
         torch.cuda.synchronize()
