@@ -384,6 +384,7 @@ struct Q8Set {
 };
 
 __device__ int g_q8_symmetric = 0;  // experiment switch (APS_Q8_SYMMETRIC=1): column code without the offset
+__device__ int g_scr_variant = 0;   // experiment switch (APS_SCR_VARIANT, bits: see match_screen_i8x16_kernel)
 
 __device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
     float mx = unord_f32(__float_as_uint(qstat[0])), mn = unord_f32(~__float_as_uint(qstat[3]));
@@ -1841,6 +1842,11 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     const int kq = lane >> 4;
     const int nA = jb.nA, nB = jb.nB;
     const int rowb = w.row0 + wave * 64;  // this wave's rows: rowb + 16 g + c, every lane quarter kq sees them
+    // experiment switches (APS_SCR_VARIANT): 1 = static priority for waves 4-7, 2 / 4 = waves 4-7 sleep 64 / 128 cycles after
+    // every hand-over barrier (a stagger between the two waves of a SIMD), 8 = the odd waves instead of waves 4-7
+    const int variant = __builtin_amdgcn_readfirstlane(g_scr_variant);
+    const bool late_half = (variant & 8) ? (wave & 1) != 0 : wave >= 4;
+    if ((variant & 1) && late_half) __builtin_amdgcn_s_setprio(1);
 
     i32x4 aq[4][2];
 #pragma unroll
@@ -1985,6 +1991,10 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             if (cb == kLast - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if ((variant & 6) && late_half) {
+                    if (variant & 2) __builtin_amdgcn_s_sleep(1);
+                    if (variant & 4) __builtin_amdgcn_s_sleep(2);
+                }
             }
         });
     };
@@ -2485,6 +2495,10 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
         {
             Prof prof("match_screen_i8");
+            if (const char* ev = std::getenv("APS_SCR_VARIANT")) {
+                const int v = std::atoi(ev);
+                APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_scr_variant), &v, sizeof v, 0, hipMemcpyHostToDevice, stream()));
+            }
             if (screen_shape_32())
                 match_screen_i8_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
                                                                                           surv_count, prune_r2, prune_thr, nullptr);

@@ -387,6 +387,8 @@ __global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restric
     __shared__ __attribute__((aligned(16))) float s_row_own[kBlurOneBuffer<R> ? 1 : IH * RPITCH];
     float* const s_row = kBlurOneBuffer<R> ? s_in : s_row_own;
     __shared__ float s_g[GH][GW + 1];
+    static_assert(GH * IW <= IH * RPITCH && IW % 4 == 0, "the horizontally interpolated gray rows fit the row-pass buffer");
+    __shared__ __attribute__((aligned(16))) float s_h_own[kBlurOneBuffer<R> ? GH * IW : 4];
     const int h = 2 * sh, w = 2 * sw;
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
@@ -437,26 +439,29 @@ __global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restric
         s_cf[tid] = f;
     }
     __syncthreads();
+    // The interpolation is separable and its horizontal half depends on (gray row, tile column) only: every gray row is
+    // interpolated ONCE along x into s_h (GH x IW values) and a doubled pixel is the vertical combination of two of those
+    // - h0 = r0[i0] a0 + r0[i1] a1 was evaluated for every doubled pixel, i.e. 3.5 times per (gray row, column) on average;
+    // same expressions on the same values, so the same bits (the kernel is vector-issue bound: 673 instructions per wave,
+    // half of them here, profiles/r04d_pmc_blur_base.txt).  s_h lives in the row-pass buffer, which is idle until then.
+    float* const s_h = kBlurOneBuffer<R> ? s_h_own : s_row;
+    for (int e = tid; e < GH * IW; e += 256) {
+        const int gy = e / IW, cx = e - gy * IW;
+        const float a1 = s_cf[cx], a0 = 1.0f - a1;
+        const float* r = s_g[gy];
+        s_h[gy * IW + cx] = r[s_ci[cx][0]] * a0 + r[s_ci[cx][1]] * a1;
+    }
+    __syncthreads();
     for (int e = tid; e < IH * NV; e += 256) {
         const int ly = e / NV, v = e - ly * NV;
         const float b1 = s_cf[IW + ly], b0 = 1.0f - b1;
-        const float* r0 = s_g[s_ci[IW + ly][0]];
-        const float* r1 = s_g[s_ci[IW + ly][1]];
-        float res[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cx = 4 * v + j;
-            const float a1 = s_cf[cx], a0 = 1.0f - a1;
-            const int i0 = s_ci[cx][0], i1 = s_ci[cx][1];
-            const float h0 = r0[i0] * a0 + r0[i1] * a1;
-            const float h1 = r1[i0] * a0 + r1[i1] * a1;
-            res[j] = h0 * b0 + h1 * b1;
-        }
+        const float4 h0 = *reinterpret_cast<const float4*>(&s_h[s_ci[IW + ly][0] * IW + 4 * v]);
+        const float4 h1 = *reinterpret_cast<const float4*>(&s_h[s_ci[IW + ly][1] * IW + 4 * v]);
         float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
-        dst[0] = res[0];
-        dst[2] = res[1];
-        dst[4] = res[2];
-        dst[6] = res[3];
+        dst[0] = h0.x * b0 + h1.x * b1;
+        dst[2] = h0.y * b0 + h1.y * b1;
+        dst[4] = h0.z * b0 + h1.z * b1;
+        dst[6] = h0.w * b0 + h1.w * b1;
     }
     blur_tile_passes<R>(s_in, s_row, gk, x0, y0, h, w, out, nullptr, 0, 0);
 }
@@ -1149,7 +1154,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
                                                     double* __restrict__ loc, int64_t ldl,
                                                     float* __restrict__ aux) {
     __shared__ unsigned long long s_hist[4][kHistLen];
-    __shared__ float s_raw[4][128];
+    __shared__ __attribute__((aligned(16))) float s_raw[4][128];
     __shared__ int s_queue[4][kDescQueue];  // per wave: samples that passed the window test, (i << 16) | (j & 0xffff)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned int oi = blockIdx.x * 4 + wv;
@@ -1290,8 +1295,20 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
     // the norms are k-ascending fma chains: every lane walks the same chain (LDS broadcast reads).  The clipped and the
     // quantised values are computed once per element (two per lane) and parked in s_raw, so that each chain step is one
     // read and one fma instead of re-deriving the element in every lane.
-    float nrm2 = 0;
-    for (int k = 0; k < 128; ++k) nrm2 = fmaf(s_raw[wv][k], s_raw[wv][k], nrm2);
+    // (the chain over s_raw in k order, four elements per LDS read: same fma sequence)
+    auto sumsq = [&]() __attribute__((always_inline)) {
+        float a = 0;
+#pragma unroll 4
+        for (int k4 = 0; k4 < 32; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(&s_raw[wv][4 * k4]);
+            a = fmaf(v.x, v.x, a);
+            a = fmaf(v.y, v.y, a);
+            a = fmaf(v.z, v.z, a);
+            a = fmaf(v.w, v.w, a);
+        }
+        return a;
+    };
+    float nrm2 = sumsq();
     const float thr = sqrtf(nrm2) * 0.2f;
     float clip[2];
 #pragma unroll
@@ -1303,8 +1320,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
     s_raw[wv][lane] = clip[0];
     s_raw[wv][lane + 64] = clip[1];
     __builtin_amdgcn_wave_barrier();
-    nrm2 = 0;
-    for (int k = 0; k < 128; ++k) nrm2 = fmaf(s_raw[wv][k], s_raw[wv][k], nrm2);
+    nrm2 = sumsq();
     const float sn = sqrtf(nrm2);
     const float scale = 512.0f / (sn > kFltEps ? sn : kFltEps);
     float qv[2];
@@ -1317,8 +1333,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
     s_raw[wv][lane] = qv[0];
     s_raw[wv][lane + 64] = qv[1];
     __builtin_amdgcn_wave_barrier();
-    float qq = 0;
-    for (int k = 0; k < 128; ++k) qq = fmaf(s_raw[wv][k], s_raw[wv][k], qq);
+    const float qq = sumsq();
     const float inv = sqrtf(qq);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
