@@ -170,7 +170,9 @@ int aps_knn_global(const float* train, int64_t ft, int64_t ldt, const float* que
  * int8 screening pass bounds its two smallest cross-image distances, :129-147 - may come back as k copies of itself
  * (distance 0): the filter removes them as self matches, fewer than two candidates remain, the query is skipped exactly
  * as the reference skips it.  Every other row gets its exact k nearest (k <= 4), bit-identical to aps_knn_global.  The
- * output of aps_global_filter on this table therefore equals its output on aps_knn_global's. */
+ * output of aps_global_filter on this table therefore equals its output on aps_knn_global's.  Pools whose (row, image)
+ * table would exceed 2^31 slots (f x n_img; BASELINE configs[4]: 5.4 M rows x 500 images) are searched in several passes
+ * over ranges of query images, every pass against all images: same result, bounded workspace. */
 int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, int layout, const int64_t* img_off, int n_img,
                             float ratio, int k, uint32_t* idx, float* dist, int64_t ldo);
 /* Diagnostics of the calling thread's most recent aps_knn_global_screened call: rows of the pool, rows that were searched. */
