@@ -2449,18 +2449,22 @@ static bool screen_shape_32() {
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
 static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2, float prune_r2 = 0.f,
                            float prune_thr = 0.f) {
-    std::vector<WgJob> wgs;
-    for (int j = 0; j < (int)jobs.size(); ++j)
-        for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r, 0});
     g_screen_rows = g_screen_surv = 0;
-    if (wgs.empty()) return;
+    bool any_rows = false;
+    for (const MatchJob& j : jobs) any_rows = any_rows || j.nA > 0;
+    if (!any_rows) return;
     Ws<MatchJob> djobs(jobs.size());
-    Ws<WgJob> dwgs(wgs.size());
     APS_HIP(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(MatchJob), hipMemcpyHostToDevice,
                            stream()));
-    APS_HIP(hipMemcpyAsync(dwgs, wgs.data(), wgs.size() * sizeof(WgJob), hipMemcpyHostToDevice,
-                           stream()));
     if (!use_split_path()) {
+        // (the 128-row tile table of the all-f32 kernel: 312 k entries for the 64 x 4K scene - built and uploaded here only;
+        // until round 4 every call paid for it, ~1 ms of host time and a 7.5 MB pageable upload the split path never read)
+        std::vector<WgJob> wgs;
+        for (int j = 0; j < (int)jobs.size(); ++j)
+            for (int r = 0; r < jobs[j].nA; r += kTM) wgs.push_back({j, r, 0});
+        Ws<WgJob> dwgs(wgs.size());
+        APS_HIP(hipMemcpyAsync(dwgs, wgs.data(), wgs.size() * sizeof(WgJob), hipMemcpyHostToDevice,
+                               stream()));
         {
             Prof prof("match2nn");
             match2nn_kernel<false><<<(unsigned)wgs.size(), 256, 0, stream()>>>(djobs, dwgs, nullptr, (int)jobs.size(), idx, d1, d2);
