@@ -2377,10 +2377,9 @@ __global__ void list_pool_kernel(const int64_t* __restrict__ seg_off, const uint
 // Pools the list segments of jobs that share a B set (same operand pointer and column count) into common tiles of kTMB
 // rows: returns the tiles (WgJob{a job of the group, start in the pooled list, rows}); pool / pool_job are filled on the
 // stream.  from / to: host copies of the per-job entry ranges (from may be empty = zeros); d_from / d_to: device copies.
-static std::vector<WgJob> pool_lists(const std::vector<MatchJob>& jobs, const MatchJob* djobs_unused, const std::vector<int64_t>& seg_off,
+static std::vector<WgJob> pool_lists(const std::vector<MatchJob>& jobs, const std::vector<int64_t>& seg_off,
                                      const uint32_t* d_list, const std::vector<unsigned int>& from, const std::vector<unsigned int>& to,
                                      const unsigned int* d_from, const unsigned int* d_to, Ws<uint32_t>& pool, Ws<int>& pool_job) {
-    (void)djobs_unused;
     const size_t nj = jobs.size();
     std::vector<int> order(nj);
     for (size_t j = 0; j < nj; ++j) order[j] = (int)j;
@@ -2525,7 +2524,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         if (pooled) {
             std::vector<int64_t> seg(jobs.size());
             for (size_t j = 0; j < jobs.size(); ++j) seg[j] = jobs[j].out_off;
-            lw = pool_lists(jobs, djobs, seg, surv_list, {}, h_surv, nullptr, surv_count, pool, pool_job);
+            lw = pool_lists(jobs, seg, surv_list, {}, h_surv, nullptr, surv_count, pool, pool_job);
         } else {
             for (int j = 0; j < (int)jobs.size(); ++j)
                 for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
@@ -3048,7 +3047,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         Ws<int> pool_job;
         if (pooled) {  // the lists of the jobs (i, j) that share the column image j in common tiles (list_count holds `to`)
             APS_HIP(hipMemcpyAsync(d_from, from.data(), (size_t)n * n * sizeof(unsigned int), hipMemcpyHostToDevice, stream()));
-            lw = pool_lists(cj, dcj, job_off, row_list, from, to, d_from, list_count, pool, pool_job);
+            lw = pool_lists(cj, job_off, row_list, from, to, d_from, list_count, pool, pool_job);
         } else {
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) {

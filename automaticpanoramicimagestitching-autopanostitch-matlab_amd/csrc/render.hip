@@ -1494,47 +1494,74 @@ __device__ __forceinline__ bool gain_sample(const DevImage& im, const float d[3]
 constexpr int kGainSlots = 128;  // per-workgroup pair table
 constexpr int kGainMaxCover = 16;
 
-// One thread per sampled canvas point.  Pair sums go through a small LDS hash table per workgroup (the points of a
-// 16 x 16 patch share a handful of pairs), flushed with one double atomicAdd per entry.
-__global__ __launch_bounds__(256) void gain_stats_kernel(DevCanvas cv, const DevImage* __restrict__ imgs, int n_img,
-                                                         int stride, int ws, int hs, double* __restrict__ Nij,
-                                                         double* __restrict__ sCi, double* __restrict__ sCj) {
-    __shared__ unsigned int s_key[kGainSlots];
-    __shared__ unsigned int s_cnt[kGainSlots];
-    __shared__ double s_sum[kGainSlots][6];
-    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
-        s_key[e] = 0u;
-        s_cnt[e] = 0u;
+// The pair sums of one workgroup of both gain-statistics kernels: a small LDS hash table keyed by the image pair (the points
+// of a 16 x 16 patch share a handful of pairs), flushed with one double atomicAdd per touched entry; a full table sends the
+// contribution straight to memory.  Outputs are n x n (x 3) column-major, entry (i, j), i < j.
+struct GainPairTable {
+    unsigned int key[kGainSlots];
+    unsigned int cnt[kGainSlots];
+    double sum[kGainSlots][6];
+    __device__ __forceinline__ void init() {
+        for (int e = threadIdx.x; e < kGainSlots; e += blockDim.x) {
+            key[e] = 0u;
+            cnt[e] = 0u;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s_sum[e][c] = 0.0;
+            for (int c = 0; c < 6; ++c) sum[e][c] = 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
-    const size_t nn = (size_t)n_img * n_img;
-    auto add_pair = [&](int i, int j, const float* ci, const float* cj) {
-        const unsigned int key = (unsigned int)(i * n_img + j) + 1u;
-        unsigned int slot = (key * 2654435761u) >> 25;
+    __device__ __forceinline__ void add(int n_img, int i, int j, const float* ci, const float* cj, double* __restrict__ Nij,
+                                        double* __restrict__ sCi, double* __restrict__ sCj) {
+        const unsigned int k = (unsigned int)(i * n_img + j) + 1u;
+        unsigned int slot = (k * 2654435761u) >> 25;
         for (int probe = 0; probe < kGainSlots; ++probe) {
-            const unsigned int old = atomicCAS(&s_key[slot], 0u, key);
-            if (old == 0u || old == key) {
-                atomicAdd(&s_cnt[slot], 1u);
+            const unsigned int old = atomicCAS(&key[slot], 0u, k);
+            if (old == 0u || old == k) {
+                atomicAdd(&cnt[slot], 1u);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    atomicAdd(&s_sum[slot][c], (double)ci[c]);
-                    atomicAdd(&s_sum[slot][3 + c], (double)cj[c]);
+                    atomicAdd(&sum[slot][c], (double)ci[c]);
+                    atomicAdd(&sum[slot][3 + c], (double)cj[c]);
                 }
                 return;
             }
             slot = (slot + 1) & (kGainSlots - 1);
         }
-        const size_t e = (size_t)i + (size_t)n_img * j;  // table full: straight to memory
+        const size_t nn = (size_t)n_img * n_img, e = (size_t)i + (size_t)n_img * j;  // table full: straight to memory
         atomicAdd(&Nij[e], 1.0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             atomicAdd(&sCi[e + nn * c], (double)ci[c]);
             atomicAdd(&sCj[e + nn * c], (double)cj[c]);
         }
-    };
+    }
+    __device__ __forceinline__ void flush(int n_img, double* __restrict__ Nij, double* __restrict__ sCi, double* __restrict__ sCj) {
+        __syncthreads();
+        const size_t nn = (size_t)n_img * n_img;
+        for (int e = threadIdx.x; e < kGainSlots; e += blockDim.x) {
+            const unsigned int k = key[e];
+            if (!k) continue;
+            const int i = (int)((k - 1u) / (unsigned int)n_img), j = (int)((k - 1u) % (unsigned int)n_img);
+            const size_t o = (size_t)i + (size_t)n_img * j;
+            atomicAdd(&Nij[o], (double)cnt[e]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                atomicAdd(&sCi[o + nn * c], sum[e][c]);
+                atomicAdd(&sCj[o + nn * c], sum[e][3 + c]);
+            }
+        }
+    }
+};
+
+// One thread per sampled canvas point.  Pair sums go through a small LDS hash table per workgroup (the points of a
+// 16 x 16 patch share a handful of pairs), flushed with one double atomicAdd per entry.
+__global__ __launch_bounds__(256) void gain_stats_kernel(DevCanvas cv, const DevImage* __restrict__ imgs, int n_img,
+                                                         int stride, int ws, int hs, double* __restrict__ Nij,
+                                                         double* __restrict__ sCi, double* __restrict__ sCj) {
+    __shared__ GainPairTable s_tab;
+    s_tab.init();
+    auto add_pair = [&](int i, int j, const float* ci, const float* cj) { s_tab.add(n_img, i, j, ci, cj, Nij, sCi, sCj); };
+    const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (ix < ws && iy < hs) {
         float d[3];
         gain_ray(cv, (float)(1 + stride * ix), (float)(1 + stride * iy), d);
@@ -1573,19 +1600,7 @@ __global__ __launch_bounds__(256) void gain_stats_kernel(DevCanvas cv, const Dev
             }
         }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
-        const unsigned int key = s_key[e];
-        if (!key) continue;
-        const int i = (int)((key - 1u) / (unsigned int)n_img), j = (int)((key - 1u) % (unsigned int)n_img);
-        const size_t o = (size_t)i + (size_t)n_img * j;
-        atomicAdd(&Nij[o], (double)s_cnt[e]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicAdd(&sCi[o + nn * c], s_sum[e][c]);
-            atomicAdd(&sCj[o + nn * c], s_sum[e][3 + c]);
-        }
-    }
+    s_tab.flush(n_img, Nij, sCi, sCj);
 }
 }  // namespace aps
 
@@ -1641,42 +1656,10 @@ __device__ __forceinline__ size_t warped_at(const WarpedSet& S, int y, int x, in
 // atomicAdd per touched pair at the end).
 __global__ __launch_bounds__(256) void gain_stats_warped_kernel(WarpedSet S, int ds, int ws, int hs, double* __restrict__ Nij,
                                                                 double* __restrict__ sCi, double* __restrict__ sCj) {
-    __shared__ unsigned int s_key[kGainSlots];
-    __shared__ unsigned int s_cnt[kGainSlots];
-    __shared__ double s_sum[kGainSlots][6];
-    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
-        s_key[e] = 0u;
-        s_cnt[e] = 0u;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s_sum[e][c] = 0.0;
-    }
-    __syncthreads();
+    __shared__ GainPairTable s_tab;
+    s_tab.init();
     const int n_img = S.n;
-    const size_t nn = (size_t)n_img * n_img;
-    auto add_pair = [&](int i, int j, const float* ci, const float* cj) {
-        const unsigned int key = (unsigned int)(i * n_img + j) + 1u;
-        unsigned int slot = (key * 2654435761u) >> 25;
-        for (int probe = 0; probe < kGainSlots; ++probe) {
-            const unsigned int old = atomicCAS(&s_key[slot], 0u, key);
-            if (old == 0u || old == key) {
-                atomicAdd(&s_cnt[slot], 1u);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    atomicAdd(&s_sum[slot][c], (double)ci[c]);
-                    atomicAdd(&s_sum[slot][3 + c], (double)cj[c]);
-                }
-                return;
-            }
-            slot = (slot + 1) & (kGainSlots - 1);
-        }
-        const size_t e = (size_t)i + (size_t)n_img * j;  // table full: straight to memory
-        atomicAdd(&Nij[e], 1.0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicAdd(&sCi[e + nn * c], (double)ci[c]);
-            atomicAdd(&sCj[e + nn * c], (double)cj[c]);
-        }
-    };
+    auto add_pair = [&](int i, int j, const float* ci, const float* cj) { s_tab.add(n_img, i, j, ci, cj, Nij, sCi, sCj); };
     const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (ix < ws && iy < hs) {
         const int x = ix * ds, y = iy * ds;
@@ -1721,19 +1704,7 @@ __global__ __launch_bounds__(256) void gain_stats_warped_kernel(WarpedSet S, int
             }
         }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < kGainSlots; e += 256) {
-        const unsigned int key = s_key[e];
-        if (!key) continue;
-        const int i = (int)((key - 1u) / (unsigned int)n_img), j = (int)((key - 1u) % (unsigned int)n_img);
-        const size_t o = (size_t)i + (size_t)n_img * j;
-        atomicAdd(&Nij[o], (double)s_cnt[e]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicAdd(&sCi[o + nn * c], s_sum[e][c]);
-            atomicAdd(&sCj[o + nn * c], s_sum[e][3 + c]);
-        }
-    }
+    s_tab.flush(n_img, Nij, sCi, sCj);
 }
 }  // namespace aps
 
