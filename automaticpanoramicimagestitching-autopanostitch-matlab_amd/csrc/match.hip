@@ -2510,9 +2510,11 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                                                                                              surv_count, prune_r2, prune_thr, nullptr);
         }
         check_launch("match_screen_i8_kernel");
+        const auto S0 = std::chrono::steady_clock::now();
         std::vector<unsigned int> h_surv(jobs.size());
         APS_HIP(hipMemcpyAsync(h_surv.data(), surv_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));
+        const auto S1 = std::chrono::steady_clock::now();
         // the survivors of the jobs that share a B set are pooled into common 512-row tiles (APS_MATCH_NO_POOL=1: one list per
         // job, as in rounds 2-3 - 6599 tiles instead of ~5600 for the 64 x 4K scene)
         const bool pooled = !std::getenv("APS_MATCH_NO_POOL");
@@ -2552,7 +2554,15 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                                                                                         pooled ? pool_job.get() : nullptr);
             }
             check_launch("match_cand_f16_kernel<list>");
+            const auto S3 = std::chrono::steady_clock::now();
             APS_HIP(hipStreamSynchronize(stream()));  // lw must outlive its copy
+            if (std::getenv("APS_TRACE")) {
+                auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                    return std::chrono::duration<double, std::milli>(b - a).count();
+                };
+                std::fprintf(stderr, "[aps] screen: launch -> counts on the host %.2f ms (incl. the wait for the kernel), tiles + pooling on the host %.2f ms, "
+                             "list pass (wait) %.2f ms\n", ms(S0, S1), ms(S1, S3), ms(S3, std::chrono::steady_clock::now()));
+            }
         }
     } else {
         Prof prof("match_cand_f16");
