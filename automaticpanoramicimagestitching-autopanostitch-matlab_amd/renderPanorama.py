@@ -475,6 +475,13 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
 
     batched = not _os.environ.get("APS_RENDER_LEGACY")  # (since round 4 'linear' and 'none' are one fused launch as well)
     workers = _render_workers() if (device_out and not batched) else 1
+    if device_out and batched and _os.environ.get("APS_RENDER_BATCH_WORKERS"):
+        # Experiment (round 4): the batched call split over host threads / streams (tiles t % workers == k each), so that one
+        # share's vector-bound warp runs beside another's latency-bound pyramid kernels.  The render alone: 18.2 -> 17.2 ms with
+        # two shares for the 66 tiles of the 64 x 4K scene (both prepare all images), 18.4-19.5 with three; inside the pipeline
+        # step nothing is left of it (19.2 against 19.4 ms), so one call stays the default.  Same bytes either way.
+        n_tiles = -(-H // int(o["tile"][0])) * -(-W // int(o["tile"][1]))
+        workers = max(1, min(int(_os.environ["APS_RENDER_BATCH_WORKERS"]), n_tiles))
     if tile_subset is None and workers <= 1:
         check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
     else:  # (first, step): only tiles t with t % step == first — the multi-GPU shard of the tile loop
