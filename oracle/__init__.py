@@ -155,6 +155,7 @@ def hamming_2nn(A, B):
 # ---- RANSAC (ransac_oracle.c) -------------------------------------------------------------------
 _orc_ransac_score = _sig("orc_ransac_score", [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp])
 _orc_fit_homography = _sig("orc_fit_homography", [_vp, _vp, _i64, _vp, _i64, _vp], _i)
+_orc_fit_homography_refit = _sig("orc_fit_homography_refit", [_vp, _vp, _i64, _vp, _i64, _vp], _i)
 _orc_check_model = _sig("orc_check_model", [_vp], _i)
 _orc_ransac_homography = _sig("orc_ransac_homography",
                               [_vp, _vp, _i64, _i64, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp])
@@ -181,12 +182,14 @@ def ransac_score(Hs, p1, p2, thr, want_mask=True):
     return n, e, mask
 
 
-def fit_homography(p1, p2, sel):
+def fit_homography(p1, p2, sel, refit=False):
+    """estimateHomography on the selected points; refit=True: with the wave-order sums of the refit on the inliers."""
     a, m = _pts(p1)
     b, _ = _pts(p2)
     sel = np.ascontiguousarray(sel, np.int64)
     H = np.zeros(9, np.float64)
-    ok = _orc_fit_homography(a.ctypes.data, b.ctypes.data, m, sel.ctypes.data, len(sel), H.ctypes.data)
+    fn = _orc_fit_homography_refit if refit else _orc_fit_homography
+    ok = fn(a.ctypes.data, b.ctypes.data, m, sel.ctypes.data, len(sel), H.ctypes.data)
     return H.reshape(3, 3).T.copy(), bool(ok)
 
 

@@ -325,6 +325,11 @@ ORC_API int orc_fit_homography(const double* p1, const double* p2, int64_t ldp, 
                                int64_t n, double* H) {
     return fit_homography(p1, p1 + ldp, p2, p2 + ldp, sel, n, H, 0);
 }
+/* the same fit with the REFIT's wave-order sums (what orc_ransac_homography runs on the inliers after the loop) */
+ORC_API int orc_fit_homography_refit(const double* p1, const double* p2, int64_t ldp, const int64_t* sel,
+                                     int64_t n, double* H) {
+    return fit_homography(p1, p1 + ldp, p2, p2 + ldp, sel, n, H, 1);
+}
 
 ORC_API int orc_check_model(const double* H) { return check_model(H); }
 

@@ -192,6 +192,14 @@ def test_dlt_by_jacobi_gram_equals_lapack_svd(m, noise):
     Ho = Ho / Ho[2, 2]
     Hs = _dlt_svd(p1, p2)
     assert np.abs(Ho - Hs).max() / np.abs(Hs).max() < 1e-8, np.abs(Ho - Hs).max()
+    # the refit on the inliers sums in the wave order (64 lane-strided partials + butterfly, round 4) instead of sequentially:
+    # a different rounding of the same sums - within 1e-11 of the sequential fit, and the same 1e-8 of LAPACK
+    Hw, ok = oracle.fit_homography(p1, p2, np.arange(m), refit=True)
+    assert ok
+    Hw = Hw / Hw[2, 2]
+    assert np.abs(Hw - Ho).max() / np.abs(Ho).max() < 1e-11 and np.abs(Hw - Hs).max() / np.abs(Hs).max() < 1e-8
+    if m > 64:
+        assert not np.array_equal(Hw, Ho)  # (with more than 64 points the two orders do round differently)
     # scoring ALL matches of a larger set with either model: identical inlier masks
     M = 2000
     a = rng.uniform([1, 1], [1600, 1200], size=(M, 2))
