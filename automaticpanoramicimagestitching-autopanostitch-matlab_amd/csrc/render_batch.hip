@@ -1292,6 +1292,8 @@ __global__ __launch_bounds__(kDFT) void rw_down_fused_kernel(RwArgs A, int l, co
 constexpr int kUP = APS_KUP;
 // (Measured and dropped in round 3: 8 waves per SIMD through amdgpu_waves_per_eu(8, 8) - 64 VGPRs with ten dwords of
 // scratch: 4.2 -> 7.6 ms at level 0.)
+// (Round 4, profiles/r04g_rw_up_staged_ab.txt: the coarser level's taps staged in LDS per 32 x 16 block - one barrier, 106
+// VGPRs - 4.14 -> 6.24 ms; the resize order settled once per thread instead of the v_cndmask swaps in up_combine: +3 %.)
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void rw_up_kernel(RwArgs A, int l, const int* __restrict__ blk_ptr, int n_blocks) {
     const int bid = xcd_contiguous_id(n_blocks);

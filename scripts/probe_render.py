@@ -21,3 +21,5 @@ for r in range(reps):
     pano, _ = rp.renderPanorama(inp, imgs, sizes, cams, "spherical", len(imgs) // 2, opts, device_out=True)
     apsamd._capi.check(apsamd.lib.aps_synchronize()); torch.cuda.synchronize()
     print(f"render {r} ({blending}): {(time.perf_counter()-t0)*1e3:.1f} ms, pano {tuple(pano.shape)}, mean {pano.float().mean().item():.3f}", flush=True)
+import zlib
+print("crc32 of the panorama bytes:", hex(zlib.crc32(pano.cpu().numpy().tobytes())), flush=True)
