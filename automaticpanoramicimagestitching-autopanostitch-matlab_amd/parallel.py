@@ -105,13 +105,20 @@ def partition_weighted(weights, world_size):
     return owner
 
 
-def partition_pairs_blocked(pairs, weights, n, world_size):
+def partition_pairs_blocked(pairs, weights, n, world_size, scatter=False):
     """Owner of every image pair for the matching stage.  The matcher prepares every descriptor set a rank's pairs touch
     (a fixed cost per image and rank), so the pairs are dealt in BLOCKS of the pair matrix instead of one by one: images
     are cut into ceil(sqrt(2 * world)) groups, the pairs are walked group-pair by group-pair (stable inside one), and the
     walk is cut into `world` contiguous segments of equal total weight.  A rank then touches the images of one or two
     group pairs (at 8 ranks and 64 views: ~32-48 of them instead of all 64); the balance is that of a prefix-sum cut: within
-    one pair's weight of even.  The result depends on (pairs, weights, n, world) only - every rank computes the same."""
+    one pair's weight of even.  The result depends on (pairs, weights, n, world) only - every rank computes the same.
+    scatter (off): the groups are drawn by a fixed pseudo-random permutation of the images instead of by index ranges.
+    The weights N_i N_j are what the proof pass costs; the survivor pass costs what the pairs OVERLAP, which nobody knows
+    yet - but image sets come in capture order, neighbours in index overlap, and index-range groups put most overlapping
+    pairs into the diagonal blocks.  Measured on the 64 x 4K scene at 8 ranks (scripts/probe_rank_costs.py,
+    profiles/r04h_rank_costs.txt): overlapping pairs per rank 33-97 -> 55-79, slowest rank 13.2 -> 12.9 ms, descriptor
+    sets per rank 25-42 -> 28-48: the proof pass is 2/3 of a rank's matching whatever its pairs overlap, so the spread of
+    the survivor pass is worth 2 % and costs preparation; index ranges stay the default."""
     P = len(pairs)
     owner = np.zeros(P, np.int64)
     if world_size <= 1 or P == 0:
@@ -119,7 +126,13 @@ def partition_pairs_blocked(pairs, weights, n, world_size):
     nb = int(np.ceil(np.sqrt(2.0 * world_size)))
     B = max(1, -(-n // nb))
     arr = np.asarray(pairs, np.int64).reshape(P, 2)
-    key = (np.minimum(arr[:, 0], arr[:, 1]) // B) * (nb + 1) + (np.maximum(arr[:, 0], arr[:, 1]) // B)
+    if scatter:
+        place = np.empty(n, np.int64)
+        place[np.random.RandomState(20240 + n).permutation(n)] = np.arange(n)
+        ga, gb = place[arr[:, 0]] // B, place[arr[:, 1]] // B
+    else:
+        ga, gb = arr[:, 0] // B, arr[:, 1] // B
+    key = np.minimum(ga, gb) * (nb + 1) + np.maximum(ga, gb)
     walk = np.argsort(key, kind="stable")
     w = np.asarray(weights, np.float64)[walk]
     total = float(w.sum())

@@ -60,6 +60,17 @@ fm.match_pairs_csr(descs, [order[p] for p in my], inp["Ratiothreshold"], inp["Ma
 sync()
 print("   kernels of one call: " + ", ".join(f"{k} {v[0]:.3f}" for k, v in capi.profile_all().items() if v[0] > 0.01))
 capi.profile_enable(False)
+full = fm.match_pairs_csr(descs, order, inp["Ratiothreshold"], inp["Matchingthreshold"], True, device_out=False)
+nm_all = np.diff(np.asarray(full[0]))
+for scatter in (False, True):
+    ow = par.partition_pairs_blocked(order, wts, n, world, scatter=scatter)
+    line = []
+    for r in range(world):
+        sel = [order[p] for p in range(len(order)) if ow[p] == r]
+        lo_r, _, _ = timed(lambda: fm.match_pairs_csr(descs, sel, inp["Ratiothreshold"], inp["Matchingthreshold"], True, device_out=True), reps=3)
+        line.append((lo_r, len(sel), len({v for q in sel for v in q}), int((nm_all[ow == r] >= 20).sum())))
+    print(f"matching per rank, groups {'scattered' if scatter else 'by index range'}: " +
+          ", ".join(f"{t:.2f} ms ({k} pairs, {s_} sets, {o} overlapping)" for t, k, s_, o in line) + f"; max {max(t for t, *_ in line):.2f} ms")
 print(f"matching of this rank's {len(my)} pairs (touching {len({v for p in my for v in order[p]})} descriptor sets): min {lo:.2f} ms, median {med:.2f} ms")
 lo, med, out_all = timed(lambda: fm.match_pairs_csr(descs, order, inp["Ratiothreshold"], inp["Matchingthreshold"], True, device_out=True), reps=2)
 print(f"matching of all {len(order)} pairs: min {lo:.2f} ms")
@@ -109,6 +120,7 @@ def host():
     return pl.recognize_panoramas(n, pairs, models_l, num_matches, Ks, labels, None)
 
 
+host()  # (the first call pays imports)
 t0 = time.perf_counter()
 for _ in range(reps):
     comps = host()
