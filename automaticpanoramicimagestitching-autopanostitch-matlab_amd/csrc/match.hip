@@ -142,153 +142,219 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
     return v;
 }
 
-// One 64-thread workgroup = 64 rows, one row per lane (the norms are sequential k-ascending chains).  A row-major set
-// is read and the copies are written through an LDS tile: every global instruction then moves whole half rows (four per
-// 16-byte-per-lane instruction) instead of 64 scattered 16-byte pieces 512 bytes apart - the kernel ran at 0.8 TB/s of
-// its ~35 MB per set on that access pattern alone.  The tile holds HALF a row per lane (64 rows x 68 floats, 17 KB; a
-// whole row was 34 KB until round 4): the kernel is one wave walking ~4000 dependent instructions, so its throughput is
-// the number of workgroups a CU holds, and LDS was what limited that to four (one wave per SIMD).
-constexpr int kPrepPitch = kDim / 2 + 4;  // floats; 68 = 4 (mod 64): ds_read/write_b128 of 16 consecutive lanes hit 16 slots
-__device__ __forceinline__ void prep_desc_rows(int64_t blk, float* __restrict__ s_t, const float* __restrict__ X, int64_t n, int64_t ld,
-                                 int layout, int normalize, float* __restrict__ P, float* __restrict__ sq,
-                                 unsigned short* __restrict__ Hf, float* __restrict__ dn,
-                                 float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
-    const int lane = threadIdx.x;
-    const int64_t r0 = blk * (int64_t)64, i = r0 + lane;
-    const bool valid = i < n;
-    const int64_t ic = valid ? i : n - 1;  // (lanes past the end work on the last row and store nothing)
-    float x[kDim];
-    const bool tiled = layout == APS_ROWMAJOR && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+// One 256-thread workgroup = 64 rows (round 4; it was ONE wave with a row per lane and x[128] in registers - 256 VGPRs, one
+// wave per SIMD, ~100 us of dependent work per workgroup: 0.9 ms for 64 sets whose 1.6 GB move in 0.4).  The tile lives in
+// LDS, and only what has to be serial is: phase A, all threads load the 64 x 128 tile as whole rows (a row-major set; other
+// layouts element by element); phase B, one lane per row walks the canonical k-ascending chain ||x||^2 (and, when the set
+// is normalised, the chain of the raw row first, all threads divide the tile, then the chain again); phase C, sixteen
+// threads per row turn eight consecutive elements each into the permuted f32 copy (evens | odds), the f16 copy and their
+// share of the row's rounding loss and of the set's extremes.  Values and codes are those of the one-wave kernel; the
+// rounding-loss norm dn is summed in a different order (eight elements per thread, then a butterfly over the sixteen), which
+// its 2^-10 margin covers just the same.
+constexpr int kPrepRows = 64, kPrepThreads = 256;
+constexpr int kPrepPitch = kDim + 4;  // floats; 132 = 4 (mod 64): the ds_read_b128 of 16 lanes on 16 rows hit 64 banks
+struct PrepLds {
+    float t[kPrepRows * kPrepPitch];
+    float row[kPrepRows];    // ||x||^2 of the (normalised) row
+    float nrm[kPrepRows];    // normalisation divisor
+    unsigned red[4][5];      // per wave: max ||x||^2, max dn, max x, ~min x, ~min ||x||^2 (as order-preserving integers)
+};
+__device__ __forceinline__ float prep_row_chain(const float* __restrict__ row) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < kDim / 4; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * j);
+        s = __fadd_rn(s, __fmul_rn(v.x, v.x));
+        s = __fadd_rn(s, __fmul_rn(v.y, v.y));
+        s = __fadd_rn(s, __fmul_rn(v.z, v.z));
+        s = __fadd_rn(s, __fmul_rn(v.w, v.w));
+    }
+    return s;
+}
+typedef __attribute__((address_space(1))) float GF32;
+typedef __attribute__((address_space(1))) unsigned short GU16;
+typedef __attribute__((address_space(1))) f32x4 GF32x4;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4_t GU32x4;
+__device__ __forceinline__ void prep_desc_rows(int64_t blk, PrepLds& L, const float* __restrict__ X_, int64_t n, int64_t ld,
+                                 int layout, int normalize, float* __restrict__ P_, float* __restrict__ sq_,
+                                 unsigned short* __restrict__ Hf_, float* __restrict__ dn_,
+                                 unsigned* __restrict__ part) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t r0 = blk * (int64_t)kPrepRows;
+    // (global address space stated explicitly: pointers read from a job table otherwise compile to FLAT loads and stores,
+    // which count on the LDS counter too - every wait for an LDS read then waited for the stores in flight as well)
+    const bool tiled = layout == APS_ROWMAJOR && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X_) & 15) == 0;
+    const GF32* X = (const GF32*)X_;
+    GF32* P = (GF32*)P_;
+    GF32* sq = (GF32*)sq_;
+    GF32* dn = (GF32*)dn_;
+    GU16* Hf = (GU16*)Hf_;
+    // phase A (rows past the end repeat the last row: they change no extreme and store nothing)
     if (tiled) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll 8
-            for (int it = 0; it < 16; ++it) {  // four 256-byte half rows per instruction
-                const int row = 4 * it + (lane >> 4), c4 = lane & 15;
-                const int64_t gr = r0 + row < n ? r0 + row : n - 1;
-                *reinterpret_cast<f32x4*>(&s_t[row * kPrepPitch + 4 * c4]) =
-                    *reinterpret_cast<const f32x4*>(X + gr * ld + 64 * half + 4 * c4);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kDim / 8; ++j) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&s_t[lane * kPrepPitch + 4 * j]);
-                x[64 * half + 4 * j + 0] = v.x;
-                x[64 * half + 4 * j + 1] = v.y;
-                x[64 * half + 4 * j + 2] = v.z;
-                x[64 * half + 4 * j + 3] = v.w;
-            }
-            __syncthreads();
+        for (int it = 0; it < kPrepRows * (kDim / 4) / kPrepThreads; ++it) {  // eight 16-byte pieces per thread, two rows per wave instruction
+            const int idx = it * kPrepThreads + tid, row = idx >> 5, c4 = idx & 31;
+            const int64_t gr = r0 + row < n ? r0 + row : n - 1;
+            *reinterpret_cast<f32x4*>(&L.t[row * kPrepPitch + 4 * c4]) = *(const GF32x4*)(X + gr * ld + 4 * c4);
+        }
+    } else if (layout == APS_ROWMAJOR) {
+        for (int e = tid; e < kPrepRows * kDim; e += kPrepThreads) {
+            const int row = e >> 7, k = e & (kDim - 1);
+            const int64_t gr = r0 + row < n ? r0 + row : n - 1;
+            L.t[row * kPrepPitch + k] = X[gr * ld + k];
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < kDim; ++k) x[k] = layout == APS_ROWMAJOR ? X[ic * ld + k] : X[ic + k * ld];
+        for (int e = tid; e < kPrepRows * kDim; e += kPrepThreads) {
+            const int row = e & (kPrepRows - 1), k = e >> 6;
+            const int64_t gr = r0 + row < n ? r0 + row : n - 1;
+            L.t[row * kPrepPitch + k] = X[gr + k * ld];
+        }
     }
-    if (normalize) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
-        // n = sqrt(sum(X.^2,2)) + eps('single'); Xn = X ./ n   (matchFeaturesScratch.m:232-233)
-        // NB: sqrtf is correctly rounded on gfx950/ROCm 7.2; __fsqrt_rn is NOT (scripts/probe/fpcheck.hip)
-        const float nrm = __fadd_rn(sqrtf(s), 1.1920928955078125e-07f);
-#pragma unroll
-        for (int k = 0; k < kDim; ++k) x[k] = __fdiv_rn(x[k], nrm);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < kDim; ++k) s = __fadd_rn(s, __fmul_rn(x[k], x[k]));
-    if (valid) sq[i] = s;
-    // the permuted f32 copy (even k, then odd k), staged per lane and stored as whole half rows: first the evens
-#pragma unroll
-    for (int odd = 0; odd < 2; ++odd) {
-#pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) {
-            f32x4 e;
-            e.x = x[8 * s4 + 0 + odd];
-            e.y = x[8 * s4 + 2 + odd];
-            e.z = x[8 * s4 + 4 + odd];
-            e.w = x[8 * s4 + 6 + odd];
-            *reinterpret_cast<f32x4*>(&s_t[lane * kPrepPitch + 4 * s4]) = e;
+    __syncthreads();
+    // phase B
+    if (normalize) {  // (uniform)
+        if (tid < kPrepRows) {
+            // n = sqrt(sum(X.^2,2)) + eps('single'); Xn = X ./ n   (matchFeaturesScratch.m:232-233)
+            // NB: sqrtf is correctly rounded on gfx950/ROCm 7.2; __fsqrt_rn is NOT (scripts/probe/fpcheck.hip)
+            L.nrm[tid] = __fadd_rn(sqrtf(prep_row_chain(&L.t[tid * kPrepPitch])), 1.1920928955078125e-07f);
         }
         __syncthreads();
-#pragma unroll 8
-        for (int it = 0; it < 16; ++it) {
-            const int row = 4 * it + (lane >> 4), c4 = lane & 15;
-            if (r0 + row < n)
-                *reinterpret_cast<f32x4*>(P + (r0 + row) * kDim + 64 * odd + 4 * c4) =
-                    *reinterpret_cast<const f32x4*>(&s_t[row * kPrepPitch + 4 * c4]);
+#pragma unroll
+        for (int it = 0; it < kPrepRows * (kDim / 4) / kPrepThreads; ++it) {
+            const int idx = it * kPrepThreads + tid, row = idx >> 5, c4 = idx & 31;
+            f32x4* pv = reinterpret_cast<f32x4*>(&L.t[row * kPrepPitch + 4 * c4]);
+            const float nr = L.nrm[row];
+            f32x4 v = *pv;
+            v.x = __fdiv_rn(v.x, nr);
+            v.y = __fdiv_rn(v.y, nr);
+            v.z = __fdiv_rn(v.z, nr);
+            v.w = __fdiv_rn(v.w, nr);
+            *pv = v;
         }
         __syncthreads();
     }
-    // screening copy in natural k order: xf = f16(x), and the norm of what the rounding dropped, ||x - xf||
-    // (rounded up): the candidate kernel's error bound is built from these norms, not from a worst case
-    if (Hf) {  // (uniform)
-        uint4* ph = reinterpret_cast<uint4*>(&s_t[lane * kPrepPitch]);
-        float ds = 0.f;
+    if (tid < kPrepRows) {
+        const float s = prep_row_chain(&L.t[tid * kPrepPitch]);
+        L.row[tid] = s;
+        if (r0 + tid < n) sq[r0 + tid] = s;
+    }
+    // phase C: item = (row, eight consecutive elements); a wave instruction covers four rows
+    float mx = -INFINITY, mn = INFINITY, md = 0.f;
 #pragma unroll
-        for (int k8 = 0; k8 < kDim / 8; ++k8) {
+    for (int it = 0; it < kPrepRows * (kDim / 8) / kPrepThreads; ++it) {
+        const int idx = it * kPrepThreads + tid, row = idx >> 4, c8 = idx & 15;
+        const bool live = r0 + row < n;
+        const f32x4 va = *reinterpret_cast<const f32x4*>(&L.t[row * kPrepPitch + 8 * c8]);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(&L.t[row * kPrepPitch + 8 * c8 + 4]);
+        const float x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        if (live) {  // the permuted f32 copy: even k, then odd k
+            *(GF32x4*)(P + (r0 + row) * kDim + 4 * c8) = f32x4{x[0], x[2], x[4], x[6]};
+            *(GF32x4*)(P + (r0 + row) * kDim + kDim / 2 + 4 * c8) = f32x4{x[1], x[3], x[5], x[7]};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // fmaxf / fminf drop NaNs; they surface in ||x||^2 / maxsq
+            mx = fmaxf(mx, x[j]);
+            mn = fminf(mn, x[j]);
+        }
+        if (Hf) {  // (uniform) screening copy in natural k order: xf = f16(x), and the norm of what the rounding dropped,
+                   // ||x - xf|| (rounded up): the candidate kernel's error bound is built from these norms, not from a worst case
             unsigned short hv[8];
+            float ds = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = x[8 * k8 + j];
                 float back;
-                hv[j] = f32_to_f16_flush(v, back);
-                const float d = v - back;  // exact when not saturated
+                hv[j] = f32_to_f16_flush(x[j], back);
+                const float d = x[j] - back;  // exact when not saturated
                 ds = fmaf(d, d, ds);
             }
-            uint4 a;
-            a.x = hv[0] | ((uint32_t)hv[1] << 16);
-            a.y = hv[2] | ((uint32_t)hv[3] << 16);
-            a.z = hv[4] | ((uint32_t)hv[5] << 16);
-            a.w = hv[6] | ((uint32_t)hv[7] << 16);
-            ph[k8] = a;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int it = 0; it < 16; ++it) {  // four 256-byte rows per instruction
-            const int row = 4 * it + (lane >> 4), c = lane & 15;
-            if (r0 + row < n)
-                *reinterpret_cast<uint4*>(Hf + (r0 + row) * kDim + 8 * c) =
-                    reinterpret_cast<const uint4*>(&s_t[row * kPrepPitch])[c];
-        }
-        const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 roundings of 2^-24 in ds, one in the root: 2^-10 covers
-        if (valid) dn[i] = dnv;
-        // one atomic per workgroup, not per row: 64 lanes x 310 workgroups of same-address atomics per statistic WERE this
-        // kernel's time (60-170 us per set; the bit patterns are compared as unsigned either way, so the result is the same)
-        const unsigned ms = wave_umax(valid ? __float_as_uint(s) : 0u);  // s >= 0
-        const unsigned md = wave_umax(valid ? __float_as_uint(dnv) : 0u);
-        if (lane == 0) {
-            atomicMax(reinterpret_cast<unsigned*>(maxsq), ms);
-            atomicMax(reinterpret_cast<unsigned*>(maxdn), md);
-        }
-    }
-    if (qstat) {  // (uniform) the int8 screen's set statistics, as order-preserving integers under atomicMax (zero fill = no rows yet):
-                  // [0] max x, [3] complement of min x (the column-side copy's range), [2] complement of min ||x||^2
-        float mx = -INFINITY, mn = INFINITY;
+            if (live)
+                *(GU32x4*)(Hf + (r0 + row) * kDim + 8 * c8) =
+                    u32x4_t{hv[0] | ((uint32_t)hv[1] << 16), hv[2] | ((uint32_t)hv[3] << 16), hv[4] | ((uint32_t)hv[5] << 16),
+                            hv[6] | ((uint32_t)hv[7] << 16)};
 #pragma unroll
-        for (int k = 0; k < kDim; ++k) {  // fmaxf / fminf drop NaNs; they surface in s / maxsq
-            mx = fmaxf(mx, x[k]);
-            mn = fminf(mn, x[k]);
-        }
-        // reduced over the workgroup's rows first (rows past the end contribute the zero fill), then a plain look: hardly
-        // any workgroup still improves on the running extremes, and a stale look only costs an atomic
-        const unsigned xb = wave_umax(valid ? ord_f32(mx) : 0u), nb = wave_umax(valid ? ~ord_f32(mn) : 0u),
-                       sb = wave_umax(valid ? ~__float_as_uint(fabsf(s)) : 0u);
-        if (lane == 0) {
-            volatile const unsigned* look = reinterpret_cast<const volatile unsigned*>(qstat);
-            if (xb > look[0]) atomicMax(reinterpret_cast<unsigned*>(qstat), xb);
-            if (nb > look[3]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 3, nb);
-            if (sb > look[2]) atomicMax(reinterpret_cast<unsigned*>(qstat) + 2, sb);
+            for (int off = 1; off < 16; off <<= 1) ds += __shfl_xor(ds, off);
+            const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 + 4 roundings of 2^-24 in ds, one in the root: 2^-10 covers
+            if (c8 == 0 && live) dn[r0 + row] = dnv;
+            md = fmaxf(md, dnv);
         }
     }
+    // the workgroup's maxima (the bit patterns are compared as unsigned: same result as on the floats)
+    __syncthreads();  // (L.row is complete)
+    const float srow = tid < kPrepRows ? L.row[tid] : 0.f;  // (rows past the end repeat the last row)
+    const unsigned ms = wave_umax(tid < kPrepRows ? __float_as_uint(srow) : 0u);  // s >= 0
+    const unsigned sb = wave_umax(tid < kPrepRows ? ~__float_as_uint(fabsf(srow)) : 0u);
+    const unsigned mdw = wave_umax(__float_as_uint(md));
+    const unsigned xb = wave_umax(ord_f32(mx)), nb = wave_umax(~ord_f32(mn));
+    if (lane == 0) {
+        L.red[wv][0] = ms;
+        L.red[wv][1] = mdw;
+        L.red[wv][2] = xb;
+        L.red[wv][3] = nb;
+        L.red[wv][4] = sb;
+    }
+    __syncthreads();
+    if (tid < 5)  // this workgroup's five maxima; prep_stats_reduce folds them into the set's statistics words
+        part[tid] = max(max(L.red[0][tid], L.red[1][tid]), max(L.red[2][tid], L.red[3][tid]));
 }
 
-__global__ __launch_bounds__(64) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
+// The set statistics are maxima over all rows of a set.  They used to be atomicMax updates of the set's words, one per
+// workgroup and word behind a volatile look - and that WAS the preparation's time: 20 000 workgroups queueing on the two
+// cache lines that hold 64 sets' words kept every workgroup resident for ~50 us (the kernel without its last six lines:
+// 283 us instead of 1151; q8_desc_kernel likewise, one look per row).  Now a workgroup stores its maxima, and one small
+// workgroup per set folds them: [0] max ||x||^2 and [1] max dn (f16 path), [4] max x, [7] ~min x, [6] ~min ||x||^2 (int8
+// codes), all as order-preserving unsigned words over a zero fill, as before.
+__device__ __forceinline__ void prep_stats_reduce(const unsigned* __restrict__ part, int n_blk, float* __restrict__ stat, bool hf,
+                                                  unsigned (*red)[5]) {
+    unsigned r[5] = {0u, 0u, 0u, 0u, 0u};
+    for (int b = threadIdx.x; b < n_blk; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r[k] = max(r[k], part[(size_t)b * 5 + k]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = wave_umax(r[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = r[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* su = reinterpret_cast<unsigned*>(stat);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r[k] = max(max(red[0][k], red[1][k]), max(red[2][k], red[3][k]));
+        if (hf) {
+            su[0] = max(su[0], r[0]);
+            su[1] = max(su[1], r[1]);
+        }
+        su[4] = max(su[4], r[2]);
+        su[7] = max(su[7], r[3]);
+        su[6] = max(su[6], r[4]);
+    }
+}
+// ... and [5], the largest column-side residual norm of the int8 codes, from q8_desc_kernel's workgroups
+__device__ __forceinline__ void q8_stats_reduce(const unsigned* __restrict__ part, int n_blk, float* __restrict__ stat, unsigned* red) {
+    unsigned r = 0u;
+    for (int b = threadIdx.x; b < n_blk; b += blockDim.x) r = max(r, part[b]);
+    r = wave_umax(r);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* su = reinterpret_cast<unsigned*>(stat);
+        su[5] = max(su[5], max(max(red[0], red[1]), max(red[2], red[3])));
+    }
+}
+__global__ __launch_bounds__(256) void prep_stats_kernel(const unsigned* __restrict__ part, int n_blk1, int n_blk2, float* __restrict__ stat,
+                                                         int hf, int which) {
+    __shared__ unsigned red[4][5];
+    if (which == 1)
+        prep_stats_reduce(part, n_blk1, stat, hf != 0, red);
+    else
+        q8_stats_reduce(part + (size_t)5 * n_blk1, n_blk2, stat, &red[0][0]);
+}
+
+__global__ __launch_bounds__(kPrepThreads) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
                                  int normalize, float* __restrict__ P, float* __restrict__ sq,
-                                 unsigned short* __restrict__ Hf, float* __restrict__ dn,
-                                 float* __restrict__ maxsq, float* __restrict__ maxdn, float* __restrict__ qstat) {
-    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
-    prep_desc_rows(blockIdx.x, s_t, X, n, ld, layout, normalize, P, sq, Hf, dn, maxsq, maxdn, qstat);
+                                 unsigned short* __restrict__ Hf, float* __restrict__ dn, unsigned* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) PrepLds L;
+    prep_desc_rows(blockIdx.x, L, X, n, ld, layout, normalize, P, sq, Hf, dn, part + (size_t)5 * blockIdx.x);
 }
 
 // Every set of a pair batch in ONE launch (round 4): block b belongs to job j with blk_ptr[j] <= b < blk_ptr[j + 1].
@@ -305,6 +371,8 @@ struct PrepJob {
     float *dnq, *invs;
     int* sumq;
     uint4* aug;
+    unsigned* part;  // per-workgroup maxima: 5 words per prep_desc workgroup, then one per q8_desc workgroup
+    int nb1, nb2;    // ... and how many of each
 };
 __device__ __forceinline__ int prep_find_job(const int* __restrict__ blk_ptr, int n_jobs, int b) {
     int lo = 0, hi = n_jobs - 1;  // largest j with blk_ptr[j] <= b
@@ -314,12 +382,20 @@ __device__ __forceinline__ int prep_find_job(const int* __restrict__ blk_ptr, in
     }
     return lo;
 }
-__global__ __launch_bounds__(64) void prep_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
-    __shared__ __attribute__((aligned(16))) float s_t[64 * kPrepPitch];
+__global__ __launch_bounds__(kPrepThreads) void prep_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
+    __shared__ __attribute__((aligned(16))) PrepLds L;
     const int j = prep_find_job(blk_ptr, n_jobs, (int)blockIdx.x);
     const PrepJob J = jobs[j];
-    prep_desc_rows((int64_t)blockIdx.x - blk_ptr[j], s_t, J.X, J.n, J.ld, J.layout, J.normalize, J.P, J.sq, J.Hf, J.dn, J.stat, J.stat + 1,
-                   J.stat + 4);
+    const int64_t blk = (int64_t)blockIdx.x - blk_ptr[j];
+    prep_desc_rows(blk, L, J.X, J.n, J.ld, J.layout, J.normalize, J.P, J.sq, J.Hf, J.dn, J.part + (size_t)5 * blk);
+}
+__global__ __launch_bounds__(256) void prep_stats_batch_kernel(const PrepJob* __restrict__ jobs, int which) {
+    __shared__ unsigned red[4][5];
+    const PrepJob J = jobs[blockIdx.x];
+    if (which == 1)
+        prep_stats_reduce(J.part, J.nb1, J.stat, J.Hf != nullptr, red);
+    else
+        q8_stats_reduce(J.part + (size_t)5 * J.nb1, J.nb2, J.stat, &red[0][0]);
 }
 
 // Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
@@ -412,7 +488,8 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
                                                       float* __restrict__ qstat, const float* __restrict__ row_sq,
                                                       const float* __restrict__ row_dn, int64_t n_pad,
                                                       const float* __restrict__ maxsq, uint4* __restrict__ aug,
-                                                      float* __restrict__ aug_res) {
+                                                      float* __restrict__ aug_res, unsigned* __restrict__ part_out, unsigned* s_red) {
+    unsigned db_bits = 0u;
     const int64_t i = g >> 3;
     const int part = (int)(g & 7);
     if (part == 0) aug_desc_row(i, row_sq, row_dn, n, n_pad, maxsq, aug, aug_res);
@@ -420,7 +497,7 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
     float xs[16];
     float rmax = 0.f;
     if (i < n) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(P + i * kDim + 16 * part);
+        const GF32x4* src = (const GF32x4*)((const GF32*)P + i * kDim + 16 * part);  // (global, not flat: see prep_desc_rows)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const f32x4 v = src[q4];
@@ -463,8 +540,9 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
             wa[q4] = pa;
             wb[q4] = pb;
         }
-        *reinterpret_cast<uint4*>(QA + i * kDim + 16 * part) = make_uint4(wa[0], wa[1], wa[2], wa[3]);
-        *reinterpret_cast<uint4*>(QB + i * kDim + 16 * part) = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+        typedef __attribute__((address_space(1))) signed char GI8;
+        *(GU32x4*)((GI8*)QA + i * kDim + 16 * part) = u32x4_t{wa[0], wa[1], wa[2], wa[3]};
+        *(GU32x4*)((GI8*)QB + i * kDim + 16 * part) = u32x4_t{wb[0], wb[1], wb[2], wb[3]};
     }
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) {
@@ -476,10 +554,14 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
         dnqa[i] = sqrtf(dsa) * 1.001f;  // 130 roundings of 2^-24 in the sum, one in the root
         invsa[i] = inv_sa;
         sumqa[i] = sq;
-        const float db = sqrtf(dsb) * 1.001f;  // [1]: the largest column-side residual norm of the set
-        if (__float_as_uint(db) > reinterpret_cast<const volatile unsigned*>(qstat)[1])
-            atomicMax(reinterpret_cast<unsigned*>(qstat) + 1, __float_as_uint(db));
+        db_bits = __float_as_uint(sqrtf(dsb) * 1.001f);  // qstat[1]: the largest column-side residual norm of the set
     }
+    // (one word per workgroup, folded by q8_stats_reduce: a look at the running maximum and an atomic per ROW kept this
+    // kernel at a quarter of the rate its bytes move at)
+    db_bits = wave_umax(db_bits);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = db_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) *part_out = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
 __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
@@ -488,15 +570,18 @@ __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ 
                                                       float* __restrict__ qstat, const float* __restrict__ row_sq,
                                                       const float* __restrict__ row_dn, int64_t n_pad,
                                                       const float* __restrict__ maxsq, uint4* __restrict__ aug,
-                                                      float* __restrict__ aug_res) {
+                                                      float* __restrict__ aug_res, unsigned* __restrict__ part) {
+    __shared__ unsigned s_red[4];
     q8_desc_rows(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, P, n, QA, QB, dnqa, invsa, sumqa, qstat, row_sq, row_dn, n_pad, maxsq, aug,
-                 aug_res);
+                 aug_res, part + blockIdx.x, s_red);
 }
 __global__ __launch_bounds__(256) void q8_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
+    __shared__ unsigned s_red[4];
     const int j = prep_find_job(blk_ptr, n_jobs, (int)blockIdx.x);
     const PrepJob J = jobs[j];
-    q8_desc_rows(((int64_t)blockIdx.x - blk_ptr[j]) * (int64_t)blockDim.x + threadIdx.x, J.P, J.n, J.QA, J.QB, J.dnq, J.invs, J.sumq, J.stat + 4,
-                 J.sq, J.dn, J.n_pad, J.stat, J.aug, J.stat + 2);
+    const int64_t blk = (int64_t)blockIdx.x - blk_ptr[j];
+    q8_desc_rows(blk * (int64_t)blockDim.x + threadIdx.x, J.P, J.n, J.QA, J.QB, J.dnq, J.invs, J.sumq, J.stat + 4,
+                 J.sq, J.dn, J.n_pad, J.stat, J.aug, J.stat + 2, J.part + (size_t)5 * J.nb1 + blk, s_red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2184,6 +2269,8 @@ struct Prepared {
     Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
     Ws<float> dnq, invs;
     Ws<int> sumq;
+    Ws<unsigned> part;  // per-workgroup maxima of prep_desc / q8_desc (PrepJob::part)
+    int nb1 = 0, nb2 = 0;
     float* stat = nullptr;  // the eight statistics words: own (maxsq) or a slice of the caller's block (one fill for many sets)
     int64_t n = 0;
 };
@@ -2209,15 +2296,16 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
         explicit MaybeProf(bool on) { if (on) p = new Prof("match_prep"); }
         ~MaybeProf() { delete p; }
     } prof(bracket);
-    prep_desc_kernel<<<cdiv(n, 64), 64, 0, st>>>(X_dev, n, ld, layout, normalize ? 1 : 0,
-                                                        out.P, out.sq, out.H, out.dn, out.stat,
-                                                        out.stat + 1, qstat);
-    q8_desc_kernel<<<cdiv(n_pad * 8, 256), 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn,
-                                                         n_pad, out.stat, out.aug, out.stat + 2);
+    prep_desc_kernel<<<out.nb1, kPrepThreads, 0, st>>>(X_dev, n, ld, layout, normalize ? 1 : 0, out.P, out.sq, out.H, out.dn, out.part);
+    prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 1);
+    q8_desc_kernel<<<out.nb2, 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn, n_pad, out.stat,
+                                            out.aug, out.stat + 2, out.part + (size_t)5 * out.nb1);
+    prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 2);
     check_launch("prep_desc_kernel");
 }
 
-// Several sets in two launches on the caller's stream (prep_desc_batch_kernel, q8_desc_batch_kernel).  stat_ext[s]: the
+// Several sets in four launches on the caller's stream (prep_desc_batch_kernel, q8_desc_batch_kernel, each followed by the fold of
+// its workgroups' maxima, prep_stats_batch_kernel).  stat_ext[s]: the
 // set's eight zeroed statistics words (the caller's block).
 struct PrepRequest {
     const float* X;
@@ -2234,9 +2322,10 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
         if (r.n == 0) continue;
         const Prepared& o = *r.out;
         const int64_t n_pad = (std::max<int64_t>(r.n, 1) + kTNB - 1) / kTNB * kTNB;
-        jobs.push_back(PrepJob{r.X, r.n, r.ld, n_pad, layout, r.normalize ? 1 : 0, o.P, o.sq, o.dn, o.stat, o.H, o.QA, o.QB, o.dnq, o.invs, o.sumq, o.aug});
-        bp.push_back(bp.back() + (int)cdiv(r.n, 64));
-        bq.push_back(bq.back() + (int)cdiv(n_pad * 8, 256));
+        jobs.push_back(PrepJob{r.X, r.n, r.ld, n_pad, layout, r.normalize ? 1 : 0, o.P, o.sq, o.dn, o.stat, o.H, o.QA, o.QB, o.dnq, o.invs, o.sumq, o.aug,
+                               o.part, o.nb1, o.nb2});
+        bp.push_back(bp.back() + o.nb1);
+        bq.push_back(bq.back() + o.nb2);
     }
     if (std::getenv("APS_Q8_SYMMETRIC")) {
         const int sym = 1;
@@ -2250,8 +2339,10 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
     APS_HIP(hipMemcpyAsync(dbq, bq.data(), bq.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
     {
         Prof prof("match_prep");
-        prep_desc_batch_kernel<<<(unsigned)bp.back(), 64, 0, stream()>>>(dj, dbp, (int)jobs.size());
+        prep_desc_batch_kernel<<<(unsigned)bp.back(), kPrepThreads, 0, stream()>>>(dj, dbp, (int)jobs.size());
+        prep_stats_batch_kernel<<<(unsigned)jobs.size(), 256, 0, stream()>>>(dj, 1);
         q8_desc_batch_kernel<<<(unsigned)bq.back(), 256, 0, stream()>>>(dj, dbq, (int)jobs.size());
+        prep_stats_batch_kernel<<<(unsigned)jobs.size(), 256, 0, stream()>>>(dj, 2);
     }
     check_launch("prep_desc_batch_kernel");
     APS_HIP(hipStreamSynchronize(stream()));  // the host tables (and dj / dbp / dbq) must outlive the launches
@@ -2278,6 +2369,9 @@ static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_
     out.dnq.alloc(rows);
     out.invs.alloc(rows);
     out.sumq.alloc(rows);
+    out.nb1 = (int)cdiv(rows, kPrepRows);
+    out.nb2 = (int)cdiv((size_t)n_pad * 8, 256);
+    out.part.alloc((size_t)5 * out.nb1 + out.nb2);
 }
 
 static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, int64_t out_off) {
@@ -2975,15 +3069,15 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     if (!t3_idx || slots == 0) return slots;
     APS_REQUIRE(slots < ((int64_t)1 << 31), APS_E_DIM, "too many (row, image) pairs for one pass (%lld)", (long long)slots);
     std::vector<Prepared> prep(n);
-    {  // the images' operand forms, eight chains of small launches side by side (as in match_pairs_impl)
-        constexpr int kPrepStreams = 8;
-        AuxScope fork(kPrepStreams);
-        Prof prof("match_prep");
+    Ws<float> prep_stats((size_t)8 * std::max(n, 1));
+    {  // the images' operand forms: every set in one batch of launches (as in match_pairs_impl)
+        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)8 * std::max(n, 1) * sizeof(float), stream()));
+        std::vector<PrepRequest> req;
         for (int b = 0; b < n; ++b) {
             const float* xb = layout == APS_ROWMAJOR ? X_dev + (size_t)img_off[b] * ld : X_dev + img_off[b];
-            prepare(xb, img_off[b + 1] - img_off[b], ld, layout, false, prep[b], fork.streams[b % kPrepStreams], false);
+            req.push_back({xb, img_off[b + 1] - img_off[b], ld, false, &prep[b], prep_stats.get() + 8 * b});
         }
-        fork.join();
+        prepare_batch(req, layout);
     }
     // ---- the int8 screen over every ordered pair of different images: bounds per (row, image) ----
     std::vector<MatchJob> jobs;
