@@ -19,6 +19,8 @@
 #include <memory>
 #include <vector>
 
+#include <functional>
+
 #include "render_dev.h"
 
 namespace aps {
@@ -1071,11 +1073,36 @@ struct PreparedImages {
     std::vector<ImgJob> jobs;
     Ws<DevImage> dev;
     Ws<ImgJob> djobs;
+    std::vector<char> converted;   // image i's pixels and tent tables are in place
+    std::vector<std::vector<ImgJob>> sel;  // the job lists of the convert_images() calls (host copies kept until the entry point returns)
 };
 
+// Pixels (uint8 -> packed RGBA words) and tent tables of the images marked in `used` (all when null) that have not been converted
+// yet.  A rank of a sharded render only meets the views its tiles show - a third of them at 8 ranks on the 64-view scene - and
+// converting all 64 was a quarter of its render's kernel time.
+static void convert_images(PreparedImages& P, const std::vector<char>* used) {
+    const int n = (int)P.jobs.size();
+    std::vector<ImgJob> sel;
+    int max_len = 1;
+    for (int i = 0; i < n; ++i) {
+        if (P.converted[i] || (used && !(*used)[i])) continue;
+        P.converted[i] = 1;
+        sel.push_back(P.jobs[i]);
+        max_len = std::max(max_len, std::max(P.jobs[i].h, P.jobs[i].w));
+    }
+    if (sel.empty()) return;
+    const int m = (int)sel.size();
+    P.sel.push_back(std::move(sel));
+    APS_HIP(hipMemcpyAsync(P.djobs, P.sel.back().data(), m * sizeof(ImgJob), hipMemcpyHostToDevice, stream()));
+    to_rgba_batch_kernel<<<dim3(512, m), 256, 0, stream()>>>(P.djobs);
+    tent_batch_kernel<<<dim3(cdiv(max_len, 256), 2 * m), 256, 0, stream()>>>(P.djobs);
+    check_launch("to_rgba_batch_kernel");
+}
+
 // No synchronisation here: the host tables are members of P and outlive the stream work of the calling entry point.
-static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
+static void prepare_images(const aps_image* images, int n, PreparedImages& P, bool convert_now = true) {
     P.src.resize(n);
+    P.converted.assign(n, 0);
     P.host.resize(n);
     P.jobs.resize(n);
     size_t px_total = 0, tent_total = 0;
@@ -1136,10 +1163,8 @@ static void prepare_images(const aps_image* images, int n, PreparedImages& P) {
     P.dev.alloc(n);
     P.djobs.alloc(n);
     APS_HIP(hipMemcpyAsync(P.dev, P.host.data(), n * sizeof(DevImage), hipMemcpyHostToDevice, stream()));
-    APS_HIP(hipMemcpyAsync(P.djobs, P.jobs.data(), n * sizeof(ImgJob), hipMemcpyHostToDevice, stream()));
-    to_rgba_batch_kernel<<<dim3(512, n), 256, 0, stream()>>>(P.djobs);
-    tent_batch_kernel<<<dim3(cdiv(max_len, 256), 2 * n), 256, 0, stream()>>>(P.djobs);
-    check_launch("to_rgba_batch_kernel");
+    (void)max_len;
+    if (convert_now) convert_images(P, nullptr);
 }
 
 static DevCanvas make_canvas(const aps_canvas& c) {
@@ -1267,7 +1292,8 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         }
         ctx();
         PreparedImages P;
-        prepare_images(images, n_img, P);
+        prepare_images(images, n_img, P, false);  // tables now, pixels once the tiles' footprints say which images are met
+        const std::function<void(const std::vector<char>&)> convert = [&P](const std::vector<char>& used) { convert_images(P, &used); };
         const DevCanvas cv = make_canvas(*canvas);
         const int H = cv.H, W = cv.W;
         const size_t HW = (size_t)H * W;
@@ -1296,7 +1322,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         // multiband: all tiles level-major in one launch sequence (render_batch.hip); APS_RENDER_LEGACY=1 keeps the
         // per-tile path below, whose arithmetic the batched kernels reproduce bit for bit
         if (opts->blending == APS_BLEND_MULTIBAND && !std::getenv("APS_RENDER_LEGACY") &&
-            render_multiband_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr)) {
+            render_multiband_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr, convert)) {
             oP.commit();
             oC.commit();
             APS_HIP(hipStreamSynchronize(stream()));
@@ -1305,12 +1331,13 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         // 'linear' / 'none': one fused launch over all tiles (render_batch.hip, rw_fuse_kernel); APS_RENDER_LEGACY=1 keeps the
         // per-tile kernels below, whose bytes it reproduces
         if (opts->blending != APS_BLEND_MULTIBAND && !std::getenv("APS_RENDER_LEGACY") &&
-            render_fuse_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr)) {
+            render_fuse_batched(P.dev, P.host.data(), n_img, cv, *opts, tiles, out_layout, oP, oC.present() ? oC.get() : nullptr, convert)) {
             oP.commit();
             oC.commit();
             APS_HIP(hipStreamSynchronize(stream()));
             return;
         }
+        convert_images(P, nullptr);  // the per-tile path below samples whatever its cover pass finds
         // phase 1: footprint of every image in every tile (the reference skips images with ~any(Mi), :989;
         // here the bounding box of Mi also bounds all later work on that layer); one read-back
         std::vector<int> hbox((size_t)nt * n_img * 4, 0);

@@ -1761,7 +1761,8 @@ static void tile_footprints(const RwArgs& A, const DevImage* himgs, int n_img, c
 }  // namespace
 
 bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
-                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered) {
+                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered,
+                              const NeedImages& need_images) {
     const int nt = (int)tiles.size();
     if (nt == 0) return true;
     const Taps tp = make_taps(o.pyr_sigma);
@@ -1918,6 +1919,11 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
         T.ne = (int)ents.size() - T.e0;
     }
     const int ne = (int)ents.size();
+    {  // the images these tiles meet: their pixels are needed from here on
+        std::vector<char> used(n_img, 0);
+        for (const RwEntry& E : ents) used[E.img] = 1;
+        need_images(used);
+    }
     if (std::getenv("APS_RENDER_DEBUG")) {
         long long rect0 = 0, canvas = 0;
         for (const RwEntry& E : ents) rect0 += (long long)(E.g[0].x1 - E.g[0].x0) * (E.g[0].y1 - E.g[0].y0);
@@ -2036,7 +2042,8 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
 
 // 'linear' / 'none': all tiles in one launch (rw_fuse_kernel).  Same tile list and footprints as the multiband form.
 bool render_fuse_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
-                         const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered) {
+                         const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered,
+                         const NeedImages& need_images) {
     const int nt = (int)tiles.size();
     if (nt == 0) return true;
     if (o.blending != APS_BLEND_LINEAR && o.blending != APS_BLEND_NONE) return false;
@@ -2093,6 +2100,11 @@ bool render_fuse_batched(const DevImage* dimgs, const DevImage* himgs, int n_img
             ents.push_back(E);
         }
         T.ne = (int)ents.size() - T.e0;
+    }
+    {
+        std::vector<char> used(n_img, 0);
+        for (const RwEntry& E : ents) used[E.img] = 1;
+        need_images(used);
     }
     // every tile is painted (a tile without layers gets the canvas colour): blocks over the level-0 grid of all tiles
     std::vector<int> blk0(nt + 1, 0);

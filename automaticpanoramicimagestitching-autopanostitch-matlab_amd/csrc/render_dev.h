@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <vector>
 
 #include "aps_internal.h"
@@ -255,9 +256,14 @@ struct TileRect {
 // Renders the given tiles of the canvas with multiband blending, all tiles in one launch sequence.  dimgs: the
 // prepared device image table, himgs its host copy (the analytic footprints read the cameras there).  pano/covered are DEVICE pointers.  Returns false when the configuration is outside
 // what the batched kernels are built for (the caller then takes the per-tile path).
+// need_images(used): called once, before the first kernel that samples pixels, with used[i] != 0 for every image that meets one
+// of the tiles - the caller converts those images' pixels then (and no others).
+using NeedImages = std::function<void(const std::vector<char>& used)>;
 bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
-                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered);
+                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered,
+                              const NeedImages& need_images);
 bool render_fuse_batched(const DevImage* dimgs, const DevImage* himgs, int n_img, const DevCanvas& cv, const aps_render_opts& o,
-                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered);
+                              const std::vector<TileRect>& tiles, int out_layout, uint8_t* pano, uint8_t* covered,
+                              const NeedImages& need_images);
 
 }  // namespace aps
