@@ -85,10 +85,12 @@ def _grid_rays(cam, H, W, nx=48, ny=32, border=0):
     return np.asarray(cam["R"], np.float64).T @ rayC
 
 
-def _all_grid_rays(cams, imgSize, border=0):
+def _all_grid_rays(cams, imgSize, border=0, stacked=False):
     """_grid_rays of every camera, batched per image size (one LAPACK call and one matrix product for all cameras of
-    a size; the per-camera results are the same numbers as the one-at-a-time form)."""
+    a size; the per-camera results are the same numbers as the one-at-a-time form).  stacked: the per-size stacks
+    (n_cameras_of_that_size x 3 x points) instead of one array per camera, for callers that only reduce over everything."""
     out = [None] * len(cams)
+    stacks = []
     groups = {}
     for i in range(len(cams)):
         groups.setdefault((int(imgSize[i][0]), int(imgSize[i][1])), []).append(i)
@@ -105,16 +107,18 @@ def _all_grid_rays(cams, imgSize, border=0):
                 _RAYC_CACHE.clear()
             rayC = _RAYC_CACHE[key] = _solve_K(Ks, np.broadcast_to(xy1, (len(ids),) + xy1.shape))
         rays = Rt @ rayC
+        stacks.append(rays)
         for q, i in enumerate(ids):
             out[i] = rays[q]
-    return out
+    return stacks if stacked else out
 
 
 def sphericalBounds(cams, imgSize):
     """renderPanorama.m:1544-1579."""
     tmin = pmin = math.inf
     tmax = pmax = -math.inf
-    for x, y, z in _all_grid_rays(cams, imgSize):
+    for rays in _all_grid_rays(cams, imgSize, stacked=True):  # (all cameras of a size at once: the same elementwise values)
+        x, y, z = rays[:, 0], rays[:, 1], rays[:, 2]
         th = np.arctan2(x, z)
         ph = np.arctan2(y, np.hypot(x, z))
         tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
@@ -126,7 +130,8 @@ def cylindricalBounds(cams, imgSize):
     """renderPanorama.m:1507-1542."""
     tmin = hmin = math.inf
     tmax = hmax = -math.inf
-    for x, y, z in _all_grid_rays(cams, imgSize):
+    for rays in _all_grid_rays(cams, imgSize, stacked=True):
+        x, y, z = rays[:, 0], rays[:, 1], rays[:, 2]
         th = np.arctan2(x, z)
         hh = y / np.hypot(x, z)
         tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
