@@ -1292,7 +1292,9 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         }
         ctx();
         PreparedImages P;
-        prepare_images(images, n_img, P, false);  // tables now, pixels once the tiles' footprints say which images are met
+        // all tiles: every image's pixels at once, converted while the host works out the footprints; a share of the tiles (a
+        // rank of a sharded render): tables now, pixels once the footprints say which images the share meets
+        prepare_images(images, n_img, P, tile_step == 1);
         const std::function<void(const std::vector<char>&)> convert = [&P](const std::vector<char>& used) { convert_images(P, &used); };
         const DevCanvas cv = make_canvas(*canvas);
         const int H = cv.H, W = cv.W;

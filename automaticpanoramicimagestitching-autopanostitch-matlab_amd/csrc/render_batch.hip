@@ -26,6 +26,8 @@
 #include <map>
 #include <vector>
 
+#include <chrono>
+
 #include "render_dev.h"
 
 namespace aps {
@@ -1765,6 +1767,12 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
                               const NeedImages& need_images) {
     const int nt = (int)tiles.size();
     if (nt == 0) return true;
+    const bool trace = std::getenv("APS_TRACE") != nullptr;  // host phases of this call on stderr
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto T0 = t_now();
     const Taps tp = make_taps(o.pyr_sigma);
     APS_REQUIRE(tp.r >= 1 && tp.r <= 4, APS_E_ARG, "pyrSigma %g needs a %d-tap filter; 3..9 taps are built",
                 (double)o.pyr_sigma, 2 * tp.r + 1);
@@ -1885,8 +1893,10 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
     A.rt = d_rt;
 
     // ---- pass 1: the footprint rectangle of every image in every tile ----------------------------------------------
+    const auto T1 = t_now();
     std::vector<int> hbox;
     tile_footprints(A, himgs, n_img, ht_, xshift, d_xshift, d_tiles, max_ht, max_wt, hbox);
+    const auto T2 = t_now();
 
     // ---- entries, compact stores, block tables ----------------------------------------------------------------
     std::vector<RwEntry> ents;
@@ -1977,6 +1987,7 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
         p[nt] = (int)run;
         up_blocks[l] = (int)run;
     }
+    const auto T3 = t_now();
     Ws<RwEntry> d_ents(std::max(ne, 1));
     Ws<int> d_blk(blk.size()), d_blk0(blk0.size());
     APS_HIP(hipMemcpyAsync(d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
@@ -2033,9 +2044,13 @@ bool render_multiband_batched(const DevImage* dimgs, const DevImage* himgs, int 
             check_launch("rw_up_kernel");
         }
     }
+    const auto T4 = t_now();
     int status = 0;
     APS_HIP(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream()));
     APS_HIP(hipStreamSynchronize(stream()));  // also keeps the host tables alive until their uploads have run
+    if (trace)
+        std::fprintf(stderr, "[aps render] host: tiles + tap tables %.2f ms, footprints %.2f, entries + block tables %.2f, uploads + launches %.2f, wait for the kernels %.2f\n",
+                     t_ms(T0, T1), t_ms(T1, T2), t_ms(T2, T3), t_ms(T3, T4), t_ms(T4, t_now()));
     APS_REQUIRE(status == 0, APS_E_INTERNAL, "batched render: tap table assumption violated (status %d)", status);
     return true;
 }
