@@ -245,10 +245,10 @@ def cameras_from_models(n, pairs, models, num_matches, Ks):
                 Kinv[i] = np.linalg.inv(Ks[i])
             Ms.append(Kinv[i] @ models[p] @ Ks[j])  # ~ R_i R_j'
         U, _, Vt = np.linalg.svd(np.stack(Ms))
+        Rall = U @ Vt  # (stacked products and determinants: the per-matrix routines, called once)
+        Rall = np.where((np.linalg.det(Rall) < 0)[:, None, None], -Rall, Rall)
         for e, (a, b, p, inv) in enumerate(edges):
-            Rij = U[e] @ Vt[e]
-            if np.linalg.det(Rij) < 0:
-                Rij = -Rij
+            Rij = Rall[e]
             # a == i, b == j: R_j = Rij' R_i ; a == j, b == i: R_i = Rij R_j
             R[b] = Rij.T @ R[a] if not inv else Rij @ R[a]
     cams = [({"K": Ks[k], "R": R[k], "f": float(Ks[k][0, 0]), "noRotation": 0} if k in R else None) for k in range(n)]

@@ -1,0 +1,13 @@
+import re
+src = open("scripts/probe_rank_costs.py").read()
+# keep everything up to the host() definition and profile it
+cut = src.index("host()  # (the first call pays imports)")
+code = src[:cut] + '''
+import cProfile, pstats
+host()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20): host()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+'''
+exec(compile(code, "probe", "exec"))
