@@ -358,9 +358,8 @@ __global__ __launch_bounds__(kPrepThreads) void prep_desc_kernel(const float* __
 }
 
 // Every set of a pair batch in ONE launch (round 4): block b belongs to job j with blk_ptr[j] <= b < blk_ptr[j + 1].
-// (Round 2 measured a batched launch at 7.3 ms against 2.1 for eight streams of per-set launches - with the whole-row tile,
-// four workgroups per CU.  With the half-row tile eight fit, and the per-set chains of ~128 small launches on streams that
-// share hardware queues had become the cost: 2.0 ms for 64 sets, 0.85 ms for the 25 sets of one rank of eight.)
+// (History: round 2 measured a batched launch at 7.3 ms against 2.1 for eight streams of per-set launches, early round 4 both
+// at 2.0 - all of them the statistics' atomics, see prep_stats_reduce: 0.5 ms for 64 sets now.)
 struct PrepJob {
     const float* X;
     int64_t n, ld, n_pad;
@@ -3409,10 +3408,8 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
         (norm ? need_nrm : need_raw)[pa[p]] = 1;
         (norm ? need_nrm : need_raw)[pb[p]] = 1;
     }
-    {  // the sets are independent chains of small launches: eight of them side by side.  (Measured and dropped: all sets in
-       // ONE prep_desc launch and ONE q8_desc launch - 7.3 ms against 2.1: a prep_desc workgroup is one wave with 34 KB of
-       // LDS and ~100 us of dependent work, four of them fit a CU, and 19.8 k workgroups in 19 rounds of that latency are no
-       // faster than eight streams of 310; the lever would be the workgroup's own latency, not the launch count.)
+    {  // every set of the batch in four launches (prepare_batch); APS_MATCH_PREP_STREAMS=1 keeps the older form, one chain of
+       // launches per set on eight forked streams
         constexpr int kPrepStreams = 8;
         APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)16 * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
         if (!std::getenv("APS_MATCH_PREP_STREAMS")) {  // round 4: every set in two launches (see prep_desc_batch_kernel)
