@@ -126,6 +126,7 @@ _SIGNATURES = {
     "aps_ransac_draws_exhausted": [],
     "aps_gather_match_points": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64],
     "aps_match_screen_stats": [_vp, _vp],
+    "aps_match_set_stats": [_vp, _i64, _i64, C.c_int, C.c_int, _vp],
     "aps_global_normalize": [_vp, _i64, _i64, _i, _i, _vp],
     "aps_knn_hamming": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64],
     "aps_ba_pair_blocks": [_vp, _vp, _i64, _vp, _i, _vp, _d, _i, _vp],

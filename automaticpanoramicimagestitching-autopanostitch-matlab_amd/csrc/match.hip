@@ -3523,6 +3523,36 @@ int aps_match_pairs(const float* const* desc, const int64_t* counts, const int64
 
 }  // extern "C"
 
+extern "C" int aps_match_set_stats(const float* X, int64_t n, int64_t ld, int layout, int normalize, float* stats) {
+    using namespace aps;
+    return guarded([&] {
+        APS_REQUIRE(X != nullptr && stats != nullptr, APS_E_ARG, "NULL argument");
+        APS_REQUIRE(n >= 1, APS_E_DIM, "need at least one row");
+        APS_REQUIRE(layout == APS_ROWMAJOR || layout == APS_COLMAJOR, APS_E_ARG, "unknown layout");
+        APS_REQUIRE(layout == APS_ROWMAJOR ? ld >= kDim : ld >= n, APS_E_DIM, "leading dimension too small");
+        ctx();
+        In<float> dx;
+        dx.bind(X, layout == APS_ROWMAJOR ? (size_t)(n - 1) * ld + kDim : (size_t)(kDim - 1) * ld + n);
+        Prepared p;
+        prepare(dx, n, ld, layout, normalize != 0, p);
+        float raw[8];
+        APS_HIP(hipMemcpyAsync(raw, p.stat, sizeof raw, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipStreamSynchronize(stream()));
+        // the int8 words are stored as order-preserving integers (complemented where a minimum is kept as a maximum)
+        auto bits = [&](int k) { unsigned u; std::memcpy(&u, &raw[k], 4); return u; };
+        auto unord = [](unsigned k) { const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+        auto as_f = [](unsigned u) { float f; std::memcpy(&f, &u, 4); return f; };
+        stats[0] = raw[0];
+        stats[1] = raw[1];
+        stats[2] = raw[2];
+        stats[3] = raw[3];
+        stats[4] = unord(bits(4));
+        stats[5] = raw[5];
+        stats[6] = as_f(~bits(6));
+        stats[7] = unord(~bits(7));
+    });
+}
+
 #ifdef APS_DBG
 // co-run experiment (scripts/probe_overlap_race3.py): a workgroup that only occupies a CU's resources for a while
 namespace aps {

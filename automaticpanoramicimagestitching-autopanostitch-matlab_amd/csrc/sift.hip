@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // The haloed input tile is fetched in 16-byte pieces: the horizontal halo is rounded up to a multiple of four
     // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
     // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
-    constexpr int RP = (R + 3) & ~3, OFF = RP - R;
+    constexpr int RP = (R + 3) & ~3;
     constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
     static_assert(IH % 2 == 0 && kTH % 4 == 0, "row pairs");
     // Both passes run two fma chains per v_pk_fma_f32, and a packed operand must be an aligned register pair.  A pair

@@ -136,6 +136,14 @@ int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2
  * row that can pass it); the counters exist for benchmarks and for tests that guard against a silently disabled screen. */
 int aps_match_screen_stats(int64_t* rows, int64_t* survivors);
 
+/* Diagnostics: the eight statistics words the matcher's proofs take from ONE descriptor set (n x 128 f32, `normalize` != 0:
+ * rows L2-normalised first as matchFeaturesScratch.m:232-233 does), as the preparation kernels compute them (maxima over
+ * all rows, folded from per-workgroup maxima): stats[0] = max ||x||^2 (canonical k-ascending f32 sum), [1] = max ||x - f16(x)||
+ * (rounded up), [2], [3] = residuals of the f16 norm pieces (0 for ordinary data), [4] = max x, [5] = max column-side int8
+ * residual norm (rounded up), [6] = min ||x||^2, [7] = min x.  Host output.  For tests: a statistic that misses a row makes
+ * a bound unsound without changing any result on ordinary data. */
+int aps_match_set_stats(const float* X, int64_t n, int64_t ld, int layout, int normalize, float* stats);
+
 /* a3: featureMatchingPairwise (featureMatchingPairwise.m:48-63): all upper-triangular image pairs
  * in the reference's order (column-major linear index of triu(.,1): (1,2),(1,3),(2,3),(1,4),...),
  * each through aps_match_features' rule, in ONE batched launch sequence.

@@ -645,3 +645,58 @@ def test_pooled_survivor_tiles_of_unequal_sets_equal_per_job_lists_and_oracle(fm
             got = np.stack([ia[pp[p]:pp[p + 1]], ib[pp[p]:pp[p + 1]]], axis=1).astype(np.int64)
             assert np.array_equal(got, om.astype(np.int64)), (unit, i, j)
             assert np.array_equal(met[pp[p]:pp[p + 1]].view(np.uint32), np.asarray(omet, np.float32).view(np.uint32)), (unit, i, j)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 129, 1000, 19801])
+@pytest.mark.parametrize("layout", ["row", "col"])
+def test_set_statistics_see_every_row(gpu, n, layout):
+    """The proofs of the screening passes rest on statistics of a whole descriptor set (largest and smallest ||x||^2, largest
+    and smallest element, largest rounding losses).  They are maxima over all rows, folded from per-workgroup maxima
+    (prep_stats_reduce): a fold that misses a workgroup - the last, ragged one above all - would make bounds unsound without
+    changing any result on ordinary data.  The extreme rows are planted at the first row, the last row and the first row of
+    the last 64-row workgroup in turn, and the words are compared with the same quantities computed on the host."""
+    import ctypes as C
+
+    capi = gpu._capi
+    rng = np.random.default_rng(1000 + n)
+    f32 = np.float32
+
+    def seq_sq(x):  # canonical ||x||^2: k-ascending f32 sum of f32 squares
+        s = np.zeros(x.shape[0], f32)
+        for k in range(x.shape[1]):
+            s = (s + x[:, k] * x[:, k]).astype(f32)
+        return s
+
+    for where in sorted({0, n - 1, (n - 1) // 64 * 64}):
+        x = (rng.random((n, 128), dtype=f32) * 0.1 + 0.01).astype(f32)  # entries 0.01 .. 0.11: ||x||^2 ~ 0.6
+        x[where] = 0.0
+        x[where, 0:128:2] = f32(0.9173)         # the largest norm and the largest element ...
+        x[where, 5] = f32(-0.7331)              # ... and the smallest element live in the planted row
+        small = (where + 1) % n
+        if n > 1:
+            x[small] = f32(1e-3) * (1.0 + rng.random(128, dtype=f32))  # the smallest norm next to it (cyclically)
+        xin = np.ascontiguousarray(x) if layout == "row" else np.asfortranarray(x)
+        ld = 128 if layout == "row" else n
+        out = np.zeros(8, f32)
+        capi.check(capi.lib.aps_match_set_stats(capi.ptr(xin), n, ld, capi.APS_ROWMAJOR if layout == "row" else capi.APS_COLMAJOR,
+                                                0, capi.ptr(out)))
+        sq = seq_sq(x)
+        assert out[0] == sq.max() and out[6] == sq.min(), (n, where, out, sq.max(), sq.min())
+        assert out[4] == x.max() and out[7] == x.min(), (n, where, out)
+        # rounding losses: at least the true f64 loss of the worst row, at most a few per cent above it
+        h = x.astype(np.float16).astype(np.float64)
+        h[np.abs(h) < 6.103515625e-05] = 0.0
+        dn = np.sqrt(((x.astype(np.float64) - h) ** 2).sum(1)).max()
+        assert dn <= out[1] <= dn * 1.01 + 1e-12, (n, where, out[1], dn)
+        step = (float(x.max()) - float(x.min())) / 255.0
+        cb = np.rint(np.float64(f32(x.min()) * f32(f32(255.0) / f32(x.max() - x.min())))) + 128.0
+        qb = np.clip(np.rint(x.astype(np.float64) / step) - cb, -128, 127)
+        db = np.sqrt(((x.astype(np.float64) - (qb + cb) * step) ** 2).sum(1)).max()
+        assert 0.9 * db <= out[5] <= 1.1 * db + 1e-9, (n, where, out[5], db)
+        assert 0.0 <= out[2] < 1e-6 and out[3] == 0.0  # ([2]: what three f16 pieces lose of b2/2 when a set's norms lie far apart)
+    # normalised rows: every norm is 1 up to rounding, the extremes follow the rows
+    xn = (rng.random((n, 128), dtype=f32) * 50.0).astype(f32)
+    out = np.zeros(8, f32)
+    capi.check(capi.lib.aps_match_set_stats(capi.ptr(xn), n, 128, capi.APS_ROWMAJOR, 1, capi.ptr(out)))
+    assert abs(out[0] - 1.0) < 1e-5 and abs(out[6] - 1.0) < 1e-5 and 0.0 <= out[7] < out[4] < 1.0
