@@ -455,7 +455,11 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         else:
             ldesc, lkps = {}, {}
             if mine_img:
-                for i, (d, p) in zip(mine_img, pl.sift_many(input, [local_images[i] for i in mine_img], ready=ready)):
+                # an image's keypoints go back to the device as soon as that image is done, while the workers extract the
+                # next ones (64 small uploads after the last image were 2 ms of every step)
+                futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready)
+                for i, f in zip(mine_img, futs):
+                    d, p = f.result()
                     ldesc[i] = d
                     lkps[i] = torch.from_numpy(p).to(dev)
             times.add("features", t0)
