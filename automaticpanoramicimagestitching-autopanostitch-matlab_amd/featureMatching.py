@@ -287,13 +287,17 @@ def match_pairs_csr(allDescriptors, pairs, MaxRatio, MatchThreshold, Unique=True
     ptrs = (C.c_void_p * n)(*[ptr(p[0]) if p[1] > 0 else None for p in prepared])
     counts = (C.c_int64 * n)(*[p[1] for p in prepared])
     lds = (C.c_int64 * n)(*[max(p[2], DIM if layout == _capi.APS_ROWMAJOR else p[1]) for p in prepared])
-    pa = np.ascontiguousarray([p[0] for p in pairs], np.int32)
-    pb = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+    if isinstance(pairs, np.ndarray):  # [P, 2] (pair_order_array and slices of it)
+        pa = np.ascontiguousarray(pairs[:, 0], np.int32)
+        pb = np.ascontiguousarray(pairs[:, 1], np.int32)
+    else:
+        pa = np.ascontiguousarray([p[0] for p in pairs], np.int32)
+        pb = np.ascontiguousarray([p[1] for p in pairs], np.int32)
     P = len(pairs)
     pair_ptr = np.zeros(P + 1, np.int64)
     o = _opts(MaxRatio, MatchThreshold, Unique, normalize)
     cnt = C.c_int64(0)
-    rows = sum(prepared[a][1] for a in pa.tolist())
+    rows = int(np.asarray([p[1] for p in prepared], np.int64)[pa].sum()) if P else 0
     # resident outputs: room for every row (uninitialised device memory from torch's cache costs nothing, and a second
     # pass over all pairs after APS_E_CAP costs the whole matcher again - well-overlapping small sets keep more than a
     # sixteenth of their rows); host outputs: a sixteenth, grown on demand
@@ -331,6 +335,19 @@ def pair_order(numImg):
     if numImg not in _PAIR_ORDER:
         _PAIR_ORDER[numImg] = [(i, j) for j in range(1, numImg) for i in range(j)]
     return _PAIR_ORDER[numImg]
+
+
+_PAIR_ORDER_ARR = {}
+
+
+def pair_order_array(numImg):
+    """pair_order as a read-only int32 array [P, 2] (cached): match_pairs_csr takes it without walking 2016 tuples."""
+    numImg = int(numImg)
+    if numImg not in _PAIR_ORDER_ARR:
+        a = np.asarray(pair_order(numImg), np.int32).reshape(-1, 2)
+        a.setflags(write=False)
+        _PAIR_ORDER_ARR[numImg] = a
+    return _PAIR_ORDER_ARR[numImg]
 
 
 def featureMatchingPairwise(input, allDescriptors, numImg):

@@ -473,16 +473,22 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
 
         # 3) match: pair list partitioned by N_i * N_j; the index lists stay on the device
         t0 = time.perf_counter()
-        w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
-        pown = partition_pairs_blocked(order, w, n, ws) if _multi(ws) else np.zeros(len(order), np.int64)
-        my = [p for p in range(len(order)) if pown[p] == rank]
+        if _multi(ws):
+            w = [float(counts[i]) * float(counts[j]) for (i, j) in order]
+            pown = partition_pairs_blocked(order, w, n, ws)
+            my = [p for p in range(len(order)) if pown[p] == rank]
+            my_pairs = [order[p] for p in my]
+        else:  # (one rank: every pair, handed over as the cached array - no per-step walk over 2016 tuples)
+            pown = np.zeros(len(order), np.int64)
+            my = slice(None)
+            my_pairs = fm.pair_order_array(n)
         if use_global:
             # featureMatchingGlobal (the reference's default, inputs.m:46): pooled exact k-NN + per-query filter.  Every rank
             # holds all descriptors after the exchange and computes the (deterministic) result itself: no further exchange.
             pp, ia_d, ib_d = fm.match_global_csr(descs, input["Ratiothreshold"], int(input.get("k", 4)), device_out=True)
-            my = list(range(len(order)))
+            my = slice(None)
         else:
-            pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, [order[p] for p in my], input["Ratiothreshold"],
+            pp, ia_d, ib_d, _ = fm.match_pairs_csr(descs, my_pairs, input["Ratiothreshold"],
                                                    input["Matchingthreshold"], True, device_out=not host_lists)
     if host_lists and not use_global:
         ia_d = torch.from_numpy(ia_d.astype(np.int32)).to(dev)
