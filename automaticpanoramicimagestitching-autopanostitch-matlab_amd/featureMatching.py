@@ -389,11 +389,13 @@ def _fence_fresh_blocks():
     torch.cuda.current_stream().synchronize()
 
 
-def sift_extract(input, image, device_out=False, want_aux=False):
+def sift_extract(input, image, device_out=False, want_aux=False, points_device=False):
     """aps_sift_extract with automatic capacity: returns (features, validPts[, aux]).
 
     image: H x W x 3 or H x W uint8, numpy (host) or torch (host/device), row-major.
-    device_out=True keeps the descriptors on the GPU (torch float32 [n,128]) for the resident pipeline."""
+    device_out=True keeps the descriptors on the GPU (torch float32 [n,128]) for the resident pipeline;
+    points_device=True (with device_out) leaves the keypoints there as well (torch float64 [n,2]) instead of bringing
+    them to the host - the resident pipeline only ever hands them back to the device (aps_gather_match_points)."""
     if _capi.is_torch(image):
         img = image.contiguous()
         h, w = int(img.shape[0]), int(img.shape[1])
@@ -415,7 +417,11 @@ def sift_extract(input, image, device_out=False, want_aux=False):
             _fence_fresh_blocks()
         else:
             desc = np.zeros((cap, DIM), np.float32)
-        loc = np.zeros((2, cap), np.float64)  # column-major cap x 2
+        if device_out and points_device:
+            loc = torch.empty((2, cap), dtype=torch.float64, device="cuda")
+            _fence_fresh_blocks()
+        else:
+            loc = np.zeros((2, cap), np.float64)  # column-major cap x 2
         aux = np.zeros((cap, 4), np.float32) if want_aux else None
         rc = lib.aps_sift_extract(ptr(img), h, w, c, _capi.APS_IMG_U8_HWC, C.byref(prm), ptr(desc),
                                   _capi.APS_ROWMAJOR, DIM, ptr(loc), cap, ptr(aux), cap, C.byref(cnt))
@@ -425,7 +431,12 @@ def sift_extract(input, image, device_out=False, want_aux=False):
         check(rc)
         break
     n = cnt.value
-    pts = np.ascontiguousarray(loc[:, :n].T)
+    dev_pts = device_out and points_device
+    if dev_pts:
+        check(lib.aps_synchronize())  # (with every output resident the call returns without waiting for its last kernel)
+        pts = loc[:, :n].t().contiguous()
+    else:
+        pts = np.ascontiguousarray(loc[:, :n].T)
     # the capacity buffer is sized for the worst case (H*W/64 rows = 66 MB for a 4K view): hand back a right-sized copy
     # instead of a view that keeps it alive (64 views would pin ~4 GB); the library synchronised its stream above
     if device_out:

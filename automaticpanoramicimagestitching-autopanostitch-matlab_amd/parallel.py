@@ -88,6 +88,10 @@ def _gather(t, parts, dst):
         dist.gather(t, parts, dst=dst)
 
 
+def _is_cuda_tensor(x):
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
 def shard_indices(n, world_size, rank):
     """Image i lives on rank i % world (block-cyclic keeps pixel counts balanced for equal-size images)."""
     return [i for i in range(n) if i % world_size == rank]
@@ -455,13 +459,14 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         else:
             ldesc, lkps = {}, {}
             if mine_img:
-                # an image's keypoints go back to the device as soon as that image is done, while the workers extract the
-                # next ones (64 small uploads after the last image were 2 ms of every step)
-                futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready)
+                # resident images: the keypoints never leave the device (the host copy and the 64 small uploads after the last
+                # image were 2 ms of every step); host images: uploaded as soon as their image is done
+                resident = dev.type == "cuda" and all(_is_cuda_tensor(local_images[i]) for i in mine_img)
+                futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready, points_device=resident)
                 for i, f in zip(mine_img, futs):
                     d, p = f.result()
                     ldesc[i] = d
-                    lkps[i] = torch.from_numpy(p).to(dev)
+                    lkps[i] = p if resident else torch.from_numpy(p).to(dev)
             times.add("features", t0)
             t0 = time.perf_counter()
             descs = [ldesc[i] for i in range(n)]

@@ -102,10 +102,11 @@ def _init_worker(device):
         _capi.check(_capi.lib.aps_synchronize())
 
 
-def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
+def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None, points_device=False):
     """The asynchronous form of sift_many: one future per image, submitted in input order to the worker pool, so that
     a caller can start matching the first images while the later ones are still being extracted (parallel._match_pass).
-    Each future resolves to (descriptors, keypoints) once that worker's stream has finished the image."""
+    Each future resolves to (descriptors, keypoints) once that worker's stream has finished the image.
+    points_device: resident images only - the keypoints stay on the device (fm.sift_extract)."""
     global _SIFT_POOL
     import os
     import torch
@@ -127,7 +128,7 @@ def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None):
         _capi.check(_capi.lib.aps_set_thread_device(images[k].device.index if dev else here))
         if ready is not None:
             ready[k].synchronize()
-        r = fm.sift_extract(input, images[k], device_out=dev)
+        r = fm.sift_extract(input, images[k], device_out=dev, points_device=bool(dev and points_device))
         _sync()  # this thread's stream
         return r
 

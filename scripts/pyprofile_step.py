@@ -14,4 +14,4 @@ pr.enable()
 bench.main()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)
