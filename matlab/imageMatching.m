@@ -1,4 +1,4 @@
-function [allMatches, numMatches, tforms] = imageMatching(input, n, matchesAll, keypoints, imagesProcessed)
+function [allMatches, numMatches, tforms] = imageMatching(input, n, keypoints, matchesAll, imagesProcessed)
     %IMAGEMATCHING Shadows PP/imageMatching/imageMatching.m: the candidate pairs are chosen as the reference chooses
     %   them (:76-100), then ALL of them are verified in one device batch (aps_ransac_homography_batch) instead of one
     %   refineMatch call per parfor iteration (:121-156); outputs as the reference's (n x n cells, tforms{i,j} and its
@@ -6,7 +6,7 @@ function [allMatches, numMatches, tforms] = imageMatching(input, n, matchesAll, 
     %   input.useMATLABImageMatching = 1 (estgeotform2d) and input.showKeypointsPlot = 1 (the montage of refineMatch) are
     %   forwarded to the reference's own file.
     if input.useMATLABImageMatching == 1 || (isfield(input, 'showKeypointsPlot') && input.showKeypointsPlot == 1)
-        [allMatches, numMatches, tforms] = aps_call_shadowed('imageMatching', mfilename('fullpath'), input, n, matchesAll, keypoints, imagesProcessed);
+        [allMatches, numMatches, tforms] = aps_call_shadowed('imageMatching', mfilename('fullpath'), input, n, keypoints, matchesAll, imagesProcessed);
         return;
     end
     if numel(keypoints) ~= n
