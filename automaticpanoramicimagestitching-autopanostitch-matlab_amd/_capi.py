@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaps_hip.so")
+LIB_PATH = os.environ.get("APS_LIB_PATH") or os.path.join(_HERE, "lib", "libaps_hip.so")   # APS_LIB_PATH: the `make debug` library for the probes
 
 APS_OK, APS_E_ARG, APS_E_DIM, APS_E_TYPE, APS_E_OOM, APS_E_DEVICE, APS_E_INTERNAL, APS_E_CAP = (
     0, -1, -2, -3, -4, -5, -6, -7)
@@ -126,6 +126,7 @@ _SIGNATURES = {
     "aps_ransac_draws_exhausted": [],
     "aps_gather_match_points": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64],
     "aps_match_screen_stats": [_vp, _vp],
+    "aps_match_screen_kernel_regs": [C.c_int, C.c_int, _vp, _vp],
     "aps_match_set_stats": [_vp, _i64, _i64, C.c_int, C.c_int, _vp],
     "aps_global_normalize": [_vp, _i64, _i64, _i, _i, _vp],
     "aps_knn_hamming": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64],

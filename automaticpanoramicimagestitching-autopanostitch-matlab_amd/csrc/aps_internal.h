@@ -229,7 +229,11 @@ int64_t screened_block_top3(const float* X_dev, int64_t ld, int layout, const st
 // prefix of the three nearest rows of that image and the bound of its unlisted rows.
 int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
                              std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
-                             int64_t* n_survivors, int img_a = 0, int img_b = -1);  // [img_a, img_b): the query images of this call
+                             int64_t* n_survivors, int img_a = 0, int img_b = -1,  // [img_a, img_b): the query images of this call
+                             struct GlobalPrep* keep = nullptr);  // the images' operand forms, built by the first pass and reused by the next
+// (a search in several passes over ranges of query images prepares the column sets once: global_prep_new / _free own them)
+struct GlobalPrep* global_prep_new();
+void global_prep_free(struct GlobalPrep* p);
 
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 

@@ -1,9 +1,9 @@
-// Debug build only (make EXTRA=-DAPS_DBG): the co-runner of scripts/probe_overlap_race3.py with its int8 MFMA accumulators
+// Debug target only (`make debug`): the co-runner of scripts/probe_overlap_race3.py with its int8 MFMA accumulators
 // in AGPRs.  This file alone is compiled with -amdgpu-mfma-vgpr-form=0 (Makefile), the rest of the library with =1:
 // DESIGN.md section 5 ("Co-residency finding") - SIFT kernels sharing a SIMD with VGPR-form v_mfma_i32_32x32x32_i8
 // waves returned different bits; is it the VGPR form?
 #include <hip/hip_runtime.h>
-#ifdef APS_DBG
+
 namespace aps {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -29,4 +29,4 @@ void dbg_corun_agpr_launch(int mode, int n_wg, int spin, int* sink, hipStream_t 
     dbg_corun_agpr_kernel<<<n_wg, 512, 0, st>>>(mode, spin, sink);
 }
 }  // namespace aps
-#endif
+

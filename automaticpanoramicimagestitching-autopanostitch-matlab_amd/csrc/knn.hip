@@ -752,7 +752,16 @@ int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, i
             int64_t run = 0;
             for (int i = 0; i < n_img; ++i) {
                 const int64_t need = (ioff[i + 1] - ioff[i]) * (int64_t)n_img;
-                APS_REQUIRE(need <= ((int64_t)1 << 31) - 2, APS_E_DIM, "image %d alone needs %lld (row, image) slots", i, (long long)need);
+                if (need > ((int64_t)1 << 31) - 2) {
+                    // one image alone exceeds the 32-bit slot range: no pass can hold its table - the plain exact search
+                    // answers the whole call (slower, same result), as it did before the search was cut into passes
+                    const int rc = aps_knn_global(pool, f, ld, pool, f, ld, dim, layout, k, idx, dist, ldo);
+                    if (rc != APS_OK) {
+                        const std::string why = aps_last_error();
+                        fail(rc, "%s", why.c_str());
+                    }
+                    return;
+                }
                 if (run > 0 && run + need > slot_cap) {
                     cuts.push_back(i);
                     run = 0;
@@ -773,6 +782,10 @@ int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, i
         APS_HIP(hipMemcpyAsync(d_boff, ioff.data(), (n_img + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
         APS_HIP(hipMemsetAsync(unc_n, 0, sizeof(unsigned int), stream()));
         int64_t n_surv = 0;
+        struct PrepKeep {  // the images' operand forms are prepared by the first pass and reused by the others
+            GlobalPrep* p = global_prep_new();
+            ~PrepKeep() { global_prep_free(p); }
+        } keep;
         for (size_t c = 0; c + 1 < cuts.size(); ++c) {
             const int ia = cuts[c], ib = cuts[c + 1];
             const int64_t slots = screened_global_top3(nullptr, ld, layout, ioff, ratio, job_off, nullptr, nullptr, nullptr, nullptr, nullptr, ia, ib);
@@ -780,7 +793,7 @@ int aps_knn_global_screened(const float* pool, int64_t f, int64_t ld, int dim, i
             Ws<uint32_t> t3i((size_t)slots * 3);
             Ws<float> t3d((size_t)slots * 3), t3b((size_t)slots);
             int64_t n_surv_c = 0;
-            screened_global_top3(dT, ld, layout, ioff, ratio, job_off, t3i, t3d, t3b, dismissed, &n_surv_c, ia, ib);
+            screened_global_top3(dT, ld, layout, ioff, ratio, job_off, t3i, t3d, t3b, dismissed, &n_surv_c, ia, ib, keep.p);
             n_surv += n_surv_c;
             APS_HIP(hipMemcpyAsync(d_joff, job_off.data(), (size_t)n_img * n_img * sizeof(int64_t), hipMemcpyHostToDevice, stream()));
             {

@@ -240,7 +240,8 @@ __device__ __forceinline__ void prep_desc_rows(int64_t blk, PrepLds& L, const fl
         if (r0 + tid < n) sq[r0 + tid] = s;
     }
     // phase C: item = (row, eight consecutive elements); a wave instruction covers four rows
-    float mx = -INFINITY, mn = INFINITY, md = 0.f;
+    float mx = -INFINITY, mn = INFINITY;
+    unsigned md = 0u;  // max dn as a bit pattern (dn >= 0: unsigned order = float order, and a NaN dn stays on top instead of being dropped)
 #pragma unroll
     for (int it = 0; it < kPrepRows * (kDim / 8) / kPrepThreads; ++it) {
         const int idx = it * kPrepThreads + tid, row = idx >> 4, c8 = idx & 15;
@@ -276,7 +277,7 @@ __device__ __forceinline__ void prep_desc_rows(int64_t blk, PrepLds& L, const fl
             for (int off = 1; off < 16; off <<= 1) ds += __shfl_xor(ds, off);
             const float dnv = sqrtf(ds) * 1.0009765625f;  // 128 + 4 roundings of 2^-24 in ds, one in the root: 2^-10 covers
             if (c8 == 0 && live) dn[r0 + row] = dnv;
-            md = fmaxf(md, dnv);
+            md = max(md, __float_as_uint(dnv));
         }
     }
     // the workgroup's maxima (the bit patterns are compared as unsigned: same result as on the floats)
@@ -284,7 +285,7 @@ __device__ __forceinline__ void prep_desc_rows(int64_t blk, PrepLds& L, const fl
     const float srow = tid < kPrepRows ? L.row[tid] : 0.f;  // (rows past the end repeat the last row)
     const unsigned ms = wave_umax(tid < kPrepRows ? __float_as_uint(srow) : 0u);  // s >= 0
     const unsigned sb = wave_umax(tid < kPrepRows ? ~__float_as_uint(fabsf(srow)) : 0u);
-    const unsigned mdw = wave_umax(__float_as_uint(md));
+    const unsigned mdw = wave_umax(md);
     const unsigned xb = wave_umax(ord_f32(mx)), nb = wave_umax(~ord_f32(mn));
     if (lane == 0) {
         L.red[wv][0] = ms;
@@ -1928,9 +1929,11 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     const int rowb = w.row0 + wave * 64;  // this wave's rows: rowb + 16 g + c, every lane quarter kq sees them
     // experiment switches (APS_SCR_VARIANT): 1 = static priority for waves 4-7, 2 / 4 = waves 4-7 sleep 64 / 128 cycles after
     // every hand-over barrier (a stagger between the two waves of a SIMD), 8 = the odd waves instead of waves 4-7
+#ifdef APS_MATCH_TIMING  // (timing builds only, like the ablation bits)
     const int variant = __builtin_amdgcn_readfirstlane(g_scr_variant);
     const bool late_half = (variant & 8) ? (wave & 1) != 0 : wave >= 4;
     if ((variant & 1) && late_half) __builtin_amdgcn_s_setprio(1);
+#endif
 
     i32x4 aq[4][2];
 #pragma unroll
@@ -2075,10 +2078,12 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             if (cb == kLast - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+#ifdef APS_MATCH_TIMING
                 if ((variant & 6) && late_half) {
                     if (variant & 2) __builtin_amdgcn_s_sleep(1);
                     if (variant & 4) __builtin_amdgcn_s_sleep(2);
                 }
+#endif
             }
         });
     };
@@ -2279,16 +2284,29 @@ struct Prepared {
 // the buffers of a set (and, when the set owns its statistics words, their zero fill on `st`)
 static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext);
 
+// An experiment switch read from the environment reaches the device when its value differs from what the device holds
+// (also back to 0 when the variable is unset again), by a synchronous copy from a live variable - same-process A/Bs see
+// the value they set, and no copy is queued from a stack slot that is gone when it runs.
+static void sync_device_switch(const char* env, const void* symbol, int& held) {
+    const char* e = std::getenv(env);
+    const int want = e ? std::atoi(e) : 0;
+    if (want == held) return;
+    APS_HIP(hipStreamSynchronize(stream()));  // kernels in flight keep the value they were launched under
+    APS_HIP(hipMemcpyToSymbol(symbol, &want, sizeof want, 0, hipMemcpyHostToDevice));
+    held = want;
+}
+static void sync_q8_symmetric_switch() {
+    static thread_local int held = 0;  // (one context per thread: core.hip)
+    sync_device_switch("APS_Q8_SYMMETRIC", &g_q8_symmetric, held);
+}
+
 static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
                     Prepared& out, hipStream_t st = nullptr, bool bracket = true, float* stat_ext = nullptr) {
     if (!st) st = stream();
     prepare_alloc(n, out, st, stat_ext);
     float* const qstat = out.stat + 4;
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
-    if (std::getenv("APS_Q8_SYMMETRIC")) {  // A/B switch: column code without the offset
-        const int sym = 1;
-        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, st));
-    }
+    sync_q8_symmetric_switch();  // A/B switch APS_Q8_SYMMETRIC: column code without the offset
     if (n == 0) return;
     struct MaybeProf {  // (event brackets live on the caller's own stream: a forked section is bracketed as a whole)
         Prof* p = nullptr;
@@ -2296,7 +2314,7 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
         ~MaybeProf() { delete p; }
     } prof(bracket);
     prep_desc_kernel<<<out.nb1, kPrepThreads, 0, st>>>(X_dev, n, ld, layout, normalize ? 1 : 0, out.P, out.sq, out.H, out.dn, out.part);
-    prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 1);
+    prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, (const unsigned short*)out.H != nullptr ? 1 : 0, 1);
     q8_desc_kernel<<<out.nb2, 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn, n_pad, out.stat,
                                             out.aug, out.stat + 2, out.part + (size_t)5 * out.nb1);
     prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 2);
@@ -2326,10 +2344,7 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
         bp.push_back(bp.back() + o.nb1);
         bq.push_back(bq.back() + o.nb2);
     }
-    if (std::getenv("APS_Q8_SYMMETRIC")) {
-        const int sym = 1;
-        APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q8_symmetric), &sym, sizeof sym, 0, hipMemcpyHostToDevice, stream()));
-    }
+    sync_q8_symmetric_switch();
     if (jobs.empty()) return;
     Ws<PrepJob> dj(jobs.size());
     Ws<int> dbp(bp.size()), dbq(bq.size());
@@ -2536,6 +2551,28 @@ static bool screen_shape_32() {
     return e && std::atoi(e) == 32;
 }
 
+// The co-residency rule: waves of other kernels that shared a SIMD with int8-MFMA waves came back with
+// different bits, so the screening kernels claim the SIMD's whole register file - 512 threads per workgroup = two waves
+// per SIMD, 256 registers each (the `v_mov_b32 v255` in their first lines).  That holds only while the compiler really
+// allocates 256: checked against the loaded code object before the first launch of a process, and by tests/test_abi.py
+// against the code object's metadata on the CPU.
+static void screen_regs(int shape32, int bounds, int* num_regs, int* max_threads) {
+    hipFuncAttributes fa;
+    const void* f = shape32 ? (bounds ? reinterpret_cast<const void*>(&match_screen_i8_kernel<true>) : reinterpret_cast<const void*>(&match_screen_i8_kernel<false>))
+                            : (bounds ? reinterpret_cast<const void*>(&match_screen_i8x16_kernel<true>) : reinterpret_cast<const void*>(&match_screen_i8x16_kernel<false>));
+    APS_HIP(hipFuncGetAttributes(&fa, f));
+    *num_regs = fa.numRegs;
+    *max_threads = fa.maxThreadsPerBlock;
+}
+static void require_whole_simd(int shape32, int bounds = 0) {
+    static int ok[4] = {0, 0, 0, 0};
+    if (ok[2 * shape32 + bounds]) return;
+    int regs = 0, thr = 0;
+    screen_regs(shape32, bounds, &regs, &thr);
+    APS_REQUIRE((regs + 7) / 8 * 8 >= 256, APS_E_INTERNAL,
+                "the int8 screening kernel holds %d registers per lane, not 256: other kernels' waves could share its SIMDs (DESIGN.md section 5)", regs);
+    ok[2 * shape32 + bounds] = 1;
+}
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 // prune_r2 > 0: the caller will apply the ratio / threshold filter with these constants, so rows that cannot pass it
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
@@ -2591,10 +2628,13 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
         {
             Prof prof("match_screen_i8");
-            if (const char* ev = std::getenv("APS_SCR_VARIANT")) {
-                const int v = std::atoi(ev);
-                APS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_scr_variant), &v, sizeof v, 0, hipMemcpyHostToDevice, stream()));
+#ifdef APS_MATCH_TIMING
+            {
+                static thread_local int held = 0;
+                sync_device_switch("APS_SCR_VARIANT", &g_scr_variant, held);
             }
+#endif
+            require_whole_simd(screen_shape_32() ? 1 : 0);
             if (screen_shape_32())
                 match_screen_i8_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
                                                                                           surv_count, prune_r2, prune_thr, nullptr);
@@ -3046,13 +3086,21 @@ __global__ void global_t3_init_kernel(uint32_t* __restrict__ t3_idx, float* __re
     t3_b[s] = INFINITY;
 }
 
+struct GlobalPrep {
+    std::vector<Prepared> prep;
+    Ws<float> stats;
+    bool ready = false;
+};
+GlobalPrep* global_prep_new() { return new GlobalPrep(); }
+void global_prep_free(GlobalPrep* p) { delete p; }
+
 // X_dev: the (normalised) pool; img_off: n + 1 row offsets of the images.  Slots: job (i, j), EVERY j (the diagonal too:
 // the rows of q's own image and q itself are candidates of the k nearest), slot = job_off[i n + j] + local row.
 // Outputs t3_* as screened_block_top3 for the rows with dismissed[q] == 0 (the other slots are not written).
 // Returns the slot count; call with t3_idx == nullptr to get it (and job_off) first.
 int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const std::vector<int64_t>& img_off, float ratio,
                              std::vector<int64_t>& job_off, uint32_t* t3_idx, float* t3_d, float* t3_b, uint8_t* dismissed,
-                             int64_t* n_survivors, int img_a, int img_b) {
+                             int64_t* n_survivors, int img_a, int img_b, GlobalPrep* keep) {
     // [img_a, img_b): the QUERY images of this call (every image is a column set); a pool whose (row, image) table exceeds
     // 2^31 slots - BASELINE configs[4]: 500 images, 5.4 M rows - is searched in several calls over ranges of query images
     const int n = (int)img_off.size() - 1;
@@ -3067,9 +3115,13 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         }
     if (!t3_idx || slots == 0) return slots;
     APS_REQUIRE(slots < ((int64_t)1 << 31), APS_E_DIM, "too many (row, image) pairs for one pass (%lld)", (long long)slots);
-    std::vector<Prepared> prep(n);
-    Ws<float> prep_stats((size_t)8 * std::max(n, 1));
-    {  // the images' operand forms: every set in one batch of launches (as in match_pairs_impl)
+    GlobalPrep local;
+    GlobalPrep& G = keep ? *keep : local;
+    std::vector<Prepared>& prep = G.prep;
+    Ws<float>& prep_stats = G.stats;
+    if (!G.ready) {  // the images' operand forms: every set in one batch of launches (as in match_pairs_impl)
+        prep.resize(n);
+        prep_stats.alloc((size_t)8 * std::max(n, 1));
         APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)8 * std::max(n, 1) * sizeof(float), stream()));
         std::vector<PrepRequest> req;
         for (int b = 0; b < n; ++b) {
@@ -3077,6 +3129,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
             req.push_back({xb, img_off[b + 1] - img_off[b], ld, false, &prep[b], prep_stats.get() + 8 * b});
         }
         prepare_batch(req, layout);
+        G.ready = true;
     }
     // ---- the int8 screen over every ordered pair of different images: bounds per (row, image) ----
     std::vector<MatchJob> jobs;
@@ -3103,6 +3156,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
         APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
         {
             Prof prof("match_screen_i8_bounds");
+            require_whole_simd(screen_shape_32() ? 1 : 0, 1);
             if (screen_shape_32())
                 match_screen_i8_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
                                                                                          nullptr, nullptr, 0.f, 0.f, bounds);
@@ -3553,79 +3607,11 @@ extern "C" int aps_match_set_stats(const float* X, int64_t n, int64_t ld, int la
     });
 }
 
-#ifdef APS_DBG
-// co-run experiment (scripts/probe_overlap_race3.py): a workgroup that only occupies a CU's resources for a while
-namespace aps {
-__global__ __launch_bounds__(512) void dbg_corun_kernel(int mode, int spin, const signed char* __restrict__ src, int* __restrict__ sink) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[96 * 1024];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int acc = 0;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    i32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    i32x4 c4 = {0, 0, 0, 0};
-    f32x16 cf = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float vf = (float)lane;
-    const i32x4 a = {lane, 1, 2, 3};
-    for (int it = 0; it < spin; ++it) {
-        if (mode & 1) {  // LDS-DMA into the own allocation
-            const signed char* s = src + ((size_t)(it & 255) * 8 + wave) * 1024 + lane * 16;
-            const uint32_t dst = lds_base + wave * 1024 + (it & 7) * 8192;
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(s), "s"(dst)
-                         : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (mode & 2) {  // int8 MFMA
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c, 0, 0, 0);
-        }
-        if (mode & 64) {  // int8 MFMA, the 16x16x64 shape (the screening kernel's since round 4)
-            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
-            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
-            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
-            c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c4, 0, 0, 0);
-        }
-        if (mode & 8) {  // f16 MFMA
-            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-            const h8 ah = {(_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f, (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2.f};
-            cf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, cf, 0, 0, 0);
-            cf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, cf, 0, 0, 0);
-        }
-        if (mode & 32) {  // plain VALU pressure
-#pragma unroll
-            for (int q = 0; q < 16; ++q) vf = fmaf(vf, 1.0001f, 0.5f);
-        }
-        if (mode & 4) {  // plain LDS traffic
-            reinterpret_cast<volatile int*>(lds)[threadIdx.x + 512 * (it & 31)] = it;
-            acc += reinterpret_cast<volatile int*>(lds)[(threadIdx.x * 7 + it) & 16383];
-        }
-        if (!(mode & (7 | 64))) __builtin_amdgcn_s_sleep(20);
-    }
-    if (acc + c[0] + c4[0] + (int)cf[0] + (int)vf == 0x7fffffff) sink[0] = acc;
-}
-}  // namespace aps
-
-namespace aps { void dbg_corun_agpr_launch(int mode, int n_wg, int spin, int* sink, hipStream_t st); }
-extern "C" int aps_dbg_corun(int mode, int n_wg, int spin) {
+extern "C" int aps_match_screen_kernel_regs(int shape, int bounds_pass, int* num_regs, int* max_threads_per_block) {
     using namespace aps;
     return guarded([&] {
+        APS_REQUIRE(num_regs && max_threads_per_block && (shape == 16 || shape == 32), APS_E_ARG, "shape is 16 or 32; the outputs must not be null");
         ctx();
-        Ws<signed char> src((size_t)256 * 8 * 1024 + 65536);
-        Ws<int> sink(4);
-        if (mode & (128 | 256)) {  // the same int8 MFMAs with their accumulators in AGPRs (dbg_agpr.hip)
-            // Round 4: with this co-runner beside the SIFT worker streams the process died with "Memory access fault by GPU"
-            // (mode 128, profiles/r04c_corun_probe.txt) - the co-runner itself touches no memory.  Not to be run again on a
-            // shared pool without a reason: the switch below keeps it from being started by accident.
-            APS_REQUIRE(std::getenv("APS_DBG_ALLOW_AGPR_CORUN") != nullptr, APS_E_ARG,
-                        "co-run modes 128 / 256 faulted the GPU in round 4; set APS_DBG_ALLOW_AGPR_CORUN=1 to run them anyway");
-            dbg_corun_agpr_launch(mode, n_wg, spin, sink, stream());
-        } else
-            dbg_corun_kernel<<<n_wg, 512, 0, stream()>>>(mode, spin, src, sink);
-        check_launch("dbg_corun_kernel");
-        APS_HIP(hipStreamSynchronize(stream()));
+        screen_regs(shape == 32, bounds_pass != 0, num_regs, max_threads_per_block);
     });
 }
-#endif

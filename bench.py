@@ -230,12 +230,82 @@ def global_matcher_probe(pl, capi, input_, images):
     }
 
 
+def launcher_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) runs as a CHILD process: one rank
+    per GPU under torch.distributed.run, rendezvous on 127.0.0.1 - the form the driver itself uses."""
+    if port is None:
+        import socket
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_gpus, argv):
+    """Starts the N ranks before this process has made any GPU call (it never makes one: a process that has initialised the
+    GPU must not exec, and this one only waits), relays rank 0's single JSON line and returns the child's exit code."""
+    import subprocess
+
+    have = torch.cuda.device_count()  # (counting devices does not initialise the runtime)
+    if os.environ.get("APS_BENCH_RANK_PROBE") != "1" and have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(launcher_command(n_gpus, argv), stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in proc.stdout.read().splitlines() if l.strip()]
+    rc = proc.wait()
+    results = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in results:
+            print(l, file=sys.stderr)
+    if rc == 0 and len(results) != 1:
+        print(f"bench.py: expected ONE result line from rank 0, got {len(results)}", file=sys.stderr)
+        rc = 3
+    if results:
+        print(results[-1], flush=True)
+    return rc
+
+
+def rank_probe(args):
+    """APS_BENCH_RANK_PROBE=1 (test hook, tests/test_parallel_cpu.py): what every rank does before it touches a GPU - the
+    environment torch.distributed.run hands over, the --gpus / WORLD_SIZE check, a process group (gloo), one all-reduce, ONE
+    JSON line from rank 0 - so that the launcher's argument handling and relay are covered without a device."""
+    import torch.distributed as dist
+
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "rank_sum": float(t.item()), "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     if os.environ.get("APS_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run takes longer
         import faulthandler
 
         faulthandler.dump_traceback_later(int(os.environ["APS_BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    # `--gpus N` is what decides the rank count.  Launched by torch.distributed.run (the driver's form for N > 1) the
+    # environment carries WORLD_SIZE, which must agree; launched plainly with N > 1 the ranks are started here as children.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} ranks were launched", file=sys.stderr)
+            sys.exit(2)
+    elif args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("APS_BENCH_RANK_PROBE") == "1":
+        sys.exit(rank_probe(args))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout
     # when a communicator comes up): everything but the result line is sent to stderr by pointing fd 1 at fd 2 for the
     # run; the result is written to the saved descriptor at the end.

@@ -144,6 +144,13 @@ int aps_match_screen_stats(int64_t* rows, int64_t* survivors);
  * a bound unsound without changing any result on ordinary data. */
 int aps_match_set_stats(const float* X, int64_t n, int64_t ld, int layout, int normalize, float* stats);
 
+/* Diagnostics of the co-residency rule: registers per lane and the workgroup bound of the int8
+ * screening kernel as the LOADED code object declares them (hipFuncGetAttributes).  shape = 16 (v_mfma_i32_16x16x64_i8, the
+ * default) or 32 (v_mfma_i32_32x32x32_i8, APS_SCREEN_SHAPE=32); bounds_pass != 0: the pooled matcher's instantiation.  The
+ * kernels must hold 256 registers at 512 threads per workgroup so that no other kernel's waves share a SIMD with int8-MFMA
+ * waves; the library refuses to launch them otherwise (APS_E_INTERNAL). */
+int aps_match_screen_kernel_regs(int shape, int bounds_pass, int* num_regs, int* max_threads_per_block);
+
 /* a3: featureMatchingPairwise (featureMatchingPairwise.m:48-63): all upper-triangular image pairs
  * in the reference's order (column-major linear index of triu(.,1): (1,2),(1,3),(2,3),(1,4),...),
  * each through aps_match_features' rule, in ONE batched launch sequence.

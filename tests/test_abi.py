@@ -55,3 +55,68 @@ def test_product_does_not_import_oracle(aps):
                 src = open(os.path.join(base, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libaps_oracle" not in src, f
+
+
+# ---- the co-residency rule, checked on the code objects the library carries ---------------------------
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _device_code_objects(tmp_path):
+    """The gfx950 code objects bundled in libaps_hip.so, extracted into tmp_path (llvm-objdump writes beside its input)."""
+    import shutil
+    import subprocess
+    so = os.path.join(tmp_path, "libaps_hip.so")
+    lib_path = os.path.join(ROOT, "automaticpanoramicimagestitching-autopanostitch-matlab_amd", "lib", "libaps_hip.so")
+    shutil.copy(lib_path, so)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], check=True, capture_output=True)
+    return sorted(os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if f.endswith("gfx950"))
+
+
+def _kernel_metadata(code_object):
+    """{kernel symbol: {vgpr_count, agpr_count, max_flat_workgroup_size}} from the AMDGPU metadata note."""
+    import subprocess
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", code_object], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for entry in re.split(r"\n\s+- \.agpr_count:", "\n" + notes)[1:]:
+        entry = ".agpr_count:" + entry
+        get = lambda key: re.search(r"\.%s:\s+(\S+)" % key, entry)
+        if not get("symbol"):
+            continue
+        out[get("symbol").group(1).replace(".kd", "")] = {k: int(get(k).group(1)) for k in ("agpr_count", "vgpr_count", "max_flat_workgroup_size")}
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="needs the ROCm llvm tools")
+def test_every_int8_mfma_kernel_claims_the_whole_register_file_of_its_simd(tmp_path):
+    """Kernels whose waves issue v_mfma_i32_*_i8 must not share a SIMD with waves of other kernels (round 3 / 4 finding:
+    co-resident SIFT kernels returned different bits).  The rule is kept by register allocation: 256 registers per lane
+    at 512 threads per workgroup = two waves per SIMD x 256 = the whole 512-entry file.  This reads the allocation from
+    the code objects in the shipped library and fails when any int8-MFMA kernel holds less (for example when the
+    `v_mov_b32 v255` claim in match_screen_i8*_kernel is removed, or a new int8 kernel is added without it)."""
+    import subprocess
+    found = {}
+    for co in _device_code_objects(str(tmp_path)):
+        meta = _kernel_metadata(co)
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        current = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                current = m.group(1)
+            elif current and "v_mfma_i32" in line and current in meta:
+                found[current] = meta[current]
+    assert len(found) >= 4, sorted(found)   # both shapes, list and bounds instantiations
+    for name, md in found.items():
+        regs = (md["vgpr_count"] + md["agpr_count"] + 7) // 8 * 8
+        assert regs >= 256, "%s: %d registers per lane - other kernels' waves can share its SIMDs" % (name, regs)
+        assert md["max_flat_workgroup_size"] == 512, (name, md)
+
+
+def test_product_library_carries_no_debug_kernels(aps):
+    """The probe kernels (csrc/debug/) belong to `make debug`'s libaps_hip_dbg.so only."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "automaticpanoramicimagestitching-autopanostitch-matlab_amd", "lib", "libaps_hip.so")],
+                          check=True, capture_output=True, text=True).stdout
+    assert "dbg" not in syms, [l for l in syms.splitlines() if "dbg" in l]
+    mk = open(os.path.join(ROOT, "automaticpanoramicimagestitching-autopanostitch-matlab_amd", "csrc", "Makefile")).read()
+    assert "SRCS = $(wildcard *.hip)" in mk and not os.path.exists(os.path.join(os.path.dirname(aps.__file__), "csrc", "dbg_agpr.hip"))

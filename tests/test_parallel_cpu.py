@@ -166,3 +166,46 @@ def test_blocked_pair_partition_is_balanced_and_touches_fewer_images():
                 assert max(touched) <= 44 and sum(touched) / ws <= 36, touched  # all 64 with a pair-by-pair deal
     assert par.partition_pairs_blocked([], [], 4, 8).size == 0
     assert np.array_equal(par.partition_pairs_blocked([(0, 1)], [0.0], 2, 4), [0])
+
+
+# ---- bench.py's own launcher (`python bench.py --gpus N` without torch.distributed.run around it) --------------------------
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks_and_relays_one_line():
+    """--gpus 2 with no WORLD_SIZE: bench.py starts two ranks as children (torch.distributed.run, 127.0.0.1), every rank sees
+    WORLD_SIZE = 2 and the flags, rank 0's single JSON line comes back on stdout and nothing else does.  The ranks stop at
+    the rank probe (gloo), so no GPU is needed."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", env={"APS_BENCH_RANK_PROBE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"probe": True, "n_gpus": 2, "gpus_arg": 2, "steps": 3, "warmup": 1, "rank_sum": 3.0, "master_addr": "127.0.0.1"}
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench("--gpus", "2", env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0", "APS_BENCH_RANK_PROBE": "1"})
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+    r = _bench("--gpus", "0")
+    assert r.returncode == 2
+
+
+def test_bench_launcher_command_is_the_drivers_form():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cmd = mod.launcher_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"], port=29999)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port",
+                       "29999", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"]
