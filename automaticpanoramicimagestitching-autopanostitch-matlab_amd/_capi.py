@@ -94,6 +94,7 @@ _SIGNATURES = {
     "aps_profile_get": [C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
     "aps_profile_names": [C.c_char_p, _i],
     "aps_match_2nn_ssd": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp],
+    "aps_match_pca2nn": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "aps_match_features": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, C.POINTER(aps_match_opts), _vp,
                            _vp, _vp, _i64, C.POINTER(_i64)],
     "aps_match_pairwise": [C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _i, _i, _i,

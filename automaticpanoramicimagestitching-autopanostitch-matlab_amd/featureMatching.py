@@ -119,37 +119,35 @@ def nearest2SubsetPdist2(A, B, subset=12000, candB=None, seed=0):
     return idx1, candB[i2.astype(np.int64) - 1].astype(np.uint32), e1, e2
 
 
-def pca_coeff(Bc, k):
-    """pca(X, 'NumComponents', k) coefficients for centred X (toolbox, unpinned): eigenvectors of the covariance
-    by descending variance, each column signed so that its largest-magnitude entry is positive."""
-    cov = (Bc.astype(np.float64).T @ Bc.astype(np.float64)) / max(Bc.shape[0] - 1, 1)
-    w, V = np.linalg.eigh(cov)
-    V = V[:, np.argsort(-w, kind="stable")[:k]]
-    sgn = np.sign(V[np.abs(V).argmax(0), np.arange(V.shape[1])])
-    sgn[sgn == 0] = 1
-    return (V * sgn).astype(np.float32)
-
-
-def nearest2ApproxFloatFast(A, B, opts=None):
+def nearest2ApproxFloatFast(A, B, opts=None, return_basis=False):
     """[idx1, idx2, dBest, dSecond] = nearest2ApproxFloatFast(A, B, opts) (matchFeaturesScratch.m:442-573): PCA of B
-    to ApproxNumComponents (48) dimensions, both sets projected and L2-normalised, then the top two cosine
-    similarities per row, returned as d = 2 - 2*sim.  On unit rows that is the squared distance, so the top-2
-    search is the device's exhaustive SSD kernel on the projected, zero-padded rows (d = a2 + b2 - 2ab equals
-    2 - 2 sim up to the ulp-level deviation of a2, b2 from 1).  The PCA itself stays on the host."""
+    to ApproxNumComponents (48) dimensions, both sets centred with B's mean and projected, L2-normalised, then the top
+    two cosine similarities per row of A, returned as d = 2 - 2*sim.  All of it on the device (aps_match_pca2nn: column
+    means and the covariance B'B through the f32 MFMA path, projection, normalisation, the cosine product and its top
+    two); only the 128 x 128 symmetric eigen-problem is solved on the host (inside the library).  opts: 'UsePCA',
+    'ApproxNumComponents' as in the reference; BlockRows / UseParfor / UseGPU only partition the reference's loop and
+    have no effect on a row's result.  return_basis: also (mu, coeff) of the projection (None when it is skipped)."""
     o = {"ApproxNumComponents": 48, "UsePCA": True}
     o.update(opts or {})
-    A = np.asarray(A, np.float32)
-    B = np.asarray(B, np.float32)
+    A, n1, lda, la = _as_desc(A)
+    B, n2, ldb, lb = _as_desc(B)
+    if la != lb:
+        raise ValueError("A and B must share a storage order")
+    if n1 == 0 or n2 == 0:
+        raise ValueError("Expected input to be nonempty.")
+    if A.shape[1] != DIM or B.shape[1] != DIM:
+        raise ValueError("Descriptor dimensions must match for non-binary.")
     k = int(o["ApproxNumComponents"])
-    if o["UsePCA"] and A.shape[1] > k:
-        mu = np.nanmean(B, 0, dtype=np.float32)
-        coeff = pca_coeff(B - mu, k)
-        B = (B - mu) @ coeff
-        A = (A - mu) @ coeff
-    eps = np.float32(np.finfo(np.float32).eps)
-    A = A / (np.sqrt((A * A).sum(1, dtype=np.float32, keepdims=True)) + eps)
-    B = B / (np.sqrt((B * B).sum(1, dtype=np.float32, keepdims=True)) + eps)
-    return nearest2SSDExhaustive(_pad_dim(A), _pad_dim(B))
+    idx2 = np.zeros(n1, np.uint32)
+    d1 = np.zeros(n1, np.float32)
+    d2 = np.zeros(n1, np.float32)
+    projected = bool(o["UsePCA"]) and DIM > k
+    mu = np.zeros(DIM, np.float32) if return_basis and projected else None
+    coeff = np.zeros((DIM, k), np.float32) if return_basis and projected else None
+    check(lib.aps_match_pca2nn(ptr(A), n1, lda, ptr(B), n2, ldb, DIM, la, k, int(bool(o["UsePCA"])), ptr(idx2), ptr(d1), ptr(d2),
+                               ptr(mu) if mu is not None else None, ptr(coeff) if coeff is not None else None))
+    out = (np.arange(1, n1 + 1, dtype=np.float64), idx2, d1, d2)
+    return out + ((mu, coeff),) if return_basis else out
 
 
 def filter_matches(idx2, dBest, dSecond, n2, MaxRatio, MatchThreshold, Unique):

@@ -109,6 +109,22 @@ int aps_profile_names(char* buf, int buf_len);
 int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, int64_t n2,
                       int64_t ldb, int dim, int layout, uint32_t* idx2, float* d1, float* d2);
 
+/* a6: nearest2ApproxFloatFast + doBlock (matchFeaturesScratch.m:442-573), the 'pca2nn' back end of Method = 'Approximate':
+ *   muB = mean(B,1,'omitnan'); coeff = pca(B - muB, 'NumComponents', n_components); both sets centred with muB and
+ *   projected (:480-484; skipped when use_pca == 0 or dim <= n_components, :478); rows / (sqrt(sum(row.^2)) + eps('single'))
+ *   (:488-489); G = A*B'; idx2 = first argmax_j G(i,j), the second similarity = max of the rest; d = 2 - 2*sim (:552-570).
+ * Arithmetic contract (the canonical order the oracle restates; MATLAB leaves it open):
+ *   mean / covariance sums per chunk of 256 rows in ascending row order (the covariance chunk as the f32 fma chain of
+ *   v_mfma_f32_32x32x2_f32), chunk partials added in f64 in ascending order, covariance / (n2 - 1);
+ *   principal axes = eigenvectors of that covariance by cyclic Jacobi rotations in f64 on the HOST (fixed order), sorted by
+ *   descending eigenvalue, each signed so that its largest-magnitude entry is positive (pca's convention), cast to f32;
+ *   projection = k-ascending f32 fma chain; squared norm s = s + y*y over ascending components;
+ *   G(i,j) = component-ascending f32 fma chain (one MFMA chain).
+ * idx2: 1-based uint32[n1]; d1, d2: f32[n1] (d2 = +inf when n2 == 1).  mu_out (f32[dim]) and coeff_out (f32[dim x
+ * n_components], row-major) are optional (NULL) and filled only when the projection runs.  n1, n2 >= 1. */
+int aps_match_pca2nn(const float* A, int64_t n1, int64_t lda, const float* B, int64_t n2, int64_t ldb, int dim, int layout,
+                     int n_components, int use_pca, uint32_t* idx2, float* d1, float* d2, float* mu_out, float* coeff_out);
+
 /* Options of the a4 driver (matchFeaturesScratch.m:59-78 name/value pairs). */
 typedef struct aps_match_opts {
     double max_ratio;       /* 'MaxRatio'       (inputs.m:59  Ratiothreshold = 0.6).  f64 like MATLAB's scalars:

@@ -103,6 +103,23 @@ static void cmd_match(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]
     }
 }
 
+// [idx2, dBest, dSecond] = aps_mex('pca_2nn', A single N1x128, B single N2x128, ApproxNumComponents, UsePCA)
+// nearest2ApproxFloatFast (matchFeaturesScratch.m:442-573): idx2 uint32 N1x1 (1-based), distances single N1x1
+static void cmd_pca2nn(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 5 && mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]), "aps:type", "descriptors must be single");
+    const int64_t n1 = mxGetM(prhs[1]), n2 = mxGetM(prhs[2]);
+    need(mxGetN(prhs[1]) == mxGetN(prhs[2]), "aps:dim", "Descriptor dimensions must match for non-binary.");
+    need(n1 > 0 && n2 > 0, "aps:args", "Expected input to be nonempty.");
+    plhs[0] = mxCreateNumericMatrix(n1, 1, mxUINT32_CLASS, mxREAL);
+    mxArray* d1 = mxCreateNumericMatrix(n1, 1, mxSINGLE_CLASS, mxREAL);
+    mxArray* d2 = mxCreateNumericMatrix(n1, 1, mxSINGLE_CLASS, mxREAL);
+    check(aps_match_pca2nn((const float*)mxGetData(prhs[1]), n1, n1, (const float*)mxGetData(prhs[2]), n2, n2, (int)mxGetN(prhs[1]),
+                           APS_COLMAJOR, (int)mxGetScalar(prhs[3]), mxGetScalar(prhs[4]) != 0, (uint32_t*)mxGetData(plhs[0]),
+                           (float*)mxGetData(d1), (float*)mxGetData(d2), nullptr, nullptr));
+    if (nlhs > 1) plhs[1] = d1; else mxDestroyArray(d1);
+    if (nlhs > 2) plhs[2] = d2; else mxDestroyArray(d2);
+}
+
 // matches = aps_mex('match_pairwise', allDescriptors (1xN cell of single Ki x 128), opts) -> N x N cell, upper triangle
 static void cmd_pairwise(int, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     need(nrhs == 3 && mxIsCell(prhs[1]), "aps:type", "allDescriptors must be a cell array");
@@ -598,6 +615,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (cmd == "set_device") check(aps_set_device((int)mxGetScalar(prhs[1])));
     else if (cmd == "sift_extract") cmd_sift(nlhs, plhs, nrhs, prhs);
     else if (cmd == "match_features") cmd_match(nlhs, plhs, nrhs, prhs);
+    else if (cmd == "pca_2nn") cmd_pca2nn(nlhs, plhs, nrhs, prhs);
     else if (cmd == "match_pairwise") cmd_pairwise(nlhs, plhs, nrhs, prhs);
     else if (cmd == "knn_global") cmd_knn(nlhs, plhs, nrhs, prhs);
     else if (cmd == "match_global") cmd_match_global(nlhs, plhs, nrhs, prhs);

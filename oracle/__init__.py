@@ -153,6 +153,33 @@ def hamming_2nn(A, B):
 
 
 # ---- RANSAC (ransac_oracle.c) -------------------------------------------------------------------
+# ---- a6: nearest2ApproxFloatFast (pca_oracle.c) -------------------------------------------------------------------
+_orc_pca2nn = _sig("orc_pca2nn", [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
+_orc_pca_basis = _sig("orc_pca_basis", [_vp, _i64, _i, _i, _vp, _vp, _vp])
+
+
+def pca_basis(B, n_components=48):
+    """(mu [dim], coeff [dim x n_components], cov [dim x dim] f64) of matchFeaturesScratch.m:480-482."""
+    B = _f32(B)
+    mu = np.zeros(B.shape[1], np.float32)
+    coeff = np.zeros((B.shape[1], n_components), np.float32)
+    cov = np.zeros((B.shape[1], B.shape[1]), np.float64)
+    _orc_pca_basis(B.ctypes.data, B.shape[0], B.shape[1], int(n_components), mu.ctypes.data, coeff.ctypes.data, cov.ctypes.data)
+    return mu, coeff, cov
+
+
+def pca2nn(A, B, n_components=48, use_pca=True):
+    """[idx2 (1-based), d1, d2] of nearest2ApproxFloatFast (matchFeaturesScratch.m:442-573)."""
+    A, B = _f32(A), _f32(B)
+    n1 = A.shape[0]
+    idx = np.zeros(n1, np.uint32)
+    d1 = np.zeros(n1, np.float32)
+    d2 = np.zeros(n1, np.float32)
+    _orc_pca2nn(A.ctypes.data, n1, B.ctypes.data, B.shape[0], A.shape[1], int(n_components), int(bool(use_pca)), idx.ctypes.data,
+                d1.ctypes.data, d2.ctypes.data, None, None)
+    return idx, d1, d2
+
+
 _orc_ransac_score = _sig("orc_ransac_score", [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp])
 _orc_fit_homography = _sig("orc_fit_homography", [_vp, _vp, _i64, _vp, _i64, _vp], _i)
 _orc_fit_homography_refit = _sig("orc_fit_homography_refit", [_vp, _vp, _i64, _vp, _i64, _vp], _i)

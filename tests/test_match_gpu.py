@@ -286,9 +286,11 @@ def test_subset_backend_is_exact_on_the_subset(gpu):
         fm.nearest2SubsetPdist2(An, Bn, 400, candB=np.ones(400, np.int64))
 
 
-def test_pca_backend_finds_the_planted_matches(gpu):
-    """PCA-48 + cosine is an approximation OF the exhaustive search (pca is toolbox code: unpinned); the planted
-    near-duplicates must still come out, and the host restatement of the same projection must agree exactly."""
+def test_pca_backend_equals_the_oracle_bit_for_bit(gpu):
+    """Row a6 (matchFeaturesScratch.m:442-573) on the device against oracle/pca_oracle.c: the mean, the principal axes (sign
+    convention: largest-magnitude entry of every axis positive), and idx2 / d1 / d2 of the cosine 2-NN are identical bits,
+    for a ragged size, a one-row B set, UsePCA off, and column-major (MATLAB) storage.  PCA-48 + cosine is an approximation
+    OF the exhaustive search: the planted near-duplicates must still come out of the filtered matcher."""
     fm = import_module(gpu.__name__ + ".featureMatching")
     A, B = _approx_sets(2)
     me, _ = fm.matchFeaturesScratch(A, B, Method="Exhaustive", MatchThreshold=1.5, MaxRatio=0.6)
@@ -296,17 +298,43 @@ def test_pca_backend_finds_the_planted_matches(gpu):
     se, sp = {tuple(r) for r in me.tolist()}, {tuple(r) for r in mp.tolist()}
     assert len(se & sp) >= 0.9 * len(se)
     An, Bn = fm._normalize_like_reference(A, B)
-    mu = Bn.mean(0, dtype=np.float32)
-    co = fm.pca_coeff(Bn - mu, 48)
-    Ap, Bp = (An - mu) @ co, (Bn - mu) @ co
-    eps = np.float32(np.finfo(np.float32).eps)
-    Ap = Ap / (np.sqrt((Ap * Ap).sum(1, dtype=np.float32, keepdims=True)) + eps)
-    Bp = Bp / (np.sqrt((Bp * Bp).sum(1, dtype=np.float32, keepdims=True)) + eps)
-    pad = lambda X: np.concatenate([X, np.zeros((len(X), 80), np.float32)], 1)  # noqa: E731
-    oi, od1, od2 = oracle.match_2nn_ssd(pad(Ap), pad(Bp))
-    _, idx2, d1, d2 = fm.nearest2ApproxFloatFast(An, Bn)
+    omu, oco, _ = oracle.pca_basis(Bn, 48)
+    _, idx2, d1, d2, (mu, co) = fm.nearest2ApproxFloatFast(An, Bn, return_basis=True)
+    assert np.array_equal(mu, omu) and np.array_equal(co, oco)
+    assert np.all(co[np.abs(co).argmax(0), np.arange(48)] > 0)          # the sign convention
+    oi, od1, od2 = oracle.pca2nn(An, Bn, 48, True)
     assert np.array_equal(idx2, oi) and np.array_equal(d1, od1) and np.array_equal(d2, od2)
-    assert np.abs(d1 - (2 - 2 * (pad(Ap) * pad(Bp)[oi.astype(np.int64) - 1]).sum(1))).max() < 1e-5
+    # the same through MATLAB's column-major storage
+    _, i_f, d1_f, d2_f = fm.nearest2ApproxFloatFast(np.asfortranarray(An), np.asfortranarray(Bn))
+    assert np.array_equal(i_f, oi) and np.array_equal(d1_f, od1) and np.array_equal(d2_f, od2)
+    # other shapes: ragged tile tails (n2 not a multiple of 32, n1 not of 128), 20 components, a duplicated B row (the
+    # first-index rule of max, :558, and its twin as the second), no projection, a single B row (d2 = 2 - 2 * -inf = inf)
+    rng = np.random.default_rng(5)
+    Bs = np.vstack([Bn[:333], Bn[7:8]])
+    As = np.vstack([An[:131], Bn[7:8]])
+    for k, use in ((48, True), (20, True), (48, False)):
+        oi, od1, od2 = oracle.pca2nn(As, Bs, k, use)
+        _, i2, e1, e2 = fm.nearest2ApproxFloatFast(As, Bs, {"ApproxNumComponents": k, "UsePCA": use})
+        assert np.array_equal(i2, oi) and np.array_equal(e1, od1) and np.array_equal(e2, od2), (k, use)
+        assert i2[-1] == 8 and e1[-1] == e2[-1]                        # the twin rows 8 and 334: the first wins, the other is second
+    oi, od1, od2 = oracle.pca2nn(As, Bs[:1], 48, False)
+    _, i2, e1, e2 = fm.nearest2ApproxFloatFast(As, Bs[:1], {"UsePCA": False})
+    assert np.array_equal(i2, oi) and np.array_equal(e1, od1) and np.all(np.isinf(e2)) and np.all(np.isinf(od2))
+    with pytest.raises(ValueError):
+        fm.nearest2ApproxFloatFast(As[:0], Bs)
+
+
+def test_pca_backend_at_bench_scale_equals_the_oracle(gpu):
+    """20 k x 20 k rows (what one pair of 4K views holds): every index and distance equal to the oracle's."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    rng = np.random.default_rng(9)
+    base = sift_like(rng, 26000)
+    A = base[:20000]
+    B = np.maximum(base[3000:23000] + 0.03 * rng.standard_normal((20000, 128)).astype(np.float32), 0)
+    B = (B / np.linalg.norm(B, axis=1, keepdims=True)).astype(np.float32)
+    oi, od1, od2 = oracle.pca2nn(A, B, 48, True)
+    _, i2, e1, e2 = fm.nearest2ApproxFloatFast(A, B)
+    assert np.array_equal(i2, oi) and np.array_equal(e1, od1) and np.array_equal(e2, od2)
 
 
 def test_pair_shards_compose_to_the_all_pairs_result(fm):

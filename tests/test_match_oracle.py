@@ -120,3 +120,70 @@ def test_hamming_tie_rules_and_edges():
     assert d2.tolist() == [16.0, 16.0]
     idx, d1, d2 = oracle.hamming_2nn(A, B[:0])      # N2 == 0 -> idx 0, NaN (:42-45)
     assert idx.tolist() == [0, 0] and np.all(np.isnan(d1)) and np.all(np.isnan(d2))
+
+
+# ---- a6: nearest2ApproxFloatFast (oracle/pca_oracle.c) against an independent numpy / LAPACK evaluation --------------------
+def _pca_sets(seed=3, n1=300, n2=700):
+    rng = np.random.default_rng(seed)
+    base = sift_like(rng, n2 + 100)
+    A = np.maximum(base[:n1] + 0.02 * rng.standard_normal((n1, 128)).astype(np.float32), 0)
+    A = (A / np.linalg.norm(A, axis=1, keepdims=True)).astype(np.float32)
+    return A, base[50:50 + n2].copy()
+
+
+def test_pca_basis_spans_lapacks_principal_subspace_with_pcas_sign_convention():
+    """The oracle's cyclic-Jacobi axes against numpy.linalg.eigh of a float64 covariance: same eigenvalues, the same axes up
+    to what float32 storage and the f32 covariance chain allow, every axis signed so that its largest entry is positive
+    (pca's documented convention), orthonormal, ordered by descending variance."""
+    _, B = _pca_sets()
+    mu, coeff, cov = oracle.pca_basis(B, 48)
+    assert np.allclose(mu, B.astype(np.float64).mean(0), rtol=0, atol=1e-7)
+    Bc = B.astype(np.float64) - B.astype(np.float64).mean(0)
+    cov64 = Bc.T @ Bc / (len(B) - 1)
+    assert np.abs(cov - cov64).max() < 2e-6 * np.abs(cov64).max()
+    w, V = np.linalg.eigh(cov)
+    V = V[:, ::-1][:, :48]
+    C = coeff.astype(np.float64)
+    assert np.abs(C.T @ C - np.eye(48)).max() < 1e-6
+    assert np.all(C[np.abs(C).argmax(0), np.arange(48)] > 0)
+    var = np.einsum("kc,kl,lc->c", C, cov, C)
+    assert np.all(np.diff(var) <= 1e-12) and np.allclose(var, w[::-1][:48], rtol=1e-5)
+    # axis by axis where the spectrum is well separated, as a subspace otherwise
+    gaps = np.abs(np.diff(w[::-1][:49]))
+    for c in range(48):
+        if min(gaps[c], gaps[c - 1] if c else np.inf) > 1e-3 * w[-1]:
+            assert abs(abs(C[:, c] @ V[:, c]) - 1) < 1e-5, c
+    assert np.linalg.norm(C - V @ (V.T @ C)) < 1e-4
+
+
+def test_pca2nn_equals_a_numpy_evaluation_of_the_reference_steps():
+    """matchFeaturesScratch.m:476-490, 552-570 step by step in numpy (float64 products, so only clear winners are compared bit
+    for bit): indices agree wherever the two best similarities are separated, distances to 1e-5; UsePCA = false and a
+    dimension not above ApproxNumComponents skip the projection (:478)."""
+    A, B = _pca_sets(4)
+    idx, d1, d2 = oracle.pca2nn(A, B, 48, True)
+    mu, coeff, _ = oracle.pca_basis(B, 48)
+    Ap, Bp = (A - mu).astype(np.float64) @ coeff, (B - mu).astype(np.float64) @ coeff
+    eps = np.finfo(np.float32).eps
+    Ap /= np.sqrt((Ap * Ap).sum(1, keepdims=True)) + eps
+    Bp /= np.sqrt((Bp * Bp).sum(1, keepdims=True)) + eps
+    G = Ap @ Bp.T
+    order = np.argsort(-G, axis=1, kind="stable")
+    s1, s2 = G[np.arange(len(A)), order[:, 0]], G[np.arange(len(A)), order[:, 1]]
+    clear = s1 - s2 > 1e-5
+    assert clear.mean() > 0.95 and np.array_equal(idx[clear], order[clear, 0] + 1)
+    assert np.abs(d1 - (2 - 2 * s1)).max() < 1e-5 and np.abs(d2 - (2 - 2 * s2)).max() < 1e-5
+    i0, e1, e2 = oracle.pca2nn(A, B, 48, False)
+    i128, f1, f2 = oracle.pca2nn(A, B, 128, True)
+    assert np.array_equal(i0, i128) and np.array_equal(e1, f1) and np.array_equal(e2, f2)
+    An = A / (np.sqrt((A.astype(np.float64) ** 2).sum(1, keepdims=True)) + eps)
+    Bn = B / (np.sqrt((B.astype(np.float64) ** 2).sum(1, keepdims=True)) + eps)
+    G = An @ Bn.T
+    assert np.mean(i0 == G.argmax(1) + 1) > 0.99
+    # first-index rule and the twin as the second (:558-560)
+    B2 = np.vstack([B[:40], B[5:6]])
+    i2, g1, g2 = oracle.pca2nn(B[5:6], B2, 48, False)
+    assert i2[0] == 6 and g1[0] == g2[0]
+    # a single B row: the second similarity is max of an all -inf row
+    i1, h1, h2 = oracle.pca2nn(A[:3], B[:1], 48, False)
+    assert np.all(i1 == 1) and np.all(np.isinf(h2)) and np.all(h2 > 0)
