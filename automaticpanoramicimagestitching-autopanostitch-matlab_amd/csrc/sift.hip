@@ -1008,6 +1008,162 @@ __global__ __launch_bounds__(256) void extrema_march_kernel(const PyrTable* __re
     }
 }
 
+// ---- the same sweep, one wave per strip, rows in registers (round 5, the default) ---------------------------------------------
+// extrema_march_kernel's counters (profiles/r04d_pmc_extrema.txt): 61 M vector, 54 M scalar and 16 M LDS wave-instructions per
+// 4K view, two barriers per four rows, four workgroups per CU - three pipes a third busy each and chained by the barriers; it
+// streamed at 2.9 TB/s.  Here nothing is shared between waves: a wave owns a strip of 128 columns (lane l: columns x0 + 2 l and
+// x0 + 2 l + 1, the two outer lanes are halo) and walks down its chunk of rows.  Per arriving row a lane subtracts its 2 x (nl + 2)
+// DoG values, takes the horizontal 3-max / 3-min with its neighbours' edge values through DPP (wave_shr / wave_shl, no LDS), keeps
+// those for the last three rows in registers (slots rotate by a 3x unrolled loop), and tests the centre row.  The loads of the
+// row three steps ahead are in flight while a row is consumed.  No LDS traffic but the rare cell records, no barrier.  Same
+// window logic, same cells (their order is irrelevant: they are sorted into the canonical keypoint order later).
+constexpr int kWS = 124;     // columns a wave owns (64 lanes x 2 - 4)
+constexpr int kWCells = 256; // cell records a wave parks in LDS before they go to the global list
+struct ExtremaWavePlan {
+    int job_ptr[17];  // first wave job of octave o
+    int nstrip[16];   // strips per row of chunks
+    int ch[16];       // rows per chunk
+};
+
+__device__ __forceinline__ float dpp_from_lower_lane(float v) {  // lane l <- lane l - 1 (wave_shr:1); lane 0 keeps its own
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float v) {  // lane l <- lane l + 1 (wave_shl:1); lane 63 keeps its own
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int nl>
+__global__ __launch_bounds__(256) void extrema_wave_kernel(const PyrTable* __restrict__ pt, ExtremaWavePlan plan, float thr,
+                                                           unsigned long long* __restrict__ cells,
+                                                           unsigned int* __restrict__ count, unsigned int cap) {
+    constexpr int NG = nl + 3, ND = nl + 2;
+    __shared__ unsigned long long s_cells[4][kWCells];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job = (int)blockIdx.x * 4 + wave;
+    if (job >= plan.job_ptr[16]) return;  // (whole waves leave: nothing below synchronises across waves)
+    int o = 0;
+    while (o < 15 && job >= plan.job_ptr[o + 1]) ++o;
+    const OctaveDesc& od = pt->oct[o];
+    const int w = od.w, h = od.h;
+    const int local = job - plan.job_ptr[o];
+    const int strip = local % plan.nstrip[o], chunk = local / plan.nstrip[o];
+    const int x0 = strip * kWS - 2, y0 = chunk * plan.ch[o], y1 = min(y0 + plan.ch[o], h);
+    const int rc0 = max(y0, kBorder), rc1 = min(y1, h - kBorder);  // centre rows [rc0, rc1)
+    if (rc0 >= rc1) return;
+    const __attribute__((address_space(1))) float* G[NG];
+#pragma unroll
+    for (int p = 0; p < NG; ++p) G[p] = (const __attribute__((address_space(1))) float*)od.G[p];
+    // this lane's column pair; pairs past the image edge are clamped inside the row (their values only reach columns
+    // within kBorder of the edge, which are never centres)
+    const int c0 = x0 + 2 * lane;
+    const int cb = min(max(c0, 0), w - 2);
+    const bool own = lane >= 1 && lane <= 62;
+    const bool ok0 = own && c0 >= kBorder && c0 < w - kBorder, ok1 = own && c0 + 1 >= kBorder && c0 + 1 < w - kBorder;
+    typedef float f32x2g __attribute__((ext_vector_type(2)));
+    f32x2g q[3][NG];  // rows in flight, slot = (row - (rc0 - 1)) % 3
+    auto fetch = [&](auto S, int row) __attribute__((always_inline)) {
+        constexpr int sl = decltype(S)::value;
+        const size_t off = (size_t)min(row, h - 1) * w + cb;
+#pragma unroll
+        for (int p = 0; p < NG; ++p) q[sl][p] = *reinterpret_cast<const __attribute__((address_space(1))) f32x2g*>(G[p] + off);
+    };
+    float hm[3][ND][2], hn[3][ND][2];  // horizontal 3-max / 3-min of the DoG rows, by row slot
+    float dc[3][nl][2];                // the DoG values of the rows themselves, layers 1 .. nl
+    // a row's loaded planes -> its slot of hm / hn / dc
+    auto reduce_row = [&](auto S) __attribute__((always_inline)) {
+        constexpr int sl = decltype(S)::value;
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const float d0 = q[sl][p + 1].x - q[sl][p].x, d1 = q[sl][p + 1].y - q[sl][p].y;
+            const float lf = dpp_from_lower_lane(d1), rt = dpp_from_upper_lane(d0);
+            hm[sl][p][0] = fmaxf(fmaxf(lf, d0), d1);
+            hm[sl][p][1] = fmaxf(fmaxf(d0, d1), rt);
+            hn[sl][p][0] = fminf(fminf(lf, d0), d1);
+            hn[sl][p][1] = fminf(fminf(d0, d1), rt);
+            if (p >= 1 && p <= nl) {
+                dc[sl][p - 1][0] = d0;
+                dc[sl][p - 1][1] = d1;
+            }
+        }
+    };
+    int qn = 0;  // cell records of this wave so far (wave-uniform)
+    auto emit = [&](bool pass, int layer, int r, int c) __attribute__((always_inline)) {
+        const unsigned long long m = __ballot(pass);
+        if (m == 0ull) return;
+        if (pass) {
+            const unsigned long long cell = ((unsigned long long)o << 40) | ((unsigned long long)layer << 32) |
+                                            ((unsigned long long)r << 16) | (unsigned long long)c;
+            const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
+            if (at < kWCells) {
+                s_cells[wave][at] = cell;
+            } else {
+                const unsigned int slot2 = atomicAdd(count, 1u);
+                if (slot2 < cap) cells[slot2] = cell;
+            }
+        }
+        qn += __popcll(m);
+    };
+    // centre row r: A = slot of row r - 1, B = slot of row r, C = slot of row r + 1 (just reduced)
+    auto test_row = [&](auto SA, auto SB, auto SC, int r) __attribute__((always_inline)) {
+        constexpr int a = decltype(SA)::value, b = decltype(SB)::value, c = decltype(SC)::value;
+        float wmax[3][2], wmin[3][2];
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                wmax[p % 3][k] = fmaxf(fmaxf(hm[a][p][k], hm[b][p][k]), hm[c][p][k]);
+                wmin[p % 3][k] = fminf(fminf(hn[a][p][k], hn[b][p][k]), hn[c][p][k]);
+            }
+            if (p < 2) continue;
+            const int layer = p - 1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float val = dc[b][layer - 1][k];
+                const float mx = fmaxf(fmaxf(wmax[0][k], wmax[1][k]), wmax[2][k]);
+                const float mn = fminf(fminf(wmin[0][k], wmin[1][k]), wmin[2][k]);
+                const bool pass = (k ? ok1 : ok0) && fabsf(val) > thr && ((val > 0 && val >= mx) || (val < 0 && val <= mn));
+                emit(pass, layer, r, c0 + k);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // rows rc0 - 1 (slot 0) and rc0 (slot 1) first; from then on the row three ahead is requested as a row is consumed
+    fetch(I0{}, rc0 - 1);
+    fetch(I1{}, rc0);
+    fetch(I2{}, rc0 + 1);
+    reduce_row(I0{});
+    fetch(I0{}, rc0 + 2);
+    reduce_row(I1{});
+    fetch(I1{}, rc0 + 3);
+    for (int r = rc0; r < rc1; r += 3) {
+        // row r + 1 is in slot 2, rows r + 2 / r + 3 are in flight in slots 0 / 1
+        reduce_row(I2{});
+        fetch(I2{}, r + 4);
+        test_row(I0{}, I1{}, I2{}, r);
+        if (r + 1 >= rc1) break;
+        reduce_row(I0{});
+        fetch(I0{}, r + 5);
+        test_row(I1{}, I2{}, I0{}, r + 1);
+        if (r + 2 >= rc1) break;
+        reduce_row(I1{});
+        fetch(I1{}, r + 6);
+        test_row(I2{}, I0{}, I1{}, r + 2);
+    }
+    if (qn == 0) return;
+    const int n_loc = min(qn, kWCells);
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned int)n_loc);
+    base = __builtin_amdgcn_readfirstlane(base);
+    __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: the records above land before these reads)
+    for (int e = lane; e < n_loc; e += 64) {
+        const unsigned int slot = base + e;
+        if (slot < cap) cells[slot] = s_cells[wave][e];
+    }
+}
+
 // one lane per detected extremum: Newton refinement + contrast/edge tests (dense, no divergence against
 // the detection sweep)
 __global__ void refine_kernel(const PyrTable* __restrict__ pt, const unsigned long long* __restrict__ cells,
@@ -1583,8 +1739,42 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         unsigned int h_counts[2] = {0, 0};
         for (int attempt = 0; attempt < 2; ++attempt) {
             APS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned int), stream()));
-            if (!std::getenv("APS_EXTREMA_TILES")) {
-                // one marching launch over all octaves (extrema_march_kernel)
+            if (!std::getenv("APS_EXTREMA_TILES") && !std::getenv("APS_EXTREMA_MARCH")) {
+                // one launch over all octaves, one wave per strip and chunk of rows (extrema_wave_kernel)
+                ExtremaWavePlan plan;
+                std::memset(&plan, 0, sizeof plan);
+                static const int ch_env = std::getenv("APS_EXTREMA_CH") ? std::atoi(std::getenv("APS_EXTREMA_CH")) : 0;
+                int run = 0;
+                for (int o = 0; o < 16; ++o) {
+                    plan.job_ptr[o] = run;
+                    plan.nstrip[o] = plan.ch[o] = 1;
+                    if (o >= n_oct) continue;
+                    const OctaveDesc& od = table.oct[o];
+                    if (od.w <= 2 * kBorder || od.h <= 2 * kBorder) continue;
+                    const int ns = cdiv(od.w, kWS);
+                    // rows per chunk (every chunk re-reads two halo rows): ~8000 wave jobs on the largest octave, >= 24 rows
+                    int ch = (int)(((long long)od.h * ns + 8191) / 8192);
+                    ch = std::max(24, ch);
+                    if (ch_env > 0) ch = ch_env;
+                    plan.nstrip[o] = ns;
+                    plan.ch[o] = ch;
+                    run += ns * cdiv(od.h, ch);
+                }
+                plan.job_ptr[16] = run;
+                if (run > 0) {
+                    Prof prof("sift_extrema");
+                    const int wgs = cdiv(run, 4);
+                    switch (nl) {
+                        case 1: extrema_wave_kernel<1><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 2: extrema_wave_kernel<2><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 3: extrema_wave_kernel<3><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        case 4: extrema_wave_kernel<4><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                        default: extrema_wave_kernel<5><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
+                    }
+                    check_launch("extrema_wave_kernel");
+                }
+            } else if (!std::getenv("APS_EXTREMA_TILES")) {
+                // one marching launch over all octaves (extrema_march_kernel; APS_EXTREMA_MARCH=1, rounds 3-4)
                 ExtremaPlan plan;
                 std::memset(&plan, 0, sizeof plan);
                 int run = 0;
