@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--global-probe", choices=["auto", "off"], default="auto",
                     help="after the timed steps, one pass of the reference's default matcher (featureMatchingGlobal) on the same "
                          "views, reported as global_matcher_probe (off: for profiling runs that want per-step launch counts)")
+    ap.add_argument("--with-gain", choices=["auto", "off"], default="auto",
+                    help="after the timed steps, time the same steps with input.gainCompensation = 1 (the reference's default, "
+                         "PP/inputs.m:94); reported as value_with_gain")
     ap.add_argument("--gain-compensation", action="store_true",
                     help="also run gainCompensationRKf (device overlap statistics + host solve) before the render; "
                          "off in the headline configuration, which follows BASELINE.json configs[2]")
@@ -497,6 +500,24 @@ def main():
     dt = time.perf_counter() - t0
     prof = capi.profile_all()
     capi.profile_enable(False)
+    # The same steps with input.gainCompensation = 1 (the reference's default, PP/inputs.m:94; renderPanorama.m:303-330): the
+    # overlap statistics on the device (gain_stats_kernel), the N x N x 3 sums back to the host, the host solve, the gains into
+    # the warp.  Reported as value_with_gain; the headline follows BASELINE.json configs[2], which does not name the switch.
+    dt_gain, infos_g = None, []
+    if args.with_gain == "auto" and not input_.get("gainCompensation"):
+        input_["gainCompensation"] = 1
+        try:
+            step(sync_download=True)  # warm-up (the statistics' workspaces)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pano_g, info_g = step()
+                info_g.pop("panoramas", None)
+                infos_g.append(info_g)
+            barrier()
+            dt_gain = time.perf_counter() - t0
+        finally:
+            input_["gainCompensation"] = 0
     dt_e2e = None
     if args.end_to_end == "auto":
         step(upload=True)  # warm-up: side stream
@@ -518,10 +539,11 @@ def main():
         if k not in prof:
             prof[k] = (v[0] * args.steps / warm_steps, v[1] * args.steps // warm_steps)
     if multi:
-        t = torch.tensor([dt, dt_e2e or 0.0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_e2e or 0.0, dt_gain or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         dt_e2e = float(t[1].item()) if dt_e2e is not None else None
+        dt_gain = float(t[2].item()) if dt_gain is not None else None
 
     if rank == 0:
         info = infos[-1]
@@ -588,7 +610,7 @@ def main():
         TRAFFIC_KEYS = {"match_screen_i8": ["match_screen_i8"], "match_cand_f16": ["match_cand_f16_kernel"], "match2nn": ["match2nn_kernel"],
                         "sift_blur": ["aps::blur_kernel<"], "render_warp": ["rw_warp_staged_kernel", "rw_warp_kernel"],
                         "render_pyr_down": ["rw_down_fused_kernel", "rw_down_kernel", "rw_up_kernel"]}
-        SIFT_KERNELS = ["blur_kernel", "blur_march_kernel", "extrema_march_kernel", "extrema_kernel", "gray_up_kernel", "descr_kernel",
+        SIFT_KERNELS = ["blur_kernel", "blur_march_kernel", "extrema_wave_kernel", "extrema_march_kernel", "extrema_kernel", "gray_up_kernel", "descr_kernel",
                         "orient_kernel", "refine_kernel", "decimate_kernel"]
 
         def roof(kernel, name, bound, work_per_step, peak, unit, note="", streams=1):
@@ -609,13 +631,15 @@ def main():
                  "concurrent_streams": streams, "wall_share_ms": round(ms / args.steps / streams, 3),
                  "timed": "live over the timed steps" if kernel in live else "during the last warm-up step"}
             if r["traffic"] is not None:
-                r["traffic_note"] = ("HBM-side bytes per launch: TCC_EA0_RDREQ/WRREQ x 64 B from a separate rocprofv3 --pmc "
+                r["traffic_note"] = ("HBM-side bytes per launch: the L2's memory-side requests by size (TCC_BUBBLE x 128 B + 64-B + 32-B reads; "
+                                     "64-B + 32-B writes: rocprofv3's own FETCH_SIZE / WRITE_SIZE terms) from separate rocprofv3 --pmc "
                                      f"pass of this workload ({traffic_file}, taken from these kernel sources); replayed from "
                                      "that committed file, not observed in this run")
                 if bound == "hbm":  # what the memory system really moved per step for this chain, over the chain's time
                     per_step = traffic_of(TRAFFIC_KEYS.get(kernel, ["\0"]), per_step=True)
                     r["traffic_bytes_per_step"] = per_step
                     r["achieved_measured_bytes"] = round(per_step * args.steps / (ms * 1e-3) / 1e9, 2)
+                    r["frac_measured_bytes"] = round(r["achieved_measured_bytes"] / peak, 4)
             elif traffic_stale:
                 r["traffic_note"] = traffic_stale
             if bound == "hbm" and streams == 1:  # (event sums of concurrent streams overlap: no rate from those)
@@ -634,7 +658,9 @@ def main():
         capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(scr_rows), ctypes.byref(scr_surv)))
         surv_share = scr_surv.value / scr_rows.value if scr_rows.value else 1.0
         cands = [
-            roof("match_screen_i8", "match_screen_i8x16_kernel (v_mfma_i32_16x16x64_i8: every descriptor pair once on int8 copies, "
+            roof("match_screen_i8", ("match_screen_i8_kernel (v_mfma_i32_32x32x32_i8, APS_SCREEN_SHAPE=32" if os.environ.get("APS_SCREEN_SHAPE") == "32"
+                                     else "match_screen_i8x16_kernel (v_mfma_i32_16x16x64_i8") +
+                 ": every descriptor pair once on int8 copies, "
                  "exact integer accumulation, per-row top-2, proof that a row fails the ratio/threshold filter)", "mfma",
                  flops_rank0, MFMA_I8_PEAK_TOPS, "TOP/s",
                  "achieved counts the ALGORITHMIC 2*128*Ni*Nj INTEGER multiply-adds against the dense int8 MFMA peak (5 POP/s = "
@@ -661,6 +687,8 @@ def main():
                  16.0 * a_cov + 3.0 * npix_rank0, HBM_PEAK_GBS, "GB/s"),
         ]
         cands = [c for c in cands if c]
+        for c_ in cands:  # every entry carries both fractions: the algorithmic one and the one on the bytes the memory system moved
+            c_.setdefault("frac_measured_bytes", None)
         dominant = max(cands, key=lambda c: c["wall_share_ms"]) if cands else None
         # The feature-extraction STAGE as one roofline entry (its kernels run on ten streams side by side, so per-kernel
         # event sums overlap): algorithmic bytes of SURVEY 8(d)'s materialised-pyramid model, and the bytes the stage
@@ -675,6 +703,7 @@ def main():
                           "traffic": round(sift_bytes) if sift_bytes else None,
                           **({"traffic_note": traffic_stale} if traffic_stale and not sift_bytes else {}),
                           "achieved_measured_bytes": round(sift_bytes / t_feat / 1e9, 2) if sift_bytes else None,
+                          "frac_measured_bytes": round(sift_bytes / t_feat / 1e9 / HBM_PEAK_GBS, 4) if sift_bytes else None,
                           "algorithmic_work_per_step": 574.0 * npix_rank0, "ms_per_step": round(1e3 * t_feat, 3),
                           "note": "574 B per input pixel is the survey's model (G and DoG planes written and re-read); DoG planes are "
                                   "not stored here, so `traffic` (bytes per STEP for this entry, all SIFT kernels) is lower; "
@@ -689,8 +718,13 @@ def main():
             # `value`: inputs resident in HBM when the timed region starts -> cropped uint8 panorama in pinned HOST memory.
             # value_end_to_end: pinned host uint8 images -> the same (PCIe both ways; SURVEY 8(d)'s "first byte uploaded").
             # value_resident: the same steps as `value` without the device-to-host copy of the panorama.
+            "value_definition": "bench contract: inputs resident in HBM when the timed region starts -> cropped uint8 panorama in pinned "
+                                "host memory; SURVEY 8(d)'s clock (first byte uploaded -> panorama on the host) is value_end_to_end, "
+                                "the reference's default gainCompensation = 1 is value_with_gain",
             "value_end_to_end": round(mpix_in * args.steps / dt_e2e, 2) if dt_e2e else None,
             "ms_per_step_end_to_end": round(1e3 * dt_e2e / args.steps, 2) if dt_e2e else None,
+            "value_with_gain": round(mpix_in * args.steps / dt_gain, 2) if dt_gain else None,
+            "ms_per_step_with_gain": round(1e3 * dt_gain / args.steps, 2) if dt_gain else None,
             "value_resident": round(mpix_in * args.steps / dt_resident, 2),
             "ms_per_step_resident": round(1e3 * dt_resident / args.steps, 2),
             # the panorama's device-to-host copy runs beside the next step's feature extraction (two pinned buffers); alone
@@ -699,9 +733,7 @@ def main():
             "ms_per_step_latency": round(1e3 * (dt_resident / args.steps + (min(dl_alone) if dl_alone else 0.0)), 2),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"[`value` starts with the inputs RESIDENT IN HBM and ends with the cropped uint8 panorama in pinned host "
-                            f"memory - it is not SURVEY 8(d)'s first-byte-uploaded number, which is value_end_to_end in this line] "
-                            f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
+                "workload": f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "
                             f"{int(OVERLAP * 100)}% overlap): SIFT -> " + ("all-pairs exhaustive 2-NN + Lowe ratio" if args.matcher == "pairwise" else "pooled exact 4-NN of all descriptors + per-query filter (featureMatchingGlobal)") + " -> batched RANSAC -> "
                             f"host match graph/cameras ({args.cameras}) -> spherical inverse warp + {args.bands}-band multiband blend, "
                             f"tile 2048 -> cropNonzeroBbox -> panorama copied to pinned host memory; BASELINE.json configs[2].  "
@@ -720,6 +752,8 @@ def main():
             # uploads, the device-to-host copy of the cropped panorama and the final synchronisation)
             "stages_ms_per_step_end_to_end": ({k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos_h) / len(infos_h), 2)
                                                for k in infos_h[-1]["times"]} if dt_e2e else None),
+            "stages_ms_per_step_with_gain": ({k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos_g) / len(infos_g), 2)
+                                             for k in infos_g[-1]["times"]} if dt_gain else None),
             "kernels": kernels,
         }
         if world == 1 and args.matcher == "pairwise" and (nx, ny) == (NX, NY) and args.global_probe == "auto":

@@ -1,0 +1,104 @@
+"""Round-5 probe (second half): what share of the rows would survive a screening pass on 6-bit (e2m3) or
+4-bit (e2m1) block-scaled codes instead of int8?  The screen's proof ("The int8 screen ... proves
+instead of computing") only needs an exactly known code product and the measured residual norms:
+    a . b_j = code(a) . code(b_j) + terms bounded by E_i = |ea| max|b| + (|a| + |ea|) max|eb|
+    L1 = a2 + min|b|^2 - 2 (D0 + E),  H2 = a2 + max|b|^2 - 2 (D1 - E),   row dismissed iff L1 > r^2 H2 or L1 > MatchThreshold
+with D0 >= D1 the two largest code products of the row.  Emulated here in float64 on the bench scene's descriptors for
+  int8   : rows scaled per row to +-127, columns per set with an offset to 0..255 (what q8_desc_kernel does),
+  int7   : the same with 127 column levels (the APS_Q8_SYMMETRIC experiment of round 4, for calibration of the emulation),
+  e2m3   : MX fp6, one power-of-two scale per 32 elements (free in v_mfma_scale_f32_16x16x128_f8f6f4), round to nearest,
+  e2m3c  : the same on data centred by a constant per set (uses the sign bit; the cross terms are exact row / column sums),
+  e2m1   : MX fp4.
+Pairs: overlapping neighbours and far-apart (non-overlapping) views of the 64 x 4K scene, weighted as the bench's 2016 pairs
+are (210 overlapping, 1806 not)."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+import apsamd
+from importlib import import_module
+synth = import_module(apsamd.__name__ + ".synth")
+pl = import_module(apsamd.__name__ + ".pipeline")
+
+W, H, F = 3840, 2160, 8000.0
+cams = synth.grid_cameras(8, 8, W, H, F, 2 * np.arctan(W / (2 * F)) * 0.6, 2 * np.arctan(H / (2 * F)) * 0.6, 1.0, 12345)
+views = [0, 1, 8, 9, 36, 63]
+imgs = [synth.render_view(cams[i], H, W, 12345, "cuda", finest_px=16.0) for i in views]
+inp = pl.default_input(bands=5)
+descs = [d.double() for d, _ in pl.sift_many(inp, imgs)]
+del imgs
+R2, THR = 0.36, 1.5
+
+E2M3 = torch.tensor(sorted({(m / 8.0 if e == 0 else (1 + m / 8.0) * 2 ** (e - 1)) for e in range(4) for m in range(8)}), dtype=torch.float64, device="cuda")
+E2M1 = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6], dtype=torch.float64, device="cuda")
+
+
+def q_uniform_rows(X, levels):      # per-row symmetric scale
+    s = X.abs().amax(1, keepdim=True).clamp_min(1e-30) / levels
+    return torch.round(X / s).clamp(-levels, levels) * s
+
+
+def q_uniform_cols(X, levels):      # per-set scale + offset, `levels` steps over [min, max]
+    lo, hi = X.min(), X.max()
+    s = (hi - lo) / levels
+    return torch.round((X - lo) / s).clamp(0, levels) * s + lo
+
+
+def q_mx(X, table):                 # block of 32 elements: power-of-two scale so that the block maximum fits the table's top
+    n = X.shape[0]
+    B = X.view(n, 4, 32)
+    top = table[-1]
+    s = torch.exp2(torch.ceil(torch.log2(B.abs().amax(2, keepdim=True).clamp_min(1e-30) / top)))
+    Y = (B / s).abs()
+    idx = torch.bucketize(Y, (table[1:] + table[:-1]) / 2)   # round to nearest table entry
+    return (table[idx] * torch.sign(B) * s).view(n, 128)
+
+
+def survivors(A, B, Aq, Bq):
+    ea = (A - Aq).norm(dim=1)
+    eb = (B - Bq).norm(dim=1).max()
+    nb = B.norm(dim=1)
+    a2 = (A * A).sum(1)
+    E = ea * nb.max() + (A.norm(dim=1) + ea) * eb
+    keep = 0
+    for r0 in range(0, A.shape[0], 4096):
+        D = Aq[r0:r0 + 4096] @ Bq.T
+        top = torch.topk(D, 2, dim=1).values
+        L1 = a2[r0:r0 + 4096] + nb.min() ** 2 - 2 * (top[:, 0] + E[r0:r0 + 4096])
+        H2 = a2[r0:r0 + 4096] + nb.max() ** 2 - 2 * (top[:, 1] - E[r0:r0 + 4096])
+        keep += int((~((L1 > R2 * H2) | (L1 > THR))).sum())
+    return keep / A.shape[0], float(ea.mean()), float(eb)
+
+
+def codes(X, rows):
+    out = {
+        "int8": q_uniform_rows(X, 127) if rows else q_uniform_cols(X, 255),
+        "int7": q_uniform_rows(X, 127) if rows else q_uniform_cols(X, 127),
+        "e2m3": q_mx(X, E2M3),
+        "e2m1": q_mx(X, E2M1),
+    }
+    return out
+
+
+pairs = {"overlapping": [(0, 1), (0, 2), (1, 3)], "disjoint": [(0, 4), (0, 5), (1, 5)]}
+res = {}
+for kind, pl_ in pairs.items():
+    for (i, j) in pl_:
+        A, B = descs[i], descs[j]
+        ca, cb = codes(A, True), codes(B, False)
+        for name in ca:
+            s, ea, eb = survivors(A, B, ca[name], cb[name])
+            res.setdefault((kind, name), []).append((s, ea, eb))
+        # centred e2m3: x - c with c = the set's mean element; (a - c).(b - c) = a.b - c (sum a + sum b) + 128 c^2, the correction exact
+        c = float(torch.cat([A, B]).mean())
+        # (a2, |b| in the bound are those of the original rows; only the residuals come from the shifted data)
+        Aq, Bq = q_mx(A - c, E2M3) + c, q_mx(B - c, E2M3) + c
+        s, ea, eb = survivors(A, B, Aq, Bq)
+        res.setdefault((kind, "e2m3c"), []).append((s, ea, eb))
+print(f"views {views}: rows per view {[int(d.shape[0]) for d in descs]}")
+print(f"{'code':8s} {'overlapping pairs':>22s} {'disjoint pairs':>22s} {'bench-weighted':>16s}   mean |ea|  max |eb|")
+for name in ["int8", "int7", "e2m3", "e2m3c", "e2m1"]:
+    so = np.mean([r[0] for r in res[("overlapping", name)]])
+    sd = np.mean([r[0] for r in res[("disjoint", name)]])
+    ea = np.mean([r[1] for r in res[("disjoint", name)]])
+    eb = np.mean([r[2] for r in res[("disjoint", name)]])
+    print(f"{name:8s} {100 * so:21.2f}% {100 * sd:21.2f}% {100 * (210 * so + 1806 * sd) / 2016:15.2f}%   {ea:.5f}  {eb:.5f}")
