@@ -117,6 +117,8 @@ _SIGNATURES = {
                    _vp, _vp],
     "aps_render_tiles": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), C.POINTER(aps_render_opts), _i,
                          _i, _i, _vp, _vp],
+    "aps_render_tile_range": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), C.POINTER(aps_render_opts), _i,
+                              _i, _i, _vp, _vp],
     "aps_warp_tile": [C.POINTER(aps_image), C.POINTER(aps_canvas), _i, _i, _i, _i, _f, _vp, _vp, _vp,
                       _vp],
     "aps_gain_overlap_stats": [C.POINTER(aps_image), _i, C.POINTER(aps_canvas), _i, _vp, _vp, _vp],

@@ -1275,11 +1275,28 @@ int aps_render(const aps_image* images, int n_img, const aps_canvas* canvas,
     return aps_render_tiles(images, n_img, canvas, opts, out_layout, 0, 1, pano, covered);
 }
 
+// the tile loop for the tiles t (row-major index) with first <= t < last and (t - first) % step == 0; every = all tiles of the canvas
+static int render_tiles_impl(const aps_image* images, int n_img, const aps_canvas* canvas, const aps_render_opts* opts, int out_layout,
+                             int tile_first, int tile_step, int tile_last, bool every, uint8_t* pano, uint8_t* covered);
+
 int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canvas,
                      const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
                      uint8_t* pano, uint8_t* covered) {
+    if (!(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step))
+        return guarded([&] { fail(APS_E_ARG, "bad tile subset"); });
+    return render_tiles_impl(images, n_img, canvas, opts, out_layout, tile_first, tile_step, 0x7fffffff, tile_step == 1, pano, covered);
+}
+
+int aps_render_tile_range(const aps_image* images, int n_img, const aps_canvas* canvas, const aps_render_opts* opts, int out_layout,
+                          int tile_begin, int tile_end, uint8_t* pano, uint8_t* covered) {
+    if (!(tile_begin >= 0 && tile_end >= tile_begin))
+        return guarded([&] { fail(APS_E_ARG, "bad tile range"); });
+    return render_tiles_impl(images, n_img, canvas, opts, out_layout, tile_begin, 1, tile_end, false, pano, covered);
+}
+
+static int render_tiles_impl(const aps_image* images, int n_img, const aps_canvas* canvas, const aps_render_opts* opts, int out_layout,
+                             int tile_first, int tile_step, int tile_last, bool every, uint8_t* pano, uint8_t* covered) {
     return guarded([&] {
-        APS_REQUIRE(tile_step >= 1 && tile_first >= 0 && tile_first < tile_step, APS_E_ARG, "bad tile subset");
         APS_REQUIRE(images && canvas && opts && pano, APS_E_ARG, "NULL argument");
         APS_REQUIRE(n_img >= 1, APS_E_ARG, "need at least one image");
         APS_REQUIRE(opts->tile_h > 0 && opts->tile_w > 0, APS_E_ARG,
@@ -1294,7 +1311,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         PreparedImages P;
         // all tiles: every image's pixels at once, converted while the host works out the footprints; a share of the tiles (a
         // rank of a sharded render): tables now, pixels once the footprints say which images the share meets
-        prepare_images(images, n_img, P, tile_step == 1);
+        prepare_images(images, n_img, P, every);
         const std::function<void(const std::vector<char>&)> convert = [&P](const std::vector<char>& used) { convert_images(P, &used); };
         const DevCanvas cv = make_canvas(*canvas);
         const int H = cv.H, W = cv.W;
@@ -1307,7 +1324,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         std::vector<Ws<float4>> store;
         // a host buffer receives the whole canvas back: start from its current content so that tiles of
         // other ranks are left untouched
-        if (tile_step > 1) {
+        if (!every) {
             if (oP.host) APS_HIP(hipMemcpyAsync(oP.d, oP.host, HW * 3, hipMemcpyHostToDevice, stream()));
             if (oC.host) APS_HIP(hipMemcpyAsync(oC.d, oC.host, HW, hipMemcpyHostToDevice, stream()));
         }
@@ -1317,7 +1334,7 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
         for (int r0 = 0; r0 < H; r0 += TH)
             for (int c0 = 0; c0 < W; c0 += TW) {
                 ++tile_index;
-                if (tile_index % tile_step != tile_first) continue;
+                if (tile_index < tile_first || tile_index >= tile_last || (tile_index - tile_first) % tile_step != 0) continue;
                 tiles.push_back({r0, c0, std::min(TH, H - r0), std::min(TW, W - c0)});
             }
         const int nt = (int)tiles.size();

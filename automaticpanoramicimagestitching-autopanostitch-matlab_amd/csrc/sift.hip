@@ -371,12 +371,53 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     blur_tile_passes<R>(s_in, s_row, gk, x0, y0, h, w, out, dec, dh, dw);
 }
 
+// Gray plane of the source image as bytes, row-major (round 5): rgb2gray's value is an integer 0..255 (floor(d + 0.5) of the
+// f64 combination), so a uint8 plane holds it exactly.  blur_base_kernel used to convert the RGB footprint of every tile
+// itself - 936 footprint pixels for 512 source pixels, three byte loads and the f64 arithmetic each, a quarter of the
+// kernel's vector instructions; now the conversion runs once per source pixel (25 MB read, 8 MB written per 4K view) and
+// the tiles read bytes.
+__global__ __launch_bounds__(256) void gray_u8_kernel(const uint8_t* __restrict__ img, int h, int w, int c, int layout,
+                                                      uint8_t* __restrict__ gray) {
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w) return;
+    uint8_t g[4];
+    const bool fast = c == 3 && layout == APS_IMG_U8_HWC && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0;
+    if (fast) {  // 4 pixels = 12 bytes = three aligned dwords
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(img + ((size_t)y * w + x4) * 3);
+        const uint32_t a = p[0], b = p[1], d_ = p[2];
+        const uint8_t ch[12] = {(uint8_t)a, (uint8_t)(a >> 8), (uint8_t)(a >> 16), (uint8_t)(a >> 24), (uint8_t)b, (uint8_t)(b >> 8),
+                                (uint8_t)(b >> 16), (uint8_t)(b >> 24), (uint8_t)d_, (uint8_t)(d_ >> 8), (uint8_t)(d_ >> 16), (uint8_t)(d_ >> 24)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double d = 0.298936021293775 * ch[3 * k] + 0.587043074451121 * ch[3 * k + 1] + 0.114020904255103 * ch[3 * k + 2];
+            g[k] = (uint8_t)(float)floor(d + 0.5);
+        }
+        *reinterpret_cast<uint32_t*>(gray + (size_t)y * w + x4) = g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
+        return;
+    }
+    for (int k = 0; k < 4 && x4 + k < w; ++k) {
+        const int x = x4 + k;
+        float v;
+        if (c == 1) {
+            v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * w + x] : img[(size_t)x * h + y]);
+        } else {
+            uint8_t ch[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                ch[q] = layout == APS_IMG_U8_HWC ? img[((size_t)y * w + x) * 3 + q] : img[(size_t)q * h * w + (size_t)x * h + y];
+            const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
+            v = (float)floor(d + 0.5);
+        }
+        gray[(size_t)y * w + x] = (uint8_t)v;
+    }
+}
+
 // The base plane of octave 0 in one pass: gray conversion, 2x bilinear upsample (gray_up_kernel's expressions, so the same
 // bits) and the first blur.  The tile's inputs are interpolated straight into the blur's LDS tile from the gray values of
 // the tile's footprint (computed into LDS first); neither the gray plane nor the doubled plane is ever stored - a 4K view
 // saves the 133 MB write of gray_up_kernel and the 133 MB read of the blur.  img is sh x sw; the output plane 2sh x 2sw.
 template <int R>
-__global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restrict__ img, int sh, int sw, int c, int layout,
+__global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restrict__ gray, int sh, int sw,
                                                         GaussK gk, float* __restrict__ out) {
     constexpr int RP = (R + 3) & ~3;
     constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
@@ -399,19 +440,7 @@ __global__ __launch_bounds__(256) void blur_base_kernel(const uint8_t* __restric
     for (int e = tid; e < GH * GW; e += 256) {
         const int ly = e / GW, lx = e - ly * GW;
         const int y = min(cy0 + ly, sh - 1), x = min(cx0 + lx, sw - 1);
-        float v;
-        if (c == 1) {
-            v = (float)(layout == APS_IMG_U8_HWC ? img[(size_t)y * sw + x] : img[(size_t)x * sh + y]);
-        } else {
-            uint8_t ch[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                ch[k] = layout == APS_IMG_U8_HWC ? img[((size_t)y * sw + x) * 3 + k]
-                                                 : img[(size_t)k * sh * sw + (size_t)x * sh + y];
-            const double d = 0.298936021293775 * ch[0] + 0.587043074451121 * ch[1] + 0.114020904255103 * ch[2];
-            v = (float)floor(d + 0.5);
-        }
-        s_g[ly][lx] = v;
+        s_g[ly][lx] = (float)gray[(size_t)y * sw + x];  // (gray_u8_kernel: rgb2gray's integer value)
     }
     // the interpolation's row and column terms (index of the first source in s_g, index of the second, second weight), once
     // per tile row / column instead of once per pixel; same expressions as gray_up_kernel.  (The clamps only act on halo
@@ -1610,7 +1639,7 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
 
 // gray + 2x upsample + first blur in one kernel (blur_base_kernel); false when the radius has no tile instantiation (the
 // caller then takes gray_up_kernel + launch_blur).  APS_SIFT_NO_BASE_FUSE=1 forces that two-kernel path (same bits).
-static bool launch_base_blur(const uint8_t* img, int sh, int sw, int c, int layout, double sigma, float* out) {
+static bool launch_base_blur(const uint8_t* img, int sh, int sw, int c, int layout, double sigma, float* out, Ws<uint8_t>& gray) {
     static const bool off = [] {
         const char* e = std::getenv("APS_SIFT_NO_BASE_FUSE");
         return e && e[0] == '1';
@@ -1618,12 +1647,15 @@ static bool launch_base_blur(const uint8_t* img, int sh, int sw, int c, int layo
     if (off) return false;
     const GaussK gk = make_gauss(sigma);
     const int r = (gk.n - 1) / 2;
+    if (r < 3 || r > 8) return false;
     const dim3 grid(cdiv(2 * sw, kTW), cdiv(2 * sh, kTH));
     Prof prof("sift_blur");
+    gray.alloc((size_t)sh * sw);
+    gray_u8_kernel<<<dim3(cdiv(cdiv(sw, 4), 256), sh), 256, 0, stream()>>>(img, sh, sw, c, layout, gray);
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
-        blur_base_kernel<R><<<grid, 256, 0, stream()>>>(img, sh, sw, c, layout, gk, out); \
+        blur_base_kernel<R><<<grid, 256, 0, stream()>>>(gray, sh, sw, gk, out); \
         break;
         APS_BLUR_CASE(3)
         APS_BLUR_CASE(4)
@@ -1669,6 +1701,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         const int H = height, W = width;
         In<uint8_t> dimg(img, (size_t)H * W * channels);
         Ws<float> up, scratch;  // (up: the doubled gray plane, only when the fused base kernel does not apply)
+        Ws<uint8_t> gray8;      // the source gray plane as bytes (gray_u8_kernel), read by blur_base_kernel
         const int n_oct = std::min(num_octaves(H, W), 16);
         if (n_oct <= 0) return;
         // pyramid storage
@@ -1701,7 +1734,7 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             if (o == 0) {
                 double sd = params->sigma * params->sigma - 4.0 * 0.5 * 0.5;
                 if (sd < 0.01) sd = 0.01;
-                if (!launch_base_blur(dimg, H, W, channels, img_layout, std::sqrt(sd), G[0])) {
+                if (!launch_base_blur(dimg, H, W, channels, img_layout, std::sqrt(sd), G[0], gray8)) {
                     up.alloc((size_t)4 * H * W);
                     gray_up_kernel<<<dim3(cdiv(2 * W, kGUW), cdiv(2 * H, kGUH)), 256, 0, stream()>>>(dimg, H, W, channels, img_layout, up);
                     check_launch("gray_up_kernel");

@@ -433,13 +433,15 @@ def sift_extract(input, image, device_out=False, want_aux=False, points_device=F
     if dev_pts:
         check(lib.aps_synchronize())  # (with every output resident the call returns without waiting for its last kernel)
         pts = loc[:, :n].t().contiguous()
+        torch.cuda.current_stream().synchronize()  # the (small) transpose ran on torch's stream; consumers run on the library's
     else:
         pts = np.ascontiguousarray(loc[:, :n].T)
-    # the capacity buffer is sized for the worst case (H*W/64 rows = 66 MB for a 4K view): hand back a right-sized copy
-    # instead of a view that keeps it alive (64 views would pin ~4 GB); the library synchronised its stream above
+    # Resident output: the first n rows of the capacity buffer, as a view.  (Until round 4 a right-sized clone was handed
+    # back so that the worst-case buffer - H*W/64 rows = 66 MB for a 4K view - could be freed: a 10 MB device copy per view
+    # on torch's stream plus a stream synchronisation, 23 us of a chip-filling copy kernel and the host wait, to save
+    # 64 x 56 MB = 3.6 GB of a 288 GB device for the length of one step.)
     if device_out:
-        d = desc[:n].clone()
-        torch.cuda.current_stream().synchronize()  # the copy ran on torch's stream; consumers run on the library's
+        d = desc[:n]
     else:
         d = np.ascontiguousarray(desc[:n])
     if want_aux:

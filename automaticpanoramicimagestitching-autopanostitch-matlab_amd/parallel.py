@@ -355,22 +355,46 @@ def tile_rects(H, W, tile):
     return [(r0, c0, min(TH, H - r0), min(TW, W - c0)) for r0 in range(0, H, TH) for c0 in range(0, W, TW)]
 
 
-def gather_tiles_to_root(pano, tile, root=0):
-    """Rank r holds the tiles t % world == r of `pano` (H x W x C, zero elsewhere).  Instead of an all-reduce of
-    the whole canvas, every rank sends exactly its tiles to `root` (xGMI is point to point: the transfers of
-    the other ranks run side by side), which copies them into place.  Returns pano (complete on root only)."""
+def tile_ranges(H, W, tile, world_size):
+    """Contiguous runs of the row-major tile list, one per rank, cut where the cumulative tile AREA passes k / world of
+    the canvas (the last tile row and column are partial): [(begin, end)] * world.  A rank's tiles are neighbours, so its
+    render converts only the views under its band of the canvas (64 x 4K on 8 ranks: ~20 of 64, where tiles dealt
+    t % world met 47 - profiles/r04b_rank_costs.txt) and its output is ~one rectangle."""
+    rects = tile_rects(H, W, tile)
+    area = np.cumsum([ht * wt for (_, _, ht, wt) in rects], dtype=np.float64)
+    cuts = [0]
+    for k in range(1, world_size):
+        # first tile whose cumulative area reaches k / world of the total; never before the previous cut
+        cuts.append(max(cuts[-1], int(np.searchsorted(area, area[-1] * k / world_size, side="left")) + 1 if len(rects) else 0))
+    cuts.append(len(rects))
+    cuts = [min(c, len(rects)) for c in cuts]
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world_size)]
+
+
+def gather_tiles_to_root(pano, tile, root=0, ranges=None):
+    """Rank r holds the tiles t % world == r of `pano` (H x W x C, zero elsewhere) - or, with `ranges` (tile_ranges), the
+    tiles ranges[r][0] <= t < ranges[r][1].  Instead of an all-reduce of the whole canvas, every rank sends exactly its
+    tiles to `root` (xGMI is point to point: the transfers of the other ranks run side by side), which copies them into
+    place.  Returns pano (complete on root only)."""
     ws, rank = world()
     if not _multi(ws):
         return pano
     H, W = int(pano.shape[0]), int(pano.shape[1])
     rects = tile_rects(H, W, tile)
     C_ = int(pano.shape[2])
-    sizes = [sum(ht * wt * C_ for t, (_, _, ht, wt) in enumerate(rects) if t % ws == r) for r in range(ws)]
+    if ranges is not None:
+        owner = np.full(len(rects), -1, np.int64)
+        for r, (b, e) in enumerate(ranges):
+            owner[b:e] = r
+        assert (owner >= 0).all(), "tile ranges must cover the canvas"
+    else:
+        owner = np.arange(len(rects)) % ws
+    sizes = [sum(ht * wt * C_ for t, (_, _, ht, wt) in enumerate(rects) if owner[t] == r) for r in range(ws)]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=pano.dtype, device=pano.device)
     off = 0
     for t, (r0, c0, ht, wt) in enumerate(rects):
-        if t % ws == rank:
+        if owner[t] == rank:
             m = ht * wt * C_
             buf[off:off + m] = pano[r0:r0 + ht, c0:c0 + wt].reshape(-1)
             off += m
@@ -382,7 +406,7 @@ def gather_tiles_to_root(pano, tile, root=0):
                 continue
             off = 0
             for t, (r0, c0, ht, wt) in enumerate(rects):
-                if t % ws == r:
+                if owner[t] == r:
                     m = ht * wt * C_
                     pano[r0:r0 + ht, c0:c0 + wt] = parts[r][off:off + m].reshape(ht, wt, C_)
                     off += m
@@ -712,15 +736,20 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
             root = pano_root if pano_root is not None else None
             pano = _deliver_panorama(pano, int(comp_owner[ci]), root, dev)
         else:
+            # tiles second: every rank a contiguous, area-balanced run of the tile list (APS_TILE_DEAL=mod: t % world, rounds 1-4)
+            tranges = None
+            if _multi(ws) and os.environ.get("APS_TILE_DEAL") != "mod":
+                tranges = tile_ranges(int(geo["H"]), int(geo["W"]), rp.effective_tile(opts, geo), ws)
+            subset = None if not _multi(ws) else (("range",) + tranges[rank]) if tranges is not None else (rank, ws)
             pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
-                                        gains=gains, device_out=True, tile_subset=(rank, ws) if _multi(ws) else None, geo=geo)
+                                        gains=gains, device_out=True, tile_subset=subset, geo=geo)
             pl._sync()
             if _multi(ws):
                 torch.cuda.synchronize()
                 if pano_root is None:
                     _all_reduce(pano, dist.ReduceOp.MAX)  # disjoint tiles, zero elsewhere
                 else:
-                    pano = gather_tiles_to_root(pano, rp.effective_tile(opts, geo), pano_root)
+                    pano = gather_tiles_to_root(pano, rp.effective_tile(opts, geo), pano_root, ranges=tranges)
                 torch.cuda.synchronize()
                 if opts["cropBorder"] and (pano_root is None or rank == pano_root):
                     pano = rp.cropNonzeroBbox(pano, opts["canvasColor"])[0]  # the combined canvas (renderPanorama.m:430-432)

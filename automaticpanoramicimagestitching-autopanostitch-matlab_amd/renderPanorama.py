@@ -489,7 +489,17 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
         workers = max(1, min(int(_os.environ["APS_RENDER_BATCH_WORKERS"]), n_tiles))
     if tile_subset is None and workers <= 1:
         check(lib.aps_render(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC, ptr(pano), ptr(cov)))
-    else:  # (first, step): only tiles t with t % step == first — the multi-GPU shard of the tile loop
+    elif tile_subset is not None and tile_subset[0] == "range":
+        # ("range", begin, end): the contiguous tiles begin <= t < end - a rank's band of the canvas (parallel.tile_ranges)
+        import torch
+
+        if device_out:
+            pano.zero_()
+            cov.zero_()
+            torch.cuda.current_stream().synchronize()  # torch's fills must land before the library's stream paints tiles
+        check(lib.aps_render_tile_range(arr, len(images), C.byref(cv), C.byref(ro), _capi.APS_IMG_U8_HWC,
+                                        int(tile_subset[1]), int(tile_subset[2]), ptr(pano), ptr(cov)))
+    else:  # (first, step): only tiles t with t % step == first — an interleaved shard of the tile loop
         first, step = (0, 1) if tile_subset is None else (int(tile_subset[0]), int(tile_subset[1]))
         if device_out and tile_subset is not None:
             import torch

@@ -391,6 +391,12 @@ int aps_render_tiles(const aps_image* images, int n_img, const aps_canvas* canva
                      const aps_render_opts* opts, int out_layout, int tile_first, int tile_step,
                      uint8_t* pano, uint8_t* covered);
 
+/* The same for the CONTIGUOUS tiles tile_begin <= t < tile_end of the row-major tile list: a rank that owns a run of
+ * neighbouring tiles meets (and converts) only the ~20 of 64 views under its band of the canvas, where tiles dealt
+ * t % p meet 47 (round 5; section 6 of DESIGN.md). */
+int aps_render_tile_range(const aps_image* images, int n_img, const aps_canvas* canvas, const aps_render_opts* opts, int out_layout,
+                          int tile_begin, int tile_end, uint8_t* pano, uint8_t* covered);
+
 /* SURVEY 8(f) rank 2 -- imresize(I, s | [oh ow], 'bicubic' | 'bilinear') on a uint8 image, the preprocessing step in
  * front of SIFT (PP/imageProcessing/resizeImagesToLimits.m:57-61,103; loadImages.m:66-68).  Antialiased on shrink,
  * half-pixel centres, replicate borders, the smaller-scale dimension first, uint8 rounding after each pass.

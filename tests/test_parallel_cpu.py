@@ -104,6 +104,16 @@ def _worker(rank, world, port, q):
         dist.all_reduce(red, op=dist.ReduceOp.MAX)  # the all-ranks form gives the same canvas
         if rank == 0:
             assert torch.equal(red, full)
+        # the same with contiguous, area-balanced tile runs (tile_ranges: what the sharded render deals since round 5)
+        ranges = par.tile_ranges(H, W, (3, 4), world)
+        pano = torch.zeros((H, W, 3), dtype=torch.uint8)
+        for t, (r0, c0, ht, wt) in enumerate(rects):
+            if ranges[rank][0] <= t < ranges[rank][1]:
+                pano[r0:r0 + ht, c0:c0 + wt] = t + 1
+        full = par.gather_tiles_to_root(pano.clone(), (3, 4), root=0, ranges=ranges)
+        if rank == 0:
+            for t, (r0, c0, ht, wt) in enumerate(rects):
+                assert bool((full[r0:r0 + ht, c0:c0 + wt] == t + 1).all()), t
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -112,6 +122,26 @@ def _worker(rank, world, port, q):
 
         q.put((rank, traceback.format_exc()))
         raise e
+
+
+def test_tile_ranges_are_contiguous_cover_the_canvas_and_balance_area():
+    sys.path.insert(0, ROOT)
+    import apsamd
+
+    par = import_module(apsamd.__name__ + ".parallel")
+    for (H, W, tile, ws) in [(11400, 20200, (2048, 2048), 8), (11400, 20200, (2048, 2048), 2), (7, 10, (3, 4), 2), (100, 100, (64, 64), 8),
+                             (5000, 50300, (2048, 2048), 8)]:
+        rects = par.tile_rects(H, W, tile)
+        rg = par.tile_ranges(H, W, tile, ws)
+        assert len(rg) == ws and rg[0][0] == 0 and rg[-1][1] == len(rects)
+        assert all(rg[r][1] == rg[r + 1][0] for r in range(ws - 1)) and all(b <= e for b, e in rg)
+        area = [sum(rects[t][2] * rects[t][3] for t in range(b, e)) for b, e in rg]
+        if len(rects) >= 4 * ws:  # enough tiles to balance: no rank above 1.35x the mean (one tile of slack)
+            assert max(area) <= 1.35 * (H * W / ws), (H, W, area)
+    # the bench canvas on 8 ranks: a rank's tiles lie in at most two tile rows
+    rects = par.tile_rects(11400, 20200, (2048, 2048))
+    for b, e in par.tile_ranges(11400, 20200, (2048, 2048), 8):
+        assert len({rects[t][0] for t in range(b, e)}) <= 2
 
 
 def test_partition_helpers():

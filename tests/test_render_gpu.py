@@ -251,6 +251,35 @@ def test_tile_shards_compose_to_the_full_render(rp, world):
     assert np.array_equal(acc_t.cpu().numpy(), full)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("blending", ["multiband", "linear"])
+def test_contiguous_tile_ranges_compose_to_the_full_render(gpu, rp, world, blending):
+    """Round 5: a rank renders a contiguous, area-balanced run of the tile list (parallel.tile_ranges ->
+    aps_render_tile_range) instead of the tiles t % world.  The runs must cover the canvas and reproduce the one-process
+    render in every byte, host and resident."""
+    import torch
+
+    par = import_module(gpu.__name__ + ".parallel")
+    rng = np.random.default_rng(33)
+    imgs, cams = _scene(rng, n=5, W=200, H=130, f=280.0)
+    sizes = [(130, 200, 3)] * 5
+    opts = {"anglePower": 2, "blending": blending, "pyrLevels": 4, "pyrSigma": 1.0, "tile": (64, 80), "cropBorder": False}
+    full, _, cov, geo = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, return_covered=True)
+    ranges = par.tile_ranges(int(geo["H"]), int(geo["W"]), (64, 80), world)
+    acc = np.zeros_like(full)
+    acc_t = None
+    dimgs = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    for r in range(world):
+        part, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 2, opts, tile_subset=("range",) + ranges[r])
+        assert not (acc.astype(bool) & part.astype(bool)).any()      # disjoint
+        acc = np.maximum(acc, part)
+        pt, _ = rp.renderPanorama({}, dimgs, sizes, cams, "spherical", 2, opts, tile_subset=("range",) + ranges[r], device_out=True)
+        acc_t = pt if acc_t is None else torch.maximum(acc_t, pt)
+    assert cov.sum() > 10000 and np.array_equal(acc, full)
+    assert np.array_equal(acc_t.cpu().numpy(), full)
+
+
 @pytest.mark.parametrize("workers", [1, 2, 3])
 @pytest.mark.parametrize("subset", [None, (1, 2)])
 def test_threaded_tile_loop_changes_no_byte(rp, monkeypatch, workers, subset):
