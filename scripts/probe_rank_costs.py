@@ -133,3 +133,12 @@ geo = None
 for label, sub in (("this rank's 1/8 of the tiles", (0, world)), ("all tiles", None)):
     lo, med, _ = timed(lambda: rp.renderPanorama(inp, imgs, sizes, cams_e, "spherical", comp["ref"], opts, device_out=True, tile_subset=sub))
     print(f"render of {label}: min {lo:.2f} ms, median {med:.2f} ms")
+# round 5: contiguous, area-balanced tile runs per rank (parallel.tile_ranges) against the t % world deal, every rank's share
+full_, _, _, geo_ = rp.renderPanorama(inp, imgs, sizes, cams_e, "spherical", comp["ref"], opts, device_out=True, return_covered=True)
+ranges = par.tile_ranges(int(geo_["H"]), int(geo_["W"]), (2048, 2048), world)
+for label, subs in (("t % 8", [(r, world) for r in range(world)]), ("contiguous runs", [("range",) + ranges[r] for r in range(world)])):
+    ts_ = []
+    for sub in subs:
+        lo, med, _ = timed(lambda: rp.renderPanorama(inp, imgs, sizes, cams_e, "spherical", comp["ref"], opts, device_out=True, tile_subset=sub), reps=3)
+        ts_.append(lo)
+    print(f"render per rank, tiles dealt {label}: " + ", ".join(f"{t:.2f}" for t in ts_) + f" ms; max {max(ts_):.2f} ms  (ranges {ranges if label != 't % 8' else ''})")
