@@ -504,7 +504,7 @@ def main():
     # overlap statistics on the device (gain_stats_kernel), the N x N x 3 sums back to the host, the host solve, the gains into
     # the warp.  Reported as value_with_gain; the headline follows BASELINE.json configs[2], which does not name the switch.
     dt_gain, infos_g = None, []
-    if args.with_gain == "auto" and not input_.get("gainCompensation"):
+    if args.with_gain == "auto" and world == 1 and not input_.get("gainCompensation"):  # (N = 1 only, like the other extra legs)
         input_["gainCompensation"] = 1
         try:
             step(sync_download=True)  # warm-up (the statistics' workspaces)

@@ -728,3 +728,19 @@ def test_set_statistics_see_every_row(gpu, n, layout):
     out = np.zeros(8, f32)
     capi.check(capi.lib.aps_match_set_stats(capi.ptr(xn), n, 128, capi.APS_ROWMAJOR, 1, capi.ptr(out)))
     assert abs(out[0] - 1.0) < 1e-5 and abs(out[6] - 1.0) < 1e-5 and 0.0 <= out[7] < out[4] < 1.0
+
+
+def test_int8_screening_kernels_hold_the_whole_register_file_of_their_simds(gpu):
+    """The co-residency rule as the LOADED code object declares it (hipFuncGetAttributes; tests/test_abi.py reads the same
+    from the code object's metadata without a device): every int8-MFMA kernel - both shapes, the list form and the pooled
+    matcher's bounds form - holds 256 registers per lane at a 512-thread workgroup bound, i.e. two waves fill a SIMD's 512
+    registers and no other kernel's wave can sit beside them.  The library itself refuses to launch them otherwise."""
+    import ctypes
+    for shape in (16, 32):
+        for bounds in (0, 1):
+            regs, thr = ctypes.c_int(0), ctypes.c_int(0)
+            gpu._capi.check(gpu.lib.aps_match_screen_kernel_regs(shape, bounds, ctypes.byref(regs), ctypes.byref(thr)))
+            assert (regs.value + 7) // 8 * 8 >= 256, (shape, bounds, regs.value)
+            assert thr.value == 512, (shape, bounds, thr.value)
+    regs, thr = ctypes.c_int(0), ctypes.c_int(0)
+    assert gpu.lib.aps_match_screen_kernel_regs(8, 0, ctypes.byref(regs), ctypes.byref(thr)) == gpu._capi.APS_E_ARG
