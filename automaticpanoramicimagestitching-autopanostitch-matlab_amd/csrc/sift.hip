@@ -225,13 +225,13 @@ template <int R>
 constexpr bool kBlurOneBuffer = R >= 7;
 
 // The two passes of blur_kernel / blur_base_kernel on a filled tile (s_in row-interleaved, see blur_kernel).
-template <int R>
+template <int R, int TW = kTW, int NT = 256>
 __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row, const GaussK& gk, int x0, int y0, int h, int w,
                                                  float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
     constexpr int RP = (R + 3) & ~3, OFF = RP - R;
-    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R;
+    constexpr int IW = TW + 2 * RP, IH = kTH + 2 * R;
     constexpr int IP2 = 2 * IW + 4;
-    constexpr int RPITCH = kTW + 2;
+    constexpr int RPITCH = TW + 2;
     const int tid = threadIdx.x;
     __syncthreads();
     // row pass: IH/2 row pairs x 8 segments of 8 outputs; consecutive lanes = consecutive row pairs
@@ -241,9 +241,9 @@ __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row
     // a kernel whose fill -> row pass -> column pass -> store chain is latency per workgroup needs; the small radii are
     // memory-bound and lose a few per cent to the extra barrier (round 2's measurement), so they keep two buffers.
     constexpr bool one_buf = kBlurOneBuffer<R>;
-    static_assert(!one_buf || (IH / 2) * (kTW / 8) <= 256, "one work item per thread");
-    for (int u = tid; u < (one_buf ? 256 : (IH / 2) * (kTW / 8)); u += 256) {
-        const bool live = u < (IH / 2) * (kTW / 8);
+    static_assert(!one_buf || (IH / 2) * (TW / 8) <= NT, "one work item per thread");
+    for (int u = tid; u < (one_buf ? NT : (IH / 2) * (TW / 8)); u += NT) {
+        const bool live = u < (IH / 2) * (TW / 8);
         const int uc = live ? u : 0;
         const int seg = uc / (IH / 2), p = uc - seg * (IH / 2), xb = seg * 8;
         const f32x2* src = reinterpret_cast<const f32x2*>(&s_in[p * IP2 + 2 * (OFF + xb)]);
@@ -269,8 +269,8 @@ __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row
     }
     __syncthreads();
     // column pass: 32 column pairs x kTH/4 groups of 4 rows
-    for (int u = tid; u < (kTW / 2) * (kTH / 4); u += 256) {
-        const int lx = 2 * (u & (kTW / 2 - 1)), yb = (u / (kTW / 2)) * 4;
+    for (int u = tid; u < (TW / 2) * (kTH / 4); u += NT) {
+        const int lx = 2 * (u & (TW / 2 - 1)), yb = (u / (TW / 2)) * 4;
         f32x2 v[4 + 2 * R], acc[4];
 #pragma unroll
         for (int j = 0; j < 4 + 2 * R; ++j) v[j] = *reinterpret_cast<const f32x2*>(&s_row[(yb + j) * RPITCH + lx]);
@@ -308,8 +308,8 @@ __device__ __forceinline__ void blur_tile_passes(const float* s_in, float* s_row
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
+template <int R, int TW = kTW, int NT = 256>
+__global__ __launch_bounds__(NT) void blur_kernel(const float* __restrict__ in, int h, int w, GaussK gk,
                                                    float* __restrict__ out, float* __restrict__ dec, int dh, int dw) {
     // dec (optional): the next octave's base plane, out(2y, 2x) for y < dh, x < dw - written from the registers that
     // hold the result instead of by a decimation pass that re-reads the plane.
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // pixels so that every piece is aligned when the row pitch is (the kernel was instruction-bound on its
     // dword-per-thread tile fill, not on HBM).  Pieces that cross the image border fall back to reflected scalars.
     constexpr int RP = (R + 3) & ~3;
-    constexpr int IW = kTW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
+    constexpr int IW = TW + 2 * RP, IH = kTH + 2 * R, NV = IW / 4;
     static_assert(IH % 2 == 0 && kTH % 4 == 0, "row pairs");
     // Both passes run two fma chains per v_pk_fma_f32, and a packed operand must be an aligned register pair.  A pair
     // of horizontally adjacent inputs is aligned for every other tap only, so the passes pair the OTHER direction:
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // Every accumulator still sees its taps in ascending order: the scalar form's chain, bit for bit.
     // Pitches (floats): 4 * odd, so that consecutive row pairs land on distinct 16-byte bank groups.
     constexpr int IP2 = 2 * IW + 4;
-    constexpr int RPITCH = kTW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
+    constexpr int RPITCH = TW + 2;  // column pass: 8-byte reads by consecutive lanes; row pass: dword writes, rows 2 apart
     static_assert((IP2 / 4) % 2 == 1, "pitch");
     static_assert(IH * RPITCH <= (IH / 2) * IP2, "the row-pass result fits the tile's buffer");
     __shared__ __attribute__((aligned(16))) float s_in[(IH / 2) * IP2];
@@ -336,23 +336,23 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     // (Measured and dropped, round 5: an XCD-contiguous tile order - XCD k walks the k-th eighth of the tile list, so that
     // the halo columns two neighbours share sit in one L2 - made every octave-0 launch 7-12 us SLOWER (R = 4: 57.7 -> 64.6 us):
     // the round-robin deal spreads a plane's rows over all memory channels at any moment, the contiguous order does not.)
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kTH;
     const int tid = threadIdx.x;
     const bool vec_ok = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     // All of a thread's pieces are requested before the first one is parked in LDS: as a plain loop (request, wait, store,
     // next) every workgroup paid the memory latency NPF times in series before its first barrier.
-    constexpr int NPF = (IH * NV + 255) / 256;
+    constexpr int NPF = (IH * NV + NT - 1) / NT;
     float4 pf[NPF];
     // Interior tiles (the haloed patch lies inside the plane: all but the rim, 94 % of the tiles of a 7680 x 4320 plane) take
     // their pieces at 32-bit offsets from one scalar base, without the reflection, the border tests and the scalar
     // fallback of the general form below - that bookkeeping was ~25 vector instructions per piece, 125 of the 250-470 a
     // thread executes (round 5).
-    const bool interior = vec_ok && x0 >= RP && x0 + kTW + RP <= w && y0 >= R && y0 + kTH + R <= h;
+    const bool interior = vec_ok && x0 >= RP && x0 + TW + RP <= w && y0 >= R && y0 + kTH + R <= h;
     if (interior) {
         const float* base = in + ((size_t)(y0 - R) * w + (x0 - RP));
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
-            const int e = tid + 256 * q;
+            const int e = tid + NT * q;
             const int ec = e < IH * NV ? e : IH * NV - 1;
             const int ly = ec / NV, v = ec - ly * NV;
             pf[q] = *reinterpret_cast<const float4*>(base + (unsigned)(ly * w + 4 * v));  // (scalar base + 32-bit lane offset)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     } else {
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
-            const int e = tid + 256 * q;
+            const int e = tid + NT * q;
             const int ec = e < IH * NV ? e : IH * NV - 1;  // (threads past the end re-read the last piece and drop it)
             const int ly = ec / NV, v = ec - ly * NV;
             const int gy = reflect101(y0 + ly - R, h), gx = x0 - RP + 4 * v;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
     }
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
-        const int e = tid + 256 * q;
+        const int e = tid + NT * q;
         if (e < IH * NV) {
             const int ly = e / NV, v = e - ly * NV;
             float* dst = &s_in[(ly >> 1) * IP2 + 8 * v + (ly & 1)];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
             dst[6] = pf[q].w;
         }
     }
-    blur_tile_passes<R>(s_in, s_row, gk, x0, y0, h, w, out, dec, dh, dw);
+    blur_tile_passes<R, TW, NT>(s_in, s_row, gk, x0, y0, h, w, out, dec, dh, dw);
 }
 
 // Gray plane of the source image as bytes, row-major (round 5): rgb2gray's value is an integer 0..255 (floor(d + 0.5) of the
@@ -1627,6 +1627,9 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
         check_launch("blur_march_kernel");
         return dec != nullptr;
     }
+    // (Measured and dropped, round 5: 128-column tiles on 512 threads - blur_kernel<R, 128, 512>, fills in rows of 544-608 B
+    // instead of 288-352 B - read 58.7 / 70 / 85 us per octave-0 plane at R = 4 / 5 / 10 against 56.8 / 60 / 72:
+    // profiles/r05j_blur_tile_variants.txt.  The tile shape stays 64 x 32 on 256 threads.)
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
