@@ -742,7 +742,9 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
                 tranges = tile_ranges(int(geo["H"]), int(geo["W"]), rp.effective_tile(opts, geo), ws)
             subset = None if not _multi(ws) else (("range",) + tranges[rank]) if tranges is not None else (rank, ws)
             pano, _ = rp.renderPanorama(input, [images[k] for k in members], sizes, c["cameras"], mode, c["ref"], opts,
-                                        gains=gains, device_out=True, tile_subset=subset, geo=geo)
+                                        gains=gains, device_out=True, tile_subset=subset, geo=geo,
+                                        # (runs gathered to a root cover the canvas: nothing outside a rank's run is read)
+                                        zero_rest=not (tranges is not None and pano_root is not None))
             pl._sync()
             if _multi(ws):
                 torch.cuda.synchronize()

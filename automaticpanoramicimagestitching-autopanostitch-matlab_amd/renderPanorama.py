@@ -438,7 +438,7 @@ def pureNonRotationalPanoramas(images, cameras, numImages, opts, gains=None):
 
 
 def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gains=None,
-                   return_covered=False, device_out=False, tile_subset=None, geo=None):
+                   return_covered=False, device_out=False, tile_subset=None, geo=None, zero_rest=True):
     """[panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts)
     (renderPanorama.m:1-500).  refIdx is 0-based here.  Differences that are deliberate:
       * opts['tile'] must be explicit; the reference derives it from free GPU/CPU memory (:269-298),
@@ -493,7 +493,9 @@ def renderPanorama(input, images, imgSize, cameras, mode, refIdx, opts=None, gai
         # ("range", begin, end): the contiguous tiles begin <= t < end - a rank's band of the canvas (parallel.tile_ranges)
         import torch
 
-        if device_out:
+        # zero_rest=False (a resident shard whose tiles alone are sent on: parallel.gather_tiles_to_root): the ~1 GB fill of
+        # the canvas outside the run is skipped - those pixels are never read
+        if device_out and zero_rest:
             pano.zero_()
             cov.zero_()
             torch.cuda.current_stream().synchronize()  # torch's fills must land before the library's stream paints tiles
