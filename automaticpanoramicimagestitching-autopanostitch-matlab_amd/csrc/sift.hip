@@ -1627,6 +1627,11 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
         check_launch("blur_march_kernel");
         return dec != nullptr;
     }
+    // (Measured and dropped, round 5: one wave per 128-column strip marching down its rows with the row-pass results of the last
+    // 2R + 2 rows in registers - no barrier, no halo rows recomputed, 0.55 instead of 0.93 wave-instructions per pixel at
+    // R = 10, bit-identical - read 59 / 61 / 66 / 94 / 92 / 101 us per octave-0 plane at R = 4 / 5 / 6 / 7 / 8 / 10 against
+    // 58 / 62 / 62 / 67 / 63 / 70: a lane's two pixels give two dependent fma chains of 2R + 1 per pass where the tile
+    // kernel runs eight side by side on a shared window, and the ring costs 88-170 registers.  profiles/r05j_blur_tile_variants.txt)
     // (Measured and dropped, round 5: 128-column tiles on 512 threads - blur_kernel<R, 128, 512>, fills in rows of 544-608 B
     // instead of 288-352 B - read 58.7 / 70 / 85 us per octave-0 plane at R = 4 / 5 / 10 against 56.8 / 60 / 72:
     // profiles/r05j_blur_tile_variants.txt.  The tile shape stays 64 x 32 on 256 threads.)
