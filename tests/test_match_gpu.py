@@ -744,3 +744,20 @@ def test_int8_screening_kernels_hold_the_whole_register_file_of_their_simds(gpu)
             assert thr.value == 512, (shape, bounds, thr.value)
     regs, thr = ctypes.c_int(0), ctypes.c_int(0)
     assert gpu.lib.aps_match_screen_kernel_regs(8, 0, ctypes.byref(regs), ctypes.byref(thr)) == gpu._capi.APS_E_ARG
+
+
+def test_pca2nn_argument_errors(gpu):
+    """aps_match_pca2nn refuses what nearest2ApproxFloatFast's `arguments` block and the library's layout contract refuse:
+    other descriptor lengths, empty sets, a non-positive component count, leading dimensions below the row length."""
+    import ctypes
+    lib, capi = gpu.lib, gpu._capi
+    A = np.zeros((4, 128), np.float32)
+    idx, d1, d2 = np.zeros(4, np.uint32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+    p = lambda x: x.ctypes.data  # noqa: E731
+    call = lambda n1, lda, n2, ldb, dim, k: lib.aps_match_pca2nn(p(A), n1, lda, p(A), n2, ldb, dim, capi.APS_ROWMAJOR, k, 1, p(idx), p(d1), p(d2), None, None)  # noqa: E731
+    assert call(4, 128, 4, 128, 64, 48) == capi.APS_E_DIM
+    assert call(0, 128, 4, 128, 128, 48) == capi.APS_E_ARG
+    assert call(4, 128, 0, 128, 128, 48) == capi.APS_E_ARG
+    assert call(4, 128, 4, 128, 128, 0) == capi.APS_E_ARG
+    assert call(4, 64, 4, 128, 128, 48) == capi.APS_E_DIM
+    assert call(4, 128, 4, 128, 128, 48) == capi.APS_OK

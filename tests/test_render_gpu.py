@@ -583,3 +583,16 @@ def test_batched_linear_and_none_equal_per_tile_path(rp, monkeypatch, mode, tile
     assert (cov != oc).mean() <= 1e-3  # (the per-tile path's stated agreement with the oracle: test_render_matches_oracle)
     dd = np.abs(op.astype(int) - pano.astype(int))[(cov == 1) & (oc == 1)]
     assert (dd <= 1).mean() >= 0.998
+
+
+def test_tile_range_argument_errors_and_empty_range(gpu, rp):
+    """aps_render_tile_range: a negative or reversed range is refused; an empty range paints nothing."""
+    rng = np.random.default_rng(34)
+    imgs, cams = _scene(rng, n=3, W=120, H=90, f=200.0)
+    sizes = [(90, 120, 3)] * 3
+    opts = {"anglePower": 2, "blending": "multiband", "pyrLevels": 3, "pyrSigma": 1.0, "tile": (64, 64), "cropBorder": False}
+    none, _ = rp.renderPanorama({}, imgs, sizes, cams, "spherical", 1, opts, tile_subset=("range", 2, 2))
+    assert not none.any()
+    with pytest.raises(gpu.ApsError) as e:
+        rp.renderPanorama({}, imgs, sizes, cams, "spherical", 1, opts, tile_subset=("range", 3, 1))
+    assert e.value.code == gpu._capi.APS_E_ARG
