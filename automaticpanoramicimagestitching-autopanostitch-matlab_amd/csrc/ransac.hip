@@ -299,7 +299,8 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
                                                          uint8_t* __restrict__ valid, int mlesac) {
     // work item = (active pair a, draw c0 + k): the host hands the draws over in growing chunks and stops a pair as
     // soon as its sequential loop has ended, so most of the n_samples draws of a pair are never fitted or scored.
-    // Hs keeps the [pair][draw] layout (the finalize kernel picks the winner there); valid is chunk-local [a][k].
+    // Hs and valid keep the [pair][draw] layout (the finalize kernel picks the winner there; draws may be fitted ahead of
+    // the chunk that scores them).
     extern __shared__ __attribute__((aligned(16))) double lds_fit[];
     constexpr int S = 64;  // one 9x9 problem per lane
     double* sG = lds_fit;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const double* __restrict
         ok = gram_to_h<64>(sG, sV, lane, n1, n2, H, mlesac) && (mlesac || check_model(H));
     }
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
-    valid[wid] = ok ? 1 : 0;
+    valid[gid] = ok ? 1 : 0;  // [pair][draw], like Hs (the score kernels read the chunk-local copy valid_chunk_kernel makes)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,6 +484,14 @@ __device__ double wave_mlesac_eval(const Mat3& H, const double* __restrict__ x1,
     }
     *n_inl = (int)wave_sum(pc);
     return wave_sum(ps);
+}
+
+// valid [pair][draw] -> the chunk-local [active pair][draw of the chunk] order the score kernels and the host replay walk
+__global__ void valid_chunk_kernel(const int* __restrict__ act, int n_act, int c0, int nc, int n_samples,
+                                   const uint8_t* __restrict__ valid_abs, uint8_t* __restrict__ valid_loc) {
+    const int64_t wid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (wid >= (int64_t)n_act * nc) return;
+    valid_loc[wid] = valid_abs[(int64_t)act[wid / nc] * n_samples + c0 + (int)(wid % nc)];
 }
 
 __global__ __launch_bounds__(256) void mlesac_score_kernel(
@@ -1063,7 +1072,7 @@ __global__ __launch_bounds__(64) void tform_fit_kernel(int type, const double* _
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
-    valid[wid] = ok ? 1 : 0;
+    valid[gid] = ok ? 1 : 0;  // [pair][draw], like Hs (the score kernels read the chunk-local copy valid_chunk_kernel makes)
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -1486,7 +1495,7 @@ __global__ __launch_bounds__(64) void mlesac_tform_fit_kernel(int type, const do
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) Hs[gid * 9 + e] = H.m[e];
-    valid[wid] = ok ? 1 : 0;
+    valid[gid] = ok ? 1 : 0;  // [pair][draw], like Hs (the score kernels read the chunk-local copy valid_chunk_kernel makes)
 }
 
 // evaluateModel over evaluateTransform2d, or evaluateTranslation2d for 'translation' (no division, no |w| test)
@@ -1837,7 +1846,7 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     APS_HIP(hipMemcpyAsync(d_ptr, h_ptr.data(), (n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
                            stream()));
     Ws<double> Hs(nh * 9), merr(nh);
-    Ws<uint8_t> valid(nh), scratch(std::max<int64_t>(total_rows, 1));
+    Ws<uint8_t> valid(nh), valid_loc(nh), scratch(std::max<int64_t>(total_rows, 1));
     Ws<int32_t> ninl(nh), best(n_pairs), d_act(n_pairs);
     Ws<unsigned long long> med_keys(type == APS_TFORM_PROJECTIVE ? 1 : std::max<int64_t>(total_rows, 1));
     const size_t lds_bytes = 2 * 81 * 64 * sizeof(double);
@@ -1870,43 +1879,52 @@ static void ransac_batch(const double* d_p1, const double* d_p2, int64_t ldp,
     std::vector<int32_t> h_ninl, h_best(n_pairs);
     std::vector<double> h_merr;
     g_draws_exhausted = 0;
-    int c0 = 0, nc_prev = 0;
+    // (Round 5.)  The FIRST scored chunk is capped at 96 draws per pair - a pair with >= 50 % inliers ends within it - and a
+    // batch small enough for one round of the fit kernel (one rank of eight: 28 pairs x 564 draws) is FITTED whole in the
+    // first iteration: a fit launch costs its ~0.35 ms of latency whatever its size, a score launch costs by the draws.
+    // Before, such a batch fitted and scored all 564 draws of every pair in one chunk (fit 0.36 + score 0.52 ms per rank);
+    // the results do not depend on the chunking.
+    int c0 = 0, nc_prev = 0, fitted = 0;
     while (!act.empty() && c0 < n_samples) {
         const int n_act = (int)act.size();
-        int nc = std::max(std::max(16, 2 * nc_prev), 16384 / n_act);
+        int nc = std::max(std::max(16, 2 * nc_prev), nc_prev == 0 ? std::min(96, 16384 / n_act) : 16384 / n_act);
         nc = std::min(nc, n_samples - c0);
         const int64_t nw = (int64_t)n_act * nc;
         APS_HIP(hipMemcpyAsync(d_act, act.data(), n_act * sizeof(int), hipMemcpyHostToDevice, stream()));
-        {
+        if (c0 + nc > fitted) {
+            const int nf = (int64_t)n_act * (n_samples - fitted) <= 16384 ? n_samples - fitted : c0 + nc - fitted;
+            const int64_t nwf = (int64_t)n_act * nf;
             Prof prof("ransac_fit");
             if (type == APS_TFORM_PROJECTIVE)
-                ransac_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                              d_samples, n_samples, Hs, valid, mlesac);
+                ransac_fit_kernel<<<cdiv(nwf, 64), 64, lds_bytes, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, fitted, nf,
+                                                                               d_samples, n_samples, Hs, valid, mlesac);
             else if (mlesac)
-                mlesac_tform_fit_kernel<<<cdiv(nw, 64), 64, lds_bytes, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act,
-                                                                                    c0, nc, d_samples, n_samples, Hs, valid);
+                mlesac_tform_fit_kernel<<<cdiv(nwf, 64), 64, lds_bytes, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act,
+                                                                                     fitted, nf, d_samples, n_samples, Hs, valid);
             else
-                tform_fit_kernel<<<cdiv(nw, 64), 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                     d_samples, n_samples, Hs, valid);
+                tform_fit_kernel<<<cdiv(nwf, 64), 64, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, fitted, nf,
+                                                                      d_samples, n_samples, Hs, valid);
+            fitted += nf;
         }
         check_launch("ransac_fit_kernel");
         {
             Prof prof("ransac_score");
+            valid_chunk_kernel<<<cdiv(nw, 256), 256, 0, stream()>>>(d_act, n_act, c0, nc, n_samples, valid, valid_loc);
             if (mlesac && type != APS_TFORM_PROJECTIVE)
                 mlesac_tform_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                              n_samples, Hs, valid, o.max_distance, ninl, merr);
+                                                                              n_samples, Hs, valid_loc, o.max_distance, ninl, merr);
             else if (mlesac)
                 mlesac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                        n_samples, Hs, valid, o.max_distance, ninl, merr);
+                                                                        n_samples, Hs, valid_loc, o.max_distance, ninl, merr);
             else
                 ransac_score_kernel<<<cdiv(nw, 4), 256, 0, stream()>>>(type, d_p1, d_p2, ldp, d_ptr, d_act, n_act, c0, nc,
-                                                                        n_samples, Hs, valid, o.max_distance, ninl, merr);
+                                                                        n_samples, Hs, valid_loc, o.max_distance, ninl, merr);
         }
         check_launch("ransac_score_kernel");
         h_valid.resize(nw);
         h_ninl.resize(nw);
         h_merr.resize(nw);
-        APS_HIP(hipMemcpyAsync(h_valid.data(), valid, nw, hipMemcpyDeviceToHost, stream()));
+        APS_HIP(hipMemcpyAsync(h_valid.data(), valid_loc, nw, hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipMemcpyAsync(h_ninl.data(), ninl, nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipMemcpyAsync(h_merr.data(), merr, nw * sizeof(double), hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));
