@@ -1,4 +1,4 @@
-// Debug target only (`make debug`): the co-runner of scripts/probe_overlap_race3.py with its int8 MFMA accumulators
+// Debug target only (`make debug`): the co-runner of scripts/probe/probe_overlap_race3.py with its int8 MFMA accumulators
 // in AGPRs.  This file alone is compiled with -amdgpu-mfma-vgpr-form=0 (Makefile), the rest of the library with =1:
 // DESIGN.md section 5 ("Co-residency finding") - SIFT kernels sharing a SIMD with VGPR-form v_mfma_i32_32x32x32_i8
 // waves returned different bits; is it the VGPR form?

@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(512) void match_screen_i8_kernel(const MatchJob* __
     // The kernel claims the whole vector register file of its SIMDs (2 waves x 256 registers) although it needs 169:
     // waves of OTHER kernels that shared a SIMD with v_mfma_i32_32x32x32_i8 waves came back with different results
     // (SIFT's refine / orientation / descriptor kernels, from another stream, when feature extraction and matching
-    // overlap; f16 MFMA, VALU, LDS or LDS-DMA neighbours leave them alone) - measured with scripts/probe_overlap_race3.py,
+    // overlap; f16 MFMA, VALU, LDS or LDS-DMA neighbours leave them alone) - measured with scripts/probe/probe_overlap_race3.py,
     // DESIGN.md section 5.  With nothing co-resident the extraction is bit-identical again; this kernel's own results were
     // never affected.
     asm volatile("v_mov_b32 v255, 0" ::: "v255");

@@ -119,7 +119,7 @@ def partition_pairs_blocked(pairs, weights, n, world_size, scatter=False):
     scatter (off): the groups are drawn by a fixed pseudo-random permutation of the images instead of by index ranges.
     The weights N_i N_j are what the proof pass costs; the survivor pass costs what the pairs OVERLAP, which nobody knows
     yet - but image sets come in capture order, neighbours in index overlap, and index-range groups put most overlapping
-    pairs into the diagonal blocks.  Measured on the 64 x 4K scene at 8 ranks (scripts/probe_rank_costs.py,
+    pairs into the diagonal blocks.  Measured on the 64 x 4K scene at 8 ranks (scripts/probe/probe_rank_costs.py,
     profiles/r04h_rank_costs.txt): overlapping pairs per rank 33-97 -> 55-79, slowest rank 13.2 -> 12.9 ms, descriptor
     sets per rank 25-42 -> 28-48: the proof pass is 2/3 of a rank's matching whatever its pairs overlap, so the spread of
     the survivor pass is worth 2 % and costs preparation; index ranges stay the default."""

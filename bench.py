@@ -196,7 +196,7 @@ def cpu_cfg1_single_thread(synth):
 def global_matcher_probe(pl, capi, input_, images):
     """featureMatchingGlobal (the reference's default matcher) on the bench's views: SIFT once (untimed), then three passes of
     the pooled matcher (normalise, screened exact 4-NN, per-query filter); the last is reported (the first two still grow the
-    calling thread's workspaces: 202 / 177 / 177 ms in a same-process series, scripts/ab_global.py)."""
+    calling thread's workspaces: 202 / 177 / 177 ms in a same-process series, scripts/probe/ab_global.py)."""
     import ctypes
     from importlib import import_module
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel timeline of the last full matching call of scripts/probe_match_stage.py (64 x 4K scene, 2016 pairs): every launch with the
+# kernel timeline of the last full matching call of scripts/probe/probe_match_stage.py (64 x 4K scene, 2016 pairs): every launch with the
 # gap in front of it - what the stage pays beside its three big kernels
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/ms
-(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/ms -o p -- python3 scripts/probe_match_stage.py > $R/gpurun_out/match_stage_trace.txt 2>&1) || { tail -5 $R/gpurun_out/match_stage_trace.txt; exit 1; }
+(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/ms -o p -- python3 scripts/probe/probe_match_stage.py > $R/gpurun_out/match_stage_trace.txt 2>&1) || { tail -5 $R/gpurun_out/match_stage_trace.txt; exit 1; }
 python3 - <<'PY' | tee -a $R/gpurun_out/match_stage_trace.txt
 import csv
 rows = sorted(csv.DictReader(open("/tmp/ms/p_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/mp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/mp -o p -- python3 scripts/probe_match.py 8 19800 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/mp -o p -- python3 scripts/probe/probe_match.py 8 19800 > /dev/null 2>&1
 python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open("/tmp/mp/p_kernel_trace.csv")))

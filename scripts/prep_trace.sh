@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel durations of the matcher's preparation (scripts/probe_prep.py) from a rocprofv3 kernel trace, last call only
+# kernel durations of the matcher's preparation (scripts/probe/probe_prep.py) from a rocprofv3 kernel trace, last call only
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/pp
-(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python3 scripts/probe_prep.py $1 > $R/gpurun_out/prep_trace.txt 2>&1) || { tail -5 $R/gpurun_out/prep_trace.txt; exit 1; }
+(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python3 scripts/probe/probe_prep.py $1 > $R/gpurun_out/prep_trace.txt 2>&1) || { tail -5 $R/gpurun_out/prep_trace.txt; exit 1; }
 grep "^call" $R/gpurun_out/prep_trace.txt
 python3 - <<'PY' | tee -a $R/gpurun_out/prep_trace.txt
 import csv

@@ -1,5 +1,5 @@
 """Kernel-time probe of the split-precision candidate kernel (profile API), for A/B runs:
-   python scripts/probe_cand.py [n_img] [features]   (APS_MATCH_ABLATE=<bits> is honoured by builds made with
+   python scripts/probe/probe_cand.py [n_img] [features]   (APS_MATCH_ABLATE=<bits> is honoured by builds made with
    make EXTRA=-DAPS_MATCH_TIMING only: 1 no selection, 2 no DMA, 4 screen never fires, 8 print phase timings, 32 no rescoring)"""
 import sys
 

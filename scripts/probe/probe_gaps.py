@@ -1,5 +1,5 @@
 """Gap statistics of exact 2-NN distances on bench-like SIFT descriptors: how often is d(K+1) - d(2) < eps?
-Decides how many candidates a lower-precision screening product needs.  python scripts/probe_gaps.py"""
+Decides how many candidates a lower-precision screening product needs.  python scripts/probe/probe_gaps.py"""
 import sys
 
 import numpy as np

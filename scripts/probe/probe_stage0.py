@@ -7,7 +7,7 @@
   H2 >= d2 : second smallest EXACT distance over a fixed 1/s sample of the columns.
 A row is dismissed when L1 > r^2 H2 (matchFeaturesScratch.m:170-178, r = 0.6).
 
-python scripts/probe_stage0.py
+python scripts/probe/probe_stage0.py
 """
 import sys
 

@@ -1,5 +1,5 @@
 import re
-src = open("scripts/probe_rank_costs.py").read()
+src = open("scripts/probe/probe_rank_costs.py").read()
 # keep everything up to the host() definition and profile it
 cut = src.index("host()  # (the first call pays imports)")
 code = src[:cut] + '''

@@ -1,4 +1,4 @@
-"""cProfile of bench steps (host-side overheads): python scripts/pyprofile_step.py - the package's own functions by cumulative
+"""cProfile of bench steps (host-side overheads): python scripts/probe/pyprofile_step.py - the package's own functions by cumulative
 time per step, then everything by internal time."""
 import cProfile
 import pstats

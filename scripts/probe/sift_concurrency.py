@@ -1,6 +1,6 @@
 """Reads a rocprofv3 --kernel-trace csv of bench.py and reports, for the LAST feature stage, how many kernels were in
 flight over time (time-weighted histogram), the share of the window with no kernel running, and the largest idle gaps.
-usage: python3 scripts/sift_concurrency.py <kernel_trace.csv>"""
+usage: python3 scripts/probe/sift_concurrency.py <kernel_trace.csv>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=${1:-run}
 rm -rf /tmp/prof_$tag
-(cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python3 scripts/probe_render.py 4 > $R/gpurun_out/render_kernel_times_$tag.txt 2>&1) || exit 1
+(cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python3 scripts/probe/probe_render.py 4 > $R/gpurun_out/render_kernel_times_$tag.txt 2>&1) || exit 1
 grep "render\|crc32" $R/gpurun_out/render_kernel_times_$tag.txt | grep -v rocprofv3
 python3 - $tag <<'PY' | tee -a $R/gpurun_out/render_kernel_times_$tag.txt
 import csv, glob, sys

@@ -6,9 +6,9 @@ if [ "$2" = "test" ]; then
   python -m pytest tests/test_render_gpu.py tests/test_pipeline_gpu.py tests/test_fullsize_gpu.py -x -q > gpurun_out/${TAG}_test.log 2>&1; tail -5 gpurun_out/${TAG}_test.log
 fi
 export APS_RENDER_WORKERS=1
-python3 scripts/probe_render.py 3 || exit 1
+python3 scripts/probe/probe_render.py 3 || exit 1
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python3 scripts/probe_render.py 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python3 scripts/probe/probe_render.py 3 > /dev/null 2>&1
 cp /tmp/prof/p_kernel_stats.csv gpurun_out/${TAG}_render_kernel_stats.csv
 python3 - <<PY
 import csv

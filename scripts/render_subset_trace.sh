@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/rs
-(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/rs -o p -- python3 scripts/probe_render.py 4 8x8 multiband ${1:-0/8} > $R/gpurun_out/render_subset.txt 2>&1) || { tail -5 $R/gpurun_out/render_subset.txt; exit 1; }
+(cd $R && rocprofv3 --kernel-trace --output-format csv -d /tmp/rs -o p -- python3 scripts/probe/probe_render.py 4 8x8 multiband ${1:-0/8} > $R/gpurun_out/render_subset.txt 2>&1) || { tail -5 $R/gpurun_out/render_subset.txt; exit 1; }
 grep "^render" $R/gpurun_out/render_subset.txt
 python3 - <<'PY' | tee -a $R/gpurun_out/render_subset.txt
 import csv

@@ -2,7 +2,7 @@
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/st
-rocprofv3 --kernel-trace --output-format csv -d /tmp/st -o p -- python3 scripts/probe_sift_trace.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/st -o p -- python3 scripts/probe/probe_sift_trace.py > /dev/null 2>&1
 python3 - <<PY
 import csv, collections
 rows=list(csv.DictReader(open("/tmp/st/p_kernel_trace.csv")))

@@ -42,7 +42,7 @@ def test_resident_and_host_list_paths_agree(gpu, monkeypatch):
 
 def test_extraction_beside_matching_changes_no_bit(gpu):
     """Feature extraction on the worker streams while the main thread runs the batched matcher (int8 screening kernel,
-    f16 list pass, filter) - the overlap of scripts/probe_overlap_race.py as a regression test.  Round 2 found
+    f16 list pass, filter) - the overlap of scripts/probe/probe_overlap_race.py as a regression test.  Round 2 found
     SIFT's refine / orientation / descriptor kernels returning different results when they shared a SIMD with int8-MFMA
     waves; the screening kernel therefore keeps its SIMDs to itself (match_screen_i8_kernel claims the whole register
     file).  Whatever co-runs, every descriptor, location and match must equal the quiet run's."""
