@@ -193,6 +193,38 @@ def cpu_cfg1_single_thread(synth):
                       f"planar-scan composite {ow}x{oh} with a 3-band blend; oracle, one thread"}
 
 
+def sift_standalone_probe(pl, capi, input_, image):
+    """One view through the extraction on ONE stream, its launch sites bracketed by HIP events (outside the timed region): the
+    kernels' stand-alone times.  In the timed steps ten streams run side by side and the event intervals of a launch site
+    overlap (the `sift_blur` entry sums 5x the stage's wall time), so per-kernel rates of the extraction come from here."""
+    from importlib import import_module
+
+    fm = import_module(pl.__name__.rsplit(".", 1)[0] + ".featureMatching")
+    best = None
+    for _ in range(3):
+        capi.profile_enable(1)
+        capi.profile_reset()
+        d, p_ = fm.sift_extract(input_, image, device_out=True, points_device=True)
+        capi.check(capi.lib.aps_synchronize())
+        prof = capi.profile_all()
+        capi.profile_enable(False)
+        best = prof
+    h, w = int(image.shape[0]), int(image.shape[1])
+    oct_px = 4.0 * h * w * 4.0 / 3.0  # pixels of all octaves of the doubled base
+    ms = {k: v[0] for k, v in best.items() if k.startswith("sift_")}
+    out = {"ms_per_view": {k: round(v, 4) for k, v in ms.items()}, "features": int(d.shape[0])}
+    if ms.get("sift_blur"):
+        # six blurs per octave, each reading and writing one plane: 6 x 8 B per octave pixel (+ the base: 3 B in, 4 B out per doubled pixel)
+        b = 48.0 * oct_px + 3.0 * h * w + 16.0 * h * w
+        out["blur_chain"] = {"algorithmic_bytes": b, "GB/s": round(b / (ms["sift_blur"] * 1e-3) / 1e9, 1),
+                             "frac": round(b / (ms["sift_blur"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if ms.get("sift_extrema"):
+        b = 28.0 * oct_px  # the seven Gaussian planes of every octave, once
+        out["extrema_sweep"] = {"algorithmic_bytes": b, "GB/s": round(b / (ms["sift_extrema"] * 1e-3) / 1e9, 1),
+                                "frac": round(b / (ms["sift_extrema"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def global_matcher_probe(pl, capi, input_, images):
     """featureMatchingGlobal (the reference's default matcher) on the bench's views: SIFT once (untimed), then three passes of
     the pooled matcher (normalise, screened exact 4-NN, per-query filter); the last is reported (the first two still grow the
@@ -763,6 +795,17 @@ def main():
                 out["global_matcher_probe"] = global_matcher_probe(pl, capi, input_, [local[i] for i in range(n)])
             except Exception as e:  # a report, never a reason to lose the bench line
                 out["global_matcher_probe"] = {"ms": None, "note": f"failed: {e}"}
+        if world == 1:
+            try:  # (a report, never a reason to lose the bench line)
+                out["sift_standalone"] = sift_standalone_probe(pl, capi, input_, local[0])
+                for c_ in out["rooflines_all"]:
+                    if c_["kernel"].startswith("blur_kernel") and out["sift_standalone"].get("blur_chain"):
+                        c_["frac_standalone"] = out["sift_standalone"]["blur_chain"]["frac"]
+                        c_["standalone_note"] = ("`frac` divides by event intervals summed over ten concurrent streams (5x the stage's wall "
+                                                 "time); frac_standalone = the blur chain's algorithmic bytes (48 B per octave pixel + the "
+                                                 "base) over its launch sites' time for one view alone on one stream (sift_standalone)")
+            except Exception as e:
+                out["sift_standalone"] = {"note": f"failed: {e}"}
         if world == 1 and args.cpu_baseline == "auto":
             try:
                 out["cpu_baseline"] = cpu_baseline(synth, input_, f, args.bands, float(pano.shape[0] * pano.shape[1]))
