@@ -117,12 +117,19 @@ def sphericalBounds(cams, imgSize):
     """renderPanorama.m:1544-1579."""
     tmin = pmin = math.inf
     tmax = pmax = -math.inf
-    for rays in _all_grid_rays(cams, imgSize, stacked=True):  # (all cameras of a size at once: the same elementwise values)
-        x, y, z = rays[:, 0], rays[:, 1], rays[:, 2]
+
+    def ext(r):
+        x, y, z = r[:, 0], r[:, 1], r[:, 2]
         th = np.arctan2(x, z)
         ph = np.arctan2(y, np.hypot(x, z))
-        tmin, tmax = min(tmin, th.min()), max(tmax, th.max())
-        pmin, pmax = min(pmin, ph.min()), max(pmax, ph.max())
+        return th.min(), th.max(), ph.min(), ph.max()
+
+    # (Round 5: the same evaluation cut into camera chunks on four host threads is no faster - 0.88 against 0.73 ms for 64
+    # cameras on the GPU box's host - so it stays one piece.)
+    for rays in _all_grid_rays(cams, imgSize, stacked=True):  # (all cameras of a size at once: the same elementwise values)
+        a, b, c, d = ext(rays)
+        tmin, tmax = min(tmin, a), max(tmax, b)
+        pmin, pmax = min(pmin, c), max(pmax, d)
     return tmin, tmax, pmin, pmax
 
 
