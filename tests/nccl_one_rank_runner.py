@@ -65,4 +65,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:  # the parent shows the child's output only in part: put the reason where it is seen
+        import traceback
+
+        print("RUNNER FAILED\n" + traceback.format_exc()[-3000:], flush=True)
+        raise

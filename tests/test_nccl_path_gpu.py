@@ -15,13 +15,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_forced_collectives_over_nccl_equal_the_plain_run(gpu):
+def _run_once():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_PORT=str(port))
     env.pop("APS_PARALLEL_FORCE_COLLECTIVES", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_one_rank_runner.py")], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_one_rank_runner.py")], env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=600)
+
+
+def test_forced_collectives_over_nccl_equal_the_plain_run(gpu):
+    r = _run_once()
+    if r.returncode != 0 and "AssertionError" not in r.stdout + r.stderr:
+        # The child failed before it could compare anything (seen once in round 5, in the middle of a full-suite run, with
+        # nothing but torch's shutdown warning in the captured tail): bring-up of the process group beside the parent's own
+        # GPU context.  One second attempt on a new port; a COMPARISON failure (AssertionError) is never retried.
+        print("first attempt failed without an assertion:\n" + r.stdout[-1500:] + "\n" + r.stderr[-1500:])
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):  # (kept for inspection: a retry must not hide what happened)
+            with open(os.path.join(out_dir, "nccl_one_rank_first_attempt.txt"), "w") as f:
+                f.write("rc %d\n--- stdout ---\n%s\n--- stderr ---\n%s\n" % (r.returncode, r.stdout[-20000:], r.stderr[-20000:]))
+        r = _run_once()
+    if not (r.returncode == 0 and "OK" in r.stdout):
+        # (the runner prints its traceback to stdout behind a marker; RCCL's banner and torch's shutdown warning are noise)
+        tail = r.stdout[r.stdout.find("RUNNER FAILED"):] if "RUNNER FAILED" in r.stdout else r.stdout[-1500:]
+        err = "\n".join(l for l in r.stderr.splitlines() if "ProcessGroupNCCL" not in l and "amdgpu.ids" not in l)[-2500:]
+        pytest.fail("one-rank RCCL run failed (rc %d)\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r.returncode, tail, err), pytrace=False)
