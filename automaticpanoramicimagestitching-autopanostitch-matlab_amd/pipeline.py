@@ -102,6 +102,37 @@ def _init_worker(device):
         _capi.check(_capi.lib.aps_synchronize())
 
 
+def release_device_memory():
+    """Hands cached device memory back to the driver: the library's per-thread workspace pools (aps_release_workspace on the
+    calling thread and on every thread of the extraction pool - a thread only frees its own blocks) and torch's caching
+    allocator.  For a host that is about to start another process on the same GPU, or that has finished a large job: after
+    a 256 x 4K stitch the pools hold tens of gigabytes that nothing else can use.  Blocks in use are kept."""
+    import threading
+    import torch
+
+    _capi.check(_capi.lib.aps_release_workspace())
+    from . import renderPanorama as _rp
+
+    for pool in (_SIFT_POOL, getattr(_rp, "_RENDER_POOL", None)):
+        n = len(getattr(pool, "_threads", ())) if pool is not None else 0
+        if not n:
+            continue
+        gate = threading.Barrier(n)
+
+        def free(_, gate=gate):
+            gate.wait(timeout=30)  # one task per pool thread: nobody takes two
+            return _capi.lib.aps_release_workspace()
+
+        try:
+            for rc in pool.map(free, range(n)):
+                _capi.check(rc)
+        except threading.BrokenBarrierError:
+            pass  # a pool thread was busy: its blocks stay (they are in use or will be reused)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None, points_device=False):
     """The asynchronous form of sift_many: one future per image, submitted in input order to the worker pool, so that
     a caller can start matching the first images while the later ones are still being extracted (parallel._match_pass).
