@@ -284,7 +284,7 @@ def launch_ranks(n_gpus, argv):
     import subprocess
 
     have = torch.cuda.device_count()  # (counting devices does not initialise the runtime)
-    if os.environ.get("APS_BENCH_RANK_PROBE") != "1" and have < n_gpus:
+    if os.environ.get("APS_BENCH_RANK_PROBE") != "1" and os.environ.get("APS_BENCH_REHEARSE") != "1" and have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s)", file=sys.stderr)
         return 2
     env = dict(os.environ)
@@ -350,6 +350,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # APS_BENCH_REHEARSE=1 (test hook): every rank on device 0 over the gloo backend - RCCL refuses two ranks on one GPU, and a
+    # one-GPU box has no other way to walk this file's N > 1 path (the shard arithmetic of the roofline entries, the
+    # max-over-ranks reduction, rank 0's single line).  The numbers of such a run mean nothing.
+    rehearse = os.environ.get("APS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     # APS_PARALLEL_FORCE_COLLECTIVES=1 (test hook, see parallel._multi): the N > 1 launch path - process group on "nccl",
     # barriers, the max-over-ranks reduction, every collective of the sharded driver - with a single rank, which is as far
     # as a one-GPU box can rehearse what `torchrun --nproc-per-node N bench.py --gpus N` does
@@ -369,7 +375,10 @@ def main():
     if multi:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     synth = import_module(apsamd.__name__ + ".synth")
     pl = import_module(apsamd.__name__ + ".pipeline")
     par = import_module(apsamd.__name__ + ".parallel")
