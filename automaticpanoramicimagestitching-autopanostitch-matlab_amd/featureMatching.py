@@ -358,8 +358,20 @@ def featureMatchingPairwise(input, allDescriptors, numImg):
         raise ValueError("numImg must be positive and match numel(allDescriptors)")
     thr = input.get("Matchingthreshold", 1.5)
     ratio = input.get("Ratiothreshold", 0.6)
-    pair_ptr, ii, jj, _ = match_pairwise_csr(allDescriptors, ratio, thr, True)
+    if int(input.get("useMATLABFeatureMatch", 0)) == 1:
+        # getMatches :103-107 hands the pair to the toolbox's matchFeatures (closed code): no device counterpart
+        raise NotImplementedError("input.useMATLABFeatureMatch = 1 selects the Computer Vision Toolbox's matchFeatures; "
+                                  "set it to 0 for the device matcher (the MATLAB overlay forwards this switch to the reference)")
     matches = [[None] * numImg for _ in range(numImg)]
+    if str(input.get("Matchingmethod", "Exhaustive")).lower() == "approximate":
+        # getMatches :108-117 with Method = 'Approximate': pair by pair through matchFeaturesScratch, as the reference's parfor
+        # (:48-63) does; 'pca2nn' = nearest2ApproxFloatFast on the device, 'kdtree' / 'subsetpdist2' the exact device search
+        for (i, j) in pair_order(numImg):
+            m, _ = matchFeaturesScratch(allDescriptors[i], allDescriptors[j], Method="Approximate", MatchThreshold=thr, MaxRatio=ratio,
+                                        Unique=True, ApproxFloatNNMethod=input.get("ApproxFloatNNMethod", "pca2nn"))
+            matches[i][j] = np.asarray(m, np.float64).reshape(-1, 2)
+        return matches
+    pair_ptr, ii, jj, _ = match_pairwise_csr(allDescriptors, ratio, thr, True)
     for p, (i, j) in enumerate(pair_order(numImg)):
         s, e = pair_ptr[p], pair_ptr[p + 1]
         matches[i][j] = np.stack([ii[s:e], jj[s:e]], axis=1).astype(np.float64)

@@ -761,3 +761,30 @@ def test_pca2nn_argument_errors(gpu):
     assert call(4, 128, 4, 128, 128, 0) == capi.APS_E_ARG
     assert call(4, 64, 4, 128, 128, 48) == capi.APS_E_DIM
     assert call(4, 128, 4, 128, 128, 48) == capi.APS_OK
+
+
+def test_pairwise_operator_honours_the_matcher_switches(gpu):
+    """featureMatchingPairwise.m:103-117 (getMatches): Matchingmethod = 'Approximate' sends every pair through
+    matchFeaturesScratch with ApproxFloatNNMethod (pca2nn: the device PCA path, equal to the oracle's filtered result per pair);
+    'Exhaustive' is the batched all-pairs call; useMATLABFeatureMatch = 1 (toolbox matchFeatures) has no device form."""
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    rng = np.random.default_rng(21)
+    base = sift_like(rng, 900)
+    descs = []
+    for i in range(3):
+        keep = rng.permutation(900)[: 500 + 40 * i]
+        d = np.maximum(base[keep] + 0.02 * rng.standard_normal((len(keep), 128)).astype(np.float32), 0)
+        descs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
+    inp = {"Matchingthreshold": 1.5, "Ratiothreshold": 0.6, "useMATLABFeatureMatch": 0}
+    ex = fm.featureMatchingPairwise(dict(inp, Matchingmethod="Exhaustive"), descs, 3)
+    ap = fm.featureMatchingPairwise(dict(inp, Matchingmethod="Approximate", ApproxFloatNNMethod="pca2nn"), descs, 3)
+    for (i, j) in fm.pair_order(3):
+        assert ex[i][j].dtype == np.float64 and ap[i][j].dtype == np.float64 and ap[i][j].shape[1] == 2
+        oi, od1, od2 = oracle.pca2nn(descs[i], descs[j], 48, True)
+        want, _ = fm.filter_matches(oi, od1, od2, len(descs[j]), 0.6, 1.5, True)
+        assert np.array_equal(ap[i][j], want.astype(np.float64)), (i, j)
+        se, sa = {tuple(r) for r in ex[i][j].tolist()}, {tuple(r) for r in ap[i][j].tolist()}
+        assert len(se & sa) >= 0.85 * len(se) > 50
+    assert ap[1][0] is None and ap[0][0] is None
+    with pytest.raises(NotImplementedError):
+        fm.featureMatchingPairwise(dict(inp, useMATLABFeatureMatch=1), descs, 3)
