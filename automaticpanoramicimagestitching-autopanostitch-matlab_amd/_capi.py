@@ -129,6 +129,7 @@ _SIGNATURES = {
     "aps_ransac_draws_exhausted": [],
     "aps_gather_match_points": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64],
     "aps_match_screen_stats": [_vp, _vp],
+    "aps_match_screen_exact_jobs": [_vp, _vp],
     "aps_match_screen_kernel_regs": [C.c_int, C.c_int, _vp, _vp],
     "aps_match_set_stats": [_vp, _i64, _i64, C.c_int, C.c_int, _vp],
     "aps_global_normalize": [_vp, _i64, _i64, _i, _i, _vp],

@@ -330,16 +330,29 @@ __device__ __forceinline__ void prep_stats_reduce(const unsigned* __restrict__ p
         su[6] = max(su[6], r[4]);
     }
 }
-// ... and [5], the largest column-side residual norm of the int8 codes, from q8_desc_kernel's workgroups
-__device__ __forceinline__ void q8_stats_reduce(const unsigned* __restrict__ part, int n_blk, float* __restrict__ stat, unsigned* red) {
-    unsigned r = 0u;
-    for (int b = threadIdx.x; b < n_blk; b += blockDim.x) r = max(r, part[b]);
-    r = wave_umax(r);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+// ... and from q8_desc_kernel's workgroups (kQ8Part words each): [5] the largest column-side residual norm of the int8 codes,
+// and the exact codes' words (round 6): [8] the largest row divisor, [9] ~ the smallest, [10] != 0: some row has no exact code
+constexpr int kQ8Part = 4;
+constexpr int kStatWords = 12;  // statistics words per set
+__device__ __forceinline__ void q8_stats_reduce(const unsigned* __restrict__ part, int n_blk, float* __restrict__ stat, unsigned (*red)[5]) {
+    unsigned r[kQ8Part] = {0u, 0u, 0u, 0u};
+    for (int b = threadIdx.x; b < n_blk; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < kQ8Part; ++k) r[k] = max(r[k], part[(size_t)b * kQ8Part + k]);
+#pragma unroll
+    for (int k = 0; k < kQ8Part; ++k) r[k] = wave_umax(r[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < kQ8Part; ++k) red[threadIdx.x >> 6][k] = r[k];
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned* su = reinterpret_cast<unsigned*>(stat);
-        su[5] = max(su[5], max(max(red[0], red[1]), max(red[2], red[3])));
+#pragma unroll
+        for (int k = 0; k < kQ8Part; ++k) r[k] = max(max(red[0][k], red[1][k]), max(red[2][k], red[3][k]));
+        su[5] = max(su[5], r[0]);
+        su[8] = max(su[8], r[1]);
+        su[9] = max(su[9], r[2]);
+        su[10] = max(su[10], r[3]);
     }
 }
 __global__ __launch_bounds__(256) void prep_stats_kernel(const unsigned* __restrict__ part, int n_blk1, int n_blk2, float* __restrict__ stat,
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(256) void prep_stats_kernel(const unsigned* __restr
     if (which == 1)
         prep_stats_reduce(part, n_blk1, stat, hf != 0, red);
     else
-        q8_stats_reduce(part + (size_t)5 * n_blk1, n_blk2, stat, &red[0][0]);
+        q8_stats_reduce(part + (size_t)5 * n_blk1, n_blk2, stat, red);
 }
 
 __global__ __launch_bounds__(kPrepThreads) void prep_desc_kernel(const float* __restrict__ X, int64_t n, int64_t ld, int layout,
@@ -373,6 +386,10 @@ struct PrepJob {
     uint4* aug;
     unsigned* part;  // per-workgroup maxima: 5 words per prep_desc workgroup, then one per q8_desc workgroup
     int nb1, nb2;    // ... and how many of each
+    // round 6, the exact integer codes (q8_desc_rows): code bytes, per row the divisor, per row 128 x the code sum (n_pad entries)
+    signed char* QX;
+    float* tt;
+    int* cin;
 };
 __device__ __forceinline__ int prep_find_job(const int* __restrict__ blk_ptr, int n_jobs, int b) {
     int lo = 0, hi = n_jobs - 1;  // largest j with blk_ptr[j] <= b
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(256) void prep_stats_batch_kernel(const PrepJob* __
     if (which == 1)
         prep_stats_reduce(J.part, J.nb1, J.stat, J.Hf != nullptr, red);
     else
-        q8_stats_reduce(J.part + (size_t)5 * J.nb1, J.nb2, J.stat, &red[0][0]);
+        q8_stats_reduce(J.part + (size_t)5 * J.nb1, J.nb2, J.stat, red);
 }
 
 // Scales of the three b2/2 pieces of a descriptor set: b2/2 <= 2^e for the set's largest norm; piece i carries bits
@@ -461,6 +478,11 @@ struct Q8Set {
 
 __device__ int g_q8_symmetric = 0;  // experiment switch (APS_Q8_SYMMETRIC=1): column code without the offset
 __device__ int g_scr_variant = 0;   // experiment switch (APS_SCR_VARIANT, bits: see match_screen_i8x16_kernel)
+__device__ int g_q8_noexact = 0;    // A/B switch (APS_MATCH_NO_EXACT=1): no set gets exact integer codes (rounds 2-5's screen)
+#ifdef APS_MATCH_TIMING
+__device__ int g_q8_center = 0;     // timing builds only (APS_Q8_CENTER=c, -1 for 0): the exact codes as clamp(u - c): WRONG results, for
+                                    // measuring how the screening kernel's clock depends on the operands' magnitudes
+#endif
 
 __device__ __forceinline__ Q8Set q8_set(const float* __restrict__ qstat) {
     float mx = unord_f32(__float_as_uint(qstat[0])), mn = unord_f32(~__float_as_uint(qstat[3]));
@@ -488,7 +510,8 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
                                                       float* __restrict__ qstat, const float* __restrict__ row_sq,
                                                       const float* __restrict__ row_dn, int64_t n_pad,
                                                       const float* __restrict__ maxsq, uint4* __restrict__ aug,
-                                                      float* __restrict__ aug_res, unsigned* __restrict__ part_out, unsigned* s_red) {
+                                                      float* __restrict__ aug_res, unsigned* __restrict__ part_out, unsigned (*s_red)[kQ8Part],
+                                                      signed char* __restrict__ QX, float* __restrict__ ttv, int* __restrict__ cin) {
     unsigned db_bits = 0u;
     const int64_t i = g >> 3;
     const int part = (int)(g & 7);
@@ -556,12 +579,127 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
         sumqa[i] = sq;
         db_bits = __float_as_uint(sqrtf(dsb) * 1.001f);  // qstat[1]: the largest column-side residual norm of the set
     }
-    // (one word per workgroup, folded by q8_stats_reduce: a look at the running maximum and an atomic per ROW kept this
+    // ---- the exact code (round 6) ----
+    // SIFT descriptors are integers u of 0 .. 255 (OpenCV's quantisation) divided by their norm: x_k = fl(u_k / t), t =
+    // fl(sqrt(sum u^2)).  Where a row has that form the integers are recovered here - the smallest positive entry is tried as
+    // u = 1 .. kXTry, the candidate u = rint(x m / x_min) is accepted when every entry is an integer to 1e-3, none exceeds 255
+    // and, with t = fl(sqrt(sum u^2)), fl(u_k / t) reproduces x_k BIT FOR BIT for all k.  Then p = u - 128 is an exact int8
+    // code for rows and columns alike:
+    //     u_i . u_j = p_i . p_j + 128 sum p_i + 128 sum p_j + 128^3            (integers)
+    //     a . b_j   = u_i . u_j / (t_i t_j) within a factor 1 +- 2^-23          (every term >= 0, two roundings each)
+    // The column term 128 sum p_j is what the screening kernel's accumulators start from (cin: its MFMA's C operand), the
+    // row terms are put back in its tail, which bounds the unknown column divisor by the set's extremes of t (words [8], [9];
+    // an all-zero row has every dot product 0 whatever divisor it is given: t = 1, left out of the extremes).  One row without
+    // such a form (word [10]) and the set's jobs use the general codes above - both kinds are always written.
+    // A set that has already lost (some earlier workgroup met a row without such a form: word [11], a plain store that later
+    // workgroups may or may not see yet) skips the search: sets of ordinary floats pay for a few workgroups' tries only.
+    constexpr int kXTry = 24;
+    unsigned tmax_bits = 0u, tmin_bits = 0u, fail_bits = 0u;
+    volatile unsigned* const xlost = reinterpret_cast<volatile unsigned*>(qstat) + 7;
+    const bool lost = __builtin_amdgcn_readfirstlane((int)*xlost) != 0 || g_q8_noexact != 0;
+    {
+        float mn = INFINITY;
+        bool nonneg = true;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (xs[e] > 0.f) mn = fminf(mn, xs[e]);
+            nonneg = nonneg && xs[e] >= 0.f;  // (a NaN is not)
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            nonneg = (__shfl_xor(nonneg ? 1 : 0, off) != 0) && nonneg;
+        }
+        const bool live = i < n;
+        const bool zero_row = live && nonneg && mn == INFINITY;
+        bool done = !live || !nonneg || zero_row || lost;  // nothing (more) to try
+        bool found = zero_row;
+        float t_row = 1.f;
+        int usum = zero_row ? -128 * 16 : 0;  // this lane's share of sum p
+        uint32_t wx[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // u = 0 everywhere
+        for (int m = 1; m <= kXTry && __any(!done); ++m) {
+            const float t = __fdiv_rn((float)m, mn);
+            bool ok = !done;
+            int qq = 0;
+            float uf[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = __fmul_rn(xs[e], t);
+                uf[e] = rintf(v);
+                ok = ok && fabsf(v - uf[e]) <= 1e-3f * fmaxf(uf[e], 1.f) && uf[e] <= 255.f;
+                qq += (int)fminf(uf[e], 255.f) * (int)fminf(uf[e], 255.f);
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                ok = (__shfl_xor(ok ? 1 : 0, off) != 0) && ok;
+                qq += __shfl_xor(qq, off);
+            }
+            const float tq = sqrtf((float)qq);  // (qq <= 128 * 255^2 < 2^24: exact; sqrtf is correctly rounded here)
+            bool same = ok;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) same = same && __float_as_uint(__fdiv_rn(uf[e], tq)) == __float_as_uint(xs[e]);
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) same = (__shfl_xor(same ? 1 : 0, off) != 0) && same;
+            if (same && !done) {
+                found = true;
+                done = true;
+                t_row = tq;
+                usum = 0;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    uint32_t pw = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#ifdef APS_MATCH_TIMING
+                        const int cx = g_q8_center == 0 ? 128 : max(g_q8_center, 0);
+                        const int pq = min(max((int)uf[4 * q4 + e] - cx, -128), 127);
+#else
+                        const int pq = (int)uf[4 * q4 + e] - 128;
+#endif
+                        usum += pq;
+                        pw |= ((uint32_t)pq & 0xffu) << (8 * e);
+                    }
+                    wx[q4] = pw;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) usum += __shfl_xor(usum, off);
+        if (live) {
+            typedef __attribute__((address_space(1))) signed char GI8;
+            *(GU32x4*)((GI8*)QX + i * kDim + 16 * part) = u32x4_t{wx[0], wx[1], wx[2], wx[3]};
+            if (part == 0) {
+                ((GF32*)ttv)[i] = t_row;
+                if (!found || lost) {
+                    fail_bits = 1u;
+                    if (!lost) *xlost = 1u;
+                }
+#ifdef APS_MATCH_TIMING
+                if (!found && !lost && g_q8_center == 999) printf("[q8] row %lld of %lld has no exact code: min positive entry %g, non-negative %d, first entries %g %g %g %g\n", (long long)i, (long long)n, mn, (int)nonneg, xs[0], xs[1], xs[2], xs[3]);
+#endif
+                if (found && !zero_row) {
+                    tmax_bits = __float_as_uint(t_row);   // t > 0: the bit patterns order like the values
+                    tmin_bits = ~__float_as_uint(t_row);
+                }
+            }
+        }
+        if (i < n_pad && part == 0) ((__attribute__((address_space(1))) int*)cin)[i] = (live && found) ? 128 * usum : 0;
+    }
+    // (kQ8Part words per workgroup, folded by q8_stats_reduce: a look at the running maximum and an atomic per ROW kept this
     // kernel at a quarter of the rate its bytes move at)
     db_bits = wave_umax(db_bits);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = db_bits;
+    tmax_bits = wave_umax(tmax_bits);
+    tmin_bits = wave_umax(tmin_bits);
+    fail_bits = wave_umax(fail_bits);
+    if ((threadIdx.x & 63) == 0) {
+        s_red[threadIdx.x >> 6][0] = db_bits;
+        s_red[threadIdx.x >> 6][1] = tmax_bits;
+        s_red[threadIdx.x >> 6][2] = tmin_bits;
+        s_red[threadIdx.x >> 6][3] = fail_bits;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) *part_out = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    if (threadIdx.x < kQ8Part)
+        part_out[threadIdx.x] = max(max(s_red[0][threadIdx.x], s_red[1][threadIdx.x]), max(s_red[2][threadIdx.x], s_red[3][threadIdx.x]));
 }
 
 __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ P, int64_t n, signed char* __restrict__ QA,
@@ -570,18 +708,19 @@ __global__ __launch_bounds__(256) void q8_desc_kernel(const float* __restrict__ 
                                                       float* __restrict__ qstat, const float* __restrict__ row_sq,
                                                       const float* __restrict__ row_dn, int64_t n_pad,
                                                       const float* __restrict__ maxsq, uint4* __restrict__ aug,
-                                                      float* __restrict__ aug_res, unsigned* __restrict__ part) {
-    __shared__ unsigned s_red[4];
+                                                      float* __restrict__ aug_res, unsigned* __restrict__ part,
+                                                      signed char* __restrict__ QX, float* __restrict__ ttv, int* __restrict__ cin) {
+    __shared__ unsigned s_red[4][kQ8Part];
     q8_desc_rows(blockIdx.x * (int64_t)blockDim.x + threadIdx.x, P, n, QA, QB, dnqa, invsa, sumqa, qstat, row_sq, row_dn, n_pad, maxsq, aug,
-                 aug_res, part + blockIdx.x, s_red);
+                 aug_res, part + (size_t)kQ8Part * blockIdx.x, s_red, QX, ttv, cin);
 }
 __global__ __launch_bounds__(256) void q8_desc_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ blk_ptr, int n_jobs) {
-    __shared__ unsigned s_red[4];
+    __shared__ unsigned s_red[4][kQ8Part];
     const int j = prep_find_job(blk_ptr, n_jobs, (int)blockIdx.x);
     const PrepJob J = jobs[j];
     const int64_t blk = (int64_t)blockIdx.x - blk_ptr[j];
     q8_desc_rows(blk * (int64_t)blockDim.x + threadIdx.x, J.P, J.n, J.QA, J.QB, J.dnq, J.invs, J.sumq, J.stat + 4,
-                 J.sq, J.dn, J.n_pad, J.stat, J.aug, J.stat + 2, J.part + (size_t)5 * J.nb1 + blk, s_red);
+                 J.sq, J.dn, J.n_pad, J.stat, J.aug, J.stat + 2, J.part + (size_t)5 * J.nb1 + (size_t)kQ8Part * blk, s_red, J.QX, J.tt, J.cin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,6 +751,17 @@ struct MatchJob {
     const float* invsA;
     const int* sumqA;
     const float* qstatB;
+    // round 6, the exact integer codes (q8_desc_rows): code bytes of both sets, the A rows' divisors, 128 x the code sums of the
+    // A rows and of the B columns (cinB: ncinB entries, a multiple of 128), and the sets' words [8..10]: largest divisor, ~smallest,
+    // != 0 when some row has no exact code (then the job takes the general codes)
+    const signed char* AX;
+    const signed char* BX;
+    const float* ttA;
+    const int* cinA;
+    const int* cinB;
+    const unsigned* xstatA;
+    const unsigned* xstatB;
+    int ncinB;
 };
 
 struct WgJob {
@@ -1623,11 +1773,14 @@ __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
 // MFMA shapes of the screening kernel.
 constexpr int kScreenNone = -2147483647 - 1;
 
+// Does this job take the exact integer codes (q8_desc_rows)?  Every row of both sets has one.
+__device__ __forceinline__ bool screen_exact(const MatchJob& jb) { return (jb.xstatA[2] | jb.xstatB[2]) == 0u; }
+
 template <bool BOUNDS>
 __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row, int e0, int e1, int lane,
                                             uint32_t* __restrict__ out_idx, float* __restrict__ out_d1, float* __restrict__ out_d2,
                                             uint32_t* __restrict__ surv_list, unsigned int* __restrict__ surv_count, float prune_r2,
-                                            float prune_thr, float* __restrict__ bounds_out) {
+                                            float prune_thr, float* __restrict__ bounds_out, bool exact = false) {
     constexpr int kNone = kScreenNone;
     const int nA = jb.nA, nB = jb.nB;
     bool survive = false;
@@ -1651,6 +1804,38 @@ __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row
         bo[0] = L1f;
         bo[1] = H1f;
         bo[2] = H2f;
+        }
+    } else if (row < nA && exact) {
+        // Exact integer codes (q8_desc_rows): e0 >= e1 are the two largest (group maxima of) p_i.p_j + 128 sum p_j, so
+        //     u_i.u_j = e + 128 sum p_i + 128^3 =: I        (an exact integer, >= 0)
+        // and the real dot product of the two f32 rows is I / (t_i t_j) within a factor 1 +- 2^-23.  Only the column's divisor
+        // is unknown here: t_j lies in the set's [tmin, tmax] (an all-zero column has I = 0 and fits any divisor), hence
+        //     a.b_j0 <= I0 / (t_i tmin),    a.b_j1 >= I1 / (t_i tmax)
+        // and L1, H2 follow as in the general form below with E = 0.
+        bool pruned = false;
+        const float msb = *jb.maxsqB;
+        const float b2min = __uint_as_float(~__float_as_uint(jb.qstatB[2]));
+        const float tmax = __uint_as_float(jb.xstatB[0]), tmin = __uint_as_float(~jb.xstatB[1]);
+        if (msb < 1e37f && b2min >= 0.f && tmin > 0.f && tmax >= tmin && tmax < 1e30f && nB >= 2 && e1 != kNone) {
+            const double a2 = (double)jb.sqA[row];
+            const double na = sqrt(a2) * 1.00001, nb = sqrt((double)msb) * 1.00001;
+            const double ti = (double)jb.ttA[row];
+            const double rc = (double)jb.cinA[row] + 2097152.0;
+            const double s_hi = ((double)e0 + rc) / (ti * (double)tmin) * (1.0 + 4e-7);
+            const double s_lo = fmax((double)e1 + rc, 0.0) / (ti * (double)tmax) * (1.0 - 4e-7);
+            const double delta = 1.52587890625e-05 * (a2 + (double)msb + 2.0 * na * nb) + 1e-37;
+            const double L1 = a2 + (double)b2min - 2.0 * s_hi - delta;
+            const double H2 = a2 + (double)msb - 2.0 * s_lo + delta;
+            const double lo = L1 * (1.0 - 1e-5) - 1e-30;
+            pruned = ti > 0.0 && H2 >= 0.0 && (lo > (double)prune_r2 * H2 * (1.0 + 1e-5) || lo > (double)prune_thr * (1.0 + 1e-5));
+        }
+        if (pruned) {
+            const int64_t slot = jb.out_off + row;
+            out_idx[slot] = 0u;
+            out_d1[slot] = INFINITY;
+            out_d2[slot] = INFINITY;
+        } else {
+            survive = true;
         }
     } else if (row < nA) {
         const ScreenSet q = screen_set(jb);
@@ -1909,8 +2094,9 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
                                                                     uint32_t* __restrict__ out_idx, float* __restrict__ out_d1,
                                                                     float* __restrict__ out_d2, uint32_t* __restrict__ surv_list,
                                                                     unsigned int* __restrict__ surv_count, float prune_r2,
-                                                                    float prune_thr, float* __restrict__ bounds_out) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes];  // [buf][256][128 B], tile t in buf t % 3
+                                                                    float prune_thr, float* __restrict__ bounds_out, unsigned int* __restrict__ exact_flag) {
+    // [buf][256][128 B], tile t in buf t % 3; then [buf][256] accumulator start values (round 6: cinB, 1 KiB per tile)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes + 3 * 1024];
     int wg = blockIdx.x;
     {  // XCD-aware order, as in match_cand_f16_kernel
         const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
@@ -1927,6 +2113,13 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     const int kq = lane >> 4;
     const int nA = jb.nA, nB = jb.nB;
     const int rowb = w.row0 + wave * 64;  // this wave's rows: rowb + 16 g + c, every lane quarter kq sees them
+    // Round 6: where every row of both sets has an exact integer code (q8_desc_rows) the pass runs on those - same loop, other
+    // operands: the code bytes AX / BX and, as the C operand of each column block's first MFMA, the columns' 128 sum p_j
+    // (cinB; zeros for the general codes).  The pooled matcher's bounds pass keeps the general codes.
+    const bool exact = !BOUNDS && screen_exact(jb);
+    if (!BOUNDS && exact && tid == 0) exact_flag[w.job] = 1u;  // (diagnostics: aps_match_screen_exact_jobs)
+    const signed char* const opA = exact ? jb.AX : jb.AQ;
+    const signed char* const opB = exact ? jb.BX : jb.BQ;
     // experiment switches (APS_SCR_VARIANT): 1 = static priority for waves 4-7, 2 / 4 = waves 4-7 sleep 64 / 128 cycles after
     // every hand-over barrier (a stagger between the two waves of a SIMD), 8 = the odd waves instead of waves 4-7
 #ifdef APS_MATCH_TIMING  // (timing builds only, like the ablation bits)
@@ -1941,7 +2134,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
         const int arow = min(rowb + 16 * g + c, nA - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            aq[g][ks] = *reinterpret_cast<const i32x4*>(jb.AQ + (size_t)arow * kDim + 64 * ks + 16 * kq);
+            aq[g][ks] = *reinterpret_cast<const i32x4*>(opA + (size_t)arow * kDim + 64 * ks + 16 * kq);
     }
     constexpr int kNone = kScreenNone;
     int d0[4] = {kNone, kNone, kNone, kNone}, d1[4] = {kNone, kNone, kNone, kNone};
@@ -1954,7 +2147,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
         const int piece = wave * 4 + u;
         const int lrow = 8 * piece + dma_sub;
         const int brow = min(t * kQTN + lrow, nB - 1);
-        const signed char* src = jb.BQ + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
+        const signed char* src = opB + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
         const uint32_t dst = lds_base + buf * kQTileBytes + piece * 1024;
         uint32_t keep;
         asm volatile(
@@ -1963,6 +2156,24 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             : "v"(src), "s"(dst)
             : "memory");
     };
+    // The accumulators' start values of tile t (cinB, one int per column: 1 KiB per tile) travel with piece 0 of the tile,
+    // issued by wave 0; entries past the set's padded length are clamped to its last four (columns >= nB: masked in the fold).
+    // General codes: the three 1-KiB areas are zero-filled once, below.
+    const int ncin = jb.ncinB;
+    auto issue_cin = [&](int t, int buf) {
+        if (exact && wave == 0) {
+            const int col = min(t * kQTN + 4 * lane, ncin - 4);
+            const int* src = jb.cinB + col;
+            const uint32_t dst = lds_base + 3 * kQTileBytes + buf * 1024;
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+    if (!exact && tid < 192) *reinterpret_cast<i32x4*>(lds + 3 * kQTileBytes + 16 * tid) = i32x4{0, 0, 0, 0};
     i32x4 acc[2][2][4];  // [block parity][sub-block][row group]
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -2012,6 +2223,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     if (ntiles > 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+        issue_cin(0, 0);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(aq[g][0]), "v"(aq[g][1]));
@@ -2021,14 +2233,21 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     // per-lane read offsets: slot s of a block = sub-block s >> 1, k-step s & 1: row 16 (s >> 1) + c, chunk (4 (s & 1) + kq)
     // ^ ((c >> 1) & 7)  (the sub-block's 16 rows leave (row >> 1) & 7 alone)
     const int hx = (16 * kq) ^ (16 * ((c >> 1) & 7));
-    const i32x4 zero4 = {0, 0, 0, 0};
     constexpr int kAhead = 3;
     auto slot_off = [&](int s) __attribute__((always_inline)) { return (s >> 1) * 16 * kDim + ((64 * (s & 1)) ^ hx); };
     i32x4 bq[4];
+    // cin[u]: the start values of the lane's four columns 16 u + 4 kq + r of the NEXT block to start (read one block ahead)
+    i32x4 cin[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const unsigned char* const cin_lds = lds + 3 * kQTileBytes + 16 * kq;
     if (ntiles > 0) {
-        if (ntiles > 1) issue_piece(1, 1, 0);
+        if (ntiles > 1) {
+            issue_piece(1, 1, 0);
+            issue_cin(1, 1);
+        }
 #pragma unroll
         for (int s = 0; s < kAhead; ++s) bq[s] = *reinterpret_cast<const i32x4*>(lds + c * kDim + slot_off(s));
+        cin[0] = *reinterpret_cast<const i32x4*>(cin_lds);
+        cin[1] = *reinterpret_cast<const i32x4*>(cin_lds + 64);
     }
     int b_cur = 0;  // t % 3
     auto run_tile = [&](int t, auto MASK) __attribute__((always_inline)) {
@@ -2038,6 +2257,8 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
         const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
         const unsigned char* tile = lds + b_cur * kQTileBytes + c * kDim;
         const unsigned char* tile_n = lds + b_nxt * kQTileBytes + c * kDim;
+        const unsigned char* cin_t = cin_lds + b_cur * 1024;
+        const unsigned char* cin_n = cin_lds + b_nxt * 1024;
         b_cur = b_nxt;
         static_for<0, kQBlk>([&](auto CB) {
             constexpr int cb = decltype(CB)::value;
@@ -2046,7 +2267,10 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             if (cb == 0 || cb == 2 || cb == 4) {
                 if (more) issue_piece(t + 1, b_nxt, cb / 2 + 1);
             } else if (cb == kLast) {
-                if (more2) issue_piece(t + 2, b_nxt2, 0);
+                if (more2) {
+                    issue_piece(t + 2, b_nxt2, 0);
+                    issue_cin(t + 2, b_nxt2);
+                }
             }
             const unsigned char* blk = tile + cb * 32 * kDim;
             const unsigned char* nblk = cb < kLast ? blk + 32 * kDim : tile_n;
@@ -2063,7 +2287,14 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    acc[par][u][g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xq, aq[g][ks], ks == 0 ? zero4 : acc[par][u][g], 0, 0, 0);
+                    acc[par][u][g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xq, aq[g][ks], ks == 0 ? cin[u] : acc[par][u][g], 0, 0, 0);
+                // sub-block u's start values are consumed: fetch the next block's (the same tile's, or the next tile's first)
+                if (ks == 1) {
+                    if (cb < kLast)
+                        cin[u] = *reinterpret_cast<const i32x4*>(cin_t + (32 * (cb + 1) + 16 * u) * 4);
+                    else if (more)
+                        cin[u] = *reinterpret_cast<const i32x4*>(cin_n + (16 * u) * 4);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // the block being searched is the previous one: (t, cb - 1), or the last block of tile t - 1 (never ragged)
                 constexpr bool first = cb == 1, last = cb == 0;
@@ -2118,7 +2349,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
         }
     }
     const int row = rowb + lane;  // = rowb + 16 kq + c
-    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out);
+    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out, exact);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2273,9 +2504,13 @@ struct Prepared {
     Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
     Ws<float> dnq, invs;
     Ws<int> sumq;
+    Ws<signed char> QX;  // round 6: the exact integer codes (q8_desc_rows), the rows' divisors, 128 x the code sums (n_pad entries)
+    Ws<float> tt;
+    Ws<int> cin;
+    int64_t n_pad = 0;
     Ws<unsigned> part;  // per-workgroup maxima of prep_desc / q8_desc (PrepJob::part)
     int nb1 = 0, nb2 = 0;
-    float* stat = nullptr;  // the eight statistics words: own (maxsq) or a slice of the caller's block (one fill for many sets)
+    float* stat = nullptr;  // the kStatWords statistics words: own (maxsq) or a slice of the caller's block (one fill for many sets)
     int64_t n = 0;
 };
 
@@ -2296,8 +2531,13 @@ static void sync_device_switch(const char* env, const void* symbol, int& held) {
     held = want;
 }
 static void sync_q8_symmetric_switch() {
-    static thread_local int held = 0;  // (one context per thread: core.hip)
+    static thread_local int held = 0, held_nx = 0;  // (one context per thread: core.hip)
     sync_device_switch("APS_Q8_SYMMETRIC", &g_q8_symmetric, held);
+    sync_device_switch("APS_MATCH_NO_EXACT", &g_q8_noexact, held_nx);
+#ifdef APS_MATCH_TIMING
+    static thread_local int held_c = 0;
+    sync_device_switch("APS_Q8_CENTER", &g_q8_center, held_c);
+#endif
 }
 
 static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool normalize,
@@ -2316,7 +2556,7 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     prep_desc_kernel<<<out.nb1, kPrepThreads, 0, st>>>(X_dev, n, ld, layout, normalize ? 1 : 0, out.P, out.sq, out.H, out.dn, out.part);
     prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, (const unsigned short*)out.H != nullptr ? 1 : 0, 1);
     q8_desc_kernel<<<out.nb2, 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn, n_pad, out.stat,
-                                            out.aug, out.stat + 2, out.part + (size_t)5 * out.nb1);
+                                            out.aug, out.stat + 2, out.part + (size_t)5 * out.nb1, out.QX, out.tt, out.cin);
     prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 2);
     check_launch("prep_desc_kernel");
 }
@@ -2340,7 +2580,7 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
         const Prepared& o = *r.out;
         const int64_t n_pad = (std::max<int64_t>(r.n, 1) + kTNB - 1) / kTNB * kTNB;
         jobs.push_back(PrepJob{r.X, r.n, r.ld, n_pad, layout, r.normalize ? 1 : 0, o.P, o.sq, o.dn, o.stat, o.H, o.QA, o.QB, o.dnq, o.invs, o.sumq, o.aug,
-                               o.part, o.nb1, o.nb2});
+                               o.part, o.nb1, o.nb2, o.QX, o.tt, o.cin});
         bp.push_back(bp.back() + o.nb1);
         bq.push_back(bq.back() + o.nb2);
     }
@@ -2372,8 +2612,8 @@ static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_
     if (stat_ext) {  // zeroed by the caller
         out.stat = stat_ext;
     } else {
-        out.maxsq.alloc(8);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's (one fill for both)
-        APS_HIP(hipMemsetAsync(out.maxsq, 0, 8 * sizeof(float), st));
+        out.maxsq.alloc(kStatWords);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's, [8..10] its exact codes' (one fill)
+        APS_HIP(hipMemsetAsync(out.maxsq, 0, kStatWords * sizeof(float), st));
         out.stat = out.maxsq;
     }
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
@@ -2383,9 +2623,13 @@ static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_
     out.dnq.alloc(rows);
     out.invs.alloc(rows);
     out.sumq.alloc(rows);
+    out.QX.alloc(rows * kDim);
+    out.tt.alloc(rows);
+    out.cin.alloc((size_t)n_pad);
+    out.n_pad = n_pad;
     out.nb1 = (int)cdiv(rows, kPrepRows);
     out.nb2 = (int)cdiv((size_t)n_pad * 8, 256);
-    out.part.alloc((size_t)5 * out.nb1 + out.nb2);
+    out.part.alloc((size_t)5 * out.nb1 + (size_t)kQ8Part * out.nb2);
 }
 
 static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, int64_t out_off) {
@@ -2410,6 +2654,14 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.invsA = a.invs;
     j.sumqA = a.sumq;
     j.qstatB = b.stat + 4;
+    j.AX = a.QX;
+    j.BX = b.QX;
+    j.ttA = a.tt;
+    j.cinA = a.cin;
+    j.cinB = b.cin;
+    j.xstatA = reinterpret_cast<const unsigned*>(a.stat + 8);
+    j.xstatB = reinterpret_cast<const unsigned*>(b.stat + 8);
+    j.ncinB = (int)b.n_pad;
     return j;
 }
 
@@ -2544,6 +2796,7 @@ static std::vector<WgJob> pool_lists(const std::vector<MatchJob>& jobs, const st
 }
 
 static thread_local int64_t g_screen_rows = 0, g_screen_surv = 0;  // aps_match_screen_stats
+static thread_local int64_t g_screen_jobs = 0, g_screen_exact = 0;  // aps_match_screen_exact_jobs
 
 // A/B switch: APS_SCREEN_SHAPE=32 runs the screening pass on v_mfma_i32_32x32x32_i8 (rounds 2-3) instead of 16x16x64
 static bool screen_shape_32() {
@@ -2578,7 +2831,7 @@ static void require_whole_simd(int shape32, int bounds = 0) {
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
 static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, float* d1, float* d2, float prune_r2 = 0.f,
                            float prune_thr = 0.f) {
-    g_screen_rows = g_screen_surv = 0;
+    g_screen_rows = g_screen_surv = g_screen_jobs = g_screen_exact = 0;
     bool any_rows = false;
     for (const MatchJob& j : jobs) any_rows = any_rows || j.nA > 0;
     if (!any_rows) return;
@@ -2624,8 +2877,8 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     const bool screen = prune_r2 > 0.f && !std::getenv("APS_MATCH_NO_SCREEN");
     if (screen) {
         Ws<uint32_t> surv_list((size_t)total_rows);
-        Ws<unsigned int> surv_count(jobs.size());
-        APS_HIP(hipMemsetAsync(surv_count, 0, jobs.size() * sizeof(unsigned int), stream()));
+        Ws<unsigned int> surv_count(2 * jobs.size());  // per job: survivors, then 1 where the job ran on exact integer codes
+        APS_HIP(hipMemsetAsync(surv_count, 0, 2 * jobs.size() * sizeof(unsigned int), stream()));
         {
             Prof prof("match_screen_i8");
 #ifdef APS_MATCH_TIMING
@@ -2640,13 +2893,18 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
                                                                                           surv_count, prune_r2, prune_thr, nullptr);
             else
                 match_screen_i8x16_kernel<false><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), idx, d1, d2, surv_list,
-                                                                                             surv_count, prune_r2, prune_thr, nullptr);
+                                                                                             surv_count, prune_r2, prune_thr, nullptr,
+                                                                                             surv_count.get() + jobs.size());
         }
         check_launch("match_screen_i8_kernel");
         const auto S0 = std::chrono::steady_clock::now();
-        std::vector<unsigned int> h_surv(jobs.size());
-        APS_HIP(hipMemcpyAsync(h_surv.data(), surv_count, jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        std::vector<unsigned int> h_surv(2 * jobs.size());
+        APS_HIP(hipMemcpyAsync(h_surv.data(), surv_count, 2 * jobs.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
         APS_HIP(hipStreamSynchronize(stream()));
+        g_screen_jobs = (int64_t)jobs.size();
+        g_screen_exact = 0;
+        for (size_t j = 0; j < jobs.size(); ++j) g_screen_exact += h_surv[jobs.size() + j] ? 1 : 0;
+        h_surv.resize(jobs.size());
         const auto S1 = std::chrono::steady_clock::now();
         // the survivors of the jobs that share a B set are pooled into common 512-row tiles (APS_MATCH_NO_POOL=1: one list per
         // job, as in rounds 2-3 - 6599 tiles instead of ~5600 for the 64 x 4K scene)
@@ -3121,12 +3379,12 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
     Ws<float>& prep_stats = G.stats;
     if (!G.ready) {  // the images' operand forms: every set in one batch of launches (as in match_pairs_impl)
         prep.resize(n);
-        prep_stats.alloc((size_t)8 * std::max(n, 1));
-        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)8 * std::max(n, 1) * sizeof(float), stream()));
+        prep_stats.alloc((size_t)kStatWords * std::max(n, 1));
+        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)kStatWords * std::max(n, 1) * sizeof(float), stream()));
         std::vector<PrepRequest> req;
         for (int b = 0; b < n; ++b) {
             const float* xb = layout == APS_ROWMAJOR ? X_dev + (size_t)img_off[b] * ld : X_dev + img_off[b];
-            req.push_back({xb, img_off[b + 1] - img_off[b], ld, false, &prep[b], prep_stats.get() + 8 * b});
+            req.push_back({xb, img_off[b + 1] - img_off[b], ld, false, &prep[b], prep_stats.get() + kStatWords * b});
         }
         prepare_batch(req, layout);
         G.ready = true;
@@ -3162,7 +3420,7 @@ int64_t screened_global_top3(const float* X_dev, int64_t ld, int layout, const s
                                                                                          nullptr, nullptr, 0.f, 0.f, bounds);
             else
                 match_screen_i8x16_kernel<true><<<(unsigned)bw.size(), 512, 0, stream()>>>(djobs, dbw, (int)bw.size(), nullptr, nullptr, nullptr,
-                                                                                            nullptr, nullptr, 0.f, 0.f, bounds);
+                                                                                            nullptr, nullptr, 0.f, 0.f, bounds, nullptr);
         }
         check_launch("match_screen_i8_kernel (bounds)");
         APS_HIP(hipStreamSynchronize(stream()));  // djobs / dbw go out of scope
@@ -3455,7 +3713,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
     auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
     std::vector<Prepared> raw(n_img), nrm(n_img);
-    Ws<float> prep_stats((size_t)16 * std::max(n_img, 1));
+    Ws<float> prep_stats((size_t)2 * kStatWords * std::max(n_img, 1));
     std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
     for (int64_t p = 0; p < n_pairs; ++p) {
         const bool norm = big(pa[p]) || big(pb[p]);
@@ -3465,12 +3723,12 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     {  // every set of the batch in four launches (prepare_batch); APS_MATCH_PREP_STREAMS=1 keeps the older form, one chain of
        // launches per set on eight forked streams
         constexpr int kPrepStreams = 8;
-        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)16 * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
+        APS_HIP(hipMemsetAsync(prep_stats, 0, (size_t)2 * kStatWords * std::max(n_img, 1) * sizeof(float), stream()));  // all sets' statistics
         if (!std::getenv("APS_MATCH_PREP_STREAMS")) {  // round 4: every set in two launches (see prep_desc_batch_kernel)
             std::vector<PrepRequest> req;
             for (int i = 0; i < n_img; ++i) {
-                if (need_raw[i]) req.push_back({din[i], counts[i], ld[i], false, &raw[i], prep_stats.get() + 16 * i});
-                if (need_nrm[i]) req.push_back({din[i], counts[i], ld[i], true, &nrm[i], prep_stats.get() + 16 * i + 8});
+                if (need_raw[i]) req.push_back({din[i], counts[i], ld[i], false, &raw[i], prep_stats.get() + 2 * kStatWords * i});
+                if (need_nrm[i]) req.push_back({din[i], counts[i], ld[i], true, &nrm[i], prep_stats.get() + 2 * kStatWords * i + kStatWords});
             }
             prepare_batch(req, layout);
         } else {
@@ -3479,8 +3737,8 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
             Prof prof("match_prep");
             int k = 0;
             for (int i = 0; i < n_img; ++i) {
-                if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i);
-                if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 16 * i + 8);
+                if (need_raw[i]) prepare(din[i], counts[i], ld[i], layout, false, raw[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 2 * kStatWords * i);
+                if (need_nrm[i]) prepare(din[i], counts[i], ld[i], layout, true, nrm[i], aux[k++ % kPrepStreams], false, prep_stats.get() + 2 * kStatWords * i + kStatWords);
             }
             fork.join();
         }
@@ -3543,6 +3801,12 @@ extern "C" {
 int aps_match_screen_stats(int64_t* rows, int64_t* survivors) {
     if (rows) *rows = g_screen_rows;
     if (survivors) *survivors = g_screen_surv;
+    return APS_OK;
+}
+
+int aps_match_screen_exact_jobs(int64_t* jobs, int64_t* exact_jobs) {
+    if (jobs) *jobs = g_screen_jobs;
+    if (exact_jobs) *exact_jobs = g_screen_exact;
     return APS_OK;
 }
 

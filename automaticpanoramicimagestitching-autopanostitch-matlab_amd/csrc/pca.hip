@@ -290,15 +290,17 @@ void jacobi_eigh(std::vector<double>& A, int n, std::vector<double>& V) {
 }
 
 // principal axes of cov (128 x 128, f64) by descending eigenvalue (ties: lower Jacobi column first), each signed so that
-// its largest-magnitude entry (first on ties) is positive; coeff[k * ncomp + c], f32
-void pca_axes(std::vector<double>& cov, int ncomp, std::vector<float>& coeff) {
+// its largest-magnitude entry (first on ties) is positive; coeff[k * ncomp + c], f32.  Only the first `keep` axes are filled:
+// pca() of n observations returns min(n - 1, NumComponents) columns (the centred data has rank <= n - 1), and an axis of zeros
+// projects every row of either set to exactly 0 - the same sums, norms and cosines as a basis without that column.
+void pca_axes(std::vector<double>& cov, int ncomp, int keep, std::vector<float>& coeff) {
     std::vector<double> V;
     jacobi_eigh(cov, kD, V);
     std::vector<int> order(kD);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cov[(size_t)a * kD + a] > cov[(size_t)b * kD + b]; });
     coeff.assign((size_t)kD * ncomp, 0.f);
-    for (int c = 0; c < ncomp; ++c) {
+    for (int c = 0; c < std::min(ncomp, keep); ++c) {
         const int col = order[c];
         int big = 0;
         for (int k = 1; k < kD; ++k)
@@ -347,7 +349,7 @@ extern "C" int aps_match_pca2nn(const float* A, int64_t n1, int64_t lda, const f
             APS_HIP(hipMemcpyAsync(h_cov.data(), cov, h_cov.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
             APS_HIP(hipStreamSynchronize(stream()));
             std::vector<float> h_coeff;
-            pca_axes(h_cov, ncomp, h_coeff);
+            pca_axes(h_cov, ncomp, (int)std::min<int64_t>(n2 - 1, ncomp), h_coeff);  // :481-482 with fewer than ncomp + 1 rows in B
             APS_HIP(hipMemcpyAsync(coeff, h_coeff.data(), h_coeff.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
             APS_HIP(hipStreamSynchronize(stream()));  // (h_coeff is pageable and goes out of scope)
             if (coeff_out) {

@@ -120,8 +120,12 @@ int aps_match_2nn_ssd(const float* A, int64_t n1, int64_t lda, const float* B, i
  *   descending eigenvalue, each signed so that its largest-magnitude entry is positive (pca's convention), cast to f32;
  *   projection = k-ascending f32 fma chain; squared norm s = s + y*y over ascending components;
  *   G(i,j) = component-ascending f32 fma chain (one MFMA chain).
+ *   Fewer than n_components + 1 rows in B: pca() returns min(n2 - 1, n_components) columns (the centred data has rank
+ *   <= n2 - 1); the other columns of the basis are ZERO here, which projects every row of A and of B to exactly 0 on them -
+ *   the same norms, similarities and distances as the reference's narrower basis (n2 == 1: no column at all, d1 = 2).
  * idx2: 1-based uint32[n1]; d1, d2: f32[n1] (d2 = +inf when n2 == 1).  mu_out (f32[dim]) and coeff_out (f32[dim x
- * n_components], row-major) are optional (NULL) and filled only when the projection runs.  n1, n2 >= 1. */
+ * n_components], row-major; columns min(n2 - 1, n_components) .. are zero) are optional (NULL) and filled only when the
+ * projection runs.  n1, n2 >= 1. */
 int aps_match_pca2nn(const float* A, int64_t n1, int64_t lda, const float* B, int64_t n2, int64_t ldb, int dim, int layout,
                      int n_components, int use_pca, uint32_t* idx2, float* d1, float* d2, float* mu_out, float* coeff_out);
 
@@ -151,6 +155,14 @@ int aps_match_features(const float* F1, int64_t n1, int64_t ld1, const float* F2
  * path.  The screen never changes a result (matchFeaturesScratch.m:170-178 is evaluated on exact distances for every
  * row that can pass it); the counters exist for benchmarks and for tests that guard against a silently disabled screen. */
 int aps_match_screen_stats(int64_t* rows, int64_t* survivors);
+
+/* ... and of the same call: jobs = the (A set, B set) jobs the screening pass ran, exact_jobs = those it ran on EXACT int8
+ * codes.  A set whose every row is a vector of integers 0 .. 255 divided by its f32 norm, bit for bit (SIFT descriptors as
+ * OpenCV quantises them and the SIFT stage hands them over; detected per row, no hint needed), is coded as u - 128 without any
+ * rounding, and a job of two such sets bounds its distances from exact integer dot products: the only slack left is the
+ * spread of the column set's norms.  Any other job takes the rounded codes with their error terms.  Same results either
+ * way; APS_MATCH_NO_EXACT=1 switches the exact codes off (A/B).  For benchmarks and tests. */
+int aps_match_screen_exact_jobs(int64_t* jobs, int64_t* exact_jobs);
 
 /* Diagnostics: the eight statistics words the matcher's proofs take from ONE descriptor set (n x 128 f32, `normalize` != 0:
  * rows L2-normalised first as matchFeaturesScratch.m:232-233 does), as the preparation kernels compute them (maxima over

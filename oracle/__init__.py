@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaps_oracle.so")
+# APS_ORACLE_LIB: another build of the same sources (tests/test_oracle_sanitized.py: `make -C oracle asan`)
+LIB_PATH = os.environ.get("APS_ORACLE_LIB") or os.path.join(_HERE, "lib", "libaps_oracle.so")
 
 
 def build(force: bool = False) -> None:

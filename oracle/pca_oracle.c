@@ -145,7 +145,11 @@ ORC_API void orc_pca_basis(const float* B, int64_t n, int dim, int ncomp, float*
         }
         order[j + 1] = o;
     }
-    for (int c = 0; c < ncomp; ++c) {
+    /* pca() of n observations returns min(n - 1, NumComponents) columns (centred data has rank <= n - 1; MATLAB's default
+     * 'Economy' form, matchFeaturesScratch.m:481-482 passes no other): the remaining columns of coeff stay zero, which projects
+     * every row to exactly 0 there - the sums, norms and cosines of a basis without those columns (round 6) */
+    memset(coeff, 0, (size_t)dim * ncomp * sizeof(float));
+    for (int c = 0; c < ncomp && c < n - 1; ++c) {
         const int col = order[c];
         int big = 0;
         for (int k = 1; k < dim; ++k)

@@ -320,6 +320,13 @@ def test_pca_backend_equals_the_oracle_bit_for_bit(gpu):
     oi, od1, od2 = oracle.pca2nn(As, Bs[:1], 48, False)
     _, i2, e1, e2 = fm.nearest2ApproxFloatFast(As, Bs[:1], {"UsePCA": False})
     assert np.array_equal(i2, oi) and np.array_equal(e1, od1) and np.all(np.isinf(e2)) and np.all(np.isinf(od2))
+    # fewer rows in B than components + 1: pca() returns min(n2 - 1, 48) columns, the rest of the basis stays zero
+    for n2 in (2, 10, 48, 49):
+        oi, od1, od2 = oracle.pca2nn(As, Bs[:n2], 48, True)
+        omu, oco, _ = oracle.pca_basis(Bs[:n2], 48)
+        _, i2, e1, e2, (mu2, co2) = fm.nearest2ApproxFloatFast(As, Bs[:n2], return_basis=True)
+        assert np.array_equal(mu2, omu) and np.array_equal(co2, oco) and not co2[:, min(n2 - 1, 48):].any(), n2
+        assert np.array_equal(i2, oi) and np.array_equal(e1, od1) and np.array_equal(e2, od2), n2
     with pytest.raises(ValueError):
         fm.nearest2ApproxFloatFast(As[:0], Bs)
 
@@ -564,6 +571,119 @@ def test_int8_screen_adversarial_sets(fm, monkeypatch):
     # unnormalised 0..255 descriptors: the reference normalises them (max > 2), the screen sees the normalised copy
     a4, b4, _, _ = planted_pair(rng, 1000, 1300, 500, noise=0.03, unit=False)
     _screen_ab(fm, monkeypatch, a4, b4, 0.6, 3.5, True)
+
+
+def _screen_share(gpu):
+    import ctypes
+
+    rows, surv = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    return rows.value, surv.value
+
+
+def _exact_jobs(gpu):
+    import ctypes
+
+    jobs, ex = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_exact_jobs(ctypes.byref(jobs), ctypes.byref(ex)))
+    return jobs.value, ex.value
+
+
+def test_int8_screen_exact_integer_codes(fm, gpu, monkeypatch):
+    """Round 6: sets of integers 0 .. 255 (SIFT descriptors as OpenCV quantises them) that are matched in normalised form take
+    EXACT int8 codes u - 128 on both sides, the column term of the centring entering as the MFMA's C operand.  The match lists
+    must equal the oracle's, those of the general codes (APS_MATCH_NO_EXACT=1) and those without the screen; the exact codes
+    must dismiss more rows; ragged column counts, zero rows, saturated entries, duplicated columns, one column, and a set
+    that is not integer-valued (whose jobs must take the general codes)."""
+    rng = np.random.default_rng(61)
+    a, b, _, ib = planted_pair(rng, 3000, 3500, 1200, noise=0.03, unit=False)
+    assert a.max() > 2 and np.array_equal(a, np.rint(a))
+
+    def shares(x, y, ratio, thr, unique, want_exact=True):
+        monkeypatch.delenv("APS_MATCH_NO_EXACT", raising=False)
+        m, met = fm.matchFeaturesScratch(x, y, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+        rows, s_exact = _screen_share(gpu)
+        assert want_exact is None or _exact_jobs(gpu) == (1, 1 if want_exact else 0)
+        monkeypatch.setenv("APS_MATCH_NO_EXACT", "1")
+        m1, met1 = fm.matchFeaturesScratch(x, y, MatchThreshold=thr, MaxRatio=ratio, Unique=unique)
+        _, s_general = _screen_share(gpu)
+        assert _exact_jobs(gpu) == (1, 0)
+        monkeypatch.delenv("APS_MATCH_NO_EXACT", raising=False)
+        assert np.array_equal(m, m1) and np.array_equal(bits(met), bits(met1)) and rows == len(x)
+        return len(m), s_exact, s_general
+
+    for ratio, thr, unique in ((0.6, 3.5, True), (0.8, 1.5, False), (1.0, 3.5, True), (0.36, 0.2, True)):
+        _screen_ab(fm, monkeypatch, a, b, ratio, thr, unique)
+        k, s_exact, s_general = shares(a, b, ratio, thr, unique)
+        assert s_exact <= s_general, (ratio, s_exact, s_general)
+        assert k <= s_exact, (k, s_exact)
+    # planted pairs whose ratios scatter around the boundary: here the general codes' error band keeps rows the exact codes
+    # dismiss (a guard against a silently disabled exact mode)
+    ah, bh, ia, ibh = planted_pair(rng, 3000, 3500, 1500, noise=0.02)
+    noise = rng.uniform(0.0, 0.25, len(ibh))[:, None]
+    pert = np.maximum(ah[ia] + noise * rng.standard_normal((len(ia), 128)).astype(np.float32), 0)
+    bh[ibh] = (pert / (np.linalg.norm(pert, axis=1, keepdims=True) + 1e-12)).astype(np.float32)
+    ah, bh = np.round(ah * 512).clip(0, 255).astype(np.float32), np.round(bh * 512).clip(0, 255).astype(np.float32)
+    _screen_ab(fm, monkeypatch, ah, bh, 0.6, 3.5, True)
+    k, s_exact, s_general = shares(ah, bh, 0.6, 3.5, True)
+    assert k <= s_exact <= s_general, (k, s_exact, s_general)
+    # degenerate rows: a duplicated best column (d1 == d2), all-zero rows (divisor eps), saturated and one-hot rows (an
+    # all-255 row has no exact code within the tries: its set falls back to the general codes)
+    b[100] = b[ib[0]]
+    b[101] = 0
+    a[7] = 0
+    a[8] = 255
+    b[102] = 255
+    a[9, :] = 0
+    a[9, 5] = 255
+    for ratio, thr, unique in ((0.6, 3.5, True), (0.8, 1.5, False), (1.0, 3.5, True)):
+        _screen_ab(fm, monkeypatch, a, b, ratio, thr, unique)
+        shares(a, b, ratio, thr, unique, want_exact=None)
+    a[8], b[102] = a[10], b[103]  # without the all-255 rows both sets have exact codes again (zero rows fit any divisor)
+    shares(a, b, 0.6, 3.5, True)
+    a, b, _, ib = planted_pair(rng, 3000, 3500, 1200, noise=0.03, unit=False)
+    # the form the SIFT stage hands over: the same integers divided by their norm in f32 (matched without normalisation)
+    au = (a / np.sqrt((a * a).sum(1, dtype=np.float32))[:, None].clip(1e-30)).astype(np.float32)
+    bu = (b / np.sqrt((b * b).sum(1, dtype=np.float32))[:, None].clip(1e-30)).astype(np.float32)
+    assert au.max() <= 1.0
+    _screen_ab(fm, monkeypatch, au, bu, 0.6, 3.5, True)
+    k, s_exact, s_general = shares(au, bu, 0.6, 3.5, True)
+    assert k <= s_exact <= s_general, (k, s_exact, s_general)
+    ahu = (ah / np.sqrt((ah * ah).sum(1, dtype=np.float32))[:, None].clip(1e-30)).astype(np.float32)
+    bhu = (bh / np.sqrt((bh * bh).sum(1, dtype=np.float32))[:, None].clip(1e-30)).astype(np.float32)
+    _screen_ab(fm, monkeypatch, ahu, bhu, 0.6, 3.5, True)
+    k, s_exact, s_general = shares(ahu, bhu, 0.6, 3.5, True)
+    assert k <= s_exact <= s_general, (k, s_exact, s_general)
+    for n2 in (1, 2, 3, 31, 255, 256, 257, 513, 1025):
+        a2, b2, _, _ = planted_pair(rng, 700, n2, min(n2, 200), noise=0.03, unit=False)
+        b2[-1] = a2[5]
+        _screen_ab(fm, monkeypatch, a2, b2, 0.6, 3.5, True)
+        _screen_ab(fm, monkeypatch, a2, b2, 0.9, 0.5, False)
+    # a batch of several sets of unequal sizes through the pooled list pass
+    sets = [planted_pair(rng, 900 + 211 * k, 10, 5, unit=False)[0] for k in range(4)]
+    sets[2][:300] = sets[0][:300]
+    monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
+    pp, ii, jj, met = fm.match_pairwise_csr(sets, 0.6, 3.5, True)
+    assert _exact_jobs(gpu) == (6, 6)
+    p = 0
+    for j in range(1, 4):
+        for i in range(j):
+            om, omet = oracle.match_features(sets[i], sets[j], 0.6, 3.5, True, 2)
+            sl = slice(pp[p], pp[p + 1])
+            assert np.array_equal(np.stack([ii[sl], jj[sl]], 1), om) and np.array_equal(bits(met[sl]), bits(omet)), (i, j)
+            p += 1
+    # one set with a single non-integer entry: general codes for the three jobs it takes part in, same lists
+    sets[1] = sets[1].copy()
+    sets[1][3, 3] += 0.5
+    pp, ii, jj, met = fm.match_pairwise_csr(sets, 0.6, 3.5, True)
+    assert _exact_jobs(gpu) == (6, 3)
+    p = 0
+    for j in range(1, 4):
+        for i in range(j):
+            om, omet = oracle.match_features(sets[i], sets[j], 0.6, 3.5, True, 2)
+            sl = slice(pp[p], pp[p + 1])
+            assert np.array_equal(np.stack([ii[sl], jj[sl]], 1), om) and np.array_equal(bits(met[sl]), bits(omet)), (i, j)
+            p += 1
 
 
 def test_int8_screen_is_off_for_non_finite_sets(fm, monkeypatch):

@@ -2,6 +2,7 @@
 The reference holds no golden vectors for this path, so the oracle is checked against hand-derived
 answers and an independent float64 brute force."""
 import numpy as np
+import pytest
 
 import oracle
 from util import planted_pair, sift_like
@@ -187,3 +188,33 @@ def test_pca2nn_equals_a_numpy_evaluation_of_the_reference_steps():
     # a single B row: the second similarity is max of an all -inf row
     i1, h1, h2 = oracle.pca2nn(A[:3], B[:1], 48, False)
     assert np.all(i1 == 1) and np.all(np.isinf(h2)) and np.all(h2 > 0)
+
+
+@pytest.mark.parametrize("n2", [1, 2, 10, 48, 49])
+def test_pca2nn_with_fewer_rows_than_components(n2):
+    """pca(B - muB, 'NumComponents', 48) returns min(n2 - 1, 48) columns when B has few rows (matchFeaturesScratch.m:481-482;
+    the centred data has rank <= n2 - 1).  The restatement keeps the other columns of the basis at zero; the result must equal
+    a float64 numpy evaluation on the narrower basis (axes of B's null space are not in the reference's basis - they
+    would lengthen every A row and shrink its cosines)."""
+    A, B = _pca_sets(6)
+    B = B[:n2]
+    keep = min(n2 - 1, 48)
+    mu, coeff, _ = oracle.pca_basis(B, 48)
+    assert coeff.shape == (128, 48) and not coeff[:, keep:].any() and (keep == 0 or coeff[:, :keep].any(0).all())
+    idx, d1, d2 = oracle.pca2nn(A, B, 48, True)
+    eps = np.finfo(np.float32).eps
+    Ap, Bp = (A - mu).astype(np.float64) @ coeff[:, :keep], (B - mu).astype(np.float64) @ coeff[:, :keep]
+    Ap /= np.sqrt((Ap * Ap).sum(1, keepdims=True)) + eps
+    Bp /= np.sqrt((Bp * Bp).sum(1, keepdims=True)) + eps
+    G = Ap @ Bp.T
+    s = -np.sort(-G, axis=1)
+    assert np.abs(d1 - (2 - 2 * s[:, 0])).max() < 2e-5
+    if n2 >= 2:
+        assert np.abs(d2 - (2 - 2 * s[:, 1])).max() < 2e-5
+        clear = s[:, 0] - s[:, 1] > 1e-4
+        assert np.array_equal(idx[clear], G.argmax(1)[clear] + 1)
+    else:
+        assert np.all(d1 == 2.0) and np.all(np.isinf(d2))
+    if 2 <= n2 <= 48:
+        # the full-width basis of rounds 1-5 (axes of the null space included) is measurably different: the test would catch it
+        assert np.abs(d1 - 2.0).max() > 0.05
