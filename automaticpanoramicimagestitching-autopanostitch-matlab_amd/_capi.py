@@ -93,6 +93,7 @@ _SIGNATURES = {
     "aps_profile_reset": [],
     "aps_profile_get": [C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
     "aps_profile_names": [C.c_char_p, _i],
+    "aps_profile_series": [C.c_char_p, C.POINTER(_d), _i, C.POINTER(_i)],
     "aps_match_2nn_ssd": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp],
     "aps_match_pca2nn": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "aps_match_features": [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, C.POINTER(aps_match_opts), _vp,
@@ -217,6 +218,13 @@ def profile_get(name: str):
     t, n = C.c_double(0), C.c_int(0)
     check(lib.aps_profile_get(name.encode(), C.byref(t), C.byref(n)))
     return t.value, n.value
+
+
+def profile_series(name: str, cap: int = 4096):
+    """The recorded launches of the named kernel since the last reset, one duration (ms) each, in launch order."""
+    buf, n = (C.c_double * cap)(), C.c_int(0)
+    check(lib.aps_profile_series(name.encode(), buf, cap, C.byref(n)))
+    return [buf[k] for k in range(min(n.value, cap))]
 
 
 def profile_all():

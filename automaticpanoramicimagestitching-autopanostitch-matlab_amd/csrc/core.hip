@@ -323,6 +323,26 @@ int aps_profile_get(const char* name, double* total_ms, int* launches) {
     });
 }
 
+int aps_profile_series(const char* name, double* ms, int cap, int* count) {
+    return guarded([&] {
+        APS_REQUIRE(name && count && cap >= 0 && (cap == 0 || ms), APS_E_ARG, "bad argument");
+        ctx();
+        APS_HIP(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        int n = 0;
+        for (auto& r : g_prof)
+            if (std::strcmp(r.name, name) == 0) {
+                if (n < cap) {
+                    float t = 0;
+                    APS_HIP(hipEventElapsedTime(&t, r.a, r.b));
+                    ms[n] = t;
+                }
+                ++n;
+            }
+        *count = n;
+    });
+}
+
 int aps_profile_names(char* buf, int buf_len) {
     return guarded([&] {
         APS_REQUIRE(buf && buf_len > 0, APS_E_ARG, "bad buffer");

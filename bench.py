@@ -58,7 +58,8 @@ def csrc_sha256():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when launched by torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=str, default=f"{NX}x{NY}", help="views as NXxNY (default 8x8 = 64)")
@@ -193,6 +194,74 @@ def cpu_cfg1_single_thread(synth):
                       f"planar-scan composite {ow}x{oh} with a 3-band blend; oracle, one thread"}
 
 
+class GpuStateSampler:
+    """Clock and power of THIS rank's GPU while a step runs, read from the amdgpu driver's hwmon files (plain file reads from a
+    host thread: no other program is started, no GPU API is touched - a process that has initialised the GPU must not exec).
+    The chip is power-limited under the dense int8 stream of the matching stage (1.9-2.0 GHz of 2.4), so two boxes that read
+    3 % apart can be told apart by the clock they held.  Nothing here is inside the timed region."""
+
+    def __init__(self, device_index):
+        self.files, self.samples, self._stop, self._thr = None, [], False, None
+        try:
+            want = self._pci_of(device_index)
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                if "-" in os.path.basename(card):
+                    continue
+                pci = os.path.basename(os.path.realpath(os.path.join(card, "device"))).lower()
+                fr = glob.glob(os.path.join(card, "device", "hwmon", "hwmon*", "freq1_input"))
+                pw = glob.glob(os.path.join(card, "device", "hwmon", "hwmon*", "power1_input")) or \
+                    glob.glob(os.path.join(card, "device", "hwmon", "hwmon*", "power1_average"))
+                if fr and pw and (want is None or pci == want):
+                    self.files = (fr[0], pw[0], pci)
+                    if want is not None:
+                        break
+            if want is None:
+                self.files = None  # several cards and no way to tell which one is ours
+        except Exception:
+            self.files = None
+
+    @staticmethod
+    def _pci_of(device_index):
+        import ctypes
+
+        buf = ctypes.create_string_buffer(64)
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                if ctypes.CDLL(name).hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+                    return buf.value.decode().lower()
+            except OSError:
+                continue
+        return None
+
+    def _run(self):
+        fr, pw, _ = self.files
+        while not self._stop:
+            try:
+                self.samples.append((time.perf_counter(), int(open(fr).read()) / 1e6, int(open(pw).read()) / 1e6))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.002)
+
+    def start(self):
+        if self.files:
+            import threading
+
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr:
+            self._thr.join()
+
+    def window(self, t_a, t_b):
+        sel = [(f, p) for t, f, p in self.samples if t_a <= t <= t_b]
+        if not sel:
+            return None
+        return {"sclk_mhz_median": round(float(np.median([f for f, _ in sel])), 0), "sclk_mhz_min": round(min(f for f, _ in sel), 0),
+                "power_w_median": round(float(np.median([p for _, p in sel])), 0), "samples": len(sel)}
+
+
 def sift_standalone_probe(pl, capi, input_, image):
     """One view through the extraction on ONE stream, its launch sites bracketed by HIP events (outside the timed region): the
     kernels' stand-alone times.  In the timed steps ten streams run side by side and the event intervals of a launch site
@@ -283,7 +352,9 @@ def launch_ranks(n_gpus, argv):
     GPU must not exec, and this one only waits), relays rank 0's single JSON line and returns the child's exit code."""
     import subprocess
 
-    have = torch.cuda.device_count()  # (counting devices does not initialise the runtime)
+    # (device_count() may call hipGetDeviceCount on this image; that is harmless HERE because this process never execs - it
+    # starts the ranks as a CHILD and waits.  Keep it that way: no os.exec* below this line.)
+    have = torch.cuda.device_count()
     if os.environ.get("APS_BENCH_RANK_PROBE") != "1" and os.environ.get("APS_BENCH_REHEARSE") != "1" and have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s)", file=sys.stderr)
         return 2
@@ -328,11 +399,14 @@ def main():
 
         faulthandler.dump_traceback_later(int(os.environ["APS_BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    if args.gpus is None:  # (not given: a launcher's WORLD_SIZE decides, a plain run is one GPU)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     # `--gpus N` is what decides the rank count.  Launched by torch.distributed.run (the driver's form for N > 1) the
     # environment carries WORLD_SIZE, which must agree; launched plainly with N > 1 the ranks are started here as children.
     if "WORLD_SIZE" in os.environ:
         if int(os.environ["WORLD_SIZE"]) != args.gpus:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} ranks were launched", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} ranks were launched: pass --gpus "
+                  f"{os.environ['WORLD_SIZE']} (or leave --gpus out) under this launcher", file=sys.stderr)
             sys.exit(2)
     elif args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -515,6 +589,25 @@ def main():
             barrier()
             warm_prof, warm_steps = capi.profile_all(), 1
             capi.profile_enable(False)
+    # the GPU's clock and power during one more untimed step, by stage (GpuStateSampler; rank 0 reports its own GPU)
+    gpu_state = None
+    if args.warmup > 0:  # (every rank takes the step: it runs the sharded driver's collectives)
+        sampler = GpuStateSampler(local_rank)
+        sampler.start()
+        t_s0 = time.perf_counter()
+        _, info_s = step(sync_download=True)
+        barrier()
+        sampler.stop()
+        if sampler.files and rank == 0:
+            tm = info_s["times"]
+            t_f = t_s0 + tm.get("features", 0.0) + tm.get("exchange", 0.0)
+            t_m = t_f + tm.get("matching", 0.0)
+            gpu_state = {"source": "amdgpu hwmon freq1_input / power1_input of " + sampler.files[2] + ", one untimed step, 2 ms sampling",
+                         "features": sampler.window(t_s0 + 0.1 * (t_f - t_s0), t_f - 0.1 * (t_f - t_s0)),
+                         "matching_screen": sampler.window(t_f + 0.05 * (t_m - t_f), t_f + 0.75 * (t_m - t_f)),
+                         "render": sampler.window(t_s0 + info_s["t_stitch"] - tm.get("render", 0.0), t_s0 + info_s["t_stitch"])}
+        elif rank == 0:
+            gpu_state = {"source": None, "note": "no readable amdgpu hwmon files for this rank's GPU"}
     # the un-overlapped cost of one panorama copy (both pinned buffers exist by now): three synchronous copies of a
     # canvas-sized device buffer, the fastest counts
     if rank == 0 and args.warmup > 0 and pano_w is not None and pano_w.numel():
@@ -529,7 +622,7 @@ def main():
     capi.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    infos = []
+    infos, marks = [], []
     for _ in range(args.steps):
         pano, info = step()
         # keep the step's numbers, not its panoramas: a list that pins every step's 737 MB output makes each step
@@ -537,9 +630,14 @@ def main():
         # bench's bookkeeping, not of a stitch.  The current panorama stays alive until the next one replaces it.
         info.pop("panoramas", None)
         infos.append(info)
+        marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    # wall time of each timed step (start of step k to start of step k + 1; the last one ends at the closing barrier, which
+    # includes the last panorama's copy): their mean is ms_per_step, the median and the minimum make a 2 ms change visible
+    step_walls = [b - a for a, b in zip([t0] + marks[:-1], marks[:-1] + [t0 + dt])]
     prof = capi.profile_all()
+    screen_series = capi.profile_series("match_screen_i8")
     capi.profile_enable(False)
     # The same steps with input.gainCompensation = 1 (the reference's default, PP/inputs.m:94; renderPanorama.m:303-330): the
     # overlap statistics on the device (gain_stats_kernel), the N x N x 3 sums back to the host, the host solve, the gains into
@@ -728,6 +826,13 @@ def main():
                  16.0 * a_cov + 3.0 * npix_rank0, HBM_PEAK_GBS, "GB/s"),
         ]
         cands = [c for c in cands if c]
+        # the dominant kernel launch by launch (one per step): median and minimum beside the mean
+        if screen_series and cands and cands[0]["kernel"].startswith("match_screen"):
+            n_l = max(1, len(screen_series) // max(args.steps, 1))
+            per = [sum(screen_series[k * n_l:(k + 1) * n_l]) for k in range(len(screen_series) // n_l)]
+            cands[0]["ms_per_step_median"] = round(float(np.median(per)), 3)
+            cands[0]["ms_per_step_min"] = round(float(min(per)), 3)
+            cands[0]["frac_median"] = round(flops_rank0 / (float(np.median(per)) * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4)
         for c_ in cands:  # every entry carries both fractions: the algorithmic one and the one on the bytes the memory system moved
             c_.setdefault("frac_measured_bytes", None)
         dominant = max(cands, key=lambda c: c["wall_share_ms"]) if cands else None
@@ -750,18 +855,32 @@ def main():
                                   "not stored here, so `traffic` (bytes per STEP for this entry, all SIFT kernels) is lower; "
                                   "achieved_measured_bytes = traffic / stage wall time"})
         stages = {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in infos[-1]["times"]}
+        # the descriptor-distance path as a STAGE (preparation, screen, list pass, fallback, filter and their gaps): the same
+        # algorithmic 2*128*Ni*Nj over the stage's wall time, beside the dominant kernel's own fraction
+        t_match = sum(i["times"].get("matching", 0.0) for i in infos) / len(infos)
+        matching_stage = None
+        if t_match > 0 and args.matcher == "pairwise":
+            matching_stage = {"ms_per_step": round(1e3 * t_match, 3), "achieved": round(flops_rank0 / t_match / 1e12, 2), "peak": MFMA_I8_PEAK_TOPS,
+                              "unit": "TOP/s", "frac": round(flops_rank0 / t_match / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                              "kernels_ms": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if k.startswith("match")},
+                              "note": "wall time of the matching stage (host phases and read-backs included) against the int8 peak"}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 3), "launches_per_step": v[1] // max(args.steps, 1)}
                    for k, v in prof.items()}
         out = {
             "metric": "MPix/s end-to-end stitch (SIFT->blend), 64x4K images",
             "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step_median": round(1e3 * float(np.median(step_walls)), 2), "ms_per_step_min": round(1e3 * min(step_walls), 2),
+            "ms_per_step_series": [round(1e3 * x, 2) for x in step_walls],
             # `value`: inputs resident in HBM when the timed region starts -> cropped uint8 panorama in pinned HOST memory.
             # value_end_to_end: pinned host uint8 images -> the same (PCIe both ways; SURVEY 8(d)'s "first byte uploaded").
             # value_resident: the same steps as `value` without the device-to-host copy of the panorama.
-            "value_definition": "bench contract: inputs resident in HBM when the timed region starts -> cropped uint8 panorama in pinned "
-                                "host memory; SURVEY 8(d)'s clock (first byte uploaded -> panorama on the host) is value_end_to_end, "
-                                "the reference's default gainCompensation = 1 is value_with_gain",
+            "value_definition": "`value` follows the build contract of this bench line (\"whole-job throughput with inputs already resident "
+                                "in HBM when the timed region starts; if the boundary hands over host buffers, the PCIe-inclusive rate is "
+                                "noted elsewhere - it is never `value`\"): resident uint8 views -> cropped uint8 panorama in pinned host "
+                                "memory.  BASELINE.md section 2 / SURVEY 8(d)'s clock (first input byte in pinned host memory -> final "
+                                "panorama in host memory) is value_end_to_end / ms_per_step_end_to_end in this same line, 0.3-0.6 % "
+                                "apart (both transfers overlap device work); the reference's default gainCompensation = 1 is value_with_gain",
             "value_end_to_end": round(mpix_in * args.steps / dt_e2e, 2) if dt_e2e else None,
             "ms_per_step_end_to_end": round(1e3 * dt_e2e / args.steps, 2) if dt_e2e else None,
             "value_with_gain": round(mpix_in * args.steps / dt_gain, 2) if dt_gain else None,
@@ -787,7 +906,7 @@ def main():
                 "int8_screen_survivor_share": round(surv_share, 4) if scr_rows.value else None,
                 "panorama": [int(pano.shape[1]), int(pano.shape[0])], "parallelism": f"{world} rank(s), images/pairs/tiles sharded",
             },
-            "roofline": dominant, "rooflines_all": cands,
+            "roofline": dominant, "rooflines_all": cands, "matching_stage": matching_stage, "gpu_state": gpu_state,
             "stages_ms_per_step": stages,
             # the same stages in the end-to-end steps; "download" = everything outside stitch_distributed (queueing the
             # uploads, the device-to-host copy of the cropped panorama and the final synchronisation)

@@ -91,6 +91,9 @@ int aps_timer_end(float* ms);
 int aps_profile_enable(int on);
 int aps_profile_reset(void);
 int aps_profile_get(const char* name, double* total_ms, int* launches);
+/* The recorded launches of `name` one by one, in launch order: ms[0 .. min(*count, cap) - 1]; *count = how many there are.
+ * (bench.py: the dominant kernel's duration per step - its median and minimum, not only the mean.) */
+int aps_profile_series(const char* name, double* ms, int cap, int* count);
 /* Writes a ';'-separated list of the kernel names recorded since the last reset into buf. */
 int aps_profile_names(char* buf, int buf_len);
 

@@ -6,12 +6,20 @@ function [panorama, rgbAnnotation] = renderPanorama(input, images, imgSize, came
     %   (:430-432, cropNonzeroBbox) is a device reduction.  Gain compensation still runs the reference's own
     %   gainCompensationRKf (host solve) when opts.gainCompensation is set.
     %   Deliberate differences: opts.tile defaults to [2048 2048] clamped to the canvas (the reference derives it from free
-    %   memory, :269-298, which makes its multiband output machine dependent); rgbAnnotation is always [] (insertShape /
-    %   insertText overlays are display code).
+    %   memory, :269-298, which makes its multiband output machine dependent).
+    %   rgbAnnotation (the panorama with every image's warped outline and number drawn in, :438-477 and :653-679, which
+    %   displayPanorama.m:126-136 stores) exists only when opts.showPanoramaImgsNums && opts.showCropBoundingBox: such a call
+    %   is a debugging display and is forwarded whole to the reference's own file (aps_call_shadowed), whose local
+    %   allWarpedBoxes / insertShape / insertText code draws it - like the display switches of the other shadows.
     if nargin < 7, opts = struct(); end
+    if isfield(opts, 'showPanoramaImgsNums') && isfield(opts, 'showCropBoundingBox') && ...
+            all(logical(opts.showPanoramaImgsNums)) && all(logical(opts.showCropBoundingBox))
+        [panorama, rgbAnnotation] = aps_call_shadowed('renderPanorama', mfilename('fullpath'), input, images, imgSize, cameras, mode, refIdx, opts);
+        return
+    end
     opts = fillDefaults(opts, cameras, refIdx);
     numImages = numel(images);
-    rgbAnnotation = [];
+    rgbAnnotation = [];   % (:75, the reference's value when the two switches are not both set)
     if cameras(1).noRotation == 1 || (isfield(input, 'forcePlanarScan') && input.forcePlanarScan)
         panorama = planarScanPanorama(images, cameras, numImages, opts);   % :519-699 over the imageWarp shadow
         return

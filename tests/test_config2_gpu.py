@@ -51,6 +51,33 @@ def test_sift_of_4k_views_is_bit_identical_to_the_oracle(features):
     assert len(features) == 4
 
 
+@pytest.mark.parametrize("view", [0, 59])  # the grid's first corner (row 0, column 0) and an edge view (row 7, column 3)
+def test_sift_of_a_corner_and_an_edge_view_is_bit_identical_to_the_oracle(gpu, view):
+    """Round 6: the views at the rim of the 8 x 8 grid look at the world's poles / its seam and differ in content statistics
+    (stretch of the texture, keypoint density per octave) from the centre block above.  Same comparison: descriptors, locations,
+    (octave, layer, scale, angle), bit for bit; and the pair (corner, its right neighbour) through the matcher."""
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    fm = import_module(gpu.__name__ + ".featureMatching")
+    inp = import_module(gpu.__name__ + ".pipeline").default_input()
+    cams = synth.grid_cameras(NX, NY, W, H, F, 2 * np.arctan(W / (2 * F)) * (1 - OVERLAP),
+                              2 * np.arctan(H / (2 * F)) * (1 - OVERLAP), 1.0, SEED)
+    img = synth.render_view(cams[view], H, W, SEED, "cuda", finest_px=FINEST)
+    torch.cuda.synchronize()
+    img = img.cpu().numpy()
+    f, pts, aux = fm.sift_extract(inp, img, want_aux=True)
+    od, ol, oa = oracle.sift(img, inp["Sigma"], inp["NumLayersInOctave"], inp["ContrastThreshold"], inp["EdgeThreshold"])
+    assert f.shape == od.shape and f.shape[0] > 5000, (f.shape, od.shape)
+    assert np.array_equal(bits(f), bits(od)) and np.array_equal(bits(pts), bits(ol)) and np.array_equal(bits(aux), bits(oa))
+    if view == 0:
+        img2 = synth.render_view(cams[1], H, W, SEED, "cuda", finest_px=FINEST).cpu().numpy()
+        f2, _ = fm.sift_extract(inp, img2)
+        m, met = fm.matchFeaturesScratch(f, f2, MatchThreshold=inp["Matchingthreshold"], MaxRatio=inp["Ratiothreshold"])
+        om, omet = oracle.match_features(f, f2, inp["Ratiothreshold"], inp["Matchingthreshold"], True, 2)
+        assert len(om) > 500 and np.array_equal(m, om) and np.array_equal(bits(met), bits(omet))
+
+
 def test_six_pairs_match_lists_and_ransac_models_equal_the_oracle(gpu, features):
     fm = import_module(gpu.__name__ + ".featureMatching")
     im = import_module(gpu.__name__ + ".imageMatching")

@@ -140,6 +140,32 @@ def test_bench_scale_matching_screen_on_equals_screen_off(gpu, mods, monkeypatch
     monkeypatch.delenv("APS_MATCH_NO_SCREEN", raising=False)
     assert np.array_equal(pp, pp0) and int(pp[-1]) > 100000
     assert bool(torch.equal(ia, ia0)) and bool(torch.equal(ib, ib0)) and bool(torch.equal(met.view(torch.int32), met0.view(torch.int32)))
+    del pp0, ia0, ib0, met0
+    # round 6, the last hop of the chain at this scale: the all-f32 kernel (v_mfma_f32_32x32x2_f32 = the k-ascending fma chain of
+    # the contract, the kernel the small-size tests pin to the oracle) on EVERY row of all 2016 pairs - same pair offsets, both
+    # index lists, the metric's bits
+    monkeypatch.setenv("APS_MATCH_MODE", "f32")
+    pp3, ia3, ib3, met3 = fm.match_pairs_csr(descs, order, 0.6, 1.5, True, device_out=True)
+    monkeypatch.delenv("APS_MATCH_MODE", raising=False)
+    assert np.array_equal(pp, pp3)
+    assert bool(torch.equal(ia, ia3)) and bool(torch.equal(ib, ib3)) and bool(torch.equal(met.view(torch.int32), met3.view(torch.int32)))
+    del pp3, ia3, ib3, met3
+    # round 6: the SIFT stage's descriptors are integers over their norm, so every job ran on exact int8 codes; with the
+    # general codes (APS_MATCH_NO_EXACT=1) more rows survive the screen and the lists are the same
+    jobs, exact = ctypes.c_int64(0), ctypes.c_int64(0)
+    monkeypatch.setenv("APS_MATCH_NO_EXACT", "1")
+    pp4, ia4, ib4, met4 = fm.match_pairs_csr(descs, order, 0.6, 1.5, True, device_out=True)
+    monkeypatch.delenv("APS_MATCH_NO_EXACT", raising=False)
+    rows4, surv4 = ctypes.c_int64(0), ctypes.c_int64(0)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_stats(ctypes.byref(rows4), ctypes.byref(surv4)))
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_exact_jobs(ctypes.byref(jobs), ctypes.byref(exact)))
+    assert (jobs.value, exact.value) == (len(order), 0) and surv.value < 0.7 * surv4.value
+    assert np.array_equal(pp, pp4) and bool(torch.equal(ia, ia4)) and bool(torch.equal(ib, ib4))
+    assert bool(torch.equal(met.view(torch.int32), met4.view(torch.int32)))
+    del pp4, ia4, ib4, met4
+    fm.match_pairs_csr(descs[:8], fm.pair_order(8), 0.6, 1.5, True, device_out=True)
+    gpu._capi.check(gpu._capi.lib.aps_match_screen_exact_jobs(ctypes.byref(jobs), ctypes.byref(exact)))
+    assert (jobs.value, exact.value) == (28, 28)
     # the screening pass on the other MFMA shape (v_mfma_i32_32x32x32_i8, rounds 2-3; the default is 16x16x64): its groups of
     # columns differ, so its survivor set may differ by a few rows - the lists may not
     monkeypatch.setenv("APS_SCREEN_SHAPE", "32")
@@ -147,7 +173,7 @@ def test_bench_scale_matching_screen_on_equals_screen_off(gpu, mods, monkeypatch
     monkeypatch.delenv("APS_SCREEN_SHAPE", raising=False)
     rows2, surv2 = ctypes.c_int64(0), ctypes.c_int64(0)
     gpu._capi.check(gpu._capi.lib.aps_match_screen_stats(ctypes.byref(rows2), ctypes.byref(surv2)))
-    assert rows2.value == rows.value and abs(surv2.value - surv.value) < 0.01 * surv.value
+    assert rows2.value == rows.value and abs(surv2.value - surv4.value) < 0.01 * surv4.value  # (this shape runs the general codes)
     assert np.array_equal(pp, pp2) and bool(torch.equal(ia, ia2)) and bool(torch.equal(ib, ib2))
     assert bool(torch.equal(met.view(torch.int32), met2.view(torch.int32)))
     # one-to-one per pair: within a pair's segment no column index repeats

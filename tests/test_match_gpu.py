@@ -674,7 +674,7 @@ def test_int8_screen_exact_integer_codes(fm, gpu, monkeypatch):
             p += 1
     # one set with a single non-integer entry: general codes for the three jobs it takes part in, same lists
     sets[1] = sets[1].copy()
-    sets[1][3, 3] += 0.5
+    sets[1][3, 3] += 0.3
     pp, ii, jj, met = fm.match_pairwise_csr(sets, 0.6, 3.5, True)
     assert _exact_jobs(gpu) == (6, 3)
     p = 0

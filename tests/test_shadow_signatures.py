@@ -113,6 +113,21 @@ def test_forwarding_calls_keep_the_argument_order():
             assert passed == ins[:len(passed)] and len(passed) >= len([a for a in ins if a != "varargin"]) - 1, (f, passed, ins)
 
 
+def test_render_shadow_forwards_the_annotation_call_to_the_reference():
+    """rgbAnnotation is filled only when opts.showPanoramaImgsNums && opts.showCropBoundingBox (renderPanorama.m:438-477,
+    653-679; displayPanorama.m:126-136 stores it): the shadow must hand exactly that case, with both outputs and all seven
+    inputs, to the reference's own file, and must do so BEFORE any device work."""
+    text = re.sub(r"\.\.\.[^\n]*\n", " ", open(os.path.join(MATLAB, "renderPanorama.m")).read())
+    text = "\n".join(l for l in text.split("\n") if not l.lstrip().startswith("%"))
+    fwd = text.index("aps_call_shadowed('renderPanorama'")
+    guard = text.rfind("if ", 0, fwd)
+    cond = text[guard:fwd]
+    assert "showPanoramaImgsNums" in cond and "showCropBoundingBox" in cond and "isfield" in cond
+    assert re.search(r"\[panorama,\s*rgbAnnotation\]\s*=\s*aps_call_shadowed\('renderPanorama',\s*mfilename\('fullpath'\),\s*input,\s*images,\s*"
+                     r"imgSize,\s*cameras,\s*mode,\s*refIdx,\s*opts\);\s*return", text)
+    assert fwd < text.index("aps_mex(") and fwd < text.index("fillDefaults(opts")
+
+
 def split_args(s):
     """Top-level comma split of a MATLAB argument list (strings, (), [], {} respected)."""
     out, depth, cur, i, in_str = [], 0, "", 0, False
