@@ -84,6 +84,13 @@ def parse():
     ap.add_argument("--with-gain", choices=["auto", "off"], default="auto",
                     help="after the timed steps, time the same steps with input.gainCompensation = 1 (the reference's default, "
                          "PP/inputs.m:94); reported as value_with_gain")
+    ap.add_argument("--config", type=int, choices=[0, 1, 3, 4], default=None,
+                    help="one of the OTHER BASELINE.json configs on one GPU, as its own JSON line with roofline / cpu_baseline / stages "
+                         "(the default invocation is configs[2], the headline): 0 = two-view planar homography stitch, 1 = 20-view ring "
+                         "(Grand-Canyon-sized set, spherical, 3 bands), 3 = the 256 x 4K image set, 4 = 500 mixed 2K views -> six "
+                         "equirectangular panoramas; synthetic realisations of BASELINE.md section 2 / SURVEY 8(d)")
+    ap.add_argument("--reference-defaults", action="store_true",
+                    help="with --config 1: the reference's default switches (PP/inputs.m:46,94,99-101): global matcher, gain compensation on, 3 bands")
     ap.add_argument("--gain-compensation", action="store_true",
                     help="also run gainCompensationRKf (device overlap statistics + host solve) before the render; "
                          "off in the headline configuration, which follows BASELINE.json configs[2]")
@@ -334,6 +341,235 @@ def global_matcher_probe(pl, capi, input_, images):
     }
 
 
+def cpu_sample(synth, input_, w, h, f, overlap, finest, bands, mode, seed, n_views, n_pairs, n_cand, pano_area):
+    """The oracle chain (C + OpenMP port) on a 2 x 2 block of a config's own views, and the whole config modelled from its
+    pieces (SIFT by views, exhaustive matching by pairs, RANSAC by candidate pairs, render by canvas area)."""
+    import oracle
+    import apsamd
+    from importlib import import_module
+
+    imgs, cams = synth.make_scene(2, 2, w, h, f, overlap, seed=seed, device="cuda", finest_px=finest)
+    imgs = [i.cpu().numpy() for i in imgs]
+    t0 = time.perf_counter()
+    feats = [oracle.sift(im, input_["Sigma"], input_["NumLayersInOctave"], input_["ContrastThreshold"], input_["EdgeThreshold"]) for im in imgs]
+    t_sift = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    matches = {(i, j): oracle.match_features(feats[i][0], feats[j][0], input_["Ratiothreshold"], input_["Matchingthreshold"], True, 2)[0]
+               for j in range(1, 4) for i in range(j)}
+    t_match = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(0)
+    for (i, j), m in matches.items():
+        if len(m) >= 4:
+            smp = np.stack([rng.permutation(len(m))[:4] + 1 for _ in range(564)]).astype(np.uint32)
+            oracle.ransac_homography(feats[j][1][m[:, 1] - 1], feats[i][1][m[:, 0] - 1], smp, input_["maxDistance"], input_["inliersConfidence"], input_["maxIter"])
+    t_ransac = time.perf_counter() - t0
+    rp = import_module(apsamd.__name__ + ".renderPanorama")
+    sizes = [(h, w, 3)] * 4
+    geo = rp.canvas_geometry(cams, sizes, mode, 0, rp.default_opts({"anglePower": 2}, cams, 0))
+    t0 = time.perf_counter()
+    oracle.render(imgs, cams, geo, (2048, 2048), 2.0, "multiband", bands, 1.0)
+    t_render = time.perf_counter() - t0
+    total = t_sift + t_match + t_ransac + t_render
+    ratio = pano_area / float(geo["W"] * geo["H"])
+    t_all = (n_views / 4.0) * t_sift + (n_pairs / 6.0) * t_match + (n_cand / 6.0) * t_ransac + ratio * t_render
+    mp = 4 * w * h / 1e6
+    return {"value": round(mp / total, 3), "unit": "MPix/s", "cores": int(oracle.NUM_THREADS), "kind": "port",
+            "sample": f"2x2 block of this config's {w}x{h} views ({mp:.1f} MPix in): oracle SIFT x4 ({t_sift:.1f}s), 6 pairs exhaustive match "
+                      f"({t_match:.1f}s), RANSAC ({t_ransac:.1f}s), {mode} render + {bands}-band blend of {geo['W']}x{geo['H']} ({t_render:.1f}s)",
+            "modelled_whole_config": {"value": round(n_views * w * h / 1e6 / t_all, 3), "unit": "MPix/s", "seconds": round(t_all, 1),
+                                      "how": f"{n_views}/4 x SIFT + {n_pairs}/6 x match + {n_cand}/6 x RANSAC + {ratio:.1f} x render of the sample"}}
+
+
+def run_config(args):
+    """`bench.py --config N`: BASELINE.json configs[N] (N != 2) on ONE GPU - the same contract as the headline line (W warm-up
+    steps, K timed steps between device synchronisations, inputs resident in HBM, ONE JSON line with roofline / cpu_baseline /
+    stages), on the synthetic realisations tests/test_config0_gpu.py, test_config1_gpu.py and test_fullsize_gpu.py stitch."""
+    import ctypes
+    import apsamd
+    from importlib import import_module
+
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(0)
+    capi = apsamd._capi
+    capi.check(capi.lib.aps_set_device(0))
+    synth = import_module(apsamd.__name__ + ".synth")
+    pl = import_module(apsamd.__name__ + ".pipeline")
+    par = import_module(apsamd.__name__ + ".parallel")
+    fm = import_module(apsamd.__name__ + ".featureMatching")
+    im = import_module(apsamd.__name__ + ".imageMatching")
+    rp = import_module(apsamd.__name__ + ".renderPanorama")
+    cfg, ref = args.config, bool(args.reference_defaults)
+    if cfg == 0:
+        w, h, f, name = 1024, 768, 1100.0, "BASELINE.json configs[0]: two 1024x768 views related by a homography, SIFT -> exhaustive match -> RANSAC -> planar-scan composite (host-orchestrated over the device imageWarp / multiband operators), 3 bands"
+        views, cams = synth.make_scene(2, 1, w, h, f, 0.55, seed=77, device="cuda", finest_px=4.0)
+        input_ = pl.default_input(bands=3)
+        mode = "planar"
+    elif cfg == 1:
+        w, h, f = 1600, 1200, 1400.0
+        views, cams = synth.make_scene(10, 2, w, h, f, 0.35, seed=2024, device="cuda", finest_px=4.0)
+        input_ = pl.default_input(bands=3)
+        if ref:
+            input_.update(matchFeaturesPairwise=0, k=4, gainCompensation=1)
+        name = ("BASELINE.json configs[1]: 20 views of 1600x1200 (10x2 ring, f=1400, 35% overlap), spherical, 3-band multiband" +
+                (", the reference's default switches (global matcher k=4, gain compensation on; PP/inputs.m:46,94,99-101)" if ref else ", all-pairs exhaustive matcher"))
+        mode = "spherical"
+    elif cfg == 3:
+        w, h, f = W, H, FOCAL
+        cams = synth.grid_cameras(32, 8, w, h, f, np.radians(11.25), np.radians(9.2), 1.0, 12345)
+        views = [synth.render_view(c, h, w, 12345, "cuda", finest_px=FINEST_PX) for c in cams]
+        input_ = pl.default_input(bands=5)
+        name = "BASELINE.json configs[3]'s image set on ONE GPU: 256 views of 3840x2160 (32x8 full ring, f=8000), all 32640 pairs, spherical, 5 bands (the 8-GPU sharding needs the node)"
+        mode = "spherical"
+    else:
+        w, h, f = 2048, 1080, 2400.0
+        fov_x = 2 * np.arctan(w / (2 * f))
+        worlds = [(10, 6, 0.40), (10, 7, 0.40), (10, 8, 0.40), (10, 9, 0.45), (19, 5, 1.0 - (2 * np.pi / 19) / fov_x), (15, 7, 0.45)]
+        views, cams = [], []
+        for wi, (nx_, ny_, ov) in enumerate(worlds):
+            v_, c_ = synth.make_scene(nx_, ny_, w, h, f, ov, seed=1000 + 17 * wi, device="cuda", finest_px=10.0)
+            views += v_
+            cams += c_
+        perm = np.random.default_rng(9).permutation(len(views))
+        views, cams = [views[k] for k in perm], [cams[k] for k in perm]
+        input_ = pl.default_input(bands=5, panorama2DisplaynSave="equirectangular")
+        name = "BASELINE.json configs[4] on ONE GPU: 500 mixed 2048x1080 views of six worlds, all 124750 pairs -> connected components -> six equirectangular panoramas, 5 bands"
+        mode = "equirectangular"
+    torch.cuda.synchronize()
+    n = len(views)
+    Ks = [c["K"] for c in cams]
+    local = dict(enumerate(views))
+    views_host = [v.cpu().numpy() for v in views] if cfg == 0 else None
+
+    def sync():
+        capi.check(capi.lib.aps_synchronize())
+        torch.cuda.synchronize()
+
+    def step():
+        t_s = time.perf_counter()
+        if cfg == 0:
+            times = pl.StageTimes()
+            t0 = time.perf_counter()
+            feats = pl.sift_many(input_, views)
+            times.add("features", t0)
+            t0 = time.perf_counter()
+            cells = fm.featureMatchingPairwise(input_, [d for d, _ in feats], 2)
+            times.add("matching", t0)
+            t0 = time.perf_counter()
+            m = cells[0][1].astype(np.int64)
+            p1, p2 = np.asarray(feats[0][1])[m[:, 0] - 1].astype(np.float64), np.asarray(feats[1][1])[m[:, 1] - 1].astype(np.float64)
+            Hm, mask, found = im.estimateTransformationRANSAC(p2, p1, "projective", input_, sample_idx=im.draw_samples([len(m)], 564, seed=11)[0])
+            times.add("im_ransac", t0)
+            if not found:
+                raise RuntimeError("configs[0]: the pair was not verified")
+            t0 = time.perf_counter()
+            pcams = [{"H2refined": np.eye(3), "noRotation": 1}, {"H2refined": Hm / Hm[2, 2], "noRotation": 1}]
+            # (the planar-scan path, renderPanorama.m:519-699, is host-orchestrated like the reference's: numpy canvases
+            # over the device imageWarp / multiBandBlending operators; it takes the views from host memory)
+            pano_, _ = rp.renderPanorama(input_, views_host, [(h, w, 3)] * 2, pcams, "planar", 0,
+                                         {"blending": "multiband", "pyrLevels": 3, "pyrSigma": 1.0, "canvasColor": "black"})
+            pano_ = torch.from_numpy(np.ascontiguousarray(pano_))
+            times.add("render", t0)
+            info_ = {"times": dict(times), "n_features": [int(d.shape[0]) for d, _ in feats], "n_pairs_verified": 1, "panoramas": [pano_], "n_components": 1}
+        else:
+            pano_, info_ = par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, None, pano_root=0)
+        sync()
+        info_["t_step"] = time.perf_counter() - t_s
+        return pano_, info_
+
+    warm_prof = {}
+    n_warm = max(args.warmup, 2)  # (the per-image / per-tile launch sites are bracketed in the LAST warm-up step: never the process's first step)
+    for k in range(n_warm):
+        last = k == n_warm - 1
+        if last:
+            capi.profile_enable(1)
+            capi.profile_reset()
+        pano, info = step()
+        if last:
+            warm_prof = capi.profile_all()
+            capi.profile_enable(False)
+    capi.profile_enable(2)
+    capi.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(args.steps):
+        pano, info = step()
+        shapes = [tuple(int(v) for v in p_.shape) for p_ in info.get("panoramas", [pano])]
+        info.pop("panoramas", None)
+        info["shapes"] = shapes
+        infos.append(info)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = {k: (v[0], v[1]) for k, v in capi.profile_all().items()}
+    live = set(prof)
+    capi.profile_enable(False)
+    for k, v in warm_prof.items():
+        if k not in prof:
+            prof[k] = (v[0] * args.steps, v[1] * args.steps)
+    info = infos[-1]
+    counts = info["n_features"]
+    mpix_in = n * w * h / 1e6
+    walls = [i["t_step"] for i in infos]
+    Fsum = float(sum(counts))
+    pair_w = sum(float(counts[i]) * float(counts[j]) for j in range(1, n) for i in range(j))
+    glob = not input_.get("matchFeaturesPairwise", 1)
+    flops = 2.0 * 128.0 * ((Fsum * Fsum - sum(float(c) ** 2 for c in counts)) if glob else pair_w)
+    a_cov = float(n * w * h)
+    a_pano = float(sum(s_[0] * s_[1] for s_ in info["shapes"]))
+
+    def roof(keys, name_, bound, work, peak, unit):
+        ms = sum(prof.get(k, (0.0, 0))[0] for k in keys)
+        if ms <= 0:
+            return None
+        scale = 1e12 if unit in ("TFLOP/s", "TOP/s") else 1e9
+        ach = work * args.steps / (ms * 1e-3) / scale
+        return {"bound": bound, "kernel": name_, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                "algorithmic_work_per_step": work, "ms_per_step": round(ms / args.steps, 3),
+                "launches_per_step": sum(prof.get(k, (0.0, 0))[1] for k in keys) // max(args.steps, 1),
+                "timed": "live over the timed steps" if keys[0] in live else "during the last warm-up step"}
+
+    cands = [roof(["match_screen_i8_bounds"] if glob else ["match_screen_i8"], "match_screen_i8x16_kernel (int8 proof pass" + (", bounds form of the pooled matcher)" if glob else ")"),
+                  "mfma", flops, MFMA_I8_PEAK_TOPS, "TOP/s"),
+             roof(["render_pyr_down", "render_collapse"], "multiband chain (rw_down_fused x levels, rw_up x levels incl. paint)", "hbm", 64.0 * a_cov + 32.0 * a_pano, HBM_PEAK_GBS, "GB/s"),
+             roof(["render_warp"], "rw_warp_staged_kernel", "hbm", 16.0 * a_cov + 3.0 * a_cov, HBM_PEAK_GBS, "GB/s"),
+             roof(["multiband"], "planar-scan multiband blend (aps_multiband_blend: 64 B per canvas pixel and layer)", "hbm", 64.0 * a_pano * n, HBM_PEAK_GBS, "GB/s")]
+    t_feat = sum(i["times"].get("features", 0.0) for i in infos) / len(infos)
+    if t_feat > 0:
+        ach = 574.0 * a_cov / t_feat / 1e9
+        cands.append({"bound": "hbm", "kernel": "SIFT stage (all kernels of all views on their worker streams, wall time of the stage)", "achieved": round(ach, 2),
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_work_per_step": 574.0 * a_cov,
+                      "ms_per_step": round(1e3 * t_feat, 3), "timed": "live over the timed steps"})
+    cands = [c for c in cands if c]
+    dominant = max(cands, key=lambda c: c["ms_per_step"]) if cands else None
+    rows, surv = ctypes.c_int64(0), ctypes.c_int64(0)
+    capi.check(capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv)))
+    out = {"metric": "MPix/s end-to-end stitch (SIFT->blend)", "value": round(mpix_in * args.steps / dt, 2), "unit": "MPix/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "ms_per_step_median": round(1e3 * float(np.median(walls)), 2),
+           "ms_per_step_min": round(1e3 * min(walls), 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": name + "; inputs resident in HBM, panoramas left in HBM", "baseline_config_index": cfg, "reference_defaults": ref,
+                      "views": n, "input_mpix": round(mpix_in, 1), "features_per_view": int(np.mean(counts)), "pairs_verified": info.get("n_pairs_verified"),
+                      "components": info.get("n_components"), "panoramas": [[s_[1], s_[0]] for s_ in info["shapes"]],
+                      "int8_screen_survivor_share": round(surv.value / rows.value, 4) if rows.value else None},
+           "roofline": dominant, "rooflines_all": cands,
+           "stages_ms_per_step": {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in info["times"]},
+           "kernels": {k: {"ms_per_step": round(v[0] / args.steps, 3), "launches_per_step": v[1] // max(args.steps, 1)} for k, v in prof.items() if v[0] / args.steps > 0.005}}
+    if args.cpu_baseline == "auto":
+        try:
+            if cfg == 0:
+                out["cpu_baseline"] = dict(cpu_cfg1_single_thread(synth), kind="port")
+            else:
+                n_pairs = n * (n - 1) // 2
+                out["cpu_baseline"] = cpu_sample(synth, input_, w, h, f, {1: 0.35, 3: 0.4, 4: 0.4}[cfg], {1: 4.0, 3: FINEST_PX, 4: 10.0}[cfg], input_["bands"],
+                                                 "spherical", {1: 2024, 3: 12345, 4: 1000}[cfg], n, n_pairs, max(1, int(info.get("n_pairs_verified") or n)), a_pano)
+        except Exception as e:  # a report, never a reason to lose the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    return 0
+
+
 def launcher_command(n_gpus, argv, port=None):
     """The command `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) runs as a CHILD process: one rank
     per GPU under torch.distributed.run, rendezvous on 127.0.0.1 - the form the driver itself uses."""
@@ -415,6 +651,11 @@ def main():
         sys.exit(2)
     if os.environ.get("APS_BENCH_RANK_PROBE") == "1":
         sys.exit(rank_probe(args))
+    if args.config is not None:
+        if args.gpus != 1:
+            print("bench.py: --config N runs on one GPU (the headline, configs[2], is the line that scales)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(run_config(args))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout
     # when a communicator comes up): everything but the result line is sent to stderr by pointing fd 1 at fd 2 for the
     # run; the result is written to the saved descriptor at the end.
