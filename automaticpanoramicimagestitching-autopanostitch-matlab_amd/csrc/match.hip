@@ -1836,6 +1836,18 @@ __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row
             out_d2[slot] = INFINITY;
         } else {
             survive = true;
+            // The exact list pass (match_list_i8_kernel) will name the columns that can be the row's best or second best by the
+            // canonical f32 distance: two distinct columns have u_i.u_j >= I1 = e1 + rc, so the second largest similarity is at
+            // least I1 / (t_i tmax), and a column can reach that only with I_j >= I1 tmin / tmax.  The margin 2e-4 covers the
+            // two 2^-23 factors and the rounding of the canonical distance itself (delta above: 2^-16 of the magnitudes).  The
+            // threshold travels in the row's d1 slot, in accumulator units (I - rc); INT_MIN: every column is a candidate.
+            int thr = -2147483647 - 1;
+            if (tmin > 0.f && tmax >= tmin && tmax < 1e30f && nB >= 2 && e1 != kNone) {
+                const double rc = (double)jb.cinA[row] + 2097152.0;
+                const double t = floor(((double)e1 + rc) * ((double)tmin / (double)tmax) * (1.0 - 2e-4)) - 2.0 - rc;
+                thr = t > -2147483000.0 ? (int)t : thr;
+            }
+            out_d1[jb.out_off + row] = __int_as_float(thr);
         }
     } else if (row < nA) {
         const ScreenSet q = screen_set(jb);
@@ -2353,6 +2365,262 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
 }
 
 // ------------------------------------------------------------------------------------------------
+// the exact list pass (round 6): survivors of jobs on exact integer codes
+// ------------------------------------------------------------------------------------------------
+// The survivors of the screen need their exact two nearest columns.  Until round 5 that was one f16 product per (survivor,
+// column) with a certified error bound (match_cand_f16_kernel<LIST>).  With exact integer codes the same sweep runs on the
+// int8 pipe at twice the rate and needs no error analysis: the products are exact, and the screen has left every survivor a
+// threshold (screen_tail) that only the columns which can be its best or second best by the canonical f32 distance reach - a
+// handful per row.  This kernel streams a pooled 512-row survivor tile against its B set exactly like the screening kernel
+// (same LDS image, DMA, hand-over, read-ahead, C operand), compares instead of folding - per (32-column block, row group)
+// the maximum of the lane's eight products against the row's threshold, and only on a hit (rare) the eight values one by
+// one - and appends (column) to the row's candidate list: cand[p * kCandCap ..], count in cand_cnt[p], p = the row's position
+// in the pooled survivor list (counts beyond the capacity are kept: such a row goes to the exact-f32 fallback).  match_rescore_kernel then evaluates the canonical f32
+// distance of every candidate and writes the row's (idx, d1, d2).  Whole register file claimed like the screening kernels.
+constexpr int kCandCap = 32;
+
+__global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __restrict__ jobs, const WgJob* __restrict__ wgs, int n_wg,
+                                                            const uint32_t* __restrict__ row_list, const int* __restrict__ list_job,
+                                                            const float* __restrict__ thr_slot, uint32_t* __restrict__ cand,
+                                                            unsigned int* __restrict__ cand_cnt) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * kQTileBytes + 3 * 1024];
+    __shared__ unsigned int s_cnt[512];  // candidates found so far per row of the tile (the four lane quarters of a wave share a row)
+    s_cnt[threadIdx.x] = 0u;
+    int wg = blockIdx.x;
+    {
+        const int q = n_wg / 8, r = n_wg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");  // (nothing shares a SIMD with int8-MFMA waves)
+    const WgJob w = wgs[wg];
+    const MatchJob jb = jobs[w.job];  // (any job of the tile's group: the B set is common)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int kq = lane >> 4;
+    const int nB = jb.nB;
+    constexpr int kNone = kScreenNone;
+    // this lane's four rows: list entries w.row0 + wave * 64 + 16 g + c (entries past the tile's end: no row, nothing can hit)
+    i32x4 aq[4][2];
+    int thr[4];
+    int pos_of[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int e = wave * 64 + 16 * g + c;
+        const bool live = e < w.list_cnt;
+        pos_of[g] = w.row0 + (live ? e : 0);
+        const int arow = (int)row_list[pos_of[g]];  // (the pooled list names rows within their job: list_pool_kernel)
+        const MatchJob& jr = jobs[list_job[pos_of[g]]];
+        thr[g] = live ? __float_as_int(thr_slot[jr.out_off + arow]) : 2147483647;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            aq[g][ks] = *reinterpret_cast<const i32x4*>(jr.AX + (size_t)arow * kDim + 64 * ks + 16 * kq);
+    }
+    const int ntiles = (nB + kQTN - 1) / kQTN;
+    const int dma_sub = lane >> 3, dma_pos = lane & 7;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto issue_piece = [&](int t, int buf, int u) {
+        const int piece = wave * 4 + u;
+        const int lrow = 8 * piece + dma_sub;
+        const int brow = min(t * kQTN + lrow, nB - 1);
+        const signed char* src = jb.BX + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
+        const uint32_t dst = lds_base + buf * kQTileBytes + piece * 1024;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    };
+    const int ncin = jb.ncinB;
+    auto issue_cin = [&](int t, int buf) {
+        if (wave == 0) {
+            const int col = min(t * kQTN + 4 * lane, ncin - 4);
+            const int* src = jb.cinB + col;
+            const uint32_t dst = lds_base + 3 * kQTileBytes + buf * 1024;
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+    i32x4 acc[2][2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[p][u][g][e] = kNone;
+    // the test of a finished block for row group g: col0 = first column of the block; columns >= nB never count
+    auto test_group = [&](auto PAR, auto G, int col0) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value, g = decltype(G)::value;
+        int v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[par][e >> 2][g][e & 3];
+        int m;
+        asm volatile("v_max3_i32 %0, %1, %2, %3\n\tv_max3_i32 %0, %0, %4, %5\n\tv_max3_i32 %0, %0, %6, %7\n\tv_max_i32 %0, %0, %8"
+                     : "=&v"(m)
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        if (__builtin_expect(__any(m >= thr[g]), 0)) {
+            // (one emission site behind a bit mask of the lane's hits: with the eight tests unrolled around eight atomics the
+            // kernel's loop body outgrew the instruction cache - 32 call sites per tile - and ran at half the screen's rate)
+            unsigned hits = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hits |= (v[e] >= thr[g] ? 1u : 0u) << e;
+#pragma unroll 1
+            while (hits) {
+                const int e = __builtin_ctz(hits);
+                hits &= hits - 1u;
+                const int col = col0 + 16 * (e >> 2) + 4 * kq + (e & 3);
+                if (col < nB) {
+                    // (the row's counter lives in LDS: a returning GLOBAL atomic is waited for on vmcnt, behind the tile's
+                    // LDS-DMA pieces in flight - every hit then stalled its wave until the next tile had landed)
+                    const unsigned int pos = atomicAdd(&s_cnt[wave * 64 + 16 * g + c], 1u);
+                    if (pos < (unsigned)kCandCap) cand[(size_t)pos_of[g] * kCandCap + pos] = (uint32_t)col;
+                }
+            }
+        }
+    };
+    if (ntiles > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) issue_piece(0, 0, u);
+        issue_cin(0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(aq[g][0]), "v"(aq[g][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int hx = (16 * kq) ^ (16 * ((c >> 1) & 7));
+    constexpr int kAhead = 3;
+    auto slot_off = [&](int s) __attribute__((always_inline)) { return (s >> 1) * 16 * kDim + ((64 * (s & 1)) ^ hx); };
+    i32x4 bq[4];
+    i32x4 cin[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const unsigned char* const cin_lds = lds + 3 * kQTileBytes + 16 * kq;
+    if (ntiles > 0) {
+        if (ntiles > 1) {
+            issue_piece(1, 1, 0);
+            issue_cin(1, 1);
+        }
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) bq[s] = *reinterpret_cast<const i32x4*>(lds + c * kDim + slot_off(s));
+        cin[0] = *reinterpret_cast<const i32x4*>(cin_lds);
+        cin[1] = *reinterpret_cast<const i32x4*>(cin_lds + 64);
+    }
+    int b_cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        const bool more2 = t + 2 < ntiles;
+        const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_nxt2 = b_nxt == 2 ? 0 : b_nxt + 1;
+        const unsigned char* tile = lds + b_cur * kQTileBytes + c * kDim;
+        const unsigned char* tile_n = lds + b_nxt * kQTileBytes + c * kDim;
+        const unsigned char* cin_t = cin_lds + b_cur * 1024;
+        const unsigned char* cin_n = cin_lds + b_nxt * 1024;
+        b_cur = b_nxt;
+        static_for<0, kQBlk>([&](auto CB) {
+            constexpr int cb = decltype(CB)::value;
+            constexpr int kLast = kQBlk - 1;
+            constexpr int par = cb & 1;
+            if (cb == 0 || cb == 2 || cb == 4) {
+                if (more) issue_piece(t + 1, b_nxt, cb / 2 + 1);
+            } else if (cb == kLast) {
+                if (more2) {
+                    issue_piece(t + 2, b_nxt2, 0);
+                    issue_cin(t + 2, b_nxt2);
+                }
+            }
+            const unsigned char* blk = tile + cb * 32 * kDim;
+            const unsigned char* nblk = cb < kLast ? blk + 32 * kDim : tile_n;
+            const bool fetch = cb < kLast || more;
+            // the block being tested is the previous one: (t, cb - 1), or the last block of tile t - 1
+            const int col_prev = cb > 0 ? t * kQTN + (cb - 1) * 32 : (t - 1) * kQTN + kLast * 32;
+            static_for<0, 4>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                constexpr int u = s >> 1, ks = s & 1;
+                const i32x4 xq = bq[s & 3];
+                if (s + kAhead < 4) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(blk + slot_off(s + kAhead));
+                } else if (fetch) {
+                    bq[(s + kAhead) & 3] = *reinterpret_cast<const i32x4*>(nblk + slot_off(s + kAhead - 4));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[par][u][g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xq, aq[g][ks], ks == 0 ? cin[u] : acc[par][u][g], 0, 0, 0);
+                if (ks == 1) {
+                    if (cb < kLast)
+                        cin[u] = *reinterpret_cast<const i32x4*>(cin_t + (32 * (cb + 1) + 16 * u) * 4);
+                    else if (more)
+                        cin[u] = *reinterpret_cast<const i32x4*>(cin_n + (16 * u) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (cb > 0 || t > 0) test_group(std::integral_constant<int, par ^ 1>{}, S, col_prev);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (cb == kLast - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        });
+    }
+    if (ntiles > 0) {
+        const int col_last = (ntiles - 1) * kQTN + (kQBlk - 1) * 32;
+        static_for<0, 4>([&](auto S) { test_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, col_last); });
+    }
+    __syncthreads();
+    if (tid < w.list_cnt) cand_cnt[w.row0 + tid] = s_cnt[tid];  // (row e of the tile = wave e / 64, group (e % 64) / 16, c = e % 16: s_cnt's order)
+}
+
+// The candidates of a row (match_list_i8_kernel) -> its exact (idx, d1, d2): eight lanes per row, lane e evaluates the
+// canonical f32 distance (exact_dist: the k-ascending fma chain of the contract) of candidates e, e + 8, ..., keeping its two
+// smallest by (distance, index); a butterfly over the eight lanes merges them.  Rows with more candidates than slots go to
+// the exact-f32 fallback list of their job.
+__global__ __launch_bounds__(256) void match_rescore_kernel(const MatchJob* __restrict__ jobs, const uint32_t* __restrict__ row_list,
+                                                            const int* __restrict__ list_job, int64_t n_rows,
+                                                            const uint32_t* __restrict__ cand, const unsigned int* __restrict__ cand_cnt,
+                                                            uint32_t* __restrict__ out_idx, float* __restrict__ out_d1, float* __restrict__ out_d2,
+                                                            uint32_t* __restrict__ fb_list, unsigned int* __restrict__ fb_count) {
+    const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int e0 = threadIdx.x & 7;
+    const bool live = r < n_rows;
+    const int row = (int)row_list[live ? r : 0];  // (a row within its job)
+    const int job = list_job[live ? r : 0];
+    const MatchJob& jb = jobs[job];
+    const int64_t slot = jb.out_off + row;
+    const unsigned int cnt = live ? cand_cnt[r] : 0u;
+    float b = INFINITY, s2 = INFINITY;
+    int bi = 0x7fffffff;
+    if (live && cnt <= (unsigned)kCandCap) {
+        const float* pa = jb.PA + (size_t)row * kDim;
+        const float a2 = jb.sqA[row];
+        for (unsigned int e = e0; e < cnt; e += 8u) {
+            const int id = (int)cand[(size_t)r * kCandCap + e];
+            const float d = exact_dist(pa, jb.PB + (size_t)id * kDim, a2, jb.sqB[id]);
+            top2_merge(b, bi, s2, d, id, INFINITY);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const float ob = __shfl_xor(b, off), os = __shfl_xor(s2, off);
+        const int oi = __shfl_xor(bi, off);
+        top2_merge(b, bi, s2, ob, oi, os);
+    }
+    if (live && e0 == 0) {
+        if (cnt > (unsigned)kCandCap || cnt == 0u) {  // (no candidate cannot happen for nB >= 1; the exact kernel decides then)
+            const unsigned int p = atomicAdd(fb_count + job, 1u);
+            fb_list[jb.out_off + p] = (uint32_t)slot;
+        } else {
+            out_idx[slot] = (uint32_t)bi + 1u;
+            out_d1[slot] = b;
+            out_d2[slot] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ratio / threshold / uniqueness  (matchFeaturesScratch.m:170-211)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t order_f32(float f) {
@@ -2497,18 +2765,48 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
+// The operand arrays of the sets of ONE matching call come out of one slab (round 6): 64 sets x 16 arrays were 1024 trips
+// through the workspace pool's best-fit scan per call, ~0.4 ms of host time between the probe and the first preparation
+// launch.  An Arena in counting mode only adds up the sizes (the dry run that sizes the slab).
+struct Arena {
+    Ws<unsigned char> slab;
+    size_t off = 0, cap = 0;
+    bool counting = false;
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        void* p = counting ? nullptr : static_cast<void*>(slab.get() + off);
+        APS_REQUIRE(counting || off + bytes <= cap, APS_E_INTERNAL, "descriptor arena too small");
+        off += bytes;
+        return p;
+    }
+};
+template <class T>
+struct Buf {  // an array of a prepared set: a piece of the call's arena, or its own workspace block
+    T* p = nullptr;
+    Ws<T> own;
+    void alloc(size_t n, Arena* a) {
+        if (a) {
+            p = static_cast<T*>(a->take((n ? n : 1) * sizeof(T)));
+        } else {
+            own.alloc(n);
+            p = own.get();
+        }
+    }
+    T* get() const { return p; }
+    operator T*() const { return p; }
+};
 struct Prepared {
-    Ws<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals, [4..7] int8 screen
-    Ws<unsigned short> H;
-    Ws<uint4> aug;
-    Ws<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
-    Ws<float> dnq, invs;
-    Ws<int> sumq;
-    Ws<signed char> QX;  // round 6: the exact integer codes (q8_desc_rows), the rows' divisors, 128 x the code sums (n_pad entries)
-    Ws<float> tt;
-    Ws<int> cin;
+    Buf<float> P, sq, dn, maxsq;  // maxsq[0] = max ||x||^2, [1] = max ||x - f16(x)||, [2], [3] = aug residuals, [4..7] int8 screen
+    Buf<unsigned short> H;
+    Buf<uint4> aug;
+    Buf<signed char> QA, QB;  // int8 screening copies (row side / column side) and their side data (see MatchJob)
+    Buf<float> dnq, invs;
+    Buf<int> sumq;
+    Buf<signed char> QX;  // round 6: the exact integer codes (q8_desc_rows), the rows' divisors, 128 x the code sums (n_pad entries)
+    Buf<float> tt;
+    Buf<int> cin;
     int64_t n_pad = 0;
-    Ws<unsigned> part;  // per-workgroup maxima of prep_desc / q8_desc (PrepJob::part)
+    Buf<unsigned> part;  // per-workgroup maxima of prep_desc / q8_desc (PrepJob::part)
     int nb1 = 0, nb2 = 0;
     float* stat = nullptr;  // the kStatWords statistics words: own (maxsq) or a slice of the caller's block (one fill for many sets)
     int64_t n = 0;
@@ -2517,7 +2815,7 @@ struct Prepared {
 // `st`: the stream the set's launches go to (the caller's own stream, or one of its auxiliary streams when many sets are
 // prepared side by side - each set is a chain of small launches that leaves most of the chip idle)
 // the buffers of a set (and, when the set owns its statistics words, their zero fill on `st`)
-static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext);
+static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext, Arena* arena = nullptr);
 
 // An experiment switch read from the environment reaches the device when its value differs from what the device holds
 // (also back to 0 when the variable is unset again), by a synchronous copy from a live variable - same-process A/Bs see
@@ -2571,11 +2869,20 @@ struct PrepRequest {
     Prepared* out;
     float* stat_ext;
 };
-static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
+static void prepare_batch(const std::vector<PrepRequest>& req, int layout, Arena* arena = nullptr) {
     std::vector<PrepJob> jobs;
     std::vector<int> bp{0}, bq{0};
+    if (arena) {  // the dry run that sizes the slab (stat_ext is set for every set of a batch)
+        Arena count;
+        count.counting = true;
+        Prepared dry;
+        for (const PrepRequest& r : req) prepare_alloc(r.n, dry, stream(), r.stat_ext, &count);
+        arena->slab.alloc(count.off);
+        arena->cap = count.off;
+        arena->off = 0;
+    }
     for (const PrepRequest& r : req) {
-        prepare_alloc(r.n, *r.out, stream(), r.stat_ext);
+        prepare_alloc(r.n, *r.out, stream(), r.stat_ext, arena);
         if (r.n == 0) continue;
         const Prepared& o = *r.out;
         const int64_t n_pad = (std::max<int64_t>(r.n, 1) + kTNB - 1) / kTNB * kTNB;
@@ -2602,34 +2909,36 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout) {
     APS_HIP(hipStreamSynchronize(stream()));  // the host tables (and dj / dbp / dbq) must outlive the launches
 }
 
-static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext) {
+static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext, Arena* arena) {
+    Arena* const a = arena;
     out.n = n;
     const size_t rows = (size_t)std::max<int64_t>(n, 1);
-    out.P.alloc(rows * kDim);
-    out.sq.alloc(rows);
-    out.H.alloc(rows * kDim);
-    out.dn.alloc(rows);
+    out.P.alloc(rows * kDim, a);
+    out.sq.alloc(rows, a);
+    out.H.alloc(rows * kDim, a);
+    out.dn.alloc(rows, a);
     if (stat_ext) {  // zeroed by the caller
         out.stat = stat_ext;
     } else {
-        out.maxsq.alloc(kStatWords);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's, [8..10] its exact codes' (one fill)
+        APS_REQUIRE(a == nullptr, APS_E_INTERNAL, "a set in an arena takes its statistics words from the caller's block");
+        out.maxsq.alloc(kStatWords, nullptr);  // [0..3] the f16 path's set statistics, [4..7] the int8 screen's, [8..10] its exact codes' (one fill)
         APS_HIP(hipMemsetAsync(out.maxsq, 0, kStatWords * sizeof(float), st));
         out.stat = out.maxsq;
     }
     const int64_t n_pad = (std::max<int64_t>(n, 1) + kTNB - 1) / kTNB * kTNB;
-    out.aug.alloc((size_t)n_pad);
-    out.QA.alloc(rows * kDim);
-    out.QB.alloc(rows * kDim);
-    out.dnq.alloc(rows);
-    out.invs.alloc(rows);
-    out.sumq.alloc(rows);
-    out.QX.alloc(rows * kDim);
-    out.tt.alloc(rows);
-    out.cin.alloc((size_t)n_pad);
+    out.aug.alloc((size_t)n_pad, a);
+    out.QA.alloc(rows * kDim, a);
+    out.QB.alloc(rows * kDim, a);
+    out.dnq.alloc(rows, a);
+    out.invs.alloc(rows, a);
+    out.sumq.alloc(rows, a);
+    out.QX.alloc(rows * kDim, a);
+    out.tt.alloc(rows, a);
+    out.cin.alloc((size_t)n_pad, a);
     out.n_pad = n_pad;
     out.nb1 = (int)cdiv(rows, kPrepRows);
     out.nb2 = (int)cdiv((size_t)n_pad * 8, 256);
-    out.part.alloc((size_t)5 * out.nb1 + (size_t)kQ8Part * out.nb2);
+    out.part.alloc((size_t)5 * out.nb1 + (size_t)kQ8Part * out.nb2, a);
 }
 
 static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, int64_t out_off) {
@@ -2826,6 +3135,26 @@ static void require_whole_simd(int shape32, int bounds = 0) {
                 "the int8 screening kernel holds %d registers per lane, not 256: other kernels' waves could share its SIMDs (DESIGN.md section 5)", regs);
     ok[2 * shape32 + bounds] = 1;
 }
+static void require_whole_simd_list() {  // (the same rule for the exact list pass)
+    static int ok = 0;
+    if (ok) return;
+    hipFuncAttributes fa;
+    APS_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&match_list_i8_kernel)));
+    APS_REQUIRE((fa.numRegs + 7) / 8 * 8 >= 256, APS_E_INTERNAL,
+                "the int8 list kernel holds %d registers per lane, not 256: other kernels' waves could share its SIMDs (DESIGN.md section 5)", fa.numRegs);
+    ok = 1;
+}
+// tile k of a dense pass = rows [r, r + rows_per_tile) of job j, where off[j] <= k < off[j + 1] and r = (k - off[j]) * rows_per_tile
+__global__ void expand_tiles_kernel(const int* __restrict__ off, int n_jobs, int n_tiles, int rows_per_tile, WgJob* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tiles) return;
+    int lo = 0, hi = n_jobs - 1;  // the largest j with off[j] <= k (jobs without rows have empty ranges)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    out[k] = WgJob{lo, (k - off[lo]) * rows_per_tile, 0, 0, 0, 0};
+}
 // Runs the 2-NN search for a list of jobs whose operands are already prepared on the device.
 // prune_r2 > 0: the caller will apply the ratio / threshold filter with these constants, so rows that cannot pass it
 // may come back as idx 0 / inf without an exact evaluation (see match_cand_f16_kernel's tail)
@@ -2861,11 +3190,18 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
     Ws<uint32_t> fb_list((size_t)total_rows);
     Ws<unsigned int> fb_count(jobs.size());
     APS_HIP(hipMemsetAsync(fb_count, 0, jobs.size() * sizeof(unsigned int), stream()));
-    std::vector<WgJob> bw;
-    for (int j = 0; j < (int)jobs.size(); ++j)
-        for (int r = 0; r < jobs[j].nA; r += kTMB) bw.push_back({j, r, 0});
-    Ws<WgJob> dbw(bw.size());
-    APS_HIP(hipMemcpyAsync(dbw, bw.data(), bw.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+    // the dense tile table {job, first row} of the screening / candidate kernels, expanded on the device from the jobs' tile
+    // offsets (round 6: 78 k entries for the 64 x 4K scene were built on the host and uploaded from pageable memory, ~0.2 ms)
+    std::vector<int> wg_off(jobs.size() + 1, 0);
+    for (size_t j = 0; j < jobs.size(); ++j) wg_off[j + 1] = wg_off[j] + (jobs[j].nA + kTMB - 1) / kTMB;
+    struct { size_t n; size_t size() const { return n; } } bw{(size_t)wg_off.back()};
+    Ws<WgJob> dbw(std::max<size_t>(bw.size(), 1));
+    Ws<int> d_wg_off(wg_off.size());
+    APS_HIP(hipMemcpyAsync(d_wg_off, wg_off.data(), wg_off.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    if (bw.size() > 0) {
+        expand_tiles_kernel<<<(unsigned)cdiv(bw.size(), 256), 256, 0, stream()>>>(d_wg_off, (int)jobs.size(), (int)bw.size(), kTMB, dbw);
+        check_launch("expand_tiles_kernel");
+    }
 #ifdef APS_MATCH_TIMING  // ablation bits are honoured by timing builds only (they invalidate the results)
     const char* ab = std::getenv("APS_MATCH_ABLATE");
     const int ablate = ab ? std::atoi(ab) : 0;
@@ -2903,7 +3239,11 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         APS_HIP(hipStreamSynchronize(stream()));
         g_screen_jobs = (int64_t)jobs.size();
         g_screen_exact = 0;
-        for (size_t j = 0; j < jobs.size(); ++j) g_screen_exact += h_surv[jobs.size() + j] ? 1 : 0;
+        std::vector<char> h_exact(jobs.size());
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            h_exact[j] = h_surv[jobs.size() + j] ? 1 : 0;
+            g_screen_exact += h_exact[j];
+        }
         h_surv.resize(jobs.size());
         const auto S1 = std::chrono::steady_clock::now();
         // the survivors of the jobs that share a B set are pooled into common 512-row tiles (APS_MATCH_NO_POOL=1: one list per
@@ -2917,7 +3257,46 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         if (pooled) {
             std::vector<int64_t> seg(jobs.size());
             for (size_t j = 0; j < jobs.size(); ++j) seg[j] = jobs[j].out_off;
-            lw = pool_lists(jobs, seg, surv_list, {}, h_surv, nullptr, surv_count, pool, pool_job);
+            // Round 6: the survivors of jobs that ran on exact integer codes take the exact int8 list pass (match_list_i8_kernel +
+            // match_rescore_kernel), the others the f16 candidate kernel as before; each kind is pooled on its own.
+            // APS_MATCH_NO_LIST_I8=1: the f16 kernel for all (A/B).
+            std::vector<unsigned int> cnt_x(jobs.size(), 0u), cnt_g(h_surv);
+            size_t n_x = 0;
+            if (!std::getenv("APS_MATCH_NO_LIST_I8"))
+                for (size_t j = 0; j < jobs.size(); ++j)
+                    if (h_exact[j] && jobs[j].nB >= 1) {
+                        cnt_x[j] = h_surv[j];
+                        cnt_g[j] = 0u;
+                        n_x += h_surv[j];
+                    }
+            if (n_x > 0) {
+                Ws<unsigned int> d_cnt_x(jobs.size()), d_cnt_g(jobs.size());
+                APS_HIP(hipMemcpyAsync(d_cnt_x, cnt_x.data(), jobs.size() * sizeof(unsigned int), hipMemcpyHostToDevice, stream()));
+                APS_HIP(hipMemcpyAsync(d_cnt_g, cnt_g.data(), jobs.size() * sizeof(unsigned int), hipMemcpyHostToDevice, stream()));
+                Ws<uint32_t> pool_x;
+                Ws<int> pool_job_x;
+                const std::vector<WgJob> lx = pool_lists(jobs, seg, surv_list, {}, cnt_x, nullptr, d_cnt_x, pool_x, pool_job_x);
+                Ws<WgJob> dlx(lx.size());
+                Ws<uint32_t> cand(n_x * kCandCap);
+                Ws<unsigned int> cand_cnt(n_x);
+                APS_HIP(hipMemcpyAsync(dlx, lx.data(), lx.size() * sizeof(WgJob), hipMemcpyHostToDevice, stream()));
+                APS_HIP(hipMemsetAsync(cand_cnt, 0, n_x * sizeof(unsigned int), stream()));
+                {
+                    Prof prof("match_list_i8");
+                    require_whole_simd_list();
+                    match_list_i8_kernel<<<(unsigned)lx.size(), 512, 0, stream()>>>(djobs, dlx, (int)lx.size(), pool_x, pool_job_x, d1, cand, cand_cnt);
+                }
+                {
+                    Prof prof("match_rescore");
+                    match_rescore_kernel<<<(unsigned)cdiv(n_x, 32), 256, 0, stream()>>>(djobs, pool_x, pool_job_x, (int64_t)n_x, cand, cand_cnt, idx, d1, d2,
+                                                                                       fb_list, fb_count);
+                }
+                check_launch("match_list_i8_kernel");
+                lw = pool_lists(jobs, seg, surv_list, {}, cnt_g, nullptr, d_cnt_g, pool, pool_job);
+                APS_HIP(hipStreamSynchronize(stream()));  // (lx, the count tables and the candidate lists go out of scope)
+            } else {
+                lw = pool_lists(jobs, seg, surv_list, {}, h_surv, nullptr, surv_count, pool, pool_job);
+            }
         } else {
             for (int j = 0; j < (int)jobs.size(); ++j)
                 for (unsigned int r = 0; r < h_surv[j]; r += kTMB) lw.push_back({j, (int)r, (int)std::min<unsigned int>(kTMB, h_surv[j] - r)});
@@ -3713,6 +4092,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
     // (matchFeaturesScratch.m:105: max|A|>2 || max|B|>2)
     auto big = [&](int i) { return o.normalize == 1 || (o.normalize == 2 && amax[i] > 2.f); };
     std::vector<Prepared> raw(n_img), nrm(n_img);
+    Arena prep_arena;  // (outlives the sets)
     Ws<float> prep_stats((size_t)2 * kStatWords * std::max(n_img, 1));
     std::vector<char> need_raw(n_img, 0), need_nrm(n_img, 0);
     for (int64_t p = 0; p < n_pairs; ++p) {
@@ -3730,7 +4110,7 @@ static void match_pairs_impl(const float* const* desc, const int64_t* counts, co
                 if (need_raw[i]) req.push_back({din[i], counts[i], ld[i], false, &raw[i], prep_stats.get() + 2 * kStatWords * i});
                 if (need_nrm[i]) req.push_back({din[i], counts[i], ld[i], true, &nrm[i], prep_stats.get() + 2 * kStatWords * i + kStatWords});
             }
-            prepare_batch(req, layout);
+            prepare_batch(req, layout, &prep_arena);
         } else {
             AuxScope fork(kPrepStreams);
             std::vector<hipStream_t>& aux = fork.streams;

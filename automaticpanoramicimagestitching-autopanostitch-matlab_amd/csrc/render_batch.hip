@@ -23,7 +23,9 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <future>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include <chrono>
@@ -1597,14 +1599,34 @@ namespace {
 // be (kernels evaluate the exact predicate per pixel inside it).  This replaces the coverage kernel and its read-back.
 // Not applicable (returns false, the caller runs rw_cover_kernel): planar / stereographic canvases, an outline that
 // crosses the theta = +-pi seam, an image that contains a pole.
+// The images are independent (image i writes hbox[(t * n_img + i) * 4 ..] only), so the loop runs on a few host threads
+// (round 6: 0.65 ms of every render call on one thread, in front of the call's first kernel launch - most of a rank's fixed
+// render cost at 8 ranks).  APS_RENDER_HOST_THREADS=1: one thread.
+static bool host_footprints_range(const DevImage* himgs, int n_img, int i_begin, int i_end, const DevCanvas& cv, const std::vector<RwTile>& tiles,
+                                  std::vector<int>& hbox);
 bool host_footprints(const DevImage* himgs, int n_img, const DevCanvas& cv, const std::vector<RwTile>& tiles, std::vector<int>& hbox) {
     if (cv.mode != APS_PROJ_SPHERICAL && cv.mode != APS_PROJ_CYLINDRICAL) return false;
+    std::fill(hbox.begin(), hbox.end(), 0);
+    const char* e = std::getenv("APS_RENDER_HOST_THREADS");
+    int nthr = e ? std::atoi(e) : 6;
+    nthr = std::max(1, std::min({nthr, n_img / 8, (int)std::thread::hardware_concurrency()}));
+    if (nthr <= 1) return host_footprints_range(himgs, n_img, 0, n_img, cv, tiles, hbox);
+    std::vector<std::future<bool>> parts;
+    for (int k = 1; k < nthr; ++k)
+        parts.push_back(std::async(std::launch::async, [&, k] {
+            return host_footprints_range(himgs, n_img, (int)((long long)n_img * k / nthr), (int)((long long)n_img * (k + 1) / nthr), cv, tiles, hbox);
+        }));
+    bool ok = host_footprints_range(himgs, n_img, 0, n_img / nthr, cv, tiles, hbox);
+    for (auto& p : parts) ok = p.get() && ok;
+    return ok;
+}
+static bool host_footprints_range(const DevImage* himgs, int n_img, int i_begin, int i_end, const DevCanvas& cv, const std::vector<RwTile>& tiles,
+                                  std::vector<int>& hbox) {
     const double f = (double)cv.f, o0 = (double)cv.o0, o1 = (double)cv.o1;
     const int nt = (int)tiles.size();
-    std::fill(hbox.begin(), hbox.end(), 0);
     std::vector<double> px, py, qx, qy, rx, ry;
     const double kPi = 3.14159265358979323846;
-    for (int i = 0; i < n_img; ++i) {
+    for (int i = i_begin; i < i_end; ++i) {
         const DevImage& im = himgs[i];
         if (!(im.fx > 0.f) || !(im.fy > 0.f)) return false;
         const double R[9] = {im.R[0], im.R[1], im.R[2], im.R[3], im.R[4], im.R[5], im.R[6], im.R[7], im.R[8]};
