@@ -1472,20 +1472,91 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
             __builtin_amdgcn_wave_barrier();
             qn = 0;
         };
-        for (int i = -radius; i <= radius; ++i) {
-            for (int j0 = -radius; j0 <= radius; j0 += 64) {
-                const int j = j0 + lane;
-                const float c_rot = (float)j * cos_t - (float)i * sin_t;
-                const float r_rot = (float)j * sin_t + (float)i * cos_t;
-                const float rbin = r_rot + (float)(kD / 2) - 0.5f;
-                const float cbin = c_rot + (float)(kD / 2) - 0.5f;
-                const int r = py + i, c = px + j;
-                const bool pass = j <= radius && rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-                const unsigned long long m = __ballot(pass);
-                if (m == 0ull) continue;
-                if (pass) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (i << 16) | (j & 0xffff);
-                qn += __popcll(m);
-                if (qn > kDescQueue - 64) flush();
+        // The window test of sample (i, j), exactly as the sweep below evaluates it (the reference's expressions, f32, no
+        // contraction): every term is monotone in j for a fixed row i, so the passing samples of a row form ONE interval.
+        auto passes = [&](int i, int j) __attribute__((always_inline)) {
+            const float c_rot = (float)j * cos_t - (float)i * sin_t;
+            const float r_rot = (float)j * sin_t + (float)i * cos_t;
+            const float rbin = r_rot + (float)(kD / 2) - 0.5f;
+            const float cbin = c_rot + (float)(kD / 2) - 0.5f;
+            const int r = py + i, c = px + j;
+            return j >= -radius && j <= radius && rbin > -1 && rbin < kD && cbin > -1 && cbin < kD && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+        };
+        // Round 6: the rows' intervals instead of the whole square.  The square holds (2 radius + 1)^2 points of which about
+        // half pass, and testing them 64 to a wave instruction was as many vector instructions as the histogram work itself.
+        // Lane l takes row i = -radius + l (+ 64 in a second set: radius <= 63, else the plain sweep): the interval's ends are
+        // estimated from the two linear constraints in real arithmetic, widened, and then FOUND with the exact test on the
+        // five integers around each estimate; the result is verified with the exact test (the points just outside fail, so by
+        // monotonicity nothing further out passes; a row without a passing point must have an empty estimate) - a row that does
+        // not verify sends the keypoint through the plain sweep, and so does an orientation within ~0.01 degrees of an axis
+        // (|sin| or |cos| below 1e-4 of the scaled units: the estimate's error in j, ~5e-6 / |a|, must stay far below the
+        // two-integer search range).  Then every row's samples are queued without any test, 64 to an instruction.  Same set
+        // of samples, hence the same histogram bits.
+        bool plain = radius > 63 || fabsf(sin_t) < 1e-4f || fabsf(cos_t) < 1e-4f;
+        int jl_[2] = {0, 0}, len_[2] = {0, 0};
+        if (!plain) {
+            bool bad = false;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int i = -radius + lane + 64 * half;
+                const bool row_ok = i <= radius && py + i > 0 && py + i < h - 1;
+                const float fi = (float)i;
+                float lo = fmaxf(-(float)radius, (float)(1 - px)), hi = fminf((float)radius, (float)(w - 2 - px));
+                auto clip = [&](float a, float lo_v, float hi_v) __attribute__((always_inline)) {  // lo_v < j a < hi_v, |a| >= 1e-4
+                    const float p0 = lo_v / a, p1 = hi_v / a;
+                    lo = fmaxf(lo, fminf(p0, p1));
+                    hi = fminf(hi, fmaxf(p0, p1));
+                };
+                clip(sin_t, -2.5f - fi * cos_t, 2.5f - fi * cos_t);  // -1 < j sin + i cos + 1.5 < 4
+                clip(cos_t, -2.5f + fi * sin_t, 2.5f + fi * sin_t);  // -1 < j cos - i sin + 1.5 < 4
+                const int gl = (int)ceilf(lo), gh = (int)floorf(hi);
+                int jl = 0x7fffffff, jh = -0x7fffffff;
+#pragma unroll
+                for (int dlt = 2; dlt >= -2; --dlt)
+                    if (passes(i, gl + dlt)) jl = gl + dlt;
+#pragma unroll
+                for (int dlt = -2; dlt <= 2; ++dlt)
+                    if (passes(i, gh + dlt)) jh = gh + dlt;
+                const bool none = jl > jh;
+                bool good;
+                if (none)  // nothing passes within two integers of either estimated end: the estimate itself must be empty
+                    good = gl > gh;
+                else
+                    good = !passes(i, jl - 1) && !passes(i, jh + 1) && passes(i, (jl + jh) / 2) && jl >= gl - 2 && jh <= gh + 2;
+                bad = bad || (row_ok && !good);
+                jl_[half] = jl;
+                len_[half] = (row_ok && !none) ? jh - jl + 1 : 0;
+            }
+            plain = __any(bad) != 0;
+        }
+        if (!plain) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                unsigned long long rows_m = __ballot(len_[half] > 0);
+                while (rows_m) {
+                    const int l = __ffsll((long long)rows_m) - 1;
+                    rows_m &= rows_m - 1ull;
+                    const int rj = __builtin_amdgcn_readlane(jl_[half], l), rn = __builtin_amdgcn_readlane(len_[half], l);
+                    const int ri = -radius + l + 64 * half;
+                    for (int t0 = 0; t0 < rn; t0 += 64) {
+                        const int cnt = min(64, rn - t0);
+                        if (lane < cnt) q[qn + lane] = (ri << 16) | ((rj + t0 + lane) & 0xffff);
+                        qn += cnt;
+                        if (qn > kDescQueue - 64) flush();
+                    }
+                }
+            }
+        } else {
+            for (int i = -radius; i <= radius; ++i) {
+                for (int j0 = -radius; j0 <= radius; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool pass = passes(i, j);
+                    const unsigned long long m = __ballot(pass);
+                    if (m == 0ull) continue;
+                    if (pass) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (i << 16) | (j & 0xffff);
+                    qn += __popcll(m);
+                    if (qn > kDescQueue - 64) flush();
+                }
             }
         }
         if (qn > 0) flush();
