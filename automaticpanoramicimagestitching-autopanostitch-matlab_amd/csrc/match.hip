@@ -21,6 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
+#include <atomic>
 #include <type_traits>
 
 #include "aps_internal.h"
@@ -2820,21 +2823,28 @@ static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_
 // An experiment switch read from the environment reaches the device when its value differs from what the device holds
 // (also back to 0 when the variable is unset again), by a synchronous copy from a live variable - same-process A/Bs see
 // the value they set, and no copy is queued from a stack slot that is gone when it runs.
-static void sync_device_switch(const char* env, const void* symbol, int& held) {
+// (the symbols are per DEVICE and process-wide, so what a device holds is tracked per (device, symbol) for the
+// whole process under a lock - a per-thread note went stale when another thread of the same device, or the same thread on
+// another device, had changed the value.)
+static void sync_device_switch(const char* env, const void* symbol) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> held;
     const char* e = std::getenv(env);
     const int want = e ? std::atoi(e) : 0;
-    if (want == held) return;
+    int dev = 0;
+    APS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int& h = held[{dev, symbol}];  // (0 on first sight: the symbols' initial value)
+    if (want == h) return;
     APS_HIP(hipStreamSynchronize(stream()));  // kernels in flight keep the value they were launched under
     APS_HIP(hipMemcpyToSymbol(symbol, &want, sizeof want, 0, hipMemcpyHostToDevice));
-    held = want;
+    h = want;
 }
 static void sync_q8_symmetric_switch() {
-    static thread_local int held = 0, held_nx = 0;  // (one context per thread: core.hip)
-    sync_device_switch("APS_Q8_SYMMETRIC", &g_q8_symmetric, held);
-    sync_device_switch("APS_MATCH_NO_EXACT", &g_q8_noexact, held_nx);
+    sync_device_switch("APS_Q8_SYMMETRIC", &g_q8_symmetric);
+    sync_device_switch("APS_MATCH_NO_EXACT", &g_q8_noexact);
 #ifdef APS_MATCH_TIMING
-    static thread_local int held_c = 0;
-    sync_device_switch("APS_Q8_CENTER", &g_q8_center, held_c);
+    sync_device_switch("APS_Q8_CENTER", &g_q8_center);
 #endif
 }
 
@@ -3127,22 +3137,22 @@ static void screen_regs(int shape32, int bounds, int* num_regs, int* max_threads
     *max_threads = fa.maxThreadsPerBlock;
 }
 static void require_whole_simd(int shape32, int bounds = 0) {
-    static int ok[4] = {0, 0, 0, 0};
-    if (ok[2 * shape32 + bounds]) return;
+    static std::atomic<int> ok[4];  // (one code object for every device of the process: the answer is the same on all of them)
+    if (ok[2 * shape32 + bounds].load(std::memory_order_relaxed)) return;
     int regs = 0, thr = 0;
     screen_regs(shape32, bounds, &regs, &thr);
     APS_REQUIRE((regs + 7) / 8 * 8 >= 256, APS_E_INTERNAL,
                 "the int8 screening kernel holds %d registers per lane, not 256: other kernels' waves could share its SIMDs (DESIGN.md section 5)", regs);
-    ok[2 * shape32 + bounds] = 1;
+    ok[2 * shape32 + bounds].store(1, std::memory_order_relaxed);
 }
 static void require_whole_simd_list() {  // (the same rule for the exact list pass)
-    static int ok = 0;
-    if (ok) return;
+    static std::atomic<int> ok{0};
+    if (ok.load(std::memory_order_relaxed)) return;
     hipFuncAttributes fa;
     APS_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&match_list_i8_kernel)));
     APS_REQUIRE((fa.numRegs + 7) / 8 * 8 >= 256, APS_E_INTERNAL,
                 "the int8 list kernel holds %d registers per lane, not 256: other kernels' waves could share its SIMDs (DESIGN.md section 5)", fa.numRegs);
-    ok = 1;
+    ok.store(1, std::memory_order_relaxed);
 }
 // tile k of a dense pass = rows [r, r + rows_per_tile) of job j, where off[j] <= k < off[j + 1] and r = (k - off[j]) * rows_per_tile
 __global__ void expand_tiles_kernel(const int* __restrict__ off, int n_jobs, int n_tiles, int rows_per_tile, WgJob* __restrict__ out) {
@@ -3218,10 +3228,7 @@ static void run_match_jobs(const std::vector<MatchJob>& jobs, uint32_t* idx, flo
         {
             Prof prof("match_screen_i8");
 #ifdef APS_MATCH_TIMING
-            {
-                static thread_local int held = 0;
-                sync_device_switch("APS_SCR_VARIANT", &g_scr_variant, held);
-            }
+            sync_device_switch("APS_SCR_VARIANT", &g_scr_variant);
 #endif
             require_whole_simd(screen_shape_32() ? 1 : 0);
             if (screen_shape_32())

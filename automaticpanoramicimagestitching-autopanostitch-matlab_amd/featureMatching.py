@@ -399,8 +399,13 @@ def _fence_fresh_blocks():
     torch.cuda.current_stream().synchronize()
 
 
-def sift_extract(input, image, device_out=False, want_aux=False, points_device=False):
+def sift_extract(input, image, device_out=False, want_aux=False, points_device=False, compact=False):
     """aps_sift_extract with automatic capacity: returns (features, validPts[, aux]).
+
+    Retained memory of a resident result: with device_out the descriptors come back as a VIEW of the capacity
+    buffer (H*W/64 rows: 66 MB for a 4K view, ~6x what ~20 k features need), which stays allocated as long as the caller keeps
+    the descriptors.  compact=True returns a right-sized clone instead (one device copy per view); pipeline.sift_many asks for
+    it when a call extracts more than 96 views, so that a 256- or 500-view set holds what it uses.
 
     image: H x W x 3 or H x W uint8, numpy (host) or torch (host/device), row-major.
     device_out=True keeps the descriptors on the GPU (torch float32 [n,128]) for the resident pipeline;
@@ -452,7 +457,11 @@ def sift_extract(input, image, device_out=False, want_aux=False, points_device=F
     # back so that the worst-case buffer - H*W/64 rows = 66 MB for a 4K view - could be freed: a 10 MB device copy per view
     # on torch's stream plus a stream synchronisation, 23 us of a chip-filling copy kernel and the host wait, to save
     # 64 x 56 MB = 3.6 GB of a 288 GB device for the length of one step.)
-    if device_out:
+    if device_out and compact:
+        check(lib.aps_synchronize())                # the extraction ran on the library's stream,
+        d = desc[:n].clone()                        # the copy runs on torch's,
+        torch.cuda.current_stream().synchronize()   # and the consumers on the library's again
+    elif device_out:
         d = desc[:n]
     else:
         d = np.ascontiguousarray(desc[:n])

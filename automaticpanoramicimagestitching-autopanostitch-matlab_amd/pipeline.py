@@ -159,7 +159,7 @@ def sift_submit(input, images, workers=SIFT_WORKERS_DEFAULT, ready=None, points_
         _capi.check(_capi.lib.aps_set_thread_device(images[k].device.index if dev else here))
         if ready is not None:
             ready[k].synchronize()
-        r = fm.sift_extract(input, images[k], device_out=dev, points_device=bool(dev and points_device))
+        r = fm.sift_extract(input, images[k], device_out=dev, points_device=bool(dev and points_device), compact=len(images) > 96)
         _sync()  # this thread's stream
         return r
 
