@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
                                                     const OrientedKp* __restrict__ oks, unsigned int n_out,
                                                     float* __restrict__ desc, int desc_layout, int64_t ldd,
                                                     double* __restrict__ loc, int64_t ldl,
-                                                    float* __restrict__ aux) {
+                                                    float* __restrict__ aux, int plain_sweep) {
     __shared__ unsigned long long s_hist[4][kHistLen];
     __shared__ __attribute__((aligned(16))) float s_raw[4][128];
     __shared__ int s_queue[4][kDescQueue];  // per wave: samples that passed the window test, (i << 16) | (j & 0xffff)
@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const PyrTable* __restrict__
         // (|sin| or |cos| below 1e-4 of the scaled units: the estimate's error in j, ~5e-6 / |a|, must stay far below the
         // two-integer search range).  Then every row's samples are queued without any test, 64 to an instruction.  Same set
         // of samples, hence the same histogram bits.
-        bool plain = radius > 63 || fabsf(sin_t) < 1e-4f || fabsf(cos_t) < 1e-4f;
+        bool plain = plain_sweep != 0 || radius > 63 || fabsf(sin_t) < 1e-4f || fabsf(cos_t) < 1e-4f;  // (plain_sweep: APS_DESCR_PLAIN=1, A/B)
         int jl_[2] = {0, 0}, len_[2] = {0, 0};
         if (!plain) {
             bool bad = false;
@@ -2029,8 +2029,9 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         Out<double> oloc(loc, (size_t)ldl + n_out);
         {
             Prof prof("sift_descr");
+            static const int plain_sweep = std::getenv("APS_DESCR_PLAIN") ? 1 : 0;  // (A/B: the whole-square sweep of rounds 1-5; same bits)
             descr_kernel<<<cdiv(n_out, 4), 256, 0, stream()>>>(d_table, kps, oks, n_out, odesc, desc_layout, ldd, oloc, ldl,
-                                                               oaux.present() ? oaux.get() : nullptr);
+                                                               oaux.present() ? oaux.get() : nullptr, plain_sweep);
         }
         check_launch("descr_kernel");
         odesc.commit();
