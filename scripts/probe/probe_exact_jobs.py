@@ -1,3 +1,5 @@
+"""Round 6: which jobs of small matching calls run on exact int8 codes (aps_match_screen_exact_jobs): integer descriptors matched in
+normalised form, the same integers over their f32 norm, and sub-sets of both."""
 import sys, ctypes, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import apsamd
