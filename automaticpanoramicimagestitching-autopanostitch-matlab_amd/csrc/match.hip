@@ -766,6 +766,13 @@ struct MatchJob {
     const unsigned* xstatA;
     const unsigned* xstatB;
     int ncinB;
+    // ... and the B set's columns in ascending order of their divisor t (sort_columns): code bytes, 128 x code sums (ncinB
+    // entries), per 256-column tile {1 / tlo (rounded up), 1 / thi (rounded down), tlo, thi} over the tile's non-zero columns
+    // (zeros for a tile of all-zero columns), and the sorted position -> column map
+    const signed char* BXs;
+    const int* cinBs;
+    const float4* tscB;
+    const uint32_t* permB;
 };
 
 struct WgJob {
@@ -1784,7 +1791,8 @@ template <bool BOUNDS>
 __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row, int e0, int e1, int lane,
                                             uint32_t* __restrict__ out_idx, float* __restrict__ out_d1, float* __restrict__ out_d2,
                                             uint32_t* __restrict__ surv_list, unsigned int* __restrict__ surv_count, float prune_r2,
-                                            float prune_thr, float* __restrict__ bounds_out, bool exact = false) {
+                                            float prune_thr, float* __restrict__ bounds_out, bool exact = false, float s_best = 0.f,
+                                            float s_second = 0.f) {
     constexpr int kNone = kScreenNone;
     const int nA = jb.nA, nB = jb.nB;
     bool survive = false;
@@ -1810,23 +1818,22 @@ __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row
         bo[2] = H2f;
         }
     } else if (row < nA && exact) {
-        // Exact integer codes (q8_desc_rows): e0 >= e1 are the two largest (group maxima of) p_i.p_j + 128 sum p_j, so
-        //     u_i.u_j = e + 128 sum p_i + 128^3 =: I        (an exact integer, >= 0)
-        // and the real dot product of the two f32 rows is I / (t_i t_j) within a factor 1 +- 2^-23.  Only the column's divisor
-        // is unknown here: t_j lies in the set's [tmin, tmax] (an all-zero column has I = 0 and fits any divisor), hence
-        //     a.b_j0 <= I0 / (t_i tmin),    a.b_j1 >= I1 / (t_i tmax)
-        // and L1, H2 follow as in the general form below with E = 0.
+        // Exact integer codes (q8_desc_rows): u_i.u_j = acc + 128 sum p_i + 128^3 =: I is an exact integer >= 0 and the real dot
+        // product of the two f32 rows is I / (t_i t_j) within a factor 1 +- 2^-23.  The columns are sorted by their divisor, and
+        // every 256-column tile knows its range [tlo, thi]: the kernel tracked, over the tiles, s_best = max I / tlo (an upper
+        // bound of the largest I_j / t_j) and s_second = the second largest I / thi over DISTINCT column groups (a lower
+        // bound of the second largest I_j / t_j), in f32 with the reciprocals rounded outwards; L1, H2 follow as in the
+        // general form below with E = 0.
         bool pruned = false;
         const float msb = *jb.maxsqB;
         const float b2min = __uint_as_float(~__float_as_uint(jb.qstatB[2]));
-        const float tmax = __uint_as_float(jb.xstatB[0]), tmin = __uint_as_float(~jb.xstatB[1]);
-        if (msb < 1e37f && b2min >= 0.f && tmin > 0.f && tmax >= tmin && tmax < 1e30f && nB >= 2 && e1 != kNone) {
+        const bool have2 = s_second > -1e9f;
+        if (msb < 1e37f && b2min >= 0.f && nB >= 2 && have2 && s_best < 1e30f) {
             const double a2 = (double)jb.sqA[row];
             const double na = sqrt(a2) * 1.00001, nb = sqrt((double)msb) * 1.00001;
             const double ti = (double)jb.ttA[row];
-            const double rc = (double)jb.cinA[row] + 2097152.0;
-            const double s_hi = ((double)e0 + rc) / (ti * (double)tmin) * (1.0 + 4e-7);
-            const double s_lo = fmax((double)e1 + rc, 0.0) / (ti * (double)tmax) * (1.0 - 4e-7);
+            const double s_hi = fmax((double)s_best, 0.0) / ti * (1.0 + 6e-7);
+            const double s_lo = fmax((double)s_second, 0.0) / ti * (1.0 - 6e-7);
             const double delta = 1.52587890625e-05 * (a2 + (double)msb + 2.0 * na * nb) + 1e-37;
             const double L1 = a2 + (double)b2min - 2.0 * s_hi - delta;
             const double H2 = a2 + (double)msb - 2.0 * s_lo + delta;
@@ -1841,17 +1848,11 @@ __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row
         } else {
             survive = true;
             // The exact list pass (match_list_i8_kernel) will name the columns that can be the row's best or second best by the
-            // canonical f32 distance: two distinct columns have u_i.u_j >= I1 = e1 + rc, so the second largest similarity is at
-            // least I1 / (t_i tmax), and a column can reach that only with I_j >= I1 tmin / tmax.  The margin 2e-4 covers the
-            // two 2^-23 factors and the rounding of the canonical distance itself (delta above: 2^-16 of the magnitudes).  The
-            // threshold travels in the row's d1 slot, in accumulator units (I - rc); INT_MIN: every column is a candidate.
-            int thr = -2147483647 - 1;
-            if (tmin > 0.f && tmax >= tmin && tmax < 1e30f && nB >= 2 && e1 != kNone) {
-                const double rc = (double)jb.cinA[row] + 2097152.0;
-                const double t = floor(((double)e1 + rc) * ((double)tmin / (double)tmax) * (1.0 - 2e-4)) - 2.0 - rc;
-                thr = t > -2147483000.0 ? (int)t : thr;
-            }
-            out_d1[jb.out_off + row] = __int_as_float(thr);
+            // canonical f32 distance: two distinct columns have I_j / t_j >= s_second, and a column of tile T can reach that
+            // only with I_j >= s_second tlo_T.  The list pass forms that threshold per tile (with a margin of 2e-4 for the two
+            // 2^-23 factors and the rounding of the canonical distance itself: delta above is 2^-16 of the magnitudes); what
+            // travels in the row's d1 slot is s_second (-inf: every column is a candidate).
+            out_d1[jb.out_off + row] = have2 && nB >= 2 ? s_second : -INFINITY;
         }
     } else if (row < nA) {
         const ScreenSet q = screen_set(jb);
@@ -2135,7 +2136,8 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     const bool exact = !BOUNDS && screen_exact(jb);
     if (!BOUNDS && exact && tid == 0) exact_flag[w.job] = 1u;  // (diagnostics: aps_match_screen_exact_jobs)
     const signed char* const opA = exact ? jb.AX : jb.AQ;
-    const signed char* const opB = exact ? jb.BX : jb.BQ;
+    const signed char* const opB = exact ? jb.BXs : jb.BQ;  // (exact: the columns in ascending order of their divisor)
+    const int* const cin_src = jb.cinBs;
     // experiment switches (APS_SCR_VARIANT): 1 = static priority for waves 4-7, 2 / 4 = waves 4-7 sleep 64 / 128 cycles after
     // every hand-over barrier (a stagger between the two waves of a SIMD), 8 = the odd waves instead of waves 4-7
 #ifdef APS_MATCH_TIMING  // (timing builds only, like the ablation bits)
@@ -2179,7 +2181,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     auto issue_cin = [&](int t, int buf) {
         if (exact && wave == 0) {
             const int col = min(t * kQTN + 4 * lane, ncin - 4);
-            const int* src = jb.cinB + col;
+            const int* src = cin_src + col;
             const uint32_t dst = lds_base + 3 * kQTileBytes + buf * 1024;
             uint32_t keep;
             asm volatile(
@@ -2208,6 +2210,34 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     // here: a 16x16x64 MFMA holds the SIMD's vector issue for half of its 16 cycles, twice the share of the 32x32x32 form.
     // `limit` (ragged last tile only) = number of valid columns counted from the block's first.
     int m_run[4] = {kNone, kNone, kNone, kNone};
+    // Exact codes: the columns come sorted by their divisor, and every kSeg tiles the integer best two (d0, d1) of the SEGMENT
+    // are turned into bounds on I / t_j with the segment's divisor range [tlo of its first tile, thi of its last] and join the
+    // row's best two in f32: s0 = max I / tlo, (f0, f1) = the two largest I / thi; then the integers start again.  (Per TILE
+    // the same fold cost 40 vector instructions per tile and wave: the screen ran 64.2 against 60.9 ms; a segment of eight
+    // tiles still spans only a tenth of the set's divisor range: 2.0x % of the rows survive either way.)
+    constexpr int kSeg = 8;
+    float s0[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, f0[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY},
+          f1[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int rc[4] = {0, 0, 0, 0};  // 128 sum p_i + 128^3 of the lane's four rows
+    if (exact) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rc[g] = jb.cinA[min(rowb + 16 * g + c, nA - 1)] + 2097152;
+    }
+    auto seg_fold = [&](int t_first, int t_last) __attribute__((always_inline)) {  // tiles t_first .. t_last are folded
+        const float rlo = jb.tscB[t_first].x, rhi = jb.tscB[t_last].y;  // (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int a0 = d0[g], a1 = d1[g];
+            const float i0 = (float)(a0 + rc[g]), i1 = (float)(a1 + rc[g]);  // (I < 2^24: exact)
+            const float hi = a0 != kNone ? i0 * rlo : -INFINITY;
+            const float l0 = a0 != kNone ? i0 * rhi : -INFINITY, l1 = a1 != kNone ? i1 * rhi : -INFINITY;
+            s0[g] = fmaxf(s0[g], hi);
+            const float n0 = fmaxf(f0[g], l0);
+            f1[g] = fmaxf(fminf(f0[g], l0), fmaxf(f1[g], l1));
+            f0[g] = n0;
+            d0[g] = d1[g] = kNone;
+        }
+    };
     auto fold_group = [&](auto PAR, auto G, auto MASK, int limit, auto FIRST, auto LAST) __attribute__((always_inline)) {
         constexpr int par = decltype(PAR)::value, g = decltype(G)::value;
         constexpr bool mask = decltype(MASK)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
@@ -2276,6 +2306,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
         const unsigned char* cin_t = cin_lds + b_cur * 1024;
         const unsigned char* cin_n = cin_lds + b_nxt * 1024;
         b_cur = b_nxt;
+
         static_for<0, kQBlk>([&](auto CB) {
             constexpr int cb = decltype(CB)::value;
             constexpr int kLast = kQBlk - 1;
@@ -2322,6 +2353,8 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
                                std::integral_constant<bool, last>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
+            // (block 0 of this tile has folded the LAST block of tile t - 1: where that completes a segment, the segment joins)
+            if (cb == 0 && exact && t > 0 && (t % kSeg) == 0) seg_fold(t - kSeg, t - 1);
             if (cb == kLast - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -2347,25 +2380,36 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             fold_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::false_type{}, 0, std::false_type{}, std::true_type{});
         });
     }
+    if (exact && ntiles > 0) seg_fold(((ntiles - 1) / kSeg) * kSeg, ntiles - 1);  // the last (possibly short) segment
     // the four lane quarters of a wave saw disjoint columns of the same rows; quarter kq then decides row group kq
     int e0 = kNone, e1 = kNone;
+    float s_best = -INFINITY, s_second = -INFINITY;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         int a0 = d0[g], a1 = d1[g];
+        float b0 = s0[g], c0 = f0[g], c1 = f1[g];
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
             const int p0 = __shfl_xor(a0, off), p1 = __shfl_xor(a1, off);
             const int n0 = max(a0, p0);
             a1 = max(min(a0, p0), max(a1, p1));
             a0 = n0;
+            b0 = fmaxf(b0, __shfl_xor(b0, off));
+            const float q0 = __shfl_xor(c0, off), q1 = __shfl_xor(c1, off);
+            const float m0 = fmaxf(c0, q0);
+            c1 = fmaxf(fminf(c0, q0), fmaxf(c1, q1));
+            c0 = m0;
         }
         if (g == kq) {
             e0 = a0;
             e1 = a1;
+            s_best = b0;
+            s_second = c1;
         }
     }
     const int row = rowb + lane;  // = rowb + 16 kq + c
-    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out, exact);
+    screen_tail<BOUNDS>(jb, w.job, row, e0, e1, lane, out_idx, out_d1, out_d2, surv_list, surv_count, prune_r2, prune_thr, bounds_out, exact,
+                        s_best, s_second);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2378,7 +2422,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
 // handful per row.  This kernel streams a pooled 512-row survivor tile against its B set exactly like the screening kernel
 // (same LDS image, DMA, hand-over, read-ahead, C operand), compares instead of folding - per (32-column block, row group)
 // the maximum of the lane's eight products against the row's threshold, and only on a hit (rare) the eight values one by
-// one - and appends (column) to the row's candidate list: cand[p * kCandCap ..], count in cand_cnt[p], p = the row's position
+// one - and appends (column; its position in the B set's divisor-sorted order) to the row's candidate list: cand[p * kCandCap ..], count in cand_cnt[p], p = the row's position
 // in the pooled survivor list (counts beyond the capacity are kept: such a row goes to the exact-f32 fallback).  match_rescore_kernel then evaluates the canonical f32
 // distance of every candidate and writes the row's (idx, d1, d2).  Whole register file claimed like the screening kernels.
 constexpr int kCandCap = 32;
@@ -2407,8 +2451,21 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
     constexpr int kNone = kScreenNone;
     // this lane's four rows: list entries w.row0 + wave * 64 + 16 g + c (entries past the tile's end: no row, nothing can hit)
     i32x4 aq[4][2];
-    int thr[4];
+    // thr[g]: the row's threshold in accumulator units for the tile being streamed, thr_prev[g]: for the tile before (the last
+    // block of a tile is tested in the first block of the next); s2[g] = the row's lower bound of its second largest I / t_j
+    // (screen_tail), rcr[g] = 128 sum p_i + 128^3.  A column of a tile with smallest divisor tlo can reach s2 only with
+    // I >= s2 tlo; margin 2e-4 (see screen_tail), -2 for the f32 product's rounding.  A tile of all-zero columns (tlo = 0: I = 0,
+    // similarity 0) qualifies only for a row whose bound is not positive.
+    int thr[4], thr_prev[4];
+    float s2[4];
+    int rcr[4];
     int pos_of[4];
+    auto tile_thr = [&](int g, float tlo) __attribute__((always_inline)) {
+        if (!(s2[g] > -1e9f)) return -2147483647 - 1;          // no bound (or a dead lane's +inf, below): everything / nothing
+        if (!(tlo > 0.f)) return s2[g] > 0.f ? 2147483647 : -2147483647 - 1;
+        const float v = floorf(s2[g] * tlo * (1.0f - 2e-4f)) - 2.0f;
+        return v < 2.0e9f ? (int)v - rcr[g] : 2147483647;
+    };
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int e = wave * 64 + 16 * g + c;
@@ -2416,7 +2473,9 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
         pos_of[g] = w.row0 + (live ? e : 0);
         const int arow = (int)row_list[pos_of[g]];  // (the pooled list names rows within their job: list_pool_kernel)
         const MatchJob& jr = jobs[list_job[pos_of[g]]];
-        thr[g] = live ? __float_as_int(thr_slot[jr.out_off + arow]) : 2147483647;
+        s2[g] = live ? thr_slot[jr.out_off + arow] : INFINITY;  // (+inf: a lane without a row never hits)
+        rcr[g] = jr.cinA[arow] + 2097152;
+        thr[g] = thr_prev[g] = 2147483647;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             aq[g][ks] = *reinterpret_cast<const i32x4*>(jr.AX + (size_t)arow * kDim + 64 * ks + 16 * kq);
@@ -2428,7 +2487,7 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
         const int piece = wave * 4 + u;
         const int lrow = 8 * piece + dma_sub;
         const int brow = min(t * kQTN + lrow, nB - 1);
-        const signed char* src = jb.BX + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
+        const signed char* src = jb.BXs + (size_t)brow * kDim + ((dma_pos ^ ((lrow >> 1) & 7)) << 4);
         const uint32_t dst = lds_base + buf * kQTileBytes + piece * 1024;
         uint32_t keep;
         asm volatile(
@@ -2441,7 +2500,7 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
     auto issue_cin = [&](int t, int buf) {
         if (wave == 0) {
             const int col = min(t * kQTN + 4 * lane, ncin - 4);
-            const int* src = jb.cinB + col;
+            const int* src = jb.cinBs + col;
             const uint32_t dst = lds_base + 3 * kQTileBytes + buf * 1024;
             uint32_t keep;
             asm volatile(
@@ -2461,7 +2520,7 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[p][u][g][e] = kNone;
     // the test of a finished block for row group g: col0 = first column of the block; columns >= nB never count
-    auto test_group = [&](auto PAR, auto G, int col0) __attribute__((always_inline)) {
+    auto test_group = [&](auto PAR, auto G, int col0, const int (&thr)[4]) __attribute__((always_inline)) {
         constexpr int par = decltype(PAR)::value, g = decltype(G)::value;
         int v[8];
 #pragma unroll
@@ -2525,6 +2584,14 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
         const unsigned char* cin_t = cin_lds + b_cur * 1024;
         const unsigned char* cin_n = cin_lds + b_nxt * 1024;
         b_cur = b_nxt;
+        {  // this tile's thresholds (its smallest divisor: wave-uniform); the previous tile's stay for the first block's test
+            const float tlo = jb.tscB[t].z;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                thr_prev[g] = thr[g];
+                thr[g] = tile_thr(g, tlo);
+            }
+        }
         static_for<0, kQBlk>([&](auto CB) {
             constexpr int cb = decltype(CB)::value;
             constexpr int kLast = kQBlk - 1;
@@ -2561,7 +2628,10 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
                         cin[u] = *reinterpret_cast<const i32x4*>(cin_n + (16 * u) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (cb > 0 || t > 0) test_group(std::integral_constant<int, par ^ 1>{}, S, col_prev);
+                if (cb > 0)
+                    test_group(std::integral_constant<int, par ^ 1>{}, S, col_prev, thr);
+                else if (t > 0)
+                    test_group(std::integral_constant<int, par ^ 1>{}, S, col_prev, thr_prev);
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (cb == kLast - 1) {
@@ -2572,7 +2642,7 @@ __global__ __launch_bounds__(512) void match_list_i8_kernel(const MatchJob* __re
     }
     if (ntiles > 0) {
         const int col_last = (ntiles - 1) * kQTN + (kQBlk - 1) * 32;
-        static_for<0, 4>([&](auto S) { test_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, col_last); });
+        static_for<0, 4>([&](auto S) { test_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, col_last, thr); });
     }
     __syncthreads();
     if (tid < w.list_cnt) cand_cnt[w.row0 + tid] = s_cnt[tid];  // (row e of the tile = wave e / 64, group (e % 64) / 16, c = e % 16: s_cnt's order)
@@ -2601,7 +2671,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const MatchJob* __re
         const float* pa = jb.PA + (size_t)row * kDim;
         const float a2 = jb.sqA[row];
         for (unsigned int e = e0; e < cnt; e += 8u) {
-            const int id = (int)cand[(size_t)r * kCandCap + e];
+            const int id = (int)jb.permB[cand[(size_t)r * kCandCap + e]];  // (the list pass names positions in the sorted column order)
             const float d = exact_dist(pa, jb.PB + (size_t)id * kDim, a2, jb.sqB[id]);
             top2_merge(b, bi, s2, d, id, INFINITY);
         }
@@ -2774,6 +2844,7 @@ __global__ void filter_emit_rows_kernel(const FilterJob* __restrict__ fj,
 // launch.  An Arena in counting mode only adds up the sizes (the dry run that sizes the slab).
 struct Arena {
     Ws<unsigned char> slab;
+    Ws<unsigned char> sorted;  // the sets' column sides in divisor order (sort_columns)
     size_t off = 0, cap = 0;
     bool counting = false;
     void* take(size_t bytes) {
@@ -2809,6 +2880,12 @@ struct Prepared {
     Buf<signed char> QX;  // round 6: the exact integer codes (q8_desc_rows), the rows' divisors, 128 x the code sums (n_pad entries)
     Buf<float> tt;
     Buf<int> cin;
+    // ... and the set as a COLUMN set in ascending order of the divisors (sort_columns; arena batches only - a set without
+    // these has its "no exact code" word forced, so that its jobs take the rounded codes)
+    signed char* BXs = nullptr;
+    int* cins = nullptr;
+    float4* tsc = nullptr;
+    uint32_t* perm = nullptr;
     int64_t n_pad = 0;
     Buf<unsigned> part;  // per-workgroup maxima of prep_desc / q8_desc (PrepJob::part)
     int nb1 = 0, nb2 = 0;
@@ -2867,7 +2944,65 @@ static void prepare(const float* X_dev, int64_t n, int64_t ld, int layout, bool 
     q8_desc_kernel<<<out.nb2, 256, 0, st>>>(out.P, n, out.QA, out.QB, out.dnq, out.invs, out.sumq, qstat, out.sq, out.dn, n_pad, out.stat,
                                             out.aug, out.stat + 2, out.part + (size_t)5 * out.nb1, out.QX, out.tt, out.cin);
     prep_stats_kernel<<<1, 256, 0, st>>>(out.part, out.nb1, out.nb2, out.stat, 1, 2);
+    // (no sorted column side here - sort_columns runs for arena batches only: the set's jobs take the rounded codes)
+    APS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out.stat + 10), 1, 1, st));
     check_launch("prep_desc_kernel");
+}
+
+// ---- the column side of the exact codes in ascending order of the divisors (round 6) -------------------------------------
+// The exact screen's only slack is the range of the column divisors it has to assume.  Over a whole set that range is ~0.7 %
+// (SIFT: t = 512 +- 0.35 %), and ONE odd column - a descriptor saturated at 255, say - would widen it for every row; sorted by
+// t, a 256-column tile spans 1/78 of it and an outlier only spoils its own tile.  Per set: keys (the divisor's bit pattern;
+// all-zero rows, which fit any divisor, and padding last) -> rocPRIM segmented sort with the row index as the value ->
+// gather of the code bytes and of 128 sum p in sorted order, and per tile the divisor range of its non-zero columns with the
+// reciprocals rounded outwards.
+struct SortSet {
+    const float* tt;
+    const signed char* QX;
+    const int* cin;
+    int n, off;  // rows, first slot in the batch-wide key arrays
+    signed char* BXs;
+    int* cins;
+    float4* tsc;
+};
+constexpr uint32_t kSortLast = 0x7f7fffffu;  // (FLT_MAX: behind every real divisor)
+__global__ __launch_bounds__(256) void sort_keys_kernel(const SortSet* __restrict__ sets, const int* __restrict__ blk_ptr, int n_sets,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int j = prep_find_job(blk_ptr, n_sets, (int)blockIdx.x);
+    const SortSet S = sets[j];
+    const int k = ((int)blockIdx.x - blk_ptr[j]) * 256 + (int)threadIdx.x;
+    if (k >= S.n) return;
+    // (set index above the divisor's bit pattern: ONE radix sort orders every set of the batch - rocPRIM's segmented sort took
+    // 0.44 ms for 64 segments of 20 k keys, the plain sort of the 1.27 M composite keys a quarter of that)
+    const uint32_t tb = S.cin[k] == -2097152 ? kSortLast : __float_as_uint(S.tt[k]);  // (128 sum p = -128^3: an all-zero row)
+    keys[S.off + k] = ((unsigned long long)j << 32) | tb;
+    vals[S.off + k] = (uint32_t)k;
+}
+__global__ __launch_bounds__(256) void sort_gather_kernel(const SortSet* __restrict__ sets, const int* __restrict__ blk_ptr, int n_sets,
+                                                          const unsigned long long* __restrict__ keys_sorted, const uint32_t* __restrict__ perm) {
+    const int j = prep_find_job(blk_ptr, n_sets, (int)blockIdx.x);
+    const SortSet S = sets[j];
+    const int g = ((int)blockIdx.x - blk_ptr[j]) * 256 + (int)threadIdx.x;
+    const int k = g >> 3, part = g & 7;  // eight lanes per row, 16 bytes each
+    if (k >= S.n) return;
+    const uint32_t src = perm[S.off + k];
+    typedef __attribute__((address_space(1))) signed char GI8;
+    *(GU32x4*)((GI8*)S.BXs + (size_t)k * kDim + 16 * part) = *(const GU32x4*)((const GI8*)S.QX + (size_t)src * kDim + 16 * part);
+    if (part != 0) return;
+    S.cins[k] = S.cin[src];
+    const uint32_t key = (uint32_t)keys_sorted[S.off + k];
+    if (key == kSortLast) return;
+    const float t = __uint_as_float(key);
+    const int T = k >> 8;
+    float* sc = reinterpret_cast<float*>(S.tsc + T);
+    if ((k & 255) == 0) {  // the tile's first column: its smallest divisor (the key is real, so the tile has non-zero columns)
+        sc[0] = __fdiv_rn(1.0f, t) * 1.0000004f;  // (rounded to nearest, then pushed up by 3 ulp)
+        sc[2] = t;
+    }
+    if ((k & 255) == 255 || k == S.n - 1 || (uint32_t)keys_sorted[S.off + k + 1] == kSortLast) {  // ... and its last non-zero column
+        sc[1] = __fdiv_rn(1.0f, t) * 0.9999996f;  // (... down)
+        sc[3] = t;
+    }
 }
 
 // Several sets in four launches on the caller's stream (prep_desc_batch_kernel, q8_desc_batch_kernel, each followed by the fold of
@@ -2880,6 +3015,81 @@ struct PrepRequest {
     Prepared* out;
     float* stat_ext;
 };
+// The sorted column sides of a batch (see sort_keys_kernel).  Planned on the host before the batch's first launch - buffers, set
+// table, block tables - so that the whole preparation is ONE upload and one chain of launches (the bench's matching runs
+// beside the previous panorama's 737 MB download: every extra small upload or host synchronisation inside the chain waited
+// its turn behind that copy, 1 ms became 3).
+struct SortPlan {
+    std::vector<SortSet> sets;
+    std::vector<int> bk{0}, bg{0};
+    size_t total = 0, tmp_bytes = 0;
+    unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+    uint32_t *vals_in = nullptr, *vals_out = nullptr;
+    unsigned char* tsc0 = nullptr;
+    size_t tsc_bytes = 0;
+    int key_bits = 33;
+    Ws<unsigned char> tmp;
+};
+static void sort_plan(const std::vector<PrepRequest>& req, Arena& arena, SortPlan& sp) {
+    size_t bytes = 0;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    for (const PrepRequest& r : req) {
+        if (r.n <= 0) continue;
+        const Prepared& o = *r.out;
+        sp.sets.push_back(SortSet{o.tt, o.QX, o.cin, (int)r.n, (int)sp.total, nullptr, nullptr, nullptr});
+        sp.total += (size_t)r.n;  // (dense: the sorted keys of set j occupy [off_j, off_j + n_j))
+        sp.bk.push_back(sp.bk.back() + (int)cdiv((size_t)r.n, 256));
+        sp.bg.push_back(sp.bg.back() + (int)cdiv((size_t)r.n * 8, 256));
+        bytes += up((size_t)r.n * kDim) + up((size_t)o.n_pad * sizeof(int)) + up(cdiv((size_t)r.n, 256) * sizeof(float4));
+    }
+    if (sp.sets.empty()) return;
+    APS_REQUIRE(sp.total < ((size_t)1 << 31), APS_E_DIM, "too many descriptor rows in one batch (%zu)", sp.total);
+    const size_t key_bytes = up(sp.total * sizeof(unsigned long long)), val_bytes = up(sp.total * sizeof(uint32_t));
+    arena.sorted.alloc(bytes + 2 * key_bytes + 2 * val_bytes);
+    unsigned char* base = arena.sorted.get();
+    sp.keys_in = reinterpret_cast<unsigned long long*>(base);
+    sp.keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
+    sp.vals_in = reinterpret_cast<uint32_t*>(base + 2 * key_bytes);
+    sp.vals_out = reinterpret_cast<uint32_t*>(base + 2 * key_bytes + val_bytes);  // = the sets' perm arrays, back to back
+    size_t at = 2 * key_bytes + 2 * val_bytes;
+    size_t si = 0;
+    for (const PrepRequest& r : req) {
+        if (r.n <= 0) continue;
+        Prepared& o = *r.out;
+        SortSet& S = sp.sets[si++];
+        S.BXs = o.BXs = reinterpret_cast<signed char*>(base + at);
+        at += up((size_t)r.n * kDim);
+        S.cins = o.cins = reinterpret_cast<int*>(base + at);
+        at += up((size_t)o.n_pad * sizeof(int));
+        o.perm = sp.vals_out + S.off;
+    }
+    sp.tsc0 = base + at;
+    si = 0;
+    for (const PrepRequest& r : req) {  // (the tile tables last, back to back: one zero fill)
+        if (r.n <= 0) continue;
+        Prepared& o = *r.out;
+        SortSet& S = sp.sets[si++];
+        S.tsc = o.tsc = reinterpret_cast<float4*>(base + at);
+        at += up(cdiv((size_t)r.n, 256) * sizeof(float4));
+    }
+    sp.tsc_bytes = (size_t)(base + at - sp.tsc0);
+    int set_bits = 1;
+    while (((size_t)1 << set_bits) < sp.sets.size()) ++set_bits;
+    sp.key_bits = 32 + set_bits;
+    APS_HIP(rocprim::radix_sort_pairs(nullptr, sp.tmp_bytes, sp.keys_in, sp.keys_out, sp.vals_in, sp.vals_out, sp.total, 0, sp.key_bits, stream()));
+    sp.tmp.alloc(sp.tmp_bytes);
+}
+// (dsets / dbk / dbg: the plan's tables on the device, part of the batch's one upload)
+static void sort_launch(SortPlan& sp, const SortSet* dsets, const int* dbk, const int* dbg) {
+    if (sp.sets.empty()) return;
+    APS_HIP(hipMemsetAsync(sp.tsc0, 0, sp.tsc_bytes, stream()));
+    // (the 128 sum p of sorted positions past a set's rows are never used: the kernels clamp to n - 1 / mask by nB)
+    sort_keys_kernel<<<(unsigned)sp.bk.back(), 256, 0, stream()>>>(dsets, dbk, (int)sp.sets.size(), sp.keys_in, sp.vals_in);
+    APS_HIP(rocprim::radix_sort_pairs(sp.tmp.get(), sp.tmp_bytes, sp.keys_in, sp.keys_out, sp.vals_in, sp.vals_out, sp.total, 0, sp.key_bits, stream()));
+    sort_gather_kernel<<<(unsigned)sp.bg.back(), 256, 0, stream()>>>(dsets, dbg, (int)sp.sets.size(), sp.keys_out, sp.vals_out);
+    check_launch("sort_gather_kernel");
+}
+
 static void prepare_batch(const std::vector<PrepRequest>& req, int layout, Arena* arena = nullptr) {
     std::vector<PrepJob> jobs;
     std::vector<int> bp{0}, bq{0};
@@ -2904,14 +3114,33 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout, Arena
     }
     sync_q8_symmetric_switch();
     if (jobs.empty()) return;
-    Ws<PrepJob> dj(jobs.size());
-    Ws<int> dbp(bp.size()), dbq(bq.size()), dbq1(jobs.size() + 1);
+    SortPlan sp;
+    if (arena) sort_plan(req, *arena, sp);
     std::vector<int> bq1(jobs.size() + 1);  // the FIRST q8 workgroup of every set (the exact codes' probe below)
     for (size_t j = 0; j <= jobs.size(); ++j) bq1[j] = (int)j;
-    APS_HIP(hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, stream()));
-    APS_HIP(hipMemcpyAsync(dbp, bp.data(), bp.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
-    APS_HIP(hipMemcpyAsync(dbq, bq.data(), bq.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
-    APS_HIP(hipMemcpyAsync(dbq1, bq1.data(), bq1.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    // every host table of the batch in ONE upload: [PrepJob][SortSet][bp][bq][bq1][bk][bg]
+    auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+    const size_t o_jobs = 0, o_sets = o_jobs + up16(jobs.size() * sizeof(PrepJob)), o_bp = o_sets + up16(sp.sets.size() * sizeof(SortSet)),
+                 o_bq = o_bp + up16(bp.size() * sizeof(int)), o_bq1 = o_bq + up16(bq.size() * sizeof(int)),
+                 o_bk = o_bq1 + up16(bq1.size() * sizeof(int)), o_bg = o_bk + up16(sp.bk.size() * sizeof(int)),
+                 o_end = o_bg + up16(sp.bg.size() * sizeof(int));
+    std::vector<unsigned char> blob(o_end, 0);
+    std::memcpy(&blob[o_jobs], jobs.data(), jobs.size() * sizeof(PrepJob));
+    if (!sp.sets.empty()) std::memcpy(&blob[o_sets], sp.sets.data(), sp.sets.size() * sizeof(SortSet));
+    std::memcpy(&blob[o_bp], bp.data(), bp.size() * sizeof(int));
+    std::memcpy(&blob[o_bq], bq.data(), bq.size() * sizeof(int));
+    std::memcpy(&blob[o_bq1], bq1.data(), bq1.size() * sizeof(int));
+    std::memcpy(&blob[o_bk], sp.bk.data(), sp.bk.size() * sizeof(int));
+    std::memcpy(&blob[o_bg], sp.bg.data(), sp.bg.size() * sizeof(int));
+    Ws<unsigned char> dblob(o_end);
+    APS_HIP(hipMemcpyAsync(dblob, blob.data(), o_end, hipMemcpyHostToDevice, stream()));
+    const PrepJob* dj = reinterpret_cast<const PrepJob*>(dblob.get() + o_jobs);
+    const SortSet* dsets = reinterpret_cast<const SortSet*>(dblob.get() + o_sets);
+    const int* dbp = reinterpret_cast<const int*>(dblob.get() + o_bp);
+    const int* dbq = reinterpret_cast<const int*>(dblob.get() + o_bq);
+    const int* dbq1 = reinterpret_cast<const int*>(dblob.get() + o_bq1);
+    const int* dbk = reinterpret_cast<const int*>(dblob.get() + o_bk);
+    const int* dbg = reinterpret_cast<const int*>(dblob.get() + o_bg);
     {
         Prof prof("match_prep");
         prep_desc_batch_kernel<<<(unsigned)bp.back(), kPrepThreads, 0, stream()>>>(dj, dbp, (int)jobs.size());
@@ -2923,9 +3152,15 @@ static void prepare_batch(const std::vector<PrepRequest>& req, int layout, Arena
         q8_desc_batch_kernel<<<(unsigned)jobs.size(), 256, 0, stream()>>>(dj, dbq1, (int)jobs.size());
         q8_desc_batch_kernel<<<(unsigned)bq.back(), 256, 0, stream()>>>(dj, dbq, (int)jobs.size());
         prep_stats_batch_kernel<<<(unsigned)jobs.size(), 256, 0, stream()>>>(dj, 2);
+        if (arena) {
+            sort_launch(sp, dsets, dbk, dbg);
+        } else {  // no sorted column side: the sets' jobs must take the rounded codes ("some row has no exact code", word [10])
+            for (const PrepRequest& r : req)
+                if (r.n > 0) APS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(r.out->stat + 10), 1, 1, stream()));
+        }
     }
     check_launch("prep_desc_batch_kernel");
-    APS_HIP(hipStreamSynchronize(stream()));  // the host tables (and dj / dbp / dbq) must outlive the launches
+    APS_HIP(hipStreamSynchronize(stream()));  // the host tables (and the device blob, the sort's scratch) must outlive the launches
 }
 
 static void prepare_alloc(int64_t n, Prepared& out, hipStream_t st, float* stat_ext, Arena* arena) {
@@ -2990,6 +3225,10 @@ static MatchJob make_job(const Prepared& a, const Prepared& b, int nA, int nB, i
     j.xstatA = reinterpret_cast<const unsigned*>(a.stat + 8);
     j.xstatB = reinterpret_cast<const unsigned*>(b.stat + 8);
     j.ncinB = (int)b.n_pad;
+    j.BXs = b.BXs;
+    j.cinBs = b.cins;
+    j.tscB = b.tsc;
+    j.permB = b.perm;
     return j;
 }
 

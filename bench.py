@@ -776,7 +776,24 @@ def main():
         while deferred:
             start_copy(deferred.pop(0))
 
+    # Round 6: the copy starts a few milliseconds INTO the matching, not at its first instruction: the matcher opens with its
+    # bandwidth-bound operand preparation (~1.3 ms: a dozen short launches, one table upload), and beside the 737 MB download that
+    # phase took 2.5-3.6 ms; the int8 screen that follows (60 ms) does not care.  A timer thread enqueues the copy (the main
+    # thread is inside the matcher's C call by then, without the GIL); drain() joins it.
+    import threading
+
+    timers = []
+
+    def flush_deferred_soon():
+        if not deferred and not pending:
+            return
+        tm = threading.Timer(0.004, flush_deferred)
+        timers.append(tm)
+        tm.start()
+
     def drain():
+        while timers:
+            timers.pop(0).join()
         flush_deferred()
         while pending:
             pending.pop(0)[0].synchronize()
@@ -802,10 +819,10 @@ def main():
                     evs[i] = torch.cuda.Event()
                     evs[i].record(copy_stream)
             pano_, info_ = par.stitch_distributed(input_, up, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs,
-                                                  after_features=flush_deferred)
+                                                  after_features=flush_deferred_soon)
         else:
             pano_, info_ = par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0,
-                                                  after_features=flush_deferred)
+                                                  after_features=flush_deferred_soon)
         t_d = time.perf_counter()
         if rank == 0 and pano_ is not None and pano_.numel():
             pano_ = to_host(pano_, wait=sync_download)

@@ -37,7 +37,7 @@ def run(tag, reps=3):
     import ctypes
     rows, surv = ctypes.c_int64(), ctypes.c_int64()
     capi.lib.aps_match_screen_stats(ctypes.byref(rows), ctypes.byref(surv))
-    print(f"{tag:>16}: screen {best:.2f} ms (last call: wall {wall:.2f}, cand {prof['match_cand_f16'][0]:.2f}, prep {prof['match_prep'][0]:.2f}), survivors {100.0 * surv.value / max(rows.value, 1):.2f} %", flush=True)
+    print(f"{tag:>16}: screen {best:.2f} ms (last call: wall {wall:.2f}, cand {prof.get('match_cand_f16', (0.0, 0))[0]:.2f} list {prof.get('match_list_i8', (0.0, 0))[0]:.2f} rescore {prof.get('match_rescore', (0.0, 0))[0]:.2f}, prep {prof['match_prep'][0]:.2f}), survivors {100.0 * surv.value / max(rows.value, 1):.2f} %", flush=True)
 
 run("exact c=128")
 os.environ["APS_MATCH_NO_EXACT"] = "1"
