@@ -638,12 +638,43 @@ __device__ __forceinline__ void q8_desc_rows(int64_t g, const float* __restrict_
                 qq += __shfl_xor(qq, off);
             }
             if (!__any(ok)) continue;  // (no row of the wave has integers at this try: the sixteen divisions below are the expensive part)
-            const float tq = sqrtf((float)qq);  // (qq <= 128 * 255^2 < 2^24: exact; sqrtf is correctly rounded here)
+            float tq = sqrtf((float)qq);  // (qq <= 128 * 255^2 < 2^24: exact; sqrtf is correctly rounded here)
             bool same = ok;
 #pragma unroll
             for (int e = 0; e < 16; ++e) same = same && __float_as_uint(__fdiv_rn(uf[e], tq)) == __float_as_uint(xs[e]);
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) same = (__shfl_xor(same ? 1 : 0, off) != 0) && same;
+            // The representation (u, t) is unique only up to a common factor: a row whose integers are small has several, and
+            // the one with the LARGEST integers has the divisor closest to the ~512 of ordinary rows - which is what the sorted
+            // column side wants (a one-hot row would come out as u = 1, t = 1 and loosen its whole segment's bounds 500-fold).
+            // Try k u with k = floor(255 / max u) under the same bit-for-bit verification, else the largest power of two (exact).
+            if (__any(same && !done)) {
+                float umax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) umax = fmaxf(umax, uf[e]);
+#pragma unroll
+                for (int off = 1; off < 8; off <<= 1) umax = fmaxf(umax, __shfl_xor(umax, off));
+                // (only rows that are clearly under-scaled, max u < 64: an ordinary SIFT row has max u >= 512 / sqrt(128) = 45, ~100
+                // typically, and must keep its t ~ 512 - doubling the 38 % of rows whose max u is below 128 would split every
+                // set's divisors into two clusters)
+                const float kf = (umax >= 1.f && umax < 64.f) ? floorf(255.f / umax) : 1.f;
+                if (__any(same && !done && kf >= 2.f)) {
+                    const float tk = sqrtf((float)qq * kf * kf);  // (k^2 qq <= 128 * 255^2: exact)
+                    bool same_k = same && kf >= 2.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) same_k = same_k && __float_as_uint(__fdiv_rn(uf[e] * kf, tk)) == __float_as_uint(xs[e]);
+#pragma unroll
+                    for (int off = 1; off < 8; off <<= 1) same_k = (__shfl_xor(same_k ? 1 : 0, off) != 0) && same_k;
+                    float k2 = 1.f;  // the fallback: the largest power of two <= kf scales u and t exactly
+                    while (k2 * 2.f <= kf) k2 *= 2.f;
+                    const float ks = same_k ? kf : (kf >= 2.f ? k2 : 1.f);
+                    if (same && !done && ks > 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) uf[e] *= ks;
+                        tq = same_k ? tk : tq * ks;
+                    }
+                }
+            }
             if (same && !done) {
                 found = true;
                 done = true;
@@ -1785,7 +1816,14 @@ __device__ __forceinline__ ScreenSet screen_set(const MatchJob& jb) {
 constexpr int kScreenNone = -2147483647 - 1;
 
 // Does this job take the exact integer codes (q8_desc_rows)?  Every row of both sets has one.
-__device__ __forceinline__ bool screen_exact(const MatchJob& jb) { return (jb.xstatA[2] | jb.xstatB[2]) == 0u; }
+// ... and the column set's divisors lie within 2 % of each other: a column with an odd divisor (a descriptor concentrated in one or
+// two bins saturates at 255: t = 255 .. 360 instead of ~512) shares its tile with 250 ordinary columns, whose bounds it would
+// inflate beyond any real best similarity - no row of the job could be dismissed, where the rounded codes lose nothing.
+__device__ __forceinline__ bool screen_exact(const MatchJob& jb) {
+    if ((jb.xstatA[2] | jb.xstatB[2]) != 0u) return false;
+    const float tmax = __uint_as_float(jb.xstatB[0]), tmin = __uint_as_float(~jb.xstatB[1]);
+    return tmin > 0.f && tmax <= 1.02f * tmin;
+}
 
 template <bool BOUNDS>
 __device__ __forceinline__ void screen_tail(const MatchJob& jb, int job, int row, int e0, int e1, int lane,
@@ -2216,6 +2254,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
     // the same fold cost 40 vector instructions per tile and wave: the screen ran 64.2 against 60.9 ms; a segment of eight
     // tiles still spans only a tenth of the set's divisor range: 2.0x % of the rows survive either way.)
     constexpr int kSeg = 8;
+    int seg_first = 0;  // first tile of the segment being collected (wave-uniform)
     float s0[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, f0[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY},
           f1[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int rc[4] = {0, 0, 0, 0};  // 128 sum p_i + 128^3 of the lane's four rows
@@ -2354,7 +2393,12 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
                 __builtin_amdgcn_sched_barrier(0);
             });
             // (block 0 of this tile has folded the LAST block of tile t - 1: where that completes a segment, the segment joins)
-            if (cb == 0 && exact && t > 0 && (t % kSeg) == 0) seg_fold(t - kSeg, t - 1);
+            // Segments: the FIRST and the LAST tile alone (where columns with an odd divisor end up: they then loosen the bounds of
+            // 256 columns, not of a segment's 2048), kSeg tiles each in between.
+            if (cb == 0 && exact && t > 0 && (t == 1 || t - seg_first == kSeg || t == ntiles - 1)) {
+                seg_fold(seg_first, t - 1);
+                seg_first = t;
+            }
             if (cb == kLast - 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -2380,7 +2424,7 @@ __global__ __launch_bounds__(512) void match_screen_i8x16_kernel(const MatchJob*
             fold_group(std::integral_constant<int, (kQBlk - 1) & 1>{}, S, std::false_type{}, 0, std::false_type{}, std::true_type{});
         });
     }
-    if (exact && ntiles > 0) seg_fold(((ntiles - 1) / kSeg) * kSeg, ntiles - 1);  // the last (possibly short) segment
+    if (exact && ntiles > 0) seg_fold(seg_first, ntiles - 1);  // the last segment
     // the four lane quarters of a wave saw disjoint columns of the same rows; quarter kq then decides row group kq
     int e0 = kNone, e1 = kNone;
     float s_best = -INFINITY, s_second = -INFINITY;

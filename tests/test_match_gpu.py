@@ -627,6 +627,20 @@ def test_int8_screen_exact_integer_codes(fm, gpu, monkeypatch):
     _screen_ab(fm, monkeypatch, ah, bh, 0.6, 3.5, True)
     k, s_exact, s_general = shares(ah, bh, 0.6, 3.5, True)
     assert k <= s_exact <= s_general, (k, s_exact, s_general)
+    # Outlier divisors: a few columns whose norm is far from the set's (a descriptor concentrated in one or two bins saturates at
+    # 255 and has t = 255 .. 360 instead of ~512).  Such a column would inflate the bounds of the 250 ordinary columns it shares a
+    # tile with beyond any real best similarity, so a column set whose divisors spread by more than 2 % keeps the rounded codes:
+    # same lists, and the screen dismisses as many rows as it does without the exact codes.
+    bo = bh.copy()
+    for k, (i0, v0, i1, v1) in enumerate(((3, 255, 3, 255), (10, 255, 77, 255), (5, 200, 99, 120))):
+        bo[40 + k] = 0
+        bo[40 + k, i0] = v0
+        bo[40 + k, i1] = v1
+    _screen_ab(fm, monkeypatch, ah, bo, 0.6, 3.5, True)
+    k_o, s_o, s_og = shares(ah, bo, 0.6, 3.5, True, want_exact=False)
+    assert k_o <= s_o == s_og <= 1.1 * s_general + 16, (k_o, s_o, s_og, s_general)
+    _screen_ab(fm, monkeypatch, bo, ah, 0.6, 3.5, True)   # (as the ROW side the same set is no obstacle)
+    shares(bo, ah, 0.6, 3.5, True, want_exact=True)
     # degenerate rows: a duplicated best column (d1 == d2), all-zero rows (divisor eps), saturated and one-hot rows (an
     # all-255 row has no exact code within the tries: its set falls back to the general codes)
     b[100] = b[ib[0]]
