@@ -849,11 +849,16 @@ def main():
             capi.profile_enable(False)
     # the GPU's clock and power during one more untimed step, by stage (GpuStateSampler; rank 0 reports its own GPU)
     gpu_state = None
-    if args.warmup > 0:  # (every rank takes the step: it runs the sharded driver's collectives)
+    if args.warmup > 0:  # (every rank takes the steps: they run the sharded driver's collectives)
+        # Two more untimed steps in the STEADY-STATE form (the panorama's download deferred into the next step's matching): the
+        # synchronous warm-up steps above never hold two panoramas at once, so the allocator's second 737 MB canvas used to be
+        # malloc'ed - and its pages scrubbed - inside the second TIMED step (+12-18 ms there in every run's series).  The second
+        # of the two is also the step the GPU's clock and power are sampled in.
+        step()
         sampler = GpuStateSampler(local_rank)
         sampler.start()
         t_s0 = time.perf_counter()
-        _, info_s = step(sync_download=True)
+        _, info_s = step()
         barrier()
         sampler.stop()
         if sampler.files and rank == 0:
