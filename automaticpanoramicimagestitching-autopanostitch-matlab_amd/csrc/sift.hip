@@ -1868,6 +1868,13 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         Ws<unsigned int> d_count(2);  // [0] cells, [1] refined records
         const float thr = (float)(int)std::floor(0.5 * params->contrast_threshold / nl * 255.0);
         unsigned int h_counts[2] = {0, 0};
+#ifdef APS_SIFT_TIMING  // (timing builds only, results are wrong: APS_SIFT_ABLATE=2 stops after the pyramid, 1 after the extrema sweep)
+        static const int sift_ablate = std::getenv("APS_SIFT_ABLATE") ? std::atoi(std::getenv("APS_SIFT_ABLATE")) : 0;
+        if (sift_ablate == 2) {
+            APS_HIP(hipStreamSynchronize(stream()));
+            return;
+        }
+#endif
         for (int attempt = 0; attempt < 2; ++attempt) {
             APS_HIP(hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned int), stream()));
             if (!std::getenv("APS_EXTREMA_TILES") && !std::getenv("APS_EXTREMA_MARCH")) {
@@ -1959,6 +1966,9 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             cells_cap = h_counts[0];
             cells.alloc(cells_cap);
         }
+#ifdef APS_SIFT_TIMING
+        if (sift_ablate == 1) return;
+#endif
         if (h_counts[0] > 0) {
             Prof prof("sift_refine");
             refine_kernel<<<cdiv(h_counts[0], 256), 256, 0, stream()>>>(d_table, cells, d_count, cells_cap,
