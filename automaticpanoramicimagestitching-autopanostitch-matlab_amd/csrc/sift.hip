@@ -17,6 +17,11 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#ifdef APS_DBG
+#include <atomic>
+#include <map>
+#include <mutex>
+#endif
 
 #include "aps_internal.h"
 
@@ -1773,6 +1778,56 @@ static int num_octaves(int H, int W) {
     return (int)std::lrint(std::log((double)mn) / std::log(2.0) - 2.0) + 1;
 }
 
+
+#ifdef APS_DBG
+// Debug builds only (`make debug`): the co-residency experiment of DESIGN.md section 5, victim side.  APS_DBG_REPLAY=R makes
+// aps_sift_extract launch the extrema sweep, refine_kernel, orient_kernel and descr_kernel R more times each on the inputs the
+// first launch saw and compare the results on the device (order-free checksums for the atomically appended lists, word by
+// word for the indexed outputs); the pyramid's checksum is kept per image pointer and compared between calls.
+namespace dbg {
+enum { kPyrChanged, kExtReplays, kExtDiff, kRefReplays, kRefDiff, kOriReplays, kOriDiff, kOriWords, kDesReplays, kDesDiff, kDesWords, kCalls, kNStat };
+static std::atomic<long long> g_stat[kNStat];
+static std::mutex g_mu;
+static std::map<const void*, unsigned long long> g_pyr;
+__global__ void cks_kernel(const unsigned int* __restrict__ p, size_t n_rec, int wpr, int positional, unsigned long long* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    unsigned long long h = 0;
+    if (i < n_rec) {
+        h = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < wpr; ++k) {
+            h ^= p[i * wpr + k];
+            h *= 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+        if (positional) h *= (2ull * i + 1ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+__global__ void diff_kernel(const unsigned int* __restrict__ a, const unsigned int* __restrict__ b, size_t n, unsigned long long* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && a[i] != b[i]);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+static unsigned long long cks(const void* p, size_t n_rec, int wpr, int positional, unsigned long long* d_slot) {
+    APS_HIP(hipMemsetAsync(d_slot, 0, 8, stream()));
+    if (n_rec) cks_kernel<<<cdiv(n_rec, 256), 256, 0, stream()>>>((const unsigned int*)p, n_rec, wpr, positional, d_slot);
+    unsigned long long h = 0;
+    APS_HIP(hipMemcpyAsync(&h, d_slot, 8, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    return h;
+}
+static unsigned long long diff(const void* a, const void* b, size_t n_words, unsigned long long* d_slot) {
+    APS_HIP(hipMemsetAsync(d_slot, 0, 8, stream()));
+    if (n_words) diff_kernel<<<cdiv(n_words, 256), 256, 0, stream()>>>((const unsigned int*)a, (const unsigned int*)b, n_words, d_slot);
+    unsigned long long h = 0;
+    APS_HIP(hipMemcpyAsync(&h, d_slot, 8, hipMemcpyDeviceToHost, stream()));
+    APS_HIP(hipStreamSynchronize(stream()));
+    return h;
+}
+}  // namespace dbg
+#endif
 }  // namespace aps
 
 using namespace aps;
@@ -1857,6 +1912,23 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
             }
             for (int i = 0; i < nl + 3; ++i) od.G[i] = G[o * (nl + 3) + i];
         }
+#ifdef APS_DBG
+        static const int dbg_replay = std::getenv("APS_DBG_REPLAY") ? std::atoi(std::getenv("APS_DBG_REPLAY")) : 0;
+        Ws<unsigned long long> dbg_slot(1);
+        if (dbg_replay > 0) {
+            dbg::g_stat[dbg::kCalls]++;
+            unsigned long long h = 0;
+            for (int o = 0; o < std::min(n_oct, 3); ++o)
+                for (int i = 0; i < nl + 3; ++i)
+                    h = h * 1000003ull + dbg::cks(G[o * (nl + 3) + i].get(), (size_t)table.oct[o].w * table.oct[o].h, 1, 1, dbg_slot);
+            std::lock_guard<std::mutex> lk(dbg::g_mu);
+            auto it = dbg::g_pyr.find((const void*)img);
+            if (it == dbg::g_pyr.end())
+                dbg::g_pyr[(const void*)img] = h;
+            else if (it->second != h)
+                dbg::g_stat[dbg::kPyrChanged]++;
+        }
+#endif
         // extrema: detection sweep per octave -> packed cells; then one dense refinement launch
         Ws<PyrTable> d_table(1);
         APS_HIP(hipMemcpyAsync(d_table, &table, sizeof table, hipMemcpyHostToDevice, stream()));
@@ -1902,14 +1974,36 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                 if (run > 0) {
                     Prof prof("sift_extrema");
                     const int wgs = cdiv(run, 4);
-                    switch (nl) {
-                        case 1: extrema_wave_kernel<1><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
-                        case 2: extrema_wave_kernel<2><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
-                        case 3: extrema_wave_kernel<3><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
-                        case 4: extrema_wave_kernel<4><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
-                        default: extrema_wave_kernel<5><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cells, d_count, cells_cap); break;
-                    }
+                    auto launch_sweep = [&](unsigned long long* cl, unsigned int* ct) {
+                        switch (nl) {
+                            case 1: extrema_wave_kernel<1><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cl, ct, cells_cap); break;
+                            case 2: extrema_wave_kernel<2><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cl, ct, cells_cap); break;
+                            case 3: extrema_wave_kernel<3><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cl, ct, cells_cap); break;
+                            case 4: extrema_wave_kernel<4><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cl, ct, cells_cap); break;
+                            default: extrema_wave_kernel<5><<<wgs, 256, 0, stream()>>>(d_table, plan, thr, cl, ct, cells_cap); break;
+                        }
+                    };
+                    launch_sweep(cells, d_count);
                     check_launch("extrema_wave_kernel");
+#ifdef APS_DBG
+                    if (dbg_replay > 0) {
+                        Ws<unsigned long long> cells2(cells_cap);
+                        Ws<unsigned int> cnt2(2);
+                        unsigned int n1 = 0, n2 = 0;
+                        APS_HIP(hipMemcpyAsync(&n1, d_count, 4, hipMemcpyDeviceToHost, stream()));
+                        APS_HIP(hipStreamSynchronize(stream()));
+                        const unsigned long long c1 = dbg::cks(cells.get(), std::min(n1, cells_cap), 2, 0, dbg_slot);
+                        for (int rep = 0; rep < dbg_replay; ++rep) {
+                            APS_HIP(hipMemsetAsync(cnt2, 0, 8, stream()));
+                            launch_sweep(cells2, cnt2);
+                            APS_HIP(hipMemcpyAsync(&n2, cnt2, 4, hipMemcpyDeviceToHost, stream()));
+                            APS_HIP(hipStreamSynchronize(stream()));
+                            const unsigned long long c2 = dbg::cks(cells2.get(), std::min(n2, cells_cap), 2, 0, dbg_slot);
+                            dbg::g_stat[dbg::kExtReplays]++;
+                            if (n1 != n2 || c1 != c2) dbg::g_stat[dbg::kExtDiff]++;
+                        }
+                    }
+#endif
                 }
             } else if (!std::getenv("APS_EXTREMA_TILES")) {
                 // one marching launch over all octaves (extrema_march_kernel; APS_EXTREMA_MARCH=1, rounds 3-4)
@@ -1976,6 +2070,26 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                                                                      (float)params->edge_threshold, recs, d_count.get() + 1,
                                                                      cand_cap);
             check_launch("refine_kernel");
+#ifdef APS_DBG
+            if (dbg_replay > 0) {
+                Ws<KpRec> recs2(cand_cap);
+                Ws<unsigned int> cnt2(1);
+                unsigned int n1 = 0, n2 = 0;
+                APS_HIP(hipMemcpyAsync(&n1, d_count.get() + 1, 4, hipMemcpyDeviceToHost, stream()));
+                APS_HIP(hipStreamSynchronize(stream()));
+                const unsigned long long c1 = dbg::cks(recs.get(), std::min(n1, cand_cap), 6, 0, dbg_slot);
+                for (int rep = 0; rep < dbg_replay; ++rep) {
+                    APS_HIP(hipMemsetAsync(cnt2, 0, 4, stream()));
+                    refine_kernel<<<cdiv(h_counts[0], 256), 256, 0, stream()>>>(d_table, cells, d_count, cells_cap, (float)params->contrast_threshold,
+                                                                             (float)params->edge_threshold, recs2, cnt2, cand_cap);
+                    APS_HIP(hipMemcpyAsync(&n2, cnt2, 4, hipMemcpyDeviceToHost, stream()));
+                    APS_HIP(hipStreamSynchronize(stream()));
+                    const unsigned long long c2 = dbg::cks(recs2.get(), std::min(n2, cand_cap), 6, 0, dbg_slot);
+                    dbg::g_stat[dbg::kRefReplays]++;
+                    if (n1 != n2 || c1 != c2) dbg::g_stat[dbg::kRefDiff]++;
+                }
+            }
+#endif
         }
         unsigned int n_cand = 0;
         APS_HIP(hipMemcpyAsync(&n_cand, d_count.get() + 1, sizeof n_cand, hipMemcpyDeviceToHost, stream()));
@@ -2008,11 +2122,35 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
         Ws<unsigned int> ocount(n_kp), opos(n_kp);
         Ws<float> oangle((size_t)n_kp * kOriBins);
         Ws<unsigned char> obin((size_t)n_kp * kOriBins);
+#ifdef APS_DBG
+        if (dbg_replay > 0) {
+            APS_HIP(hipMemsetAsync(oangle, 0, (size_t)n_kp * kOriBins * 4, stream()));
+            APS_HIP(hipMemsetAsync(obin, 0, (size_t)n_kp * kOriBins, stream()));
+        }
+#endif
         {
             Prof prof("sift_orient");
             orient_kernel<<<cdiv(n_kp, 4), 256, 0, stream()>>>(d_table, kps, n_kp, ocount, oangle, obin);
         }
         check_launch("orient_kernel");
+#ifdef APS_DBG
+        if (dbg_replay > 0) {
+            Ws<unsigned int> ocount2(n_kp);
+            Ws<float> oangle2((size_t)n_kp * kOriBins);
+            Ws<unsigned char> obin2(((size_t)n_kp * kOriBins + 3) & ~(size_t)3);
+            for (int rep = 0; rep < dbg_replay; ++rep) {
+                APS_HIP(hipMemsetAsync(oangle2, 0, (size_t)n_kp * kOriBins * 4, stream()));
+                APS_HIP(hipMemsetAsync(obin2, 0, (size_t)n_kp * kOriBins, stream()));
+                orient_kernel<<<cdiv(n_kp, 4), 256, 0, stream()>>>(d_table, kps, n_kp, ocount2, oangle2, obin2);
+                const unsigned long long d = dbg::diff(ocount.get(), ocount2.get(), n_kp, dbg_slot) +
+                                             dbg::diff(oangle.get(), oangle2.get(), (size_t)n_kp * kOriBins, dbg_slot) +
+                                             dbg::diff(obin.get(), obin2.get(), (size_t)n_kp * kOriBins / 4, dbg_slot);
+                dbg::g_stat[dbg::kOriReplays]++;
+                if (d) dbg::g_stat[dbg::kOriDiff]++;
+                dbg::g_stat[dbg::kOriWords] += (long long)d;
+            }
+        }
+#endif
         size_t tb3 = 0;
         APS_HIP(rocprim::exclusive_scan(nullptr, tb3, ocount.get(), opos.get(), 0u, n_kp, rocprim::plus<unsigned int>(), stream()));
         Ws<char> tmp3(tb3);
@@ -2044,6 +2182,23 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
                                                                oaux.present() ? oaux.get() : nullptr, plain_sweep);
         }
         check_launch("descr_kernel");
+#ifdef APS_DBG
+        if (dbg_replay > 0 && desc_layout == APS_ROWMAJOR && ldd == 128) {
+            Ws<float> desc2((size_t)n_out * 128), aux2((size_t)n_out * 4);
+            Ws<double> loc2((size_t)2 * n_out);
+            for (int rep = 0; rep < dbg_replay; ++rep) {
+                descr_kernel<<<cdiv(n_out, 4), 256, 0, stream()>>>(d_table, kps, oks, n_out, desc2, desc_layout, 128, loc2, n_out,
+                                                                   oaux.present() ? aux2.get() : nullptr, 0);
+                unsigned long long d = dbg::diff(odesc.get(), desc2.get(), (size_t)n_out * 128, dbg_slot) +
+                                       dbg::diff(oloc.get(), loc2.get(), (size_t)2 * n_out, dbg_slot) +
+                                       dbg::diff(oloc.get() + ldl, loc2.get() + n_out, (size_t)2 * n_out, dbg_slot);
+                if (oaux.present()) d += dbg::diff(oaux.get(), aux2.get(), (size_t)n_out * 4, dbg_slot);
+                dbg::g_stat[dbg::kDesReplays]++;
+                if (d) dbg::g_stat[dbg::kDesDiff]++;
+                dbg::g_stat[dbg::kDesWords] += (long long)d;
+            }
+        }
+#endif
         odesc.commit();
         oloc.commit();
         oaux.commit();
@@ -2052,3 +2207,22 @@ int aps_sift_extract(const uint8_t* img, int height, int width, int channels, in
 }
 
 }  // extern "C"
+
+#ifdef APS_DBG
+// (debug library only) the counters of the replay experiment as text; reset = 1 clears them and the pyramid checksums
+extern "C" int aps_dbg_replay_report(char* buf, int cap, int reset) {
+    using namespace aps::dbg;
+    static const char* names[kNStat] = {"pyramid_changed", "extrema_replays", "extrema_diff", "refine_replays", "refine_diff", "orient_replays",
+                                        "orient_diff", "orient_words", "descr_replays", "descr_diff", "descr_words", "calls"};
+    int n = 0;
+    for (int i = 0; i < kNStat && n < cap; ++i) n += std::snprintf(buf + n, (size_t)(cap - n), "%s=%lld ", names[i], (long long)g_stat[i].load());
+    if (reset) {
+        for (int i = 0; i < kNStat; ++i) g_stat[i] = 0;
+        if (reset > 1) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_pyr.clear();
+        }
+    }
+    return 0;
+}
+#endif

@@ -112,6 +112,28 @@ def test_every_int8_mfma_kernel_claims_the_whole_register_file_of_its_simd(tmp_p
         assert md["max_flat_workgroup_size"] == 512, (name, md)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="needs the ROCm llvm tools")
+def test_sift_point_kernels_carry_no_compiler_made_packed_f32(tmp_path):
+    """Round 6 (profiles/r06y_corun_replay.txt): what int8-MFMA neighbours disturbed in refine_kernel / descr_kernel was the packed f32
+    code the SLP vectoriser makes of their scalar arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 / v_pk_fma_f32) - sift.hip is
+    compiled -fno-slp-vectorize, and the per-keypoint kernels of the shipped code object must hold none of it (the blurs' hand-written
+    v_pk_fma_f32 chains and the extrema sweep's v_pk_add_f32 stayed bit-identical beside the same neighbours)."""
+    import subprocess
+    seen = set()
+    for co in _device_code_objects(str(tmp_path)):
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        current = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                current = m.group(1)
+                if re.search(r"aps\d+(refine|orient|descr)_kernel", current):
+                    seen.add(current)
+            elif current and re.search(r"aps\d+(refine|orient|descr)_kernel", current):
+                assert not re.match(r"^\s+v_pk_", line), "%s: %s" % (current, line.strip())
+    assert len(seen) == 3, sorted(seen)
+
+
 def test_product_library_carries_no_debug_kernels(aps):
     """The probe kernels (csrc/debug/) belong to `make debug`'s libaps_hip_dbg.so only."""
     import subprocess
