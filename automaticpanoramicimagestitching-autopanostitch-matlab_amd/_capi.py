@@ -83,6 +83,7 @@ _SIGNATURES = {
     "aps_device_count": [],
     "aps_set_device": [_i],
     "aps_set_thread_device": [_i],
+    "aps_set_thread_stream_priority": [_i],
     "aps_get_device": [],
     "aps_set_stream": [_vp],
     "aps_synchronize": [],

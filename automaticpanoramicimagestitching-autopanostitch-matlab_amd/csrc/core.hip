@@ -249,6 +249,22 @@ int aps_set_thread_device(int device) {
     return guarded([&] { bind_device(g_ctx, device); });
 }
 
+int aps_set_thread_stream_priority(int level) {
+    return guarded([&] {
+        Ctx& c = ctx();
+        int least = 0, greatest = 0;
+        APS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = level > 0 ? greatest : (level < 0 ? least : (least + greatest) / 2);
+        if (c.own_stream) {
+            APS_HIP(hipStreamSynchronize(c.own_stream));
+            APS_HIP(hipStreamDestroy(c.own_stream));
+            c.own_stream = nullptr;
+        }
+        APS_HIP(hipStreamCreateWithPriority(&c.own_stream, hipStreamNonBlocking, prio));
+        c.own_priority = level > 0 ? 1 : 0;
+    });
+}
+
 int aps_get_device(void) {
     int dev = -1;
     const int rc = guarded([&] { dev = ctx().device; });

@@ -413,10 +413,34 @@ def gather_tiles_to_root(pano, tile, root=0, ranges=None):
     return pano
 
 
-def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None, after_features=None):
+def submit_features(input, local_images, image_events=None):
+    """Starts the feature extraction of this rank's images on the worker streams and returns at once: the handle that
+    stitch_distributed(features=...) accepts instead of extracting itself.  What a loop that stitches set after set calls
+    for the NEXT set from the current call's after_matching hook (round 6): from there on the current stitch runs RANSAC
+    (three latency-bound launches), replicated host work and the bandwidth-bound render - the extraction of the next set
+    fills the gaps between them and shares the memory system with the render (it may NOT run beside the int8 matching
+    kernels: they keep their SIMDs to themselves, and the matcher opens with a bandwidth-bound preparation).
+    local_images / image_events: as for stitch_distributed."""
+    from . import pipeline as pl
+
+    ws, _ = world()
+    mine_img = sorted(local_images)
+    if not mine_img:
+        return {"images": [], "futures": [], "resident": False}
+    dev = local_images[mine_img[0]].device
+    ready = [image_events[i] for i in mine_img] if image_events is not None else None
+    resident = (not _multi(ws)) and dev.type == "cuda" and all(_is_cuda_tensor(local_images[i]) for i in mine_img)
+    futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready, points_device=resident)
+    return {"images": mine_img, "futures": futs, "resident": resident}
+
+
+def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None, after_features=None,
+                features=None, after_matching=None, after_ransac=None):
     """Steps 1-4 on the current images: SIFT on the local shard, the descriptor exchange, the sharded pair matching
     and the sharded RANSAC verification (main.m:88-107 up to imageMatching).  Everything that is exchanged stays on
     the device; the host sees counts, candidate lists and the 3 x 3 models.
+    features: the handle of submit_features() for exactly these images (extraction already under way), or None.
+    after_matching: optional callable run when the match lists are complete, before candidate selection and RANSAC.
     Returns dict(counts, kps_t, pairs, models, num_matches, n_match, order)."""
     from . import featureMatching as fm
     from . import imageMatching as im
@@ -471,7 +495,11 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         # extract the next one, so only the last chunk's collective is left on the critical path.
         t0 = time.perf_counter()
         if _multi(ws):
-            futs = dict(zip(mine_img, pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready))) if mine_img else {}
+            if features is not None:
+                assert features["images"] == mine_img, "submit_features() was called for other images"
+                futs = dict(zip(mine_img, features["futures"]))
+            else:
+                futs = dict(zip(mine_img, pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready))) if mine_img else {}
             ex = FeatureExchange(futs, n, dev).run()
             times.add("features", t0)  # (the last local image is extracted; all but the last chunk have been sent)
             t0 = time.perf_counter()
@@ -486,7 +514,11 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
                 # resident images: the keypoints never leave the device (the host copy and the 64 small uploads after the last
                 # image were 2 ms of every step); host images: uploaded as soon as their image is done
                 resident = dev.type == "cuda" and all(_is_cuda_tensor(local_images[i]) for i in mine_img)
-                futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready, points_device=resident)
+                if features is not None:
+                    assert features["images"] == mine_img and features["resident"] == resident, "submit_features() was called for other images"
+                    futs = features["futures"]
+                else:
+                    futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready, points_device=resident)
                 for i, f in zip(mine_img, futs):
                     d, p = f.result()
                     ldesc[i] = d
@@ -542,6 +574,8 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
     else:
         gpos = pp[:-1].astype(np.int64)
     times.add("matching", t0)
+    if after_matching is not None:
+        after_matching()  # caller's hook: no int8 kernel runs from here on (e.g. submit_features() for the next set)
 
     # 4) candidate selection (redundant, deterministic) + RANSAC sharded round-robin
     t0 = time.perf_counter()
@@ -573,6 +607,9 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
         t0 = time.perf_counter()
         models, mask, found, ninl = im.ransac_batch_drawn(src, dst, wptr, cnts, input, seed, keys=mine)
         times.add("im_ransac", t0)
+        if after_ransac is not None:
+            after_ransac()
+            after_ransac = None
         t0 = time.perf_counter()
         wk = {p: k for k, p in enumerate(work)}
         vals = np.concatenate([models.reshape(len(mine), 9), found.reshape(-1, 1).astype(np.float64),
@@ -582,6 +619,8 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
             rec[rows] = torch.from_numpy(vals).to(dev)
         else:
             rec[[wk[p] for p in mine]] = vals
+    if after_ransac is not None:
+        after_ransac()  # (a rank without candidate pairs of its own)
     if _multi(ws):
         _all_reduce(rec)  # every row is written by exactly one rank, zero elsewhere
         rec = rec.cpu().numpy()
@@ -619,7 +658,8 @@ def _sync_lib():
 
 
 def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, cameras=None, pano_root=None,
-                       local_originals=None, image_events=None, after_features=None):
+                       local_originals=None, image_events=None, after_features=None, features=None, after_matching=None,
+                       after_ransac=None):
     """The whole stitch with the work sharded over the ranks of the default process group (see module doc).
     local_images: dict image index -> uint8 H x W x 3 CUDA tensor for the indices shard_indices(n, world, rank).
     pano_root: None = every panorama is combined on every rank; r = only rank r receives the tiles / panoramas of the
@@ -632,6 +672,10 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     after_features: optional callable run once the (first-pass) feature extraction has finished and before the matching
     starts - the point from which the per-image worker streams are idle; a caller that streams the PREVIOUS result to
     the host starts that copy here, where it cannot sit in front of a worker stream's kernels in a shared hardware queue.
+    features: the handle submit_features() returned for these very images (their extraction was started earlier, e.g. from
+    the previous call's after_matching hook); after_matching: optional callable run when the (first-pass) match lists are
+    complete - the point from which no int8 kernel runs any more in this call; after_ransac: the same after this rank's
+    RANSAC batch (its three launches are latency-bound: beside a busy chip they take 6 instead of 2.3 ms).
     Returns (panorama of the component that holds the best-connected image, uint8 H x W x 3 CUDA tensor; info dict
     with info["panoramas"]: one entry per connected component of at least two images, in component order)."""
     from . import pipeline as pl
@@ -651,7 +695,7 @@ def stitch_distributed(input, local_images, n, Ks, tile=(2048, 2048), seed=0, ca
     times.add("exchange", t0)
 
     res = _match_pass(input, local_images, n, seed, times, dev, image_events, before_match=img_gather.finish,
-                      after_features=after_features)
+                      after_features=after_features, features=features, after_matching=after_matching, after_ransac=after_ransac)
 
     # 5) host segment (redundant on every rank): components, second pass if asked for, cameras per component
     t0 = time.perf_counter()

@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--global-probe", choices=["auto", "off"], default="auto",
                     help="after the timed steps, one pass of the reference's default matcher (featureMatchingGlobal) on the same "
                          "views, reported as global_matcher_probe (off: for profiling runs that want per-step launch counts)")
+    ap.add_argument("--pipeline", choices=["auto", "off"], default="auto",
+                    help="auto: consecutive steps overlap as the reference's loop over image sets (PP/main.m:83-137) allows - the next "
+                         "set's feature extraction starts when the current set's match lists are complete; off: strictly one after the "
+                         "other (always reported as value_sequential)")
     ap.add_argument("--with-gain", choices=["auto", "off"], default="auto",
                     help="after the timed steps, time the same steps with input.gainCompensation = 1 (the reference's default, "
                          "PP/inputs.m:94); reported as value_with_gain")
@@ -809,20 +813,47 @@ def main():
 
     dl_alone = []
 
-    def step(upload=False, sync_download=False):
+    # Round 6: a loop that stitches set after set starts the NEXT set's feature extraction as soon as the current set's match
+    # lists are complete (parallel.submit_features from the after_matching hook): RANSAC's latency-bound launches, the replicated
+    # host work and the render's host part leave the GPU idle for ~5 ms of every step, and the bandwidth-bound render shares the
+    # chip with the extraction better than either does alone.  Every step still does all of its own work inside the timed
+    # region: the first timed step extracts its own features, the last one prefetches nothing (`pipelined` below).
+    ahead = [None]  # (images, events, handle) of the next step, extraction under way
+    prefetch_at = os.environ.get("APS_BENCH_PREFETCH_AT", "matching")  # (A/B: "ransac" starts it after this rank's RANSAC batch)
+    pipelined = os.environ.get("APS_BENCH_PIPELINE", "1" if args.pipeline == "auto" else "0") == "1"
+    if pipelined and os.environ.get("APS_BENCH_MAIN_PRIORITY", "1") != "0":
+        # the main thread's launches (RANSAC, the render chain) must not queue behind the ten worker streams' kernels: the
+        # runtime keeps separate hardware queues per priority level (157.5 against 162.0 ms per steady step, scripts/probe/ab_pipeline.sh)
+        capi.check(capi.lib.aps_set_thread_stream_priority(1))
+
+    def load_images(upload):
+        if not upload:
+            return local, None
+        up, evs = {}, {}
+        with torch.cuda.stream(copy_stream):
+            for i in mine:
+                up[i] = host_imgs[i].to("cuda", non_blocking=True)
+                evs[i] = torch.cuda.Event()
+                evs[i].record(copy_stream)
+        return up, evs
+
+    def step(upload=False, sync_download=False, prefetch_next=False):
         t_s = time.perf_counter()
-        if upload:
-            up, evs = {}, {}
-            with torch.cuda.stream(copy_stream):
-                for i in mine:
-                    up[i] = host_imgs[i].to("cuda", non_blocking=True)
-                    evs[i] = torch.cuda.Event()
-                    evs[i].record(copy_stream)
-            pano_, info_ = par.stitch_distributed(input_, up, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs,
-                                                  after_features=flush_deferred_soon)
+        if ahead[0] is not None:
+            imgs, evs, feat = ahead[0]
+            ahead[0] = None
         else:
-            pano_, info_ = par.stitch_distributed(input_, local, n, Ks, (2048, 2048), 0, gt, pano_root=0,
-                                                  after_features=flush_deferred_soon)
+            imgs, evs = load_images(upload)
+            feat = None
+
+        def start_next():
+            imgs_n, evs_n = load_images(upload)
+            ahead[0] = (imgs_n, evs_n, par.submit_features(input_, imgs_n, evs_n))
+
+        pano_, info_ = par.stitch_distributed(input_, imgs, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs,
+                                              after_features=flush_deferred_soon, features=feat,
+                                              after_matching=start_next if prefetch_next and prefetch_at == "matching" else None,
+                                              after_ransac=start_next if prefetch_next and prefetch_at == "ransac" else None)
         t_d = time.perf_counter()
         if rank == 0 and pano_ is not None and pano_.numel():
             pano_ = to_host(pano_, wait=sync_download)
@@ -881,27 +912,40 @@ def main():
             to_host(probe, wait=True)
             dl_alone.append(time.perf_counter() - t_c)
         del probe
+    def run_series(k_steps, upload=False, pipe=False):
+        """k_steps steps between two barriers; pipe: every step but the last starts the next one's feature extraction from
+        its after_matching hook (the first extracts its own, so all the work of the k_steps stitches lies between the barriers).
+        Returns (seconds, per-step infos, time marks after each step, the start time, the last panorama)."""
+        barrier()
+        t_b = time.perf_counter()
+        infos_, marks_, pano_ = [], [], None
+        for k_ in range(k_steps):
+            pano_, info_ = step(upload=upload, prefetch_next=pipe and k_ + 1 < k_steps)
+            # keep the step's numbers, not its panoramas: a list that pins every step's 737 MB output makes each step
+            # hipMalloc a fresh canvas (up to 17 ms per step when the driver has to scrub the pages first) - a cost of the
+            # bench's bookkeeping, not of a stitch.  The current panorama stays alive until the next one replaces it.
+            info_.pop("panoramas", None)
+            infos_.append(info_)
+            marks_.append(time.perf_counter())
+        barrier()
+        return time.perf_counter() - t_b, infos_, marks_, t_b, pano_
+
     capi.profile_enable(2 if warm_steps else 1)
     capi.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    infos, marks = [], []
-    for _ in range(args.steps):
-        pano, info = step()
-        # keep the step's numbers, not its panoramas: a list that pins every step's 737 MB output makes each step
-        # hipMalloc a fresh canvas (up to 17 ms per step when the driver has to scrub the pages first) - a cost of the
-        # bench's bookkeeping, not of a stitch.  The current panorama stays alive until the next one replaces it.
-        info.pop("panoramas", None)
-        infos.append(info)
-        marks.append(time.perf_counter())
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, infos, marks, t0, pano = run_series(args.steps, pipe=pipelined)
     # wall time of each timed step (start of step k to start of step k + 1; the last one ends at the closing barrier, which
     # includes the last panorama's copy): their mean is ms_per_step, the median and the minimum make a 2 ms change visible
     step_walls = [b - a for a, b in zip([t0] + marks[:-1], marks[:-1] + [t0 + dt])]
     prof = capi.profile_all()
     screen_series = capi.profile_series("match_screen_i8")
     capi.profile_enable(False)
+    # The same steps strictly one after the other (value_sequential; the stage table comes from these steps: in the pipelined
+    # series a step's "features" is only what was left to wait for and its "render" shares the chip with the next extraction).
+    dt_seq, infos_seq, seq_walls = None, infos, None
+    if pipelined:
+        n_seq = max(2, min(args.steps, 8))
+        dt_seq, infos_seq, marks_s, t0_s, _ = run_series(n_seq)
+        seq_walls = [b - a for a, b in zip([t0_s] + marks_s[:-1], marks_s[:-1] + [t0_s + dt_seq])]
     # The same steps with input.gainCompensation = 1 (the reference's default, PP/inputs.m:94; renderPanorama.m:303-330): the
     # overlap statistics on the device (gain_stats_kernel), the N x N x 3 sums back to the host, the host solve, the gains into
     # the warp.  Reported as value_with_gain; the headline follows BASELINE.json configs[2], which does not name the switch.
@@ -910,28 +954,14 @@ def main():
         input_["gainCompensation"] = 1
         try:
             step(sync_download=True)  # warm-up (the statistics' workspaces)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                pano_g, info_g = step()
-                info_g.pop("panoramas", None)
-                infos_g.append(info_g)
-            barrier()
-            dt_gain = time.perf_counter() - t0
+            dt_gain, infos_g, _, _, _ = run_series(args.steps, pipe=pipelined)
         finally:
             input_["gainCompensation"] = 0
     dt_e2e = None
     if args.end_to_end == "auto":
         step(upload=True)  # warm-up: side stream
-        barrier()
-        t0 = time.perf_counter()
-        infos_h = []
-        for _ in range(args.steps):
-            pano_h, info_h = step(upload=True)
-            info_h.pop("panoramas", None)
-            infos_h.append(info_h)
-        barrier()
-        dt_e2e = time.perf_counter() - t0
+        dt_e2e, infos_h, _, _, pano_h = run_series(args.steps, upload=True, pipe=pipelined)
+        info_h = infos_h[-1]
         if rank == 0 and (info_h["n_pairs_verified"], tuple(pano_h.shape)) != (infos[-1]["n_pairs_verified"], tuple(infos[-1]["panorama_shape"])):
             raise RuntimeError("the end-to-end step disagrees with the resident step on verified pairs / panorama size")
     # per-step view of both passes: live numbers win
@@ -941,11 +971,12 @@ def main():
         if k not in prof:
             prof[k] = (v[0] * args.steps / warm_steps, v[1] * args.steps // warm_steps)
     if multi:
-        t = torch.tensor([dt, dt_e2e or 0.0, dt_gain or 0.0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_e2e or 0.0, dt_gain or 0.0, dt_seq or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         dt_e2e = float(t[1].item()) if dt_e2e is not None else None
         dt_gain = float(t[2].item()) if dt_gain is not None else None
+        dt_seq = float(t[3].item()) if dt_seq is not None else None
 
     if rank == 0:
         info = infos[-1]
@@ -1102,7 +1133,7 @@ def main():
         # The feature-extraction STAGE as one roofline entry (its kernels run on ten streams side by side, so per-kernel
         # event sums overlap): algorithmic bytes of SURVEY 8(d)'s materialised-pyramid model, and the bytes the stage
         # really moves (PMC pass), over the stage's wall time.
-        t_feat = sum(i["times"].get("features", 0.0) for i in infos) / len(infos)
+        t_feat = sum(i["times"].get("features", 0.0) for i in infos_seq) / len(infos_seq)
         if t_feat > 0:
             sift_rows = [v for k, v in traffic_db.items() if any(n_ in k for n_ in SIFT_KERNELS)]
             sift_bytes = sum(r["read_bytes_per_step"] + r["write_bytes_per_step"] for r in sift_rows) if sift_rows else None
@@ -1117,7 +1148,9 @@ def main():
                           "note": "574 B per input pixel is the survey's model (G and DoG planes written and re-read); DoG planes are "
                                   "not stored here, so `traffic` (bytes per STEP for this entry, all SIFT kernels) is lower; "
                                   "achieved_measured_bytes = traffic / stage wall time"})
-        stages = {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in infos[-1]["times"]}
+        stages = {k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos_seq) / len(infos_seq), 2) for k in infos_seq[-1]["times"]}
+        stages_pipe = ({k: round(1e3 * sum(i["times"].get(k, 0.0) for i in infos) / len(infos), 2) for k in infos[-1]["times"]}
+                       if pipelined else None)
         # the descriptor-distance path as a STAGE (preparation, screen, list pass, fallback, filter and their gaps): the same
         # algorithmic 2*128*Ni*Nj over the stage's wall time, beside the dominant kernel's own fraction
         t_match = sum(i["times"].get("matching", 0.0) for i in infos) / len(infos)
@@ -1143,7 +1176,8 @@ def main():
                                 "noted elsewhere - it is never `value`\"): resident uint8 views -> cropped uint8 panorama in pinned host "
                                 "memory.  BASELINE.md section 2 / SURVEY 8(d)'s clock (first input byte in pinned host memory -> final "
                                 "panorama in host memory) is value_end_to_end / ms_per_step_end_to_end in this same line, 0.3-0.6 % "
-                                "apart (both transfers overlap device work); the reference's default gainCompensation = 1 is value_with_gain",
+                                "apart (both transfers overlap device work); the reference's default gainCompensation = 1 is value_with_gain.  "
+                                "Consecutive steps are pipelined (see `pipeline`); strictly sequential steps are pipeline.value_sequential",
             "value_end_to_end": round(mpix_in * args.steps / dt_e2e, 2) if dt_e2e else None,
             "ms_per_step_end_to_end": round(1e3 * dt_e2e / args.steps, 2) if dt_e2e else None,
             "value_with_gain": round(mpix_in * args.steps / dt_gain, 2) if dt_gain else None,
@@ -1153,7 +1187,21 @@ def main():
             # the panorama's device-to-host copy runs beside the next step's feature extraction (two pinned buffers); alone
             # it costs download_ms_alone, so one isolated step takes ms_per_step_latency
             "download_ms_alone": round(1e3 * min(dl_alone), 2) if dl_alone else None,
-            "ms_per_step_latency": round(1e3 * (dt_resident / args.steps + (min(dl_alone) if dl_alone else 0.0)), 2),
+            "ms_per_step_latency": round(1e3 * (sum(i["t_stitch"] for i in infos_seq) / len(infos_seq) + (min(dl_alone) if dl_alone else 0.0)), 2),
+            # strictly sequential steps of the same job (no extraction of the next set beside this set's RANSAC / render)
+            "pipeline": ({"on": True, "how": "the reference stitches set after set (PP/main.m:83-137: for myImg = 1:foldersLen); here the NEXT "
+                          "set's feature extraction (loadImages, main.m:88-91) is started when the current set's match lists are complete "
+                          "(parallel.submit_features from stitch_distributed's after_matching hook) and runs beside RANSAC, the host's graph / "
+                          "camera work and the render of the current set; results per set are unchanged (bench checks pairs and canvas), "
+                          "every timed step's work lies inside the timed region (the first timed step extracts its own features, the last "
+                          "one starts nothing), and the int8 matching kernels still run alone",
+                          "value_sequential": round(mpix_in * len(infos_seq) / dt_seq, 2), "ms_per_step_sequential": round(1e3 * dt_seq / len(infos_seq), 2),
+                          "ms_per_step_sequential_median": round(1e3 * float(np.median(seq_walls)), 2),
+                          "ms_per_step_sequential_series": [round(1e3 * x, 2) for x in seq_walls],
+                          "stages_ms_per_step_pipelined": stages_pipe,
+                          "stages_note": "stages_ms_per_step (and the SIFT-stage roofline entry) are taken from the SEQUENTIAL steps; in the "
+                                         "pipelined steps `features` is what was left to wait for and `render` shares the chip with the next extraction"}
+                         if pipelined else {"on": False}),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic {w}x{h} overlapping views ({nx}x{ny} yaw/pitch grid, f={f:.0f}px, "

@@ -67,6 +67,10 @@ int aps_set_device(int device);
  * process that drives several GPUs calls before its first entry point, so that it does not inherit whichever device
  * another thread selected last. */
 int aps_set_thread_device(int device);
+/* Recreate the calling thread's own stream at a priority of the device's range: level > 0 the highest, < 0 the lowest,
+ * 0 the middle (the default).  For a host that runs two stages side by side from two threads and wants the short launches
+ * of one not to queue behind the other's kernels (the runtime keeps separate hardware queues per priority level). */
+int aps_set_thread_stream_priority(int level);
 /* The device the calling thread is bound to (binding it to the default first if it has none); < 0 on error. */
 int aps_get_device(void);
 /* Run the calling thread's work on an existing HIP stream (e.g. torch's current stream);

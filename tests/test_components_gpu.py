@@ -76,6 +76,48 @@ def test_single_images_and_unmatched_sets_render_nothing(gpu):
     assert info["n_pairs_verified"] == 0 and info["panoramas"] == [] and pano.numel() == 0
 
 
+def test_set_after_set_with_the_next_extraction_started_early_gives_the_same_panoramas(gpu):
+    """parallel.submit_features from stitch_distributed's after_matching hook (round 6: the next set's loadImages beside the current
+    set's RANSAC / cameras / render, as bench.py's pipelined steps run it): three sets stitched one after the other with the next
+    set's extraction under way equal, byte for byte, the same sets stitched strictly one after the other."""
+    import torch
+
+    synth = import_module(gpu.__name__ + ".synth")
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    sets = []
+    for seed in (11, 23, 37):
+        cs = synth.grid_cameras(3, 2, W, H, F, 2 * np.arctan(W / (2 * F)) * 0.6, 2 * np.arctan(H / (2 * F)) * 0.6, 1.0, seed)
+        sets.append((dict(enumerate(synth.render_view(c, H, W, seed, "cuda", finest_px=6.0) for c in cs)), [c["K"] for c in cs]))
+    torch.cuda.synchronize()
+    inp = pl.default_input(bands=3)
+    plain = []
+    for views, Ks in sets:
+        pano, info = par.stitch_distributed(inp, views, len(views), Ks, (512, 512), 0, None, pano_root=0)
+        plain.append((pano.cpu().numpy(), info["n_pairs_verified"], info["n_features"]))
+    ahead = [None]
+    hooks = []
+    for k, (views, Ks) in enumerate(sets):
+        feat, ahead[0] = ahead[0], None
+
+        def start_next(k=k):
+            hooks.append(k)
+            ahead[0] = par.submit_features(inp, sets[k + 1][0])
+
+        pano, info = par.stitch_distributed(inp, views, len(views), Ks, (512, 512), 0, None, pano_root=0, features=feat,
+                                            after_matching=start_next if k + 1 < len(sets) else None)
+        assert (k == 0) == (feat is None)
+        assert info["n_pairs_verified"] == plain[k][1] and info["n_features"] == plain[k][2]
+        assert np.array_equal(pano.cpu().numpy(), plain[k][0])
+    assert hooks == [0, 1] and ahead[0] is None
+    # a handle for other images is refused
+    wrong = par.submit_features(inp, {0: sets[0][0][0], 1: sets[0][0][1]})
+    with pytest.raises(AssertionError):
+        par.stitch_distributed(inp, sets[0][0], 6, sets[0][1], (512, 512), 0, None, pano_root=0, features=wrong)
+    for f in wrong["futures"]:
+        f.result()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
