@@ -413,25 +413,42 @@ def gather_tiles_to_root(pano, tile, root=0, ranges=None):
     return pano
 
 
-def submit_features(input, local_images, image_events=None):
+def submit_features(input, local_images, image_events=None, first=None):
     """Starts the feature extraction of this rank's images on the worker streams and returns at once: the handle that
     stitch_distributed(features=...) accepts instead of extracting itself.  What a loop that stitches set after set calls
     for the NEXT set from the current call's after_matching hook (round 6): from there on the current stitch runs RANSAC
     (three latency-bound launches), replicated host work and the bandwidth-bound render - the extraction of the next set
     fills the gaps between them and shares the memory system with the render (it may NOT run beside the int8 matching
     kernels: they keep their SIMDs to themselves, and the matcher opens with a bandwidth-bound preparation).
-    local_images / image_events: as for stitch_distributed."""
+    local_images / image_events: as for stitch_distributed.
+    first: submit only the first `first` images now (a few worker streams fill the idle chip without crowding the latency-bound
+    RANSAC launches of the current set); submit_features_rest(handle) submits the others (e.g. from the after_ransac hook)."""
     from . import pipeline as pl
 
     ws, _ = world()
     mine_img = sorted(local_images)
     if not mine_img:
-        return {"images": [], "futures": [], "resident": False}
+        return {"images": [], "futures": [], "resident": False, "rest": None}
     dev = local_images[mine_img[0]].device
-    ready = [image_events[i] for i in mine_img] if image_events is not None else None
     resident = (not _multi(ws)) and dev.type == "cuda" and all(_is_cuda_tensor(local_images[i]) for i in mine_img)
-    futs = pl.sift_submit(input, [local_images[i] for i in mine_img], ready=ready, points_device=resident)
-    return {"images": mine_img, "futures": futs, "resident": resident}
+    k = len(mine_img) if first is None else max(0, min(int(first), len(mine_img)))
+
+    def submit(idx):
+        ready = [image_events[i] for i in idx] if image_events is not None else None
+        return pl.sift_submit(input, [local_images[i] for i in idx], ready=ready, points_device=resident) if idx else []
+
+    handle = {"images": mine_img, "futures": submit(mine_img[:k]), "resident": resident, "rest": None}
+    if k < len(mine_img):
+        handle["rest"] = lambda: submit(mine_img[k:])
+    return handle
+
+
+def submit_features_rest(handle):
+    """Submits the images submit_features(first=...) left out; a handle without any is left alone."""
+    if handle is not None and handle.get("rest") is not None:
+        rest, handle["rest"] = handle["rest"], None
+        handle["futures"] = list(handle["futures"]) + list(rest())
+    return handle
 
 
 def _match_pass(input, local_images, n, seed, times, dev, image_events=None, before_match=None, after_features=None,
@@ -449,6 +466,7 @@ def _match_pass(input, local_images, n, seed, times, dev, image_events=None, bef
     ws, rank = world()
     owner = lambda i: i % ws  # noqa: E731
 
+    submit_features_rest(features)  # (a handle whose second part was never submitted)
     use_global = not int(input.get("matchFeaturesPairwise", 1))  # main.m:95-99
     host_lists = bool(os.environ.get("APS_PARALLEL_HOST_LISTS"))  # A/B switch: lists through the host (round-1 path)
     order = fm.pair_order(n)

@@ -820,6 +820,7 @@ def main():
     # region: the first timed step extracts its own features, the last one prefetches nothing (`pipelined` below).
     ahead = [None]  # (images, events, handle) of the next step, extraction under way
     prefetch_at = os.environ.get("APS_BENCH_PREFETCH_AT", "matching")  # (A/B: "ransac" starts it after this rank's RANSAC batch)
+    prefetch_first = int(os.environ["APS_BENCH_PREFETCH_FIRST"]) if os.environ.get("APS_BENCH_PREFETCH_FIRST") else None
     pipelined = os.environ.get("APS_BENCH_PIPELINE", "1" if args.pipeline == "auto" else "0") == "1"
     if pipelined and os.environ.get("APS_BENCH_MAIN_PRIORITY", "1") != "0":
         # the main thread's launches (RANSAC, the render chain) must not queue behind the ten worker streams' kernels: the
@@ -848,12 +849,16 @@ def main():
 
         def start_next():
             imgs_n, evs_n = load_images(upload)
-            ahead[0] = (imgs_n, evs_n, par.submit_features(input_, imgs_n, evs_n))
+            ahead[0] = (imgs_n, evs_n, par.submit_features(input_, imgs_n, evs_n, first=prefetch_first))
+
+        def start_rest():
+            if ahead[0] is not None:
+                par.submit_features_rest(ahead[0][2])
 
         pano_, info_ = par.stitch_distributed(input_, imgs, n, Ks, (2048, 2048), 0, gt, pano_root=0, image_events=evs,
                                               after_features=flush_deferred_soon, features=feat,
                                               after_matching=start_next if prefetch_next and prefetch_at == "matching" else None,
-                                              after_ransac=start_next if prefetch_next and prefetch_at == "ransac" else None)
+                                              after_ransac=(start_next if prefetch_at == "ransac" else start_rest) if prefetch_next else None)
         t_d = time.perf_counter()
         if rank == 0 and pano_ is not None and pano_.numel():
             pano_ = to_host(pano_, wait=sync_download)

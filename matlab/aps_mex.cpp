@@ -613,6 +613,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const std::string cmd = str(prhs[0]);
     if (cmd == "version") plhs[0] = mxCreateDoubleScalar(aps_version());
     else if (cmd == "set_device") check(aps_set_device((int)mxGetScalar(prhs[1])));
+    else if (cmd == "set_thread_stream_priority") check(aps_set_thread_stream_priority((int)mxGetScalar(prhs[1])));
     else if (cmd == "sift_extract") cmd_sift(nlhs, plhs, nrhs, prhs);
     else if (cmd == "match_features") cmd_match(nlhs, plhs, nrhs, prhs);
     else if (cmd == "pca_2nn") cmd_pca2nn(nlhs, plhs, nrhs, prhs);
