@@ -15,9 +15,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 rm -rf /tmp/pt /tmp/pw
 timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d /tmp/pt -o p -- \
-    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --steps 1 --warmup 0 > /tmp/pt.json 2> /tmp/pt.err
+    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --pipeline off --steps 1 --warmup 0 > /tmp/pt.json 2> /tmp/pt.err
 timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d /tmp/pw -o p -- \
-    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --steps 1 --warmup 0 > /tmp/pw.json 2> /tmp/pw.err
+    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --pipeline off --steps 1 --warmup 0 > /tmp/pw.json 2> /tmp/pw.err
 python3 - "$TAG" <<'PY'
 import csv, collections, json, os, sys
 tag = sys.argv[1]
@@ -53,7 +53,7 @@ PY
 # issue rather than by bytes (bench.py: valu_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz / kernel time).
 rm -rf /tmp/pv
 timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d /tmp/pv -o p -- \
-    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --steps 1 --warmup 0 > /tmp/pv.json 2> /tmp/pv.err
+    python3 bench.py --cpu-baseline off --end-to-end off --global-probe off --with-gain off --pipeline off --steps 1 --warmup 0 > /tmp/pv.json 2> /tmp/pv.err
 python3 - "$TAG" <<'PY'
 import csv, collections, json, sys
 sys.path.insert(0, ".")

@@ -142,3 +142,37 @@ for label, subs in (("t % 8", [(r, world) for r in range(world)]), ("contiguous 
         lo, med, _ = timed(lambda: rp.renderPanorama(inp, imgs, sizes, cams_e, "spherical", comp["ref"], opts, device_out=True, tile_subset=sub), reps=3)
         ts_.append(lo)
     print(f"render per rank, tiles dealt {label}: " + ", ".join(f"{t:.2f}" for t in ts_) + f" ms; max {max(ts_):.2f} ms  (ranges {ranges if label != 't % 8' else ''})")
+
+# round 6: the same rank's step with its pieces strung together - strictly one after the other, and with the NEXT step's extraction
+# of its 8 views started when the match lists are complete (parallel.submit_features: beside RANSAC, the host part and the render of
+# its tiles), as bench.py's pipelined steps run it.  The exchanges are not in these numbers.
+my_pairs = [order[p] for p in my]
+my_work = work[0::world]
+local = {i: imgs[i] for i in mine}
+rsub = ("range",) + ranges[0]
+
+
+def rank_step(handle, start_next):
+    if handle is None:
+        handle = par.submit_features(inp, local)
+    for fu in handle["futures"]:
+        fu.result()
+    fm.match_pairs_csr(descs, my_pairs, inp["Ratiothreshold"], inp["Matchingthreshold"], True, device_out=True)
+    nxt = par.submit_features(inp, local) if start_next else None
+    ransac(my_work)
+    host()
+    rp.renderPanorama(inp, imgs, sizes, cams_e, "spherical", comp["ref"], opts, device_out=True, tile_subset=rsub)
+    return nxt
+
+
+capi.check(capi.lib.aps_set_thread_stream_priority(1))
+for label, pipe in (("one after the other", False), ("next extraction started after the matching", True)):
+    rank_step(None, False)
+    sync()
+    K = 12
+    t0 = time.perf_counter()
+    h_ = None
+    for k in range(K):
+        h_ = rank_step(h_, pipe and k + 1 < K)
+    sync()
+    print(f"one rank of eight, {K} steps {label}: {1e3 * (time.perf_counter() - t0) / K:.2f} ms per step")
