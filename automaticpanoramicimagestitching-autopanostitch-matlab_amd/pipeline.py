@@ -97,8 +97,11 @@ def _init_worker(device):
     """Pool initializer: each worker creates its library context (device binding, stream, events) on its own, one
     worker after the other - ten threads racing through their first HIP calls at once is what rocprofv3 was seen to
     crash under."""
+    import os
     with _INIT_LOCK:
         _capi.check(_capi.lib.aps_set_thread_device(int(device)))
+        if os.environ.get("APS_SIFT_STREAM_PRIORITY"):  # (-1: the workers' streams on the device's lowest priority level; see bench.py)
+            _capi.check(_capi.lib.aps_set_thread_stream_priority(int(os.environ["APS_SIFT_STREAM_PRIORITY"])))
         _capi.check(_capi.lib.aps_synchronize())
 
 
