@@ -1711,6 +1711,9 @@ static bool launch_blur(const float* in, int h, int w, double sigma, float* out,
     // (Measured and dropped, round 5: 128-column tiles on 512 threads - blur_kernel<R, 128, 512>, fills in rows of 544-608 B
     // instead of 288-352 B - read 58.7 / 70 / 85 us per octave-0 plane at R = 4 / 5 / 10 against 56.8 / 60 / 72:
     // profiles/r05j_blur_tile_variants.txt.  The tile shape stays 64 x 32 on 256 threads.)
+    // (Measured and dropped, round 6: 64-ROW tiles on 512 threads for R >= 7 - blur_kernel<R, 64, 512, 64>, vertical halo 1.22-1.38
+    // instead of 1.44-1.75 of the tile, one work item per thread in both passes, 30 KB of LDS - same bits, 71.4 / 65.1 us per octave-0
+    // plane at R = 10 / 7 against 69.4 / 65.0, the 64-view stage 75.6-76.4 against 74.3-74.9 ms: profiles/r06y_blur_tall_tiles.txt.)
     switch (r) {
 #define APS_BLUR_CASE(R) \
     case R:              \
