@@ -922,3 +922,30 @@ def test_pairwise_operator_honours_the_matcher_switches(gpu):
     assert ap[1][0] is None and ap[0][0] is None
     with pytest.raises(NotImplementedError):
         fm.featureMatchingPairwise(dict(inp, useMATLABFeatureMatch=1), descs, 3)
+
+
+def test_thread_stream_priority_recreates_the_stream_and_changes_no_result(gpu):
+    """aps_set_thread_stream_priority (round 6: the main thread of a set-after-set loop runs on the device's highest priority
+    level): every level gives a working stream, also after the thread's auxiliary streams exist, and the same match lists."""
+    import threading
+
+    capi = gpu._capi
+    out = {}
+
+    def work():
+        capi.check(capi.lib.aps_set_thread_device(0))
+        rng = np.random.default_rng(5)
+        a, b = sift_like(rng, 400), sift_like(rng, 380)
+        fmod = import_module(gpu.__name__ + ".featureMatching")
+        res = []
+        for level in (None, 1, 0, -1, 1):
+            if level is not None:
+                out.setdefault("rc", []).append(capi.lib.aps_set_thread_stream_priority(level))
+            pp, ia, ib, _ = fmod.match_pairs_csr([a, b], [(0, 1)], 0.9, 1.5)
+            res.append((int(pp[-1]), np.asarray(ia).tobytes(), np.asarray(ib).tobytes()))
+        out["same"] = all(r == res[0] for r in res) and res[0][0] > 0
+
+    th = threading.Thread(target=work)  # (a thread of its own: the suite's main thread keeps its stream)
+    th.start()
+    th.join()
+    assert out.get("rc") == [0, 0, 0, 0] and out.get("same"), out
