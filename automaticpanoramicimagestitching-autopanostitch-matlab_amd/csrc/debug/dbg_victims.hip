@@ -206,6 +206,46 @@ __global__ __launch_bounds__(256) void dbg_victim_kernel(int iters, unsigned lon
             r.x = got;
             r.y = 0.f;
             ey = 0.f;
+        } else if (VAR == 19 || VAR == 20) {
+            // operand kinds of the compiler's code that the variants above lack: 19 = an SGPR pair as the second source with the low
+            // half broadcast (refine_kernel: v_pk_mul_f32 V, V, S op_sel_hi:[1,0]), 20 = an inline constant (descr_kernel:
+            // v_pk_add_f32 V, V, 2.0 op_sel_hi:[1,0]); each consumed by a packed add after one wait state
+            const float sv = 1.25f + 0.001f * (it & 127);
+            if (VAR == 19) {
+                asm volatile("s_mov_b32 s40, %3\n\ts_mov_b32 s41, %3\n\tv_pk_mul_f32 %0, %1, s[40:41] op_sel_hi:[1,0]\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %2"
+                             : "=&v"(r)
+                             : "v"(p), "v"(t), "s"(__builtin_amdgcn_readfirstlane(__float_as_int(sv)))
+                             : "s40", "s41");
+                float mx, my;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(mx) : "v"(sv), "v"(p.x));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(my) : "v"(sv), "v"(p.y));
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(ex) : "v"(mx), "v"(t.x));
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(ey) : "v"(my), "v"(t.y));
+            } else {
+                asm volatile("v_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]\n\ts_nop 0\n\tv_pk_mul_f32 %0, %0, %2" : "=&v"(r) : "v"(p), "v"(q));
+                float ax, ay;
+                asm volatile("v_add_f32 %0, 2.0, %1" : "=v"(ax) : "v"(p.x));
+                asm volatile("v_add_f32 %0, 2.0, %1" : "=v"(ay) : "v"(p.y));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ex) : "v"(ax), "v"(q.x));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ey) : "v"(ay), "v"(q.y));
+            }
+        } else if (VAR == 21) {
+            // packed instructions inside a lane-divergent loop (per-lane trip counts: the compiler's exec masking around them)
+            v2f acc = p;
+            const int trips = 1 + ((lane * 7 + it) & 7);
+            float ax = p.x, ay = p.y;
+            for (int k = 0; k < trips; ++k) {
+                asm volatile("v_pk_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q), "v"(t));
+                ax = ref_mul_add(ax, q.x, t.x);
+                ay = ref_mul_add(ay, q.y, t.y);
+                if (ax > 64.0f) {  // (keeps the values bounded; data dependent like the kernels' early exits)
+                    acc.x = ax = 1.0f;
+                    acc.y = ay = 1.5f;
+                }
+            }
+            r = acc;
+            ex = ax;
+            ey = ay;
         } else {
             // VAR 7: the same work without any packed instruction (control)
             r.x = ref_mul_add(p.x, q.x, t.x);
@@ -255,6 +295,9 @@ extern "C" int aps_dbg_victim(int var, int n_wg, int iters, unsigned long long* 
             case 16: dbg_victim_kernel<16><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
             case 17: dbg_victim_kernel<17><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
             case 18: dbg_victim_kernel<18><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
+            case 19: dbg_victim_kernel<19><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
+            case 20: dbg_victim_kernel<20><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
+            case 21: dbg_victim_kernel<21><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
             default: dbg_victim_kernel<7><<<n_wg, 256, 0, stream()>>>(iters, d, buf); break;
         }
         check_launch("dbg_victim_kernel");

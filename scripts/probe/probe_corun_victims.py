@@ -15,7 +15,9 @@ NAMES = {0: "pk_mul -> s_nop 0 -> pk_add (dependent; the compiler's sequence)", 
          12: "exec shrinks, one v_add, s_or_b64 exec back to full -> pk_mul at once", 13: "pk_mul -> global_store_dwordx2 of the pair at once -> read back",
          14: "pk_mov_b32 builds a 64-bit address -> global_load_dword through it at once",
          15: "pk_mul -> v_add_f32 reads its LOW half, NO wait state", 16: "pk_mul -> v_add_f32 reads its HIGH half, NO wait state",
-         17: "pk_fma op_sel_hi:[0,1,1] -> v_add_f32 reads its low half, NO wait state", 18: "pk_mul -> s_nop 0 -> v_add_f32 reads its low half"}
+         17: "pk_fma op_sel_hi:[0,1,1] -> v_add_f32 reads its low half, NO wait state", 18: "pk_mul -> s_nop 0 -> v_add_f32 reads its low half",
+         19: "pk_mul with an SGPR pair, low half broadcast (op_sel_hi:[1,0]) -> pk_add", 20: "pk_add with the inline constant 2.0 (op_sel_hi:[1,0]) -> pk_mul",
+         21: "pk_mul -> pk_add inside a lane-divergent loop (1-8 trips per lane, data-dependent reset)"}
 NWG, ITERS, LAUNCHES = 2048, 4000, 12
 def run(var, mode):
     tot = [0, 0]
@@ -39,7 +41,7 @@ def run(var, mode):
     return tot[0], k
 results = 2 * NWG * 256 * ITERS * LAUNCHES
 print("results checked per cell: %.2e" % results)
-for var in ([int(v) for v in sys.argv[1:]] or range(19)):
+for var in ([int(v) for v in sys.argv[1:]] or range(22)):
     row = []
     for mode in (None, 64, 2):
         bad, k = run(var, mode)
