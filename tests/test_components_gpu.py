@@ -110,6 +110,42 @@ def test_set_after_set_with_the_next_extraction_started_early_gives_the_same_pan
         assert info["n_pairs_verified"] == plain[k][1] and info["n_features"] == plain[k][2]
         assert np.array_equal(pano.cpu().numpy(), plain[k][0])
     assert hooks == [0, 1] and ahead[0] is None
+    # the same with the images uploaded on a side stream (one event per image) and the extraction started in two parts
+    # (submit_features(first=) from after_matching, submit_features_rest from after_ransac)
+    side = torch.cuda.Stream()
+    host = [{i: v.cpu().pin_memory() for i, v in views.items()} for views, _ in sets]
+
+    def upload(k):
+        up, evs = {}, {}
+        with torch.cuda.stream(side):
+            for i, h in host[k].items():
+                up[i] = h.to("cuda", non_blocking=True)
+                evs[i] = torch.cuda.Event()
+                evs[i].record(side)
+        return up, evs
+
+    nxt = [None]
+    for k, (_, Ks) in enumerate(sets):
+        if nxt[0] is None:
+            up, evs = upload(k)
+            feat = None
+        else:
+            up, evs, feat = nxt[0]
+            nxt[0] = None
+
+        def first_part(k=k):
+            u, e = upload(k + 1)
+            nxt[0] = (u, e, par.submit_features(inp, u, e, first=2))
+            assert len(nxt[0][2]["futures"]) == 2
+
+        def second_part():
+            par.submit_features_rest(nxt[0][2])
+            assert len(nxt[0][2]["futures"]) == 6 and nxt[0][2]["rest"] is None
+
+        last = k + 1 == len(sets)
+        pano, info = par.stitch_distributed(inp, up, len(up), Ks, (512, 512), 0, None, pano_root=0, image_events=evs, features=feat,
+                                            after_matching=None if last else first_part, after_ransac=None if last else second_part)
+        assert info["n_pairs_verified"] == plain[k][1] and np.array_equal(pano.cpu().numpy(), plain[k][0])
     # a handle for other images is refused
     wrong = par.submit_features(inp, {0: sets[0][0][0], 1: sets[0][0][1]})
     with pytest.raises(AssertionError):
