@@ -1225,8 +1225,11 @@ def main():
                             f"host match graph/cameras ({args.cameras}) -> spherical inverse warp + {args.bands}-band multiband blend, "
                             f"tile 2048 -> cropNonzeroBbox -> panorama copied to pinned host memory; BASELINE.json configs[2].  "
                             f"`value`: inputs resident in HBM before the timed region, every step's cropped uint8 panorama is "
-                            f"copied to pinned host memory (the copy of step k overlaps the extraction of step k+1, all copies "
-                            f"complete inside the timed region); value_end_to_end adds the host-to-device upload of the images (overlapped "
+                            f"copied to pinned host memory (the copy of step k overlaps the matching of step k+1, all copies "
+                            f"complete inside the timed region); " + ("consecutive steps are pipelined like the reference's loop over image sets "
+                            "(PP/main.m:83-137): the extraction of step k+1 starts when step k's match lists are complete and runs beside its "
+                            "RANSAC, camera work and render - see `pipeline`; " if pipelined else "") +
+                            f"value_end_to_end adds the host-to-device upload of the images (overlapped "
                             f"with SIFT); value_resident leaves the panorama in HBM",
                 "input_mpix": round(mpix_in, 1), "features_per_view": int(np.mean(counts)),
                 "pairs_matched": len(order), "pairs_verified": info["n_pairs_verified"],
