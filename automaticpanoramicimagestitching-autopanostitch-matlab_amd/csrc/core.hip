@@ -255,12 +255,13 @@ int aps_set_thread_stream_priority(int level) {
         int least = 0, greatest = 0;
         APS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int prio = level > 0 ? greatest : (level < 0 ? least : (least + greatest) / 2);
+        hipStream_t fresh = nullptr;  // (the new stream first: a failure leaves the thread with the stream it had)
+        APS_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio));
         if (c.own_stream) {
-            APS_HIP(hipStreamSynchronize(c.own_stream));
-            APS_HIP(hipStreamDestroy(c.own_stream));
-            c.own_stream = nullptr;
+            (void)hipStreamSynchronize(c.own_stream);
+            (void)hipStreamDestroy(c.own_stream);
         }
-        APS_HIP(hipStreamCreateWithPriority(&c.own_stream, hipStreamNonBlocking, prio));
+        c.own_stream = fresh;
         c.own_priority = level > 0 ? 1 : 0;
     });
 }
