@@ -280,3 +280,35 @@ def test_256_views_4k_at_configs3_image_count(gpu, mods):
     assert pano.dtype == torch.uint8 and pano.shape[2] == 3
     assert pano.shape[1] > 0.95 * 2 * np.pi * f and pano.shape[0] > 1.2 * f
     assert (pano[::4, ::4].amax(dim=2) > 0).float().mean().item() > 0.6
+
+
+def test_bench_scale_set_after_set_equals_the_sequential_stitch(gpu, mods):
+    """The 64 x 4K job twice, the second stitch's extraction started from the first one's after_matching hook (bench.py's pipelined
+    steps): verified pairs, feature counts and every byte of both panoramas equal one plain stitch of the same views."""
+    import torch
+
+    synth = mods["synth"]
+    pl = import_module(gpu.__name__ + ".pipeline")
+    par = import_module(gpu.__name__ + ".parallel")
+    imgs, cams = synth.make_scene(8, 8, 3840, 2160, 8000.0, 0.4, device="cuda", finest_px=16.0)
+    local = dict(enumerate(imgs))
+    Ks = [c["K"] for c in cams]
+    inp = pl.default_input(bands=5)
+    torch.cuda.synchronize()
+    pano0, info0 = par.stitch_distributed(inp, local, len(imgs), Ks, (2048, 2048), 0, None, pano_root=0)
+    ref = (pano0.cpu(), info0["n_pairs_verified"], list(info0["n_features"]))
+    del pano0
+    nxt = [None]
+
+    def start_next():
+        nxt[0] = par.submit_features(inp, local)
+
+    pano1, info1 = par.stitch_distributed(inp, local, len(imgs), Ks, (2048, 2048), 0, None, pano_root=0, after_matching=start_next)
+    assert nxt[0] is not None and len(nxt[0]["futures"]) == 64
+    p1 = pano1.cpu()
+    del pano1
+    pano2, info2 = par.stitch_distributed(inp, local, len(imgs), Ks, (2048, 2048), 0, None, pano_root=0, features=nxt[0])
+    for p, info in ((p1, info1), (pano2.cpu(), info2)):
+        assert info["n_pairs_verified"] == ref[1] and list(info["n_features"]) == ref[2]
+        assert p.shape == ref[0].shape and torch.equal(p, ref[0])
+    pl.release_device_memory()
